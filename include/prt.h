@@ -1,0 +1,198 @@
+/*
+ * prt.h -- C ABI of libprt.so, the MI355X (gfx950) sequential-raytrace engine
+ * that sits behind mess42/pyrate's RayBundle / Surface.intersect /
+ * Material.refract API.
+ *
+ * Everything here is plain C: pointers, sizes, PODs.  No torch / C++ types.
+ * All ray buffers are DEVICE pointers owned by the caller (the Python host
+ * uses torch tensors purely as an allocator); the surface table is a HOST
+ * array that prt_system_create() copies to the device once.  Every entry point
+ * returns 0 (PRT_OK) or a negative error code and never throws; per-ray
+ * failure is a mask, like in the reference (surface_shape.py:321,
+ * material_isotropic.py:183), never an error.
+ *
+ * Ray arrays use the reference's layout: (3, N) float64, C-contiguous, i.e.
+ * component-major SoA (ray.py:40-44): x[c*N + i].
+ *
+ * Reference interface each entry point replaces (paths relative to the
+ * reference checkout, package pyrateoptics 0.4.0):
+ *
+ *   prt_trace            OpticalSystem.seqtrace      raytracer/optical_system.py:73-94
+ *                        OpticalElement.seqtrace     raytracer/optical_element.py:324-379
+ *   prt_propagate        Material.propagate          raytracer/material/material_isotropic.py:238-247
+ *                        Surface.intersect           raytracer/surface.py:116-135
+ *                        Conic.intersect             raytracer/surface_shape.py:289-325
+ *                        ExplicitShape.intersect     raytracer/surface_shape.py:448-465
+ *                        RayBundle.returnKtoD        raytracer/ray.py:136-152
+ *   prt_interact         IsotropicMaterial.refract   raytracer/material/material_isotropic.py:163-199
+ *                        IsotropicMaterial.reflect   raytracer/material/material_isotropic.py:201-236
+ *                        AnisotropicMaterial.refract raytracer/material/material_anisotropic.py:70-113
+ *                        AnisotropicMaterial.reflect raytracer/material/material_anisotropic.py:115-155
+ *                        RayBundle.getLocalSurfaceNormal  raytracer/ray.py:156-161
+ *   prt_shape_eval       Shape.getSag / getGrad / getNormal   raytracer/surface_shape.py:71-112
+ *   prt_compact          boolean fancy indexing [:, valid]    raytracer/material/material_isotropic.py:194-199
+ *
+ * In-reference precedent for a C-ABI plugin behind Shape.intersect:
+ * raytracer/surface_shape_zmxdll.py:228-404 (ctypes.CDLL, int return, caller-
+ * allocated structs).
+ */
+#ifndef PRT_H
+#define PRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRT_ABI_VERSION 1
+#define PRT_MAX_COEFFS 40 /* asphere A2.. coefficients or XY-polynomial terms */
+
+/* ---- error codes ---------------------------------------------------- */
+#define PRT_OK 0
+#define PRT_ERR_INVALID_ARG (-1)
+#define PRT_ERR_UNSUPPORTED (-2) /* shape / material outside the engine's scope */
+#define PRT_ERR_DEVICE (-3)      /* HIP runtime error; see prt_last_error() */
+#define PRT_ERR_NO_DEVICE (-4)
+#define PRT_ERR_NOMEM (-5)
+
+/* ---- enums (int32 in the POD) --------------------------------------- */
+enum { PRT_SHAPE_CONIC = 0, PRT_SHAPE_ASPHERE = 1, PRT_SHAPE_XYPOLY = 2 };
+enum { PRT_AP_NONE = 0, PRT_AP_CIRCULAR = 1, PRT_AP_RECTANGULAR = 2 };
+enum { PRT_REFRACT = 0, PRT_MIRROR = 1 };
+enum { PRT_MAT_ISOTROPIC = 0, PRT_MAT_ANISOTROPIC = 1 };
+enum { PRT_ANISO_GENERAL = 0, PRT_ANISO_ISOTROPIC = 1, PRT_ANISO_UNIAXIAL = 2 };
+
+/* frame_flags bits: let the kernels skip 3x3 mat-vecs that are identities */
+#define PRT_FRAME_SHAPE_IDENTITY 1 /* B_shape == I (pure translation)          */
+#define PRT_FRAME_AP_IS_SHAPE 2    /* aperture frame == shape frame            */
+#define PRT_FRAME_MAT_IDENTITY 4   /* B_mat == I                               */
+
+/* trace modes */
+#define PRT_MODE_PATH 0  /* write hit point / outgoing k / valid at every surface */
+#define PRT_MODE_IMAGE 1 /* write only the last surface's                          */
+
+/*
+ * One record per traced surface, in sequence order (the flattened
+ * [(elementkey, [(surfkey, options), ...]), ...] sequence).  Matrices are
+ * row-major 3x3 = LocalCoordinates.localbasis; g = .globalcoordinates
+ * (localcoordinates.py:264-295).
+ */
+typedef struct prt_surface {
+    int32_t shape_type;  /* PRT_SHAPE_*                                              */
+    int32_t n_coeffs;    /* asphere: #A coefficients; xypoly: #terms                 */
+    int32_t ap_type;     /* PRT_AP_*                                                 */
+    int32_t interaction; /* PRT_REFRACT / PRT_MIRROR (sequence option "is_mirror")   */
+    int32_t mat_type;    /* medium the ray is in AFTER the interaction               */
+    int32_t frame_flags; /* PRT_FRAME_* (computed by the host, only an optimisation) */
+    int32_t newton_maxit; /* explicit shapes: iteration cap (0 -> 30)                */
+    int32_t aniso_class; /* PRT_ANISO_* (host classification of eps, see below)      */
+    double curv;        /* conic/asphere curvature;  xypoly: unused                  */
+    double cc;          /* conic constant                                            */
+    double coeffs[PRT_MAX_COEFFS]; /* asphere: A2, A4, ...  xypoly: c / normradius^(i+j) */
+    int32_t xpow[PRT_MAX_COEFFS];  /* xypoly term powers                             */
+    int32_t ypow[PRT_MAX_COEFFS];
+    double B_shape[9], g_shape[3]; /* shape.lc                                       */
+    double B_ap[9], g_ap[3];       /* aperture.lc                                    */
+    double ap_p0, ap_p1; /* circular: minradius, maxradius; rectangular: width, height */
+    double B_mat[9];     /* lc of the medium after the interaction                   */
+    double n_after;      /* isotropic: refractive index of that medium               */
+    double eps_re[9], eps_im[9]; /* anisotropic: its (constant) epsilon tensor       */
+    /* host-side classification of a real symmetric eps (an optimisation AND what keeps the
+     * touching-sheet directions well conditioned, see csrc/prt_aniso.h):
+     * ISOTROPIC: eps = aniso_eo I;  UNIAXIAL: eps = aniso_eo I + (aniso_ee-aniso_eo) c c^T,
+     * c = aniso_axis (unit, material frame);  GENERAL: anything else. */
+    double aniso_eo, aniso_ee, aniso_axis[3];
+} prt_surface_t;
+
+typedef struct prt_system prt_system_t; /* opaque: device copy of a surface table */
+
+/* ---- library / device ----------------------------------------------- */
+int32_t prt_abi_version(void);
+int32_t prt_device_count(void);               /* < 0: error code                  */
+const char *prt_strerror(int32_t code);
+const char *prt_last_error(void);             /* thread-local detail of last error */
+int32_t prt_sizeof_surface(void);             /* sizeof(prt_surface_t): ABI check */
+
+/* ---- system (surface table) ----------------------------------------- */
+int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_t device,
+                          prt_system_t **out);
+int32_t prt_system_destroy(prt_system_t *sys);
+int32_t prt_system_num_surfaces(const prt_system_t *sys);
+/* rays entering / leaving every surface for n0 input rays (anisotropic
+ * interfaces double the count, material_anisotropic.py:87-100).  n_in, n_out:
+ * host arrays of n_surfaces int64. */
+int32_t prt_system_ray_counts(const prt_system_t *sys, int64_t n0, int64_t *n_in, int64_t *n_out);
+
+/*
+ * Whole sequence: OpticalSystem.seqtrace for splitup=False.
+ *   x0, k0        (3,n0) start points / wave vectors (global frame, |k| = n).
+ *   e0_re, e0_im  (3,n0) E field of the first segment or NULL.  Used only for the
+ *                 first segment's direction d = S/|S| (ray.py:136-152); NULL e0_re
+ *                 means E = (0,1,0) (ray.py:71-73), NULL e0_im means real E.
+ *   mode PATH:    x_hit  = concat_s (3,n_in[s]),  valid = concat_s (n_in[s]),
+ *                 k_out  = concat_s (3,n_out[s]), valid_out = concat_s (n_out[s])
+ *                 (valid_out may be NULL).  For all-isotropic tables n_in = n_out = n0
+ *                 and the arrays are plain (S,3,n0) / (S,n0).
+ *   mode IMAGE:   the same four arrays for the last surface only.
+ *   valid is the reference's cumulative mask after intersect + aperture
+ *   (ray.py:100, surface.py:135); valid_out additionally ANDs the refraction
+ *   checks (material_isotropic.py:183) -- it is what [:, valid] compaction uses.
+ *   stream: hipStream_t (NULL = default stream).  Asynchronous.
+ */
+int32_t prt_trace(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,
+                  const double *e0_re, const double *e0_im, int32_t mode, double *x_hit,
+                  double *k_out, uint8_t *valid, uint8_t *valid_out, void *stream);
+
+/*
+ * Material.propagate(raybundle, surface): intersect + aperture for one surface.
+ *   x, k (3,n); dir (3,n) unit ray directions or NULL (then e_re/e_im as in
+ *   prt_trace, or k/|k| if e_re is NULL and use_default_e == 0).
+ *   valid_in (n) or NULL (= all valid).  Writes x_hit (3,n), valid (n).
+ */
+int32_t prt_propagate(const prt_system_t *sys, int32_t surface, int64_t n, const double *x,
+                      const double *k, const double *dir, const double *e_re, const double *e_im,
+                      int32_t use_default_e, const uint8_t *valid_in, double *x_hit,
+                      uint8_t *valid, void *stream);
+
+/*
+ * Material.refract / reflect at one surface (which one: table[surface].interaction).
+ *   x_hit, k (3,n), valid_in (n) or NULL.
+ *   isotropic:   k_out (3,n), valid_out (n); dir_out may be NULL.
+ *   anisotropic: k_out (3,2n) in [sol2, sol3] stacking (material_anisotropic.py:87-95),
+ *                dir_out (3,2n) unit Poynting directions (needed by the next propagate),
+ *                e_out_re / e_out_im (3,2n) or NULL, valid_out (2n) all 1 (ray.py:68).
+ */
+int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const double *x_hit,
+                     const double *k, const uint8_t *valid_in, double *k_out, double *dir_out,
+                     double *e_out_re, double *e_out_im, uint8_t *valid_out, void *stream);
+
+/* Shape.getSag / getGrad: x, y (n) in the shape frame -> sag (n) and/or grad (3,n)
+ * (either output may be NULL). */
+int32_t prt_shape_eval(const prt_system_t *sys, int32_t surface, int64_t n, const double *x,
+                       const double *y, double *sag, double *grad, void *stream);
+
+/*
+ * Order-preserving compaction by mask (the reference's [:, valid] indexing):
+ * n_arrays row pointers of n doubles each (src[r] -> dst[r]), plus optional
+ * int64 ids.  *n_kept (host) receives the survivor count.  Synchronises the
+ * stream (the count is returned to the host).  scratch: device buffer of at
+ * least prt_compact_scratch_bytes(n) bytes.
+ */
+int64_t prt_compact_scratch_bytes(int64_t n);
+int32_t prt_compact(int64_t n, const uint8_t *mask, int32_t n_arrays, const double *const *src,
+                    double *const *dst, const int64_t *id_src, int64_t *id_dst, void *scratch,
+                    int64_t *n_kept, void *stream);
+
+/* Timing helper for bench.py: runs prt_trace `iters` times on `stream` between
+ * two HIP events recorded on that stream and returns the average milliseconds
+ * per launch in *ms_avg. */
+int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,
+                        const double *e0_re, const double *e0_im, int32_t mode, double *x_hit,
+                        double *k_out, uint8_t *valid, uint8_t *valid_out, void *stream,
+                        int32_t iters, double *ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRT_H */

@@ -1,0 +1,13 @@
+"""
+pyrate_amd -- MI355X (gfx950) sequential raytrace engine behind mess42/pyrate's
+RayBundle / Surface.intersect / Material.refract API.
+
+    pyrate_amd.csrc/        HIP kernels + C ABI (libprt.so, include/prt.h)
+    pyrate_amd._lib         ctypes binding (fails loudly when libprt.so is missing)
+    pyrate_amd.engine       device-tensor level API (DeviceSystem.trace ...)
+    pyrate_amd.surface_table  object graph -> POD surface table
+    pyrate_amd.raytracer    host-side mirror of the reference classes (drop-in)
+    pyrate_amd.systems      BASELINE workloads
+    pyrate_amd.distributed  ray sharding over ranks + image-plane all-gather
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,110 @@
+"""
+ctypes binding of ``libprt.so`` (C ABI: ``include/prt.h``).
+
+The library is built in-tree (``pyrate_amd/csrc/libprt.so``) by
+``pyrate_amd.build.build_all()`` / ``__graft_entry__.build()``.  There is no
+CPU fallback: if the shared object is missing, stale or cannot be loaded,
+``load()`` raises ``ImportError`` and every entry point of the product fails
+loudly.
+"""
+import ctypes
+import os
+
+from .surface_table import PrtSurface
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libprt.so")
+
+PRT_OK = 0
+MODE_PATH = 0
+MODE_IMAGE = 1
+
+c_double_p = ctypes.c_void_p      # device pointers travel as raw addresses
+c_u8_p = ctypes.c_void_p
+c_stream = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol declared in include/prt.h
+PROTOTYPES = {
+    "prt_abi_version": (ctypes.c_int32, []),
+    "prt_device_count": (ctypes.c_int32, []),
+    "prt_strerror": (ctypes.c_char_p, [ctypes.c_int32]),
+    "prt_last_error": (ctypes.c_char_p, []),
+    "prt_sizeof_surface": (ctypes.c_int32, []),
+    "prt_system_create": (ctypes.c_int32, [ctypes.POINTER(PrtSurface), ctypes.c_int32,
+                                           ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
+    "prt_system_destroy": (ctypes.c_int32, [ctypes.c_void_p]),
+    "prt_system_num_surfaces": (ctypes.c_int32, [ctypes.c_void_p]),
+    "prt_system_ray_counts": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64,
+                                               ctypes.POINTER(ctypes.c_int64),
+                                               ctypes.POINTER(ctypes.c_int64)]),
+    "prt_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p,
+                                   c_double_p, c_double_p, ctypes.c_int32, c_double_p,
+                                   c_double_p, c_u8_p, c_u8_p, c_stream]),
+    "prt_trace_timed": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, c_double_p,
+                                         c_double_p, c_double_p, c_double_p, ctypes.c_int32,
+                                         c_double_p, c_double_p, c_u8_p, c_u8_p, c_stream,
+                                         ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]),
+    "prt_propagate": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                       c_double_p, c_double_p, c_double_p, c_double_p,
+                                       c_double_p, ctypes.c_int32, c_u8_p, c_double_p, c_u8_p,
+                                       c_stream]),
+    "prt_interact": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                      c_double_p, c_double_p, c_u8_p, c_double_p, c_double_p,
+                                      c_double_p, c_double_p, c_u8_p, c_stream]),
+    "prt_shape_eval": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
+                                        c_double_p, c_double_p, c_double_p, c_double_p,
+                                        c_stream]),
+    "prt_compact_scratch_bytes": (ctypes.c_int64, [ctypes.c_int64]),
+    "prt_compact": (ctypes.c_int32, [ctypes.c_int64, c_u8_p, ctypes.c_int32,
+                                     ctypes.POINTER(ctypes.c_void_p),
+                                     ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.POINTER(ctypes.c_int64), c_stream]),
+}
+
+_lib = None
+
+
+class PrtError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        RuntimeError.__init__(self, "libprt error %d: %s" % (code, detail))
+
+
+def load():
+    """Load libprt.so (once).  Raises ImportError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pyrate_amd: %s is missing -- the HIP engine is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "There is no CPU fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise ImportError("pyrate_amd: cannot load %s: %s" % (LIB_PATH, exc))
+    for (name, (restype, argtypes)) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ImportError("pyrate_amd: %s does not export %s (stale build?)"
+                              % (LIB_PATH, name))
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.prt_sizeof_surface() != ctypes.sizeof(PrtSurface):
+        raise ImportError("pyrate_amd: prt_surface_t layout mismatch: C %d bytes, ctypes %d"
+                          % (lib.prt_sizeof_surface(), ctypes.sizeof(PrtSurface)))
+    _lib = lib
+    return lib
+
+
+def check(code):
+    """Turn a negative return code into PrtError (structural misuse raises,
+    like the reference's bare Exceptions; per-ray failures never do)."""
+    if code < 0:
+        lib = load()
+        detail = lib.prt_last_error().decode() or lib.prt_strerror(code).decode()
+        raise PrtError(code, detail)
+    return code

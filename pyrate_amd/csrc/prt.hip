@@ -1,0 +1,766 @@
+// prt.hip -- kernels + C ABI (include/prt.h) of the gfx950 sequential raytrace engine.
+//
+// Kernels
+//   k_trace_iso<RPT,MODE>  whole isotropic sequence in one launch: a thread loads its
+//                          ray(s) once (x0,k0: 48 B/ray), marches all S surfaces with
+//                          the state in VGPRs and streams out hit point / outgoing k /
+//                          valid per surface (49 B/ray/surface).  HBM-bound by design:
+//                          algorithmic bytes = 48 N (+E0) + 50 N S.
+//   k_propagate            one Material.propagate (intersect + aperture)
+//   k_interact_iso         one IsotropicMaterial.refract / reflect
+//   k_interact_aniso       one AnisotropicMaterial.refract / reflect (N -> 2N rays)
+//   k_shape_eval           Shape.getSag / getGrad
+//   k_compact_*            order-preserving compaction by mask
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC prt.hip -o libprt.so
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include "prt_device.h"
+#include "prt_aniso.h"
+
+#define PRT_BLOCK 256
+
+// ---------------------------------------------------------------------------
+// host-side state
+// ---------------------------------------------------------------------------
+struct prt_system {
+    int32_t device;
+    int32_t n_surfaces;
+    int32_t all_isotropic;
+    prt_surface_t *d_table;  // device copy
+    prt_surface_t *h_table;  // host copy (for dispatch decisions)
+};
+
+static thread_local char g_err[512] = "";
+
+static int32_t fail(int32_t code, const char *what, hipError_t e = hipSuccess) {
+    if (e != hipSuccess)
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(g_err, sizeof(g_err), "%s", what);
+    return code;
+}
+
+#define HIP_TRY(call)                                                   \
+    do {                                                                \
+        hipError_t e_ = (call);                                         \
+        if (e_ != hipSuccess) return fail(PRT_ERR_DEVICE, #call, e_);   \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// ray load / store helpers.  Arrays are (3,N) component-major.  RPT=2 uses one
+// 16-byte access per component (needs N even so that every row stays 16-B
+// aligned; the host falls back to RPT=1 otherwise).
+// ---------------------------------------------------------------------------
+template <int RPT>
+struct rayio;
+
+template <>
+struct rayio<1> {
+    static PRT_DEV void load(const double *__restrict__ a, int64_t n, int64_t i, vec3 v[1]) {
+        v[0] = v3(a[i], a[n + i], a[2 * n + i]);
+    }
+    static PRT_DEV void store(double *__restrict__ a, int64_t n, int64_t i, const vec3 v[1]) {
+        a[i] = v[0].x;
+        a[n + i] = v[0].y;
+        a[2 * n + i] = v[0].z;
+    }
+    static PRT_DEV void store_mask(uint8_t *__restrict__ m, int64_t i, const bool b[1]) {
+        m[i] = b[0] ? 1 : 0;
+    }
+};
+
+template <>
+struct rayio<2> {
+    static PRT_DEV void load(const double *__restrict__ a, int64_t n, int64_t i, vec3 v[2]) {
+        const double2 x = *reinterpret_cast<const double2 *>(a + i);
+        const double2 y = *reinterpret_cast<const double2 *>(a + n + i);
+        const double2 z = *reinterpret_cast<const double2 *>(a + 2 * n + i);
+        v[0] = v3(x.x, y.x, z.x);
+        v[1] = v3(x.y, y.y, z.y);
+    }
+    static PRT_DEV void store(double *__restrict__ a, int64_t n, int64_t i, const vec3 v[2]) {
+        *reinterpret_cast<double2 *>(a + i) = make_double2(v[0].x, v[1].x);
+        *reinterpret_cast<double2 *>(a + n + i) = make_double2(v[0].y, v[1].y);
+        *reinterpret_cast<double2 *>(a + 2 * n + i) = make_double2(v[0].z, v[1].z);
+    }
+    static PRT_DEV void store_mask(uint8_t *__restrict__ m, int64_t i, const bool b[2]) {
+        *reinterpret_cast<uint16_t *>(m + i) =
+            (uint16_t)((b[0] ? 1u : 0u) | (b[1] ? 0x100u : 0u));
+    }
+};
+
+// first-segment direction selector
+//   e_mode 0: d = k/|k|        1: E = (0,1,0) (ray.py:71-73)     2: E given (re [, im])
+template <int RPT>
+PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
+                             const double *__restrict__ e_im, int64_t n, int64_t i,
+                             const vec3 k[RPT], vec3 d[RPT]) {
+    if (e_mode == 0) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) d[r] = normalized(k[r]);
+    } else if (e_mode == 1) {
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) d[r] = poynting_dir(k[r], v3(0, 1, 0), v3(0, 0, 0));
+    } else {
+        vec3 er[RPT], ei[RPT];
+        rayio<RPT>::load(e_re, n, i, er);
+        if (e_im) {
+            rayio<RPT>::load(e_im, n, i, ei);
+        } else {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) ei[r] = v3(0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) d[r] = poynting_dir(k[r], er[r], ei[r]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fused isotropic march: OpticalElement.seqtrace's loop (optical_element.py:336-375)
+// ---------------------------------------------------------------------------
+template <int RPT, int MODE>
+__global__ __launch_bounds__(PRT_BLOCK) void k_trace_iso(
+    const prt_surface_t *__restrict__ tab, int32_t S, int64_t N, const double *__restrict__ x0,
+    const double *__restrict__ k0, const double *__restrict__ e_re,
+    const double *__restrict__ e_im, int32_t e_mode, double *__restrict__ xh_out,
+    double *__restrict__ k_out, uint8_t *__restrict__ valid_out_hit,
+    uint8_t *__restrict__ valid_out_refr) {
+    const int64_t i = ((int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x) * RPT;
+    if (i >= N) return;
+
+    vec3 x[RPT], k[RPT], d[RPT];
+    bool valid[RPT];
+    rayio<RPT>::load(x0, N, i, x);
+    rayio<RPT>::load(k0, N, i, k);
+    first_direction<RPT>(e_mode, e_re, e_im, N, i, k, d);
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) valid[r] = true;
+
+    for (int32_t s = 0; s < S; ++s) {
+        const prt_surface_t *__restrict__ sf = tab + s;
+        bool vhit[RPT];
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            vec3 xh, p;
+            propagate_step(sf, x[r], d[r], xh, p, valid[r]);
+            vhit[r] = valid[r];
+            interact_isotropic(sf, p, k[r], valid[r]);
+            x[r] = xh;
+        }
+        // after an isotropic interaction E is perpendicular to k, so the Poynting
+        // direction (ray.py:136-152) is k/|k| and |k| = n_after
+        const double inv_n = 1.0 / sf->n_after;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) d[r] = v3(k[r].x * inv_n, k[r].y * inv_n, k[r].z * inv_n);
+
+        if (MODE == PRT_MODE_PATH || s == S - 1) {
+            const int64_t so = (MODE == PRT_MODE_PATH) ? (int64_t)s : 0;
+            rayio<RPT>::store(xh_out + so * 3 * N, N, i, x);
+            rayio<RPT>::store(k_out + so * 3 * N, N, i, k);
+            rayio<RPT>::store_mask(valid_out_hit + so * N, i, vhit);
+            if (valid_out_refr) rayio<RPT>::store_mask(valid_out_refr + so * N, i, valid);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-surface kernels (the plugin-granular API, and the march through
+// anisotropic systems).  x is read modulo n_src so that the two children of a
+// split ray share their parent's hit point without a copy.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PRT_BLOCK) void k_propagate(
+    const prt_surface_t *__restrict__ sf, int64_t N, int64_t n_src,
+    const double *__restrict__ x_in, const double *__restrict__ k_in,
+    const double *__restrict__ dir_in, const double *__restrict__ e_re,
+    const double *__restrict__ e_im, int32_t e_mode, const uint8_t *__restrict__ valid_in,
+    double *__restrict__ xh_out, uint8_t *__restrict__ valid_out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const int64_t j = (n_src == N) ? i : (i % n_src);
+    const vec3 x = v3(x_in[j], x_in[n_src + j], x_in[2 * n_src + j]);
+    vec3 d;
+    if (dir_in) {
+        d = v3(dir_in[i], dir_in[N + i], dir_in[2 * N + i]);
+    } else {
+        vec3 k[1] = {v3(k_in[i], k_in[N + i], k_in[2 * N + i])};
+        vec3 dd[1];
+        first_direction<1>(e_mode, e_re, e_im, N, i, k, dd);
+        d = dd[0];
+    }
+    bool valid = valid_in ? (valid_in[i] != 0) : true;
+    vec3 xh, p;
+    propagate_step(sf, x, d, xh, p, valid);
+    xh_out[i] = xh.x;
+    xh_out[N + i] = xh.y;
+    xh_out[2 * N + i] = xh.z;
+    valid_out[i] = valid ? 1 : 0;
+}
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_interact_iso(
+    const prt_surface_t *__restrict__ sf, int64_t N, const double *__restrict__ xh_in,
+    const double *__restrict__ k_in, const uint8_t *__restrict__ valid_in,
+    double *__restrict__ k_out, double *__restrict__ dir_out, uint8_t *__restrict__ valid_out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const vec3 xh = v3(xh_in[i], xh_in[N + i], xh_in[2 * N + i]);
+    vec3 k = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
+    bool valid = valid_in ? (valid_in[i] != 0) : true;
+    const vec3 p = to_shape_frame(sf, xh);
+    interact_isotropic(sf, p, k, valid);
+    k_out[i] = k.x;
+    k_out[N + i] = k.y;
+    k_out[2 * N + i] = k.z;
+    if (dir_out) {
+        const vec3 d = normalized(k);
+        dir_out[i] = d.x;
+        dir_out[N + i] = d.y;
+        dir_out[2 * N + i] = d.z;
+    }
+    if (valid_out) valid_out[i] = valid ? 1 : 0;
+}
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_interact_aniso(
+    const prt_surface_t *__restrict__ sf, int64_t N, const double *__restrict__ xh_in,
+    const double *__restrict__ k_in, double *__restrict__ k_out, double *__restrict__ dir_out,
+    double *__restrict__ e_re_out, double *__restrict__ e_im_out,
+    uint8_t *__restrict__ valid_out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const vec3 xh = v3(xh_in[i], xh_in[N + i], xh_in[2 * N + i]);
+    const vec3 k = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
+    const vec3 p = to_shape_frame(sf, xh);
+    aniso_solution sol[2];
+    interact_anisotropic(sf, p, k, sol);
+    const int64_t M = 2 * N;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t o = i + b * N;  // np.hstack((sol2, sol3)), material_anisotropic.py:89
+        k_out[o] = sol[b].k.x;
+        k_out[M + o] = sol[b].k.y;
+        k_out[2 * M + o] = sol[b].k.z;
+        dir_out[o] = sol[b].d.x;
+        dir_out[M + o] = sol[b].d.y;
+        dir_out[2 * M + o] = sol[b].d.z;
+        if (e_re_out) {
+            e_re_out[o] = sol[b].er.x;
+            e_re_out[M + o] = sol[b].er.y;
+            e_re_out[2 * M + o] = sol[b].er.z;
+        }
+        if (e_im_out) {
+            e_im_out[o] = sol[b].ei.x;
+            e_im_out[M + o] = sol[b].ei.y;
+            e_im_out[2 * M + o] = sol[b].ei.z;
+        }
+        if (valid_out) valid_out[o] = 1;  // new bundle starts all-valid (ray.py:68)
+    }
+}
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_shape_eval(const prt_surface_t *__restrict__ sf,
+                                                          int64_t N, const double *__restrict__ x,
+                                                          const double *__restrict__ y,
+                                                          double *__restrict__ sag,
+                                                          double *__restrict__ grad) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const double xx = x[i], yy = y[i];
+    if (sag) sag[i] = shape_sag(sf, xx, yy);
+    if (grad) {
+        vec3 g;
+        if (sf->shape_type == PRT_SHAPE_CONIC) {
+            // Conic.getGrad as the reference evaluates it (surface_shape.py:229-235)
+            const double z = conic_sag(sf->curv, sf->cc, xx * xx + yy * yy);
+            g = v3(-sf->curv * xx, -sf->curv * yy, 1.0 - sf->curv * z * (1.0 + sf->cc));
+        } else {
+            g = shape_grad(sf, xx, yy);
+        }
+        grad[i] = g.x;
+        grad[N + i] = g.y;
+        grad[2 * N + i] = g.z;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// compaction: per-block popcount -> single-block scan of block totals -> scatter
+// ---------------------------------------------------------------------------
+#define CMP_ITEMS 4  // mask bytes per thread (one 32-bit load)
+#define CMP_TILE (PRT_BLOCK * CMP_ITEMS)
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_compact_count(const uint8_t *__restrict__ mask,
+                                                             int64_t N,
+                                                             int64_t *__restrict__ block_sums) {
+    __shared__ int wsum[PRT_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_ITEMS;
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q)
+        if (base + q < N && mask[base + q]) ++c;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < PRT_BLOCK / 64; ++w) t += wsum[w];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of block_sums in place; total -> block_sums[nb]
+__global__ __launch_bounds__(PRT_BLOCK) void k_compact_scan(int64_t *__restrict__ block_sums,
+                                                            int64_t nb) {
+    __shared__ int64_t part[PRT_BLOCK];
+    const int64_t chunk = (nb + PRT_BLOCK - 1) / PRT_BLOCK;
+    const int64_t lo = (int64_t)threadIdx.x * chunk;
+    const int64_t hi = (lo + chunk < nb) ? lo + chunk : nb;
+    int64_t s = 0;
+    for (int64_t q = lo; q < hi; ++q) s += block_sums[q];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t run = 0;
+        for (int q = 0; q < PRT_BLOCK; ++q) {
+            const int64_t v = part[q];
+            part[q] = run;
+            run += v;
+        }
+        block_sums[nb] = run;
+    }
+    __syncthreads();
+    int64_t run = part[threadIdx.x];
+    for (int64_t q = lo; q < hi; ++q) {
+        const int64_t v = block_sums[q];
+        block_sums[q] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_compact_scatter(
+    const uint8_t *__restrict__ mask, int64_t N, const int64_t *__restrict__ block_offs,
+    int32_t n_arrays, const double *const *__restrict__ src, double *const *__restrict__ dst,
+    const int64_t *__restrict__ id_src, int64_t *__restrict__ id_dst) {
+    __shared__ int woff[PRT_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_ITEMS;
+    bool keep[CMP_ITEMS];
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        keep[q] = (base + q < N) && mask[base + q];
+        c += keep[q] ? 1 : 0;
+    }
+    // inclusive scan of c within the wave
+    int incl = c;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) woff[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wbase += woff[w];
+    int64_t pos = block_offs[blockIdx.x] + wbase + (incl - c);
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        if (keep[q]) {
+            for (int a = 0; a < n_arrays; ++a) dst[a][pos] = src[a][base + q];
+            if (id_src) id_dst[pos] = id_src[base + q];
+            ++pos;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+static inline unsigned nblocks(int64_t n, int per_block) {
+    return (unsigned)((n + per_block - 1) / per_block);
+}
+
+static int32_t e_mode_of(const double *e_re, int32_t use_default_e) {
+    if (e_re) return 2;
+    return use_default_e ? 1 : 0;
+}
+
+template <int RPT>
+static void launch_trace_iso(const prt_system_t *sys, int64_t n0, const double *x0,
+                             const double *k0, const double *e_re, const double *e_im,
+                             int32_t e_mode, int32_t mode, double *x_hit, double *k_out,
+                             uint8_t *valid, uint8_t *valid_out, hipStream_t st) {
+    const unsigned grid = nblocks(n0, PRT_BLOCK * RPT);
+    if (mode == PRT_MODE_PATH)
+        hipLaunchKernelGGL((k_trace_iso<RPT, PRT_MODE_PATH>), dim3(grid), dim3(PRT_BLOCK), 0, st,
+                           sys->d_table, sys->n_surfaces, n0, x0, k0, e_re, e_im, e_mode, x_hit,
+                           k_out, valid, valid_out);
+    else
+        hipLaunchKernelGGL((k_trace_iso<RPT, PRT_MODE_IMAGE>), dim3(grid), dim3(PRT_BLOCK), 0, st,
+                           sys->d_table, sys->n_surfaces, n0, x0, k0, e_re, e_im, e_mode, x_hit,
+                           k_out, valid, valid_out);
+}
+
+extern "C" {
+
+int32_t prt_abi_version(void) { return PRT_ABI_VERSION; }
+int32_t prt_sizeof_surface(void) { return (int32_t)sizeof(prt_surface_t); }
+
+int32_t prt_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(PRT_ERR_NO_DEVICE, "hipGetDeviceCount", e);
+    return n;
+}
+
+const char *prt_strerror(int32_t code) {
+    switch (code) {
+        case PRT_OK: return "ok";
+        case PRT_ERR_INVALID_ARG: return "invalid argument";
+        case PRT_ERR_UNSUPPORTED: return "unsupported shape/material";
+        case PRT_ERR_DEVICE: return "HIP runtime error";
+        case PRT_ERR_NO_DEVICE: return "no HIP device";
+        case PRT_ERR_NOMEM: return "out of memory";
+        default: return "unknown error";
+    }
+}
+
+const char *prt_last_error(void) { return g_err; }
+
+static int32_t check_record(const prt_surface_t *r, int idx) {
+    char msg[128];
+    if (r->shape_type < PRT_SHAPE_CONIC || r->shape_type > PRT_SHAPE_XYPOLY) {
+        snprintf(msg, sizeof msg, "surface %d: unknown shape_type %d", idx, r->shape_type);
+        return fail(PRT_ERR_UNSUPPORTED, msg);
+    }
+    if (r->n_coeffs < 0 || r->n_coeffs > PRT_MAX_COEFFS) {
+        snprintf(msg, sizeof msg, "surface %d: n_coeffs %d out of range", idx, r->n_coeffs);
+        return fail(PRT_ERR_INVALID_ARG, msg);
+    }
+    if (r->ap_type < PRT_AP_NONE || r->ap_type > PRT_AP_RECTANGULAR ||
+        r->interaction < PRT_REFRACT || r->interaction > PRT_MIRROR ||
+        r->mat_type < PRT_MAT_ISOTROPIC || r->mat_type > PRT_MAT_ANISOTROPIC) {
+        snprintf(msg, sizeof msg, "surface %d: bad aperture/interaction/material enum", idx);
+        return fail(PRT_ERR_INVALID_ARG, msg);
+    }
+    if (r->mat_type == PRT_MAT_ANISOTROPIC) {
+        for (int q = 0; q < 9; ++q)
+            if (r->eps_im[q] != 0.0) {
+                snprintf(msg, sizeof msg, "surface %d: complex epsilon tensor not supported", idx);
+                return fail(PRT_ERR_UNSUPPORTED, msg);
+            }
+    }
+    return PRT_OK;
+}
+
+int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_t device,
+                          prt_system_t **out) {
+    if (!table || !out || n_surfaces <= 0) return fail(PRT_ERR_INVALID_ARG, "prt_system_create: null/empty");
+    *out = nullptr;
+    for (int s = 0; s < n_surfaces; ++s) {
+        int32_t rc = check_record(table + s, s);
+        if (rc != PRT_OK) return rc;
+    }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(PRT_ERR_NO_DEVICE, "no HIP device visible", e);
+    if (device < 0 || device >= ndev) return fail(PRT_ERR_INVALID_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    prt_system *sys = new (std::nothrow) prt_system();
+    if (!sys) return fail(PRT_ERR_NOMEM, "host alloc");
+    sys->device = device;
+    sys->n_surfaces = n_surfaces;
+    sys->h_table = new (std::nothrow) prt_surface_t[n_surfaces];
+    if (!sys->h_table) {
+        delete sys;
+        return fail(PRT_ERR_NOMEM, "host alloc");
+    }
+    memcpy(sys->h_table, table, sizeof(prt_surface_t) * n_surfaces);
+    sys->all_isotropic = 1;
+    for (int s = 0; s < n_surfaces; ++s)
+        if (table[s].mat_type != PRT_MAT_ISOTROPIC) sys->all_isotropic = 0;
+    e = hipMalloc((void **)&sys->d_table, sizeof(prt_surface_t) * n_surfaces);
+    if (e != hipSuccess) {
+        delete[] sys->h_table;
+        delete sys;
+        return fail(PRT_ERR_NOMEM, "hipMalloc(table)", e);
+    }
+    e = hipMemcpy(sys->d_table, table, sizeof(prt_surface_t) * n_surfaces, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(sys->d_table);
+        delete[] sys->h_table;
+        delete sys;
+        return fail(PRT_ERR_DEVICE, "hipMemcpy(table)", e);
+    }
+    *out = sys;
+    return PRT_OK;
+}
+
+int32_t prt_system_destroy(prt_system_t *sys) {
+    if (!sys) return PRT_OK;
+    (void)hipSetDevice(sys->device);
+    (void)hipFree(sys->d_table);
+    delete[] sys->h_table;
+    delete sys;
+    return PRT_OK;
+}
+
+int32_t prt_system_num_surfaces(const prt_system_t *sys) {
+    if (!sys) return fail(PRT_ERR_INVALID_ARG, "null system");
+    return sys->n_surfaces;
+}
+
+int32_t prt_system_ray_counts(const prt_system_t *sys, int64_t n0, int64_t *n_in, int64_t *n_out) {
+    if (!sys || n0 < 0 || !n_in || !n_out) return fail(PRT_ERR_INVALID_ARG, "prt_system_ray_counts");
+    int64_t n = n0;
+    for (int s = 0; s < sys->n_surfaces; ++s) {
+        n_in[s] = n;
+        if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC) n *= 2;
+        n_out[s] = n;
+    }
+    return PRT_OK;
+}
+
+static bool aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// march through a table that contains anisotropic media: one launch pair per surface
+static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *x0,
+                             const double *k0, const double *e_re, const double *e_im,
+                             int32_t mode, double *x_hit, double *k_out, uint8_t *valid,
+                             uint8_t *valid_out, hipStream_t st) {
+    const int S = sys->n_surfaces;
+    // scratch: directions after anisotropic interfaces, plus ping-pong state in IMAGE mode
+    int64_t n_final = n0;
+    for (int s = 0; s < S; ++s)
+        if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC) n_final *= 2;
+    double *dirbuf[2] = {nullptr, nullptr};
+    double *xbuf[2] = {nullptr, nullptr}, *kbuf[2] = {nullptr, nullptr};
+    uint8_t *vbuf[2] = {nullptr, nullptr}, *wbuf[2] = {nullptr, nullptr};
+    HIP_TRY(hipMallocAsync((void **)&dirbuf[0], sizeof(double) * 3 * n_final, st));
+    HIP_TRY(hipMallocAsync((void **)&dirbuf[1], sizeof(double) * 3 * n_final, st));
+    if (mode == PRT_MODE_IMAGE) {
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(hipMallocAsync((void **)&xbuf[b], sizeof(double) * 3 * n_final, st));
+            HIP_TRY(hipMallocAsync((void **)&kbuf[b], sizeof(double) * 3 * n_final, st));
+            HIP_TRY(hipMallocAsync((void **)&vbuf[b], n_final, st));
+            HIP_TRY(hipMallocAsync((void **)&wbuf[b], n_final, st));
+        }
+    }
+    uint8_t *vo_scratch = nullptr;  // valid_out storage when the caller passed NULL in PATH mode
+    int64_t tot_out = 0;
+    {
+        int64_t n = n0;
+        for (int s = 0; s < S; ++s) {
+            if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC) n *= 2;
+            tot_out += n;
+        }
+    }
+    if (mode == PRT_MODE_PATH && !valid_out) {
+        HIP_TRY(hipMallocAsync((void **)&vo_scratch, tot_out, st));
+        valid_out = vo_scratch;
+    }
+
+    const double *cur_x = x0, *cur_k = k0, *cur_dir = nullptr;
+    const uint8_t *cur_valid = nullptr;
+    int64_t n_src = n0;  // number of distinct points in cur_x
+    int64_t n = n0;
+    int64_t off_in = 0, off_out = 0;  // element offsets into the concatenated outputs
+    int e_mode = e_mode_of(e_re, 1);
+    for (int s = 0; s < S; ++s) {
+        const prt_surface_t *rec = sys->h_table + s;
+        const bool last = (s == S - 1);
+        const bool aniso = rec->mat_type == PRT_MAT_ANISOTROPIC;
+        const int64_t n_o = aniso ? 2 * n : n;
+        double *xh_dst, *k_dst;
+        uint8_t *v_dst, *vo_dst;
+        if (mode == PRT_MODE_PATH) {
+            xh_dst = x_hit + 3 * off_in;
+            k_dst = k_out + 3 * off_out;
+            v_dst = valid + off_in;
+            vo_dst = valid_out + off_out;
+        } else if (last) {
+            xh_dst = x_hit;
+            k_dst = k_out;
+            v_dst = valid;
+            vo_dst = valid_out ? valid_out : wbuf[s & 1];
+        } else {
+            xh_dst = xbuf[s & 1];
+            k_dst = kbuf[s & 1];
+            v_dst = vbuf[s & 1];
+            vo_dst = wbuf[s & 1];
+        }
+        hipLaunchKernelGGL(k_propagate, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st,
+                           sys->d_table + s, n, n_src, cur_x, cur_k, cur_dir,
+                           (s == 0) ? e_re : nullptr, (s == 0) ? e_im : nullptr,
+                           (s == 0) ? e_mode : 0, cur_valid, xh_dst, v_dst);
+        double *dir_dst = dirbuf[s & 1];
+        if (aniso) {
+            hipLaunchKernelGGL(k_interact_aniso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
+                               st, sys->d_table + s, n, xh_dst, cur_k, k_dst, dir_dst,
+                               (double *)nullptr, (double *)nullptr, vo_dst);
+            cur_dir = dir_dst;
+        } else {
+            hipLaunchKernelGGL(k_interact_iso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st,
+                               sys->d_table + s, n, xh_dst, cur_k, v_dst, k_dst,
+                               (double *)nullptr, vo_dst);
+            cur_dir = nullptr;  // k/|k|
+        }
+        cur_x = xh_dst;
+        n_src = n;
+        cur_k = k_dst;
+        cur_valid = vo_dst;
+        off_in += n;
+        off_out += n_o;
+        n = n_o;
+    }
+    HIP_TRY(hipGetLastError());
+    for (int b = 0; b < 2; ++b) {
+        HIP_TRY(hipFreeAsync(dirbuf[b], st));
+        if (xbuf[b]) HIP_TRY(hipFreeAsync(xbuf[b], st));
+        if (kbuf[b]) HIP_TRY(hipFreeAsync(kbuf[b], st));
+        if (vbuf[b]) HIP_TRY(hipFreeAsync(vbuf[b], st));
+        if (wbuf[b]) HIP_TRY(hipFreeAsync(wbuf[b], st));
+    }
+    if (vo_scratch) HIP_TRY(hipFreeAsync(vo_scratch, st));
+    return PRT_OK;
+}
+
+int32_t prt_trace(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,
+                  const double *e0_re, const double *e0_im, int32_t mode, double *x_hit,
+                  double *k_out, uint8_t *valid, uint8_t *valid_out, void *stream) {
+    if (!sys || n0 < 0 || !x0 || !k0 || !x_hit || !k_out || !valid)
+        return fail(PRT_ERR_INVALID_ARG, "prt_trace: null pointer / negative count");
+    if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE)
+        return fail(PRT_ERR_INVALID_ARG, "prt_trace: bad mode");
+    if (n0 == 0) return PRT_OK;
+    HIP_TRY(hipSetDevice(sys->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!sys->all_isotropic)
+        return trace_general(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, valid, valid_out, st);
+    const int32_t e_mode = e_mode_of(e0_re, 1);
+    const bool vec_ok = (n0 % 2 == 0) && aligned16(x0) && aligned16(k0) && aligned16(x_hit) &&
+                        aligned16(k_out) && (!e0_re || aligned16(e0_re)) &&
+                        (!e0_im || aligned16(e0_im)) && ((((uintptr_t)valid) & 1u) == 0) &&
+                        (!valid_out || (((uintptr_t)valid_out) & 1u) == 0);
+    if (vec_ok)
+        launch_trace_iso<2>(sys, n0, x0, k0, e0_re, e0_im, e_mode, mode, x_hit, k_out, valid, valid_out, st);
+    else
+        launch_trace_iso<1>(sys, n0, x0, k0, e0_re, e0_im, e_mode, mode, x_hit, k_out, valid, valid_out, st);
+    HIP_TRY(hipGetLastError());
+    return PRT_OK;
+}
+
+int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,
+                        const double *e0_re, const double *e0_im, int32_t mode, double *x_hit,
+                        double *k_out, uint8_t *valid, uint8_t *valid_out, void *stream,
+                        int32_t iters, double *ms_avg) {
+    if (!ms_avg || iters <= 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace_timed");
+    if (!sys) return fail(PRT_ERR_INVALID_ARG, "null system");
+    HIP_TRY(hipSetDevice(sys->device));
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    HIP_TRY(hipEventRecord(a, st));
+    for (int it = 0; it < iters; ++it) {
+        int32_t rc = prt_trace(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, valid, valid_out, stream);
+        if (rc != PRT_OK) {
+            (void)hipEventDestroy(a);
+            (void)hipEventDestroy(b);
+            return rc;
+        }
+    }
+    HIP_TRY(hipEventRecord(b, st));
+    HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_avg = (double)ms / iters;
+    return PRT_OK;
+}
+
+int32_t prt_propagate(const prt_system_t *sys, int32_t surface, int64_t n, const double *x,
+                      const double *k, const double *dir, const double *e_re, const double *e_im,
+                      int32_t use_default_e, const uint8_t *valid_in, double *x_hit,
+                      uint8_t *valid, void *stream) {
+    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0 || !x || (!k && !dir) || !x_hit || !valid)
+        return fail(PRT_ERR_INVALID_ARG, "prt_propagate: bad argument");
+    if (n == 0) return PRT_OK;
+    HIP_TRY(hipSetDevice(sys->device));
+    hipLaunchKernelGGL(k_propagate, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
+                       (hipStream_t)stream, sys->d_table + surface, n, n, x, k, dir, e_re, e_im,
+                       e_mode_of(e_re, use_default_e), valid_in, x_hit, valid);
+    HIP_TRY(hipGetLastError());
+    return PRT_OK;
+}
+
+int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const double *x_hit,
+                     const double *k, const uint8_t *valid_in, double *k_out, double *dir_out,
+                     double *e_out_re, double *e_out_im, uint8_t *valid_out, void *stream) {
+    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0 || !x_hit || !k || !k_out)
+        return fail(PRT_ERR_INVALID_ARG, "prt_interact: bad argument");
+    if (n == 0) return PRT_OK;
+    HIP_TRY(hipSetDevice(sys->device));
+    const prt_surface_t *rec = sys->h_table + surface;
+    if (rec->mat_type == PRT_MAT_ANISOTROPIC) {
+        if (!dir_out) return fail(PRT_ERR_INVALID_ARG, "prt_interact: anisotropic needs dir_out");
+        hipLaunchKernelGGL(k_interact_aniso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
+                           (hipStream_t)stream, sys->d_table + surface, n, x_hit, k, k_out,
+                           dir_out, e_out_re, e_out_im, valid_out);
+    } else {
+        hipLaunchKernelGGL(k_interact_iso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
+                           (hipStream_t)stream, sys->d_table + surface, n, x_hit, k, valid_in,
+                           k_out, dir_out, valid_out);
+    }
+    HIP_TRY(hipGetLastError());
+    return PRT_OK;
+}
+
+int32_t prt_shape_eval(const prt_system_t *sys, int32_t surface, int64_t n, const double *x,
+                       const double *y, double *sag, double *grad, void *stream) {
+    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0 || !x || !y)
+        return fail(PRT_ERR_INVALID_ARG, "prt_shape_eval: bad argument");
+    if (n == 0) return PRT_OK;
+    HIP_TRY(hipSetDevice(sys->device));
+    hipLaunchKernelGGL(k_shape_eval, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
+                       (hipStream_t)stream, sys->d_table + surface, n, x, y, sag, grad);
+    HIP_TRY(hipGetLastError());
+    return PRT_OK;
+}
+
+int64_t prt_compact_scratch_bytes(int64_t n) {
+    if (n < 0) return 0;
+    const int64_t nb = (n + CMP_TILE - 1) / CMP_TILE;
+    // block sums (+1 total) and the two pointer tables (up to 16 arrays each)
+    return (nb + 1) * (int64_t)sizeof(int64_t) + 2 * 16 * (int64_t)sizeof(void *) + 64;
+}
+
+int32_t prt_compact(int64_t n, const uint8_t *mask, int32_t n_arrays, const double *const *src,
+                    double *const *dst, const int64_t *id_src, int64_t *id_dst, void *scratch,
+                    int64_t *n_kept, void *stream) {
+    if (n < 0 || !mask || n_arrays < 0 || n_arrays > 16 || (n_arrays && (!src || !dst)) ||
+        !scratch || !n_kept || (id_src && !id_dst))
+        return fail(PRT_ERR_INVALID_ARG, "prt_compact: bad argument");
+    *n_kept = 0;
+    if (n == 0) return PRT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nb = (n + CMP_TILE - 1) / CMP_TILE;
+    int64_t *sums = (int64_t *)scratch;
+    uintptr_t pbase = ((uintptr_t)(sums + nb + 1) + 15u) & ~(uintptr_t)15u;
+    const double **d_src = (const double **)pbase;
+    double **d_dst = (double **)(pbase + 16 * sizeof(void *));
+    if (n_arrays) {
+        HIP_TRY(hipMemcpyAsync((void *)d_src, src, sizeof(void *) * n_arrays, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((void *)d_dst, dst, sizeof(void *) * n_arrays, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nb), dim3(PRT_BLOCK), 0, st, mask, n, sums);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(PRT_BLOCK), 0, st, sums, nb);
+    hipLaunchKernelGGL(k_compact_scatter, dim3((unsigned)nb), dim3(PRT_BLOCK), 0, st, mask, n, sums,
+                       n_arrays, (const double *const *)d_src, (double *const *)d_dst, id_src, id_dst);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(n_kept, sums + nb, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PRT_OK;
+}
+
+}  // extern "C"

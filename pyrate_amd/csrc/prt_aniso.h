@@ -1,0 +1,286 @@
+// prt_aniso.h -- AnisotropicMaterial.refract / reflect per ray (device).
+//
+// Reference: material_anisotropic.py:70-155 -> MaxwellMaterial.sortKnormEField
+// (material.py:122-153) -> calcKnormEfield (:98-108) -> calcXiEigenvectorsNorm
+// (:407-454, per-ray scipy.linalg.eig of a 6x6 pencil) -> calcPoytingVectorNorm
+// (:214-223).  Mathematically: with k = kpa + xi n (kpa the in-plane part of the
+// incoming wave vector, n the unit normal, everything in the material frame)
+//     W(xi) E = 0,   W = eps - (k.k) I + k k^T  ( = xi^2 M + xi C + K, :385-392 )
+// has four finite solutions xi.  The reference takes them from LAPACK; here
+//   * det W(xi) = p4 xi^4 + ... + p0 with the coefficients of
+//     calcXiPolynomialNorm (material.py:501-566);
+//   * eps = e I            : xi = +-sqrt(e - kpa.kpa), each double (closed form);
+//   * uniaxial eps = eo I + (ee-eo) c c^T : the quartic factors exactly into the
+//     ordinary sphere  xi^2 = eo - kpa.kpa  and the extraordinary ellipsoid
+//     k^T eps k = eo ee  (a quadratic in xi) -- each well conditioned even where
+//     the two sheets touch (the polynomial's double root is not);
+//   * anything else (biaxial / non-symmetric real eps): Aberth-Ehrlich iteration
+//     on the quartic in complex arithmetic + Newton polish.
+//   The host classifies eps once per surface (surface_table.py) -> aniso_class.
+//   E = null vector of W(xi) (largest cross product of two rows; rank-1 fallback
+//   for the touching sheets), scaled like LAPACK's unit-norm 6-vector [xi E; E]:
+//   |E|^2 (1+|xi|^2) = 1 -- S.n is computed with that scaling and decides the
+//   order of the two transmitted solutions (material.py:144-151).
+// Solutions with complex xi (evanescent) come out as NaN (the reference carries
+// complex k there; out of scope, flagged invalid downstream by checkfinite).
+#pragma once
+#include "prt_device.h"
+
+struct aniso_solution {
+    vec3 k;       // wave vector, global frame
+    vec3 d;       // unit Poynting direction, global frame
+    vec3 er, ei;  // E field, global frame (imaginary part 0 for real eps / real xi)
+};
+
+struct cplx {
+    double re, im;
+};
+PRT_DEV cplx cmul(cplx a, cplx b) { return cplx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+PRT_DEV cplx cadd(cplx a, cplx b) { return cplx{a.re + b.re, a.im + b.im}; }
+PRT_DEV cplx csub(cplx a, cplx b) { return cplx{a.re - b.re, a.im - b.im}; }
+PRT_DEV cplx cdiv(cplx a, cplx b) {
+    const double den = 1.0 / (b.re * b.re + b.im * b.im);
+    return cplx{(a.re * b.re + a.im * b.im) * den, (a.im * b.re - a.re * b.im) * den};
+}
+PRT_DEV double cabs2(cplx a) { return a.re * a.re + a.im * a.im; }
+
+PRT_DEV vec3 cross(const vec3 &a, const vec3 &b) {
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+PRT_DEV vec3 sym_mat_vec(const double *__restrict__ e, const vec3 &v) { return mat_vec(e, v); }
+
+// quartic coefficients, calcXiPolynomialNorm (material.py:501-566), real eps
+PRT_DEV void xi_polynomial(const double *__restrict__ eps, const vec3 &n, const vec3 &kpa,
+                           double p[5]) {
+    const vec3 en = mat_vec(eps, n), ek = mat_vec(eps, kpa);
+    const vec3 etn = matT_vec(eps, n), etk = matT_vec(eps, kpa);
+    const double a1 = eps[0] + eps[4] + eps[8];
+    double a2 = 0.0, a3 = 0.0;
+    // a2 = tr(eps^2), a3 = tr(eps^3)
+    double e2[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            e2[i * 3 + j] = eps[i * 3] * eps[j] + eps[i * 3 + 1] * eps[3 + j] + eps[i * 3 + 2] * eps[6 + j];
+    a2 = e2[0] + e2[4] + e2[8];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a3 += e2[i * 3 + j] * eps[j * 3 + i];
+    const double a4 = dot(kpa, kpa);
+    const double a5 = dot(kpa, ek);
+    const double a6 = dot(etk, ek);   // kpa^T eps eps kpa
+    const double a7 = dot(n, en);
+    const double a8 = dot(n, ek);     // eps_ij kpa_j n_i
+    const double a9 = dot(kpa, en);   // eps_ij kpa_i n_j
+    const double a11 = dot(etn, ek);  // n^T eps eps kpa
+    const double a12 = dot(etk, en);  // kpa^T eps eps n
+    const double a13 = dot(etn, en);  // n^T eps eps n
+    p[4] = a7;
+    p[3] = a8 + a9;
+    p[2] = (a5 + a4 * a7) + (a13 - a1 * a7);
+    p[1] = a4 * p[3] + (a11 + a12 - a1 * p[3]);
+    p[0] = a4 * a5 + (-a1 * a5 + a6) + (1.0 / 6.0) * (a1 * a1 * a1 - 3.0 * a1 * a2 + 2.0 * a3);
+}
+
+// Aberth-Ehrlich on p4 z^4 + ... + p0 (complex roots), then two Newton steps each.
+PRT_DEV void quartic_roots(const double p[5], cplx z[4]) {
+    const double ip4 = 1.0 / p[4];
+    const double a3 = p[3] * ip4, a2 = p[2] * ip4, a1 = p[1] * ip4, a0 = p[0] * ip4;
+    // Cauchy bound for the start radius
+    const double rad = 1.0 + fmax(fmax(fabs(a3), fabs(a2)), fmax(fabs(a1), fabs(a0)));
+    const double r0 = 0.5 * rad;
+    z[0] = cplx{r0 * 0.9238795325112867, r0 * 0.3826834323650898};
+    z[1] = cplx{-r0 * 0.3826834323650898, r0 * 0.9238795325112867};
+    z[2] = cplx{-r0 * 0.9238795325112867, -r0 * 0.3826834323650898};
+    z[3] = cplx{r0 * 0.3826834323650898, -r0 * 0.9238795325112867};
+    bool done = false;
+    for (int it = 0; it < 60; ++it) {
+        double worst = 0.0;
+        cplx w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const cplx zi = z[i];
+            // f = z^4 + a3 z^3 + a2 z^2 + a1 z + a0 ; f' by Horner
+            cplx f = cplx{1.0, 0.0}, fp = cplx{0.0, 0.0};
+            fp = cadd(cmul(fp, zi), f);
+            f = cadd(cmul(f, zi), cplx{a3, 0.0});
+            fp = cadd(cmul(fp, zi), f);
+            f = cadd(cmul(f, zi), cplx{a2, 0.0});
+            fp = cadd(cmul(fp, zi), f);
+            f = cadd(cmul(f, zi), cplx{a1, 0.0});
+            fp = cadd(cmul(fp, zi), f);
+            f = cadd(cmul(f, zi), cplx{a0, 0.0});
+            cplx newton = cdiv(f, fp);
+            cplx sum = cplx{0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j != i) sum = cadd(sum, cdiv(cplx{1.0, 0.0}, csub(zi, z[j])));
+            const cplx den = csub(cplx{1.0, 0.0}, cmul(newton, sum));
+            w[i] = cdiv(newton, den);
+            if (!(cabs2(fp) > 0.0) || !isfinite(w[i].re) || !isfinite(w[i].im)) w[i] = cplx{0.0, 0.0};
+            worst = fmax(worst, cabs2(w[i]) / fmax(cabs2(zi), 1e-300));
+        }
+        if (!done) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[i] = csub(z[i], w[i]);
+            done = worst < 1e-30;
+        }
+        if (__all(done)) break;
+    }
+}
+
+// null vector(s) of the real 3x3 matrix W.  variant selects which of the two
+// basis vectors is returned when W has rank <= 1 (touching dispersion sheets).
+PRT_DEV vec3 null_vector(const double W[9], int variant) {
+    const vec3 r0 = v3(W[0], W[1], W[2]), r1 = v3(W[3], W[4], W[5]), r2 = v3(W[6], W[7], W[8]);
+    const vec3 c01 = cross(r0, r1), c02 = cross(r0, r2), c12 = cross(r1, r2);
+    const double n01 = dot(c01, c01), n02 = dot(c02, c02), n12 = dot(c12, c12);
+    vec3 best = c01;
+    double nb = n01;
+    if (n02 > nb) { best = c02; nb = n02; }
+    if (n12 > nb) { best = c12; nb = n12; }
+    const double fro = dot(r0, r0) + dot(r1, r1) + dot(r2, r2);
+    if (nb > 1e-20 * fro * fro) {
+        const double inv = 1.0 / sqrt(nb);
+        return v3(best.x * inv, best.y * inv, best.z * inv);
+    }
+    // rank <= 1: null space is the plane perpendicular to the dominant row
+    vec3 r = r0;
+    double nr = dot(r0, r0);
+    if (dot(r1, r1) > nr) { r = r1; nr = dot(r1, r1); }
+    if (dot(r2, r2) > nr) { r = r2; nr = dot(r2, r2); }
+    const double ax = fabs(r.x), ay = fabs(r.y), az = fabs(r.z);
+    vec3 a = (ax <= ay && ax <= az) ? v3(1, 0, 0) : ((ay <= az) ? v3(0, 1, 0) : v3(0, 0, 1));
+    vec3 v1 = cross(r, a);
+    double inv = 1.0 / sqrt(dot(v1, v1));
+    v1 = v3(v1.x * inv, v1.y * inv, v1.z * inv);
+    if (variant == 0) return v1;
+    vec3 v2 = cross(r, v1);
+    inv = 1.0 / sqrt(dot(v2, v2));
+    return v3(v2.x * inv, v2.y * inv, v2.z * inv);
+}
+
+// The four (xi, E, S.n) solutions for one ray, then the reference's ordering.
+// p: hit point in the shape frame; k: incoming wave vector (global).
+// out[0], out[1]: refract -> sorted solutions 2, 3; mirror -> -(0), -(1).
+PRT_DEV void interact_anisotropic(const prt_surface_t *__restrict__ sf, const vec3 &p,
+                                  const vec3 &k_glob, aniso_solution out[2]) {
+    const vec3 n = normal_in_material_frame(sf, p);
+    const bool mat_id = sf->frame_flags & PRT_FRAME_MAT_IDENTITY;
+    const vec3 k1 = mat_id ? k_glob : matT_vec(sf->B_mat, k_glob);
+    const double kn = dot(k1, n);
+    const vec3 kpa = v3(k1.x - kn * n.x, k1.y - kn * n.y, k1.z - kn * n.z);
+    const double *__restrict__ eps = sf->eps_re;
+    const double kap2 = dot(kpa, kpa);
+
+    double xi[4];
+    int variant[4];
+    const int cls = sf->aniso_class;
+    if (cls == PRT_ANISO_ISOTROPIC) {
+        const double e = sf->aniso_eo;
+        const double r = sqrt(e - kap2);  // NaN if evanescent
+        xi[0] = -r; xi[1] = -r; xi[2] = r; xi[3] = r;
+        variant[0] = 0; variant[1] = 1; variant[2] = 0; variant[3] = 1;
+    } else if (cls == PRT_ANISO_UNIAXIAL) {
+        const double eo = sf->aniso_eo, ee = sf->aniso_ee;
+        const vec3 c = v3(sf->aniso_axis[0], sf->aniso_axis[1], sf->aniso_axis[2]);
+        const double ro = sqrt(eo - kap2);
+        const double nc = dot(n, c), kc = dot(kpa, c);
+        const double A = eo + (ee - eo) * nc * nc;
+        const double Bh = (ee - eo) * kc * nc;  // B/2
+        const double C = eo * kap2 + (ee - eo) * kc * kc - eo * ee;
+        const double disc = sqrt(Bh * Bh - A * C);  // NaN if evanescent
+        // stable quadratic roots
+        const double q = -(Bh + copysign(disc, Bh));
+        double x1 = q / A, x2 = (q != 0.0) ? C / q : -x1;
+        if (Bh == 0.0) { x1 = -disc / A; x2 = disc / A; }
+        xi[0] = -ro; xi[2] = ro;
+        xi[1] = fmin(x1, x2); xi[3] = fmax(x1, x2);
+        if (!isfinite(disc)) { xi[1] = xi[3] = __builtin_nan(""); }
+        variant[0] = 0; variant[2] = 0; variant[1] = 1; variant[3] = 1;
+    } else {
+        double pc[5];
+        xi_polynomial(eps, n, kpa, pc);
+        cplx z[4];
+        quartic_roots(pc, z);
+        // sort by real part (insertion), keep real ones
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+#pragma unroll
+            for (int j = i; j > 0; --j)
+                if (z[j].re < z[j - 1].re) { cplx t = z[j]; z[j] = z[j - 1]; z[j - 1] = t; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool real_root = fabs(z[i].im) <= 1e-9 * fmax(1.0, fabs(z[i].re));
+            double x = real_root ? z[i].re : __builtin_nan("");
+            // Newton polish on the real polynomial
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const double f = (((pc[4] * x + pc[3]) * x + pc[2]) * x + pc[1]) * x + pc[0];
+                const double fp = ((4.0 * pc[4] * x + 3.0 * pc[3]) * x + 2.0 * pc[2]) * x + pc[1];
+                const double dx = f / fp;
+                if (isfinite(dx) && fabs(dx) < 1e-6 * fmax(1.0, fabs(x))) x -= dx;
+            }
+            xi[i] = x;
+            variant[i] = i & 1;
+        }
+    }
+
+    // eigenvectors, Poynting vectors and S.n
+    vec3 kk[4], ee_[4], ss[4];
+    double sn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const vec3 kv = v3(kpa.x + xi[i] * n.x, kpa.y + xi[i] * n.y, kpa.z + xi[i] * n.z);
+        const double k2 = dot(kv, kv);
+        double W[9];
+        W[0] = eps[0] - k2 + kv.x * kv.x; W[1] = eps[1] + kv.x * kv.y; W[2] = eps[2] + kv.x * kv.z;
+        W[3] = eps[3] + kv.y * kv.x; W[4] = eps[4] - k2 + kv.y * kv.y; W[5] = eps[5] + kv.y * kv.z;
+        W[6] = eps[6] + kv.z * kv.x; W[7] = eps[7] + kv.z * kv.y; W[8] = eps[8] - k2 + kv.z * kv.z;
+        vec3 E = null_vector(W, variant[i]);
+        const double sc = 1.0 / sqrt(1.0 + xi[i] * xi[i]);  // LAPACK unit-norm [xi E; E]
+        E = v3(E.x * sc, E.y * sc, E.z * sc);
+        const double e2 = dot(E, E), ke = dot(kv, E);
+        const vec3 S = v3(e2 * kv.x - ke * E.x, e2 * kv.y - ke * E.y, e2 * kv.z - ke * E.z);
+        kk[i] = kv; ee_[i] = E; ss[i] = S;
+        sn[i] = dot(S, n);
+    }
+    // argsort ascending by S.n (material.py:147); NaNs last like numpy
+    int idx[4] = {0, 1, 2, 3};
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+#pragma unroll
+        for (int j = i; j > 0; --j) {
+            const double a = sn[idx[j]], b = sn[idx[j - 1]];
+            const bool less = (a < b) || (isnan(b) && !isnan(a));
+            if (less) { int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t; }
+        }
+    const bool mirror = sf->interaction == PRT_MIRROR;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int src = mirror ? idx[b] : idx[2 + b];
+        // pick without dynamic register indexing
+        vec3 kv = kk[0], E = ee_[0], S = ss[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q)
+            if (src == q) { kv = kk[q]; E = ee_[q]; S = ss[q]; }
+        if (mirror) {  // material_anisotropic.py:136-137: k, E negated (S is even in E, odd in k)
+            kv = v3(-kv.x, -kv.y, -kv.z);
+            E = v3(-E.x, -E.y, -E.z);
+            S = v3(-S.x, -S.y, -S.z);
+        }
+        const double inv = 1.0 / sqrt(dot(S, S));
+        vec3 d = v3(S.x * inv, S.y * inv, S.z * inv);
+        if (!mat_id) {
+            kv = mat_vec(sf->B_mat, kv);
+            E = mat_vec(sf->B_mat, E);
+            d = mat_vec(sf->B_mat, d);
+        }
+        out[b].k = kv;
+        out[b].d = d;
+        out[b].er = E;
+        out[b].ei = v3(0, 0, 0);
+    }
+}

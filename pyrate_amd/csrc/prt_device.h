@@ -1,0 +1,289 @@
+// prt_device.h -- per-ray device functions of the gfx950 raytrace engine.
+//
+// One thread owns one ray (or RPT adjacent rays): state x(3), k(3), valid lives in
+// VGPRs; everything that is the same for all rays -- the surface record: frames,
+// shape coefficients, aperture, index -- is read through wave-uniform addresses,
+// which hipcc turns into s_load (scalar cache -> SGPRs).  FP64 VALU instructions
+// take SGPR pairs as operands directly, so uniform coefficients cost no VGPRs, no
+// LDS traffic and no ds_read issue slots; that is why the table is NOT staged
+// through LDS (measured alternative: see DESIGN.md "surface table placement").
+//
+// No MFMA anywhere: the work is a per-ray chain of ~150 dependent FP64 ops with
+// 3x3 mat-vecs whose matrix is wave-uniform -- there is no contraction dimension
+// to feed a matrix core.
+//
+// Formulas follow the reference (cited per function); algebraically identical
+// short-cuts are marked "== " with the identity used.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/prt.h"
+
+#define PRT_DEV __device__ __forceinline__
+
+struct vec3 {
+    double x, y, z;
+};
+
+PRT_DEV vec3 v3(double x, double y, double z) { return vec3{x, y, z}; }
+PRT_DEV double dot(const vec3 &a, const vec3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// r = B v            (localcoordinates.py:391-396)
+PRT_DEV vec3 mat_vec(const double *__restrict__ B, const vec3 &v) {
+    return v3(B[0] * v.x + B[1] * v.y + B[2] * v.z, B[3] * v.x + B[4] * v.y + B[5] * v.z,
+              B[6] * v.x + B[7] * v.y + B[8] * v.z);
+}
+// r = B^T v          (localcoordinates.py:406-413)
+PRT_DEV vec3 matT_vec(const double *__restrict__ B, const vec3 &v) {
+    return v3(B[0] * v.x + B[3] * v.y + B[6] * v.z, B[1] * v.x + B[4] * v.y + B[7] * v.z,
+              B[2] * v.x + B[5] * v.y + B[8] * v.z);
+}
+
+PRT_DEV bool finite3(const vec3 &v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
+
+// ---------------------------------------------------------------------------
+// first-segment direction: RayBundle.returnKtoD, ray.py:136-152
+//   S = Re(|E|^2 k - (E.k) conj(E)),  d = S/|S|      (k real)
+// ---------------------------------------------------------------------------
+PRT_DEV vec3 poynting_dir(const vec3 &k, const vec3 &er, const vec3 &ei) {
+    const double e2 = dot(er, er) + dot(ei, ei);
+    const double ekr = dot(er, k), eki = dot(ei, k);
+    // Re((ekr + i eki)(er - i ei)) = ekr*er + eki*ei
+    vec3 s = v3(e2 * k.x - (ekr * er.x + eki * ei.x), e2 * k.y - (ekr * er.y + eki * ei.y),
+                e2 * k.z - (ekr * er.z + eki * ei.z));
+    const double inv = 1.0 / sqrt(dot(s, s));
+    return v3(s.x * inv, s.y * inv, s.z * inv);
+}
+
+PRT_DEV vec3 normalized(const vec3 &k) {
+    const double inv = 1.0 / sqrt(dot(k, k));
+    return v3(k.x * inv, k.y * inv, k.z * inv);
+}
+
+// ---------------------------------------------------------------------------
+// shapes
+// ---------------------------------------------------------------------------
+
+// Conic.intersect, surface_shape.py:305-321.  r0, d in the shape frame.
+PRT_DEV double conic_t(double c, double cc, const vec3 &r0, const vec3 &d, bool &ok) {
+    const double F = d.z - c * (d.x * r0.x + d.y * r0.y + d.z * r0.z * (1.0 + cc));
+    const double G = c * (r0.x * r0.x + r0.y * r0.y + r0.z * r0.z * (1.0 + cc)) - 2.0 * r0.z;
+    const double H = -c - cc * c * d.z * d.z;
+    const double square = F * F + H * G;
+    ok = square >= 0.0;
+    return G / (F + sqrt(square));
+}
+
+// Conic.getGrad + conic_function, surface_shape.py:208-237:
+//   z = c r2/(1+sq), sq = sqrt(1-(1+cc)c^2 r2);  grad = (-c x, -c y, 1 - c z (1+cc))
+//   == (-c x, -c y, sq)   because c z (1+cc) = (1-sq^2)/(1+sq) = 1 - sq.
+// Outside the conic's domain (1-(1+cc)c^2 r2 <= 0) the reference's sag is NaN.
+PRT_DEV vec3 conic_grad(double c, double cc, double x, double y) {
+    const double r2 = x * x + y * y;
+    const double st = 1.0 - (1.0 + cc) * c * c * r2;
+    const double sq = (st > 0.0) ? sqrt(st) : __builtin_nan("");
+    return v3(-c * x, -c * y, sq);
+}
+
+PRT_DEV double conic_sag(double c, double cc, double r2) {
+    const double st = 1.0 - (1.0 + cc) * c * c * r2;
+    if (!(st > 0.0)) return __builtin_nan("");
+    return c * r2 / (1.0 + sqrt(st));
+}
+
+// Asphere.F and Asphere.gradF, surface_shape.py:529-555, in one pass:
+//   F  = c r2/(1+sq) + sum_n a_n r2^(n+1)
+//   Fx = x (c/sq + sum_n 2(n+1) a_n r2^n),   gradient of z-F = (-Fx, -Fy, 1)
+// Horner in r2 (the reference sums the powers; same polynomial).
+PRT_DEV void asphere_eval(const prt_surface_t *__restrict__ sf, double x, double y, double &F,
+                          double &dFdr2x2 /* Fx = x * this */) {
+    const double c = sf->curv, cc = sf->cc;
+    const double r2 = x * x + y * y;
+    const double sq = sqrt(1.0 - c * c * (1.0 + cc) * r2);
+    double p = 0.0, dp = 0.0;  // p = sum a_n r2^n ; dp = sum (n+1) a_n r2^n
+    const int nc = sf->n_coeffs;
+    for (int n = nc - 1; n >= 0; --n) {
+        const double a = sf->coeffs[n];
+        p = p * r2 + a;
+        dp = dp * r2 + (double)(n + 1) * a;
+    }
+    F = c * r2 / (1.0 + sq) + p * r2;
+    dFdr2x2 = c / sq + 2.0 * dp;
+}
+
+// XYPolynomials.F / gradF, surface_shape.py:785-807.  coeffs[] already hold
+// c / normradius^(i+j) (host side).  Powers by repeated multiplication with
+// wave-uniform trip counts.
+PRT_DEV void xypoly_eval(const prt_surface_t *__restrict__ sf, double x, double y, double &F,
+                         double &Fx, double &Fy) {
+    F = 0.0;
+    Fx = 0.0;
+    Fy = 0.0;
+    const int nt = sf->n_coeffs;
+    for (int t = 0; t < nt; ++t) {
+        const int i = sf->xpow[t], j = sf->ypow[t];
+        const double c = sf->coeffs[t];
+        double xm1 = 1.0, ym1 = 1.0;  // x^(i-1), y^(j-1)
+        for (int q = 1; q < i; ++q) xm1 *= x;
+        for (int q = 1; q < j; ++q) ym1 *= y;
+        const double xi = (i >= 1) ? xm1 * x : 1.0;
+        const double yj = (j >= 1) ? ym1 * y : 1.0;
+        F += xi * yj * c;
+        if (i >= 1) Fx += (double)i * xm1 * yj * c;
+        if (j >= 1) Fy += (double)j * xi * ym1 * c;
+    }
+}
+
+// explicit z = F(x,y) shapes: value and in-plane derivatives
+PRT_DEV void explicit_eval(const prt_surface_t *__restrict__ sf, double x, double y, double &F,
+                           double &Fx, double &Fy) {
+    if (sf->shape_type == PRT_SHAPE_ASPHERE) {
+        double m;
+        asphere_eval(sf, x, y, F, m);
+        Fx = x * m;
+        Fy = y * m;
+    } else {
+        xypoly_eval(sf, x, y, F, Fx, Fy);
+    }
+}
+
+// ExplicitShape.intersect, surface_shape.py:448-465: root of
+//   g(t) = r0z + t dz - F(r0x + t dx, r0y + t dy), start t = 0.
+// The reference gives the N-vector to MINPACK hybrd (xtol 1e-6); here every ray
+// runs scalar Newton to machine precision.  The loop is wave-uniform: a wave
+// leaves when all its lanes have converged (or the cap is hit); converged lanes
+// keep their t.  *nonconv reports lanes that hit the cap.
+PRT_DEV double explicit_t(const prt_surface_t *__restrict__ sf, const vec3 &r0, const vec3 &d,
+                          bool &nonconv) {
+    double t = 0.0;
+    bool done = false;
+    const int maxit = sf->newton_maxit > 0 ? sf->newton_maxit : 30;
+    for (int it = 0; it < maxit; ++it) {
+        double F, Fx, Fy;
+        const double px = r0.x + t * d.x, py = r0.y + t * d.y;
+        explicit_eval(sf, px, py, F, Fx, Fy);
+        const double g = r0.z + t * d.z - F;
+        const double gp = d.z - Fx * d.x - Fy * d.y;
+        const double dt = g / gp;
+        if (!done) {
+            t -= dt;
+            const double scale = fmax(1.0, fabs(t));
+            // NaN/Inf steps stop the lane too (t is already non-finite -> ray invalid later)
+            done = !(fabs(dt) > 1e-15 * scale) || !isfinite(dt);
+        }
+        if (__all(done)) break;
+    }
+    nonconv = !done;
+    return t;
+}
+
+// gradient of the implicit surface function in the shape frame (not normalised)
+PRT_DEV vec3 shape_grad(const prt_surface_t *__restrict__ sf, double x, double y) {
+    if (sf->shape_type == PRT_SHAPE_CONIC) return conic_grad(sf->curv, sf->cc, x, y);
+    double F, Fx, Fy;
+    explicit_eval(sf, x, y, F, Fx, Fy);
+    return v3(-Fx, -Fy, 1.0);
+}
+
+PRT_DEV double shape_sag(const prt_surface_t *__restrict__ sf, double x, double y) {
+    if (sf->shape_type == PRT_SHAPE_CONIC) return conic_sag(sf->curv, sf->cc, x * x + y * y);
+    double F, Fx, Fy;
+    explicit_eval(sf, x, y, F, Fx, Fy);
+    return F;
+}
+
+// ---------------------------------------------------------------------------
+// aperture.py:71-139
+// ---------------------------------------------------------------------------
+PRT_DEV bool aperture_ok(const prt_surface_t *__restrict__ sf, double x, double y) {
+    if (sf->ap_type == PRT_AP_CIRCULAR) {
+        const double r2 = x * x + y * y;
+        return (r2 >= sf->ap_p0 * sf->ap_p0) && (r2 <= sf->ap_p1 * sf->ap_p1);
+    }
+    if (sf->ap_type == PRT_AP_RECTANGULAR) {
+        const double hw = sf->ap_p0 * 0.5, hh = sf->ap_p1 * 0.5;
+        return (x >= -hw) && (x <= hw) && (y >= -hh) && (y <= hh);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Material.propagate -> Surface.intersect (surface.py:116-135)
+//   in : x global start point, d global unit direction
+//   out: xh global hit point, p hit point in the shape frame, valid &= hit & aperture
+// ---------------------------------------------------------------------------
+PRT_DEV void propagate_step(const prt_surface_t *__restrict__ sf, const vec3 &x, const vec3 &d,
+                            vec3 &xh, vec3 &p, bool &valid) {
+    const int ff = sf->frame_flags;
+    vec3 r0 = v3(x.x - sf->g_shape[0], x.y - sf->g_shape[1], x.z - sf->g_shape[2]);
+    vec3 dl = d;
+    if (!(ff & PRT_FRAME_SHAPE_IDENTITY)) {
+        r0 = matT_vec(sf->B_shape, r0);
+        dl = matT_vec(sf->B_shape, d);
+    }
+    double t;
+    if (sf->shape_type == PRT_SHAPE_CONIC) {
+        bool ok;
+        t = conic_t(sf->curv, sf->cc, r0, dl, ok);
+        valid = valid && ok;
+    } else {
+        bool nonconv;
+        t = explicit_t(sf, r0, dl, nonconv);  // reference: valid all True (surface_shape.py:462)
+    }
+    p = v3(r0.x + dl.x * t, r0.y + dl.y * t, r0.z + dl.z * t);
+    if (ff & PRT_FRAME_SHAPE_IDENTITY) {
+        xh = v3(p.x + sf->g_shape[0], p.y + sf->g_shape[1], p.z + sf->g_shape[2]);
+    } else {
+        xh = mat_vec(sf->B_shape, p);
+        xh.x += sf->g_shape[0];
+        xh.y += sf->g_shape[1];
+        xh.z += sf->g_shape[2];
+    }
+    if (sf->ap_type != PRT_AP_NONE) {
+        vec3 pa = p;  // aperture frame == shape frame in the common case
+        if (!(ff & PRT_FRAME_AP_IS_SHAPE)) {
+            pa = matT_vec(sf->B_ap, v3(xh.x - sf->g_ap[0], xh.y - sf->g_ap[1], xh.z - sf->g_ap[2]));
+        }
+        valid = valid && aperture_ok(sf, pa.x, pa.y);
+    }
+}
+
+// shape-frame hit point from a global one (used when interact is called on its own)
+PRT_DEV vec3 to_shape_frame(const prt_surface_t *__restrict__ sf, const vec3 &xh) {
+    vec3 r = v3(xh.x - sf->g_shape[0], xh.y - sf->g_shape[1], xh.z - sf->g_shape[2]);
+    if (!(sf->frame_flags & PRT_FRAME_SHAPE_IDENTITY)) r = matT_vec(sf->B_shape, r);
+    return r;
+}
+
+// unit normal in the frame of the medium: RayBundle.getLocalSurfaceNormal, ray.py:156-161
+PRT_DEV vec3 normal_in_material_frame(const prt_surface_t *__restrict__ sf, const vec3 &p) {
+    vec3 g = shape_grad(sf, p.x, p.y);
+    // Shape.getNormal, surface_shape.py:100-112
+    const double inv = 1.0 / sqrt(dot(g, g));
+    vec3 n = v3(g.x * inv, g.y * inv, g.z * inv);
+    const int ff = sf->frame_flags;
+    if (!(ff & PRT_FRAME_SHAPE_IDENTITY)) n = mat_vec(sf->B_shape, n);
+    if (!(ff & PRT_FRAME_MAT_IDENTITY)) n = matT_vec(sf->B_mat, n);
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// IsotropicMaterial.refract / reflect, material_isotropic.py:137-236
+//   k global in -> k global out; valid &= (n2^2 - kin.kin > 0) & finite(normal)
+// ---------------------------------------------------------------------------
+PRT_DEV void interact_isotropic(const prt_surface_t *__restrict__ sf, const vec3 &p, vec3 &k,
+                                bool &valid) {
+    const vec3 n = normal_in_material_frame(sf, p);
+    const bool mat_id = sf->frame_flags & PRT_FRAME_MAT_IDENTITY;
+    vec3 k1 = k;
+    if (!mat_id) k1 = matT_vec(sf->B_mat, k);
+    const double kn = dot(k1, n);
+    vec3 kin = v3(k1.x - kn * n.x, k1.y - kn * n.y, k1.z - kn * n.z);
+    const double n2 = sf->n_after;
+    const double square = n2 * n2 - dot(kin, kin);
+    const double xi = sqrt(square);
+    valid = valid && (square > 0.0) && finite3(n);
+    if (sf->interaction == PRT_MIRROR) kin = v3(-kin.x, -kin.y, -kin.z);  // :224
+    vec3 k2 = v3(kin.x + xi * n.x, kin.y + xi * n.y, kin.z + xi * n.z);
+    k = mat_id ? k2 : mat_vec(sf->B_mat, k2);
+}

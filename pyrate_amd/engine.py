@@ -1,0 +1,237 @@
+"""
+Thin host wrapper around the C ABI: a surface table living on one GPU plus
+``trace`` / ``propagate`` / ``interact`` / ``shape_eval`` / ``compact`` calls
+on device-resident (3, N) float64 tensors.  torch is used only as the device
+allocator and stream provider; every number is produced by ``libprt.so``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .surface_table import pack_table
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream_handle(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _check_rays(t, name, n=None):
+    if t.dtype != torch.float64 or t.dim() != 2 or t.shape[0] != 3 or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous (3, N) float64 tensor" % name)
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU" % name)
+    if n is not None and t.shape[1] != n:
+        raise ValueError("%s has %d rays, expected %d" % (name, t.shape[1], n))
+
+
+class TraceResult(object):
+    """Dense (uncompacted) outputs of one sequence trace.
+
+    ``x_hit[s]`` (3, n_in[s]), ``valid[s]`` (n_in[s]) cumulative mask after
+    intersect + aperture, ``k_out[s]`` (3, n_out[s]), ``valid_out[s]`` (n_out[s])
+    mask carried into the next segment (what the reference compacts by).
+    In image mode the lists have one entry (the last surface).
+    """
+
+    def __init__(self, x_hit, k_out, valid, valid_out, n_in, n_out, mode):
+        self.x_hit = x_hit
+        self.k_out = k_out
+        self.valid = valid
+        self.valid_out = valid_out
+        self.n_in = n_in
+        self.n_out = n_out
+        self.mode = mode
+
+
+class DeviceSystem(object):
+    """A flattened surface table resident on one GPU (``prt_system_t``)."""
+
+    def __init__(self, records, device=0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("pyrate_amd: no HIP device visible; the engine has no CPU fallback")
+        self.device = torch.device("cuda", device if isinstance(device, int) else device.index or 0)
+        self.records = list(records)
+        self.n_surfaces = len(self.records)
+        self._table = pack_table(self.records)
+        self.all_isotropic = all(r["material"]["type"] == "isotropic" for r in self.records)
+        handle = ctypes.c_void_p()
+        torch.cuda.init()
+        _lib.check(self.lib.prt_system_create(self._table, self.n_surfaces,
+                                              self.device.index, ctypes.byref(handle)))
+        self._h = handle
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.prt_system_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- bookkeeping ------------------------------------------------------
+    def ray_counts(self, n0):
+        n_in = (ctypes.c_int64 * self.n_surfaces)()
+        n_out = (ctypes.c_int64 * self.n_surfaces)()
+        _lib.check(self.lib.prt_system_ray_counts(self._h, n0, n_in, n_out))
+        return list(n_in), list(n_out)
+
+    def alloc_outputs(self, n0, mode=_lib.MODE_PATH, with_valid_out=True):
+        (n_in, n_out) = self.ray_counts(n0)
+        if mode == _lib.MODE_IMAGE:
+            n_in, n_out = n_in[-1:], n_out[-1:]
+        dev = self.device
+        bufs = dict(
+            x_hit=torch.empty(3 * sum(n_in), dtype=torch.float64, device=dev),
+            k_out=torch.empty(3 * sum(n_out), dtype=torch.float64, device=dev),
+            valid=torch.empty(sum(n_in), dtype=torch.uint8, device=dev),
+            valid_out=(torch.empty(sum(n_out), dtype=torch.uint8, device=dev)
+                       if with_valid_out else None),
+            n_in=n_in, n_out=n_out, mode=mode)
+        return bufs
+
+    # -- whole sequence ----------------------------------------------------
+    def trace_into(self, x0, k0, bufs, e0_re=None, e0_im=None):
+        """Asynchronous launch into preallocated buffers (see alloc_outputs)."""
+        n0 = x0.shape[1]
+        _lib.check(self.lib.prt_trace(self._h, n0, _ptr(x0), _ptr(k0), _ptr(e0_re), _ptr(e0_im),
+                                      bufs["mode"], _ptr(bufs["x_hit"]), _ptr(bufs["k_out"]),
+                                      _ptr(bufs["valid"]), _ptr(bufs["valid_out"]),
+                                      _stream_handle(self.device)))
+
+    def trace_timed(self, x0, k0, bufs, iters, e0_re=None, e0_im=None):
+        """Average device milliseconds per prt_trace launch (HIP events on the launch
+        stream, inside libprt)."""
+        ms = ctypes.c_double()
+        n0 = x0.shape[1]
+        _lib.check(self.lib.prt_trace_timed(self._h, n0, _ptr(x0), _ptr(k0), _ptr(e0_re),
+                                            _ptr(e0_im), bufs["mode"], _ptr(bufs["x_hit"]),
+                                            _ptr(bufs["k_out"]), _ptr(bufs["valid"]),
+                                            _ptr(bufs["valid_out"]), _stream_handle(self.device),
+                                            iters, ctypes.byref(ms)))
+        return ms.value
+
+    def trace(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH):
+        """OpticalSystem.seqtrace on device tensors; returns a TraceResult of views."""
+        _check_rays(x0, "x0")
+        n0 = x0.shape[1]
+        _check_rays(k0, "k0", n0)
+        if e0_re is not None:
+            _check_rays(e0_re, "e0_re", n0)
+        if e0_im is not None:
+            _check_rays(e0_im, "e0_im", n0)
+        with torch.cuda.device(self.device):
+            bufs = self.alloc_outputs(n0, mode)
+            self.trace_into(x0, k0, bufs, e0_re, e0_im)
+        return self.views(bufs)
+
+    @staticmethod
+    def views(bufs):
+        (xs, ks, vs, ws) = ([], [], [], [])
+        (oi, oo) = (0, 0)
+        for (ni, no) in zip(bufs["n_in"], bufs["n_out"]):
+            xs.append(bufs["x_hit"][3 * oi:3 * (oi + ni)].view(3, ni))
+            vs.append(bufs["valid"][oi:oi + ni])
+            ks.append(bufs["k_out"][3 * oo:3 * (oo + no)].view(3, no))
+            ws.append(None if bufs["valid_out"] is None else bufs["valid_out"][oo:oo + no])
+            oi += ni
+            oo += no
+        return TraceResult(xs, ks, vs, ws, bufs["n_in"], bufs["n_out"], bufs["mode"])
+
+    # -- per-surface plugin granularity -------------------------------------
+    def propagate(self, surface, x, k, direction=None, e_re=None, e_im=None,
+                  default_e=True, valid_in=None):
+        """Material.propagate / Surface.intersect for one surface."""
+        _check_rays(x, "x")
+        n = x.shape[1]
+        with torch.cuda.device(self.device):
+            x_hit = torch.empty_like(x)
+            valid = torch.empty(n, dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.prt_propagate(self._h, surface, n, _ptr(x), _ptr(k),
+                                              _ptr(direction), _ptr(e_re), _ptr(e_im),
+                                              1 if default_e else 0, _ptr(valid_in), _ptr(x_hit),
+                                              _ptr(valid), _stream_handle(self.device)))
+        return x_hit, valid
+
+    def interact(self, surface, x_hit, k, valid_in=None, want_e=False):
+        """Material.refract / reflect at one surface.  Returns
+        (k_out, dir_out, valid_out, e_re, e_im)."""
+        _check_rays(x_hit, "x_hit")
+        n = x_hit.shape[1]
+        aniso = self.records[surface]["material"]["type"] == "anisotropic"
+        m = 2 * n if aniso else n
+        with torch.cuda.device(self.device):
+            k_out = torch.empty((3, m), dtype=torch.float64, device=self.device)
+            dir_out = torch.empty((3, m), dtype=torch.float64, device=self.device)
+            valid_out = torch.empty(m, dtype=torch.uint8, device=self.device)
+            e_re = e_im = None
+            if aniso and want_e:
+                e_re = torch.empty((3, m), dtype=torch.float64, device=self.device)
+                e_im = torch.empty((3, m), dtype=torch.float64, device=self.device)
+            _lib.check(self.lib.prt_interact(self._h, surface, n, _ptr(x_hit), _ptr(k),
+                                             _ptr(valid_in), _ptr(k_out), _ptr(dir_out),
+                                             _ptr(e_re), _ptr(e_im), _ptr(valid_out),
+                                             _stream_handle(self.device)))
+        return k_out, dir_out, valid_out, e_re, e_im
+
+    def shape_eval(self, surface, x, y, want_sag=True, want_grad=True):
+        """Shape.getSag / getGrad on the device; x, y 1-d float64 tensors (shape frame)."""
+        n = x.shape[0]
+        with torch.cuda.device(self.device):
+            sag = torch.empty(n, dtype=torch.float64, device=self.device) if want_sag else None
+            grad = torch.empty((3, n), dtype=torch.float64, device=self.device) if want_grad else None
+            _lib.check(self.lib.prt_shape_eval(self._h, surface, n, _ptr(x), _ptr(y), _ptr(sag),
+                                               _ptr(grad), _stream_handle(self.device)))
+        return sag, grad
+
+
+def compact(mask, arrays, ids=None):
+    """Order-preserving ``[:, mask]`` on the device (material_isotropic.py:194-199).
+    arrays: list of (R_i, N) float64 tensors; ids: optional (N,) int64.
+    Returns (list of compacted tensors, compacted ids or None)."""
+    lib = _lib.load()
+    n = mask.shape[0]
+    dev = mask.device
+    rows_src = []
+    for a in arrays:
+        if a.dtype != torch.float64 or not a.is_contiguous() or a.shape[-1] != n:
+            raise ValueError("compact: arrays must be contiguous float64 (R, N)")
+        a2 = a.view(-1, n)
+        rows_src += [a2[r] for r in range(a2.shape[0])]
+    nrow = len(rows_src)
+    if nrow > 16:
+        raise ValueError("compact: at most 16 rows per call")
+    with torch.cuda.device(dev):
+        tmp = torch.empty((max(nrow, 1), n), dtype=torch.float64, device=dev)
+        idt = torch.empty(n, dtype=torch.int64, device=dev) if ids is not None else None
+        scratch = torch.empty(lib.prt_compact_scratch_bytes(n), dtype=torch.uint8, device=dev)
+        src = (ctypes.c_void_p * max(nrow, 1))(*[r.data_ptr() for r in rows_src])
+        dst = (ctypes.c_void_p * max(nrow, 1))(*[tmp[r].data_ptr() for r in range(nrow)])
+        kept = ctypes.c_int64()
+        _lib.check(lib.prt_compact(n, _ptr(mask), nrow, src, dst, _ptr(ids), _ptr(idt),
+                                   _ptr(scratch), ctypes.byref(kept), _stream_handle(dev)))
+    m = kept.value
+    out = []
+    r0 = 0
+    for a in arrays:
+        rr = a.view(-1, n).shape[0]
+        out.append(tmp[r0:r0 + rr, :m].contiguous().view(tuple(a.shape[:-1]) + (m,)))
+        r0 += rr
+    return out, (idt[:m].contiguous() if ids is not None else None)
+
+
+def to_device_rays(a, device):
+    """numpy (3, N) real or zero-imaginary complex -> contiguous float64 device tensor."""
+    a = np.asarray(a)
+    if np.iscomplexobj(a):
+        a = a.real
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)

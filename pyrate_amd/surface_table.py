@@ -1,0 +1,294 @@
+"""
+Surface-table flattener: walks an optical system's object graph once per
+``seqtrace`` call and turns the (element, surface) sequence into the POD table
+the HIP engine consumes (``include/prt.h: prt_surface_t``).
+
+The walk is duck-typed on exactly the attributes the reference's own trace loop
+touches, so it accepts this package's host classes (``pyrate_amd.raytracer``)
+and, unchanged, real ``pyrateoptics`` objects:
+
+* sequence / material bookkeeping: ``OpticalElement.seqtrace``
+  (raytracer/optical_element.py:324-379): ``elements[key].surfaces``,
+  ``annotations["surf_mat_connection"]``, ``materials``, ``is_mirror`` option,
+  material switching by identity (``findoutWhichMaterial`` :109-126), background
+  fallback (:344-346), reset to the background medium at every element (:328).
+* frames: ``lc.localbasis`` (3x3), ``lc.globalcoordinates`` (3,)
+  (raytracer/localcoordinates.py:264-295).
+* shapes: ``kind`` in {"shape_Conic", "shape_Asphere", "shape_XYPolynomials"} with
+  ``curvature()``/``conic()``, ``getAsphereParameters()``, ``getXYParameters()``
+  (raytracer/surface_shape.py:158-206, 599-603, 849-858).
+* apertures: ``kind`` in {"aperture", "aperture_Circular", "aperture_Rectangle"} and
+  ``annotations`` (raytracer/aperture.py:34-139).
+* materials: ``get_optical_index(x, wave)`` for isotropic media
+  (material_isotropic.py:264-265, 299-309) or ``epstensor`` for
+  ``AnisotropicMaterial`` (material_anisotropic.py:48-56).
+
+The intermediate representation is a list of plain dicts (JSON-able; the same
+records the CPU oracle and the golden fixtures use); ``pack_table`` turns it into
+the ctypes array.  Everything here is per-surface scalar bookkeeping -- no ray
+data is touched on the host.
+"""
+import ctypes
+
+import numpy as np
+
+PRT_MAX_COEFFS = 40
+
+SHAPE_CODES = {"conic": 0, "asphere": 1, "xypoly": 2}
+AP_CODES = {"none": 0, "circular": 1, "rectangular": 2}
+INTERACTION_CODES = {"refract": 0, "mirror": 1}
+MAT_CODES = {"isotropic": 0, "anisotropic": 1}
+ANISO_GENERAL, ANISO_ISOTROPIC, ANISO_UNIAXIAL = 0, 1, 2
+
+FRAME_SHAPE_IDENTITY = 1
+FRAME_AP_IS_SHAPE = 2
+FRAME_MAT_IDENTITY = 4
+
+
+class PrtSurface(ctypes.Structure):
+    """ctypes mirror of ``prt_surface_t`` (include/prt.h) -- keep in sync;
+    ``prt_sizeof_surface()`` is checked at load time."""
+    _fields_ = [
+        ("shape_type", ctypes.c_int32),
+        ("n_coeffs", ctypes.c_int32),
+        ("ap_type", ctypes.c_int32),
+        ("interaction", ctypes.c_int32),
+        ("mat_type", ctypes.c_int32),
+        ("frame_flags", ctypes.c_int32),
+        ("newton_maxit", ctypes.c_int32),
+        ("aniso_class", ctypes.c_int32),
+        ("curv", ctypes.c_double),
+        ("cc", ctypes.c_double),
+        ("coeffs", ctypes.c_double * PRT_MAX_COEFFS),
+        ("xpow", ctypes.c_int32 * PRT_MAX_COEFFS),
+        ("ypow", ctypes.c_int32 * PRT_MAX_COEFFS),
+        ("B_shape", ctypes.c_double * 9),
+        ("g_shape", ctypes.c_double * 3),
+        ("B_ap", ctypes.c_double * 9),
+        ("g_ap", ctypes.c_double * 3),
+        ("ap_p0", ctypes.c_double),
+        ("ap_p1", ctypes.c_double),
+        ("B_mat", ctypes.c_double * 9),
+        ("n_after", ctypes.c_double),
+        ("eps_re", ctypes.c_double * 9),
+        ("eps_im", ctypes.c_double * 9),
+        ("aniso_eo", ctypes.c_double),
+        ("aniso_ee", ctypes.c_double),
+        ("aniso_axis", ctypes.c_double * 3),
+    ]
+
+
+class UnsupportedError(Exception):
+    """shape / aperture / material outside the engine's scope."""
+
+
+# --------------------------------------------------------------------------
+# object graph -> list of dict records
+# --------------------------------------------------------------------------
+
+def _mat33(m):
+    return [[float(v) for v in row] for row in np.asarray(m, dtype=float).reshape(3, 3)]
+
+
+def _vec3(v):
+    return [float(c) for c in np.asarray(v, dtype=float).reshape(3)]
+
+
+def describe_shape(shape):
+    kind = getattr(shape, "kind", None)
+    if kind == "shape_Conic":
+        return {"type": "conic", "curv": float(shape.curvature()), "cc": float(shape.conic())}
+    if kind == "shape_Asphere":
+        (curv, cc, acoeffs) = shape.getAsphereParameters()
+        return {"type": "asphere", "curv": float(curv), "cc": float(cc),
+                "coeffs": [float(a) for a in acoeffs]}
+    if kind == "shape_XYPolynomials":
+        (normradius, coeffs) = shape.getXYParameters()
+        return {"type": "xypoly", "normradius": float(normradius),
+                "terms": [[int(i), int(j), float(c)] for (i, j, c) in coeffs]}
+    raise UnsupportedError("shape kind %r is outside the HIP engine's scope "
+                           "(Conic, Asphere, XYPolynomials)" % (kind,))
+
+
+def describe_aperture(aperture):
+    kind = getattr(aperture, "kind", None)
+    ann = getattr(aperture, "annotations", {})
+    if kind == "aperture":
+        return {"type": "none"}
+    if kind == "aperture_Circular":
+        return {"type": "circular", "minradius": float(ann["minradius"]),
+                "maxradius": float(ann["maxradius"])}
+    if kind == "aperture_Rectangle":
+        return {"type": "rectangular", "width": float(ann["width"]),
+                "height": float(ann["height"])}
+    raise UnsupportedError("aperture kind %r not supported" % (kind,))
+
+
+def describe_material(material, wave):
+    if hasattr(material, "epstensor"):
+        eps = np.asarray(material.epstensor, dtype=complex).reshape(3, 3)
+        return {"type": "anisotropic", "eps_re": _mat33(eps.real), "eps_im": _mat33(eps.imag)}
+    if hasattr(material, "get_optical_index"):
+        n = material.get_optical_index(np.zeros((3, 1)), wave)
+        n = np.asarray(n)
+        if n.size != 1:
+            raise UnsupportedError("position dependent index (GRIN) is out of scope")
+        n = complex(n.reshape(-1)[0])
+        if n.imag != 0.0:
+            raise UnsupportedError("complex refractive index is out of scope")
+        return {"type": "isotropic", "n": float(n.real)}
+    raise UnsupportedError("material %r has neither epstensor nor get_optical_index"
+                           % (type(material).__name__,))
+
+
+def surface_record(surface, material, is_mirror, wave):
+    """One table record: ``surface`` is hit, ``material`` is the medium the ray is in
+    after the interaction (for a mirror: the medium it stays in)."""
+    return {
+        "shape": describe_shape(surface.shape),
+        "B_shape": _mat33(surface.shape.lc.localbasis),
+        "g_shape": _vec3(surface.shape.lc.globalcoordinates),
+        "aperture": describe_aperture(surface.aperture),
+        "B_ap": _mat33(surface.aperture.lc.localbasis),
+        "g_ap": _vec3(surface.aperture.lc.globalcoordinates),
+        "interaction": "mirror" if is_mirror else "refract",
+        "material": describe_material(material, wave),
+        "B_mat": _mat33(material.lc.localbasis),
+    }
+
+
+def flatten_element_sequence(element, sequence, background_medium, wave):
+    """The bookkeeping of OpticalElement.seqtrace (optical_element.py:324-379)."""
+    records = []
+    current_material = background_medium
+    for (surfkey, surfoptions) in sequence:
+        refract_flag = not surfoptions.get("is_mirror", False)
+        surface = element.surfaces[surfkey]
+        (mnkey, pnkey) = element.annotations["surf_mat_connection"][surfkey]
+        mnmat = element.materials.get(mnkey, background_medium)
+        pnmat = element.materials.get(pnkey, background_medium)
+        if refract_flag:
+            # findoutWhichMaterial: identity comparison (optical_element.py:109-126)
+            current_material = pnmat if (mnmat is current_material) else mnmat
+        records.append(surface_record(surface, current_material, not refract_flag, wave))
+    return records
+
+
+def flatten_sequence(system, elementsequence, wave):
+    """OpticalSystem.seqtrace's element loop (optical_system.py:78-92); returns
+    (records, element_lengths)."""
+    records = []
+    lengths = []
+    for (elemkey, subseq) in elementsequence:
+        recs = flatten_element_sequence(system.elements[elemkey], subseq,
+                                        system.material_background, wave)
+        records += recs
+        lengths.append(len(recs))
+    return records, lengths
+
+
+# --------------------------------------------------------------------------
+# dict records -> ctypes table
+# --------------------------------------------------------------------------
+
+def classify_eps(eps_re, eps_im, rtol=1e-12):
+    """(class, eo, ee, axis) for the anisotropic kernel (csrc/prt_aniso.h)."""
+    er = np.asarray(eps_re, dtype=float).reshape(3, 3)
+    ei = np.asarray(eps_im, dtype=float).reshape(3, 3)
+    if np.any(ei != 0.0):
+        raise UnsupportedError("complex epsilon tensor is out of scope")
+    scale = np.max(np.abs(er))
+    if scale == 0.0 or not np.allclose(er, er.T, rtol=0, atol=rtol * scale):
+        return (ANISO_GENERAL, 0.0, 0.0, [0.0, 0.0, 1.0])
+    (w, v) = np.linalg.eigh(er)
+    tol = rtol * scale
+    if abs(w[2] - w[0]) <= tol:
+        return (ANISO_ISOTROPIC, float(np.mean(w)), float(np.mean(w)), [0.0, 0.0, 1.0])
+    if abs(w[1] - w[0]) <= tol:          # w0 = w1 ordinary, w2 extraordinary
+        return (ANISO_UNIAXIAL, float(0.5 * (w[0] + w[1])), float(w[2]), [float(c) for c in v[:, 2]])
+    if abs(w[2] - w[1]) <= tol:          # w1 = w2 ordinary, w0 extraordinary
+        return (ANISO_UNIAXIAL, float(0.5 * (w[1] + w[2])), float(w[0]), [float(c) for c in v[:, 0]])
+    return (ANISO_GENERAL, 0.0, 0.0, [0.0, 0.0, 1.0])
+
+
+def _is_identity(m):
+    return bool(np.array_equal(np.asarray(m, dtype=float).reshape(3, 3), np.eye(3)))
+
+
+def pack_record(rec, out=None):
+    r = out if out is not None else PrtSurface()
+    shape = rec["shape"]
+    r.shape_type = SHAPE_CODES[shape["type"]]
+    r.newton_maxit = int(rec.get("newton_maxit", 0))
+    if shape["type"] == "conic":
+        r.curv, r.cc, r.n_coeffs = shape["curv"], shape["cc"], 0
+    elif shape["type"] == "asphere":
+        coeffs = list(shape["coeffs"])
+        while coeffs and coeffs[-1] == 0.0:
+            coeffs.pop()                          # trailing zeros do not change F
+        if len(coeffs) > PRT_MAX_COEFFS:
+            raise UnsupportedError("asphere with more than %d coefficients" % PRT_MAX_COEFFS)
+        r.curv, r.cc, r.n_coeffs = shape["curv"], shape["cc"], len(coeffs)
+        for (q, a) in enumerate(coeffs):
+            r.coeffs[q] = a
+    else:
+        terms = shape["terms"]
+        if len(terms) > PRT_MAX_COEFFS:
+            raise UnsupportedError("XY polynomial with more than %d terms" % PRT_MAX_COEFFS)
+        nr = shape["normradius"]
+        r.curv, r.cc, r.n_coeffs = 0.0, 0.0, len(terms)
+        for (q, (i, j, c)) in enumerate(terms):
+            if i < 0 or j < 0:
+                raise UnsupportedError("negative power in XY polynomial")
+            r.xpow[q], r.ypow[q] = int(i), int(j)
+            r.coeffs[q] = c * (1. / nr ** (int(i) + int(j)))   # surface_shape.py:791
+    ap = rec["aperture"]
+    r.ap_type = AP_CODES[ap["type"]]
+    if ap["type"] == "circular":
+        r.ap_p0, r.ap_p1 = ap["minradius"], ap["maxradius"]
+    elif ap["type"] == "rectangular":
+        r.ap_p0, r.ap_p1 = ap["width"], ap["height"]
+    r.interaction = INTERACTION_CODES[rec["interaction"]]
+    flags = 0
+    Bs = np.asarray(rec["B_shape"], dtype=float).reshape(3, 3)
+    Ba = np.asarray(rec["B_ap"], dtype=float).reshape(3, 3)
+    Bm = np.asarray(rec["B_mat"], dtype=float).reshape(3, 3)
+    gs = np.asarray(rec["g_shape"], dtype=float)
+    ga = np.asarray(rec["g_ap"], dtype=float)
+    if _is_identity(Bs):
+        flags |= FRAME_SHAPE_IDENTITY
+    if np.array_equal(Bs, Ba) and np.array_equal(gs, ga):
+        flags |= FRAME_AP_IS_SHAPE
+    if _is_identity(Bm):
+        flags |= FRAME_MAT_IDENTITY
+    r.frame_flags = flags
+    for q in range(9):
+        r.B_shape[q] = Bs.flat[q]
+        r.B_ap[q] = Ba.flat[q]
+        r.B_mat[q] = Bm.flat[q]
+    for q in range(3):
+        r.g_shape[q] = gs[q]
+        r.g_ap[q] = ga[q]
+    mat = rec["material"]
+    r.mat_type = MAT_CODES[mat["type"]]
+    if mat["type"] == "isotropic":
+        r.n_after = mat["n"]
+    else:
+        er = np.asarray(mat["eps_re"], dtype=float).reshape(3, 3)
+        ei = np.asarray(mat["eps_im"], dtype=float).reshape(3, 3)
+        (cls, eo, ee, axis) = classify_eps(er, ei)
+        r.aniso_class, r.aniso_eo, r.aniso_ee = cls, eo, ee
+        for q in range(3):
+            r.aniso_axis[q] = axis[q]
+        for q in range(9):
+            r.eps_re[q] = er.flat[q]
+            r.eps_im[q] = ei.flat[q]
+        r.n_after = float("nan")
+    return r
+
+
+def pack_table(records):
+    table = (PrtSurface * len(records))()
+    for (q, rec) in enumerate(records):
+        pack_record(rec, table[q])
+    return table

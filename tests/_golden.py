@@ -1,0 +1,167 @@
+"""
+Helpers shared by the parity tests: load a golden fixture (tests/golden/*.npz,
+written by oracle/make_golden.py from the real reference) and compare a DENSE
+trace (oracle or HIP engine) against the reference's compacted RayBundles.
+
+The reference removes invalid rays after every isotropic refraction
+(material_isotropic.py:194-199) and duplicates all rays at every anisotropic
+interface (material_anisotropic.py:87-100); ``RefWalker`` replays exactly that
+bookkeeping on index arrays, so every ray of every reference bundle is mapped to
+its slot in the dense arrays ("join on rayID", done positionally so that split
+rays with equal rayID stay distinguishable).
+"""
+import json
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+ISO_CASES = ["doublet", "doublet_clipped", "double_gauss_axis", "double_gauss_field5",
+             "double_gauss_wide", "double_gauss_Fline", "double_gauss_defaultE",
+             "tilted_frames", "mirrors"]
+EXPLICIT_CASES = ["asphere_mild_axis", "asphere_mild_field5", "asphere_strong_axis",
+                  "asphere_strong_field5", "xypoly_axis", "xypoly_field5"]
+ANISO_CASES = ["aniso_doublet_isoeps", "aniso_doublet_uniaxial", "aniso_doublet_biaxial"]
+ALL_CASES = ISO_CASES + EXPLICIT_CASES + ANISO_CASES
+
+
+class Case(object):
+    def __init__(self, name):
+        self.name = name
+        z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+        self.x0 = z["x0"]
+        self.k0 = z["k0"]
+        self.E0 = z["E0"]
+        self.wave = float(z["wave"])
+        self.table = json.loads(str(z["table_json"]))
+        self.npaths = int(z["npaths"])
+        self.paths = []
+        for pi in range(self.npaths if ("p1_nb" in z.files) else 1):
+            pre = "" if pi == 0 else "p%d_" % pi
+            nb = int(z[pre + "nb"])
+            self.paths.append([dict(x=z[pre + "b%d_x" % i], k=z[pre + "b%d_k" % i],
+                                    valid=z[pre + "b%d_valid" % i], id=z[pre + "b%d_id" % i])
+                               for i in range(nb)])
+        self.bundles = self.paths[0]
+
+    @property
+    def n_surfaces(self):
+        return len(self.table)
+
+
+def load_case(name):
+    return Case(name)
+
+
+def _subsequence_positions(old_x, old_id, new_x, new_id):
+    """positions i_0 < i_1 < ... in the old bundle of the rays kept in the new one
+    (the new bundle is old[:, mask]; hit points are copied bit-exactly)."""
+    pos = np.empty(new_x.shape[1], dtype=np.int64)
+    i = 0
+    n_old = old_x.shape[1]
+    for j in range(new_x.shape[1]):
+        while True:
+            assert i < n_old, "reference bundle is not a filtered copy of its predecessor"
+            same = (old_id[i] == new_id[j]) and np.array_equal(old_x[:, i], new_x[:, j], equal_nan=True)
+            i += 1
+            if same:
+                pos[j] = i - 1
+                break
+    return pos
+
+
+def compare_dense_to_reference(case, dense, rtol_x=1e-10, atol_k=1e-10, explicit_tol=None,
+                               check_valid=True):
+    """
+    dense: list over surfaces of dicts with numpy arrays
+        x_hit (3, n_in), valid (n_in,), k_out (3, n_out), valid_out (n_out,)
+    Returns dict(max_rel_x, max_abs_k, n_compared).  Raises AssertionError on a
+    validity / bookkeeping mismatch or when a tolerance is exceeded.
+
+    explicit_tol: optional callable (surface_index, x_ref (3,m), ...) -> per-ray absolute
+    tolerance on x for surfaces whose reference hit points are not converged
+    (fsolve, SURVEY.md headline 4); applied to that surface and everything after it.
+    """
+    b = case.bundles
+    S = case.n_surfaces
+    assert len(b) == S + 2, "unexpected number of reference bundles"
+    # b[0] initial, b[1] the same bundle object again (optical_element.py:330), then one per surface
+    pos = np.array(b[1]["id"], dtype=np.int64)      # reference slot -> dense slot (initial: rayID)
+    max_rel_x = 0.0
+    max_abs_k = 0.0
+    ncmp = 0
+    extra_x = None          # per reference-slot extra absolute tolerance (explicit shapes)
+    for s in range(S):
+        B = b[s + 1]
+        d = dense[s]
+        n_dense_in = d["x_hit"].shape[1]
+        xr = B["x"][-1]
+        vr = B["valid"][-1].astype(bool)
+        xd = d["x_hit"][:, pos]
+        vd = d["valid"][pos].astype(bool)
+        if explicit_tol is not None:
+            tol_s = explicit_tol(s, B, case.table[s])
+            if tol_s is not None:
+                extra_x = tol_s if extra_x is None else np.maximum(extra_x, tol_s)
+        if check_valid:
+            assert np.array_equal(vd, vr), \
+                "%s surface %d: valid mask differs for %d rays" % (case.name, s, np.sum(vd != vr))
+        cmp_mask = vr & vd
+        if np.any(cmp_mask):
+            scale = np.maximum(np.sqrt(np.sum(xr[:, cmp_mask] ** 2, axis=0)), 1e-30)
+            err = np.abs(xd[:, cmp_mask] - xr[:, cmp_mask])
+            if extra_x is not None:
+                err = np.maximum(err - extra_x[cmp_mask], 0.0)
+            rel = np.max(err / scale)
+            max_rel_x = max(max_rel_x, float(rel))
+            ncmp += int(np.sum(cmp_mask))
+        # ---- the bundle created by refract / reflect at this surface
+        Bn = b[s + 2]
+        aniso = case.table[s]["material"]["type"] == "anisotropic"
+        if aniso:
+            n_ref = B["x"].shape[2]
+            assert Bn["x"].shape[2] == 2 * n_ref
+            new_pos = np.concatenate((pos, pos + n_dense_in))
+            if extra_x is not None:
+                extra_x = np.concatenate((extra_x, extra_x))
+        else:
+            sub = _subsequence_positions(B["x"][-1], B["id"], Bn["x"][0], Bn["id"])
+            new_pos = pos[sub]
+            if check_valid:
+                kept_dense = d["valid_out"][pos].astype(bool)
+                kept_ref = np.zeros(len(pos), dtype=bool)
+                kept_ref[sub] = True
+                assert np.array_equal(kept_dense, kept_ref), \
+                    "%s surface %d: refraction validity differs" % (case.name, s)
+            if extra_x is not None:
+                extra_x = extra_x[sub]
+        kr = Bn["k"][0]
+        assert np.max(np.abs(np.imag(kr))) < 1e-9 if np.iscomplexobj(kr) else True
+        kr = np.real(kr)
+        kd = d["k_out"][:, new_pos]
+        fin = np.all(np.isfinite(kr), axis=0)
+        if np.any(fin):
+            errk = np.abs(kd[:, fin] - kr[:, fin])
+            if extra_x is not None:
+                # direction errors inherited from unconverged reference hit points
+                errk = np.maximum(errk - extra_x[fin] * 1.0, 0.0)
+            max_abs_k = max(max_abs_k, float(np.max(errk)))
+        pos = new_pos
+    assert max_rel_x <= rtol_x, "%s: hit points differ by %.3e relative" % (case.name, max_rel_x)
+    assert max_abs_k <= atol_k, "%s: wave vectors differ by %.3e" % (case.name, max_abs_k)
+    return dict(max_rel_x=max_rel_x, max_abs_k=max_abs_k, n_compared=ncmp)
+
+
+def dense_from_oracle(out):
+    return [dict(x_hit=o["x_hit"], valid=o["valid"], k_out=np.real(o["k_out"]),
+                 valid_out=o["valid_out"]) for o in out]
+
+
+def dense_from_engine(res):
+    """TraceResult (device tensors) -> list of numpy dicts."""
+    dense = []
+    for s in range(len(res.x_hit)):
+        dense.append(dict(x_hit=res.x_hit[s].cpu().numpy(), valid=res.valid[s].cpu().numpy(),
+                          k_out=res.k_out[s].cpu().numpy(), valid_out=res.valid_out[s].cpu().numpy()))
+    return dense
