@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""
+bench.py -- ray-surface-ops/s of the sequential-raytrace hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of OpticalSystem.seqtrace over one bundle: BASELINE.json
+configs[1], the 12-surface Rudolph double Gauss (12 spherical Conic surfaces,
+ConstantIndexGlass d-line indices), ~1e7 rays PER GPU (RectGrid disk raster,
+collimated on-axis), float64, full path materialised (hit point, outgoing wave
+vector and validity at every surface written to HBM).  Inputs are resident in
+HBM before the timed region.  For N > 1 the bundle of N x 1e7 rays is sharded by
+rays (weak scaling, no data-path collective) and every step ends with the
+image-plane all-gather (RCCL), issued on a side stream so that it overlaps the
+next step's trace; the timed region ends when everything has completed.
+
+metric: ray-surface-ops/s = rays x surfaces / seconds (the reference's own
+definition, demos/demo_benchmark.py:82-85).
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(n_rays, n_surfaces, with_e0=True):
+    """HBM bytes the fused path-mode march must move per launch:
+    read x0, k0 (+E0) once: 48 (+24) B/ray; write per surface x_hit 24 + k_out 24 +
+    valid 1 + valid_out 1 = 50 B/ray."""
+    return n_rays * ((72 if with_e0 else 48) + 50 * n_surfaces)
+
+
+def cpu_baseline(records, o, k, e0, target_rays=4_000_000, chunk=100_000):
+    """the CPU oracle (NumPy port of the reference algorithm, geometry only -- i.e.
+    WITHOUT the reference's SVD E-field step that is 91% of its time) on a bounded
+    sample of the same workload, single process."""
+    from oracle import seqtrace_np as oracle
+    n = min(o.shape[1], target_rays)
+    t0 = time.perf_counter()
+    done = 0
+    with np.errstate(all="ignore"):
+        while done < n:
+            hi = min(done + chunk, n)
+            oracle.trace(records, o[:, done:hi], k[:, done:hi], e0[:, done:hi])
+            done = hi
+    dt = time.perf_counter() - t0
+    # a small sample with the SVD E-field step, the reference's true cost profile
+    m = min(o.shape[1], 50_000)
+    t1 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        oracle.trace(records, o[:, :m], k[:, :m], e0[:, :m], with_efield=True)
+    dt_e = time.perf_counter() - t1
+    S = len(records)
+    return {"value": n * S / dt, "unit": "ray-surface-ops/s", "cores": 1, "kind": "port",
+            "sample": "first %d of the %d rays x %d surfaces, chunks of %d, NumPy oracle "
+                      "(geometry only), %.1f s" % (n, o.shape[1], S, chunk, dt),
+            "with_svd_efield": {"value": m * S / dt_e, "sample": "%d rays, %.1f s" % (m, dt_e)},
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rays", type=int, default=10_000_000, help="requested rays per GPU")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the image-plane all-gather")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["path", "image"], default="path")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n_gpus = world
+
+    from pyrate_amd import engine, systems, _lib
+    from pyrate_amd import distributed as pdist
+
+    records = systems.double_gauss_records()
+    S = len(records)
+    # the global bundle: n_gpus x rays, rank r traces its contiguous slice
+    (o, k, e0) = systems.double_gauss_bundle(args.rays * n_gpus)
+    n_total = o.shape[1]
+    (lo, hi) = pdist.shard_range(n_total, rank, n_gpus)
+    n_local = hi - lo
+    x0 = engine.to_device_rays(o[:, lo:hi], dev)
+    k0 = engine.to_device_rays(k[:, lo:hi], dev)
+    e0d = engine.to_device_rays(e0[:, lo:hi], dev)
+
+    sysd = engine.DeviceSystem(records, local_rank)
+    mode = _lib.MODE_PATH if args.mode == "path" else _lib.MODE_IMAGE
+    do_gather = (n_gpus > 1) and not args.no_gather
+    nbuf = 2 if do_gather else 1
+    bufs = [sysd.alloc_outputs(n_local, mode) for _ in range(nbuf)]
+    gathers = [pdist.ImagePlaneGather(n_total, dev) for _ in range(nbuf)] if do_gather else []
+    comm_stream = torch.cuda.Stream(device=dev) if do_gather else None
+    main_stream = torch.cuda.current_stream(dev)
+
+    def step(i):
+        b = bufs[i % nbuf]
+        if do_gather:
+            gathers[i % nbuf].wait()        # buffer pair i%2 is free once its last gather is done
+        sysd.trace_into(x0, k0, b, e0d)
+        if do_gather:
+            ev = torch.cuda.Event()
+            ev.record(main_stream)
+            v = sysd.views(b)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ev)
+                gathers[i % nbuf].start(v.x_hit[-1], v.k_out[-1], v.valid_out[-1])
+
+    def drain():
+        for g in gathers:
+            with torch.cuda.stream(comm_stream):
+                g.wait()
+        if comm_stream is not None:
+            comm_stream.synchronize()
+        torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    drain()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: average launch duration from HIP events on the launch stream
+    kernel_ms = sysd.trace_timed(x0, k0, bufs[0], max(args.steps, 5), e0d)
+    torch.cuda.synchronize()
+
+    ops_total = n_total * S * args.steps
+    value = ops_total / elapsed
+    if rank == 0:
+        if args.mode == "path":
+            alg = algorithmic_bytes(n_local, S)
+        else:
+            alg = n_local * (72 + 50)
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                ent = tj.get("%s_%d" % (args.mode, n_local))
+                if ent:
+                    traffic = ent["bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "ray_surface_ops_per_s", "value": value, "unit": "ray-surface-ops/s",
+            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 "
+                                   "double Gauss, ConstantIndexGlass d-line), RectGrid disk bundle, "
+                                   "BASELINE configs[1]",
+                       "rays_per_gpu": n_local, "rays_total": n_total, "surfaces": S,
+                       "mode": args.mode, "sharding": "rays" if n_gpus > 1 else "none",
+                       "image_plane_gather": ("rccl all-gather, overlapped" if do_gather else "none")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_trace_iso", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg,
+                         "bytes_per_ray_surface_op": alg / (n_local * S),
+                         "frac_at_98B_per_op_convention": (n_local * S * 98 / (kernel_ms * 1e-3) / 1e9) / HBM_PEAK_GBS},
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(records, o, k, e0)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

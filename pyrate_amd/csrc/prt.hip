@@ -627,11 +627,12 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
 int32_t prt_trace(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,
                   const double *e0_re, const double *e0_im, int32_t mode, double *x_hit,
                   double *k_out, uint8_t *valid, uint8_t *valid_out, void *stream) {
-    if (!sys || n0 < 0 || !x0 || !k0 || !x_hit || !k_out || !valid)
-        return fail(PRT_ERR_INVALID_ARG, "prt_trace: null pointer / negative count");
+    if (!sys || n0 < 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace: null system / negative count");
     if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE)
         return fail(PRT_ERR_INVALID_ARG, "prt_trace: bad mode");
-    if (n0 == 0) return PRT_OK;
+    if (n0 == 0) return PRT_OK;  // empty bundle: nothing to do (buffers may be NULL)
+    if (!x0 || !k0 || !x_hit || !k_out || !valid)
+        return fail(PRT_ERR_INVALID_ARG, "prt_trace: null pointer");
     HIP_TRY(hipSetDevice(sys->device));
     hipStream_t st = (hipStream_t)stream;
     if (!sys->all_isotropic)
@@ -683,9 +684,11 @@ int32_t prt_propagate(const prt_system_t *sys, int32_t surface, int64_t n, const
                       const double *k, const double *dir, const double *e_re, const double *e_im,
                       int32_t use_default_e, const uint8_t *valid_in, double *x_hit,
                       uint8_t *valid, void *stream) {
-    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0 || !x || (!k && !dir) || !x_hit || !valid)
-        return fail(PRT_ERR_INVALID_ARG, "prt_propagate: bad argument");
+    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0)
+        return fail(PRT_ERR_INVALID_ARG, "prt_propagate: bad system / surface / count");
     if (n == 0) return PRT_OK;
+    if (!x || (!k && !dir) || !x_hit || !valid)
+        return fail(PRT_ERR_INVALID_ARG, "prt_propagate: null pointer");
     HIP_TRY(hipSetDevice(sys->device));
     hipLaunchKernelGGL(k_propagate, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                        (hipStream_t)stream, sys->d_table + surface, n, n, x, k, dir, e_re, e_im,
@@ -697,9 +700,10 @@ int32_t prt_propagate(const prt_system_t *sys, int32_t surface, int64_t n, const
 int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const double *x_hit,
                      const double *k, const uint8_t *valid_in, double *k_out, double *dir_out,
                      double *e_out_re, double *e_out_im, uint8_t *valid_out, void *stream) {
-    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0 || !x_hit || !k || !k_out)
-        return fail(PRT_ERR_INVALID_ARG, "prt_interact: bad argument");
+    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0)
+        return fail(PRT_ERR_INVALID_ARG, "prt_interact: bad system / surface / count");
     if (n == 0) return PRT_OK;
+    if (!x_hit || !k || !k_out) return fail(PRT_ERR_INVALID_ARG, "prt_interact: null pointer");
     HIP_TRY(hipSetDevice(sys->device));
     const prt_surface_t *rec = sys->h_table + surface;
     if (rec->mat_type == PRT_MAT_ANISOTROPIC) {
@@ -718,9 +722,10 @@ int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const 
 
 int32_t prt_shape_eval(const prt_system_t *sys, int32_t surface, int64_t n, const double *x,
                        const double *y, double *sag, double *grad, void *stream) {
-    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0 || !x || !y)
-        return fail(PRT_ERR_INVALID_ARG, "prt_shape_eval: bad argument");
+    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0)
+        return fail(PRT_ERR_INVALID_ARG, "prt_shape_eval: bad system / surface / count");
     if (n == 0) return PRT_OK;
+    if (!x || !y) return fail(PRT_ERR_INVALID_ARG, "prt_shape_eval: null pointer");
     HIP_TRY(hipSetDevice(sys->device));
     hipLaunchKernelGGL(k_shape_eval, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                        (hipStream_t)stream, sys->d_table + surface, n, x, y, sag, grad);

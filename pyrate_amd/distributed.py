@@ -1,0 +1,78 @@
+"""
+Multi-GPU: rays are independent, so a bundle is sharded into
+contiguous slices of the initial (3, N) arrays, one process per GPU, and traced
+with no data-path collective.  The only exchange step is the final image-plane
+gather: every rank contributes (x_img, k_img) (6, n) float64 + valid (n) uint8
+= 49 B/ray and receives the whole image plane (RCCL all-gather over xGMI;
+``torch.distributed`` backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU
+tests).  rayIDs are implicit: rank r owns ``shard_range(N, r, world)``.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total, rank, world):
+    """contiguous, ordered, near-equal slices: [lo, hi) of rank ``rank``"""
+    base = n_total // world
+    rem = n_total % world
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def shard_sizes(n_total, world):
+    return [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+
+
+class ImagePlaneGather(object):
+    """All-gather of the image-plane arrays of a ray-sharded trace.
+
+    Buffers are allocated once for ``n_local_max`` rays per rank (shards differ by at
+    most one ray; the tail is padding).  ``start()`` packs on the caller's current
+    stream and launches the two collectives asynchronously; ``finish()`` returns
+    (x (3,N), k (3,N), valid (N,)) views in global ray order.
+    """
+
+    def __init__(self, n_total, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n_total = n_total
+        self.sizes = shard_sizes(n_total, self.world)
+        self.n_max = max(self.sizes) if self.sizes else 0
+        self.device = device
+        self.send_f = torch.zeros((6, self.n_max), dtype=torch.float64, device=device)
+        self.send_v = torch.zeros(self.n_max, dtype=torch.uint8, device=device)
+        self.recv_f = torch.empty((self.world, 6, self.n_max), dtype=torch.float64, device=device)
+        self.recv_v = torch.empty((self.world, self.n_max), dtype=torch.uint8, device=device)
+        self._work = []
+
+    def start(self, x_img, k_img, valid):
+        n = x_img.shape[1]
+        assert n == self.sizes[self.rank], "shard size mismatch"
+        self.send_f[0:3, :n].copy_(x_img, non_blocking=True)
+        self.send_f[3:6, :n].copy_(k_img, non_blocking=True)
+        self.send_v[:n].copy_(valid, non_blocking=True)
+        if self.world == 1:
+            self.recv_f[0].copy_(self.send_f, non_blocking=True)
+            self.recv_v[0].copy_(self.send_v, non_blocking=True)
+            self._work = []
+            return
+        w1 = dist.all_gather_into_tensor(self.recv_f, self.send_f, group=self.group, async_op=True)
+        w2 = dist.all_gather_into_tensor(self.recv_v, self.send_v, group=self.group, async_op=True)
+        self._work = [w1, w2]
+
+    def wait(self):
+        for w in self._work:
+            w.wait()
+        self._work = []
+
+    def finish(self):
+        self.wait()
+        if all(s == self.n_max for s in self.sizes):
+            f = self.recv_f.permute(1, 0, 2).reshape(6, self.world * self.n_max)
+            v = self.recv_v.reshape(-1)
+        else:
+            f = torch.cat([self.recv_f[r, :, :s] for (r, s) in enumerate(self.sizes)], dim=1)
+            v = torch.cat([self.recv_v[r, :s] for (r, s) in enumerate(self.sizes)])
+        return f[0:3], f[3:6], v

@@ -54,6 +54,13 @@ def load_case(name):
     return Case(name)
 
 
+def relative_scale(x):
+    """per-ray |x| for the relative error, floored at 1% of the largest |x| on the surface
+    (a chief ray through a vertex at the origin has |x| = 0)"""
+    nrm = np.sqrt(np.sum(x ** 2, axis=0))
+    return np.maximum(nrm, max(1e-2 * float(np.max(nrm, initial=0.0)), 1e-30))
+
+
 def _subsequence_positions(old_x, old_id, new_x, new_id):
     """positions i_0 < i_1 < ... in the old bundle of the rays kept in the new one
     (the new bundle is old[:, mask]; hit points are copied bit-exactly)."""
@@ -109,7 +116,7 @@ def compare_dense_to_reference(case, dense, rtol_x=1e-10, atol_k=1e-10, explicit
                 "%s surface %d: valid mask differs for %d rays" % (case.name, s, np.sum(vd != vr))
         cmp_mask = vr & vd
         if np.any(cmp_mask):
-            scale = np.maximum(np.sqrt(np.sum(xr[:, cmp_mask] ** 2, axis=0)), 1e-30)
+            scale = relative_scale(xr[:, cmp_mask])
             err = np.abs(xd[:, cmp_mask] - xr[:, cmp_mask])
             if extra_x is not None:
                 err = np.maximum(err - extra_x[cmp_mask], 0.0)

@@ -1,0 +1,238 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X): the HIP engine, called through
+the C ABI (libprt.so via ctypes), against
+  (1) the golden vectors produced by the real reference (tests/golden), and
+  (2) the CPU oracle on the same inputs,
+for every in-scope shape / aperture / material.  Tolerance from BASELINE.json:
+1e-10 relative on intersection points and direction cosines (residual-aware for
+the fsolve-based shapes, SURVEY.md headline 4).
+"""
+import numpy as np
+import pytest
+import torch
+
+import _golden
+from oracle import seqtrace_np as oracle
+from test_oracle_golden import explicit_tolerance
+
+pytestmark = pytest.mark.gpu
+
+
+def engine_trace(case, device, mode=0):
+    from pyrate_amd import engine
+    sysd = engine.DeviceSystem(case.table, device.index)
+    x0 = engine.to_device_rays(case.x0, device)
+    k0 = engine.to_device_rays(case.k0, device)
+    e = np.asarray(case.E0)
+    e_re = engine.to_device_rays(e.real, device)
+    e_im = engine.to_device_rays(e.imag, device) if np.iscomplexobj(e) else None
+    res = sysd.trace(x0, k0, e_re, e_im, mode=mode)
+    torch.cuda.synchronize()
+    return sysd, res
+
+
+@pytest.mark.parametrize("name", _golden.ISO_CASES)
+def test_hip_vs_reference_isotropic(name, gpu_device):
+    case = _golden.load_case(name)
+    (_, res) = engine_trace(case, gpu_device)
+    r = _golden.compare_dense_to_reference(case, _golden.dense_from_engine(res),
+                                           rtol_x=1e-10, atol_k=1e-10)
+    assert r["n_compared"] > 0
+    # the headroom really is ~5 digits
+    assert r["max_rel_x"] < 1e-13 and r["max_abs_k"] < 1e-13
+
+
+@pytest.mark.parametrize("name", _golden.EXPLICIT_CASES)
+def test_hip_vs_reference_explicit(name, gpu_device):
+    case = _golden.load_case(name)
+    (_, res) = engine_trace(case, gpu_device)
+    dense = _golden.dense_from_engine(res)
+    _golden.compare_dense_to_reference(case, dense, rtol_x=1e-10, atol_k=1e-10,
+                                       explicit_tol=explicit_tolerance)
+    # absolute: HIP hit points lie on the surface to 1e-13
+    for (s, rec) in enumerate(case.table):
+        if rec["shape"]["type"] == "conic":
+            continue
+        p = oracle.g2l_points(np.asarray(rec["B_shape"]), np.asarray(rec["g_shape"]), dense[s]["x_hit"])
+        resid = np.abs(p[2] - oracle.shape_sag(rec["shape"], p[0], p[1]))
+        assert np.nanmax(resid) < 1e-13
+
+
+@pytest.mark.parametrize("name", _golden.ANISO_CASES)
+def test_hip_vs_reference_anisotropic(name, gpu_device):
+    case = _golden.load_case(name)
+    (_, res) = engine_trace(case, gpu_device)
+    _golden.compare_dense_to_reference(case, _golden.dense_from_engine(res), rtol_x=1e-10, atol_k=1e-10)
+
+
+@pytest.mark.parametrize("name", _golden.ISO_CASES + _golden.EXPLICIT_CASES + _golden.ANISO_CASES)
+def test_hip_vs_oracle_dense(name, gpu_device):
+    """dense arrays, every ray (valid or not): masks identical, values within 1e-12
+    where both are finite and valid"""
+    case = _golden.load_case(name)
+    (_, res) = engine_trace(case, gpu_device)
+    dense = _golden.dense_from_engine(res)
+    out = oracle.trace(case.table, case.x0, case.k0, case.E0)
+    for s in range(case.n_surfaces):
+        assert np.array_equal(dense[s]["valid"].astype(bool), out[s]["valid"]), (name, s)
+        assert np.array_equal(dense[s]["valid_out"].astype(bool), out[s]["valid_out"]), (name, s)
+        v = out[s]["valid"]
+        xo = out[s]["x_hit"][:, v]
+        scale = _golden.relative_scale(xo)
+        assert np.max(np.abs(dense[s]["x_hit"][:, v] - xo) / scale, initial=0.0) < 1e-11
+        vo = out[s]["valid_out"] & np.all(np.isfinite(np.real(out[s]["k_out"])), axis=0)
+        assert np.max(np.abs(dense[s]["k_out"][:, vo] - np.real(out[s]["k_out"])[:, vo]), initial=0.0) < 1e-11
+
+
+@pytest.mark.parametrize("name", ["double_gauss_wide", "tilted_frames", "asphere_strong_field5"])
+def test_image_mode_matches_path_mode(name, gpu_device):
+    case = _golden.load_case(name)
+    (_, res_p) = engine_trace(case, gpu_device, mode=0)
+    (_, res_i) = engine_trace(case, gpu_device, mode=1)
+    assert len(res_i.x_hit) == 1
+    assert torch.equal(res_i.valid[0], res_p.valid[-1])
+    assert torch.equal(res_i.valid_out[0], res_p.valid_out[-1])
+    assert torch.equal(torch.nan_to_num(res_i.x_hit[0]), torch.nan_to_num(res_p.x_hit[-1]))
+    assert torch.equal(torch.nan_to_num(res_i.k_out[0]), torch.nan_to_num(res_p.k_out[-1]))
+
+
+@pytest.mark.parametrize("name", ["double_gauss_wide", "tilted_frames", "xypoly_field5", "mirrors"])
+def test_per_surface_api_matches_fused(name, gpu_device):
+    """Material.propagate / refract granularity (prt_propagate + prt_interact) reproduces
+    the fused march bit for bit where rays are valid."""
+    from pyrate_amd import engine
+    case = _golden.load_case(name)
+    (sysd, res) = engine_trace(case, gpu_device)
+    x = engine.to_device_rays(case.x0, gpu_device)
+    k = engine.to_device_rays(case.k0, gpu_device)
+    e = np.asarray(case.E0)
+    e_re = engine.to_device_rays(e.real, gpu_device)
+    e_im = engine.to_device_rays(e.imag, gpu_device) if np.iscomplexobj(e) else None
+    valid = None
+    for s in range(case.n_surfaces):
+        if s == 0:
+            (xh, v) = sysd.propagate(s, x, k, e_re=e_re, e_im=e_im, valid_in=valid)
+        else:
+            (xh, v) = sysd.propagate(s, x, k, default_e=False, valid_in=valid)
+        (k2, _d, vo, _, _) = sysd.interact(s, xh, k, valid_in=v)
+        assert torch.equal(v, res.valid[s])
+        assert torch.equal(vo, res.valid_out[s])
+        m = vo.bool()
+        assert torch.allclose(xh[:, m], res.x_hit[s][:, m], rtol=0, atol=1e-12)
+        assert torch.allclose(k2[:, m], res.k_out[s][:, m], rtol=0, atol=1e-13)
+        (x, k, valid) = (xh, k2, vo)
+
+
+def test_compaction_matches_boolean_indexing(gpu_device):
+    from pyrate_amd import engine
+    g = torch.Generator(device="cpu").manual_seed(1)
+    for n in (1, 7, 1024, 1025, 100003):
+        mask = (torch.rand(n, generator=g) > 0.37).to(torch.uint8).to(gpu_device)
+        x = torch.rand((3, n), generator=g, dtype=torch.float64).to(gpu_device)
+        k = torch.rand((3, n), generator=g, dtype=torch.float64).to(gpu_device)
+        ids = torch.arange(n, dtype=torch.int64, device=gpu_device)
+        ((xc, kc), idc) = engine.compact(mask, [x, k], ids)
+        mb = mask.bool()
+        assert torch.equal(xc, x[:, mb]) and torch.equal(kc, k[:, mb]) and torch.equal(idc, ids[mb])
+    # empty / all-false
+    mask = torch.zeros(100, dtype=torch.uint8, device=gpu_device)
+    ((xc,), _) = engine.compact(mask, [torch.ones((3, 100), dtype=torch.float64, device=gpu_device)])
+    assert xc.shape == (3, 0)
+
+
+def test_shape_eval_closed_forms(gpu_device):
+    """the closed forms the reference's own tests/test_surf_shape.py:56-353 pins
+    (Conic, Asphere A2=1e-3 A4=-1e-6 A6=1e-8 R=10 cc=-1.5, XY (0,2,1.),(4,5,-1.),(3,2,0.1))"""
+    from pyrate_amd import engine, systems
+    rng = np.random.RandomState(3)
+    xy = rng.rand(2, 10)
+    (x, y) = (xy[0], xy[1])
+    recs = systems.simple_system_records([
+        ({"shape": "Conic", "curv": 1. / 10., "cc": -1.5}, {"decz": 1.0}, None, "c", {}),
+        ({"shape": "Asphere", "curv": 1. / 10., "cc": -1.5, "coefficients": [1e-3, -1e-6, 1e-8]},
+         {"decz": 1.0}, None, "a", {}),
+        ({"shape": "XYPolynomials", "normradius": 1.0,
+          "coefficients": [(0, 2, 1.), (4, 5, -1.), (3, 2, 0.1)]}, {"decz": 1.0}, None, "p", {}),
+    ])
+    sysd = engine.DeviceSystem(recs, gpu_device.index)
+    xd = torch.from_numpy(x).to(gpu_device)
+    yd = torch.from_numpy(y).to(gpu_device)
+    (curv, cc) = (0.1, -1.5)
+    r2 = x ** 2 + y ** 2
+    # conic
+    (sag, grad) = sysd.shape_eval(0, xd, yd)
+    z = curv * r2 / (1 + np.sqrt(1 - (1 + cc) * curv ** 2 * r2))
+    assert np.allclose(sag.cpu().numpy(), z)
+    g = np.vstack((-curv * x, -curv * y, 1 - curv * (1 + cc) * z))
+    assert np.allclose(grad.cpu().numpy(), g)
+    # asphere
+    (sag, grad) = sysd.shape_eval(1, xd, yd)
+    za = z + 1e-3 * r2 - 1e-6 * r2 ** 2 + 1e-8 * r2 ** 3
+    assert np.allclose(sag.cpu().numpy(), za)
+    sq = np.sqrt(1 - curv ** 2 * (1 + cc) * r2)
+    gx = -curv * x / sq - 2 * 1e-3 * x + 4 * 1e-6 * x * r2 - 6 * 1e-8 * x * r2 ** 2
+    gy = -curv * y / sq - 2 * 1e-3 * y + 4 * 1e-6 * y * r2 - 6 * 1e-8 * y * r2 ** 2
+    assert np.allclose(grad.cpu().numpy(), np.vstack((gx, gy, np.ones_like(x))))
+    # xy polynomial
+    (sag, grad) = sysd.shape_eval(2, xd, yd)
+    zp = y ** 2 - x ** 4 * y ** 5 + 0.1 * x ** 3 * y ** 2
+    assert np.allclose(sag.cpu().numpy(), zp)
+    gpx = 4 * x ** 3 * y ** 5 - 0.3 * x ** 2 * y ** 2
+    gpy = -2 * y + 5 * x ** 4 * y ** 4 - 0.2 * x ** 3 * y
+    assert np.allclose(grad.cpu().numpy(), np.vstack((gpx, gpy, np.ones_like(x))))
+
+
+def test_odd_and_tiny_ray_counts(gpu_device):
+    """ragged sizes: N odd (scalar path), N=1, N=0, and N even (vector path) agree"""
+    from pyrate_amd import engine, systems
+    recs = systems.double_gauss_records()
+    sysd = engine.DeviceSystem(recs, gpu_device.index)
+    (o, k, e0) = systems.double_gauss_bundle(3000, field_deg=3.0)
+    n = o.shape[1] - (o.shape[1] % 2)
+    full = sysd.trace(engine.to_device_rays(o[:, :n], gpu_device), engine.to_device_rays(k[:, :n], gpu_device),
+                      engine.to_device_rays(e0[:, :n], gpu_device))
+    for m in (n - 1, 1, 2, 255, 257):
+        part = sysd.trace(engine.to_device_rays(o[:, :m], gpu_device), engine.to_device_rays(k[:, :m], gpu_device),
+                          engine.to_device_rays(e0[:, :m], gpu_device))
+        for s in range(len(recs)):
+            assert torch.equal(part.valid[s], full.valid[s][:m])
+            assert torch.allclose(part.x_hit[s], full.x_hit[s][:, :m], rtol=0, atol=1e-13)
+            assert torch.allclose(part.k_out[s], full.k_out[s][:, :m], rtol=0, atol=1e-14)
+    empty = sysd.trace(torch.empty((3, 0), dtype=torch.float64, device=gpu_device),
+                       torch.empty((3, 0), dtype=torch.float64, device=gpu_device))
+    assert empty.x_hit[0].shape == (3, 0)
+
+
+def test_full_size_properties(gpu_device):
+    """BASELINE config 2 at full size (1e7 rays, 12 surfaces): size-independent properties.
+    * |k_out| = n_after at every surface (dispersion relation) for valid rays
+    * hit points lie on their spheres
+    * a 1e4 sub-sample of the rays agrees with the CPU oracle to 1e-12
+    * mirror symmetry of the on-axis bundle: image-plane centroid ~ 0
+    """
+    from pyrate_amd import engine, systems
+    recs = systems.double_gauss_records()
+    sysd = engine.DeviceSystem(recs, gpu_device.index)
+    (o, k, e0) = systems.double_gauss_bundle(10 ** 7)
+    n = o.shape[1]
+    assert 0.99e7 < n < 1.01e7
+    res = sysd.trace(engine.to_device_rays(o, gpu_device), engine.to_device_rays(k, gpu_device),
+                     engine.to_device_rays(e0, gpu_device))
+    torch.cuda.synchronize()
+    for (s, rec) in enumerate(recs):
+        v = res.valid_out[s].bool()
+        assert bool(v.all())        # the nominal pupil passes unvignetted
+        kn = torch.sqrt((res.k_out[s] ** 2).sum(0))
+        assert float((kn - rec["material"]["n"]).abs().max()) < 1e-13
+        c = rec["shape"]["curv"]
+        p = res.x_hit[s] - torch.tensor(rec["g_shape"], dtype=torch.float64, device=gpu_device)[:, None]
+        resid = c * (p ** 2).sum(0) - 2 * p[2]      # sphere: c (x^2+y^2+z^2) - 2 z = 0
+        assert float(resid.abs().max()) < 1e-12
+    cen = res.x_hit[-1][:2].mean(1)
+    assert float(cen.abs().max()) < 1e-9
+    idx = np.linspace(0, n - 1, 10000).astype(np.int64)
+    out = oracle.trace(recs, o[:, idx], k[:, idx], e0[:, idx])
+    it = torch.from_numpy(idx).to(gpu_device)
+    for s in range(len(recs)):
+        assert np.max(np.abs(res.x_hit[s][:, it].cpu().numpy() - out[s]["x_hit"])) < 1e-11
+        assert np.max(np.abs(res.k_out[s][:, it].cpu().numpy() - out[s]["k_out"])) < 1e-12
