@@ -75,8 +75,8 @@ def cpu_baseline(records, o, k, e0, target_rays=4_000_000, chunk=100_000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=10_000_000, help="requested rays per GPU")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the image-plane all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
