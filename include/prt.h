@@ -161,7 +161,8 @@ int32_t prt_propagate(const prt_system_t *sys, int32_t surface, int64_t n, const
  *   isotropic:   k_out (3,n), valid_out (n); dir_out may be NULL.
  *   anisotropic: k_out (3,2n) in [sol2, sol3] stacking (material_anisotropic.py:87-95),
  *                dir_out (3,2n) unit Poynting directions (needed by the next propagate),
- *                e_out_re / e_out_im (3,2n) or NULL, valid_out (2n) all 1 (ray.py:68).
+ *                e_out_re / e_out_im (3,2n) or NULL, valid_out (2n) all 1 (ray.py:68;
+ *                valid_in is ignored: the reference does no validity filtering there).
  */
 int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const double *x_hit,
                      const double *k, const uint8_t *valid_in, double *k_out, double *dir_out,
@@ -172,17 +173,24 @@ int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const 
 int32_t prt_shape_eval(const prt_system_t *sys, int32_t surface, int64_t n, const double *x,
                        const double *y, double *sag, double *grad, void *stream);
 
+/* A unit E field perpendicular to k, (3,n) -> (3,n), for bundles that leave an
+ * isotropic interface (IsotropicMaterial.calc_e_field, material_isotropic.py:72-128,
+ * returns an arbitrary unit vector of that 2-d space; not on the parity contract). */
+int32_t prt_efield_perp(int32_t device, int64_t n, const double *k, double *e_out, void *stream);
+
 /*
  * Order-preserving compaction by mask (the reference's [:, valid] indexing):
- * n_arrays row pointers of n doubles each (src[r] -> dst[r]), plus optional
- * int64 ids.  *n_kept (host) receives the survivor count.  Synchronises the
+ * n_arrays (<= 16) row pointers of n doubles each (src[r] -> dst[r]; the pointer
+ * tables themselves are HOST arrays of device pointers), plus an optional int64
+ * id row and an optional uint8 row.  *n_kept (host) receives the survivor count.  Synchronises the
  * stream (the count is returned to the host).  scratch: device buffer of at
  * least prt_compact_scratch_bytes(n) bytes.
  */
 int64_t prt_compact_scratch_bytes(int64_t n);
 int32_t prt_compact(int64_t n, const uint8_t *mask, int32_t n_arrays, const double *const *src,
-                    double *const *dst, const int64_t *id_src, int64_t *id_dst, void *scratch,
-                    int64_t *n_kept, void *stream);
+                    double *const *dst, const int64_t *id_src, int64_t *id_dst,
+                    const uint8_t *u8_src, uint8_t *u8_dst, void *scratch, int64_t *n_kept,
+                    void *stream);
 
 /* Timing helper for bench.py: runs prt_trace `iters` times on `stream` between
  * two HIP events recorded on that stream and returns the average milliseconds

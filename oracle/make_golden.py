@@ -20,6 +20,7 @@ import logging
 import math
 import os
 import sys
+import types
 
 os.environ.setdefault("MPLBACKEND", "Agg")
 sys.dont_write_bytecode = True
@@ -36,6 +37,7 @@ REF = os.environ.get("PYRATE_REFERENCE", "/root/reference")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REF)
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 logging.disable(logging.CRITICAL)
 
 from pyrateoptics import build_simple_optical_system  # noqa: E402
@@ -52,6 +54,7 @@ from pyrateoptics.raytracer.surface_shape import Asphere, Conic, XYPolynomials  
 from pyrateoptics.sampling2d import raster  # noqa: E402
 
 from pyrate_amd import systems  # noqa: E402
+import systems_zoo as zoo  # noqa: E402
 from pyrate_amd.surface_table import flatten_sequence  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -59,14 +62,15 @@ DLINE = 0.5876e-3
 
 
 def dump_case(name, s, seq, bundle, splitup=False):
-    (records, _) = flatten_sequence(s, seq, bundle.wave)
+    (records, elem_lengths) = flatten_sequence(s, seq, bundle.wave)
     x0 = np.array(bundle.x[0])
     k0 = np.array(bundle.k[0])
     e0 = np.array(bundle.Efield[0])
     with np.errstate(all="ignore"):
         rpaths = s.seqtrace(bundle, seq, splitup=splitup)
     data = dict(x0=x0, k0=k0, E0=e0, wave=np.float64(bundle.wave),
-                table_json=np.array(json.dumps(records)), npaths=np.int64(len(rpaths)))
+                table_json=np.array(json.dumps(records)), npaths=np.int64(len(rpaths)),
+                elem_lengths=np.array(elem_lengths, dtype=np.int64))
     for (pi, rp) in enumerate(rpaths if splitup else rpaths[:1]):
         pre = "" if pi == 0 else "p%d_" % pi
         data[pre + "nb"] = np.int64(len(rp.raybundles))
@@ -98,34 +102,18 @@ def disk_bundle(nrays, rpup, z0, field_deg=0.0, wave=DLINE, efield="kxex", yshif
 
 
 # ---------------------------------------------------------------------------
+REFAPI = types.SimpleNamespace(
+    OpticalSystem=OpticalSystem, OpticalElement=OpticalElement, LocalCoordinates=LocalCoordinates,
+    Surface=Surface, Conic=Conic, Asphere=Asphere, XYPolynomials=XYPolynomials,
+    CircularAperture=CircularAperture, RectangularAperture=RectangularAperture,
+    ConstantIndexGlass=ConstantIndexGlass, ModelGlass=ModelGlass,
+    AnisotropicMaterial=AnisotropicMaterial, RayBundle=RayBundle,
+    build_simple_optical_system=build_simple_optical_system)
+
+
 def case_doublet():
     """demos/demo_doublet.py:48-101 built object by object, collimated_bundle (complex k, E)."""
-    s = OpticalSystem.p()
-    lc0 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="stop", decz=0.0),
-                                     refname=s.rootcoordinatesystem.name)
-    lc1 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="surf1", decz=-1.048), refname=lc0.name)
-    lc2 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="surf2", decz=4.0), refname=lc1.name)
-    lc3 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="surf3", decz=2.5), refname=lc2.name)
-    lc4 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="image", decz=97.2), refname=lc3.name)
-    stopsurf = Surface.p(lc0)
-    frontsurf = Surface.p(lc1, shape=Conic.p(lc1, curv=1. / 62.8),
-                          aperture=CircularAperture.p(lc1, maxradius=12.7))
-    cementsurf = Surface.p(lc2, shape=Conic.p(lc2, curv=-1. / 45.7),
-                           aperture=CircularAperture.p(lc2, maxradius=12.7))
-    rearsurf = Surface.p(lc3, shape=Conic.p(lc3, curv=-1. / 128.2),
-                         aperture=CircularAperture.p(lc3, maxradius=12.7))
-    image = Surface.p(lc4)
-    elem = OpticalElement.p(lc0, name="thorlabs_AC_254-100-A")
-    elem.addMaterial("BK7", ConstantIndexGlass.p(lc1, n=1.5168))
-    elem.addMaterial("SF5", ConstantIndexGlass.p(lc2, n=1.6727))
-    elem.addSurface("stop", stopsurf, (None, None))
-    elem.addSurface("front", frontsurf, (None, "BK7"))
-    elem.addSurface("cement", cementsurf, ("BK7", "SF5"))
-    elem.addSurface("rear", rearsurf, ("SF5", None))
-    elem.addSurface("image", image, (None, None))
-    s.addElement("AC254-100", elem)
-    seq = [("AC254-100", [("stop", {"is_stop": True}), ("front", {}), ("cement", {}),
-                          ("rear", {}), ("image", {})])]
+    (s, seq) = zoo.doublet(REFAPI)
     osa = OpticalSystemAnalysis(s, seq, name="Analysis")
     for (tag, radius, angle) in (("", 11.43, 0.0), ("_clipped", 14.5, 0.03)):
         (o, k, e0) = osa.collimated_bundle(300, {"startz": -5., "radius": radius, "anglex": angle},
@@ -155,120 +143,56 @@ def case_asphere():
         dump_case("asphere_%s_field5" % tag, s, seq, disk_bundle(96, 9.0, -5.0, field_deg=5.0))
 
 
-def xypoly_builduplist():
-    return [
-        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
-        ({"shape": "Conic", "curv": 1. / 80.}, {"decz": 5.0}, 1.5168, "front", {}),
-        ({"shape": "XYPolynomials", "normradius": 10.0,
-          "coefficients": [(0, 2, -0.12), (2, 0, -0.1), (2, 1, 0.01), (0, 3, -0.004),
-                           (4, 0, 0.002), (1, 1, 0.003)]},
-         {"decz": 12.0}, None, "back", {}),
-        ({"shape": "Conic"}, {"decz": 80.0}, None, "image", {}),
-    ]
-
-
 def case_xypoly():
-    (s, seq) = build_simple_optical_system(xypoly_builduplist())
+    (s, seq) = build_simple_optical_system(zoo.xypoly_builduplist())
     dump_case("xypoly_axis", s, seq, disk_bundle(96, 8.0, -5.0))
     dump_case("xypoly_field5", s, seq, disk_bundle(96, 8.0, -5.0, field_deg=5.0))
 
 
-def tilted_system():
-    """decentred / tilted frames (both tilt orders), a tilted material frame, a rectangular
-    aperture and an annular circular aperture, a ModelGlass."""
-    s = OpticalSystem.p()
-    lc0 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="obj", decz=0.0),
-                                     refname=s.rootcoordinatesystem.name)
-    lc1 = s.addLocalCoordinateSystem(
-        LocalCoordinates.p(name="s1", decz=10.0, decx=0.3, tiltx=0.05, tilty=-0.03), refname=lc0.name)
-    lc1ap = s.addLocalCoordinateSystem(
-        LocalCoordinates.p(name="s1ap", decy=0.4, tiltz=0.3), refname=lc1.name)
-    lc1m = s.addLocalCoordinateSystem(
-        LocalCoordinates.p(name="s1mat", tiltx=0.2, tiltz=-0.1), refname=lc1.name)
-    lc2 = s.addLocalCoordinateSystem(
-        LocalCoordinates.p(name="s2", decz=6.0, decy=-0.2, tiltx=-0.04, tiltz=0.1,
-                           tiltThenDecenter=1), refname=lc1.name)
-    lc3 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="img", decz=60.0, tilty=0.02),
-                                     refname=lc2.name)
-    s1 = Surface.p(lc1, shape=Conic.p(lc1, curv=1. / 40., cc=-0.5),
-                   aperture=RectangularAperture.p(lc1ap, width=11.0, height=9.0))
-    s2 = Surface.p(lc2, shape=Conic.p(lc2, curv=-1. / 55., cc=0.3),
-                   aperture=CircularAperture.p(lc2, maxradius=5.5, minradius=0.8))
-    s3 = Surface.p(lc3)
-    elem = OpticalElement.p(lc0, name="tilted")
-    elem.addMaterial("glass", ModelGlass.p(lc1m))
-    elem.addSurface("s1", s1, (None, "glass"))
-    elem.addSurface("s2", s2, ("glass", None))
-    elem.addSurface("img", s3, (None, None))
-    s.addElement("tilted", elem)
-    seq = [("tilted", [("s1", {}), ("s2", {}), ("img", {})])]
-    return (s, seq)
-
-
 def case_tilted():
-    (s, seq) = tilted_system()
+    (s, seq) = zoo.tilted(REFAPI)
     dump_case("tilted_frames", s, seq, disk_bundle(300, 6.5, -3.0, field_deg=2.0, wave=0.6563e-3))
 
 
 def case_mirror():
-    """paraboloid mirror + flat fold mirror; all rays valid (the reference's reflect crashes
-    as soon as one ray is invalid)."""
-    (s, seq) = build_simple_optical_system([
-        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
-        ({"shape": "Conic", "curv": -1. / 200., "cc": -1.0}, {"decz": 50.0}, None, "primary", {"is_mirror": True}),
-        ({"shape": "Conic"}, {"decz": -60.0, "tiltx": 0.2}, None, "fold", {"is_mirror": True}),
-        ({"shape": "Conic"}, {"decz": 30.0}, None, "image", {}),
-    ])
+    """all rays valid (the reference's reflect crashes as soon as one ray is invalid,
+    SURVEY.md section 7)."""
+    (s, seq) = build_simple_optical_system(zoo.mirrors_builduplist())
     dump_case("mirrors", s, seq, disk_bundle(128, 10.0, -5.0, field_deg=1.0))
 
 
-def aniso_doublet(eps1, eps2):
-    s = OpticalSystem.p(name='os')
-    lc0 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="stop", decz=0.0),
-                                     refname=s.rootcoordinatesystem.name)
-    lc1 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="surf1", decz=-1.048), refname=lc0.name)
-    lc2 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="surf2", decz=4.0), refname=lc1.name)
-    lc3 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="surf3", decz=2.5), refname=lc2.name)
-    lc4 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="image", decz=97.2), refname=lc3.name)
-    stopsurf = Surface.p(lc0, name="stopsurf")
-    frontsurf = Surface.p(lc1, name="frontsurf", shape=Conic.p(lc1, curv=1. / 62.8),
-                          aperture=CircularAperture.p(lc1, maxradius=12.7))
-    cementsurf = Surface.p(lc2, name="cementsurf", shape=Conic.p(lc2, curv=-1. / 45.7),
-                           aperture=CircularAperture.p(lc2, maxradius=12.7))
-    rearsurf = Surface.p(lc3, name="rearsurf", shape=Conic.p(lc3, curv=-1. / 128.2),
-                         aperture=CircularAperture.p(lc3, maxradius=12.7))
-    image = Surface.p(lc4, name="imagesurf")
-    elem = OpticalElement.p(lc0, name="thorlabs_AC_254-100-A")
-    elem.addMaterial("crystal1", AnisotropicMaterial.p(lc1, eps1, name="crystal1"))
-    elem.addMaterial("crystal2", AnisotropicMaterial.p(lc2, eps2, name="crystal2"))
-    elem.addSurface("stop", stopsurf, (None, None))
-    elem.addSurface("front", frontsurf, (None, "crystal1"))
-    elem.addSurface("cement", cementsurf, ("crystal1", "crystal2"))
-    elem.addSurface("rear", rearsurf, ("crystal2", None))
-    elem.addSurface("image", image, (None, None))
-    s.addElement("AC254-100", elem)
-    seq = [("AC254-100", [("stop", {}), ("front", {}), ("cement", {}), ("rear", {}), ("image", {})])]
-    return (s, seq)
+def case_two_elements():
+    (s, seq) = zoo.two_element_system(REFAPI)
+    dump_case("two_elements", s, seq, disk_bundle(200, 7.0, -2.0, field_deg=1.5))
+
+
+def biaxial_eps():
+    rot = LocalCoordinates.p(name="tmp", tiltx=0.4, tilty=0.25, tiltz=-0.3)
+    rot.update()
+    r = rot.localbasis
+    return r.dot(np.diag([1.55 ** 2, 1.60 ** 2, 1.68 ** 2])).dot(r.T)
 
 
 def case_aniso():
     # (i) the demo's isotropic-as-anisotropic tensors (demo_anisotropic_doublet.py:92-93)
-    (s, seq) = aniso_doublet(1.5168 ** 2 * np.eye(3), 1.6727 ** 2 * np.eye(3))
+    (s, seq) = zoo.aniso_doublet(REFAPI, 1.5168 ** 2 * np.eye(3), 1.6727 ** 2 * np.eye(3))
     dump_case("aniso_doublet_isoeps", s, seq, disk_bundle(60, 11.43, -5.0))
     # (ii) birefringent: calcite-like uniaxial, axis tilted 0.3 rad about x; second crystal
     #      uniaxial with another axis
     c = systems.CALCITE_TILTED
     eps1 = systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"])
     eps2 = systems.uniaxial_eps(1.6727, 1.60, (math.sin(0.2), 0.0, math.cos(0.2)))
-    (s, seq) = aniso_doublet(eps1, eps2)
+    (s, seq) = zoo.aniso_doublet(REFAPI, eps1, eps2)
     dump_case("aniso_doublet_uniaxial", s, seq, disk_bundle(60, 11.43, -5.0, field_deg=2.0))
     dump_case("aniso_doublet_uniaxial_split", s, seq, disk_bundle(30, 11.43, -5.0), splitup=True)
+    # rays outside the lens apertures: flagged invalid by propagate, but the anisotropic
+    # refract does no filtering and starts a fresh all-valid bundle (ray.py:68)
+    dump_case("aniso_doublet_uniaxial_clipped", s, seq, disk_bundle(60, 14.5, -5.0, field_deg=1.0))
+    # rays removed by an ISOTROPIC refraction (stop with aperture) before the crystal stay removed
+    (s, seq) = zoo.aniso_doublet(REFAPI, eps1, eps2, stop_radius=8.0)
+    dump_case("aniso_doublet_uniaxial_stopped", s, seq, disk_bundle(60, 11.43, -5.0, field_deg=1.0))
     # (iii) biaxial crystal (three different principal values, rotated)
-    rot = LocalCoordinates.p(name="tmp", tiltx=0.4, tilty=0.25, tiltz=-0.3)
-    rot.update()
-    r = rot.localbasis
-    eps3 = r.dot(np.diag([1.55 ** 2, 1.60 ** 2, 1.68 ** 2])).dot(r.T)
-    (s, seq) = aniso_doublet(eps3, 1.6727 ** 2 * np.eye(3))
+    (s, seq) = zoo.aniso_doublet(REFAPI, biaxial_eps(), 1.6727 ** 2 * np.eye(3))
     dump_case("aniso_doublet_biaxial", s, seq, disk_bundle(60, 11.43, -5.0, field_deg=-2.0))
 
 
@@ -281,6 +205,7 @@ def main():
     case_xypoly()
     case_tilted()
     case_mirror()
+    case_two_elements()
     case_aniso()
 
 

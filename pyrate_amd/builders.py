@@ -1,0 +1,78 @@
+"""Convenience builders with the reference's signatures
+(pyrateoptics/__init__.py:83-258): build_rotationally_symmetric_optical_system,
+build_simple_optical_element, build_simple_optical_system.  Materials may be None
+(background), a number (ConstantIndexGlass), a dict {"eps": 3x3}
+(AnisotropicMaterial) or a ready Material object; the refractiveindex.info catalogue
+is out of scope (SURVEY.md section 2 #7b)."""
+import numpy as np
+
+from .raytracer.globalconstants import numerical_tolerance
+from .raytracer.localcoordinates import LocalCoordinates
+from .raytracer.material.material import Material
+from .raytracer.material.material_anisotropic import AnisotropicMaterial
+from .raytracer.material.material_isotropic import ConstantIndexGlass
+from .raytracer.optical_element import OpticalElement
+from .raytracer.optical_system import OpticalSystem
+from .raytracer.surface import Surface
+from .raytracer.surface_shape import accessible_shapes
+
+
+def build_rotationally_symmetric_optical_system(builduplist, **kwargs):
+    """builduplist: [(r, cc, thickness, mat, name, optdict), ...] -> (s, stdseq)"""
+    out = []
+    for (r, cc, thickness, mat, name, optdict) in builduplist:
+        curv = 1. / r if abs(r) > numerical_tolerance else 0.
+        out.append(({"shape": "Conic", "curv": curv, "cc": cc}, {"decz": thickness}, mat, name, optdict))
+    return build_simple_optical_system(out, **kwargs)
+
+
+def build_simple_optical_element(lc0, builduplist, material_db_path="", name=""):
+    elem = OpticalElement.p(lc0, name=name)
+    refname = lc0.name
+    lastmat = None
+    surflist_for_sequence = []
+    for (surfdict, coordbreakdict, mat, surf_name, optdict) in builduplist:
+        surfdict = dict(surfdict)
+        lc = elem.addLocalCoordinateSystem(
+            LocalCoordinates.p(name=surf_name + "_lc", **coordbreakdict), refname=refname)
+        shapetype = "shape_" + surfdict.pop("shape", "Conic")
+        aperture = surfdict.pop("aperture", None)
+        if shapetype not in accessible_shapes:
+            raise Exception("shape %s is outside the HIP engine's scope" % shapetype)
+        actsurf = Surface.p(lc, name=surf_name + "_surf", aperture=aperture,
+                            shape=accessible_shapes[shapetype].p(lc, name=name + "_shape", **surfdict))
+        if mat is not None:
+            if isinstance(mat, Material):
+                key = mat.name
+                elem.addMaterial(key, mat)
+                mat = key
+            elif isinstance(mat, dict) and "eps" in mat:
+                key = "anisotropic_" + surf_name
+                elem.addMaterial(key, AnisotropicMaterial.p(lc, np.array(mat["eps"]), name=key))
+                mat = key
+            else:
+                try:
+                    n = float(mat)
+                except (ValueError, TypeError):
+                    raise Exception("glass catalogue materials (%r) are out of scope; pass an index "
+                                    "or a Material object" % (mat,))
+                mat = "constantindexglass_" + str(mat)
+                elem.addMaterial(mat, ConstantIndexGlass.p(lc, n=n))
+        elem.addSurface(surf_name, actsurf, (lastmat, mat))
+        lastmat = mat
+        refname = lc.name
+        surflist_for_sequence.append((surf_name, optdict))
+    return (elem, (name, surflist_for_sequence))
+
+
+def build_simple_optical_system(builduplist, material_db_path="", name=""):
+    """builduplist: [(surfdict, coordbreakdict, mat, name, optdict), ...] -> (s, stdseq)"""
+    s = OpticalSystem.p(name=name)
+    lc0 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="object", decz=0.0),
+                                     refname=s.rootcoordinatesystem.name)
+    elem_name = "stdelem"
+    (elem, elem_seq) = build_simple_optical_element(lc0, builduplist,
+                                                    material_db_path=material_db_path, name=elem_name)
+    s.addElement(elem_name, elem)
+    s.material_background.set_name("background")
+    return (s, [elem_seq])

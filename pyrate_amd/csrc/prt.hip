@@ -225,14 +225,19 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_interact_iso(
 
 __global__ __launch_bounds__(PRT_BLOCK) void k_interact_aniso(
     const prt_surface_t *__restrict__ sf, int64_t N, const double *__restrict__ xh_in,
-    const double *__restrict__ k_in, double *__restrict__ k_out, double *__restrict__ dir_out,
-    double *__restrict__ e_re_out, double *__restrict__ e_im_out,
-    uint8_t *__restrict__ valid_out) {
+    const double *__restrict__ k_in, const uint8_t *__restrict__ alive_in,
+    double *__restrict__ k_out, double *__restrict__ dir_out, double *__restrict__ e_re_out,
+    double *__restrict__ e_im_out, uint8_t *__restrict__ valid_out) {
     const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
     if (i >= N) return;
     const vec3 xh = v3(xh_in[i], xh_in[N + i], xh_in[2 * N + i]);
     const vec3 k = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
     const vec3 p = to_shape_frame(sf, xh);
+    // The reference's anisotropic refract does no validity filtering: every ray that is
+    // still IN the bundle gets two children in a fresh all-valid bundle (ray.py:68).
+    // In the dense representation "in the bundle" = alive_in (the mask the previous
+    // compaction used); rays compacted away earlier must stay dead.
+    const uint8_t alive = alive_in ? alive_in[i] : (uint8_t)1;
     aniso_solution sol[2];
     interact_anisotropic(sf, p, k, sol);
     const int64_t M = 2 * N;
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_interact_aniso(
             e_im_out[M + o] = sol[b].ei.y;
             e_im_out[2 * M + o] = sol[b].ei.z;
         }
-        if (valid_out) valid_out[o] = 1;  // new bundle starts all-valid (ray.py:68)
+        if (valid_out) valid_out[o] = alive;
     }
 }
 
@@ -281,6 +286,24 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_shape_eval(const prt_surface_t *_
         grad[N + i] = g.y;
         grad[2 * N + i] = g.z;
     }
+}
+
+// A unit E field perpendicular to k for bundles leaving an isotropic interface.  The
+// reference takes the singular vector of the smallest singular value of
+// -k^2 I + k k^T + n^2 I (material_isotropic.py:72-128), which is an ARBITRARY unit
+// vector of the 2-d null space {E : E.k = 0}; this picks E = unit(k x a), a = the
+// coordinate axis least aligned with k.  Not on the x/k parity contract.
+__global__ __launch_bounds__(PRT_BLOCK) void k_efield_perp(int64_t N, const double *__restrict__ k_in,
+                                                           double *__restrict__ e_out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const vec3 k = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
+    const double ax = fabs(k.x), ay = fabs(k.y), az = fabs(k.z);
+    const vec3 a = (ay <= ax && ay <= az) ? v3(0, 1, 0) : ((ax <= az) ? v3(1, 0, 0) : v3(0, 0, 1));
+    const vec3 e = normalized(cross(k, a));
+    e_out[i] = e.x;
+    e_out[N + i] = e.y;
+    e_out[2 * N + i] = e.z;
 }
 
 // ---------------------------------------------------------------------------
@@ -340,7 +363,8 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_compact_scan(int64_t *__restrict_
 __global__ __launch_bounds__(PRT_BLOCK) void k_compact_scatter(
     const uint8_t *__restrict__ mask, int64_t N, const int64_t *__restrict__ block_offs,
     int32_t n_arrays, const double *const *__restrict__ src, double *const *__restrict__ dst,
-    const int64_t *__restrict__ id_src, int64_t *__restrict__ id_dst) {
+    const int64_t *__restrict__ id_src, int64_t *__restrict__ id_dst,
+    const uint8_t *__restrict__ u8_src, uint8_t *__restrict__ u8_dst) {
     __shared__ int woff[PRT_BLOCK / 64];
     const int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_ITEMS;
     bool keep[CMP_ITEMS];
@@ -367,6 +391,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_compact_scatter(
         if (keep[q]) {
             for (int a = 0; a < n_arrays; ++a) dst[a][pos] = src[a][base + q];
             if (id_src) id_dst[pos] = id_src[base + q];
+            if (u8_src) u8_dst[pos] = u8_src[base + q];
             ++pos;
         }
     }
@@ -595,7 +620,7 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
         double *dir_dst = dirbuf[s & 1];
         if (aniso) {
             hipLaunchKernelGGL(k_interact_aniso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
-                               st, sys->d_table + s, n, xh_dst, cur_k, k_dst, dir_dst,
+                               st, sys->d_table + s, n, xh_dst, cur_k, cur_valid, k_dst, dir_dst,
                                (double *)nullptr, (double *)nullptr, vo_dst);
             cur_dir = dir_dst;
         } else {
@@ -709,8 +734,8 @@ int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const 
     if (rec->mat_type == PRT_MAT_ANISOTROPIC) {
         if (!dir_out) return fail(PRT_ERR_INVALID_ARG, "prt_interact: anisotropic needs dir_out");
         hipLaunchKernelGGL(k_interact_aniso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
-                           (hipStream_t)stream, sys->d_table + surface, n, x_hit, k, k_out,
-                           dir_out, e_out_re, e_out_im, valid_out);
+                           (hipStream_t)stream, sys->d_table + surface, n, x_hit, k,
+                           (const uint8_t *)nullptr, k_out, dir_out, e_out_re, e_out_im, valid_out);
     } else {
         hipLaunchKernelGGL(k_interact_iso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                            (hipStream_t)stream, sys->d_table + surface, n, x_hit, k, valid_in,
@@ -733,6 +758,17 @@ int32_t prt_shape_eval(const prt_system_t *sys, int32_t surface, int64_t n, cons
     return PRT_OK;
 }
 
+int32_t prt_efield_perp(int32_t device, int64_t n, const double *k, double *e_out, void *stream) {
+    if (n < 0) return fail(PRT_ERR_INVALID_ARG, "prt_efield_perp: negative count");
+    if (n == 0) return PRT_OK;
+    if (!k || !e_out) return fail(PRT_ERR_INVALID_ARG, "prt_efield_perp: null pointer");
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(k_efield_perp, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
+                       (hipStream_t)stream, n, k, e_out);
+    HIP_TRY(hipGetLastError());
+    return PRT_OK;
+}
+
 int64_t prt_compact_scratch_bytes(int64_t n) {
     if (n < 0) return 0;
     const int64_t nb = (n + CMP_TILE - 1) / CMP_TILE;
@@ -741,10 +777,11 @@ int64_t prt_compact_scratch_bytes(int64_t n) {
 }
 
 int32_t prt_compact(int64_t n, const uint8_t *mask, int32_t n_arrays, const double *const *src,
-                    double *const *dst, const int64_t *id_src, int64_t *id_dst, void *scratch,
-                    int64_t *n_kept, void *stream) {
-    if (n < 0 || !mask || n_arrays < 0 || n_arrays > 16 || (n_arrays && (!src || !dst)) ||
-        !scratch || !n_kept || (id_src && !id_dst))
+                    double *const *dst, const int64_t *id_src, int64_t *id_dst,
+                    const uint8_t *u8_src, uint8_t *u8_dst, void *scratch, int64_t *n_kept,
+                    void *stream) {
+    if (n < 0 || (n > 0 && !mask) || n_arrays < 0 || n_arrays > 16 || (n_arrays && (!src || !dst)) ||
+        (n > 0 && !scratch) || !n_kept || (id_src && !id_dst) || (u8_src && !u8_dst))
         return fail(PRT_ERR_INVALID_ARG, "prt_compact: bad argument");
     *n_kept = 0;
     if (n == 0) return PRT_OK;
@@ -761,7 +798,8 @@ int32_t prt_compact(int64_t n, const uint8_t *mask, int32_t n_arrays, const doub
     hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nb), dim3(PRT_BLOCK), 0, st, mask, n, sums);
     hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(PRT_BLOCK), 0, st, sums, nb);
     hipLaunchKernelGGL(k_compact_scatter, dim3((unsigned)nb), dim3(PRT_BLOCK), 0, st, mask, n, sums,
-                       n_arrays, (const double *const *)d_src, (double *const *)d_dst, id_src, id_dst);
+                       n_arrays, (const double *const *)d_src, (double *const *)d_dst, id_src, id_dst,
+                       u8_src, u8_dst);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(n_kept, sums + nb, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -58,8 +58,10 @@ class ImagePlaneGather(object):
             self.recv_v[0].copy_(self.send_v, non_blocking=True)
             self._work = []
             return
-        w1 = dist.all_gather_into_tensor(self.recv_f, self.send_f, group=self.group, async_op=True)
-        w2 = dist.all_gather_into_tensor(self.recv_v, self.send_v, group=self.group, async_op=True)
+        w1 = dist.all_gather_into_tensor(self.recv_f.view(-1), self.send_f.view(-1),
+                                          group=self.group, async_op=True)
+        w2 = dist.all_gather_into_tensor(self.recv_v.view(-1), self.send_v.view(-1),
+                                          group=self.group, async_op=True)
         self._work = [w1, w2]
 
     def wait(self):

@@ -194,10 +194,11 @@ class DeviceSystem(object):
         return sag, grad
 
 
-def compact(mask, arrays, ids=None):
+def compact(mask, arrays, ids=None, flags=None):
     """Order-preserving ``[:, mask]`` on the device (material_isotropic.py:194-199).
-    arrays: list of (R_i, N) float64 tensors; ids: optional (N,) int64.
-    Returns (list of compacted tensors, compacted ids or None)."""
+    arrays: list of (R_i, N) float64 tensors; ids: optional (N,) int64; flags: optional
+    (N,) uint8.  Returns (list of compacted tensors, compacted ids or None) and, when
+    ``flags`` is given, a third element with the compacted flags."""
     lib = _lib.load()
     n = mask.shape[0]
     dev = mask.device
@@ -213,12 +214,14 @@ def compact(mask, arrays, ids=None):
     with torch.cuda.device(dev):
         tmp = torch.empty((max(nrow, 1), n), dtype=torch.float64, device=dev)
         idt = torch.empty(n, dtype=torch.int64, device=dev) if ids is not None else None
+        flt = torch.empty(n, dtype=torch.uint8, device=dev) if flags is not None else None
         scratch = torch.empty(lib.prt_compact_scratch_bytes(n), dtype=torch.uint8, device=dev)
         src = (ctypes.c_void_p * max(nrow, 1))(*[r.data_ptr() for r in rows_src])
         dst = (ctypes.c_void_p * max(nrow, 1))(*[tmp[r].data_ptr() for r in range(nrow)])
         kept = ctypes.c_int64()
         _lib.check(lib.prt_compact(n, _ptr(mask), nrow, src, dst, _ptr(ids), _ptr(idt),
-                                   _ptr(scratch), ctypes.byref(kept), _stream_handle(dev)))
+                                   _ptr(flags), _ptr(flt), _ptr(scratch), ctypes.byref(kept),
+                                   _stream_handle(dev)))
     m = kept.value
     out = []
     r0 = 0
@@ -226,7 +229,21 @@ def compact(mask, arrays, ids=None):
         rr = a.view(-1, n).shape[0]
         out.append(tmp[r0:r0 + rr, :m].contiguous().view(tuple(a.shape[:-1]) + (m,)))
         r0 += rr
-    return out, (idt[:m].contiguous() if ids is not None else None)
+    idc = idt[:m].contiguous() if ids is not None else None
+    if flags is not None:
+        return out, idc, flt[:m].contiguous()
+    return out, idc
+
+
+def efield_perp(k):
+    """a unit E field perpendicular to k on the device (prt_efield_perp)."""
+    lib = _lib.load()
+    _check_rays(k, "k")
+    with torch.cuda.device(k.device):
+        e = torch.empty_like(k)
+        _lib.check(lib.prt_efield_perp(k.device.index, k.shape[1], _ptr(k), _ptr(e),
+                                       _stream_handle(k.device)))
+    return e
 
 
 def to_device_rays(a, device):

@@ -1,0 +1,54 @@
+"""Small LRU of device-resident surface tables keyed by their JSON form, so that the
+plugin-granular calls (Shape.intersect, Material.refract, ...) and repeated seqtrace
+calls of an optimiser loop do not re-upload identical tables."""
+import json
+from collections import OrderedDict
+
+from .. import engine
+from ..surface_table import surface_record
+
+_CACHE = OrderedDict()
+_MAX = 32
+
+
+def system_for(records, device):
+    key = (json.dumps(records, sort_keys=True), device.index)
+    sysd = _CACHE.get(key)
+    if sysd is None:
+        sysd = engine.DeviceSystem(records, device.index)
+        _CACHE[key] = sysd
+        while len(_CACHE) > _MAX:
+            (_, old) = _CACHE.popitem(last=False)
+            old.close()
+    else:
+        _CACHE.move_to_end(key)
+    return sysd
+
+
+def clear():
+    while _CACHE:
+        (_, old) = _CACHE.popitem()
+        old.close()
+
+
+class _NoAperture(object):
+    kind = "aperture"
+    annotations = {}
+
+    def __init__(self, lc):
+        self.lc = lc
+
+
+class _SurfaceView(object):
+    """a (shape, aperture) pair seen as a surface by surface_record"""
+
+    def __init__(self, shape, aperture):
+        self.shape = shape
+        self.aperture = aperture
+
+
+def single_surface_system(shape, aperture, material, mirror, wave, device):
+    """one-record table for plugin-granular calls; aperture None = no vignetting"""
+    ap = aperture if aperture is not None else _NoAperture(shape.lc)
+    rec = surface_record(_SurfaceView(shape, ap), material, mirror, wave)
+    return system_for([rec], device)

@@ -1,0 +1,164 @@
+"""
+Frame tree: decenter + tilts -> ``localbasis`` (3x3) and ``globalcoordinates`` (3,).
+Mirrors ``LocalCoordinates`` of the reference (raytracer/localcoordinates.py:38-435):
+same constructor keywords, same tilt conventions (:178-187, :238-295), same
+transform method names.  The tree update runs on the host once per system change;
+the per-ray 3x3 mat-vecs of the trace are done by the HIP kernels from the
+flattened ``localbasis`` / ``globalcoordinates``.
+"""
+import math
+import uuid
+
+import numpy as np
+
+from .variables import FloatVariable, Named
+
+
+def rodrigues(angle, axis):
+    """rotation matrix about a unit axis (helpers_math.py:69-83)"""
+    a = np.asarray(axis, dtype=float)
+    m = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + math.sin(angle) * m + (1. - math.cos(angle)) * np.dot(m, m)
+
+
+class LocalCoordinates(Named):
+    kind = "localcoordinates"
+
+    def __init__(self, name="", decx=0.0, decy=0.0, decz=0.0, tiltx=0.0, tilty=0.0, tiltz=0.0,
+                 tiltThenDecenter=0):
+        Named.__init__(self, name)
+        self.decx = FloatVariable(decx, "decx")
+        self.decy = FloatVariable(decy, "decy")
+        self.decz = FloatVariable(decz, "decz")
+        self.tiltx = FloatVariable(tiltx, "tiltx")
+        self.tilty = FloatVariable(tilty, "tilty")
+        self.tiltz = FloatVariable(tiltz, "tiltz")
+        self.annotations["tiltThenDecenter"] = tiltThenDecenter
+        self.parent = None
+        self._children = []
+        self._observers = []
+        self.globalcoordinates = np.zeros(3)
+        self.localdecenter = np.zeros(3)
+        self.localrotation = np.eye(3)
+        self.localbasis = np.eye(3)
+        self.update()
+
+    @classmethod
+    def p(cls, name="", **kwargs):
+        """decx, decy, decz, tiltx, tilty, tiltz (radians), tiltThenDecenter (0: decenter then
+        tilt x, y, z; 1: tilt z, y, x then decenter) -- localcoordinates.py:44-103"""
+        allowed = ("decx", "decy", "decz", "tiltx", "tilty", "tiltz", "tiltThenDecenter")
+        return cls(name=name, **{k: v for (k, v) in kwargs.items() if k in allowed})
+
+    # -- tree -------------------------------------------------------------
+    @property
+    def children(self):
+        return self._children
+
+    def addChild(self, childlc):
+        childlc.parent = self
+        childlc.update()
+        self._children.append(childlc)
+        return childlc
+
+    def addChildToReference(self, refname, childlc):
+        if self.name == refname:
+            self.addChild(childlc)
+        else:
+            for ch in self._children:
+                ch.addChildToReference(refname, childlc)
+        return childlc
+
+    def returnConnectedNames(self):
+        lst = [self.name]
+        for ch in self._children:
+            lst = lst + ch.returnConnectedNames()
+        return lst
+
+    def returnConnectedChildren(self):
+        lst = [self]
+        for ch in self._children:
+            lst = lst + ch.returnConnectedChildren()
+        return lst
+
+    def append_observers(self, observers):
+        self._observers += list(observers)
+
+    # -- geometry ---------------------------------------------------------
+    def calculateMatrixFromTilt(self, tiltx, tilty, tiltz, tiltThenDecenter=0):
+        rx = rodrigues(tiltx, [1, 0, 0])
+        ry = rodrigues(tilty, [0, 1, 0])
+        rz = rodrigues(tiltz, [0, 0, 1])
+        if tiltThenDecenter == 0:
+            return np.dot(rz, np.dot(ry, rx))
+        return np.dot(rx, np.dot(ry, rz))
+
+    def calculate(self):
+        self.localdecenter = np.array([self.decx(), self.decy(), self.decz()])
+        self.localrotation = self.calculateMatrixFromTilt(
+            self.tiltx(), self.tilty(), self.tiltz(), self.annotations["tiltThenDecenter"])
+
+    def update(self):
+        """localcoordinates.py:264-307"""
+        self.calculate()
+        parentcoordinates = np.zeros(3)
+        parentbasis = np.eye(3)
+        if self.parent is not None:
+            parentcoordinates = self.parent.globalcoordinates
+            parentbasis = self.parent.localbasis
+        self.localbasis = np.dot(parentbasis, self.localrotation)
+        if self.annotations["tiltThenDecenter"] == 0:
+            self.globalcoordinates = parentcoordinates + np.dot(parentbasis, self.localdecenter)
+        else:
+            self.globalcoordinates = parentcoordinates + np.dot(self.localbasis, self.localdecenter)
+        for ch in self._children:
+            ch.update()
+        for obs in self._observers:
+            obs.inform_about_update()
+
+    # -- transforms (host, small arrays; localcoordinates.py:354-413) --------
+    def returnLocalToGlobalPoints(self, localpts):
+        return (np.dot(self.localbasis, localpts).T + self.globalcoordinates).T
+
+    def returnLocalToGlobalDirections(self, localdirs):
+        return np.dot(self.localbasis, localdirs)
+
+    def returnGlobalToLocalPoints(self, globalpts):
+        return np.dot(self.localbasis.T, (np.asarray(globalpts).T - self.globalcoordinates).T)
+
+    def returnGlobalToLocalDirections(self, globaldirs):
+        return np.dot(self.localbasis.T, globaldirs)
+
+    def returnActualToOtherPoints(self, localpts, lcother):
+        return lcother.returnGlobalToLocalPoints(self.returnLocalToGlobalPoints(localpts))
+
+    def returnOtherToActualPoints(self, otherpts, lcother):
+        return self.returnGlobalToLocalPoints(lcother.returnLocalToGlobalPoints(otherpts))
+
+    def returnActualToOtherDirections(self, localdirs, lcother):
+        return lcother.returnGlobalToLocalDirections(self.returnLocalToGlobalDirections(localdirs))
+
+    def returnOtherToActualDirections(self, otherdirs, lcother):
+        return self.returnGlobalToLocalDirections(lcother.returnLocalToGlobalDirections(otherdirs))
+
+
+class LocalCoordinatesTreeBase(Named):
+    """raytracer/localcoordinatestreebase.py:31-88"""
+    kind = "localcoordinatestreebase"
+
+    def __init__(self, rootcoordinatesystem, name=""):
+        Named.__init__(self, name)
+        self.rootcoordinatesystem = rootcoordinatesystem
+
+    def checkForRootConnection(self, lc):
+        return any(lc is c for c in self.rootcoordinatesystem.returnConnectedChildren())
+
+    def addLocalCoordinateSystem(self, lc, refname):
+        allnames = self.rootcoordinatesystem.returnConnectedNames()
+        if lc.name in allnames:
+            lc.name = str(uuid.uuid4())       # name already taken: choose a new one (:75-77)
+        if refname not in allnames:
+            refname = self.rootcoordinatesystem.name
+        self.rootcoordinatesystem.addChildToReference(refname, lc)
+        self.rootcoordinatesystem.update()
+        return lc

@@ -1,0 +1,308 @@
+"""
+``RayBundle`` / ``RayPath`` with the reference's data contract (raytracer/ray.py:34-260):
+``x (P,3,N) f64``, ``k (P,3,N) f64|c128``, ``Efield (P,3,N)``, ``valid (P,N) bool``,
+``rayID (N,)``, ``wave``, ``splitted`` -- but the arrays live on the GPU.  NumPy views in
+the reference shapes are produced lazily on attribute access (one D2H copy, cached), so
+a 1e7-ray path does not cross PCIe unless somebody looks at it.  Bundles returned by
+``OpticalSystem.seqtrace`` are additionally *lazily compacted*: the engine keeps dense
+arrays + masks, and the reference's ``[:, valid]`` compaction
+(material_isotropic.py:194-199) runs on the device (prt_compact) the first time a bundle
+is touched.
+"""
+import numpy as np
+import torch
+
+from .. import engine
+from .globalconstants import standard_wavelength
+
+_DEFAULT_DEVICE = [None]
+
+
+def set_default_device(device):
+    """GPU used for bundles created from NumPy arrays (default cuda:current)."""
+    _DEFAULT_DEVICE[0] = torch.device(device) if device is not None else None
+
+
+def default_device():
+    if _DEFAULT_DEVICE[0] is not None:
+        return _DEFAULT_DEVICE[0]
+    if not torch.cuda.is_available():
+        raise RuntimeError("pyrate_amd: no HIP device visible; RayBundle data lives on the GPU "
+                           "and the engine has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_dev(a, device):
+    """(3,N) numpy / tensor (real or complex) -> (re, im) contiguous float64 device tensors;
+    im is None for real input or an all-zero imaginary part."""
+    if isinstance(a, torch.Tensor):
+        if a.is_complex():
+            re = a.real.to(device=device, dtype=torch.float64).contiguous()
+            im = a.imag.to(device=device, dtype=torch.float64).contiguous()
+            return re, (im if bool((im != 0).any()) else None), True
+        return a.to(device=device, dtype=torch.float64).contiguous(), None, False
+    a = np.asarray(a)
+    if np.iscomplexobj(a):
+        re = torch.from_numpy(np.ascontiguousarray(a.real, dtype=np.float64)).to(device)
+        im = None
+        if np.any(a.imag != 0):
+            im = torch.from_numpy(np.ascontiguousarray(a.imag, dtype=np.float64)).to(device)
+        return re, im, True
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device), None, False
+
+
+class RayBundle(object):
+    def __init__(self, x0, k0, Efield0, rayID=None, wave=standard_wavelength, splitted=False,
+                 device=None):
+        """
+        :param x0: (3, N) start points, global coordinates (numpy or device tensor)
+        :param k0: (3, N) wave vectors, global coordinates, |k| = refractive index
+        :param Efield0: (3, N) polarisation (may be complex) or None -> E = ey (ray.py:71-73)
+        :param rayID: (N,) ints or None -> arange
+        :param wave: wavelength [mm]
+        """
+        self.splitted = splitted
+        self.wave = wave
+        self._thunk = None
+        dev = device
+        if dev is None:
+            dev = x0.device if (isinstance(x0, torch.Tensor) and x0.is_cuda) else default_device()
+        self.device = dev
+        (xr, xi, _) = _to_dev(x0, dev)
+        if xi is not None:
+            raise ValueError("complex ray positions are not supported")
+        (kr, ki, kcomplex) = _to_dev(k0, dev)
+        if ki is not None:
+            raise NotImplementedError("complex wave vectors (absorbing media) are out of scope")
+        if xr.dim() != 2 or xr.shape[0] != 3 or kr.shape != xr.shape:
+            raise ValueError("x0 and k0 must both be (3, N)")
+        self._k_complex = kcomplex           # round-trip the caller's dtype
+        numray = xr.shape[1]
+        self._x = [xr]
+        self._k = [kr]
+        self._valid = [torch.ones(numray, dtype=torch.uint8, device=dev)]
+        if Efield0 is None or len(Efield0) == 0:
+            self._e = [None]                  # E = (0,1,0): handled inside the kernels
+            self._e_default = True
+        else:
+            (er, ei, _) = _to_dev(Efield0, dev)
+            self._e = [(er, ei)]
+            self._e_default = False
+        self._dir = None                      # explicit unit directions for the next propagate
+        self._dir_from_k = False              # bundle left an isotropic interface: d = k/|k|
+        if rayID is None or len(rayID) == 0:
+            self._ray_id = None
+            self._n = numray
+        else:
+            self._ray_id = np.asarray(rayID)
+            self._n = numray
+        self._cache = {}
+
+    # -- lazy materialisation ------------------------------------------------
+    def _ensure(self):
+        if self._thunk is not None:
+            thunk = self._thunk
+            self._thunk = None
+            thunk(self)
+
+    @classmethod
+    def _lazy(cls, thunk, wave, device, splitted=False):
+        self = cls.__new__(cls)
+        self.splitted = splitted
+        self.wave = wave
+        self.device = device
+        self._thunk = thunk
+        self._cache = {}
+        self._k_complex = False
+        self._e_default = False
+        self._dir = None
+        self._dir_from_k = True
+        return self
+
+    @classmethod
+    def _from_device(cls, x_list, k_list, valid_list, ray_id, wave, device, e_list=None,
+                     direction=None, dir_from_k=True, k_complex=False, splitted=False):
+        self = cls.__new__(cls)
+        self.splitted = splitted
+        self.wave = wave
+        self.device = device
+        self._thunk = None
+        self._cache = {}
+        self._x = list(x_list)
+        self._k = list(k_list)
+        self._valid = list(valid_list)
+        self._e = list(e_list) if e_list is not None else [None] * len(self._x)
+        self._e_default = False
+        self._dir = direction
+        self._dir_from_k = dir_from_k
+        self._k_complex = k_complex
+        self._ray_id = ray_id
+        self._n = self._x[0].shape[1]
+        return self
+
+    # -- reference-shaped NumPy views ------------------------------------------
+    def _stack(self, key, tensors):
+        if key not in self._cache:
+            self._cache[key] = np.stack([t.cpu().numpy() for t in tensors])
+        return self._cache[key]
+
+    @property
+    def x(self):
+        self._ensure()
+        return self._stack("x", self._x)
+
+    @property
+    def k(self):
+        self._ensure()
+        k = self._stack("k", self._k)
+        if self._k_complex:
+            if "kc" not in self._cache:
+                self._cache["kc"] = k.astype(complex)
+            return self._cache["kc"]
+        return k
+
+    @property
+    def valid(self):
+        self._ensure()
+        if "valid" not in self._cache:
+            self._cache["valid"] = np.stack([v.cpu().numpy().astype(bool) for v in self._valid])
+        return self._cache["valid"]
+
+    @property
+    def Efield(self):
+        """(P,3,N).  For points created by the engine behind an isotropic interface this is
+        *a* unit vector perpendicular to k (prt_efield_perp) -- the reference's is an equally
+        arbitrary null vector (material_isotropic.py:72-128)."""
+        self._ensure()
+        if "E" not in self._cache:
+            out = []
+            for (i, e) in enumerate(self._e):
+                if e is None:
+                    if self._e_default:
+                        a = np.zeros((3, self.num_rays))
+                        a[1, :] = 1.
+                    else:
+                        a = engine.efield_perp(self._k[i]).cpu().numpy()
+                else:
+                    a = e[0].cpu().numpy()
+                    if e[1] is not None:
+                        a = a + 1j * e[1].cpu().numpy()
+                out.append(a)
+            self._cache["E"] = np.stack(out)
+        return self._cache["E"]
+
+    @property
+    def rayID(self):
+        self._ensure()
+        if self._ray_id is None:
+            self._ray_id = np.arange(self._n)
+        elif isinstance(self._ray_id, torch.Tensor):
+            self._ray_id = self._ray_id.cpu().numpy()
+        return self._ray_id
+
+    @rayID.setter
+    def rayID(self, value):
+        self._ray_id = value
+
+    @property
+    def num_rays(self):
+        self._ensure()
+        return self._x[0].shape[1]
+
+    # -- device accessors (no PCIe traffic) ---------------------------------------
+    def x_dev(self, num=-1):
+        self._ensure()
+        return self._x[num]
+
+    def k_dev(self, num=-1):
+        self._ensure()
+        return self._k[num]
+
+    def valid_dev(self, num=-1):
+        self._ensure()
+        return self._valid[num]
+
+    # -- reference API -------------------------------------------------------------
+    def newshape(self, shape2d):
+        return tuple([1] + list(shape2d))
+
+    def append(self, xnew, knew, Enew, Validnew):
+        """append one point; validity is cumulative (ray.py:83-105)"""
+        self._ensure()
+        dev = self.device
+        (xr, _, _) = _to_dev(xnew, dev)
+        if knew is None:
+            kr = self._k[-1]
+        else:
+            (kr, _, _) = _to_dev(knew, dev)
+        if isinstance(Validnew, torch.Tensor):
+            v = Validnew.to(device=dev, dtype=torch.uint8)
+        else:
+            v = torch.from_numpy(np.asarray(Validnew).astype(np.uint8)).to(dev)
+        self._x.append(xr)
+        self._k.append(kr)
+        self._valid.append(self._valid[-1] * v)
+        if Enew is None:
+            self._e.append(self._e[-1])
+        else:
+            (er, ei, _) = _to_dev(Enew, dev)
+            self._e.append((er, ei))
+        self._cache = {}
+
+    def _append_device(self, x_hit, valid_cumulative):
+        """engine-side append after a propagate: k and E stay, valid already cumulative"""
+        self._x.append(x_hit)
+        self._k.append(self._k[-1])
+        self._valid.append(valid_cumulative)
+        self._e.append(self._e[-1])
+        self._cache = {}
+
+    def clone(self):
+        """independent bundle object sharing the (immutable) device arrays (ray.py:107-115)"""
+        self._ensure()
+        other = RayBundle.__new__(RayBundle)
+        other.__dict__.update(self.__dict__)
+        other._x = list(self._x)
+        other._k = list(self._k)
+        other._valid = list(self._valid)
+        other._e = list(self._e)
+        other._cache = {}
+        return other
+
+    def __deepcopy__(self, memo):
+        return self.clone()
+
+    def returnKtoD(self):
+        """unit Poynting directions for all points, (P,3,N) (ray.py:136-152); evaluated on
+        the host from the NumPy views -- a convenience for callers, the trace itself
+        computes directions inside the kernels."""
+        k = np.asarray(self.k)
+        E = np.asarray(self.Efield)
+        absE2 = np.sum(np.conj(E) * E, axis=1, keepdims=True)
+        Ek = np.sum(E * k, axis=1, keepdims=True)
+        S = np.real(absE2 * k - Ek * np.conj(E))
+        return S / np.sqrt(np.sum(S ** 2, axis=1, keepdims=True))
+
+
+class RayPath(object):
+    """list of RayBundles (ray.py:207-260)"""
+
+    def __init__(self, initialraybundle=None):
+        self.raybundles = [] if initialraybundle is None else [initialraybundle]
+
+    def appendRayBundle(self, raybundle):
+        self.raybundles.append(raybundle)
+
+    def appendRayPath(self, raypath):
+        self.raybundles += raypath.raybundles
+
+    def containsSplitted(self):
+        return any([r.splitted for r in self.raybundles])
+
+    def clone(self):
+        other = RayPath()
+        other.raybundles = [rb.clone() for rb in self.raybundles]
+        return other
+
+    def __deepcopy__(self, memo):
+        return self.clone()

@@ -1,0 +1,37 @@
+"""
+Scalar parameter holder with the accessors the reference's trace loop uses on its
+``FloatOptimizableVariable`` (core/optimizable_variable.py:289-306): ``var()``,
+``var.evaluate()``, ``var.set_value(v)``.  The optimiser state machine (fixed /
+variable / pickup) is host bookkeeping outside the hot path.
+"""
+import uuid
+
+
+class FloatVariable(object):
+    def __init__(self, value, name=""):
+        self._value = float(value)
+        self.name = name
+
+    def evaluate(self):
+        return self._value
+
+    def __call__(self):
+        return self._value
+
+    def set_value(self, value):
+        self._value = float(value)
+
+    def __repr__(self):
+        return "FloatVariable(%r, name=%r)" % (self._value, self.name)
+
+
+class Named(object):
+    """name + kind + annotations, like core/base.py:31-89 gives every reference object"""
+    kind = "object"
+
+    def __init__(self, name=""):
+        self.name = name if name != "" else str(uuid.uuid4())
+        self.annotations = {}
+
+    def set_name(self, name):
+        self.name = name

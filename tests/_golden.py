@@ -19,10 +19,11 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 ISO_CASES = ["doublet", "doublet_clipped", "double_gauss_axis", "double_gauss_field5",
              "double_gauss_wide", "double_gauss_Fline", "double_gauss_defaultE",
-             "tilted_frames", "mirrors"]
+             "tilted_frames", "mirrors", "two_elements"]
 EXPLICIT_CASES = ["asphere_mild_axis", "asphere_mild_field5", "asphere_strong_axis",
                   "asphere_strong_field5", "xypoly_axis", "xypoly_field5"]
-ANISO_CASES = ["aniso_doublet_isoeps", "aniso_doublet_uniaxial", "aniso_doublet_biaxial"]
+ANISO_CASES = ["aniso_doublet_isoeps", "aniso_doublet_uniaxial", "aniso_doublet_biaxial",
+               "aniso_doublet_uniaxial_clipped", "aniso_doublet_uniaxial_stopped"]
 ALL_CASES = ISO_CASES + EXPLICIT_CASES + ANISO_CASES
 
 
@@ -43,7 +44,25 @@ class Case(object):
             self.paths.append([dict(x=z[pre + "b%d_x" % i], k=z[pre + "b%d_k" % i],
                                     valid=z[pre + "b%d_valid" % i], id=z[pre + "b%d_id" % i])
                                for i in range(nb)])
+        self.elem_lengths = [int(v) for v in z["elem_lengths"]]
+        self.raw_bundles = self.paths[0]
+        # canonical list [b0, b0, b1, ..., bS]: drop the duplicates the reference inserts at
+        # every further element boundary (optical_element.py:330 + ray.py:218-219)
+        self.paths = [self._drop_boundary_duplicates(p) for p in self.paths]
         self.bundles = self.paths[0]
+
+    def _drop_boundary_duplicates(self, bundles):
+        keep = []
+        pos = 0
+        for (e, L) in enumerate(self.elem_lengths):
+            # layout per element: [duplicate of current bundle] + L new bundles
+            if e == 0:
+                keep += [pos, pos + 1]
+            pos += 1
+            keep += list(range(pos + 1, pos + 1 + L))
+            pos += L
+        assert pos + 1 == len(bundles), (pos, len(bundles))
+        return [bundles[i] for i in keep]
 
     @property
     def n_surfaces(self):

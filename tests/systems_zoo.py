@@ -1,0 +1,176 @@
+"""
+The optical systems + bundles of the golden cases, written ONCE against an ``api``
+namespace so that the very same construction code runs against
+  * the real reference (oracle/make_golden.py, api = pyrateoptics classes) and
+  * this repo's host mirror (tests, api = pyrate_amd classes).
+"""
+import math
+import types
+
+import numpy as np
+
+DLINE = 0.5876e-3
+
+
+def mirror_api():
+    from pyrate_amd import builders
+    from pyrate_amd.raytracer import aperture, localcoordinates, optical_element, optical_system, ray, \
+        surface, surface_shape
+    from pyrate_amd.raytracer.material import material_anisotropic, material_isotropic
+    return types.SimpleNamespace(
+        OpticalSystem=optical_system.OpticalSystem, OpticalElement=optical_element.OpticalElement,
+        LocalCoordinates=localcoordinates.LocalCoordinates, Surface=surface.Surface,
+        Conic=surface_shape.Conic, Asphere=surface_shape.Asphere, XYPolynomials=surface_shape.XYPolynomials,
+        CircularAperture=aperture.CircularAperture, RectangularAperture=aperture.RectangularAperture,
+        ConstantIndexGlass=material_isotropic.ConstantIndexGlass, ModelGlass=material_isotropic.ModelGlass,
+        AnisotropicMaterial=material_anisotropic.AnisotropicMaterial, RayBundle=ray.RayBundle,
+        build_simple_optical_system=builders.build_simple_optical_system,
+        build_rotationally_symmetric_optical_system=builders.build_rotationally_symmetric_optical_system)
+
+
+def rect_grid(nray):
+    """RectGrid.getGrid (sampling2d/raster.py:40-60)"""
+    n_per_dim = int(round(math.sqrt(nray * 4.0 / math.pi)))
+    dx = 1. / n_per_dim
+    x1d = np.linspace(-1 + .25 * dx, 1 - .25 * dx, n_per_dim)
+    (xpup, ypup) = np.meshgrid(x1d, x1d)
+    xpup = np.reshape(xpup, n_per_dim ** 2)
+    ypup = np.reshape(ypup, n_per_dim ** 2)
+    ind = (xpup ** 2 + ypup ** 2) <= 1
+    return (xpup[ind], ypup[ind])
+
+
+def disk_bundle_arrays(nrays, rpup, z0, field_deg=0.0, efield="kxex"):
+    (px, py) = rect_grid(nrays)
+    field = field_deg * math.pi / 180.
+    starty = z0 * math.tan(field)
+    o = np.vstack((rpup * px, rpup * py + starty, z0 * np.ones_like(px)))
+    k = np.zeros_like(o)
+    k[1, :] = math.sin(field)
+    k[2, :] = math.cos(field)
+    e0 = np.cross(k, np.array([1., 0., 0.]), axisa=0, axisb=0).T if efield == "kxex" else None
+    return (o, k, e0)
+
+
+def doublet(api, mat1=None, mat2=None, stop_radius=None):
+    """demos/demo_doublet.py:48-101 / demo_anisotropic_doublet.py:55-121, object by object.
+    mat1 / mat2: callables lc -> Material (default BK7 / SF5 constant-index glasses)."""
+    s = api.OpticalSystem.p(name='os')
+    lc0 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="stop", decz=0.0),
+                                     refname=s.rootcoordinatesystem.name)
+    lc1 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="surf1", decz=-1.048), refname=lc0.name)
+    lc2 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="surf2", decz=4.0), refname=lc1.name)
+    lc3 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="surf3", decz=2.5), refname=lc2.name)
+    lc4 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="image", decz=97.2), refname=lc3.name)
+    stopsurf = api.Surface.p(lc0, name="stopsurf",
+                             aperture=(api.CircularAperture.p(lc0, maxradius=stop_radius)
+                                       if stop_radius else None))
+    frontsurf = api.Surface.p(lc1, name="frontsurf", shape=api.Conic.p(lc1, curv=1. / 62.8),
+                              aperture=api.CircularAperture.p(lc1, maxradius=12.7))
+    cementsurf = api.Surface.p(lc2, name="cementsurf", shape=api.Conic.p(lc2, curv=-1. / 45.7),
+                               aperture=api.CircularAperture.p(lc2, maxradius=12.7))
+    rearsurf = api.Surface.p(lc3, name="rearsurf", shape=api.Conic.p(lc3, curv=-1. / 128.2),
+                             aperture=api.CircularAperture.p(lc3, maxradius=12.7))
+    image = api.Surface.p(lc4, name="imagesurf")
+    elem = api.OpticalElement.p(lc0, name="thorlabs_AC_254-100-A")
+    m1 = mat1(lc1) if mat1 else api.ConstantIndexGlass.p(lc1, n=1.5168)
+    m2 = mat2(lc2) if mat2 else api.ConstantIndexGlass.p(lc2, n=1.6727)
+    elem.addMaterial("mat1", m1)
+    elem.addMaterial("mat2", m2)
+    elem.addSurface("stop", stopsurf, (None, None))
+    elem.addSurface("front", frontsurf, (None, "mat1"))
+    elem.addSurface("cement", cementsurf, ("mat1", "mat2"))
+    elem.addSurface("rear", rearsurf, ("mat2", None))
+    elem.addSurface("image", image, (None, None))
+    s.addElement("AC254-100", elem)
+    seq = [("AC254-100", [("stop", {"is_stop": True}), ("front", {}), ("cement", {}),
+                          ("rear", {}), ("image", {})])]
+    return (s, seq)
+
+
+def aniso_doublet(api, eps1, eps2, stop_radius=None):
+    return doublet(api, lambda lc: api.AnisotropicMaterial.p(lc, eps1, name="crystal1"),
+                   lambda lc: api.AnisotropicMaterial.p(lc, eps2, name="crystal2"), stop_radius)
+
+
+def tilted(api):
+    """decentred / tilted frames (both tilt orders), a tilted material frame, a rectangular
+    aperture in its own rotated frame, an annular circular aperture, a ModelGlass."""
+    s = api.OpticalSystem.p()
+    lc0 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="obj", decz=0.0),
+                                     refname=s.rootcoordinatesystem.name)
+    lc1 = s.addLocalCoordinateSystem(
+        api.LocalCoordinates.p(name="s1", decz=10.0, decx=0.3, tiltx=0.05, tilty=-0.03), refname=lc0.name)
+    lc1ap = s.addLocalCoordinateSystem(
+        api.LocalCoordinates.p(name="s1ap", decy=0.4, tiltz=0.3), refname=lc1.name)
+    lc1m = s.addLocalCoordinateSystem(
+        api.LocalCoordinates.p(name="s1mat", tiltx=0.2, tiltz=-0.1), refname=lc1.name)
+    lc2 = s.addLocalCoordinateSystem(
+        api.LocalCoordinates.p(name="s2", decz=6.0, decy=-0.2, tiltx=-0.04, tiltz=0.1,
+                               tiltThenDecenter=1), refname=lc1.name)
+    lc3 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="img", decz=60.0, tilty=0.02),
+                                     refname=lc2.name)
+    s1 = api.Surface.p(lc1, shape=api.Conic.p(lc1, curv=1. / 40., cc=-0.5),
+                       aperture=api.RectangularAperture.p(lc1ap, width=11.0, height=9.0))
+    s2 = api.Surface.p(lc2, shape=api.Conic.p(lc2, curv=-1. / 55., cc=0.3),
+                       aperture=api.CircularAperture.p(lc2, maxradius=5.5, minradius=0.8))
+    s3 = api.Surface.p(lc3)
+    elem = api.OpticalElement.p(lc0, name="tilted")
+    elem.addMaterial("glass", api.ModelGlass.p(lc1m))
+    elem.addSurface("s1", s1, (None, "glass"))
+    elem.addSurface("s2", s2, ("glass", None))
+    elem.addSurface("img", s3, (None, None))
+    s.addElement("tilted", elem)
+    seq = [("tilted", [("s1", {}), ("s2", {}), ("img", {})])]
+    return (s, seq)
+
+
+def xypoly_builduplist():
+    return [
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
+        ({"shape": "Conic", "curv": 1. / 80.}, {"decz": 5.0}, 1.5168, "front", {}),
+        ({"shape": "XYPolynomials", "normradius": 10.0,
+          "coefficients": [(0, 2, -0.12), (2, 0, -0.1), (2, 1, 0.01), (0, 3, -0.004),
+                           (4, 0, 0.002), (1, 1, 0.003)]},
+         {"decz": 12.0}, None, "back", {}),
+        ({"shape": "Conic"}, {"decz": 80.0}, None, "image", {}),
+    ]
+
+
+def mirrors_builduplist():
+    """paraboloid mirror + tilted flat fold mirror"""
+    return [
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
+        ({"shape": "Conic", "curv": -1. / 200., "cc": -1.0}, {"decz": 50.0}, None, "primary", {"is_mirror": True}),
+        ({"shape": "Conic"}, {"decz": -60.0, "tiltx": 0.2}, None, "fold", {"is_mirror": True}),
+        ({"shape": "Conic"}, {"decz": 30.0}, None, "image", {}),
+    ]
+
+
+def two_element_system(api):
+    """two OpticalElements in one system: exercises the element loop of
+    OpticalSystem.seqtrace (bundle duplicated at the element boundary, material reset to
+    the background at every element)"""
+    s = api.OpticalSystem.p()
+    lc0 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="obj", decz=0.0),
+                                     refname=s.rootcoordinatesystem.name)
+    lcs = []
+    ref = lc0.name
+    for (i, dz) in enumerate((5.0, 4.0, 10.0, 3.0, 60.0)):
+        lc = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="l%d" % i, decz=dz), refname=ref)
+        lcs.append(lc)
+        ref = lc.name
+    e1 = api.OpticalElement.p(lc0, name="e1")
+    e1.addMaterial("g", api.ConstantIndexGlass.p(lcs[0], n=1.6))
+    e1.addSurface("a", api.Surface.p(lcs[0], shape=api.Conic.p(lcs[0], curv=1. / 30.)), (None, "g"))
+    e1.addSurface("b", api.Surface.p(lcs[1], shape=api.Conic.p(lcs[1], curv=-1. / 45.),
+                                     aperture=api.CircularAperture.p(lcs[1], maxradius=6.0)), ("g", None))
+    e2 = api.OpticalElement.p(lc0, name="e2")
+    e2.addMaterial("h", api.ConstantIndexGlass.p(lcs[2], n=1.5))
+    e2.addSurface("c", api.Surface.p(lcs[2], shape=api.Conic.p(lcs[2], curv=1. / 50., cc=-0.8)), (None, "h"))
+    e2.addSurface("d", api.Surface.p(lcs[3]), ("h", None))
+    e2.addSurface("img", api.Surface.p(lcs[4]), (None, None))
+    s.addElement("e1", e1)
+    s.addElement("e2", e2)
+    seq = [("e1", [("a", {}), ("b", {})]), ("e2", [("c", {}), ("d", {}), ("img", {})])]
+    return (s, seq)

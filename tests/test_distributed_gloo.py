@@ -1,0 +1,73 @@
+"""world_size-2 ``gloo`` tests (CPU) of the multi-GPU path: ray sharding and the
+image-plane all-gather reassembly in global ray order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pyrate_amd import distributed as pdist
+
+
+def test_shard_ranges_partition_the_bundle():
+    for n in (0, 1, 7, 8, 1000, 9994476):
+        for world in (1, 2, 3, 8):
+            spans = [pdist.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b) in zip(spans[:-1], spans[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for (lo, hi) in spans]
+            assert max(sizes) - min(sizes) <= 1
+            assert sizes == pdist.shard_sizes(n, world)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.RandomState(123)
+        x = rng.rand(3, n_total)
+        k = rng.rand(3, n_total)
+        v = (rng.rand(n_total) > 0.3).astype(np.uint8)
+        (lo, hi) = pdist.shard_range(n_total, rank, world)
+        g = pdist.ImagePlaneGather(n_total, torch.device("cpu"))
+        g.start(torch.from_numpy(x[:, lo:hi].copy()), torch.from_numpy(k[:, lo:hi].copy()),
+                torch.from_numpy(v[lo:hi].copy()))
+        (gx, gk, gv) = g.finish()
+        ok = bool(np.array_equal(gx.numpy(), x) and np.array_equal(gk.numpy(), k)
+                  and np.array_equal(gv.numpy(), v))
+        # second round re-uses the buffers
+        g.start(torch.from_numpy(2 * x[:, lo:hi]), torch.from_numpy(k[:, lo:hi].copy()),
+                torch.from_numpy(v[lo:hi].copy()))
+        (gx, _, _) = g.finish()
+        ok = ok and bool(np.array_equal(gx.numpy(), 2 * x))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [1000, 1001])
+def test_image_plane_gather_world2_gloo(n_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]

@@ -1,0 +1,178 @@
+"""
+GPU tests of the drop-in layer: systems built with the host mirror classes
+(pyrate_amd.raytracer.*, same construction code as the reference run, tests/systems_zoo.py)
+and traced through ``OpticalSystem.seqtrace`` must return the reference's RayPath
+structure -- number of bundles (incl. the duplicated one per element), (P,3,N) shapes,
+compaction, rayID, valid -- with x and k inside the parity tolerance.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import _golden
+import systems_zoo as zoo
+from pyrate_amd import systems
+from test_oracle_golden import explicit_tolerance
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api(gpu_device):
+    return zoo.mirror_api()
+
+
+def bundle_of(api, case):
+    return api.RayBundle(x0=case.x0, k0=case.k0, Efield0=case.E0, wave=case.wave)
+
+
+def assert_paths_match(path, ref_bundles, rtol_x=1e-10, atol_k=1e-10, loose_x=None):
+    assert len(path.raybundles) == len(ref_bundles)
+    for (i, (rb, ref)) in enumerate(zip(path.raybundles, ref_bundles)):
+        assert rb.x.shape == ref["x"].shape, (i, rb.x.shape, ref["x"].shape)
+        assert rb.k.shape == ref["k"].shape
+        assert rb.valid.shape == ref["valid"].shape and rb.valid.dtype == bool
+        assert np.array_equal(rb.rayID, ref["id"]), i
+        assert np.array_equal(rb.valid, ref["valid"].astype(bool)), i
+        assert rb.Efield.shape == ref["x"].shape
+        for p in range(ref["x"].shape[0]):
+            v = ref["valid"][p].astype(bool)
+            if not v.any():
+                continue
+            xr = ref["x"][p][:, v]
+            err = np.abs(rb.x[p][:, v] - xr)
+            tol = rtol_x * _golden.relative_scale(xr)
+            if loose_x is not None:
+                tol = tol + loose_x
+            assert np.all(err <= tol), (i, p, float(err.max()))
+            kr = np.real(ref["k"][p][:, v])
+            fin = np.all(np.isfinite(kr), axis=0)
+            ek = np.abs(np.real(rb.k[p][:, v])[:, fin] - kr[:, fin])
+            assert np.all(ek <= atol_k + (loose_x if loose_x is not None else 0.0)), (i, p, float(ek.max()))
+
+
+def test_seqtrace_doublet_structure_and_values(api):
+    case = _golden.load_case("doublet_clipped")
+    (s, seq) = zoo.doublet(api)
+    ib = bundle_of(api, case)
+    rpaths = s.seqtrace(ib, seq)
+    assert len(rpaths) == 1
+    assert_paths_match(rpaths[0], case.raw_bundles)
+    # complex k in (collimated_bundle) -> complex k out, like the reference
+    assert np.iscomplexobj(case.k0) and np.iscomplexobj(rpaths[0].raybundles[-1].k)
+    # the initial bundle is not modified (optical_system.py:74)
+    assert ib.x.shape[0] == 1
+    # README-style access pattern
+    x_img = rpaths[0].raybundles[-1].x[-1, 0, :]
+    assert x_img.shape[0] == case.raw_bundles[-1]["x"].shape[2]
+
+
+@pytest.mark.parametrize("name,builder", [
+    ("double_gauss_wide", lambda api: api.build_rotationally_symmetric_optical_system(systems.double_gauss_tuples())),
+    ("double_gauss_defaultE", lambda api: api.build_rotationally_symmetric_optical_system(systems.double_gauss_tuples())),
+    ("tilted_frames", lambda api: zoo.tilted(api)),
+    ("mirrors", lambda api: api.build_simple_optical_system(zoo.mirrors_builduplist())),
+    ("two_elements", lambda api: zoo.two_element_system(api)),
+])
+def test_seqtrace_isotropic_cases(api, name, builder):
+    case = _golden.load_case(name)
+    (s, seq) = builder(api)
+    e0 = None if name == "double_gauss_defaultE" else case.E0
+    ib = api.RayBundle(x0=case.x0, k0=case.k0, Efield0=e0, wave=case.wave)
+    rpaths = s.seqtrace(ib, seq)
+    assert_paths_match(rpaths[0], case.raw_bundles)
+
+
+def test_seqtrace_explicit_shape(api):
+    case = _golden.load_case("xypoly_field5")
+    (s, seq) = api.build_simple_optical_system(zoo.xypoly_builduplist())
+    rpaths = s.seqtrace(bundle_of(api, case), seq)
+    # reference hit points carry the fsolve residual (SURVEY.md headline 4): loose absolute tolerance
+    assert_paths_match(rpaths[0], case.raw_bundles, loose_x=1e-9)
+
+
+def test_plugin_granular_path_matches_fused(api):
+    """OpticalElement.seqtrace (Material.propagate / refract per surface + device compaction)
+    gives the same RayPath as the fused launch"""
+    case = _golden.load_case("double_gauss_wide")
+    (s, seq) = api.build_rotationally_symmetric_optical_system(systems.double_gauss_tuples())
+    fused = s.seqtrace(bundle_of(api, case), seq)[0]
+    generic = s._seqtrace_generic(bundle_of(api, case), seq, False)[0]
+    assert_paths_match(generic, case.raw_bundles)
+    for (a, b) in zip(fused.raybundles, generic.raybundles):
+        assert np.array_equal(a.rayID, b.rayID)
+        assert np.allclose(a.x, b.x, rtol=0, atol=1e-12, equal_nan=True)
+
+
+def aniso_system(api, which, stop_radius=None):
+    if which == "isoeps":
+        return zoo.aniso_doublet(api, 1.5168 ** 2 * np.eye(3), 1.6727 ** 2 * np.eye(3))
+    c = systems.CALCITE_TILTED
+    eps1 = systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"])
+    eps2 = systems.uniaxial_eps(1.6727, 1.60, (math.sin(0.2), 0.0, math.cos(0.2)))
+    return zoo.aniso_doublet(api, eps1, eps2, stop_radius)
+
+
+@pytest.mark.parametrize("name,which,stop", [("aniso_doublet_isoeps", "isoeps", None),
+                                             ("aniso_doublet_uniaxial", "uni", None),
+                                             ("aniso_doublet_uniaxial_clipped", "uni", None),
+                                             ("aniso_doublet_uniaxial_stopped", "uni", 8.0)])
+def test_seqtrace_anisotropic(api, name, which, stop):
+    case = _golden.load_case(name)
+    (s, seq) = aniso_system(api, which, stop)
+    rpaths = s.seqtrace(bundle_of(api, case), seq)
+    assert len(rpaths) == 1
+    assert rpaths[0].containsSplitted()
+    assert_paths_match(rpaths[0], case.raw_bundles)
+    # E of the crystal bundles solves the wave equation: (eps - k^2 + k k^T) E = 0
+    rb = rpaths[0].raybundles[3]
+    eps = np.asarray(case.table[1]["material"]["eps_re"])
+    (k, E) = (np.real(rb.k[0]), np.real(rb.Efield[0]))
+    res = eps.dot(E) - np.sum(k * k, axis=0) * E + k * np.sum(k * E, axis=0)
+    assert np.nanmax(np.abs(res)) < 1e-12
+
+
+def test_seqtrace_anisotropic_splitup_forks_four_paths(api):
+    case = _golden.load_case("aniso_doublet_uniaxial_split")
+    (s, seq) = aniso_system(api, "uni")
+    rpaths = s.seqtrace(bundle_of(api, case), seq, splitup=True)
+    assert len(rpaths) == case.npaths == 4
+    for (rp, ref) in zip(rpaths, [z for z in _raw_paths(case)]):
+        assert_paths_match(rp, ref)
+
+
+def _raw_paths(case):
+    import os
+    z = np.load(os.path.join(_golden.GOLDEN_DIR, case.name + ".npz"))
+    out = []
+    for pi in range(case.npaths):
+        pre = "" if pi == 0 else "p%d_" % pi
+        nb = int(z[pre + "nb"])
+        out.append([dict(x=z[pre + "b%d_x" % i], k=z[pre + "b%d_k" % i],
+                         valid=z[pre + "b%d_valid" % i], id=z[pre + "b%d_id" % i]) for i in range(nb)])
+    return out
+
+
+def test_surface_and_shape_plugin_calls(api):
+    """Shape.intersect, Surface.intersect(remove_rays_outside_aperture), getSag/getGrad/getNormal"""
+    lc = api.LocalCoordinates.p(name="lc", decz=3.0)
+    shape = api.Conic.p(lc, curv=1. / 20., cc=-0.3)
+    surf = api.Surface.p(lc, shape=shape, aperture=api.CircularAperture.p(lc, maxradius=2.0))
+    (o, k, _) = zoo.disk_bundle_arrays(200, 4.0, 0.0)
+    b1 = api.RayBundle(o, k, None)
+    surf.intersect(b1)
+    b2 = api.RayBundle(o, k, None)
+    surf.intersect(b2, remove_rays_outside_aperture=False)
+    b3 = api.RayBundle(o, k, None)
+    shape.intersect(b3)
+    assert b1.x.shape == (2, 3, o.shape[1])
+    r2 = b1.x[1, 0] ** 2 + b1.x[1, 1] ** 2
+    assert np.array_equal(b1.valid[1], r2 <= 4.0)
+    assert b2.valid[1].all() and np.array_equal(b2.x, b3.x)
+    z = shape.getSag(b1.x[1, 0], b1.x[1, 1])
+    assert np.allclose(z, b1.x[1, 2] - 3.0, rtol=0, atol=1e-13)
+    n = shape.getNormal(b1.x[1, 0], b1.x[1, 1])
+    assert np.allclose(np.sum(n * n, axis=0), 1.0)
+    g = shape.getGrad(np.array([0.5]), np.array([-0.25]))
+    assert g.shape == (3, 1)

@@ -1,0 +1,190 @@
+"""CPU-only tests of the host side: the mirror classes flatten to the same surface
+tables as the real reference objects (tables stored in the golden fixtures), table
+packing, the C ABI exports every symbol of include/prt.h, frame arithmetic."""
+import ctypes
+import json
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _golden
+import systems_zoo as zoo
+from pyrate_amd import surface_table as st
+from pyrate_amd import systems
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _flatten(s, seq, wave):
+    return st.flatten_sequence(s, seq, wave)
+
+
+def _assert_tables_equal(a, b):
+    assert len(a) == len(b)
+    for (ra, rb) in zip(a, b):
+        assert json.dumps(ra, sort_keys=True) == json.dumps(rb, sort_keys=True)
+
+
+@pytest.fixture(scope="module")
+def api():
+    return zoo.mirror_api()
+
+
+def test_mirror_doublet_table_equals_reference(api):
+    (s, seq) = zoo.doublet(api)
+    (recs, lengths) = _flatten(s, seq, zoo.DLINE)
+    _assert_tables_equal(recs, _golden.load_case("doublet").table)
+    assert lengths == [5]
+
+
+def test_mirror_double_gauss_table_equals_reference(api):
+    (s, seq) = api.build_rotationally_symmetric_optical_system(systems.double_gauss_tuples())
+    _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("double_gauss_axis").table)
+    _assert_tables_equal(systems.double_gauss_records(), _golden.load_case("double_gauss_axis").table)
+    (s, seq) = api.build_rotationally_symmetric_optical_system(systems.double_gauss_tuples(486.1e-6))
+    _assert_tables_equal(_flatten(s, seq, 486.1e-6)[0], _golden.load_case("double_gauss_Fline").table)
+
+
+def test_mirror_tilted_frames_table_equals_reference(api):
+    """tilt conventions, both tilt orders, ModelGlass dispersion at the C line"""
+    (s, seq) = zoo.tilted(api)
+    ref = _golden.load_case("tilted_frames")
+    (recs, _) = _flatten(s, seq, ref.wave)
+    for (a, b) in zip(recs, ref.table):
+        for key in ("B_shape", "g_shape", "B_ap", "g_ap", "B_mat"):
+            assert np.allclose(np.asarray(a[key]), np.asarray(b[key]), rtol=0, atol=1e-15), key
+        assert a["aperture"] == b["aperture"] and a["shape"] == b["shape"]
+        assert a["material"]["n"] == pytest.approx(b["material"]["n"], rel=1e-15)
+
+
+def test_mirror_explicit_and_mirror_tables(api):
+    (s, seq) = api.build_simple_optical_system(systems.asphere_builduplist([1e-3, -1e-6, 1e-8], -1. / 30., -1.5))
+    _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("asphere_strong_axis").table)
+    (s, seq) = api.build_simple_optical_system(zoo.xypoly_builduplist())
+    _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("xypoly_axis").table)
+    (s, seq) = api.build_simple_optical_system(zoo.mirrors_builduplist())
+    ref = _golden.load_case("mirrors").table
+    recs = _flatten(s, seq, zoo.DLINE)[0]
+    assert [r["interaction"] for r in recs] == [r["interaction"] for r in ref] == \
+        ["refract", "mirror", "mirror", "refract"]
+    for (a, b) in zip(recs, ref):
+        assert np.allclose(np.asarray(a["B_shape"]), np.asarray(b["B_shape"]), rtol=0, atol=1e-15)
+        assert np.allclose(np.asarray(a["g_shape"]), np.asarray(b["g_shape"]), rtol=0, atol=1e-13)
+
+
+def test_mirror_two_elements_and_aniso_tables(api):
+    (s, seq) = zoo.two_element_system(api)
+    (recs, lengths) = _flatten(s, seq, zoo.DLINE)
+    _assert_tables_equal(recs, _golden.load_case("two_elements").table)
+    assert lengths == [2, 3]
+    c = systems.CALCITE_TILTED
+    eps1 = systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"])
+    eps2 = systems.uniaxial_eps(1.6727, 1.60, (math.sin(0.2), 0.0, math.cos(0.2)))
+    (s, seq) = zoo.aniso_doublet(api, eps1, eps2)
+    _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("aniso_doublet_uniaxial").table)
+    _assert_tables_equal(systems.aniso_doublet_records(eps1, eps2), _golden.load_case("aniso_doublet_uniaxial").table)
+
+
+def test_structural_errors_raise_like_the_reference(api):
+    s = api.OpticalSystem.p()
+    lc_loose = api.LocalCoordinates.p(name="loose")
+    elem = api.OpticalElement.p(lc_loose, name="e")
+    with pytest.raises(Exception):
+        s.addElement("e", elem)                   # optical_system.py:224-227
+    lc0 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="a"), refname=s.rootcoordinatesystem.name)
+    elem = api.OpticalElement.p(lc0, name="e")
+    with pytest.raises(Exception):
+        elem.addSurface("x", api.Surface.p(lc_loose), (None, None))      # optical_element.py:73-76
+    with pytest.raises(Exception):
+        elem.addMaterial("m", api.ConstantIndexGlass.p(lc_loose, 1.5))   # :104-107
+    with pytest.raises(Exception):
+        api.Surface.p(lc0, shape=api.Conic.p(lc_loose))                  # surface.py:105-108
+
+
+def test_unsupported_shapes_are_rejected():
+    class Biconic(object):
+        kind = "shape_Biconic"
+    with pytest.raises(st.UnsupportedError):
+        st.describe_shape(Biconic())
+
+
+def test_pack_table_flags_and_coefficients():
+    recs = _golden.load_case("tilted_frames").table
+    tab = st.pack_table(recs)
+    assert tab[0].frame_flags == 0                       # tilted shape, own aperture frame, tilted material
+    assert tab[0].ap_type == 2 and tab[1].ap_type == 1 and tab[2].ap_type == 0
+    assert tab[1].ap_p0 == 0.8 and tab[1].ap_p1 == 5.5
+    assert tab[2].frame_flags & st.FRAME_AP_IS_SHAPE
+    recs = _golden.load_case("double_gauss_axis").table
+    tab = st.pack_table(recs)
+    assert all(t.frame_flags == 7 for t in tab)
+    recs = _golden.load_case("xypoly_axis").table
+    tab = st.pack_table(recs)
+    assert tab[2].shape_type == 2 and tab[2].n_coeffs == 6
+    assert tab[2].coeffs[0] == -0.12 * (1. / 10.0 ** 2) and (tab[2].xpow[0], tab[2].ypow[0]) == (0, 2)
+    recs = _golden.load_case("asphere_mild_axis").table
+    tab = st.pack_table(recs)
+    assert tab[2].shape_type == 1 and tab[2].n_coeffs == 3 and tab[2].coeffs[1] == 1e-7
+
+
+def test_classify_eps():
+    assert st.classify_eps(2.25 * np.eye(3), np.zeros((3, 3)))[0] == st.ANISO_ISOTROPIC
+    eps = systems.uniaxial_eps(1.658, 1.486, (0.0, math.sin(0.3), math.cos(0.3)))
+    (cls, eo, ee, axis) = st.classify_eps(eps, np.zeros((3, 3)))
+    assert cls == st.ANISO_UNIAXIAL
+    assert eo == pytest.approx(1.658 ** 2, rel=1e-14) and ee == pytest.approx(1.486 ** 2, rel=1e-14)
+    assert abs(abs(np.dot(axis, [0.0, math.sin(0.3), math.cos(0.3)])) - 1) < 1e-14
+    rec = np.diag([2.4, 2.56, 2.8])
+    assert st.classify_eps(rec, np.zeros((3, 3)))[0] == st.ANISO_GENERAL
+    with pytest.raises(st.UnsupportedError):
+        st.classify_eps(np.eye(3), 0.1 * np.eye(3))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libprt.so loads without a GPU and exports exactly what include/prt.h declares"""
+    from pyrate_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "prt.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(prt_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.PROTOTYPES.keys())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.prt_abi_version() == 1
+    assert lib.prt_sizeof_surface() == ctypes.sizeof(st.PrtSurface)
+    assert lib.prt_strerror(-2) == b"unsupported shape/material"
+    # argument validation happens before any device work
+    assert lib.prt_system_create(None, 0, 0, None) == -1
+    assert lib.prt_trace(None, 0, None, None, None, None, 0, None, None, None, None, None) == -1
+    assert lib.prt_compact_scratch_bytes(0) > 0
+
+
+def test_localcoordinates_roundtrips(api):
+    """the properties reference tests/test_localcoordinates.py:63-214 pins"""
+    rng = np.random.RandomState(0)
+    root = api.LocalCoordinates.p(name="root")
+    lc1 = root.addChild(api.LocalCoordinates.p(name="a", decx=0.3, decy=-1.0, decz=5.0,
+                                               tiltx=0.2, tilty=-0.4, tiltz=1.1))
+    lc2 = lc1.addChild(api.LocalCoordinates.p(name="b", decz=2.0, tiltx=-0.7, tiltThenDecenter=1))
+    pts = rng.rand(3, 20)
+    for lc in (lc1, lc2):
+        assert np.allclose(lc.returnGlobalToLocalPoints(lc.returnLocalToGlobalPoints(pts)), pts)
+        assert np.allclose(lc.returnGlobalToLocalDirections(lc.returnLocalToGlobalDirections(pts)), pts)
+        assert np.allclose(np.dot(lc.localbasis.T, lc.localbasis), np.eye(3))
+        d = lc.returnLocalToGlobalDirections(pts)
+        assert np.allclose(np.sum(d * d, axis=0), np.sum(pts * pts, axis=0))
+    assert np.allclose(lc1.returnOtherToActualPoints(lc1.returnActualToOtherPoints(pts, lc2), lc2), pts)
+
+
+def test_rect_grid_matches_reference_raster():
+    """RectGrid: 1e4 requested -> 9 917 points"""
+    (px, py) = systems.rect_grid(10000)
+    assert px.shape[0] == 9917
+    assert np.all(px ** 2 + py ** 2 <= 1)
+    case = _golden.load_case("double_gauss_axis")
+    (o, k, e0) = systems.double_gauss_bundle(256)
+    assert np.array_equal(o, case.x0) and np.array_equal(k, case.k0) and np.array_equal(e0, case.E0)
