@@ -126,23 +126,30 @@ int32_t prt_system_ray_counts(const prt_system_t *sys, int64_t n0, int64_t *n_in
 
 /*
  * Whole sequence: OpticalSystem.seqtrace for splitup=False.
- *   x0, k0        (3,n0) start points / wave vectors (global frame, |k| = n).
- *   e0_re, e0_im  (3,n0) E field of the first segment or NULL.  Used only for the
+ *   x0, k0        (3,n0) start points / wave vectors (global frame, |k| = n), rows in_pitch
+ *                 elements apart (0 = n0, i.e. C-contiguous (3,n0)).
+ *   e0_re, e0_im  (3,n0) E field of the first segment (same pitch) or NULL.  Used only for the
  *                 first segment's direction d = S/|S| (ray.py:136-152); NULL e0_re
  *                 means E = (0,1,0) (ray.py:71-73), NULL e0_im means real E.
- *   mode PATH:    x_hit  = concat_s (3,n_in[s]),  valid = concat_s (n_in[s]),
- *                 k_out  = concat_s (3,n_out[s]), valid_out = concat_s (n_out[s])
- *                 (valid_out may be NULL).  For all-isotropic tables n_in = n_out = n0
- *                 and the arrays are plain (S,3,n0) / (S,n0).
+ *   mode PATH, all-isotropic table:  row-pitched arrays, element (row, ray i) at row*out_pitch+i:
+ *                 x_hit, k_out  (S,3,out_pitch) doubles;  valid, valid_out (S,out_pitch) bytes;
+ *                 out_pitch 0 = n0 (tight).  Use prt_recommended_pitch(): rows that do not start
+ *                 on a 128-B line cost ~35 % of the HBM write bandwidth.
+ *   mode PATH, table with anisotropic media (out_pitch and in_pitch must be 0): concatenated
+ *                 x_hit = concat_s (3,n_in[s]),  valid = concat_s (n_in[s]),
+ *                 k_out = concat_s (3,n_out[s]), valid_out = concat_s (n_out[s]).
  *   mode IMAGE:   the same four arrays for the last surface only.
+ *   valid_out may be NULL.
  *   valid is the reference's cumulative mask after intersect + aperture
  *   (ray.py:100, surface.py:135); valid_out additionally ANDs the refraction
  *   checks (material_isotropic.py:183) -- it is what [:, valid] compaction uses.
  *   stream: hipStream_t (NULL = default stream).  Asynchronous.
  */
-int32_t prt_trace(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,
-                  const double *e0_re, const double *e0_im, int32_t mode, double *x_hit,
-                  double *k_out, uint8_t *valid, uint8_t *valid_out, void *stream);
+int64_t prt_recommended_pitch(int64_t n); /* n rounded up to 512 elements (4 KiB of doubles) */
+int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
+                  const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
+                  int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
+                  uint8_t *valid_out, void *stream);
 
 /*
  * Material.propagate(raybundle, surface): intersect + aperture for one surface.
@@ -195,10 +202,10 @@ int32_t prt_compact(int64_t n, const uint8_t *mask, int32_t n_arrays, const doub
 /* Timing helper for bench.py: runs prt_trace `iters` times on `stream` between
  * two HIP events recorded on that stream and returns the average milliseconds
  * per launch in *ms_avg. */
-int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,
-                        const double *e0_re, const double *e0_im, int32_t mode, double *x_hit,
-                        double *k_out, uint8_t *valid, uint8_t *valid_out, void *stream,
-                        int32_t iters, double *ms_avg);
+int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
+                        const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
+                        int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
+                        uint8_t *valid_out, void *stream, int32_t iters, double *ms_avg);
 
 #ifdef __cplusplus
 }

@@ -37,13 +37,16 @@ PROTOTYPES = {
     "prt_system_ray_counts": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.POINTER(ctypes.c_int64),
                                                ctypes.POINTER(ctypes.c_int64)]),
-    "prt_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p,
-                                   c_double_p, c_double_p, ctypes.c_int32, c_double_p,
-                                   c_double_p, c_u8_p, c_u8_p, c_stream]),
-    "prt_trace_timed": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, c_double_p,
-                                         c_double_p, c_double_p, c_double_p, ctypes.c_int32,
-                                         c_double_p, c_double_p, c_u8_p, c_u8_p, c_stream,
-                                         ctypes.c_int32, ctypes.POINTER(ctypes.c_double)]),
+    "prt_recommended_pitch": (ctypes.c_int64, [ctypes.c_int64]),
+    "prt_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_double_p,
+                                   c_double_p, c_double_p, c_double_p, ctypes.c_int32,
+                                   ctypes.c_int64, c_double_p, c_double_p, c_u8_p, c_u8_p,
+                                   c_stream]),
+    "prt_trace_timed": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                         c_double_p, c_double_p, c_double_p, c_double_p,
+                                         ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p,
+                                         c_u8_p, c_u8_p, c_stream, ctypes.c_int32,
+                                         ctypes.POINTER(ctypes.c_double)]),
     "prt_propagate": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                        c_double_p, c_double_p, c_double_p, c_double_p,
                                        c_double_p, ctypes.c_int32, c_u8_p, c_double_p, c_u8_p,

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include "prt_device.h"
@@ -51,118 +52,135 @@ static int32_t fail(int32_t code, const char *what, hipError_t e = hipSuccess) {
     } while (0)
 
 // ---------------------------------------------------------------------------
-// ray load / store helpers.  Arrays are (3,N) component-major.  RPT=2 uses one
-// 16-byte access per component (needs N even so that every row stays 16-B
-// aligned; the host falls back to RPT=1 otherwise).
+// ray load / store helpers for the fused march.  Arrays are component-major rows
+// with a row PITCH (in elements): element (row r, ray i) lives at r*pitch + i.
+// A thread owns the two adjacent rays i, i+1.  With an even pitch and a 16-byte
+// aligned base every row is 16-B aligned and one dwordx4 access moves both rays
+// (VEC = true); otherwise two 8-B accesses with a tail guard.
+//
+// Row alignment decides the achievable HBM WRITE bandwidth: with rows that do not
+// start on a 128-B line a wave's 1-KiB store is split over partial lines and the
+// 72-stream path write drops from ~6.3 to ~3.9-4.7 TB/s (measured, DESIGN.md
+// "row pitch").  prt_recommended_pitch() rounds the pitch to 4 KiB.
 // ---------------------------------------------------------------------------
-template <int RPT>
-struct rayio;
+typedef double prt_double2 __attribute__((ext_vector_type(2)));
 
-template <>
-struct rayio<1> {
-    static PRT_DEV void load(const double *__restrict__ a, int64_t n, int64_t i, vec3 v[1]) {
-        v[0] = v3(a[i], a[n + i], a[2 * n + i]);
+template <bool VEC>
+struct rayio {
+    // second = false: ray i+1 does not exist (odd N tail) -> duplicate ray i
+    static PRT_DEV void load(const double *__restrict__ a, int64_t pitch, int64_t i, bool second,
+                             vec3 v[2]) {
+        if (VEC) {
+            const prt_double2 x = *reinterpret_cast<const prt_double2 *>(a + i);
+            const prt_double2 y = *reinterpret_cast<const prt_double2 *>(a + pitch + i);
+            const prt_double2 z = *reinterpret_cast<const prt_double2 *>(a + 2 * pitch + i);
+            v[0] = v3(x.x, y.x, z.x);
+            v[1] = v3(x.y, y.y, z.y);
+        } else {
+            v[0] = v3(a[i], a[pitch + i], a[2 * pitch + i]);
+            v[1] = second ? v3(a[i + 1], a[pitch + i + 1], a[2 * pitch + i + 1]) : v[0];
+        }
     }
-    static PRT_DEV void store(double *__restrict__ a, int64_t n, int64_t i, const vec3 v[1]) {
-        a[i] = v[0].x;
-        a[n + i] = v[0].y;
-        a[2 * n + i] = v[0].z;
+    static PRT_DEV void store(double *__restrict__ a, int64_t pitch, int64_t i, bool second,
+                              const vec3 v[2]) {
+        if (VEC) {
+            *reinterpret_cast<prt_double2 *>(a + i) = prt_double2{v[0].x, v[1].x};
+            *reinterpret_cast<prt_double2 *>(a + pitch + i) = prt_double2{v[0].y, v[1].y};
+            *reinterpret_cast<prt_double2 *>(a + 2 * pitch + i) = prt_double2{v[0].z, v[1].z};
+        } else {
+            a[i] = v[0].x;
+            a[pitch + i] = v[0].y;
+            a[2 * pitch + i] = v[0].z;
+            if (second) {
+                a[i + 1] = v[1].x;
+                a[pitch + i + 1] = v[1].y;
+                a[2 * pitch + i + 1] = v[1].z;
+            }
+        }
     }
-    static PRT_DEV void store_mask(uint8_t *__restrict__ m, int64_t i, const bool b[1]) {
-        m[i] = b[0] ? 1 : 0;
-    }
-};
-
-template <>
-struct rayio<2> {
-    static PRT_DEV void load(const double *__restrict__ a, int64_t n, int64_t i, vec3 v[2]) {
-        const double2 x = *reinterpret_cast<const double2 *>(a + i);
-        const double2 y = *reinterpret_cast<const double2 *>(a + n + i);
-        const double2 z = *reinterpret_cast<const double2 *>(a + 2 * n + i);
-        v[0] = v3(x.x, y.x, z.x);
-        v[1] = v3(x.y, y.y, z.y);
-    }
-    static PRT_DEV void store(double *__restrict__ a, int64_t n, int64_t i, const vec3 v[2]) {
-        *reinterpret_cast<double2 *>(a + i) = make_double2(v[0].x, v[1].x);
-        *reinterpret_cast<double2 *>(a + n + i) = make_double2(v[0].y, v[1].y);
-        *reinterpret_cast<double2 *>(a + 2 * n + i) = make_double2(v[0].z, v[1].z);
-    }
-    static PRT_DEV void store_mask(uint8_t *__restrict__ m, int64_t i, const bool b[2]) {
-        *reinterpret_cast<uint16_t *>(m + i) =
-            (uint16_t)((b[0] ? 1u : 0u) | (b[1] ? 0x100u : 0u));
+    static PRT_DEV void store_mask(uint8_t *__restrict__ m, int64_t i, bool second, const bool b[2]) {
+        if (VEC) {
+            *reinterpret_cast<uint16_t *>(m + i) = (uint16_t)((b[0] ? 1u : 0u) | (b[1] ? 0x100u : 0u));
+        } else {
+            m[i] = b[0] ? 1 : 0;
+            if (second) m[i + 1] = b[1] ? 1 : 0;
+        }
     }
 };
 
 // first-segment direction selector
 //   e_mode 0: d = k/|k|        1: E = (0,1,0) (ray.py:71-73)     2: E given (re [, im])
-template <int RPT>
+template <bool VEC>
 PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
-                             const double *__restrict__ e_im, int64_t n, int64_t i,
-                             const vec3 k[RPT], vec3 d[RPT]) {
+                             const double *__restrict__ e_im, int64_t pitch, int64_t i, bool second,
+                             const vec3 k[2], vec3 d[2]) {
     if (e_mode == 0) {
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) d[r] = normalized(k[r]);
+        for (int r = 0; r < 2; ++r) d[r] = normalized(k[r]);
     } else if (e_mode == 1) {
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) d[r] = poynting_dir(k[r], v3(0, 1, 0), v3(0, 0, 0));
+        for (int r = 0; r < 2; ++r) d[r] = poynting_dir(k[r], v3(0, 1, 0), v3(0, 0, 0));
     } else {
-        vec3 er[RPT], ei[RPT];
-        rayio<RPT>::load(e_re, n, i, er);
+        vec3 er[2], ei[2];
+        rayio<VEC>::load(e_re, pitch, i, second, er);
         if (e_im) {
-            rayio<RPT>::load(e_im, n, i, ei);
+            rayio<VEC>::load(e_im, pitch, i, second, ei);
         } else {
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) ei[r] = v3(0, 0, 0);
+            for (int r = 0; r < 2; ++r) ei[r] = v3(0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) d[r] = poynting_dir(k[r], er[r], ei[r]);
+        for (int r = 0; r < 2; ++r) d[r] = poynting_dir(k[r], er[r], ei[r]);
     }
 }
 
 // ---------------------------------------------------------------------------
 // fused isotropic march: OpticalElement.seqtrace's loop (optical_element.py:336-375)
 // ---------------------------------------------------------------------------
-template <int RPT, int MODE>
+template <int MODE, bool VEC_IN, bool VEC_OUT>
 __global__ __launch_bounds__(PRT_BLOCK) void k_trace_iso(
-    const prt_surface_t *__restrict__ tab, int32_t S, int64_t N, const double *__restrict__ x0,
-    const double *__restrict__ k0, const double *__restrict__ e_re,
-    const double *__restrict__ e_im, int32_t e_mode, double *__restrict__ xh_out,
-    double *__restrict__ k_out, uint8_t *__restrict__ valid_out_hit,
+    const prt_surface_t *__restrict__ tab, int32_t S, int64_t N, int64_t in_pitch,
+    const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
+    const double *__restrict__ e_im, int32_t e_mode, int64_t out_pitch,
+    double *__restrict__ xh_out, double *__restrict__ k_out, uint8_t *__restrict__ valid_out_hit,
     uint8_t *__restrict__ valid_out_refr) {
-    const int64_t i = ((int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x) * RPT;
+    const int64_t i = ((int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x) * 2;
     if (i >= N) return;
+    const bool second = (i + 1 < N);
 
-    vec3 x[RPT], k[RPT], d[RPT];
-    bool valid[RPT];
-    rayio<RPT>::load(x0, N, i, x);
-    rayio<RPT>::load(k0, N, i, k);
-    first_direction<RPT>(e_mode, e_re, e_im, N, i, k, d);
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) valid[r] = true;
+    vec3 x[2], k[2], d[2];
+    bool valid[2] = {true, true};
+    rayio<VEC_IN>::load(x0, in_pitch, i, second, x);
+    rayio<VEC_IN>::load(k0, in_pitch, i, second, k);
+    first_direction<VEC_IN>(e_mode, e_re, e_im, in_pitch, i, second, k, d);
+    double d2 = 1.0;  // |d|^2: unit Poynting direction on the first segment
 
     for (int32_t s = 0; s < S; ++s) {
         const prt_surface_t *__restrict__ sf = tab + s;
-        bool vhit[RPT];
+        bool vhit[2];
 #pragma unroll
-        for (int r = 0; r < RPT; ++r) {
-            vec3 xh, p;
-            propagate_step(sf, x[r], d[r], xh, p, valid[r]);
+        for (int r = 0; r < 2; ++r) {
+            vec3 xh, p, g;
+            double g2;
+            propagate_step(sf, x[r], d[r], d2, xh, p, g, g2, valid[r]);
             vhit[r] = valid[r];
-            interact_isotropic(sf, p, k[r], valid[r]);
+            const vec3 n = normal_from_grad(sf, g, g2);
+            interact_isotropic(sf, n, k[r], valid[r]);
             x[r] = xh;
+            // after an isotropic interaction E is perpendicular to k, so the Poynting
+            // direction (ray.py:136-152) is parallel to k; the next intersection takes the
+            // unnormalised k with |k|^2 = n_after^2 (conic_t / explicit_t are homogeneous in d)
+            d[r] = k[r];
         }
-        // after an isotropic interaction E is perpendicular to k, so the Poynting
-        // direction (ray.py:136-152) is k/|k| and |k| = n_after
-        const double inv_n = 1.0 / sf->n_after;
-#pragma unroll
-        for (int r = 0; r < RPT; ++r) d[r] = v3(k[r].x * inv_n, k[r].y * inv_n, k[r].z * inv_n);
+        d2 = sf->n_after * sf->n_after;
 
         if (MODE == PRT_MODE_PATH || s == S - 1) {
             const int64_t so = (MODE == PRT_MODE_PATH) ? (int64_t)s : 0;
-            rayio<RPT>::store(xh_out + so * 3 * N, N, i, x);
-            rayio<RPT>::store(k_out + so * 3 * N, N, i, k);
-            rayio<RPT>::store_mask(valid_out_hit + so * N, i, vhit);
-            if (valid_out_refr) rayio<RPT>::store_mask(valid_out_refr + so * N, i, valid);
+            rayio<VEC_OUT>::store(xh_out + so * 3 * out_pitch, out_pitch, i, second, x);
+            rayio<VEC_OUT>::store(k_out + so * 3 * out_pitch, out_pitch, i, second, k);
+            rayio<VEC_OUT>::store_mask(valid_out_hit + so * out_pitch, i, second, vhit);
+            if (valid_out_refr)
+                rayio<VEC_OUT>::store_mask(valid_out_refr + so * out_pitch, i, second, valid);
         }
     }
 }
@@ -186,14 +204,16 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_propagate(
     if (dir_in) {
         d = v3(dir_in[i], dir_in[N + i], dir_in[2 * N + i]);
     } else {
-        vec3 k[1] = {v3(k_in[i], k_in[N + i], k_in[2 * N + i])};
-        vec3 dd[1];
-        first_direction<1>(e_mode, e_re, e_im, N, i, k, dd);
+        const vec3 kk = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
+        vec3 k[2] = {kk, kk};
+        vec3 dd[2];
+        first_direction<false>(e_mode, e_re, e_im, N, i, false, k, dd);
         d = dd[0];
     }
     bool valid = valid_in ? (valid_in[i] != 0) : true;
-    vec3 xh, p;
-    propagate_step(sf, x, d, xh, p, valid);
+    vec3 xh, p, g;
+    double g2;
+    propagate_step(sf, x, d, 1.0, xh, p, g, g2, valid);
     xh_out[i] = xh.x;
     xh_out[N + i] = xh.y;
     xh_out[2 * N + i] = xh.z;
@@ -210,7 +230,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_interact_iso(
     vec3 k = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
     bool valid = valid_in ? (valid_in[i] != 0) : true;
     const vec3 p = to_shape_frame(sf, xh);
-    interact_isotropic(sf, p, k, valid);
+    interact_isotropic(sf, normal_in_material_frame(sf, p), k, valid);
     k_out[i] = k.x;
     k_out[N + i] = k.y;
     k_out[2 * N + i] = k.z;
@@ -409,20 +429,26 @@ static int32_t e_mode_of(const double *e_re, int32_t use_default_e) {
     return use_default_e ? 1 : 0;
 }
 
-template <int RPT>
-static void launch_trace_iso(const prt_system_t *sys, int64_t n0, const double *x0,
+template <int MODE>
+static void launch_trace_iso(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
                              const double *k0, const double *e_re, const double *e_im,
-                             int32_t e_mode, int32_t mode, double *x_hit, double *k_out,
-                             uint8_t *valid, uint8_t *valid_out, hipStream_t st) {
-    const unsigned grid = nblocks(n0, PRT_BLOCK * RPT);
-    if (mode == PRT_MODE_PATH)
-        hipLaunchKernelGGL((k_trace_iso<RPT, PRT_MODE_PATH>), dim3(grid), dim3(PRT_BLOCK), 0, st,
-                           sys->d_table, sys->n_surfaces, n0, x0, k0, e_re, e_im, e_mode, x_hit,
-                           k_out, valid, valid_out);
+                             int32_t e_mode, int64_t out_pitch, double *x_hit, double *k_out,
+                             uint8_t *valid, uint8_t *valid_out, bool vec_in, bool vec_out,
+                             hipStream_t st) {
+    const dim3 grid(nblocks(n0, PRT_BLOCK * 2)), block(PRT_BLOCK);
+#define PRT_LAUNCH(VI, VO)                                                                       \
+    hipLaunchKernelGGL((k_trace_iso<MODE, VI, VO>), grid, block, 0, st, sys->d_table,            \
+                       sys->n_surfaces, n0, in_pitch, x0, k0, e_re, e_im, e_mode, out_pitch,     \
+                       x_hit, k_out, valid, valid_out)
+    if (vec_in && vec_out)
+        PRT_LAUNCH(true, true);
+    else if (vec_in)
+        PRT_LAUNCH(true, false);
+    else if (vec_out)
+        PRT_LAUNCH(false, true);
     else
-        hipLaunchKernelGGL((k_trace_iso<RPT, PRT_MODE_IMAGE>), dim3(grid), dim3(PRT_BLOCK), 0, st,
-                           sys->d_table, sys->n_surfaces, n0, x0, k0, e_re, e_im, e_mode, x_hit,
-                           k_out, valid, valid_out);
+        PRT_LAUNCH(false, false);
+#undef PRT_LAUNCH
 }
 
 extern "C" {
@@ -649,36 +675,54 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
     return PRT_OK;
 }
 
-int32_t prt_trace(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,
-                  const double *e0_re, const double *e0_im, int32_t mode, double *x_hit,
-                  double *k_out, uint8_t *valid, uint8_t *valid_out, void *stream) {
+int64_t prt_recommended_pitch(int64_t n) {
+    if (n <= 0) return 0;
+    return (n + 511) / 512 * 512;  // 4 KiB of doubles: every row starts on a 128-B line
+}
+
+int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
+                  const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
+                  int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
+                  uint8_t *valid_out, void *stream) {
     if (!sys || n0 < 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace: null system / negative count");
     if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE)
         return fail(PRT_ERR_INVALID_ARG, "prt_trace: bad mode");
     if (n0 == 0) return PRT_OK;  // empty bundle: nothing to do (buffers may be NULL)
     if (!x0 || !k0 || !x_hit || !k_out || !valid)
         return fail(PRT_ERR_INVALID_ARG, "prt_trace: null pointer");
+    if (in_pitch == 0) in_pitch = n0;
+    if (in_pitch < n0 || (out_pitch != 0 && out_pitch < n0))
+        return fail(PRT_ERR_INVALID_ARG, "prt_trace: pitch smaller than the ray count");
     HIP_TRY(hipSetDevice(sys->device));
     hipStream_t st = (hipStream_t)stream;
-    if (!sys->all_isotropic)
+    if (!sys->all_isotropic) {
+        if (out_pitch != 0 || in_pitch != n0)
+            return fail(PRT_ERR_INVALID_ARG,
+                        "prt_trace: tables with anisotropic media use the concatenated layout (pitch 0)");
         return trace_general(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, valid, valid_out, st);
+    }
+    if (out_pitch == 0) out_pitch = n0;
     const int32_t e_mode = e_mode_of(e0_re, 1);
-    const bool vec_ok = (n0 % 2 == 0) && aligned16(x0) && aligned16(k0) && aligned16(x_hit) &&
-                        aligned16(k_out) && (!e0_re || aligned16(e0_re)) &&
-                        (!e0_im || aligned16(e0_im)) && ((((uintptr_t)valid) & 1u) == 0) &&
-                        (!valid_out || (((uintptr_t)valid_out) & 1u) == 0);
-    if (vec_ok)
-        launch_trace_iso<2>(sys, n0, x0, k0, e0_re, e0_im, e_mode, mode, x_hit, k_out, valid, valid_out, st);
+    const bool vec_in = (in_pitch % 2 == 0) && aligned16(x0) && aligned16(k0) &&
+                        (!e0_re || aligned16(e0_re)) && (!e0_im || aligned16(e0_im));
+    const bool vec_out = (out_pitch % 2 == 0) && aligned16(x_hit) && aligned16(k_out) &&
+                         ((((uintptr_t)valid) & 1u) == 0) &&
+                         (!valid_out || (((uintptr_t)valid_out) & 1u) == 0) &&
+                         (n0 % 2 == 0 || out_pitch > n0);  // odd N: the tail lane's 2nd ray lands in the padding
+    if (mode == PRT_MODE_PATH)
+        launch_trace_iso<PRT_MODE_PATH>(sys, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch,
+                                        x_hit, k_out, valid, valid_out, vec_in, vec_out, st);
     else
-        launch_trace_iso<1>(sys, n0, x0, k0, e0_re, e0_im, e_mode, mode, x_hit, k_out, valid, valid_out, st);
+        launch_trace_iso<PRT_MODE_IMAGE>(sys, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch,
+                                         x_hit, k_out, valid, valid_out, vec_in, vec_out, st);
     HIP_TRY(hipGetLastError());
     return PRT_OK;
 }
 
-int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,
-                        const double *e0_re, const double *e0_im, int32_t mode, double *x_hit,
-                        double *k_out, uint8_t *valid, uint8_t *valid_out, void *stream,
-                        int32_t iters, double *ms_avg) {
+int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
+                        const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
+                        int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
+                        uint8_t *valid_out, void *stream, int32_t iters, double *ms_avg) {
     if (!ms_avg || iters <= 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace_timed");
     if (!sys) return fail(PRT_ERR_INVALID_ARG, "null system");
     HIP_TRY(hipSetDevice(sys->device));
@@ -688,7 +732,8 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, const double *x0, c
     HIP_TRY(hipEventCreate(&b));
     HIP_TRY(hipEventRecord(a, st));
     for (int it = 0; it < iters; ++it) {
-        int32_t rc = prt_trace(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, valid, valid_out, stream);
+        int32_t rc = prt_trace(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out,
+                               valid, valid_out, stream);
         if (rc != PRT_OK) {
             (void)hipEventDestroy(a);
             (void)hipEventDestroy(b);

@@ -39,6 +39,38 @@ PRT_DEV vec3 matT_vec(const double *__restrict__ B, const vec3 &v) {
               B[2] * v.x + B[5] * v.y + B[8] * v.z);
 }
 
+// 1/a to ~1 ulp: v_rcp_f64 (2^-24 relative) + two Newton steps.  Replaces the IEEE
+// division sequence (div_scale x2, rcp, 5 fma, div_fmas, div_fixup) on the per-ray
+// critical path; operands here are O(1e-6 .. 1e6), far from the exponent limits the
+// scaling steps of the IEEE sequence exist for.  0, inf and NaN behave like 1/a.
+PRT_DEV double fast_rcp(double a) {
+    double r = __builtin_amdgcn_rcp(a);
+    double e = __builtin_fma(-a, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-a, r, 1.0);
+    // the last step would turn r = inf (a = 0) into NaN; keep the hardware result there
+    return isfinite(r) ? __builtin_fma(r, e, r) : r;
+}
+
+// sqrt(x) to ~1 ulp for x in the normal range: v_rsq_f64 (2^-24 relative) -> one coupled
+// Goldschmidt step (error ~2^-47) -> two Newton residual corrections.  hipcc's sqrt() adds
+// input scaling (ldexp / class tests) for denormal and huge arguments that per-ray optical
+// quantities (O(1e-12 .. 1e12)) never reach; x = 0 is handled explicitly, x < 0 gives NaN
+// like sqrt.
+PRT_DEV double fast_sqrt(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return (x == 0.0) ? 0.0 : g;
+}
+
 PRT_DEV bool finite3(const vec3 &v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
 
 // ---------------------------------------------------------------------------
@@ -51,12 +83,12 @@ PRT_DEV vec3 poynting_dir(const vec3 &k, const vec3 &er, const vec3 &ei) {
     // Re((ekr + i eki)(er - i ei)) = ekr*er + eki*ei
     vec3 s = v3(e2 * k.x - (ekr * er.x + eki * ei.x), e2 * k.y - (ekr * er.y + eki * ei.y),
                 e2 * k.z - (ekr * er.z + eki * ei.z));
-    const double inv = 1.0 / sqrt(dot(s, s));
+    const double inv = fast_rcp(fast_sqrt(dot(s, s)));
     return v3(s.x * inv, s.y * inv, s.z * inv);
 }
 
 PRT_DEV vec3 normalized(const vec3 &k) {
-    const double inv = 1.0 / sqrt(dot(k, k));
+    const double inv = fast_rcp(fast_sqrt(dot(k, k)));
     return v3(k.x * inv, k.y * inv, k.z * inv);
 }
 
@@ -65,13 +97,24 @@ PRT_DEV vec3 normalized(const vec3 &k) {
 // ---------------------------------------------------------------------------
 
 // Conic.intersect, surface_shape.py:305-321.  r0, d in the shape frame.
-PRT_DEV double conic_t(double c, double cc, const vec3 &r0, const vec3 &d, bool &ok) {
-    const double F = d.z - c * (d.x * r0.x + d.y * r0.y + d.z * r0.z * (1.0 + cc));
-    const double G = c * (r0.x * r0.x + r0.y * r0.y + r0.z * r0.z * (1.0 + cc)) - 2.0 * r0.z;
-    const double H = -c - cc * c * d.z * d.z;
+// d need not be a unit vector: with d2 = d.d the reference's H = -c - cc c dz^2 (written for
+// |d| = 1) generalises to H = -c d2 - cc c dz^2 and the returned t is measured in units of
+// |d| (the hit point r0 + t d is the same).  The fused march passes d = k (|k| = n) and
+// saves the normalisation.
+PRT_DEV double conic_t(double c, double cc, const vec3 &r0, const vec3 &d, double d2, bool &ok) {
+    double F, G, H;
+    if (cc == 0.0) {  // sphere / plane: wave-uniform branch, drops the (1+cc) and cc terms
+        F = d.z - c * (d.x * r0.x + d.y * r0.y + d.z * r0.z);
+        G = c * (r0.x * r0.x + r0.y * r0.y + r0.z * r0.z) - 2.0 * r0.z;
+        H = -c * d2;
+    } else {
+        F = d.z - c * (d.x * r0.x + d.y * r0.y + d.z * r0.z * (1.0 + cc));
+        G = c * (r0.x * r0.x + r0.y * r0.y + r0.z * r0.z * (1.0 + cc)) - 2.0 * r0.z;
+        H = -c * d2 - cc * c * d.z * d.z;
+    }
     const double square = F * F + H * G;
     ok = square >= 0.0;
-    return G / (F + sqrt(square));
+    return G * fast_rcp(F + fast_sqrt(square));
 }
 
 // Conic.getGrad + conic_function, surface_shape.py:208-237:
@@ -83,6 +126,21 @@ PRT_DEV vec3 conic_grad(double c, double cc, double x, double y) {
     const double st = 1.0 - (1.0 + cc) * c * c * r2;
     const double sq = (st > 0.0) ? sqrt(st) : __builtin_nan("");
     return v3(-c * x, -c * y, sq);
+}
+
+// The same gradient for a point p that lies ON the conic (the hit point the intersection just
+// produced): there c z (1+cc) with z = p.z needs no sag evaluation, and
+//   (1 - c (1+cc) z)^2 = 1 - (1+cc) c^2 r2        (conic equation c r2 - 2z + c(1+cc)z^2 = 0)
+// so gz = |1 - c (1+cc) p.z| equals the reference's +sqrt branch on either sheet.  The domain
+// test (NaN when 1-(1+cc)c^2 r2 <= 0) is kept.  |grad|^2 = 1 - cc c^2 r2  (== 1 for spheres).
+PRT_DEV vec3 conic_grad_on_surface(double c, double cc, const vec3 &p, double &norm2) {
+    const double r2 = p.x * p.x + p.y * p.y;
+    const double c2r2 = c * c * r2;
+    const double st = 1.0 - (1.0 + cc) * c2r2;
+    double gz = fabs(1.0 - c * (1.0 + cc) * p.z);
+    if (!(st > 0.0)) gz = __builtin_nan("");
+    norm2 = 1.0 - cc * c2r2;
+    return v3(-c * p.x, -c * p.y, gz);
 }
 
 PRT_DEV double conic_sag(double c, double cc, double r2) {
@@ -99,7 +157,7 @@ PRT_DEV void asphere_eval(const prt_surface_t *__restrict__ sf, double x, double
                           double &dFdr2x2 /* Fx = x * this */) {
     const double c = sf->curv, cc = sf->cc;
     const double r2 = x * x + y * y;
-    const double sq = sqrt(1.0 - c * c * (1.0 + cc) * r2);
+    const double sq = fast_sqrt(1.0 - c * c * (1.0 + cc) * r2);
     double p = 0.0, dp = 0.0;  // p = sum a_n r2^n ; dp = sum (n+1) a_n r2^n
     const int nc = sf->n_coeffs;
     for (int n = nc - 1; n >= 0; --n) {
@@ -107,8 +165,8 @@ PRT_DEV void asphere_eval(const prt_surface_t *__restrict__ sf, double x, double
         p = p * r2 + a;
         dp = dp * r2 + (double)(n + 1) * a;
     }
-    F = c * r2 / (1.0 + sq) + p * r2;
-    dFdr2x2 = c / sq + 2.0 * dp;
+    F = c * r2 * fast_rcp(1.0 + sq) + p * r2;
+    dFdr2x2 = c * fast_rcp(sq) + 2.0 * dp;
 }
 
 // XYPolynomials.F / gradF, surface_shape.py:785-807.  coeffs[] already hold
@@ -153,10 +211,16 @@ PRT_DEV void explicit_eval(const prt_surface_t *__restrict__ sf, double x, doubl
 // runs scalar Newton to machine precision.  The loop is wave-uniform: a wave
 // leaves when all its lanes have converged (or the cap is hit); converged lanes
 // keep their t.  *nonconv reports lanes that hit the cap.
+// gx, gy: in-plane derivatives (Fx, Fy) at the last iterate -- the step that ended the
+// iteration was <= 1e-15, so they are the derivatives at the root to rounding and the
+// normal does not need another evaluation of the shape.
+// The convergence scale is in units of |d| (d may be k, |k| = n ~ 1..2).
 PRT_DEV double explicit_t(const prt_surface_t *__restrict__ sf, const vec3 &r0, const vec3 &d,
-                          bool &nonconv) {
+                          bool &nonconv, double &gx, double &gy) {
     double t = 0.0;
     bool done = false;
+    gx = 0.0;
+    gy = 0.0;
     const int maxit = sf->newton_maxit > 0 ? sf->newton_maxit : 30;
     for (int it = 0; it < maxit; ++it) {
         double F, Fx, Fy;
@@ -164,9 +228,11 @@ PRT_DEV double explicit_t(const prt_surface_t *__restrict__ sf, const vec3 &r0, 
         explicit_eval(sf, px, py, F, Fx, Fy);
         const double g = r0.z + t * d.z - F;
         const double gp = d.z - Fx * d.x - Fy * d.y;
-        const double dt = g / gp;
+        const double dt = g * fast_rcp(gp);
         if (!done) {
             t -= dt;
+            gx = Fx;
+            gy = Fy;
             const double scale = fmax(1.0, fabs(t));
             // NaN/Inf steps stop the lane too (t is already non-finite -> ray invalid later)
             done = !(fabs(dt) > 1e-15 * scale) || !isfinite(dt);
@@ -212,8 +278,10 @@ PRT_DEV bool aperture_ok(const prt_surface_t *__restrict__ sf, double x, double 
 //   in : x global start point, d global unit direction
 //   out: xh global hit point, p hit point in the shape frame, valid &= hit & aperture
 // ---------------------------------------------------------------------------
+//        g (unnormalised surface gradient at p, shape frame) and g2 = |g|^2 as by-products
+//   d may be any positive multiple of the unit direction, d2 = d.d
 PRT_DEV void propagate_step(const prt_surface_t *__restrict__ sf, const vec3 &x, const vec3 &d,
-                            vec3 &xh, vec3 &p, bool &valid) {
+                            double d2, vec3 &xh, vec3 &p, vec3 &g, double &g2, bool &valid) {
     const int ff = sf->frame_flags;
     vec3 r0 = v3(x.x - sf->g_shape[0], x.y - sf->g_shape[1], x.z - sf->g_shape[2]);
     vec3 dl = d;
@@ -224,13 +292,18 @@ PRT_DEV void propagate_step(const prt_surface_t *__restrict__ sf, const vec3 &x,
     double t;
     if (sf->shape_type == PRT_SHAPE_CONIC) {
         bool ok;
-        t = conic_t(sf->curv, sf->cc, r0, dl, ok);
+        t = conic_t(sf->curv, sf->cc, r0, dl, d2, ok);
         valid = valid && ok;
+        p = v3(r0.x + dl.x * t, r0.y + dl.y * t, r0.z + dl.z * t);
+        g = conic_grad_on_surface(sf->curv, sf->cc, p, g2);
     } else {
         bool nonconv;
-        t = explicit_t(sf, r0, dl, nonconv);  // reference: valid all True (surface_shape.py:462)
+        double fx, fy;
+        t = explicit_t(sf, r0, dl, nonconv, fx, fy);  // reference: valid all True (surface_shape.py:462)
+        p = v3(r0.x + dl.x * t, r0.y + dl.y * t, r0.z + dl.z * t);
+        g = v3(-fx, -fy, 1.0);
+        g2 = fx * fx + fy * fy + 1.0;
     }
-    p = v3(r0.x + dl.x * t, r0.y + dl.y * t, r0.z + dl.z * t);
     if (ff & PRT_FRAME_SHAPE_IDENTITY) {
         xh = v3(p.x + sf->g_shape[0], p.y + sf->g_shape[1], p.z + sf->g_shape[2]);
     } else {
@@ -255,10 +328,29 @@ PRT_DEV vec3 to_shape_frame(const prt_surface_t *__restrict__ sf, const vec3 &xh
     return r;
 }
 
-// unit normal in the frame of the medium: RayBundle.getLocalSurfaceNormal, ray.py:156-161
+// unit normal in the frame of the medium from the shape-frame gradient g (|g|^2 = g2):
+// Shape.getNormal (surface_shape.py:100-112) + RayBundle.getLocalSurfaceNormal (ray.py:156-161).
+// Spheres have |g| = 1 identically (conic_grad_on_surface): no normalisation.
+PRT_DEV vec3 normal_from_grad(const prt_surface_t *__restrict__ sf, const vec3 &g, double g2) {
+    vec3 n = g;
+    if (!(sf->shape_type == PRT_SHAPE_CONIC && sf->cc == 0.0)) {
+        const double inv = __builtin_amdgcn_rsq(g2);
+        // one Newton step on the reciprocal square root: inv *= (1.5 - 0.5 g2 inv^2), twice
+        const double h = 0.5 * g2;
+        double r = inv * __builtin_fma(-h * inv, inv, 1.5);
+        r = r * __builtin_fma(-h * r, r, 1.5);
+        n = v3(g.x * r, g.y * r, g.z * r);
+    }
+    const int ff = sf->frame_flags;
+    if (!(ff & PRT_FRAME_SHAPE_IDENTITY)) n = mat_vec(sf->B_shape, n);
+    if (!(ff & PRT_FRAME_MAT_IDENTITY)) n = matT_vec(sf->B_mat, n);
+    return n;
+}
+
+// the same for an arbitrary point of the shape frame (per-surface API: the caller's points
+// need not lie on the surface, so the sag is evaluated like the reference does)
 PRT_DEV vec3 normal_in_material_frame(const prt_surface_t *__restrict__ sf, const vec3 &p) {
     vec3 g = shape_grad(sf, p.x, p.y);
-    // Shape.getNormal, surface_shape.py:100-112
     const double inv = 1.0 / sqrt(dot(g, g));
     vec3 n = v3(g.x * inv, g.y * inv, g.z * inv);
     const int ff = sf->frame_flags;
@@ -271,9 +363,8 @@ PRT_DEV vec3 normal_in_material_frame(const prt_surface_t *__restrict__ sf, cons
 // IsotropicMaterial.refract / reflect, material_isotropic.py:137-236
 //   k global in -> k global out; valid &= (n2^2 - kin.kin > 0) & finite(normal)
 // ---------------------------------------------------------------------------
-PRT_DEV void interact_isotropic(const prt_surface_t *__restrict__ sf, const vec3 &p, vec3 &k,
+PRT_DEV void interact_isotropic(const prt_surface_t *__restrict__ sf, const vec3 &n, vec3 &k,
                                 bool &valid) {
-    const vec3 n = normal_in_material_frame(sf, p);
     const bool mat_id = sf->frame_flags & PRT_FRAME_MAT_IDENTITY;
     vec3 k1 = k;
     if (!mat_id) k1 = matT_vec(sf->B_mat, k);
@@ -281,8 +372,10 @@ PRT_DEV void interact_isotropic(const prt_surface_t *__restrict__ sf, const vec3
     vec3 kin = v3(k1.x - kn * n.x, k1.y - kn * n.y, k1.z - kn * n.z);
     const double n2 = sf->n_after;
     const double square = n2 * n2 - dot(kin, kin);
-    const double xi = sqrt(square);
-    valid = valid && (square > 0.0) && finite3(n);
+    const double xi = fast_sqrt(square);
+    // checkfinite(normal) (material_isotropic.py:173): k is finite for a valid ray, so the
+    // normal is finite iff k.n is, and square inherits every NaN of kin
+    valid = valid && (square > 0.0) && isfinite(kn);
     if (sf->interaction == PRT_MIRROR) kin = v3(-kin.x, -kin.y, -kin.z);  // :224
     vec3 k2 = v3(kin.x + xi * n.x, kin.y + xi * n.y, kin.z + xi * n.z);
     k = mat_id ? k2 : mat_vec(sf->B_mat, k2);

@@ -21,13 +21,28 @@ def _stream_handle(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def _check_rays(t, name, n=None):
-    if t.dtype != torch.float64 or t.dim() != 2 or t.shape[0] != 3 or not t.is_contiguous():
-        raise ValueError("%s must be a contiguous (3, N) float64 tensor" % name)
+def _check_rays(t, name, n=None, allow_pitch=False):
+    """(3, N) float64 device tensor with unit stride along the rays; returns the row pitch."""
+    if t.dtype != torch.float64 or t.dim() != 2 or t.shape[0] != 3:
+        raise ValueError("%s must be a (3, N) float64 tensor" % name)
     if not t.is_cuda:
         raise ValueError("%s must live on the GPU" % name)
     if n is not None and t.shape[1] != n:
         raise ValueError("%s has %d rays, expected %d" % (name, t.shape[1], n))
+    if t.shape[1] == 0:
+        return 0
+    if t.stride(1) != 1 or (not allow_pitch and not t.is_contiguous()):
+        raise ValueError("%s must be contiguous along the ray axis" % name)
+    return t.stride(0)
+
+
+def _rows_contiguous(t):
+    """tight (3, N) copy of a pitched view (per-surface entry points take tight arrays)"""
+    return t if (t is None or t.is_contiguous()) else t.contiguous()
+
+
+def recommended_pitch(n):
+    return int(_lib.load().prt_recommended_pitch(n))
 
 
 class TraceResult(object):
@@ -85,50 +100,74 @@ class DeviceSystem(object):
         _lib.check(self.lib.prt_system_ray_counts(self._h, n0, n_in, n_out))
         return list(n_in), list(n_out)
 
-    def alloc_outputs(self, n0, mode=_lib.MODE_PATH, with_valid_out=True):
+    def alloc_outputs(self, n0, mode=_lib.MODE_PATH, with_valid_out=True, pitch=None):
+        """Output buffers for trace_into.  All-isotropic tables get ROW-PITCHED arrays
+        ((S,3,pitch) / (S,pitch), pitch = prt_recommended_pitch(n0) unless given: rows aligned
+        to 128-B lines are worth ~35 % HBM write bandwidth); tables with anisotropic media get
+        the concatenated layout (pitch 0)."""
         (n_in, n_out) = self.ray_counts(n0)
         if mode == _lib.MODE_IMAGE:
             n_in, n_out = n_in[-1:], n_out[-1:]
         dev = self.device
+        if self.all_isotropic:
+            if pitch is None:
+                pitch = recommended_pitch(n0)
+            rows = len(n_in)
+            (nx, nk, nv, nw) = (3 * rows * pitch, 3 * rows * pitch, rows * pitch, rows * pitch)
+        else:
+            pitch = 0
+            (nx, nk, nv, nw) = (3 * sum(n_in), 3 * sum(n_out), sum(n_in), sum(n_out))
         bufs = dict(
-            x_hit=torch.empty(3 * sum(n_in), dtype=torch.float64, device=dev),
-            k_out=torch.empty(3 * sum(n_out), dtype=torch.float64, device=dev),
-            valid=torch.empty(sum(n_in), dtype=torch.uint8, device=dev),
-            valid_out=(torch.empty(sum(n_out), dtype=torch.uint8, device=dev)
-                       if with_valid_out else None),
-            n_in=n_in, n_out=n_out, mode=mode)
+            x_hit=torch.empty(nx, dtype=torch.float64, device=dev),
+            k_out=torch.empty(nk, dtype=torch.float64, device=dev),
+            valid=torch.empty(nv, dtype=torch.uint8, device=dev),
+            valid_out=(torch.empty(nw, dtype=torch.uint8, device=dev) if with_valid_out else None),
+            n_in=n_in, n_out=n_out, mode=mode, pitch=pitch)
         return bufs
 
     # -- whole sequence ----------------------------------------------------
     def trace_into(self, x0, k0, bufs, e0_re=None, e0_im=None):
         """Asynchronous launch into preallocated buffers (see alloc_outputs)."""
         n0 = x0.shape[1]
-        _lib.check(self.lib.prt_trace(self._h, n0, _ptr(x0), _ptr(k0), _ptr(e0_re), _ptr(e0_im),
-                                      bufs["mode"], _ptr(bufs["x_hit"]), _ptr(bufs["k_out"]),
-                                      _ptr(bufs["valid"]), _ptr(bufs["valid_out"]),
-                                      _stream_handle(self.device)))
+        in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
+        _lib.check(self.lib.prt_trace(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
+                                      _ptr(e0_im), bufs["mode"], bufs["pitch"], _ptr(bufs["x_hit"]),
+                                      _ptr(bufs["k_out"]), _ptr(bufs["valid"]),
+                                      _ptr(bufs["valid_out"]), _stream_handle(self.device)))
+
+    @staticmethod
+    def _in_pitch(x0, k0, e0_re, e0_im):
+        if x0.shape[1] == 0:
+            return 0
+        pitch = x0.stride(0)
+        for t in (k0, e0_re, e0_im):
+            if t is not None and t.stride(0) != pitch:
+                raise ValueError("x0, k0 and E0 must share one row pitch")
+        return pitch
 
     def trace_timed(self, x0, k0, bufs, iters, e0_re=None, e0_im=None):
         """Average device milliseconds per prt_trace launch (HIP events on the launch
         stream, inside libprt)."""
         ms = ctypes.c_double()
         n0 = x0.shape[1]
-        _lib.check(self.lib.prt_trace_timed(self._h, n0, _ptr(x0), _ptr(k0), _ptr(e0_re),
-                                            _ptr(e0_im), bufs["mode"], _ptr(bufs["x_hit"]),
-                                            _ptr(bufs["k_out"]), _ptr(bufs["valid"]),
-                                            _ptr(bufs["valid_out"]), _stream_handle(self.device),
-                                            iters, ctypes.byref(ms)))
+        in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
+        _lib.check(self.lib.prt_trace_timed(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
+                                            _ptr(e0_im), bufs["mode"], bufs["pitch"],
+                                            _ptr(bufs["x_hit"]), _ptr(bufs["k_out"]),
+                                            _ptr(bufs["valid"]), _ptr(bufs["valid_out"]),
+                                            _stream_handle(self.device), iters, ctypes.byref(ms)))
         return ms.value
 
     def trace(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH):
         """OpticalSystem.seqtrace on device tensors; returns a TraceResult of views."""
-        _check_rays(x0, "x0")
         n0 = x0.shape[1]
-        _check_rays(k0, "k0", n0)
-        if e0_re is not None:
-            _check_rays(e0_re, "e0_re", n0)
-        if e0_im is not None:
-            _check_rays(e0_im, "e0_im", n0)
+        pitches = set()
+        for (t, name) in ((x0, "x0"), (k0, "k0"), (e0_re, "e0_re"), (e0_im, "e0_im")):
+            if t is not None:
+                pitches.add(_check_rays(t, name, n0, allow_pitch=True))
+        if len(pitches) > 1 or not self.all_isotropic:
+            # mixed pitches, or the per-surface march (tight arrays): tight copies
+            (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
         with torch.cuda.device(self.device):
             bufs = self.alloc_outputs(n0, mode)
             self.trace_into(x0, k0, bufs, e0_re, e0_im)
@@ -137,6 +176,20 @@ class DeviceSystem(object):
     @staticmethod
     def views(bufs):
         (xs, ks, vs, ws) = ([], [], [], [])
+        pitch = bufs.get("pitch", 0)
+        if pitch:
+            rows = len(bufs["n_in"])
+            n = bufs["n_in"][0]
+            xv = bufs["x_hit"].view(rows, 3, pitch)
+            kv = bufs["k_out"].view(rows, 3, pitch)
+            vv = bufs["valid"].view(rows, pitch)
+            wv = None if bufs["valid_out"] is None else bufs["valid_out"].view(rows, pitch)
+            for s in range(rows):
+                xs.append(xv[s, :, :n])
+                ks.append(kv[s, :, :n])
+                vs.append(vv[s, :n])
+                ws.append(None if wv is None else wv[s, :n])
+            return TraceResult(xs, ks, vs, ws, bufs["n_in"], bufs["n_out"], bufs["mode"])
         (oi, oo) = (0, 0)
         for (ni, no) in zip(bufs["n_in"], bufs["n_out"]):
             xs.append(bufs["x_hit"][3 * oi:3 * (oi + ni)].view(3, ni))
@@ -151,10 +204,11 @@ class DeviceSystem(object):
     def propagate(self, surface, x, k, direction=None, e_re=None, e_im=None,
                   default_e=True, valid_in=None):
         """Material.propagate / Surface.intersect for one surface."""
+        (x, k, direction, e_re, e_im) = [_rows_contiguous(t) for t in (x, k, direction, e_re, e_im)]
         _check_rays(x, "x")
         n = x.shape[1]
         with torch.cuda.device(self.device):
-            x_hit = torch.empty_like(x)
+            x_hit = torch.empty((3, n), dtype=torch.float64, device=self.device)
             valid = torch.empty(n, dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.prt_propagate(self._h, surface, n, _ptr(x), _ptr(k),
                                               _ptr(direction), _ptr(e_re), _ptr(e_im),
@@ -165,6 +219,7 @@ class DeviceSystem(object):
     def interact(self, surface, x_hit, k, valid_in=None, want_e=False):
         """Material.refract / reflect at one surface.  Returns
         (k_out, dir_out, valid_out, e_re, e_im)."""
+        (x_hit, k) = [_rows_contiguous(t) for t in (x_hit, k)]
         _check_rays(x_hit, "x_hit")
         n = x_hit.shape[1]
         aniso = self.records[surface]["material"]["type"] == "anisotropic"
@@ -204,10 +259,9 @@ def compact(mask, arrays, ids=None, flags=None):
     dev = mask.device
     rows_src = []
     for a in arrays:
-        if a.dtype != torch.float64 or not a.is_contiguous() or a.shape[-1] != n:
-            raise ValueError("compact: arrays must be contiguous float64 (R, N)")
-        a2 = a.view(-1, n)
-        rows_src += [a2[r] for r in range(a2.shape[0])]
+        if a.dtype != torch.float64 or a.dim() != 2 or a.shape[1] != n or (n and a.stride(1) != 1):
+            raise ValueError("compact: arrays must be float64 (R, N) with unit stride along N")
+        rows_src += [a[r] for r in range(a.shape[0])]
     nrow = len(rows_src)
     if nrow > 16:
         raise ValueError("compact: at most 16 rows per call")
@@ -226,8 +280,8 @@ def compact(mask, arrays, ids=None, flags=None):
     out = []
     r0 = 0
     for a in arrays:
-        rr = a.view(-1, n).shape[0]
-        out.append(tmp[r0:r0 + rr, :m].contiguous().view(tuple(a.shape[:-1]) + (m,)))
+        rr = a.shape[0]
+        out.append(tmp[r0:r0 + rr, :m].contiguous())
         r0 += rr
     idc = idt[:m].contiguous() if ids is not None else None
     if flags is not None:
@@ -238,6 +292,7 @@ def compact(mask, arrays, ids=None, flags=None):
 def efield_perp(k):
     """a unit E field perpendicular to k on the device (prt_efield_perp)."""
     lib = _lib.load()
+    k = _rows_contiguous(k)
     _check_rays(k, "k")
     with torch.cuda.device(k.device):
         e = torch.empty_like(k)
@@ -246,9 +301,19 @@ def efield_perp(k):
     return e
 
 
-def to_device_rays(a, device):
-    """numpy (3, N) real or zero-imaginary complex -> contiguous float64 device tensor."""
+def to_device_rays(a, device, pitched=True):
+    """numpy (3, N) real or zero-imaginary complex -> float64 device tensor.  With
+    ``pitched`` the rows live in a (3, prt_recommended_pitch(N)) allocation (the returned
+    tensor is its [:, :N] view), so that the fused kernel can use aligned 16-B loads for
+    any N."""
     a = np.asarray(a)
     if np.iscomplexobj(a):
         a = a.real
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+    n = t.shape[1]
+    if not pitched or n == 0:
+        return t.to(device)
+    buf = torch.empty((3, recommended_pitch(n)), dtype=torch.float64, device=device)
+    view = buf[:, :n]
+    view.copy_(t)
+    return view

@@ -40,15 +40,18 @@ def _to_dev(a, device):
             re = a.real.to(device=device, dtype=torch.float64).contiguous()
             im = a.imag.to(device=device, dtype=torch.float64).contiguous()
             return re, (im if bool((im != 0).any()) else None), True
-        return a.to(device=device, dtype=torch.float64).contiguous(), None, False
+        a = a.to(device=device, dtype=torch.float64)
+        if a.dim() == 2 and a.shape[1] > 0 and a.stride(1) != 1:
+            a = a.contiguous()
+        return a, None, False               # row-pitched (3, N) views are kept as they are
     a = np.asarray(a)
     if np.iscomplexobj(a):
-        re = torch.from_numpy(np.ascontiguousarray(a.real, dtype=np.float64)).to(device)
+        re = engine.to_device_rays(a.real, device)
         im = None
         if np.any(a.imag != 0):
-            im = torch.from_numpy(np.ascontiguousarray(a.imag, dtype=np.float64)).to(device)
+            im = engine.to_device_rays(a.imag, device)
         return re, im, True
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device), None, False
+    return engine.to_device_rays(a, device), None, False
 
 
 class RayBundle(object):

@@ -198,6 +198,18 @@ def test_odd_and_tiny_ray_counts(gpu_device):
             assert torch.equal(part.valid[s], full.valid[s][:m])
             assert torch.allclose(part.x_hit[s], full.x_hit[s][:, :m], rtol=0, atol=1e-13)
             assert torch.allclose(part.k_out[s], full.k_out[s][:, :m], rtol=0, atol=1e-14)
+    # tight (unpitched, odd N -> misaligned rows, scalar load/store path) == pitched layout
+    m = n - 1
+    tight_in = [torch.from_numpy(np.ascontiguousarray(a[:, :m])).to(gpu_device) for a in (o, k, e0)]
+    bufs = sysd.alloc_outputs(m, 0, pitch=m)
+    sysd.trace_into(tight_in[0], tight_in[1], bufs, tight_in[2])
+    tight = sysd.views(bufs)
+    assert tight.x_hit[0].is_contiguous() and bufs["pitch"] == m
+    for s in range(len(recs)):
+        assert torch.equal(tight.valid[s], full.valid[s][:m])
+        assert torch.equal(tight.valid_out[s], full.valid_out[s][:m])
+        assert torch.equal(tight.x_hit[s], full.x_hit[s][:, :m])
+        assert torch.equal(tight.k_out[s], full.k_out[s][:, :m])
     empty = sysd.trace(torch.empty((3, 0), dtype=torch.float64, device=gpu_device),
                        torch.empty((3, 0), dtype=torch.float64, device=gpu_device))
     assert empty.x_hit[0].shape == (3, 0)
