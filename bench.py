@@ -100,8 +100,15 @@ def main():
     from pyrate_amd import engine, systems, _lib
     from pyrate_amd import distributed as pdist
 
+    # N = 1: BASELINE configs[1] (d line).  N > 1: configs[4] -- the same lens at the five
+    # wavelengths of the prescription (spd:5), per-wavelength indices from the Conrady fit
+    # through the (d, F, C) indices; step i traces wavelength i % 5.
     records = systems.double_gauss_records()
     S = len(records)
+    if world > 1:
+        record_sets = [systems.double_gauss_records(w) for w in systems.DOUBLE_GAUSS_WAVES_MM]
+    else:
+        record_sets = [records]
     # the global bundle: n_gpus x rays, rank r traces its contiguous slice
     (o, k, e0) = systems.double_gauss_bundle(args.rays * n_gpus)
     n_total = o.shape[1]
@@ -111,7 +118,8 @@ def main():
     k0 = engine.to_device_rays(k[:, lo:hi], dev)
     e0d = engine.to_device_rays(e0[:, lo:hi], dev)
 
-    sysd = engine.DeviceSystem(records, local_rank)
+    sysds = [engine.DeviceSystem(r, local_rank) for r in record_sets]
+    sysd = sysds[0]
     mode = _lib.MODE_PATH if args.mode == "path" else _lib.MODE_IMAGE
     do_gather = (n_gpus > 1) and not args.no_gather
     nbuf = 2 if do_gather else 1
@@ -124,7 +132,7 @@ def main():
         b = bufs[i % nbuf]
         if do_gather:
             gathers[i % nbuf].wait()        # buffer pair i%2 is free once its last gather is done
-        sysd.trace_into(x0, k0, b, e0d)
+        sysds[i % len(sysds)].trace_into(x0, k0, b, e0d)
         if do_gather:
             ev = torch.cuda.Event()
             ev.record(main_stream)
@@ -194,6 +202,7 @@ def main():
                                    "BASELINE configs[1]",
                        "rays_per_gpu": n_local, "rays_total": n_total, "surfaces": S,
                        "mode": args.mode, "sharding": "rays" if n_gpus > 1 else "none",
+                       "wavelengths": len(sysds),
                        "image_plane_gather": ("rccl all-gather, overlapped" if do_gather else "none")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -186,6 +186,20 @@ int32_t prt_shape_eval(const prt_system_t *sys, int32_t surface, int64_t n, cons
 int32_t prt_efield_perp(int32_t device, int64_t n, const double *k, double *e_out, void *stream);
 
 /*
+ * Moments of a (3,n) point array (row pitch `pitch`, 0 = n) over the rays whose mask byte is
+ * non-zero (mask NULL = all):  out7 (HOST) = { count, sum(v) [3], sum(v^2) [3] } with
+ *   mode 0: v = x - ref          (ref: HOST, 3 doubles, NULL = origin)   centroid / RMS spot
+ *   mode 1: v = x/|x|            unit directions of wave vectors          centroid direction
+ *   mode 2: v = (x/|x|) x ref    cross product with a reference direction RMS angular size
+ * Deterministic two-stage reduction; synchronises the stream.  Replaces the NumPy reductions of
+ * RayBundleAnalysis.get_centroid_position / get_rms_spot_size / get_centroid_direction /
+ * get_rms_angluar_size (raytracer/analysis/ray_analysis.py:44-134).
+ */
+int32_t prt_bundle_moments(int32_t device, int64_t n, int64_t pitch, const double *x,
+                           const uint8_t *mask, int32_t mode, const double *ref, double *out7,
+                           void *stream);
+
+/*
  * Order-preserving compaction by mask (the reference's [:, valid] indexing):
  * n_arrays (<= 16) row pointers of n doubles each (src[r] -> dst[r]; the pointer
  * tables themselves are HOST arrays of device pointers), plus an optional int64

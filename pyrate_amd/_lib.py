@@ -59,6 +59,10 @@ PROTOTYPES = {
                                         c_stream]),
     "prt_efield_perp": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p,
                                          c_stream]),
+    "prt_bundle_moments": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int64,
+                                            c_double_p, c_u8_p, ctypes.c_int32,
+                                            ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_double), c_stream]),
     "prt_compact_scratch_bytes": (ctypes.c_int64, [ctypes.c_int64]),
     "prt_compact": (ctypes.c_int32, [ctypes.c_int64, c_u8_p, ctypes.c_int32,
                                      ctypes.POINTER(ctypes.c_void_p),

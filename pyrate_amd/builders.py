@@ -76,3 +76,15 @@ def build_simple_optical_system(builduplist, material_db_path="", name=""):
     s.addElement(elem_name, elem)
     s.material_background.set_name("background")
     return (s, [elem_seq])
+
+
+def raytrace(s, seq, numrays, rays_dict, bundletype="collimated", traceoptions=None, wave=None):
+    """convenience entry of the README / demos (pyrateoptics/__init__.py:457-465)"""
+    from .raytracer.analysis.optical_system_analysis import OpticalSystemAnalysis
+    from .raytracer.globalconstants import standard_wavelength
+    if traceoptions is None:
+        traceoptions = {}
+    osa = OpticalSystemAnalysis(s, seq)
+    osa.aim(numrays, rays_dict, bundletype=bundletype,
+            wave=standard_wavelength if wave is None else wave)
+    return osa.trace(**traceoptions)[0]

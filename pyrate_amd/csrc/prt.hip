@@ -327,6 +327,74 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_efield_perp(int64_t N, const doub
 }
 
 // ---------------------------------------------------------------------------
+// bundle moments: count, sum (x - ref), sum (x - ref)^2 per component over the rays whose
+// mask byte is non-zero (all rays if mask == NULL).  Two deterministic stages (fixed
+// summation order, no atomics): grid-stride partials per block, then one block adds the
+// partials.  Feeds RayBundleAnalysis.get_centroid_position / get_rms_spot_size
+// (analysis/ray_analysis.py:44-86) and turns the multi-GPU image-plane exchange into a
+// 7-double all-reduce.
+// ---------------------------------------------------------------------------
+#define MOM_VALUES 7
+__global__ __launch_bounds__(PRT_BLOCK) void k_moments_partial(int64_t N, int64_t pitch,
+                                                               const double *__restrict__ x,
+                                                               const uint8_t *__restrict__ mask,
+                                                               int32_t mode, double rx, double ry,
+                                                               double rz,
+                                                               double *__restrict__ partials) {
+    double acc[MOM_VALUES] = {0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x; i < N;
+         i += (int64_t)gridDim.x * PRT_BLOCK) {
+        if (mask && !mask[i]) continue;
+        double dx = x[i], dy = x[pitch + i], dz = x[2 * pitch + i];
+        if (mode == 0) {  // points relative to ref
+            dx -= rx;
+            dy -= ry;
+            dz -= rz;
+        } else {  // unit directions (ray.py:136-152 for E perpendicular to k), optionally x ref
+            const vec3 u = normalized(v3(dx, dy, dz));
+            dx = u.x;
+            dy = u.y;
+            dz = u.z;
+            if (mode == 2) {
+                const vec3 c = cross(u, v3(rx, ry, rz));
+                dx = c.x;
+                dy = c.y;
+                dz = c.z;
+            }
+        }
+        acc[0] += 1.0;
+        acc[1] += dx;
+        acc[2] += dy;
+        acc[3] += dz;
+        acc[4] += dx * dx;
+        acc[5] += dy * dy;
+        acc[6] += dz * dz;
+    }
+    __shared__ double sh[PRT_BLOCK / 64][MOM_VALUES];
+#pragma unroll
+    for (int q = 0; q < MOM_VALUES; ++q) {
+        double v = acc[q];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < MOM_VALUES) {
+        double v = 0.0;
+        for (int w = 0; w < PRT_BLOCK / 64; ++w) v += sh[w][threadIdx.x];
+        partials[(int64_t)blockIdx.x * MOM_VALUES + threadIdx.x] = v;
+    }
+}
+
+__global__ void k_moments_final(int nblocks_, const double *__restrict__ partials,
+                                double *__restrict__ out) {
+    if (threadIdx.x < MOM_VALUES) {
+        double v = 0.0;
+        for (int b = 0; b < nblocks_; ++b) v += partials[(int64_t)b * MOM_VALUES + threadIdx.x];
+        out[threadIdx.x] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // compaction: per-block popcount -> single-block scan of block totals -> scatter
 // ---------------------------------------------------------------------------
 #define CMP_ITEMS 4  // mask bytes per thread (one 32-bit load)
@@ -811,6 +879,36 @@ int32_t prt_efield_perp(int32_t device, int64_t n, const double *k, double *e_ou
     hipLaunchKernelGGL(k_efield_perp, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                        (hipStream_t)stream, n, k, e_out);
     HIP_TRY(hipGetLastError());
+    return PRT_OK;
+}
+
+int32_t prt_bundle_moments(int32_t device, int64_t n, int64_t pitch, const double *x,
+                           const uint8_t *mask, int32_t mode, const double *ref, double *out7,
+                           void *stream) {
+    if (n < 0 || !out7 || mode < 0 || mode > 2)
+        return fail(PRT_ERR_INVALID_ARG, "prt_bundle_moments: bad argument");
+    for (int q = 0; q < MOM_VALUES; ++q) out7[q] = 0.0;
+    if (n == 0) return PRT_OK;
+    if (!x) return fail(PRT_ERR_INVALID_ARG, "prt_bundle_moments: null pointer");
+    if (pitch == 0) pitch = n;
+    if (pitch < n) return fail(PRT_ERR_INVALID_ARG, "prt_bundle_moments: pitch < n");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    int nb = (int)((n + PRT_BLOCK * 8 - 1) / (PRT_BLOCK * 8));
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    double *scratch = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&scratch, sizeof(double) * MOM_VALUES * (nb + 1), st));
+    const double rx = ref ? ref[0] : 0.0, ry = ref ? ref[1] : 0.0, rz = ref ? ref[2] : 0.0;
+    hipLaunchKernelGGL(k_moments_partial, dim3(nb), dim3(PRT_BLOCK), 0, st, n, pitch, x, mask, mode, rx,
+                       ry, rz, scratch);
+    hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(64), 0, st, nb, scratch,
+                       scratch + (int64_t)nb * MOM_VALUES);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out7, scratch + (int64_t)nb * MOM_VALUES, sizeof(double) * MOM_VALUES,
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipFreeAsync(scratch, st));
     return PRT_OK;
 }
 

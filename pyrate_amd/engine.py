@@ -289,6 +289,26 @@ def compact(mask, arrays, ids=None, flags=None):
     return out, idc
 
 
+def bundle_moments(x, mask=None, ref=None, mode=0):
+    """(count, sum(v) (3,), sum(v**2) (3,)) of a (3, N) device array over the rays with
+    mask != 0 (prt_bundle_moments); mode 0: v = x - ref, 1: v = x/|x|, 2: v = x/|x| cross ref.
+    x may be a row-pitched view."""
+    lib = _lib.load()
+    pitch = _check_rays(x, "x", allow_pitch=True)
+    n = x.shape[1]
+    out = (ctypes.c_double * 7)()
+    refc = None
+    if ref is not None:
+        refc = (ctypes.c_double * 3)(*[float(v) for v in ref])
+    if mask is not None and (mask.dtype != torch.uint8 or not mask.is_contiguous() or mask.shape[0] != n):
+        raise ValueError("mask must be a contiguous (N,) uint8 tensor")
+    with torch.cuda.device(x.device):
+        _lib.check(lib.prt_bundle_moments(x.device.index, n, pitch, _ptr(x), _ptr(mask), mode, refc, out,
+                                          _stream_handle(x.device)))
+    v = np.array(list(out))
+    return v[0], v[1:4], v[4:7]
+
+
 def efield_perp(k):
     """a unit E field perpendicular to k on the device (prt_efield_perp)."""
     lib = _lib.load()

@@ -1,0 +1,75 @@
+"""``OpticalSystemAnalysis``: bundle generation + trace convenience with the reference's
+signatures (raytracer/analysis/optical_system_analysis.py:44-191).  For the isotropic
+background medium the dispersion relation gives k = n * unitvector directly (the reference
+runs a per-ray scipy.linalg.eig for the same result, material/material.py:456-499); E is
+*a* unit vector perpendicular to k, like the reference's eigenvector."""
+import math
+
+import numpy as np
+
+from ... import engine
+from ...sampling2d.raster import RectGrid
+from ..globalconstants import degree, standard_wavelength
+from ..ray import RayBundle, default_device
+
+
+def _perp_field(k):
+    """unit E perpendicular to each k on the device (prt_efield_perp), back as numpy"""
+    kd = engine.to_device_rays(k, default_device())
+    return engine.efield_perp(kd).cpu().numpy()
+
+
+class OpticalSystemAnalysis(object):
+    kind = "opticalsystemanalysis"
+
+    def __init__(self, os, seq, name=""):
+        self.opticalsystem = os
+        self.sequence = seq
+        self.name = name
+        self.initial_bundles = None
+
+    def _background_index(self, wave):
+        mat = self.opticalsystem.material_background
+        if not hasattr(mat, "get_optical_index"):
+            raise Exception("bundle generation needs an isotropic background medium")
+        return float(mat.get_optical_index(np.zeros((3, 1)), wave))
+
+    def collimated_bundle(self, nrays, properties_dict=None, wave=standard_wavelength):
+        """(:83-122) keys: startx, starty, startz, raster, radius, anglex, angley"""
+        pd = properties_dict or {}
+        (startx, starty, startz) = (pd.get("startx", 0.), pd.get("starty", 0.), pd.get("startz", 0.))
+        rasterobj = pd.get("raster", RectGrid())
+        radius = pd.get("radius", 1.0)
+        (angley, anglex) = (pd.get("angley", 0.0), pd.get("anglex", 0.0))
+        (px, py) = rasterobj.getGrid(nrays)
+        origin = np.vstack((radius * px + startx, radius * py + starty, startz * np.ones_like(px)))
+        unit = np.zeros_like(origin)
+        unit[0, :] = math.sin(angley) * math.cos(anglex)
+        unit[1, :] = math.sin(anglex)
+        unit[2, :] = math.cos(angley) * math.cos(anglex)
+        k = self._background_index(wave) * unit
+        return (origin, k, _perp_field(k))
+
+    def divergent_bundle(self, nrays, properties_dict=None, wave=standard_wavelength):
+        """(:124-165) keys: startx, starty, startz, raster, radius (half cone angle), anglex, angley"""
+        pd = properties_dict or {}
+        (startx, starty, startz) = (pd.get("startx", 0.), pd.get("starty", 0.), pd.get("startz", 0.))
+        rasterobj = pd.get("raster", RectGrid())
+        radius = pd.get("radius", 45.0 * degree)
+        (angley, anglex) = (pd.get("angley", 0.0), pd.get("anglex", 0.0))
+        (ax, ay) = rasterobj.getGrid(nrays)
+        origin = np.vstack((startx * np.ones_like(ax), starty * np.ones_like(ax), startz * np.ones_like(ax)))
+        unit = np.zeros_like(origin)
+        unit[0, :] = np.sin(angley + radius * ax) * np.cos(anglex + radius * ay)
+        unit[1, :] = np.sin(anglex + radius * ay)
+        unit[2, :] = np.cos(angley + radius * ax) * np.cos(anglex + radius * ay)
+        k = self._background_index(wave) * unit
+        return (origin, k, _perp_field(k))
+
+    def aim(self, numrays, rays_dict, bundletype="collimated", wave=standard_wavelength):
+        call = {"collimated": self.collimated_bundle, "divergent": self.divergent_bundle}
+        (o, k, e) = call[bundletype](numrays, rays_dict, wave=wave)
+        self.initial_bundles = [RayBundle(x0=o, k0=k, Efield0=e, wave=wave)]
+
+    def trace(self, **kwargs):
+        return [self.opticalsystem.seqtrace(ib, self.sequence, **kwargs) for ib in self.initial_bundles]

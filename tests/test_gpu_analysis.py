@@ -1,0 +1,124 @@
+"""GPU tests of the analysis layer: device reductions behind
+RayBundleAnalysis against the reference's own known answers
+(reference tests/test_ray_analysis.py:34-112) and against NumPy on traced bundles;
+OpticalSystemAnalysis / raytrace() convenience."""
+import math
+
+import numpy as np
+import pytest
+
+import _golden
+import systems_zoo as zoo
+from pyrate_amd import systems
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rb5(gpu_device):
+    from pyrate_amd.raytracer.ray import RayBundle
+    k0 = np.zeros((3, 5))
+    k0[2, :] = 1
+    e0 = np.zeros((3, 5))
+    e0[1, :] = 1.
+    return RayBundle(x0=np.array([[1., 0, 0, 1, 2], [0, 1., 0, 1, 2], [0, 0, 1., 1, 2]]), k0=k0, Efield0=e0)
+
+
+def test_reference_known_answers(rb5):
+    from pyrate_amd.raytracer.analysis.ray_analysis import RayBundleAnalysis
+    ra = RayBundleAnalysis(rb5)
+    assert np.allclose(ra.get_centroid_position(), 4. / 5.)
+    assert np.isclose(ra.get_rms_spot_size(np.array([0, 0, 0])), math.sqrt(18.0 / 4.0))
+    assert np.allclose(ra.get_centroid_direction(), np.array([0, 0, 1]))
+    ang = ra.get_rms_angluar_size(np.array([math.sin(math.pi / 180.0), 0, math.cos(math.pi / 180.0)]))
+    assert np.isclose(ang, math.pi / 180.0)
+
+
+def test_arc_length_known_answer(gpu_device):
+    from pyrate_amd.raytracer.ray import RayBundle
+    from pyrate_amd.raytracer.analysis.ray_analysis import RayBundleAnalysis
+    k0 = np.zeros((3, 2))
+    e0 = np.zeros((3, 2))
+    rb = RayBundle(x0=np.zeros((3, 2)), k0=k0, Efield0=e0)
+    valid = np.ones(2, dtype=bool)
+    for x in ([[1, 0], [0, 0], [0, 0]], [[1, 1], [1, 1], [0, 0]], [[0, 2], [1, 2], [0, 0]], [[0, 3], [0, 3], [0, 0]]):
+        rb.append(np.array(x, dtype=float), k0, e0, valid)
+    assert np.allclose(RayBundleAnalysis(rb).get_arc_length(), np.array([4., 3 * np.sqrt(2)]))
+
+
+def test_spot_statistics_of_traced_bundle_match_numpy(gpu_device):
+    """image bundle of the double Gauss (5 deg field): device moments == NumPy, and the
+    on-axis RMS radius about the origin reproduces the survey's known answer (SURVEY 8c:
+    9917 rays, rpup 5, z0 -10: 0.4450661837097206 mm)."""
+    from pyrate_amd.builders import build_rotationally_symmetric_optical_system
+    from pyrate_amd.raytracer.ray import RayBundle
+    from pyrate_amd.raytracer.analysis.ray_analysis import RayBundleAnalysis
+    (s, seq) = build_rotationally_symmetric_optical_system(systems.double_gauss_tuples())
+    (o, k, e0) = systems.double_gauss_bundle(10000)
+    assert o.shape[1] == 9917
+    img = s.seqtrace(RayBundle(o, k, e0, wave=systems.DLINE), seq)[0].raybundles[-1]
+    x = img.x[-1]
+    rms_origin = math.sqrt(np.sum(x[0] ** 2 + x[1] ** 2) / x.shape[1])
+    assert abs(rms_origin - 0.4450661837097206) < 1e-12
+    (o, k, e0) = systems.double_gauss_bundle(200000, field_deg=5.0)
+    img = s.seqtrace(RayBundle(o, k, e0, wave=systems.DLINE), seq)[0].raybundles[-1]
+    ra = RayBundleAnalysis(img)
+    x = img.x[-1]
+    cen = np.sum(x, axis=1) / (x.shape[1] + 1e-17)
+    assert np.allclose(ra.get_centroid_position(), cen, rtol=1e-13, atol=1e-13)
+    rms = math.sqrt(np.sum((x - cen[:, None]) ** 2) / (x.shape[1] - 1 + 1e-17))
+    assert abs(ra.get_rms_spot_size_centroid() - rms) < 1e-12 * max(1.0, rms)
+    d = np.real(img.k[-1])
+    d = d / np.sqrt(np.sum(d ** 2, axis=0))
+    com = np.sum(d, axis=1)
+    assert np.allclose(ra.get_centroid_direction(), com / np.linalg.norm(com), rtol=0, atol=1e-13)
+    ref = com / np.linalg.norm(com)
+    ang = math.asin(math.sqrt(np.sum(np.cross(d, ref, axisa=0).T ** 2) / d.shape[1]))
+    assert abs(ra.get_rms_angluar_size_centroid() - ang) < 1e-12
+
+
+def test_masked_moments_on_dense_engine_output(gpu_device):
+    """engine level: moments over valid_out of the dense, row-pitched image-plane arrays"""
+    from pyrate_amd import engine
+    case = _golden.load_case("double_gauss_wide")
+    sysd = engine.DeviceSystem(case.table, 0)
+    res = sysd.trace(engine.to_device_rays(case.x0, gpu_device), engine.to_device_rays(case.k0, gpu_device),
+                     engine.to_device_rays(case.E0, gpu_device))
+    (cnt, s1, s2) = engine.bundle_moments(res.x_hit[-1], mask=res.valid_out[-1])
+    m = res.valid_out[-1].cpu().numpy().astype(bool)
+    x = res.x_hit[-1].cpu().numpy()[:, m]
+    assert cnt == m.sum() == 277
+    assert np.allclose(s1, x.sum(axis=1), rtol=1e-13) and np.allclose(s2, (x ** 2).sum(axis=1), rtol=1e-13)
+
+
+def test_raytrace_convenience_readme_example(gpu_device):
+    """README singlet (README.md:200-210): raytrace(s, seq, 11, {"radius": 9.0}) -> 12 rays,
+    5 bundles; ray 0 image point / k from SURVEY 8c"""
+    from pyrate_amd.builders import build_rotationally_symmetric_optical_system, raytrace
+    (s, seq) = build_rotationally_symmetric_optical_system(
+        [(100., 0, 20., 1.5, "front", {}), (-100., 0, 5., None, "back", {}), (0, 0, 100., None, "image", {})])
+    r = raytrace(s, seq, 11, {"radius": 9.0})
+    assert len(r) == 1 and len(r[0].raybundles) == 5
+    img = r[0].raybundles[-1]
+    assert img.x.shape == (1, 3, 12)
+    assert np.allclose(img.x[-1][:, 0], [6.0134358655051567e-02, 1.8040307596514893e-01, 125.0], rtol=0, atol=1e-12)
+    assert np.allclose(np.real(img.k[-1][:, 0]), [0.02810922264455102, 0.08432766793365307, 0.9960415232424753],
+                       rtol=0, atol=1e-13)
+
+
+def test_optical_system_analysis_bundles(gpu_device):
+    from pyrate_amd.raytracer.analysis.optical_system_analysis import OpticalSystemAnalysis
+    from pyrate_amd.sampling2d import raster
+    api = zoo.mirror_api()
+    (s, seq) = zoo.doublet(api)
+    osa = OpticalSystemAnalysis(s, seq)
+    ref = _golden.load_case("doublet_clipped")       # reference collimated_bundle(300, radius 14.5, anglex 0.03)
+    (o, k, e) = osa.collimated_bundle(300, {"startz": -5., "radius": 14.5, "anglex": 0.03}, wave=zoo.DLINE)
+    assert np.array_equal(o, ref.x0)
+    assert np.allclose(k, np.real(ref.k0), rtol=0, atol=1e-15)
+    assert np.allclose(np.sum(e * k, axis=0), 0, atol=1e-15) and np.allclose(np.sum(e * e, axis=0), 1)
+    (o, k, e) = osa.divergent_bundle(50, {"radius": 0.1, "raster": raster.MeridionalFan()})
+    assert o.shape == (3, 50) and np.allclose(np.sum(k * k, axis=0), 1.0)
+    osa.aim(20, {"startz": -5., "radius": 11.43, "raster": raster.MeridionalFan()}, wave=zoo.DLINE)
+    r2 = osa.trace()[0]
+    assert len(r2[0].raybundles) == 7 and r2[0].raybundles[-1].x.shape == (1, 3, 20)
