@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""BASELINE config 2: the 12-surface double Gauss (Rudolph 1897 prescription from the
+reference's demos/data/double_gauss_rudolph_1897_v2.spd, constant d/F/C indices), three
+fields x three wavelengths like the merit function of demos/demo_doublegauss.py:189-252,
+traced on the GPU; prints the RMS spot sizes."""
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+import numpy as np
+
+from pyrate_amd import systems
+from pyrate_amd.builders import build_rotationally_symmetric_optical_system
+from pyrate_amd.raytracer.analysis.ray_analysis import RayBundleAnalysis
+from pyrate_amd.raytracer.ray import RayBundle
+
+
+def main(nrays=100000):
+    waves = {"F": 486.1e-6, "d": 587.6e-6, "C": 656.3e-6}
+    for (wname, wave) in waves.items():
+        (s, seq) = build_rotationally_symmetric_optical_system(systems.double_gauss_tuples(wave))
+        for field in (0.0, 3.5, 5.0):
+            (o, k, e0) = systems.double_gauss_bundle(nrays, field_deg=field)
+            rpaths = s.seqtrace(RayBundle(o, k, e0, wave=wave), seq)
+            img = rpaths[0].raybundles[-1]
+            ra = RayBundleAnalysis(img)
+            print("double Gauss  line %s  field %.1f deg : %7d / %7d rays, RMS spot %.5f mm, centroid y %.4f mm"
+                  % (wname, field, img.x.shape[2], o.shape[1], ra.get_rms_spot_size_centroid(),
+                     ra.get_centroid_position()[1]))
+
+
+if __name__ == "__main__":
+    main(int(float(sys.argv[1])) if len(sys.argv) > 1 else 100000)

@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""BASELINE config 1: the cemented doublet of the reference's demos/demo_doublet.py:48-101
+(5 surfaces, ConstantIndexGlass, circular apertures), built object by object with the
+mirror classes and traced on the GPU.  Prints the image-plane spot instead of drawing."""
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+import numpy as np
+
+from pyrate_amd.builders import raytrace
+from pyrate_amd.raytracer.analysis.ray_analysis import RayBundleAnalysis
+from pyrate_amd.raytracer.aperture import CircularAperture
+from pyrate_amd.raytracer.localcoordinates import LocalCoordinates
+from pyrate_amd.raytracer.material.material_isotropic import ConstantIndexGlass
+from pyrate_amd.raytracer.optical_element import OpticalElement
+from pyrate_amd.raytracer.optical_system import OpticalSystem
+from pyrate_amd.raytracer.surface import Surface
+from pyrate_amd.raytracer.surface_shape import Conic
+from pyrate_amd.sampling2d import raster
+
+wavelength = 0.5876e-3
+
+
+def build():
+    s = OpticalSystem.p()
+    lc0 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="stop", decz=0.0),
+                                     refname=s.rootcoordinatesystem.name)
+    lc1 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="surf1", decz=-1.048), refname=lc0.name)
+    lc2 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="surf2", decz=4.0), refname=lc1.name)
+    lc3 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="surf3", decz=2.5), refname=lc2.name)
+    lc4 = s.addLocalCoordinateSystem(LocalCoordinates.p(name="image", decz=97.2), refname=lc3.name)
+    elem = OpticalElement.p(lc0, name="thorlabs_AC_254-100-A")
+    elem.addMaterial("BK7", ConstantIndexGlass.p(lc1, n=1.5168))
+    elem.addMaterial("SF5", ConstantIndexGlass.p(lc2, n=1.6727))
+    ap = dict(maxradius=12.7)
+    elem.addSurface("stop", Surface.p(lc0), (None, None))
+    elem.addSurface("front", Surface.p(lc1, shape=Conic.p(lc1, curv=1. / 62.8),
+                                       aperture=CircularAperture.p(lc1, **ap)), (None, "BK7"))
+    elem.addSurface("cement", Surface.p(lc2, shape=Conic.p(lc2, curv=-1. / 45.7),
+                                        aperture=CircularAperture.p(lc2, **ap)), ("BK7", "SF5"))
+    elem.addSurface("rear", Surface.p(lc3, shape=Conic.p(lc3, curv=-1. / 128.2),
+                                      aperture=CircularAperture.p(lc3, **ap)), ("SF5", None))
+    elem.addSurface("image", Surface.p(lc4), (None, None))
+    s.addElement("AC254-100", elem)
+    sysseq = [("AC254-100", [("stop", {"is_stop": True}), ("front", {}), ("cement", {}),
+                             ("rear", {}), ("image", {})])]
+    return (s, sysseq)
+
+
+def main(nrays=20, rast=None):
+    (s, sysseq) = build()
+    r2 = raytrace(s, sysseq, nrays, {"startz": -5, "radius": 11.43,
+                                     "raster": rast or raster.MeridionalFan()}, wave=wavelength)[0]
+    img = r2.raybundles[-1]
+    ra = RayBundleAnalysis(img)
+    print("doublet: %d rays reach the image plane, RMS spot radius %.6f mm, centroid %s"
+          % (img.x.shape[2], ra.get_rms_spot_size_centroid(), np.array2string(ra.get_centroid_position(), precision=6)))
+    return r2
+
+
+if __name__ == "__main__":
+    main()
+    main(10000, raster.RectGrid())

@@ -78,3 +78,32 @@ class ImagePlaneGather(object):
             f = torch.cat([self.recv_f[r, :, :s] for (r, s) in enumerate(self.sizes)], dim=1)
             v = torch.cat([self.recv_v[r, :s] for (r, s) in enumerate(self.sizes)])
         return f[0:3], f[3:6], v
+
+
+def global_spot_statistics(x_img, valid=None, group=None, moments_fn=None):
+    """Centroid and RMS spot radius (about the centroid) of a ray-sharded image plane without
+    gathering it: every rank reduces its shard on the device (prt_bundle_moments), then two
+    7-double all-reduces combine the shards ("all-reduce of (sum x, sum x^2,
+    count) replaces the all-gather").  Same formulas as RayBundleAnalysis
+    (analysis/ray_analysis.py:44-86).  Returns (count, centroid (3,), rms)."""
+    import numpy as np
+    if moments_fn is None:
+        from . import engine
+        moments_fn = engine.bundle_moments
+    dev = x_img.device
+
+    def allreduce(vec):
+        if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+            return vec
+        t = torch.tensor(vec, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t.cpu().numpy()
+
+    (cnt, s1, _) = moments_fn(x_img, valid)
+    tot = allreduce(np.concatenate(([cnt], s1)))
+    count = tot[0]
+    centroid = tot[1:4] / (count + 1e-17)
+    (_, _, s2) = moments_fn(x_img, valid, centroid)
+    tot2 = allreduce(np.concatenate(([0.0], s2)))
+    rms = float(np.sqrt(np.sum(tot2[1:4]) / (count - 1 + 1e-17)))
+    return count, centroid, rms

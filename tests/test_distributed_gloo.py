@@ -53,6 +53,20 @@ def _worker(rank, world, port, n_total, q):
                 torch.from_numpy(v[lo:hi].copy()))
         (gx, _, _) = g.finish()
         ok = ok and bool(np.array_equal(gx.numpy(), 2 * x))
+        # sharded spot statistics == statistics of the whole bundle (NumPy stand-in for the
+        # device reduction: this test runs without a GPU; the all-reduce plumbing is what it checks)
+        def np_moments(xs, mask=None, ref=None):
+            a = xs.numpy()
+            m = np.ones(a.shape[1], dtype=bool) if mask is None else mask.numpy().astype(bool)
+            r = np.zeros(3) if ref is None else np.asarray(ref)
+            dlt = a[:, m] - r[:, None]
+            return float(m.sum()), dlt.sum(axis=1), (dlt ** 2).sum(axis=1)
+        (cnt, cen, rms) = pdist.global_spot_statistics(torch.from_numpy(x[:, lo:hi].copy()),
+                                                       torch.from_numpy(v[lo:hi].copy()), moments_fn=np_moments)
+        m = v.astype(bool)
+        cen_ref = x[:, m].sum(axis=1) / m.sum()
+        rms_ref = np.sqrt(((x[:, m] - cen_ref[:, None]) ** 2).sum() / (m.sum() - 1))
+        ok = ok and cnt == m.sum() and bool(np.allclose(cen, cen_ref, rtol=1e-13)) and abs(rms - rms_ref) < 1e-13
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
