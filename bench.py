@@ -44,7 +44,7 @@ def algorithmic_bytes(n_rays, n_surfaces, with_e0=True):
     return n_rays * ((72 if with_e0 else 48) + 50 * n_surfaces)
 
 
-def cpu_baseline(records, o, k, e0, target_rays=4_000_000, chunk=100_000):
+def cpu_baseline(records, o, k, e0, target_rays=4_000_000, chunk=100_000, n_all=None):
     """the CPU oracle (NumPy port of the reference algorithm, geometry only -- i.e.
     WITHOUT the reference's SVD E-field step that is 91% of its time) on a bounded
     sample of the same workload, single process."""
@@ -67,7 +67,7 @@ def cpu_baseline(records, o, k, e0, target_rays=4_000_000, chunk=100_000):
     S = len(records)
     return {"value": n * S / dt, "unit": "ray-surface-ops/s", "cores": 1, "kind": "port",
             "sample": "first %d of the %d rays x %d surfaces, chunks of %d, NumPy oracle "
-                      "(geometry only), %.1f s" % (n, o.shape[1], S, chunk, dt),
+                      "(geometry only), %.1f s" % (n, n_all or o.shape[1], S, chunk, dt),
             "with_svd_efield": {"value": m * S / dt_e, "sample": "%d rays, %.1f s" % (m, dt_e)},
             "host_cpus": os.cpu_count()}
 
@@ -109,14 +109,12 @@ def main():
         record_sets = [systems.double_gauss_records(w) for w in systems.DOUBLE_GAUSS_WAVES_MM]
     else:
         record_sets = [records]
-    # the global bundle: n_gpus x rays, rank r traces its contiguous slice
-    (o, k, e0) = systems.double_gauss_bundle(args.rays * n_gpus)
-    n_total = o.shape[1]
+    # the global bundle: n_gpus x rays (RectGrid disk raster, generated on the device,
+    # bit-identical to the NumPy raster of the reference); rank r owns a contiguous slice
+    (_, n_total) = engine.rect_grid_count(args.rays * n_gpus, dev)
     (lo, hi) = pdist.shard_range(n_total, rank, n_gpus)
     n_local = hi - lo
-    x0 = engine.to_device_rays(o[:, lo:hi], dev)
-    k0 = engine.to_device_rays(k[:, lo:hi], dev)
-    e0d = engine.to_device_rays(e0[:, lo:hi], dev)
+    (x0, k0, e0d, _) = systems.double_gauss_bundle_device(args.rays * n_gpus, dev, lo=lo, hi=hi)
 
     sysds = [engine.DeviceSystem(r, local_rank) for r in record_sets]
     sysd = sysds[0]
@@ -212,7 +210,9 @@ def main():
                          "frac_at_98B_per_op_convention": (n_local * S * 98 / (kernel_ms * 1e-3) / 1e9) / HBM_PEAK_GBS},
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(records, o, k, e0)
+            m = min(n_local, 4_000_000)
+            out["cpu_baseline"] = cpu_baseline(records, x0[:, :m].cpu().numpy(), k0[:, :m].cpu().numpy(),
+                                               e0d[:, :m].cpu().numpy(), n_all=n_local)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -186,6 +186,27 @@ int32_t prt_shape_eval(const prt_system_t *sys, int32_t surface, int64_t n, cons
 int32_t prt_efield_perp(int32_t device, int64_t n, const double *k, double *e_out, void *stream);
 
 /*
+ * Device-side bundle generation: RectGrid.getGrid (sampling2d/raster.py:40-60, square raster
+ * clipped to the unit disk, row-major order, reproduced bit-exactly) +
+ * OpticalSystemAnalysis.collimated_bundle (analysis/optical_system_analysis.py:83-122) for an
+ * isotropic background: origin = radius*p + start, k and E constant over the bundle.
+ *   prt_rect_grid_count: number of samples per dimension and inside the disk for a requested
+ *                        ray count (the raster returns "approximately nray" points).
+ *   prt_collimated_bundle: writes rays [lo, hi) of that raster (a rank's shard, or 0..n_in_disk)
+ *                        into (3, pitch) arrays x_out, k_out and (optionally) e_out.
+ */
+typedef struct prt_collimated {
+    double radius, startx, starty, startz;
+    double k[3]; /* n * unit vector (optical_system_analysis.py:110-118) */
+    double e[3]; /* E field of every ray                                  */
+} prt_collimated_t;
+int32_t prt_rect_grid_count(int32_t device, int64_t nray, int64_t *n_per_dim, int64_t *n_in_disk,
+                            void *stream);
+int32_t prt_collimated_bundle(int32_t device, int64_t nray, int64_t lo, int64_t hi,
+                              const prt_collimated_t *prm, int64_t pitch, double *x_out,
+                              double *k_out, double *e_out, void *stream);
+
+/*
  * Moments of a (3,n) point array (row pitch `pitch`, 0 = n) over the rays whose mask byte is
  * non-zero (mask NULL = all):  out7 (HOST) = { count, sum(v) [3], sum(v^2) [3] } with
  *   mode 0: v = x - ref          (ref: HOST, 3 doubles, NULL = origin)   centroid / RMS spot

@@ -71,6 +71,20 @@ PROTOTYPES = {
                                      ctypes.POINTER(ctypes.c_int64), c_stream]),
 }
 
+class PrtCollimated(ctypes.Structure):
+    """ctypes mirror of prt_collimated_t"""
+    _fields_ = [("radius", ctypes.c_double), ("startx", ctypes.c_double), ("starty", ctypes.c_double),
+                ("startz", ctypes.c_double), ("k", ctypes.c_double * 3), ("e", ctypes.c_double * 3)]
+
+
+PROTOTYPES["prt_rect_grid_count"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int64,
+                                                     ctypes.POINTER(ctypes.c_int64),
+                                                     ctypes.POINTER(ctypes.c_int64), c_stream])
+PROTOTYPES["prt_collimated_bundle"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int64,
+                                                       ctypes.c_int64, ctypes.POINTER(PrtCollimated),
+                                                       ctypes.c_int64, c_double_p, c_double_p,
+                                                       c_double_p, c_stream])
+
 _lib = None
 
 

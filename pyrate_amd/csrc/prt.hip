@@ -17,12 +17,15 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <new>
 #include "prt_device.h"
 #include "prt_aniso.h"
 
 #define PRT_BLOCK 256
+#define CMP_ITEMS 4  // mask bytes per thread in the compaction / raster kernels
+#define CMP_TILE (PRT_BLOCK * CMP_ITEMS)
 
 // ---------------------------------------------------------------------------
 // host-side state
@@ -397,8 +400,6 @@ __global__ void k_moments_final(int nblocks_, const double *__restrict__ partial
 // ---------------------------------------------------------------------------
 // compaction: per-block popcount -> single-block scan of block totals -> scatter
 // ---------------------------------------------------------------------------
-#define CMP_ITEMS 4  // mask bytes per thread (one 32-bit load)
-#define CMP_TILE (PRT_BLOCK * CMP_ITEMS)
 
 __global__ __launch_bounds__(PRT_BLOCK) void k_compact_count(const uint8_t *__restrict__ mask,
                                                              int64_t N,
@@ -482,6 +483,94 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_compact_scatter(
             if (u8_src) u8_dst[pos] = u8_src[base + q];
             ++pos;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// device-side bundle generation: RectGrid.getGrid (sampling2d/raster.py:40-60) +
+// OpticalSystemAnalysis.collimated_bundle (analysis/optical_system_analysis.py:83-122).
+// The raster is reproduced BIT-EXACTLY: numpy.linspace is i*step + start with two
+// roundings and the last sample forced to `stop`; the disk test is x*x + y*y <= 1 with
+// separate roundings -- hence the explicit _rn intrinsics (no FMA contraction).
+// ---------------------------------------------------------------------------
+// a*b and a+b rounded separately: HIP's __dmul_rn/__dadd_rn are plain operators that hipcc
+// contracts into FMAs, so contraction is switched off per statement instead
+PRT_DEV double mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+PRT_DEV double add_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+PRT_DEV double lin_sample(int64_t i, int64_t n, double start, double step, double stop) {
+    return (i == n - 1) ? stop : add_rn(mul_rn((double)i, step), start);
+}
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_rectgrid_mask(int64_t n, double start, double step,
+                                                             double stop,
+                                                             uint8_t *__restrict__ mask) {
+    const int64_t idx = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (idx >= n * n) return;
+    const int64_t iy = idx / n, ix = idx - iy * n;  // np.meshgrid(x1d, x1d): x varies fastest
+    const double x = lin_sample(ix, n, start, step, stop), y = lin_sample(iy, n, start, step, stop);
+    mask[idx] = (add_rn(mul_rn(x, x), mul_rn(y, y)) <= 1.0) ? 1 : 0;
+}
+
+struct collimated_params {
+    double radius, startx, starty, startz;
+    double k[3], e[3];
+};
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_rectgrid_scatter(
+    const uint8_t *__restrict__ mask, int64_t n, double start, double step, double stop,
+    const int64_t *__restrict__ block_offs, int64_t lo, int64_t hi, collimated_params prm,
+    int64_t pitch, double *__restrict__ x_out, double *__restrict__ k_out,
+    double *__restrict__ e_out) {
+    __shared__ int woff[PRT_BLOCK / 64];
+    const int64_t total = n * n;
+    const int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_ITEMS;
+    bool keep[CMP_ITEMS];
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        keep[q] = (base + q < total) && mask[base + q];
+        c += keep[q] ? 1 : 0;
+    }
+    int incl = c;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) woff[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wbase += woff[w];
+    int64_t pos = block_offs[blockIdx.x] + wbase + (incl - c);
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        if (!keep[q]) continue;
+        if (pos >= lo && pos < hi) {
+            const int64_t idx = base + q;
+            const int64_t iy = idx / n, ix = idx - iy * n;
+            const double px = lin_sample(ix, n, start, step, stop);
+            const double py = lin_sample(iy, n, start, step, stop);
+            const int64_t o = pos - lo;
+            // origin = radius * p + start (optical_system_analysis.py:106-108), two roundings
+            x_out[o] = add_rn(mul_rn(prm.radius, px), prm.startx);
+            x_out[pitch + o] = add_rn(mul_rn(prm.radius, py), prm.starty);
+            x_out[2 * pitch + o] = prm.startz;
+            k_out[o] = prm.k[0];
+            k_out[pitch + o] = prm.k[1];
+            k_out[2 * pitch + o] = prm.k[2];
+            if (e_out) {
+                e_out[o] = prm.e[0];
+                e_out[pitch + o] = prm.e[1];
+                e_out[2 * pitch + o] = prm.e[2];
+            }
+        }
+        ++pos;
     }
 }
 
@@ -880,6 +969,90 @@ int32_t prt_efield_perp(int32_t device, int64_t n, const double *k, double *e_ou
                        (hipStream_t)stream, n, k, e_out);
     HIP_TRY(hipGetLastError());
     return PRT_OK;
+}
+
+static void rect_grid_params(int64_t nray, int64_t *n_per_dim, double *start, double *step,
+                             double *stop) {
+    // nPerDim = int(round(sqrt(nray*4/pi))); dx = 1/nPerDim; linspace(-1+.25dx, 1-.25dx, nPerDim)
+    const double v = sqrt((double)nray * 4.0 / 3.14159265358979323846);
+    int64_t n = (int64_t)nearbyint(v);  // Python round(): half to even, like nearbyint
+    if (n < 1) n = 1;
+    const double dx = 1.0 / (double)n;
+    *start = -1.0 + 0.25 * dx;
+    *stop = 1.0 - 0.25 * dx;
+    *step = (n > 1) ? (*stop - *start) / (double)(n - 1) : 0.0;
+    *n_per_dim = n;
+}
+
+// mask + block counts + scan for the raster; returns device scratch (caller frees)
+static int32_t rect_grid_scan(int64_t nray, hipStream_t st, int64_t *n_per_dim, double *start,
+                              double *step, double *stop, uint8_t **d_mask, int64_t **d_sums,
+                              int64_t *nb_out, int64_t *total_out) {
+    rect_grid_params(nray, n_per_dim, start, step, stop);
+    const int64_t n = *n_per_dim, pts = n * n;
+    const int64_t nb = (pts + CMP_TILE - 1) / CMP_TILE;
+    HIP_TRY(hipMallocAsync((void **)d_mask, (size_t)pts, st));
+    HIP_TRY(hipMallocAsync((void **)d_sums, sizeof(int64_t) * (size_t)(nb + 1), st));
+    hipLaunchKernelGGL(k_rectgrid_mask, dim3(nblocks(pts, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st, n, *start,
+                       *step, *stop, *d_mask);
+    hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nb), dim3(PRT_BLOCK), 0, st, *d_mask, pts, *d_sums);
+    hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(PRT_BLOCK), 0, st, *d_sums, nb);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(total_out, *d_sums + nb, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *nb_out = nb;
+    return PRT_OK;
+}
+
+int32_t prt_rect_grid_count(int32_t device, int64_t nray, int64_t *n_per_dim, int64_t *n_in_disk,
+                            void *stream) {
+    if (nray < 1 || !n_per_dim || !n_in_disk) return fail(PRT_ERR_INVALID_ARG, "prt_rect_grid_count");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    double start, step, stop;
+    uint8_t *d_mask = nullptr;
+    int64_t *d_sums = nullptr;
+    int64_t nb = 0;
+    int32_t rc = rect_grid_scan(nray, st, n_per_dim, &start, &step, &stop, &d_mask, &d_sums, &nb, n_in_disk);
+    if (d_mask) (void)hipFreeAsync(d_mask, st);
+    if (d_sums) (void)hipFreeAsync(d_sums, st);
+    return rc;
+}
+
+int32_t prt_collimated_bundle(int32_t device, int64_t nray, int64_t lo, int64_t hi,
+                              const prt_collimated_t *prm, int64_t pitch, double *x_out,
+                              double *k_out, double *e_out, void *stream) {
+    if (nray < 1 || !prm || lo < 0 || hi < lo) return fail(PRT_ERR_INVALID_ARG, "prt_collimated_bundle");
+    if (hi == lo) return PRT_OK;
+    if (!x_out || !k_out) return fail(PRT_ERR_INVALID_ARG, "prt_collimated_bundle: null pointer");
+    if (pitch == 0) pitch = hi - lo;
+    if (pitch < hi - lo) return fail(PRT_ERR_INVALID_ARG, "prt_collimated_bundle: pitch < hi - lo");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    double start, step, stop;
+    uint8_t *d_mask = nullptr;
+    int64_t *d_sums = nullptr;
+    int64_t nb = 0, n = 0, total = 0;
+    int32_t rc = rect_grid_scan(nray, st, &n, &start, &step, &stop, &d_mask, &d_sums, &nb, &total);
+    if (rc == PRT_OK && hi > total) rc = fail(PRT_ERR_INVALID_ARG, "prt_collimated_bundle: hi beyond the raster");
+    if (rc == PRT_OK) {
+        collimated_params cp;
+        cp.radius = prm->radius;
+        cp.startx = prm->startx;
+        cp.starty = prm->starty;
+        cp.startz = prm->startz;
+        for (int q = 0; q < 3; ++q) {
+            cp.k[q] = prm->k[q];
+            cp.e[q] = prm->e[q];
+        }
+        hipLaunchKernelGGL(k_rectgrid_scatter, dim3((unsigned)nb), dim3(PRT_BLOCK), 0, st, d_mask, n, start,
+                           step, stop, d_sums, lo, hi, cp, pitch, x_out, k_out, e_out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(PRT_ERR_DEVICE, "k_rectgrid_scatter", e);
+    }
+    if (d_mask) (void)hipFreeAsync(d_mask, st);
+    if (d_sums) (void)hipFreeAsync(d_sums, st);
+    return rc;
 }
 
 int32_t prt_bundle_moments(int32_t device, int64_t n, int64_t pitch, const double *x,

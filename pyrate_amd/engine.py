@@ -309,6 +309,40 @@ def bundle_moments(x, mask=None, ref=None, mode=0):
     return v[0], v[1:4], v[4:7]
 
 
+def rect_grid_count(nray, device):
+    """(samples per dimension, points inside the unit disk) of RectGrid.getGrid(nray)"""
+    lib = _lib.load()
+    n_per_dim = ctypes.c_int64()
+    n_disk = ctypes.c_int64()
+    with torch.cuda.device(device):
+        _lib.check(lib.prt_rect_grid_count(device.index, int(nray), ctypes.byref(n_per_dim),
+                                           ctypes.byref(n_disk), _stream_handle(device)))
+    return n_per_dim.value, n_disk.value
+
+
+def collimated_bundle_device(nray, radius, start, kvec, evec, device, lo=0, hi=None):
+    """RectGrid raster + collimated bundle generated on the GPU (prt_collimated_bundle).
+    Returns row-pitched (3, hi-lo) views x, k, e and the total number of rays in the raster."""
+    lib = _lib.load()
+    (_, total) = rect_grid_count(nray, device)
+    if hi is None:
+        hi = total
+    n = hi - lo
+    prm = _lib.PrtCollimated()
+    (prm.radius, prm.startx, prm.starty, prm.startz) = (float(radius), float(start[0]), float(start[1]),
+                                                       float(start[2]))
+    for q in range(3):
+        prm.k[q] = float(kvec[q])
+        prm.e[q] = float(evec[q])
+    pitch = recommended_pitch(n)
+    with torch.cuda.device(device):
+        bufs = [torch.empty((3, max(pitch, 1)), dtype=torch.float64, device=device) for _ in range(3)]
+        _lib.check(lib.prt_collimated_bundle(device.index, int(nray), lo, hi, ctypes.byref(prm), pitch,
+                                             _ptr(bufs[0]), _ptr(bufs[1]), _ptr(bufs[2]),
+                                             _stream_handle(device)))
+    return bufs[0][:, :n], bufs[1][:, :n], bufs[2][:, :n], total
+
+
 def efield_perp(k):
     """a unit E field perpendicular to k on the device (prt_efield_perp)."""
     lib = _lib.load()

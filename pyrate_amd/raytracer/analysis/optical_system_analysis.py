@@ -67,9 +67,31 @@ class OpticalSystemAnalysis(object):
         return (origin, k, _perp_field(k))
 
     def aim(self, numrays, rays_dict, bundletype="collimated", wave=standard_wavelength):
+        """(:167-181).  A collimated bundle on the default RectGrid raster is generated
+        directly on the GPU (prt_collimated_bundle, bit-identical samples, no H2D copy)."""
+        rays_dict = rays_dict or {}
+        if bundletype == "collimated" and type(rays_dict.get("raster", RectGrid())) is RectGrid:
+            self.initial_bundles = [self._collimated_bundle_on_device(numrays, rays_dict, wave)]
+            return
         call = {"collimated": self.collimated_bundle, "divergent": self.divergent_bundle}
         (o, k, e) = call[bundletype](numrays, rays_dict, wave=wave)
         self.initial_bundles = [RayBundle(x0=o, k0=k, Efield0=e, wave=wave)]
+
+    def _collimated_bundle_on_device(self, nrays, pd, wave):
+        (angley, anglex) = (pd.get("angley", 0.0), pd.get("anglex", 0.0))
+        unit = np.array([math.sin(angley) * math.cos(anglex), math.sin(anglex),
+                         math.cos(angley) * math.cos(anglex)])
+        kvec = self._background_index(wave) * unit
+        # one unit vector perpendicular to k for the whole bundle (same rule as prt_efield_perp)
+        axis = np.eye(3)[int(np.argmin(np.abs(kvec)))] if abs(kvec[1]) > min(abs(kvec[0]), abs(kvec[2])) \
+            else np.array([0., 1., 0.])
+        evec = np.cross(kvec, axis)
+        evec = evec / np.linalg.norm(evec)
+        dev = default_device()
+        (x, k, e, _) = engine.collimated_bundle_device(
+            nrays, pd.get("radius", 1.0), (pd.get("startx", 0.), pd.get("starty", 0.), pd.get("startz", 0.)),
+            kvec, evec, dev)
+        return RayBundle(x0=x, k0=k, Efield0=e, wave=wave, device=dev)
 
     def trace(self, **kwargs):
         return [self.opticalsystem.seqtrace(ib, self.sequence, **kwargs) for ib in self.initial_bundles]

@@ -169,6 +169,17 @@ def double_gauss_bundle(nrays, rpup=5.0, z0=-10.0, field_deg=0.0):
     return (o, k, np.ascontiguousarray(e0))
 
 
+def double_gauss_bundle_device(nrays, device, rpup=5.0, z0=-10.0, field_deg=0.0, lo=0, hi=None):
+    """the same bundle generated on the GPU (bit-identical to double_gauss_bundle; rays
+    [lo, hi) of the raster only -- a rank's shard).  Returns (x0, k0, e0, n_total)."""
+    from . import engine
+    field = field_deg * math.pi / 180.
+    k = (0.0, math.sin(field), math.cos(field))
+    e = (0.0, k[2], -k[1])                        # k x ex
+    return engine.collimated_bundle_device(nrays, rpup, (0.0, z0 * math.tan(field), z0), k, e, device,
+                                           lo=lo, hi=hi)
+
+
 # ---- config 1: cemented doublet (demos/demo_doublet.py:48-101) --------------------
 def doublet_builduplist(mat1=1.5168, mat2=1.6727):
     ap = {"type": "CircularAperture", "maxradius": 12.7}

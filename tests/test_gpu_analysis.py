@@ -122,3 +122,23 @@ def test_optical_system_analysis_bundles(gpu_device):
     osa.aim(20, {"startz": -5., "radius": 11.43, "raster": raster.MeridionalFan()}, wave=zoo.DLINE)
     r2 = osa.trace()[0]
     assert len(r2[0].raybundles) == 7 and r2[0].raybundles[-1].x.shape == (1, 3, 20)
+
+
+@pytest.mark.parametrize("nray", [11, 100, 10000, 123457])
+def test_device_bundle_generation_is_bit_identical_to_the_numpy_raster(gpu_device, nray):
+    """RectGrid + collimated bundle generated on the GPU == the host raster
+    (identical pupil samples), whole bundle and arbitrary shards"""
+    import torch
+    from pyrate_amd import engine
+    for field in (0.0, 5.0):
+        (o, k, e0) = systems.double_gauss_bundle(nray, field_deg=field)
+        (xd, kd, ed, total) = systems.double_gauss_bundle_device(nray, gpu_device, field_deg=field)
+        assert total == o.shape[1] == engine.rect_grid_count(nray, gpu_device)[1]
+        assert np.array_equal(xd.cpu().numpy(), o)
+        assert np.array_equal(kd.cpu().numpy(), k)
+        assert np.array_equal(ed.cpu().numpy(), e0)
+    (lo, hi) = (total // 3, total // 3 + max(1, total // 2))
+    (xs, ks, es, _) = systems.double_gauss_bundle_device(nray, gpu_device, field_deg=5.0, lo=lo, hi=hi)
+    assert np.array_equal(xs.cpu().numpy(), o[:, lo:hi]) and np.array_equal(ks.cpu().numpy(), k[:, lo:hi])
+    (px, py) = systems.rect_grid(nray)
+    assert engine.rect_grid_count(nray, gpu_device) == (int(round(math.sqrt(nray * 4.0 / math.pi))), px.shape[0])
