@@ -23,6 +23,7 @@
  *                        Surface.intersect           raytracer/surface.py:116-135
  *                        Conic.intersect             raytracer/surface_shape.py:289-325
  *                        ExplicitShape.intersect     raytracer/surface_shape.py:448-465
+ *                          (Asphere :520-606, Biconic :609-706, XYPolynomials :780-858)
  *                        RayBundle.returnKtoD        raytracer/ray.py:136-152
  *   prt_interact         IsotropicMaterial.refract   raytracer/material/material_isotropic.py:163-199
  *                        IsotropicMaterial.reflect   raytracer/material/material_isotropic.py:201-236
@@ -57,7 +58,7 @@ extern "C" {
 #define PRT_ERR_NOMEM (-5)
 
 /* ---- enums (int32 in the POD) --------------------------------------- */
-enum { PRT_SHAPE_CONIC = 0, PRT_SHAPE_ASPHERE = 1, PRT_SHAPE_XYPOLY = 2 };
+enum { PRT_SHAPE_CONIC = 0, PRT_SHAPE_ASPHERE = 1, PRT_SHAPE_XYPOLY = 2, PRT_SHAPE_BICONIC = 3 };
 enum { PRT_AP_NONE = 0, PRT_AP_CIRCULAR = 1, PRT_AP_RECTANGULAR = 2 };
 enum { PRT_REFRACT = 0, PRT_MIRROR = 1 };
 enum { PRT_MAT_ISOTROPIC = 0, PRT_MAT_ANISOTROPIC = 1 };
@@ -80,16 +81,17 @@ enum { PRT_ANISO_GENERAL = 0, PRT_ANISO_ISOTROPIC = 1, PRT_ANISO_UNIAXIAL = 2 };
  */
 typedef struct prt_surface {
     int32_t shape_type;  /* PRT_SHAPE_*                                              */
-    int32_t n_coeffs;    /* asphere: #A coefficients; xypoly: #terms                 */
+    int32_t n_coeffs;    /* asphere: #A coefficients; xypoly: #terms; biconic: #(A,B) pairs */
     int32_t ap_type;     /* PRT_AP_*                                                 */
     int32_t interaction; /* PRT_REFRACT / PRT_MIRROR (sequence option "is_mirror")   */
     int32_t mat_type;    /* medium the ray is in AFTER the interaction               */
     int32_t frame_flags; /* PRT_FRAME_* (computed by the host, only an optimisation) */
     int32_t newton_maxit; /* explicit shapes: iteration cap (0 -> 30)                */
     int32_t aniso_class; /* PRT_ANISO_* (host classification of eps, see below)      */
-    double curv;        /* conic/asphere curvature;  xypoly: unused                  */
-    double cc;          /* conic constant                                            */
-    double coeffs[PRT_MAX_COEFFS]; /* asphere: A2, A4, ...  xypoly: c / normradius^(i+j) */
+    double curv;        /* conic/asphere curvature;  biconic: curvx;  xypoly: unused  */
+    double cc;          /* conic constant;  biconic: ccx                             */
+    double coeffs[PRT_MAX_COEFFS]; /* asphere: A2, A4, ...  xypoly: c / normradius^(i+j);
+                                      biconic: A2, B2, A4, B4, ... (pairs)            */
     int32_t xpow[PRT_MAX_COEFFS];  /* xypoly term powers                             */
     int32_t ypow[PRT_MAX_COEFFS];
     double B_shape[9], g_shape[3]; /* shape.lc                                       */
@@ -103,6 +105,7 @@ typedef struct prt_surface {
      * ISOTROPIC: eps = aniso_eo I;  UNIAXIAL: eps = aniso_eo I + (aniso_ee-aniso_eo) c c^T,
      * c = aniso_axis (unit, material frame);  GENERAL: anything else. */
     double aniso_eo, aniso_ee, aniso_axis[3];
+    double curv_y, cc_y; /* biconic: curvature and conic constant of the y section         */
 } prt_surface_t;
 
 typedef struct prt_system prt_system_t; /* opaque: device copy of a surface table */

@@ -149,6 +149,12 @@ def case_xypoly():
     dump_case("xypoly_field5", s, seq, disk_bundle(96, 8.0, -5.0, field_deg=5.0))
 
 
+def case_biconic():
+    (s, seq) = build_simple_optical_system(zoo.biconic_builduplist())
+    dump_case("biconic_axis", s, seq, disk_bundle(96, 8.0, -5.0))
+    dump_case("biconic_field5", s, seq, disk_bundle(96, 8.0, -5.0, field_deg=5.0))
+
+
 def case_tilted():
     (s, seq) = zoo.tilted(REFAPI)
     dump_case("tilted_frames", s, seq, disk_bundle(300, 6.5, -3.0, field_deg=2.0, wave=0.6563e-3))
@@ -203,6 +209,7 @@ def main():
     case_double_gauss()
     case_asphere()
     case_xypoly()
+    case_biconic()
     case_tilted()
     case_mirror()
     case_two_elements()

@@ -192,6 +192,36 @@ PRT_DEV void xypoly_eval(const prt_surface_t *__restrict__ sf, double x, double 
     }
 }
 
+// Biconic.F / gradF, surface_shape.py:618-647:
+//   F = (cx x^2 + cy y^2)/(1+sq) + sum_n a_n w_n^(n+1),  w_n = r2 - b_n (x^2 - y^2)
+//   sq = sqrt(1 - cx^2 (1+ccx) x^2 - cy^2 (1+ccy) y^2)
+//   Fx = cx x (cx (1+ccx) u + 2 (sq+1) sq) / ((sq+1)^2 sq) + sum 2 a_n (n+1) x (1-b_n) w_n^n   (u = cx x^2 + cy y^2)
+PRT_DEV void biconic_eval(const prt_surface_t *__restrict__ sf, double x, double y, double &F,
+                          double &Fx, double &Fy) {
+    const double cx = sf->curv, ccx = sf->cc, cy = sf->curv_y, ccy = sf->cc_y;
+    const double x2 = x * x, y2 = y * y;
+    const double u = cx * x2 + cy * y2;
+    const double sq = fast_sqrt(1.0 - cx * cx * (1.0 + ccx) * x2 - cy * cy * (1.0 + ccy) * y2);
+    const double den = 1.0 + sq;
+    const double iden = fast_rcp(den);
+    F = u * iden;
+    const double common = iden * iden * fast_rcp(sq);
+    const double two_den_sq = 2.0 * den * sq;
+    Fx = cx * x * (cx * (ccx + 1.0) * u + two_den_sq) * common;
+    Fy = cy * y * (cy * (ccy + 1.0) * u + two_den_sq) * common;
+    const int np = sf->n_coeffs;
+    for (int n = 0; n < np; ++n) {
+        const double a = sf->coeffs[2 * n], b = sf->coeffs[2 * n + 1];
+        const double w = x2 * (1.0 - b) + y2 * (1.0 + b);
+        double wn = 1.0;  // w^n
+        for (int q = 0; q < n; ++q) wn *= w;
+        F += a * wn * w;
+        const double d = 2.0 * a * (double)(n + 1) * wn;
+        Fx += d * x * (1.0 - b);
+        Fy += d * y * (1.0 + b);
+    }
+}
+
 // explicit z = F(x,y) shapes: value and in-plane derivatives
 PRT_DEV void explicit_eval(const prt_surface_t *__restrict__ sf, double x, double y, double &F,
                            double &Fx, double &Fy) {
@@ -200,6 +230,8 @@ PRT_DEV void explicit_eval(const prt_surface_t *__restrict__ sf, double x, doubl
         asphere_eval(sf, x, y, F, m);
         Fx = x * m;
         Fy = y * m;
+    } else if (sf->shape_type == PRT_SHAPE_BICONIC) {
+        biconic_eval(sf, x, y, F, Fx, Fy);
     } else {
         xypoly_eval(sf, x, y, F, Fx, Fy);
     }

@@ -1,6 +1,6 @@
 """
 Surface shapes with the reference's interface (raytracer/surface_shape.py): ``Conic``
-(:158-325), ``Asphere`` (:520-606), ``XYPolynomials`` (:780-858).  ``intersect`` and the
+(:158-325), ``Asphere`` (:520-606), ``Biconic`` (:609-706), ``XYPolynomials`` (:780-858).  ``intersect`` and the
 ``getSag`` / ``getGrad`` / ``getNormal`` evaluations run on the GPU through
 ``prt_propagate`` / ``prt_shape_eval``; these classes hold parameters and frames.
 
@@ -124,6 +124,32 @@ class Asphere(ExplicitShape):
         return self.params["curv"].evaluate()
 
 
+class Biconic(ExplicitShape):
+    kind = "shape_Biconic"
+
+    @classmethod
+    def p(cls, lc, curvx=0, ccx=0, curvy=0, ccy=0, coefficients=None, name=""):
+        """biconic z = (cx x^2 + cy y^2)/(1+sqrt(1-(1+ccx)cx^2 x^2-(1+ccy)cy^2 y^2))
+        + sum a_n (r^2 - b_n (x^2-y^2))^(n+1); ``coefficients`` = [(a2, b2), (a4, b4), ...]
+        (surface_shape.py:664-689)"""
+        if coefficients is None:
+            coefficients = []
+        plist = [("curvx", curvx), ("curvy", curvy), ("ccx", ccx), ("ccy", ccy)] + \
+            [("A" + str(2 * i + 2), a) for (i, (a, b)) in enumerate(coefficients)] + \
+            [("B" + str(2 * i + 2), b) for (i, (a, b)) in enumerate(coefficients)]
+        obj = cls(lc, plist, name=name)
+        obj.annotations["numcoefficients"] = len(coefficients)
+        return obj
+
+    def getBiconicParameters(self):
+        return (self.params["curvx"](), self.params["curvy"](), self.params["ccx"](), self.params["ccy"](),
+                [(self.params["A" + str(2 * i + 2)](), self.params["B" + str(2 * i + 2)]())
+                 for i in range(self.annotations["numcoefficients"])])
+
+    def getCentralCurvature(self):
+        return 0.5 * (self.params["curvx"]() + self.params["curvy"]())
+
+
 class XYPolynomials(ExplicitShape):
     kind = "shape_XYPolynomials"
 
@@ -150,5 +176,5 @@ class XYPolynomials(ExplicitShape):
         return (c20 + c02) / nr ** 2
 
 
-accessible_shapes = {"shape_Conic": Conic, "shape_Asphere": Asphere,
+accessible_shapes = {"shape_Conic": Conic, "shape_Asphere": Asphere, "shape_Biconic": Biconic,
                      "shape_XYPolynomials": XYPolynomials}

@@ -14,9 +14,9 @@ and, unchanged, real ``pyrateoptics`` objects:
   fallback (:344-346), reset to the background medium at every element (:328).
 * frames: ``lc.localbasis`` (3x3), ``lc.globalcoordinates`` (3,)
   (raytracer/localcoordinates.py:264-295).
-* shapes: ``kind`` in {"shape_Conic", "shape_Asphere", "shape_XYPolynomials"} with
-  ``curvature()``/``conic()``, ``getAsphereParameters()``, ``getXYParameters()``
-  (raytracer/surface_shape.py:158-206, 599-603, 849-858).
+* shapes: ``kind`` in {"shape_Conic", "shape_Asphere", "shape_Biconic", "shape_XYPolynomials"}
+  with ``curvature()``/``conic()``, ``getAsphereParameters()``, ``getBiconicParameters()``,
+  ``getXYParameters()`` (raytracer/surface_shape.py:158-206, 599-603, 694-702, 849-858).
 * apertures: ``kind`` in {"aperture", "aperture_Circular", "aperture_Rectangle"} and
   ``annotations`` (raytracer/aperture.py:34-139).
 * materials: ``get_optical_index(x, wave)`` for isotropic media
@@ -34,7 +34,7 @@ import numpy as np
 
 PRT_MAX_COEFFS = 40
 
-SHAPE_CODES = {"conic": 0, "asphere": 1, "xypoly": 2}
+SHAPE_CODES = {"conic": 0, "asphere": 1, "xypoly": 2, "biconic": 3}
 AP_CODES = {"none": 0, "circular": 1, "rectangular": 2}
 INTERACTION_CODES = {"refract": 0, "mirror": 1}
 MAT_CODES = {"isotropic": 0, "anisotropic": 1}
@@ -75,6 +75,8 @@ class PrtSurface(ctypes.Structure):
         ("aniso_eo", ctypes.c_double),
         ("aniso_ee", ctypes.c_double),
         ("aniso_axis", ctypes.c_double * 3),
+        ("curv_y", ctypes.c_double),
+        ("cc_y", ctypes.c_double),
     ]
 
 
@@ -106,8 +108,12 @@ def describe_shape(shape):
         (normradius, coeffs) = shape.getXYParameters()
         return {"type": "xypoly", "normradius": float(normradius),
                 "terms": [[int(i), int(j), float(c)] for (i, j, c) in coeffs]}
+    if kind == "shape_Biconic":
+        (curvx, curvy, ccx, ccy, coeffs) = shape.getBiconicParameters()
+        return {"type": "biconic", "curvx": float(curvx), "curvy": float(curvy), "ccx": float(ccx),
+                "ccy": float(ccy), "coeffs": [[float(a), float(b)] for (a, b) in coeffs]}
     raise UnsupportedError("shape kind %r is outside the HIP engine's scope "
-                           "(Conic, Asphere, XYPolynomials)" % (kind,))
+                           "(Conic, Asphere, Biconic, XYPolynomials)" % (kind,))
 
 
 def describe_aperture(aperture):
@@ -231,6 +237,15 @@ def pack_record(rec, out=None):
         r.curv, r.cc, r.n_coeffs = shape["curv"], shape["cc"], len(coeffs)
         for (q, a) in enumerate(coeffs):
             r.coeffs[q] = a
+    elif shape["type"] == "biconic":
+        pairs = list(shape["coeffs"])
+        if 2 * len(pairs) > PRT_MAX_COEFFS:
+            raise UnsupportedError("biconic with more than %d coefficient pairs" % (PRT_MAX_COEFFS // 2))
+        r.curv, r.cc, r.curv_y, r.cc_y = shape["curvx"], shape["ccx"], shape["curvy"], shape["ccy"]
+        r.n_coeffs = len(pairs)
+        for (q, (a, b)) in enumerate(pairs):
+            r.coeffs[2 * q] = a
+            r.coeffs[2 * q + 1] = b
     else:
         terms = shape["terms"]
         if len(terms) > PRT_MAX_COEFFS:

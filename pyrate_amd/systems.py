@@ -43,6 +43,11 @@ def _shape_record(surfdict):
         return {"type": "asphere", "curv": float(surfdict.get("curv", 0.0)),
                 "cc": float(surfdict.get("cc", 0.0)),
                 "coeffs": [float(a) for a in surfdict.get("coefficients", [])]}
+    if shape == "Biconic":
+        return {"type": "biconic", "curvx": float(surfdict.get("curvx", 0.0)),
+                "curvy": float(surfdict.get("curvy", 0.0)), "ccx": float(surfdict.get("ccx", 0.0)),
+                "ccy": float(surfdict.get("ccy", 0.0)),
+                "coeffs": [[float(a), float(b)] for (a, b) in surfdict.get("coefficients", [])]}
     if shape == "XYPolynomials":
         return {"type": "xypoly", "normradius": float(surfdict.get("normradius", 1.0)),
                 "terms": [[int(i), int(j), float(c)] for (i, j, c) in surfdict.get("coefficients", [])]}

@@ -21,6 +21,7 @@ def mirror_api():
         OpticalSystem=optical_system.OpticalSystem, OpticalElement=optical_element.OpticalElement,
         LocalCoordinates=localcoordinates.LocalCoordinates, Surface=surface.Surface,
         Conic=surface_shape.Conic, Asphere=surface_shape.Asphere, XYPolynomials=surface_shape.XYPolynomials,
+        Biconic=surface_shape.Biconic,
         CircularAperture=aperture.CircularAperture, RectangularAperture=aperture.RectangularAperture,
         ConstantIndexGlass=material_isotropic.ConstantIndexGlass, ModelGlass=material_isotropic.ModelGlass,
         AnisotropicMaterial=material_anisotropic.AnisotropicMaterial, RayBundle=ray.RayBundle,
@@ -134,6 +135,17 @@ def xypoly_builduplist():
                            (4, 0, 0.002), (1, 1, 0.003)]},
          {"decz": 12.0}, None, "back", {}),
         ({"shape": "Conic"}, {"decz": 80.0}, None, "image", {}),
+    ]
+
+
+def biconic_builduplist():
+    """a toric / biconic front surface with polynomial terms (the shape of demos/demo_hud.py)"""
+    return [
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
+        ({"shape": "Biconic", "curvx": 1. / 45., "curvy": 1. / 70., "ccx": -0.4, "ccy": 0.2,
+          "coefficients": [(1e-4, 0.3), (-2e-7, -0.5)]}, {"decz": 5.0}, 1.5168, "front", {}),
+        ({"shape": "Conic", "curv": -1. / 90.}, {"decz": 6.0}, None, "back", {}),
+        ({"shape": "Conic"}, {"decz": 70.0}, None, "image", {}),
     ]
 
 

@@ -182,6 +182,35 @@ def test_shape_eval_closed_forms(gpu_device):
     assert np.allclose(grad.cpu().numpy(), np.vstack((gpx, gpy, np.ones_like(x))))
 
 
+def test_shape_eval_biconic_closed_form(gpu_device):
+    """Biconic sag / gradient against an independently typed closed form (the reference pins
+    the same in tests/test_surf_shape.py:180-284) incl. finite differences of the sag"""
+    from pyrate_amd import engine, systems
+    rng = np.random.RandomState(5)
+    (x, y) = (rng.rand(50) * 4 - 2, rng.rand(50) * 4 - 2)
+    (cx, cy, ccx, ccy) = (1. / 10., 1. / 15., -1.5, 0.4)
+    coeffs = [(1e-3, 0.2), (-1e-5, -0.6), (2e-7, 0.1)]
+    recs = systems.simple_system_records([
+        ({"shape": "Biconic", "curvx": cx, "curvy": cy, "ccx": ccx, "ccy": ccy, "coefficients": coeffs},
+         {"decz": 1.0}, None, "b", {})])
+    sysd = engine.DeviceSystem(recs, gpu_device.index)
+
+    def sag(x, y):
+        z = (cx * x ** 2 + cy * y ** 2) / (1 + np.sqrt(1 - (1 + ccx) * cx ** 2 * x ** 2 - (1 + ccy) * cy ** 2 * y ** 2))
+        for (n, (a, b)) in enumerate(coeffs):
+            z = z + a * ((x ** 2 + y ** 2) - b * (x ** 2 - y ** 2)) ** (n + 1)
+        return z
+    (s_dev, g_dev) = sysd.shape_eval(0, torch.from_numpy(x).to(gpu_device), torch.from_numpy(y).to(gpu_device))
+    assert np.allclose(s_dev.cpu().numpy(), sag(x, y), rtol=1e-14, atol=1e-15)
+    h = 1e-6
+    gx = -(sag(x + h, y) - sag(x - h, y)) / (2 * h)
+    gy = -(sag(x, y + h) - sag(x, y - h)) / (2 * h)
+    g = g_dev.cpu().numpy()
+    assert np.allclose(g[0], gx, rtol=1e-7, atol=1e-9) and np.allclose(g[1], gy, rtol=1e-7, atol=1e-9)
+    assert np.all(g[2] == 1.0)
+    assert np.allclose(g, oracle.biconic_grad(recs[0]["shape"], x, y), rtol=1e-13, atol=1e-15)
+
+
 def test_odd_and_tiny_ray_counts(gpu_device):
     """ragged sizes: N odd (scalar path), N=1, N=0, and N even (vector path) agree"""
     from pyrate_amd import engine, systems

@@ -65,6 +65,8 @@ def test_mirror_explicit_and_mirror_tables(api):
     _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("asphere_strong_axis").table)
     (s, seq) = api.build_simple_optical_system(zoo.xypoly_builduplist())
     _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("xypoly_axis").table)
+    (s, seq) = api.build_simple_optical_system(zoo.biconic_builduplist())
+    _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("biconic_axis").table)
     (s, seq) = api.build_simple_optical_system(zoo.mirrors_builduplist())
     ref = _golden.load_case("mirrors").table
     recs = _flatten(s, seq, zoo.DLINE)[0]
@@ -105,10 +107,10 @@ def test_structural_errors_raise_like_the_reference(api):
 
 
 def test_unsupported_shapes_are_rejected():
-    class Biconic(object):
-        kind = "shape_Biconic"
+    class GridSag(object):
+        kind = "shape_GridSag"
     with pytest.raises(st.UnsupportedError):
-        st.describe_shape(Biconic())
+        st.describe_shape(GridSag())
 
 
 def test_pack_table_flags_and_coefficients():
