@@ -129,6 +129,8 @@ class DeviceSystem(object):
     def trace_into(self, x0, k0, bufs, e0_re=None, e0_im=None):
         """Asynchronous launch into preallocated buffers (see alloc_outputs)."""
         n0 = x0.shape[1]
+        if not self.all_isotropic:      # per-surface march: tight arrays
+            (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
         in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
         _lib.check(self.lib.prt_trace(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
                                       _ptr(e0_im), bufs["mode"], bufs["pitch"], _ptr(bufs["x_hit"]),
@@ -150,6 +152,8 @@ class DeviceSystem(object):
         stream, inside libprt)."""
         ms = ctypes.c_double()
         n0 = x0.shape[1]
+        if not self.all_isotropic:
+            (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
         in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
         _lib.check(self.lib.prt_trace_timed(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
                                             _ptr(e0_im), bufs["mode"], bufs["pitch"],
