@@ -99,6 +99,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so).  It must be in the process
+    # BEFORE libprt.so is loaded, so that libprt's NEEDED libamdhip64.so.7 resolves to that
+    # same runtime: device pointers, streams and events are then shared between the torch
+    # allocator and the kernels.  Loading libprt first pulls in /opt/rocm's runtime, which
+    # then coexists with torch's and reports "no ROCm-capable device".
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "pyrate_amd: %s is missing -- the HIP engine is not built. Run "
