@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the image-plane all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["path", "image"], default="path")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: dry run of the multi-rank path on ONE GPU (all ranks share cuda:0, "
+                         "the gather is staged through host memory); not a measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,10 +94,15 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     n_gpus = world
 
     from pyrate_amd import engine, systems, _lib
@@ -122,7 +130,8 @@ def main():
     do_gather = (n_gpus > 1) and not args.no_gather
     nbuf = 2 if do_gather else 1
     bufs = [sysd.alloc_outputs(n_local, mode) for _ in range(nbuf)]
-    gathers = [pdist.ImagePlaneGather(n_total, dev) for _ in range(nbuf)] if do_gather else []
+    gathers = [pdist.ImagePlaneGather(n_total, dev, stage_on_host=(args.backend == "gloo"))
+               for _ in range(nbuf)] if do_gather else []
     comm_stream = torch.cuda.Stream(device=dev) if do_gather else None
     main_stream = torch.cuda.current_stream(dev)
 
@@ -164,7 +173,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=(dev if args.backend == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -195,13 +204,17 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 "
-                                   "double Gauss, ConstantIndexGlass d-line), RectGrid disk bundle, "
-                                   "BASELINE configs[1]",
+            "config": {"workload": ("demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 "
+                                    "double Gauss, ConstantIndexGlass d-line), RectGrid disk bundle, "
+                                    "BASELINE configs[1]") if n_gpus == 1 else
+                                   ("demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 double "
+                                    "Gauss), 5 wavelengths cycled (Conrady indices), RectGrid disk "
+                                    "bundle ray-sharded over the GPUs, BASELINE configs[4]"),
                        "rays_per_gpu": n_local, "rays_total": n_total, "surfaces": S,
                        "mode": args.mode, "sharding": "rays" if n_gpus > 1 else "none",
                        "wavelengths": len(sysds),
-                       "image_plane_gather": ("rccl all-gather, overlapped" if do_gather else "none")},
+                       "image_plane_gather": (("rccl all-gather, overlapped" if args.backend == "nccl"
+                                               else "gloo dry run (host staged)") if do_gather else "none")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_trace_iso", "kernel_ms": kernel_ms,

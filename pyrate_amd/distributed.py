@@ -33,18 +33,23 @@ class ImagePlaneGather(object):
     (x (3,N), k (3,N), valid (N,)) views in global ray order.
     """
 
-    def __init__(self, n_total, device, group=None):
+    def __init__(self, n_total, device, group=None, stage_on_host=False):
+        """stage_on_host: exchange through pinned host buffers (for the ``gloo`` backend, which
+        cannot all-gather device tensors; used by the single-GPU dry run of the multi-rank
+        bench path -- the production path is RCCL on device buffers)."""
         self.group = group
+        self.stage_on_host = stage_on_host
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_total = n_total
         self.sizes = shard_sizes(n_total, self.world)
         self.n_max = max(self.sizes) if self.sizes else 0
         self.device = device
-        self.send_f = torch.zeros((6, self.n_max), dtype=torch.float64, device=device)
-        self.send_v = torch.zeros(self.n_max, dtype=torch.uint8, device=device)
-        self.recv_f = torch.empty((self.world, 6, self.n_max), dtype=torch.float64, device=device)
-        self.recv_v = torch.empty((self.world, self.n_max), dtype=torch.uint8, device=device)
+        bdev = torch.device("cpu") if stage_on_host else device
+        self.send_f = torch.zeros((6, self.n_max), dtype=torch.float64, device=bdev)
+        self.send_v = torch.zeros(self.n_max, dtype=torch.uint8, device=bdev)
+        self.recv_f = torch.empty((self.world, 6, self.n_max), dtype=torch.float64, device=bdev)
+        self.recv_v = torch.empty((self.world, self.n_max), dtype=torch.uint8, device=bdev)
         self._work = []
 
     def start(self, x_img, k_img, valid):
@@ -53,6 +58,8 @@ class ImagePlaneGather(object):
         self.send_f[0:3, :n].copy_(x_img, non_blocking=True)
         self.send_f[3:6, :n].copy_(k_img, non_blocking=True)
         self.send_v[:n].copy_(valid, non_blocking=True)
+        if self.stage_on_host and x_img.is_cuda:
+            torch.cuda.current_stream(x_img.device).synchronize()     # D2H staging complete
         if self.world == 1:
             self.recv_f[0].copy_(self.send_f, non_blocking=True)
             self.recv_v[0].copy_(self.send_v, non_blocking=True)
