@@ -44,31 +44,46 @@ def algorithmic_bytes(n_rays, n_surfaces, with_e0=True):
     return n_rays * ((72 if with_e0 else 48) + 50 * n_surfaces)
 
 
-def cpu_baseline(records, o, k, e0, target_rays=4_000_000, chunk=100_000, n_all=None):
-    """the CPU oracle (NumPy port of the reference algorithm, geometry only -- i.e.
-    WITHOUT the reference's SVD E-field step that is 91% of its time) on a bounded
-    sample of the same workload, single process."""
+def cpu_baseline(records, o, k, e0, n_all=None, chunk=100_000):
+    """CPU restatements of the reference algorithm (test oracles, geometry only -- i.e. WITHOUT
+    the reference's SVD E-field step that is 91% of its time) on a bounded sample of the same
+    workload, timed on this box's host cores:
+      value: C / OpenMP port (oracle/seqtrace_c.c) on all host threads
+      numpy_single_core: the NumPy port (oracle/seqtrace_np.py), one process
+      with_svd_efield: NumPy port incl. the SVD E-field step, the reference's true cost profile"""
     from oracle import seqtrace_np as oracle
-    n = min(o.shape[1], target_rays)
+    from oracle import seqtrace_c
+    S = len(records)
+    n = o.shape[1]
+    seqtrace_c.trace_arrays(records, o[:, :10000], k[:, :10000], e0[:, :10000])          # warm-up
+    reps = 0
     t0 = time.perf_counter()
+    while True:
+        (_, _, _, _, used) = seqtrace_c.trace_arrays(records, o, k, e0)
+        reps += 1
+        dt_c = time.perf_counter() - t0
+        if dt_c > 5.0 or reps >= 20:
+            break
+    m_np = min(n, 1_000_000)
+    t1 = time.perf_counter()
     done = 0
     with np.errstate(all="ignore"):
-        while done < n:
-            hi = min(done + chunk, n)
+        while done < m_np:
+            hi = min(done + chunk, m_np)
             oracle.trace(records, o[:, done:hi], k[:, done:hi], e0[:, done:hi])
             done = hi
-    dt = time.perf_counter() - t0
-    # a small sample with the SVD E-field step, the reference's true cost profile
-    m = min(o.shape[1], 50_000)
-    t1 = time.perf_counter()
+    dt_np = time.perf_counter() - t1
+    m_e = min(n, 50_000)
+    t2 = time.perf_counter()
     with np.errstate(all="ignore"):
-        oracle.trace(records, o[:, :m], k[:, :m], e0[:, :m], with_efield=True)
-    dt_e = time.perf_counter() - t1
-    S = len(records)
-    return {"value": n * S / dt, "unit": "ray-surface-ops/s", "cores": 1, "kind": "port",
-            "sample": "first %d of the %d rays x %d surfaces, chunks of %d, NumPy oracle "
-                      "(geometry only), %.1f s" % (n, n_all or o.shape[1], S, chunk, dt),
-            "with_svd_efield": {"value": m * S / dt_e, "sample": "%d rays, %.1f s" % (m, dt_e)},
+        oracle.trace(records, o[:, :m_e], k[:, :m_e], e0[:, :m_e], with_efield=True)
+    dt_e = time.perf_counter() - t2
+    return {"value": reps * n * S / dt_c, "unit": "ray-surface-ops/s", "cores": used, "kind": "port",
+            "sample": "C/OpenMP oracle: %d x (first %d of the %d rays x %d surfaces, path written to "
+                      "host RAM), %.1f s" % (reps, n, n_all or n, S, dt_c),
+            "numpy_single_core": {"value": m_np * S / dt_np, "sample": "%d rays in chunks of %d, %.1f s"
+                                  % (m_np, chunk, dt_np)},
+            "with_svd_efield": {"value": m_e * S / dt_e, "sample": "%d rays, %.1f s" % (m_e, dt_e)},
             "host_cpus": os.cpu_count()}
 
 
