@@ -69,7 +69,18 @@ def flat_table(records):
     return tab
 
 
-def trace_arrays(records, x0, k0, E0=None, nthreads=0):
+class Workspace(object):
+    """pre-allocated (and pre-touched) output arrays, so that repeated timed calls do not pay
+    first-touch page faults inside the parallel region"""
+
+    def __init__(self, n_surfaces, n):
+        self.x_hit = np.zeros((n_surfaces, 3, n))
+        self.k_out = np.zeros((n_surfaces, 3, n))
+        self.valid = np.zeros((n_surfaces, n), dtype=np.uint8)
+        self.valid_out = np.zeros((n_surfaces, n), dtype=np.uint8)
+
+
+def trace_arrays(records, x0, k0, E0=None, nthreads=0, workspace=None):
     """dense arrays: x_hit (S,3,N), k_out (S,3,N), valid (S,N), valid_out (S,N), threads used"""
     lib = load()
     tab = np.ascontiguousarray(flat_table(records))
@@ -82,10 +93,9 @@ def trace_arrays(records, x0, k0, E0=None, nthreads=0):
     with np.errstate(invalid="ignore", divide="ignore"):
         d0 = np.ascontiguousarray(seqtrace_np.poynting_direction(k0, np.asarray(E0)))   # ray.py:136-152
     S = len(records)
-    x_hit = np.empty((S, 3, n))
-    k_out = np.empty((S, 3, n))
-    valid = np.empty((S, n), dtype=np.uint8)
-    valid_out = np.empty((S, n), dtype=np.uint8)
+    ws = workspace if workspace is not None else Workspace(S, n)
+    (x_hit, k_out, valid, valid_out) = (ws.x_hit, ws.k_out, ws.valid, ws.valid_out)
+    assert x_hit.shape == (S, 3, n)
     used = lib.seqtrace_c(tab.ctypes.data, S, n, x0.ctypes.data, k0.ctypes.data, d0.ctypes.data,
                           x_hit.ctypes.data, k_out.ctypes.data, valid.ctypes.data, valid_out.ctypes.data,
                           int(nthreads))
