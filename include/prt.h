@@ -209,6 +209,19 @@ int32_t prt_collimated_bundle(int32_t device, int64_t nray, int64_t lo, int64_t 
                               const prt_collimated_t *prm, int64_t pitch, double *x_out,
                               double *k_out, double *e_out, void *stream);
 
+/* RayBundle.returnKtoD (raytracer/ray.py:136-152) for one stored point: unit Poynting
+ * directions d_out (3,n) from k (3,n) and E (e_re / e_im (3,n) or NULL; NULL e_re means E = ey
+ * when use_default_e, else d = k/|k|).  Tight arrays. */
+int32_t prt_poynting_dir(int32_t device, int64_t n, const double *k, const double *e_re,
+                         const double *e_im, int32_t use_default_e, double *d_out, void *stream);
+
+/* Per-ray sums over the n_points stored points of a bundle: mode 0 arc length
+ * sum |x_{p+1}-x_p| (RayBundleAnalysis.get_arc_length, analysis/ray_analysis.py:136-147),
+ * mode 1 phase difference sum (x_{p+1}.k_{p+1} - x_p.k_p) (get_phase_difference, :149-163).
+ * xs / ks: HOST tables of n_points device pointers to tight (3,n) arrays; out (n) device. */
+int32_t prt_path_sums(int32_t device, int32_t n_points, int64_t n, const double *const *xs,
+                      const double *const *ks, int32_t mode, double *out, void *stream);
+
 /*
  * Moments of a (3,n) point array (row pitch `pitch`, 0 = n) over the rays whose mask byte is
  * non-zero (mask NULL = all):  out7 (HOST) = { count, sum(v) [3], sum(v^2) [3] } with

@@ -85,6 +85,13 @@ PROTOTYPES["prt_collimated_bundle"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.c
                                                        ctypes.c_int64, c_double_p, c_double_p,
                                                        c_double_p, c_stream])
 
+PROTOTYPES["prt_poynting_dir"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p,
+                                                  c_double_p, ctypes.c_int32, c_double_p, c_stream])
+PROTOTYPES["prt_path_sums"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                               ctypes.POINTER(ctypes.c_void_p),
+                                               ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
+                                               c_double_p, c_stream])
+
 _lib = None
 
 

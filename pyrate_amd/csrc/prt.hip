@@ -329,6 +329,52 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_efield_perp(int64_t N, const doub
     e_out[2 * N + i] = e.z;
 }
 
+// RayBundle.returnKtoD (ray.py:136-152) for one stored point: unit Poynting direction from
+// (k, E); e_mode as in first_direction (0: k/|k|, 1: E = ey, 2: E given).
+__global__ __launch_bounds__(PRT_BLOCK) void k_poynting_dir(int64_t N, const double *__restrict__ k_in,
+                                                            const double *__restrict__ e_re,
+                                                            const double *__restrict__ e_im,
+                                                            int32_t e_mode,
+                                                            double *__restrict__ d_out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const vec3 kk = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
+    vec3 k[2] = {kk, kk};
+    vec3 dd[2];
+    first_direction<false>(e_mode, e_re, e_im, N, i, false, k, dd);
+    d_out[i] = dd[0].x;
+    d_out[N + i] = dd[0].y;
+    d_out[2 * N + i] = dd[0].z;
+}
+
+// RayBundleAnalysis.get_arc_length / get_phase_difference (analysis/ray_analysis.py:136-163):
+// per ray, sum over consecutive stored points p of |x_{p+1} - x_p|  (mode 0) or of
+// x_{p+1}.k_{p+1} - x_p.k_p (mode 1).  xs / ks: device tables of P pointers to tight (3,N) arrays.
+__global__ __launch_bounds__(PRT_BLOCK) void k_path_sums(int32_t P, int64_t N,
+                                                         const double *const *__restrict__ xs,
+                                                         const double *const *__restrict__ ks,
+                                                         int32_t mode, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    double acc = 0.0;
+    vec3 xa = v3(xs[0][i], xs[0][N + i], xs[0][2 * N + i]);
+    double pa = 0.0;
+    if (mode == 1) pa = dot(xa, v3(ks[0][i], ks[0][N + i], ks[0][2 * N + i]));
+    for (int p = 1; p < P; ++p) {
+        const vec3 xb = v3(xs[p][i], xs[p][N + i], xs[p][2 * N + i]);
+        if (mode == 0) {
+            const vec3 dlt = v3(xb.x - xa.x, xb.y - xa.y, xb.z - xa.z);
+            acc += sqrt(dot(dlt, dlt));
+        } else {
+            const double pb = dot(xb, v3(ks[p][i], ks[p][N + i], ks[p][2 * N + i]));
+            acc += pb - pa;
+            pa = pb;
+        }
+        xa = xb;
+    }
+    out[i] = acc;
+}
+
 // ---------------------------------------------------------------------------
 // bundle moments: count, sum (x - ref), sum (x - ref)^2 per component over the rays whose
 // mask byte is non-zero (all rays if mask == NULL).  Two deterministic stages (fixed
@@ -388,12 +434,50 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_moments_partial(int64_t N, int64_
     }
 }
 
-__global__ void k_moments_final(int nblocks_, const double *__restrict__ partials,
-                                double *__restrict__ out) {
-    if (threadIdx.x < MOM_VALUES) {
-        double v = 0.0;
-        for (int b = 0; b < nblocks_; ++b) v += partials[(int64_t)b * MOM_VALUES + threadIdx.x];
-        out[threadIdx.x] = v;
+__global__ __launch_bounds__(PRT_BLOCK) void k_moments_final(int nblocks_,
+                                                             const double *__restrict__ partials,
+                                                             double *__restrict__ out) {
+    // fixed summation order: thread t adds blocks t, t+256, ...; then a fixed-shape tree
+    __shared__ double sh[PRT_BLOCK][MOM_VALUES];
+    double acc[MOM_VALUES] = {0, 0, 0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks_; b += PRT_BLOCK)
+#pragma unroll
+        for (int q = 0; q < MOM_VALUES; ++q) acc[q] += partials[(int64_t)b * MOM_VALUES + q];
+#pragma unroll
+    for (int q = 0; q < MOM_VALUES; ++q) sh[threadIdx.x][q] = acc[q];
+    __syncthreads();
+    for (int stride = PRT_BLOCK / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride)
+#pragma unroll
+            for (int q = 0; q < MOM_VALUES; ++q) sh[threadIdx.x][q] += sh[threadIdx.x + stride][q];
+        __syncthreads();
+    }
+    if (threadIdx.x < MOM_VALUES) out[threadIdx.x] = sh[0][threadIdx.x];
+}
+
+// Order-preserving slot assignment inside one CMP_TILE (= 4 sub-tiles of PRT_BLOCK consecutive
+// elements; thread t owns elements q*PRT_BLOCK + t, so loads and stores are lane-consecutive):
+// ballot + popcount per wave, then a prefix over the 4 x 4 (sub-tile, wave) counts.
+// keep[q] in -> pos[q] out (offset of the element among the tile's survivors).
+PRT_DEV void tile_slots(const bool keep[CMP_ITEMS], int pos[CMP_ITEMS]) {
+    __shared__ int cnt[CMP_ITEMS][PRT_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int rank[CMP_ITEMS];
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        const unsigned long long b = __ballot(keep[q]);
+        rank[q] = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) cnt[q][wave] = __popcll(b);
+    }
+    __syncthreads();
+    int run = 0;
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+#pragma unroll
+        for (int w = 0; w < PRT_BLOCK / 64; ++w) {
+            if (w == wave) pos[q] = run + rank[q];
+            run += cnt[q][w];
+        }
     }
 }
 
@@ -405,11 +489,13 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_compact_count(const uint8_t *__re
                                                              int64_t N,
                                                              int64_t *__restrict__ block_sums) {
     __shared__ int wsum[PRT_BLOCK / 64];
-    const int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_ITEMS;
+    const int64_t tile = (int64_t)blockIdx.x * CMP_TILE;
     int c = 0;
 #pragma unroll
-    for (int q = 0; q < CMP_ITEMS; ++q)
-        if (base + q < N && mask[base + q]) ++c;
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        const int64_t idx = tile + q * PRT_BLOCK + threadIdx.x;
+        if (idx < N && mask[idx]) ++c;
+    }
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
@@ -454,35 +540,24 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_compact_scatter(
     int32_t n_arrays, const double *const *__restrict__ src, double *const *__restrict__ dst,
     const int64_t *__restrict__ id_src, int64_t *__restrict__ id_dst,
     const uint8_t *__restrict__ u8_src, uint8_t *__restrict__ u8_dst) {
-    __shared__ int woff[PRT_BLOCK / 64];
-    const int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_ITEMS;
+    const int64_t tile = (int64_t)blockIdx.x * CMP_TILE;
     bool keep[CMP_ITEMS];
-    int c = 0;
+    int pos[CMP_ITEMS];
 #pragma unroll
     for (int q = 0; q < CMP_ITEMS; ++q) {
-        keep[q] = (base + q < N) && mask[base + q];
-        c += keep[q] ? 1 : 0;
+        const int64_t idx = tile + q * PRT_BLOCK + threadIdx.x;
+        keep[q] = (idx < N) && mask[idx];
     }
-    // inclusive scan of c within the wave
-    int incl = c;
-    const int lane = threadIdx.x & 63;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) woff[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wbase += woff[w];
-    int64_t pos = block_offs[blockIdx.x] + wbase + (incl - c);
+    tile_slots(keep, pos);
+    const int64_t off = block_offs[blockIdx.x];
 #pragma unroll
     for (int q = 0; q < CMP_ITEMS; ++q) {
-        if (keep[q]) {
-            for (int a = 0; a < n_arrays; ++a) dst[a][pos] = src[a][base + q];
-            if (id_src) id_dst[pos] = id_src[base + q];
-            if (u8_src) u8_dst[pos] = u8_src[base + q];
-            ++pos;
-        }
+        if (!keep[q]) continue;
+        const int64_t idx = tile + q * PRT_BLOCK + threadIdx.x;
+        const int64_t o = off + pos[q];
+        for (int a = 0; a < n_arrays; ++a) dst[a][o] = src[a][idx];
+        if (id_src) id_dst[o] = id_src[idx];
+        if (u8_src) u8_dst[o] = u8_src[idx];
     }
 }
 
@@ -527,50 +602,39 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_rectgrid_scatter(
     const int64_t *__restrict__ block_offs, int64_t lo, int64_t hi, collimated_params prm,
     int64_t pitch, double *__restrict__ x_out, double *__restrict__ k_out,
     double *__restrict__ e_out) {
-    __shared__ int woff[PRT_BLOCK / 64];
     const int64_t total = n * n;
-    const int64_t base = (int64_t)blockIdx.x * CMP_TILE + (int64_t)threadIdx.x * CMP_ITEMS;
+    const int64_t tile = (int64_t)blockIdx.x * CMP_TILE;
     bool keep[CMP_ITEMS];
-    int c = 0;
+    int pos[CMP_ITEMS];
 #pragma unroll
     for (int q = 0; q < CMP_ITEMS; ++q) {
-        keep[q] = (base + q < total) && mask[base + q];
-        c += keep[q] ? 1 : 0;
+        const int64_t idx = tile + q * PRT_BLOCK + threadIdx.x;
+        keep[q] = (idx < total) && mask[idx];
     }
-    int incl = c;
-    const int lane = threadIdx.x & 63;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) woff[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    int wbase = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) wbase += woff[w];
-    int64_t pos = block_offs[blockIdx.x] + wbase + (incl - c);
+    tile_slots(keep, pos);
+    const int64_t off = block_offs[blockIdx.x];
 #pragma unroll
     for (int q = 0; q < CMP_ITEMS; ++q) {
         if (!keep[q]) continue;
-        if (pos >= lo && pos < hi) {
-            const int64_t idx = base + q;
-            const int64_t iy = idx / n, ix = idx - iy * n;
-            const double px = lin_sample(ix, n, start, step, stop);
-            const double py = lin_sample(iy, n, start, step, stop);
-            const int64_t o = pos - lo;
-            // origin = radius * p + start (optical_system_analysis.py:106-108), two roundings
-            x_out[o] = add_rn(mul_rn(prm.radius, px), prm.startx);
-            x_out[pitch + o] = add_rn(mul_rn(prm.radius, py), prm.starty);
-            x_out[2 * pitch + o] = prm.startz;
-            k_out[o] = prm.k[0];
-            k_out[pitch + o] = prm.k[1];
-            k_out[2 * pitch + o] = prm.k[2];
-            if (e_out) {
-                e_out[o] = prm.e[0];
-                e_out[pitch + o] = prm.e[1];
-                e_out[2 * pitch + o] = prm.e[2];
-            }
+        const int64_t p = off + pos[q];
+        if (p < lo || p >= hi) continue;
+        const int64_t idx = tile + q * PRT_BLOCK + threadIdx.x;
+        const int64_t iy = idx / n, ix = idx - iy * n;
+        const double px = lin_sample(ix, n, start, step, stop);
+        const double py = lin_sample(iy, n, start, step, stop);
+        const int64_t o = p - lo;
+        // origin = radius * p + start (optical_system_analysis.py:106-108), two roundings
+        x_out[o] = add_rn(mul_rn(prm.radius, px), prm.startx);
+        x_out[pitch + o] = add_rn(mul_rn(prm.radius, py), prm.starty);
+        x_out[2 * pitch + o] = prm.startz;
+        k_out[o] = prm.k[0];
+        k_out[pitch + o] = prm.k[1];
+        k_out[2 * pitch + o] = prm.k[2];
+        if (e_out) {
+            e_out[o] = prm.e[0];
+            e_out[pitch + o] = prm.e[1];
+            e_out[2 * pitch + o] = prm.e[2];
         }
-        ++pos;
     }
 }
 
@@ -1056,6 +1120,40 @@ int32_t prt_collimated_bundle(int32_t device, int64_t nray, int64_t lo, int64_t 
     return rc;
 }
 
+int32_t prt_poynting_dir(int32_t device, int64_t n, const double *k, const double *e_re,
+                         const double *e_im, int32_t use_default_e, double *d_out, void *stream) {
+    if (n < 0) return fail(PRT_ERR_INVALID_ARG, "prt_poynting_dir: negative count");
+    if (n == 0) return PRT_OK;
+    if (!k || !d_out) return fail(PRT_ERR_INVALID_ARG, "prt_poynting_dir: null pointer");
+    HIP_TRY(hipSetDevice(device));
+    hipLaunchKernelGGL(k_poynting_dir, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
+                       (hipStream_t)stream, n, k, e_re, e_im, e_mode_of(e_re, use_default_e), d_out);
+    HIP_TRY(hipGetLastError());
+    return PRT_OK;
+}
+
+int32_t prt_path_sums(int32_t device, int32_t n_points, int64_t n, const double *const *xs,
+                      const double *const *ks, int32_t mode, double *out, void *stream) {
+    if (n < 0 || n_points < 1 || n_points > 64 || mode < 0 || mode > 1)
+        return fail(PRT_ERR_INVALID_ARG, "prt_path_sums: bad argument");
+    if (n == 0) return PRT_OK;
+    if (!xs || !out || (mode == 1 && !ks)) return fail(PRT_ERR_INVALID_ARG, "prt_path_sums: null pointer");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const double **d_tab = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&d_tab, sizeof(void *) * 2 * n_points, st));
+    HIP_TRY(hipMemcpyAsync((void *)d_tab, xs, sizeof(void *) * n_points, hipMemcpyHostToDevice, st));
+    if (ks)
+        HIP_TRY(hipMemcpyAsync((void *)(d_tab + n_points), ks, sizeof(void *) * n_points,
+                               hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_path_sums, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st, n_points, n,
+                       (const double *const *)d_tab, (const double *const *)(d_tab + n_points), mode, out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));   // the host pointer tables must outlive the copies
+    HIP_TRY(hipFreeAsync((void *)d_tab, st));
+    return PRT_OK;
+}
+
 int32_t prt_bundle_moments(int32_t device, int64_t n, int64_t pitch, const double *x,
                            const uint8_t *mask, int32_t mode, const double *ref, double *out7,
                            void *stream) {
@@ -1076,7 +1174,7 @@ int32_t prt_bundle_moments(int32_t device, int64_t n, int64_t pitch, const doubl
     const double rx = ref ? ref[0] : 0.0, ry = ref ? ref[1] : 0.0, rz = ref ? ref[2] : 0.0;
     hipLaunchKernelGGL(k_moments_partial, dim3(nb), dim3(PRT_BLOCK), 0, st, n, pitch, x, mask, mode, rx,
                        ry, rz, scratch);
-    hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(64), 0, st, nb, scratch,
+    hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, nb, scratch,
                        scratch + (int64_t)nb * MOM_VALUES);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out7, scratch + (int64_t)nb * MOM_VALUES, sizeof(double) * MOM_VALUES,

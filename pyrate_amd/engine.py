@@ -285,7 +285,7 @@ def compact(mask, arrays, ids=None, flags=None):
     r0 = 0
     for a in arrays:
         rr = a.shape[0]
-        out.append(tmp[r0:r0 + rr, :m].contiguous())
+        out.append(tmp[r0:r0 + rr, :m])        # row-pitched view (pitch n), no second copy
         r0 += rr
     idc = idt[:m].contiguous() if ids is not None else None
     if flags is not None:
@@ -345,6 +345,35 @@ def collimated_bundle_device(nray, radius, start, kvec, evec, device, lo=0, hi=N
                                              _ptr(bufs[0]), _ptr(bufs[1]), _ptr(bufs[2]),
                                              _stream_handle(device)))
     return bufs[0][:, :n], bufs[1][:, :n], bufs[2][:, :n], total
+
+
+def poynting_dir(k, e_re=None, e_im=None, default_e=False):
+    """unit Poynting directions (3, N) on the device (prt_poynting_dir; ray.py:136-152)"""
+    lib = _lib.load()
+    (k, e_re, e_im) = [_rows_contiguous(t) for t in (k, e_re, e_im)]
+    _check_rays(k, "k")
+    with torch.cuda.device(k.device):
+        d = torch.empty((3, k.shape[1]), dtype=torch.float64, device=k.device)
+        _lib.check(lib.prt_poynting_dir(k.device.index, k.shape[1], _ptr(k), _ptr(e_re), _ptr(e_im),
+                                        1 if default_e else 0, _ptr(d), _stream_handle(k.device)))
+    return d
+
+
+def path_sums(xs, ks=None, mode=0):
+    """per-ray arc length (mode 0) / phase difference (mode 1) over a list of (3, N) device arrays"""
+    lib = _lib.load()
+    xs = [_rows_contiguous(t) for t in xs]
+    n = xs[0].shape[1]
+    dev = xs[0].device
+    xt = (ctypes.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
+    kt = None
+    if ks is not None:
+        ks = [_rows_contiguous(t) for t in ks]
+        kt = (ctypes.c_void_p * len(ks))(*[t.data_ptr() for t in ks])
+    with torch.cuda.device(dev):
+        out = torch.empty(n, dtype=torch.float64, device=dev)
+        _lib.check(lib.prt_path_sums(dev.index, len(xs), n, xt, kt, mode, _ptr(out), _stream_handle(dev)))
+    return out
 
 
 def efield_perp(k):

@@ -34,51 +34,39 @@ class RayBundleAnalysis(object):
     def get_rms_spot_size_centroid(self):
         return self.get_rms_spot_size(self.get_centroid_position())
 
-    def _directions_source(self):
-        rb = self.raybundle
-        rb._ensure()
-        if rb._dir is not None:
-            return rb._dir                      # explicit Poynting directions (anisotropic media)
-        if not rb._dir_from_k:
-            return None                         # user bundle: E decides; use the host formula
-        return rb.k_dev(-1)
-
     def get_centroid_direction(self):
         """normalised mean of the unit ray directions (:88-102)"""
-        src = self._directions_source()
-        if src is None:
-            d = self.raybundle.returnKtoD()[-1]
-            com = np.sum(d, axis=1)
-        else:
-            (_, com, _) = engine.bundle_moments(src, mode=1)
+        (_, com, _) = engine.bundle_moments(self.raybundle.direction_dev(-1), mode=1)
         return com / np.sqrt(np.sum(com ** 2))
 
     def get_rms_angluar_size(self, ref_direction):
         """arcsin of the RMS of |d x ref| (:104-125; spelling as in the reference)"""
         ref = np.asarray(ref_direction, dtype=float).reshape(3)
-        src = self._directions_source()
-        if src is None:
-            d = self.raybundle.returnKtoD()[-1]
-            cr = np.cross(d, ref, axisa=0).T
-            return math.asin(math.sqrt(np.sum(cr ** 2) / d.shape[1]))
-        (cnt, _, s2) = engine.bundle_moments(src, ref=ref, mode=2)
+        (cnt, _, s2) = engine.bundle_moments(self.raybundle.direction_dev(-1), ref=ref, mode=2)
         return math.asin(math.sqrt(float(np.sum(s2)) / cnt))
 
     def get_rms_angluar_size_centroid(self):
         return self.get_rms_angluar_size(self.get_centroid_direction())
 
+    def _point_range(self, first, last):
+        rb = self.raybundle
+        rb._ensure()
+        npts = len(rb._x)
+        stop = npts if last is None else (last if last >= 0 else npts + last)
+        return list(range(first, stop))
+
     def get_arc_length(self, first=0, last=None):
-        """per-ray arc length over the stored points (:136-147); evaluated from the NumPy
-        views (a per-ray output array, not a reduction)"""
-        last_no = 0 if last is None else last
-        x = self.raybundle.x
-        delta_s = np.sqrt(np.sum((x[first + 1:last] - x[first:-1 + last_no]) ** 2, axis=1))
-        return np.sum(delta_s, axis=0)
+        """per-ray arc length over the stored points first..last (:136-147), device kernel
+        (prt_path_sums); returned as a NumPy array like the reference"""
+        idx = self._point_range(first, last)
+        if len(idx) < 2:
+            return np.zeros(self.raybundle.num_rays)
+        return engine.path_sums([self.raybundle._x[p] for p in idx], mode=0).cpu().numpy()
 
     def get_phase_difference(self, first=0, last=None):
-        """(:149-163)"""
-        last_no = 0 if last is None else last
-        x = self.raybundle.x
-        k_real = np.real(self.raybundle.k)
-        dph = x[first + 1:last] * k_real[first + 1:last] - x[first:-1 + last_no] * k_real[first:-1 + last_no]
-        return np.sum(np.sum(dph, axis=1), axis=0)
+        """per-ray sum of x.k differences between consecutive stored points (:149-163)"""
+        idx = self._point_range(first, last)
+        if len(idx) < 2:
+            return np.zeros(self.raybundle.num_rays)
+        rb = self.raybundle
+        return engine.path_sums([rb._x[p] for p in idx], [rb._k[p] for p in idx], mode=1).cpu().numpy()

@@ -275,16 +275,22 @@ class RayBundle(object):
     def __deepcopy__(self, memo):
         return self.clone()
 
+    def direction_dev(self, num=-1):
+        """unit Poynting direction of stored point ``num`` on the device (ray.py:136-152)"""
+        self._ensure()
+        last = (num == -1 or num == len(self._x) - 1)
+        if last and self._dir is not None:
+            return self._dir
+        e = self._e[num]
+        if e is None:
+            return engine.poynting_dir(self._k[num], default_e=self._e_default)
+        return engine.poynting_dir(self._k[num], e[0], e[1])
+
     def returnKtoD(self):
-        """unit Poynting directions for all points, (P,3,N) (ray.py:136-152); evaluated on
-        the host from the NumPy views -- a convenience for callers, the trace itself
-        computes directions inside the kernels."""
-        k = np.asarray(self.k)
-        E = np.asarray(self.Efield)
-        absE2 = np.sum(np.conj(E) * E, axis=1, keepdims=True)
-        Ek = np.sum(E * k, axis=1, keepdims=True)
-        S = np.real(absE2 * k - Ek * np.conj(E))
-        return S / np.sqrt(np.sum(S ** 2, axis=1, keepdims=True))
+        """unit Poynting directions for all stored points, (P,3,N) (ray.py:136-152); computed
+        on the device (prt_poynting_dir), returned as NumPy like the reference"""
+        self._ensure()
+        return np.stack([self.direction_dev(p).cpu().numpy() for p in range(len(self._x))])
 
 
 class RayPath(object):

@@ -45,7 +45,7 @@ float run(int S, int64_t N, double* x0, double* k0, double* xh, double* ko, uint
 #define ROW(IT) { float tc = run<IT,false,1>(S,N,x0,k0,xh,ko,v1,v2); float ts = run<IT,true,1>(S,N,x0,k0,xh,ko,v1,v2); \
    printf("fp64 instr/ray/surface %4d : compute-only %.3f ms   compute+stores %.3f ms\n", IT*6, tc, ts); }
 int main(){
-  const int S=12; const int64_t N = 9994476;
+  const int S=12; const int64_t N = 9994752;
   double *x0,*k0,*xh,*ko; uint8_t *v1,*v2;
   CHECK(hipMalloc(&x0, 3*N*8)); CHECK(hipMalloc(&k0, 3*N*8));
   CHECK(hipMalloc(&xh, (size_t)S*3*N*8)); CHECK(hipMalloc(&ko, (size_t)S*3*N*8));
