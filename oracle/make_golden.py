@@ -167,6 +167,11 @@ def case_mirror():
     dump_case("mirrors", s, seq, disk_bundle(128, 10.0, -5.0, field_deg=1.0))
 
 
+def case_hud():
+    (s, seq) = build_simple_optical_system(zoo.hud_like_builduplist())
+    dump_case("hud_biconic_mirrors", s, seq, disk_bundle(120, 9.0, -5.0, field_deg=1.0))
+
+
 def case_two_elements():
     (s, seq) = zoo.two_element_system(REFAPI)
     dump_case("two_elements", s, seq, disk_bundle(200, 7.0, -2.0, field_deg=1.5))
@@ -212,6 +217,7 @@ def main():
     case_biconic()
     case_tilted()
     case_mirror()
+    case_hud()
     case_two_elements()
     case_aniso()
 

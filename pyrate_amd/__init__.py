@@ -11,3 +11,12 @@ RayBundle / Surface.intersect / Material.refract API.
     pyrate_amd.distributed  ray sharding over ranks + image-plane all-gather
 """
 __version__ = "0.1.0"
+
+
+def __getattr__(name):
+    """lazy re-exports of the convenience entry points (pyrateoptics/__init__.py:83-465)"""
+    if name in ("build_rotationally_symmetric_optical_system", "build_simple_optical_element",
+                "build_simple_optical_system", "raytrace"):
+        from . import builders
+        return getattr(builders, name)
+    raise AttributeError(name)

@@ -159,6 +159,21 @@ def mirrors_builduplist():
     ]
 
 
+def hud_like_builduplist():
+    """off-axis biconic mirrors in tilted / decentred frames (the kind of system of the
+    reference's demos/demo_hud.py:87-104), all rays valid"""
+    return [
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
+        ({"shape": "Biconic", "curvx": -1. / 300., "curvy": -1. / 260., "ccx": -0.8, "ccy": 0.3,
+          "coefficients": [(2e-6, 0.2)]}, {"decz": 40.0, "tiltx": 0.25, "decy": 1.0}, None, "m1",
+         {"is_mirror": True}),
+        ({"shape": "Biconic", "curvx": 1. / 500., "curvy": 1. / 420., "ccx": 0.0, "ccy": -0.5,
+          "coefficients": []}, {"decz": -35.0, "tiltx": 0.25, "tiltThenDecenter": 1}, None, "m2",
+         {"is_mirror": True}),
+        ({"shape": "Conic"}, {"decz": 45.0, "tiltx": -0.05}, None, "image", {}),
+    ]
+
+
 def two_element_system(api):
     """two OpticalElements in one system: exercises the element loop of
     OpticalSystem.seqtrace (bundle duplicated at the element boundary, material reset to
