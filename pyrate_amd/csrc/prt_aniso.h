@@ -125,7 +125,7 @@ PRT_DEV void quartic_roots(const double p[5], cplx z[4]) {
         if (!done) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) z[i] = csub(z[i], w[i]);
-            done = worst < 1e-30;
+            done = worst < 1e-22;  // 1e-11 relative: the real-polynomial Newton polish below finishes the job
         }
         if (__all(done)) break;
     }
@@ -133,32 +133,34 @@ PRT_DEV void quartic_roots(const double p[5], cplx z[4]) {
 
 // null vector(s) of the real 3x3 matrix W.  variant selects which of the two
 // basis vectors is returned when W has rank <= 1 (touching dispersion sheets).
-PRT_DEV vec3 null_vector(const double W[9], int variant) {
-    const vec3 r0 = v3(W[0], W[1], W[2]), r1 = v3(W[3], W[4], W[5]), r2 = v3(W[6], W[7], W[8]);
+// (rows passed as three register vectors: with an array the compiler turns the row selection
+// of the fallback into indexed scratch loads)
+PRT_DEV vec3 null_vector(const vec3 &r0, const vec3 &r1, const vec3 &r2, int variant) {
     const vec3 c01 = cross(r0, r1), c02 = cross(r0, r2), c12 = cross(r1, r2);
     const double n01 = dot(c01, c01), n02 = dot(c02, c02), n12 = dot(c12, c12);
-    vec3 best = c01;
-    double nb = n01;
-    if (n02 > nb) { best = c02; nb = n02; }
-    if (n12 > nb) { best = c12; nb = n12; }
+    // component-wise selects (a vec3 "best = cXY" under an if becomes an indexed scratch load)
+    const bool p02 = (n02 > n01) && (n02 >= n12), p12 = (n12 > n01) && (n12 > n02);
+    const double nb = p12 ? n12 : (p02 ? n02 : n01);
+    const vec3 best = v3(p12 ? c12.x : (p02 ? c02.x : c01.x), p12 ? c12.y : (p02 ? c02.y : c01.y),
+                         p12 ? c12.z : (p02 ? c02.z : c01.z));
     const double fro = dot(r0, r0) + dot(r1, r1) + dot(r2, r2);
     if (nb > 1e-20 * fro * fro) {
-        const double inv = 1.0 / sqrt(nb);
+        const double inv = fast_rsqrt(nb);
         return v3(best.x * inv, best.y * inv, best.z * inv);
     }
     // rank <= 1: null space is the plane perpendicular to the dominant row
-    vec3 r = r0;
-    double nr = dot(r0, r0);
-    if (dot(r1, r1) > nr) { r = r1; nr = dot(r1, r1); }
-    if (dot(r2, r2) > nr) { r = r2; nr = dot(r2, r2); }
+    const double q0 = dot(r0, r0), q1 = dot(r1, r1), q2 = dot(r2, r2);
+    const bool use1 = (q1 > q0) && (q1 >= q2), use2 = (q2 > q0) && (q2 > q1);
+    const vec3 r = v3(use2 ? r2.x : (use1 ? r1.x : r0.x), use2 ? r2.y : (use1 ? r1.y : r0.y),
+                      use2 ? r2.z : (use1 ? r1.z : r0.z));
     const double ax = fabs(r.x), ay = fabs(r.y), az = fabs(r.z);
     vec3 a = (ax <= ay && ax <= az) ? v3(1, 0, 0) : ((ay <= az) ? v3(0, 1, 0) : v3(0, 0, 1));
     vec3 v1 = cross(r, a);
-    double inv = 1.0 / sqrt(dot(v1, v1));
+    double inv = fast_rsqrt(dot(v1, v1));
     v1 = v3(v1.x * inv, v1.y * inv, v1.z * inv);
     if (variant == 0) return v1;
     vec3 v2 = cross(r, v1);
-    inv = 1.0 / sqrt(dot(v2, v2));
+    inv = fast_rsqrt(dot(v2, v2));
     return v3(v2.x * inv, v2.y * inv, v2.z * inv);
 }
 
@@ -180,18 +182,18 @@ PRT_DEV void interact_anisotropic(const prt_surface_t *__restrict__ sf, const ve
     const int cls = sf->aniso_class;
     if (cls == PRT_ANISO_ISOTROPIC) {
         const double e = sf->aniso_eo;
-        const double r = sqrt(e - kap2);  // NaN if evanescent
+        const double r = fast_sqrt(e - kap2);  // NaN if evanescent
         xi[0] = -r; xi[1] = -r; xi[2] = r; xi[3] = r;
         variant[0] = 0; variant[1] = 1; variant[2] = 0; variant[3] = 1;
     } else if (cls == PRT_ANISO_UNIAXIAL) {
         const double eo = sf->aniso_eo, ee = sf->aniso_ee;
         const vec3 c = v3(sf->aniso_axis[0], sf->aniso_axis[1], sf->aniso_axis[2]);
-        const double ro = sqrt(eo - kap2);
+        const double ro = fast_sqrt(eo - kap2);
         const double nc = dot(n, c), kc = dot(kpa, c);
         const double A = eo + (ee - eo) * nc * nc;
         const double Bh = (ee - eo) * kc * nc;  // B/2
         const double C = eo * kap2 + (ee - eo) * kc * kc - eo * ee;
-        const double disc = sqrt(Bh * Bh - A * C);  // NaN if evanescent
+        const double disc = fast_sqrt(Bh * Bh - A * C);  // NaN if evanescent
         // stable quadratic roots
         const double q = -(Bh + copysign(disc, Bh));
         double x1 = q / A, x2 = (q != 0.0) ? C / q : -x1;
@@ -235,28 +237,39 @@ PRT_DEV void interact_anisotropic(const prt_surface_t *__restrict__ sf, const ve
     for (int i = 0; i < 4; ++i) {
         const vec3 kv = v3(kpa.x + xi[i] * n.x, kpa.y + xi[i] * n.y, kpa.z + xi[i] * n.z);
         const double k2 = dot(kv, kv);
-        double W[9];
-        W[0] = eps[0] - k2 + kv.x * kv.x; W[1] = eps[1] + kv.x * kv.y; W[2] = eps[2] + kv.x * kv.z;
-        W[3] = eps[3] + kv.y * kv.x; W[4] = eps[4] - k2 + kv.y * kv.y; W[5] = eps[5] + kv.y * kv.z;
-        W[6] = eps[6] + kv.z * kv.x; W[7] = eps[7] + kv.z * kv.y; W[8] = eps[8] - k2 + kv.z * kv.z;
-        vec3 E = null_vector(W, variant[i]);
-        const double sc = 1.0 / sqrt(1.0 + xi[i] * xi[i]);  // LAPACK unit-norm [xi E; E]
+        const vec3 w0 = v3(eps[0] - k2 + kv.x * kv.x, eps[1] + kv.x * kv.y, eps[2] + kv.x * kv.z);
+        const vec3 w1 = v3(eps[3] + kv.y * kv.x, eps[4] - k2 + kv.y * kv.y, eps[5] + kv.y * kv.z);
+        const vec3 w2 = v3(eps[6] + kv.z * kv.x, eps[7] + kv.z * kv.y, eps[8] - k2 + kv.z * kv.z);
+        vec3 E = null_vector(w0, w1, w2, variant[i]);
+        const double sc = fast_rsqrt(1.0 + xi[i] * xi[i]);  // LAPACK unit-norm [xi E; E]
         E = v3(E.x * sc, E.y * sc, E.z * sc);
         const double e2 = dot(E, E), ke = dot(kv, E);
         const vec3 S = v3(e2 * kv.x - ke * E.x, e2 * kv.y - ke * E.y, e2 * kv.z - ke * E.z);
         kk[i] = kv; ee_[i] = E; ss[i] = S;
         sn[i] = dot(S, n);
     }
-    // argsort ascending by S.n (material.py:147); NaNs last like numpy
-    int idx[4] = {0, 1, 2, 3};
-#pragma unroll
-    for (int i = 1; i < 4; ++i)
-#pragma unroll
-        for (int j = i; j > 0; --j) {
-            const double a = sn[idx[j]], b = sn[idx[j - 1]];
-            const bool less = (a < b) || (isnan(b) && !isnan(a));
-            if (less) { int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t; }
-        }
+    // argsort ascending by S.n (material.py:147); NaNs last like numpy.  Compare-exchange
+    // network on (key, id) pairs held in registers (indexing sn[] by a sorted index would put
+    // the arrays in scratch memory).
+    int id0 = 0, id1 = 1, id2 = 2, id3 = 3;
+    double s0 = sn[0], s1 = sn[1], s2 = sn[2], s3 = sn[3];
+#define PRT_CSWAP(ka, kb, ia, ib)                                   \
+    {                                                               \
+        const bool sw = (kb < ka) || (isnan(ka) && !isnan(kb));     \
+        const double tk = sw ? kb : ka;                             \
+        kb = sw ? ka : kb;                                          \
+        ka = tk;                                                    \
+        const int ti = sw ? ib : ia;                                \
+        ib = sw ? ia : ib;                                          \
+        ia = ti;                                                    \
+    }
+    PRT_CSWAP(s0, s1, id0, id1)
+    PRT_CSWAP(s2, s3, id2, id3)
+    PRT_CSWAP(s0, s2, id0, id2)
+    PRT_CSWAP(s1, s3, id1, id3)
+    PRT_CSWAP(s1, s2, id1, id2)
+#undef PRT_CSWAP
+    const int idx[4] = {id0, id1, id2, id3};
     const bool mirror = sf->interaction == PRT_MIRROR;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -271,7 +284,7 @@ PRT_DEV void interact_anisotropic(const prt_surface_t *__restrict__ sf, const ve
             E = v3(-E.x, -E.y, -E.z);
             S = v3(-S.x, -S.y, -S.z);
         }
-        const double inv = 1.0 / sqrt(dot(S, S));
+        const double inv = fast_rsqrt(dot(S, S));
         vec3 d = v3(S.x * inv, S.y * inv, S.z * inv);
         if (!mat_id) {
             kv = mat_vec(sf->B_mat, kv);

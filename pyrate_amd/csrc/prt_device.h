@@ -71,6 +71,15 @@ PRT_DEV double fast_sqrt(double x) {
     return (x == 0.0) ? 0.0 : g;
 }
 
+// 1/sqrt(x) to ~1 ulp: v_rsq_f64 + two Newton steps  r <- r (1.5 - 0.5 x r^2)
+PRT_DEV double fast_rsqrt(double x) {
+    const double r0 = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    double r = r0 * __builtin_fma(-h * r0, r0, 1.5);
+    r = r * __builtin_fma(-h * r, r, 1.5);
+    return r;
+}
+
 PRT_DEV bool finite3(const vec3 &v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
 
 // ---------------------------------------------------------------------------
@@ -366,11 +375,7 @@ PRT_DEV vec3 to_shape_frame(const prt_surface_t *__restrict__ sf, const vec3 &xh
 PRT_DEV vec3 normal_from_grad(const prt_surface_t *__restrict__ sf, const vec3 &g, double g2) {
     vec3 n = g;
     if (!(sf->shape_type == PRT_SHAPE_CONIC && sf->cc == 0.0)) {
-        const double inv = __builtin_amdgcn_rsq(g2);
-        // one Newton step on the reciprocal square root: inv *= (1.5 - 0.5 g2 inv^2), twice
-        const double h = 0.5 * g2;
-        double r = inv * __builtin_fma(-h * inv, inv, 1.5);
-        r = r * __builtin_fma(-h * r, r, 1.5);
+        const double r = fast_rsqrt(g2);
         n = v3(g.x * r, g.y * r, g.z * r);
     }
     const int ff = sf->frame_flags;
