@@ -55,6 +55,8 @@ class OpticalSystem(LocalCoordinatesTreeBase):
         initialbundle._ensure()
         fused_ok = all(r["material"]["type"] == "isotropic" for r in records) \
             and initialbundle._dir is None and len(records) > 0
+        if fused_ok and len(initialbundle._valid) > 1 and not bool(initialbundle._valid[-1].all()):
+            fused_ok = False      # a bundle that already carries invalid rays: per-surface path
         if fused_ok:
             return [self._seqtrace_fused(initialbundle, records, lengths)]
         return self._seqtrace_generic(initialbundle, elementsequence, splitup)
