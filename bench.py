@@ -103,7 +103,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=10_000_000, help="requested rays per GPU")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the image-plane all-gather")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the final image-plane all-gather")
+    ap.add_argument("--no-stats", action="store_true", help="N>1: skip the per-step spot statistics all-reduce")
+    ap.add_argument("--gather-every-step", action="store_true",
+                    help="N>1: all-gather the image plane (49 B/ray) after every step instead of once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["path", "image"], default="path")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -152,31 +155,57 @@ def main():
     sysds = [engine.DeviceSystem(r, local_rank) for r in record_sets]
     sysd = sysds[0]
     mode = _lib.MODE_PATH if args.mode == "path" else _lib.MODE_IMAGE
-    do_gather = (n_gpus > 1) and not args.no_gather
-    nbuf = 2 if do_gather else 1
+    multi = n_gpus > 1
+    # N > 1 (BASELINE configs[4]): every step ends with the device-side image-plane spot
+    # statistics of the sharded bundle (two 7-double all-reduces instead of moving the image
+    # plane), issued on a side stream so that they overlap the next step's
+    # trace; the full image plane is all-gathered ONCE, after the last step ("the final
+    # image-plane gather"), inside the timed region.  --gather-every-step moves the 49 B/ray
+    # all-gather into every step instead.
+    do_stats = multi and not args.no_stats
+    do_final_gather = multi and not args.no_gather and not args.gather_every_step
+    do_step_gather = multi and args.gather_every_step
+    nbuf = 2 if (do_stats or do_step_gather) else 1
     bufs = [sysd.alloc_outputs(n_local, mode) for _ in range(nbuf)]
-    gathers = [pdist.ImagePlaneGather(n_total, dev, stage_on_host=(args.backend == "gloo"))
-               for _ in range(nbuf)] if do_gather else []
-    comm_stream = torch.cuda.Stream(device=dev) if do_gather else None
+    host_staged = (args.backend == "gloo")
+    stats = [pdist.SpotStatistics(dev) for _ in range(nbuf)] if do_stats else []
+    gathers = [pdist.ImagePlaneGather(n_total, dev, stage_on_host=host_staged)
+               for _ in range(nbuf if do_step_gather else 1)] if (do_step_gather or do_final_gather) else []
+    comm_stream = torch.cuda.Stream(device=dev) if multi else None
     main_stream = torch.cuda.current_stream(dev)
+    side_done = [None] * nbuf          # event: side-stream work on buffer pair b has finished
 
     def step(i):
-        b = bufs[i % nbuf]
-        if do_gather:
-            gathers[i % nbuf].wait()        # buffer pair i%2 is free once its last gather is done
-        sysds[i % len(sysds)].trace_into(x0, k0, b, e0d)
-        if do_gather:
+        b = i % nbuf
+        if side_done[b] is not None:
+            main_stream.wait_event(side_done[b])      # buffer pair b is free again
+        sysds[i % len(sysds)].trace_into(x0, k0, bufs[b], e0d)
+        if do_stats or do_step_gather:
             ev = torch.cuda.Event()
             ev.record(main_stream)
-            v = sysd.views(b)
+            v = sysd.views(bufs[b])
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
-                gathers[i % nbuf].start(v.x_hit[-1], v.k_out[-1], v.valid_out[-1])
+                if do_stats:
+                    stats[b].start(v.x_hit[-1], v.valid_out[-1])
+                if do_step_gather:
+                    gathers[b].wait()
+                    gathers[b].start(v.x_hit[-1], v.k_out[-1], v.valid_out[-1])
+                    gathers[b].wait()
+                done = torch.cuda.Event()
+                done.record(comm_stream)
+                side_done[b] = done
 
-    def drain():
-        for g in gathers:
+    def finish(last_step):
+        """everything that must be complete when the job is done"""
+        if do_final_gather and last_step >= 0:
+            v = sysd.views(bufs[last_step % nbuf])
+            ev = torch.cuda.Event()
+            ev.record(main_stream)
             with torch.cuda.stream(comm_stream):
-                g.wait()
+                comm_stream.wait_event(ev)
+                gathers[0].start(v.x_hit[-1], v.k_out[-1], v.valid_out[-1])
+                gathers[0].wait()
         if comm_stream is not None:
             comm_stream.synchronize()
         torch.cuda.synchronize()
@@ -187,13 +216,13 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    drain()
+    finish(args.warmup - 1)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    drain()
+    finish(args.steps - 1)
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -201,6 +230,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=(dev if args.backend == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    spot = None
+    if do_stats:
+        (cnt, cen, rms) = stats[(args.steps - 1) % nbuf].result()
+        spot = {"rays": float(cnt), "centroid_mm": [float(c) for c in cen], "rms_spot_mm": rms}
 
     # dominant kernel: average launch duration from HIP events on the launch stream
     kernel_ms = sysd.trace_timed(x0, k0, bufs[0], max(args.steps, 5), e0d)
@@ -238,8 +271,15 @@ def main():
                        "rays_per_gpu": n_local, "rays_total": n_total, "surfaces": S,
                        "mode": args.mode, "sharding": "rays" if n_gpus > 1 else "none",
                        "wavelengths": len(sysds),
-                       "image_plane_gather": (("rccl all-gather, overlapped" if args.backend == "nccl"
-                                               else "gloo dry run (host staged)") if do_gather else "none")},
+                       "image_plane_exchange": {
+                           "per_step": ("device spot statistics + two 7-double all-reduces, overlapped"
+                                        if do_stats else ("image-plane all-gather 49 B/ray" if do_step_gather
+                                                          else "none")),
+                           "final": ("image-plane all-gather 49 B/ray, once, inside the timed region"
+                                     if do_final_gather else "none"),
+                           "backend": ("rccl" if args.backend == "nccl" else "gloo dry run (host staged)")
+                           if multi else "none"},
+                       "image_plane_spot": spot},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_trace_iso", "kernel_ms": kernel_ms,

@@ -236,6 +236,17 @@ int32_t prt_bundle_moments(int32_t device, int64_t n, int64_t pitch, const doubl
                            const uint8_t *mask, int32_t mode, const double *ref, double *out7,
                            void *stream);
 
+/* The same reduction without host round trips (for stream pipelines and multi-GPU all-reduce
+ * chains): the result stays on the device (out7_dev), the reference point comes from the device
+ * (ref_kind 0: origin, 1: ref_dev = 3 doubles, 2: ref_dev = a moments vector, e.g. the all-reduced
+ * first pass -> reference = its centroid sum/(count + 1e-17)), scratch_dev holds at least
+ * prt_moments_scratch_doubles(n) doubles.  Asynchronous. */
+int64_t prt_moments_scratch_doubles(int64_t n);
+int32_t prt_bundle_moments_async(int32_t device, int64_t n, int64_t pitch, const double *x,
+                                 const uint8_t *mask, int32_t mode, const double *ref_dev,
+                                 int32_t ref_kind, double *out7_dev, double *scratch_dev,
+                                 void *stream);
+
 /*
  * Order-preserving compaction by mask (the reference's [:, valid] indexing):
  * n_arrays (<= 16) row pointers of n doubles each (src[r] -> dst[r]; the pointer

@@ -92,6 +92,11 @@ PROTOTYPES["prt_path_sums"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, 
                                                ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32,
                                                c_double_p, c_stream])
 
+PROTOTYPES["prt_moments_scratch_doubles"] = (ctypes.c_int64, [ctypes.c_int64])
+PROTOTYPES["prt_bundle_moments_async"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int64, ctypes.c_int64,
+                                                          c_double_p, c_u8_p, ctypes.c_int32, c_double_p,
+                                                          ctypes.c_int32, c_double_p, c_double_p, c_stream])
+
 _lib = None
 
 

@@ -389,7 +389,21 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_moments_partial(int64_t N, int64_
                                                                const uint8_t *__restrict__ mask,
                                                                int32_t mode, double rx, double ry,
                                                                double rz,
+                                                               const double *__restrict__ ref_dev,
+                                                               int32_t ref_kind,
                                                                double *__restrict__ partials) {
+    // ref_kind 1: ref_dev holds the reference point (3 doubles); 2: ref_dev holds a moments
+    // vector {count, sum x, ...} (e.g. all-reduced over the ranks) -> reference = centroid
+    if (ref_kind == 1) {
+        rx = ref_dev[0];
+        ry = ref_dev[1];
+        rz = ref_dev[2];
+    } else if (ref_kind == 2) {
+        const double inv = 1.0 / (ref_dev[0] + 1e-17);  // numerical_tolerance, ray_analysis.py:55
+        rx = ref_dev[1] * inv;
+        ry = ref_dev[2] * inv;
+        rz = ref_dev[3] * inv;
+    }
     double acc[MOM_VALUES] = {0, 0, 0, 0, 0, 0, 0};
     for (int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x; i < N;
          i += (int64_t)gridDim.x * PRT_BLOCK) {
@@ -1173,7 +1187,7 @@ int32_t prt_bundle_moments(int32_t device, int64_t n, int64_t pitch, const doubl
     HIP_TRY(hipMallocAsync((void **)&scratch, sizeof(double) * MOM_VALUES * (nb + 1), st));
     const double rx = ref ? ref[0] : 0.0, ry = ref ? ref[1] : 0.0, rz = ref ? ref[2] : 0.0;
     hipLaunchKernelGGL(k_moments_partial, dim3(nb), dim3(PRT_BLOCK), 0, st, n, pitch, x, mask, mode, rx,
-                       ry, rz, scratch);
+                       ry, rz, (const double *)nullptr, 0, scratch);
     hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, nb, scratch,
                        scratch + (int64_t)nb * MOM_VALUES);
     HIP_TRY(hipGetLastError());
@@ -1181,6 +1195,33 @@ int32_t prt_bundle_moments(int32_t device, int64_t n, int64_t pitch, const doubl
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipFreeAsync(scratch, st));
+    return PRT_OK;
+}
+
+int64_t prt_moments_scratch_doubles(int64_t n) {
+    (void)n;
+    return (int64_t)MOM_VALUES * 2048;
+}
+
+int32_t prt_bundle_moments_async(int32_t device, int64_t n, int64_t pitch, const double *x,
+                                 const uint8_t *mask, int32_t mode, const double *ref_dev,
+                                 int32_t ref_kind, double *out7_dev, double *scratch_dev,
+                                 void *stream) {
+    if (n < 0 || !out7_dev || !scratch_dev || mode < 0 || mode > 2 || ref_kind < 0 || ref_kind > 2 ||
+        (ref_kind != 0 && !ref_dev))
+        return fail(PRT_ERR_INVALID_ARG, "prt_bundle_moments_async: bad argument");
+    if (n > 0 && !x) return fail(PRT_ERR_INVALID_ARG, "prt_bundle_moments_async: null pointer");
+    if (pitch == 0) pitch = n;
+    if (pitch < n) return fail(PRT_ERR_INVALID_ARG, "prt_bundle_moments_async: pitch < n");
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    int nb = (int)((n + PRT_BLOCK * 8 - 1) / (PRT_BLOCK * 8));
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_moments_partial, dim3(nb), dim3(PRT_BLOCK), 0, st, n, pitch, x, mask, mode, 0.0,
+                       0.0, 0.0, ref_dev, ref_kind, scratch_dev);
+    hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, nb, scratch_dev, out7_dev);
+    HIP_TRY(hipGetLastError());
     return PRT_OK;
 }
 

@@ -114,3 +114,35 @@ def global_spot_statistics(x_img, valid=None, group=None, moments_fn=None):
     tot2 = allreduce(np.concatenate(([0.0], s2)))
     rms = float(np.sqrt(np.sum(tot2[1:4]) / (count - 1 + 1e-17)))
     return count, centroid, rms
+
+
+class SpotStatistics(object):
+    """Asynchronous, device-resident version of ``global_spot_statistics`` for stream pipelines:
+    ``start`` enqueues (current stream) pass 1 -> all-reduce -> pass 2 about the global centroid ->
+    all-reduce, with no host synchronisation; ``result`` syncs and returns
+    (count, centroid (3,), rms).  One instance per in-flight bundle."""
+
+    def __init__(self, device, group=None):
+        from . import engine
+        self.engine = engine
+        self.group = group
+        self.ws = engine.MomentsWorkspace(device, n_results=2)
+        self.multi = dist.is_initialized() and dist.get_world_size(group) > 1
+
+    def start(self, x_img, valid):
+        eng = self.engine
+        m1 = eng.bundle_moments_async(x_img, valid, self.ws, slot=0)
+        if self.multi:
+            dist.all_reduce(m1, op=dist.ReduceOp.SUM, group=self.group)     # stream-ordered (NCCL)
+        m2 = eng.bundle_moments_async(x_img, valid, self.ws, slot=1, ref_dev=m1, ref_kind=2)
+        if self.multi:
+            dist.all_reduce(m2, op=dist.ReduceOp.SUM, group=self.group)
+
+    def result(self):
+        import numpy as np
+        m1 = self.ws.out[0].cpu().numpy()
+        m2 = self.ws.out[1].cpu().numpy()
+        count = m1[0]
+        centroid = m1[1:4] / (count + 1e-17)
+        rms = float(np.sqrt(np.sum(m2[4:7]) / (count - 1 + 1e-17)))
+        return count, centroid, rms

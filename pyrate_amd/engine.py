@@ -347,6 +347,30 @@ def collimated_bundle_device(nray, radius, start, kvec, evec, device, lo=0, hi=N
     return bufs[0][:, :n], bufs[1][:, :n], bufs[2][:, :n], total
 
 
+class MomentsWorkspace(object):
+    """device scratch + result vectors for bundle_moments_async (no allocation per call)"""
+
+    def __init__(self, device, n_results=2):
+        lib = _lib.load()
+        self.device = device
+        self.scratch = torch.empty(lib.prt_moments_scratch_doubles(0), dtype=torch.float64, device=device)
+        self.out = [torch.zeros(7, dtype=torch.float64, device=device) for _ in range(n_results)]
+
+
+def bundle_moments_async(x, mask, ws, slot=0, mode=0, ref_dev=None, ref_kind=0):
+    """asynchronous prt_bundle_moments on the current stream; the 7-vector stays on the device
+    (ws.out[slot]).  ref_kind 1: ref_dev = reference point (3,), 2: ref_dev = a moments vector whose
+    centroid is the reference."""
+    lib = _lib.load()
+    pitch = _check_rays(x, "x", allow_pitch=True)
+    n = x.shape[1]
+    with torch.cuda.device(x.device):
+        _lib.check(lib.prt_bundle_moments_async(x.device.index, n, pitch, _ptr(x), _ptr(mask), mode,
+                                                _ptr(ref_dev), ref_kind, _ptr(ws.out[slot]),
+                                                _ptr(ws.scratch), _stream_handle(x.device)))
+    return ws.out[slot]
+
+
 def poynting_dir(k, e_re=None, e_im=None, default_e=False):
     """unit Poynting directions (3, N) on the device (prt_poynting_dir; ray.py:136-152)"""
     lib = _lib.load()
