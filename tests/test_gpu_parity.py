@@ -277,3 +277,28 @@ def test_full_size_properties(gpu_device):
     for s in range(len(recs)):
         assert np.max(np.abs(res.x_hit[s][:, it].cpu().numpy() - out[s]["x_hit"])) < 1e-11
         assert np.max(np.abs(res.k_out[s][:, it].cpu().numpy() - out[s]["k_out"])) < 1e-12
+
+
+def test_error_codes_and_unsupported_tables(gpu_device):
+    """structural misuse raises (like the reference's bare Exceptions), never a silent CPU path"""
+    from pyrate_amd import engine, _lib, systems
+    from pyrate_amd.surface_table import UnsupportedError
+    recs = systems.aniso_doublet_records(np.eye(3) * 2.25 + 0.1j * np.eye(3), np.eye(3) * 2.5)
+    with pytest.raises(UnsupportedError):
+        engine.DeviceSystem(recs, 0)                       # complex epsilon: out of scope
+    sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
+    x = torch.zeros((3, 8), dtype=torch.float64, device=gpu_device)
+    with pytest.raises(ValueError):
+        sysd.trace(x.float(), x)                           # wrong dtype
+    with pytest.raises(_lib.PrtError):
+        sysd.propagate(99, x, x)                           # surface index out of range
+    bufs = sysd.alloc_outputs(8, 0)
+    bufs["mode"] = 7
+    with pytest.raises(_lib.PrtError):
+        sysd.trace_into(x, x, bufs)                        # bad mode -> PRT_ERR_INVALID_ARG
+    rec_a = systems.aniso_doublet_records()
+    sysa = engine.DeviceSystem(rec_a, 0)
+    bufa = sysa.alloc_outputs(8, 0)
+    bufa["pitch"] = 512
+    with pytest.raises(_lib.PrtError):
+        sysa.trace_into(x, x, bufa)                        # crystals use the concatenated layout

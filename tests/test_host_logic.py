@@ -191,3 +191,24 @@ def test_rect_grid_matches_reference_raster():
     case = _golden.load_case("double_gauss_axis")
     (o, k, e0) = systems.double_gauss_bundle(256)
     assert np.array_equal(o, case.x0) and np.array_equal(k, case.k0) and np.array_equal(e0, case.E0)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """no CPU fallback: without libprt.so every product entry point raises ImportError"""
+    from pyrate_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libprt.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+    from pyrate_amd import engine
+    with pytest.raises(ImportError):
+        engine.DeviceSystem(_golden.load_case("doublet").table, 0)
+
+
+def test_no_product_module_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under pyrate_amd/ may import it"""
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "pyrate_amd", "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
+        assert "seqtrace_np" not in src and "seqtrace_c" not in src, path
