@@ -34,6 +34,7 @@ struct prt_system {
     int32_t device;
     int32_t n_surfaces;
     int32_t all_isotropic;
+    int32_t all_conic;
     prt_surface_t *d_table;  // device copy
     prt_surface_t *h_table;  // host copy (for dispatch decisions)
 };
@@ -140,13 +141,31 @@ PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
 // ---------------------------------------------------------------------------
 // fused isotropic march: OpticalElement.seqtrace's loop (optical_element.py:336-375)
 // ---------------------------------------------------------------------------
-template <int MODE, bool VEC_IN, bool VEC_OUT>
+// LDS_TAB = true is the measured alternative of DESIGN.md ("surface table placement"): the block
+// first copies the table into LDS and the march reads the records from there (ds_read broadcast
+// into VGPRs) instead of through the scalar cache (s_load into SGPRs).  Kept only for that A/B
+// (PRT_LDS_TABLE=1); it is slower and uses more VGPRs.
+#define PRT_LDS_TAB_MAX 16
+// EXPLICIT = false: the host guarantees that every shape of the table is a Conic, and the
+// Newton / polynomial code of the explicit shapes is compiled out (fewer VGPRs: one more wave
+// per SIMD for the all-conic systems such as the double Gauss).
+template <int MODE, bool VEC_IN, bool VEC_OUT, bool EXPLICIT = true, bool LDS_TAB = false>
 __global__ __launch_bounds__(PRT_BLOCK) void k_trace_iso(
-    const prt_surface_t *__restrict__ tab, int32_t S, int64_t N, int64_t in_pitch,
+    const prt_surface_t *__restrict__ tab_g, int32_t S, int64_t N, int64_t in_pitch,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, int64_t out_pitch,
     double *__restrict__ xh_out, double *__restrict__ k_out, uint8_t *__restrict__ valid_out_hit,
     uint8_t *__restrict__ valid_out_refr) {
+    const prt_surface_t *__restrict__ tab = tab_g;
+    if (LDS_TAB) {
+        __shared__ prt_surface_t lds_tab[PRT_LDS_TAB_MAX];
+        const int words = S * (int)(sizeof(prt_surface_t) / 8);
+        const double *src = reinterpret_cast<const double *>(tab_g);
+        double *dst = reinterpret_cast<double *>(lds_tab);
+        for (int w = threadIdx.x; w < words; w += PRT_BLOCK) dst[w] = src[w];
+        __syncthreads();
+        tab = lds_tab;
+    }
     const int64_t i = ((int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x) * 2;
     if (i >= N) return;
     const bool second = (i + 1 < N);
@@ -165,9 +184,9 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_iso(
         for (int r = 0; r < 2; ++r) {
             vec3 xh, p, g;
             double g2;
-            propagate_step(sf, x[r], d[r], d2, xh, p, g, g2, valid[r]);
+            propagate_step<EXPLICIT>(sf, x[r], d[r], d2, xh, p, g, g2, valid[r]);
             vhit[r] = valid[r];
-            const vec3 n = normal_from_grad(sf, g, g2);
+            const vec3 n = normal_from_grad<EXPLICIT>(sf, g, g2);
             interact_isotropic(sf, n, k[r], valid[r]);
             x[r] = xh;
             // after an isotropic interaction E is perpendicular to k, so the Poynting
@@ -757,11 +776,23 @@ static void launch_trace_iso(const prt_system_t *sys, int64_t n0, int64_t in_pit
                              uint8_t *valid, uint8_t *valid_out, bool vec_in, bool vec_out,
                              hipStream_t st) {
     const dim3 grid(nblocks(n0, PRT_BLOCK * 2)), block(PRT_BLOCK);
-#define PRT_LAUNCH(VI, VO)                                                                       \
-    hipLaunchKernelGGL((k_trace_iso<MODE, VI, VO>), grid, block, 0, st, sys->d_table,            \
+#define PRT_LAUNCH_E(VI, VO, EX)                                                                 \
+    hipLaunchKernelGGL((k_trace_iso<MODE, VI, VO, EX>), grid, block, 0, st, sys->d_table,        \
                        sys->n_surfaces, n0, in_pitch, x0, k0, e_re, e_im, e_mode, out_pitch,     \
                        x_hit, k_out, valid, valid_out)
-    if (vec_in && vec_out)
+#define PRT_LAUNCH(VI, VO)                 \
+    do {                                   \
+        if (sys->all_conic)                \
+            PRT_LAUNCH_E(VI, VO, false);   \
+        else                               \
+            PRT_LAUNCH_E(VI, VO, true);    \
+    } while (0)
+    static const bool lds_table = getenv("PRT_LDS_TABLE") != nullptr;
+    if (vec_in && vec_out && lds_table && sys->all_conic && sys->n_surfaces <= PRT_LDS_TAB_MAX)
+        hipLaunchKernelGGL((k_trace_iso<MODE, true, true, false, true>), grid, block, 0, st, sys->d_table,
+                           sys->n_surfaces, n0, in_pitch, x0, k0, e_re, e_im, e_mode, out_pitch, x_hit,
+                           k_out, valid, valid_out);
+    else if (vec_in && vec_out)
         PRT_LAUNCH(true, true);
     else if (vec_in)
         PRT_LAUNCH(true, false);
@@ -770,6 +801,7 @@ static void launch_trace_iso(const prt_system_t *sys, int64_t n0, int64_t in_pit
     else
         PRT_LAUNCH(false, false);
 #undef PRT_LAUNCH
+#undef PRT_LAUNCH_E
 }
 
 extern "C" {
@@ -849,8 +881,11 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     }
     memcpy(sys->h_table, table, sizeof(prt_surface_t) * n_surfaces);
     sys->all_isotropic = 1;
-    for (int s = 0; s < n_surfaces; ++s)
+    sys->all_conic = 1;
+    for (int s = 0; s < n_surfaces; ++s) {
         if (table[s].mat_type != PRT_MAT_ISOTROPIC) sys->all_isotropic = 0;
+        if (table[s].shape_type != PRT_SHAPE_CONIC) sys->all_conic = 0;
+    }
     e = hipMalloc((void **)&sys->d_table, sizeof(prt_surface_t) * n_surfaces);
     if (e != hipSuccess) {
         delete[] sys->h_table;

@@ -321,6 +321,7 @@ PRT_DEV bool aperture_ok(const prt_surface_t *__restrict__ sf, double x, double 
 // ---------------------------------------------------------------------------
 //        g (unnormalised surface gradient at p, shape frame) and g2 = |g|^2 as by-products
 //   d may be any positive multiple of the unit direction, d2 = d.d
+template <bool EXPLICIT = true>
 PRT_DEV void propagate_step(const prt_surface_t *__restrict__ sf, const vec3 &x, const vec3 &d,
                             double d2, vec3 &xh, vec3 &p, vec3 &g, double &g2, bool &valid) {
     const int ff = sf->frame_flags;
@@ -331,7 +332,7 @@ PRT_DEV void propagate_step(const prt_surface_t *__restrict__ sf, const vec3 &x,
         dl = matT_vec(sf->B_shape, d);
     }
     double t;
-    if (sf->shape_type == PRT_SHAPE_CONIC) {
+    if (!EXPLICIT || sf->shape_type == PRT_SHAPE_CONIC) {
         bool ok;
         t = conic_t(sf->curv, sf->cc, r0, dl, d2, ok);
         valid = valid && ok;
@@ -372,9 +373,10 @@ PRT_DEV vec3 to_shape_frame(const prt_surface_t *__restrict__ sf, const vec3 &xh
 // unit normal in the frame of the medium from the shape-frame gradient g (|g|^2 = g2):
 // Shape.getNormal (surface_shape.py:100-112) + RayBundle.getLocalSurfaceNormal (ray.py:156-161).
 // Spheres have |g| = 1 identically (conic_grad_on_surface): no normalisation.
+template <bool EXPLICIT = true>
 PRT_DEV vec3 normal_from_grad(const prt_surface_t *__restrict__ sf, const vec3 &g, double g2) {
     vec3 n = g;
-    if (!(sf->shape_type == PRT_SHAPE_CONIC && sf->cc == 0.0)) {
+    if (!((!EXPLICIT || sf->shape_type == PRT_SHAPE_CONIC) && sf->cc == 0.0)) {
         const double r = fast_rsqrt(g2);
         n = v3(g.x * r, g.y * r, g.z * r);
     }

@@ -92,8 +92,10 @@ def test_image_mode_matches_path_mode(name, gpu_device):
     assert len(res_i.x_hit) == 1
     assert torch.equal(res_i.valid[0], res_p.valid[-1])
     assert torch.equal(res_i.valid_out[0], res_p.valid_out[-1])
-    assert torch.equal(torch.nan_to_num(res_i.x_hit[0]), torch.nan_to_num(res_p.x_hit[-1]))
-    assert torch.equal(torch.nan_to_num(res_i.k_out[0]), torch.nan_to_num(res_p.k_out[-1]))
+    # two different kernel instantiations: equal up to FMA-contraction / scheduling rounding
+    m = res_p.valid_out[-1].bool()
+    assert torch.allclose(res_i.x_hit[0][:, m], res_p.x_hit[-1][:, m], rtol=1e-13, atol=1e-13)
+    assert torch.allclose(res_i.k_out[0][:, m], res_p.k_out[-1][:, m], rtol=0, atol=1e-14)
 
 
 @pytest.mark.parametrize("name", ["double_gauss_wide", "tilted_frames", "xypoly_field5", "mirrors"])
