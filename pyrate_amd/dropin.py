@@ -1,0 +1,39 @@
+"""
+Entry points for using the engine from UNMODIFIED reference objects:
+the reference's ``OpticalSystem`` / ``OpticalElement`` / ``Surface`` / ``Shape`` / ``Material`` /
+``LocalCoordinates`` instances are only *read* (``surface_table.flatten_sequence`` is duck-typed on
+the attributes the reference's own trace loop uses); rays and results live in this package's
+device-resident ``RayBundle`` / ``RayPath``.
+
+    from pyrate_amd import dropin
+    rpaths = dropin.seqtrace(s, initialbundle, seq)        # s: pyrateoptics OpticalSystem
+    x_img = rpaths[0].raybundles[-1].x[-1]                 # reference shapes, lazily copied
+
+All-isotropic sequences only (one fused launch); sequences through ``AnisotropicMaterial`` need this
+package's material classes (``pyrate_amd.raytracer``), whose ``refract`` runs on the GPU.
+"""
+from .raytracer.optical_system import seqtrace_fused
+from .raytracer.ray import RayBundle
+from .surface_table import UnsupportedError, flatten_sequence
+
+
+def as_device_bundle(bundle, device=None):
+    """reference RayBundle (NumPy, (P,3,N)) -> device RayBundle holding its last point"""
+    if isinstance(bundle, RayBundle):
+        return bundle
+    return RayBundle(x0=bundle.x[-1], k0=bundle.k[-1], Efield0=bundle.Efield[-1],
+                     rayID=bundle.rayID, wave=bundle.wave, device=device)
+
+
+def seqtrace(system, initialbundle, elementsequence, splitup=False, device=None):
+    """OpticalSystem.seqtrace (raytracer/optical_system.py:73-94) for any duck-typed system"""
+    ib = as_device_bundle(initialbundle, device)
+    ib._ensure()
+    (records, lengths) = flatten_sequence(system, elementsequence, ib.wave)
+    if not records:
+        raise UnsupportedError("empty sequence")
+    if any(r["material"]["type"] != "isotropic" for r in records):
+        if hasattr(system, "_seqtrace_generic"):
+            return system._seqtrace_generic(ib, elementsequence, splitup)
+        raise UnsupportedError("sequences through anisotropic media need pyrate_amd's material classes")
+    return [seqtrace_fused(ib, records, lengths)]

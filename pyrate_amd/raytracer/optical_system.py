@@ -77,65 +77,73 @@ class OpticalSystem(LocalCoordinatesTreeBase):
         return rpaths
 
     def _seqtrace_fused(self, ib, records, lengths):
-        dev = ib.device
-        sysd = _dispatch.system_for(records, dev)
-        S = len(records)
-        x0 = ib._x[-1]
-        k0 = ib._k[-1]
-        (e_re, e_im) = (None, None)
-        if ib._dir_from_k:
-            e_re = engine.efield_perp(k0)          # E perpendicular to k: Poynting direction = k/|k|
-        elif ib._e[-1] is not None:
-            (e_re, e_im) = ib._e[-1]
-        res = sysd.trace(x0, k0, e_re, e_im, mode=_lib.MODE_PATH)
-        n = x0.shape[1]
-        if ib._ray_id is None:
-            ids0 = torch.arange(n, dtype=torch.int64, device=dev)
-        elif isinstance(ib._ray_id, torch.Tensor):
-            ids0 = ib._ray_id.to(dev)
-        else:
-            import numpy as np
-            ids0 = torch.from_numpy(np.ascontiguousarray(ib._ray_id, dtype=np.int64)).to(dev)
-        wave = ib.wave
-        kc = ib._k_complex
+        return seqtrace_fused(ib, records, lengths)
 
-        # bundle 0: copy of the initial bundle + the first hit point
-        b0 = ib.clone()
-        b0._append_device(res.x_hit[0], res.valid[0] * ib._valid[-1])
 
-        def make_thunk(j):
-            def thunk(b):
-                mask = res.valid_out[j - 1]
-                arrays = [res.x_hit[j - 1], res.k_out[j - 1]]
-                flags = None
-                if j < S:
-                    arrays.append(res.x_hit[j])
-                    flags = res.valid[j]
-                out = engine.compact(mask, arrays, ids0, flags)
-                (cx, ck) = (out[0][0], out[0][1])
-                m = cx.shape[1]
-                ones = torch.ones(m, dtype=torch.uint8, device=dev)
-                b._x = [cx]
-                b._k = [ck]
-                b._valid = [ones]
-                b._e = [None]
-                if j < S:
-                    b._x.append(out[0][2])
-                    b._k.append(ck)
-                    b._valid.append(out[2])
-                    b._e.append(None)
-                b._ray_id = out[1]
-                b._n = m
-                b._k_complex = kc
-            return thunk
+def seqtrace_fused(ib, records, lengths):
+    """One fused launch for an all-isotropic flattened sequence -> RayPath with the reference's
+    bundle structure (lazy, device-resident).  Needs only the surface-table records, so it
+    serves any object graph ``flatten_sequence`` understands (this package's classes or real
+    pyrateoptics objects, see pyrate_amd/dropin.py)."""
+    dev = ib.device
+    sysd = _dispatch.system_for(records, dev)
+    S = len(records)
+    x0 = ib._x[-1]
+    k0 = ib._k[-1]
+    (e_re, e_im) = (None, None)
+    if ib._dir_from_k:
+        e_re = engine.efield_perp(k0)          # E perpendicular to k: Poynting direction = k/|k|
+    elif ib._e[-1] is not None:
+        (e_re, e_im) = ib._e[-1]
+    res = sysd.trace(x0, k0, e_re, e_im, mode=_lib.MODE_PATH)
+    n = x0.shape[1]
+    if ib._ray_id is None:
+        ids0 = torch.arange(n, dtype=torch.int64, device=dev)
+    elif isinstance(ib._ray_id, torch.Tensor):
+        ids0 = ib._ray_id.to(dev)
+    else:
+        import numpy as np
+        ids0 = torch.from_numpy(np.ascontiguousarray(ib._ray_id, dtype=np.int64)).to(dev)
+    wave = ib.wave
+    kc = ib._k_complex
 
-        bundles = [b0] + [RayBundle._lazy(make_thunk(j), wave, dev) for j in range(1, S + 1)]
-        path = RayPath(bundles[0])
-        idx = 0
-        for L in lengths:
-            path.appendRayBundle(bundles[idx])           # the element restarts with the same bundle
-            for l in range(L):
-                path.appendRayBundle(bundles[idx + l + 1])
-            idx += L
-        path.dense = res                                  # dense device arrays for GPU consumers
-        return path
+    # bundle 0: copy of the initial bundle + the first hit point
+    b0 = ib.clone()
+    b0._append_device(res.x_hit[0], res.valid[0] * ib._valid[-1])
+
+    def make_thunk(j):
+        def thunk(b):
+            mask = res.valid_out[j - 1]
+            arrays = [res.x_hit[j - 1], res.k_out[j - 1]]
+            flags = None
+            if j < S:
+                arrays.append(res.x_hit[j])
+                flags = res.valid[j]
+            out = engine.compact(mask, arrays, ids0, flags)
+            (cx, ck) = (out[0][0], out[0][1])
+            m = cx.shape[1]
+            ones = torch.ones(m, dtype=torch.uint8, device=dev)
+            b._x = [cx]
+            b._k = [ck]
+            b._valid = [ones]
+            b._e = [None]
+            if j < S:
+                b._x.append(out[0][2])
+                b._k.append(ck)
+                b._valid.append(out[2])
+                b._e.append(None)
+            b._ray_id = out[1]
+            b._n = m
+            b._k_complex = kc
+        return thunk
+
+    bundles = [b0] + [RayBundle._lazy(make_thunk(j), wave, dev) for j in range(1, S + 1)]
+    path = RayPath(bundles[0])
+    idx = 0
+    for L in lengths:
+        path.appendRayBundle(bundles[idx])           # the element restarts with the same bundle
+        for l in range(L):
+            path.appendRayBundle(bundles[idx + l + 1])
+        idx += L
+    path.dense = res                                  # dense device arrays for GPU consumers
+    return path

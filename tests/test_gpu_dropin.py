@@ -176,3 +176,37 @@ def test_surface_and_shape_plugin_calls(api):
     assert np.allclose(np.sum(n * n, axis=0), 1.0)
     g = shape.getGrad(np.array([0.5]), np.array([-0.25]))
     assert g.shape == (3, 1)
+
+
+def test_dropin_seqtrace_on_duck_typed_objects(api):
+    """pyrate_amd.dropin.seqtrace only READS the object graph through the attributes the
+    reference's loop uses, so stripped-down stand-ins (no methods at all) are enough"""
+    import types
+    from pyrate_amd import dropin
+    case = _golden.load_case("two_elements")
+    (s, seq) = zoo.two_element_system(api)
+
+    def strip(obj, names):
+        return types.SimpleNamespace(**{n: getattr(obj, n) for n in names})
+
+    def strip_lc(lc):
+        return types.SimpleNamespace(localbasis=lc.localbasis, globalcoordinates=lc.globalcoordinates)
+    elements = {}
+    for (ek, el) in s.elements.items():
+        surfaces = {}
+        for (sk, su) in el.surfaces.items():
+            shape = types.SimpleNamespace(kind=su.shape.kind, lc=strip_lc(su.shape.lc),
+                                          curvature=su.shape.curvature, conic=su.shape.conic)
+            ap = types.SimpleNamespace(kind=su.aperture.kind, annotations=su.aperture.annotations,
+                                       lc=strip_lc(su.aperture.lc))
+            surfaces[sk] = types.SimpleNamespace(shape=shape, aperture=ap)
+        mats = {mk: types.SimpleNamespace(lc=strip_lc(m.lc), get_optical_index=m.get_optical_index)
+                for (mk, m) in el.materials.items()}
+        elements[ek] = types.SimpleNamespace(surfaces=surfaces, materials=mats, annotations=el.annotations)
+    bg = types.SimpleNamespace(lc=strip_lc(s.material_background.lc),
+                               get_optical_index=s.material_background.get_optical_index)
+    plain_system = types.SimpleNamespace(elements=elements, material_background=bg)
+    ref_bundle = types.SimpleNamespace(x=case.x0[None], k=case.k0[None], Efield=case.E0[None],
+                                       rayID=np.arange(case.x0.shape[1]), wave=case.wave)
+    rpaths = dropin.seqtrace(plain_system, ref_bundle, seq)
+    assert_paths_match(rpaths[0], case.raw_bundles)
