@@ -45,6 +45,35 @@ def recommended_pitch(n):
     return int(_lib.load().prt_recommended_pitch(n))
 
 
+class _LazyViews(object):
+    """list-like: per-surface tensor views created on first access (a 12-surface path has 48
+    of them; an optimiser loop that only looks at the image plane should not pay for all)"""
+
+    def __init__(self, n, make):
+        self._n = n
+        self._make = make
+        self._cache = {}
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, s):
+        if isinstance(s, slice):
+            return [self[i] for i in range(*s.indices(self._n))]
+        if s < 0:
+            s += self._n
+        if not 0 <= s < self._n:
+            raise IndexError(s)
+        v = self._cache.get(s)
+        if v is None:
+            v = self._make(s)
+            self._cache[s] = v
+        return v
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
+
 class TraceResult(object):
     """Dense (uncompacted) outputs of one sequence trace.
 
@@ -62,6 +91,36 @@ class TraceResult(object):
         self.n_in = n_in
         self.n_out = n_out
         self.mode = mode
+
+    @classmethod
+    def from_buffers(cls, bufs):
+        (n_in, n_out) = (bufs["n_in"], bufs["n_out"])
+        rows = len(n_in)
+        pitch = bufs.get("pitch", 0)
+        (bx, bk, bv, bw) = (bufs["x_hit"], bufs["k_out"], bufs["valid"], bufs["valid_out"])
+        if pitch:
+            n = n_in[0]
+
+            def rays(buf):
+                return lambda s: buf[3 * s * pitch:3 * (s + 1) * pitch].view(3, pitch)[:, :n]
+
+            def mask(buf):
+                return lambda s: buf[s * pitch:s * pitch + n]
+            return cls(_LazyViews(rows, rays(bx)), _LazyViews(rows, rays(bk)), _LazyViews(rows, mask(bv)),
+                       _LazyViews(rows, (mask(bw) if bw is not None else (lambda s: None))),
+                       n_in, n_out, bufs["mode"])
+        # concatenated layout (tables with anisotropic media)
+        off_in = [0]
+        off_out = [0]
+        for (ni, no) in zip(n_in, n_out):
+            off_in.append(off_in[-1] + ni)
+            off_out.append(off_out[-1] + no)
+        return cls(
+            _LazyViews(rows, lambda s: bx[3 * off_in[s]:3 * off_in[s + 1]].view(3, n_in[s])),
+            _LazyViews(rows, lambda s: bk[3 * off_out[s]:3 * off_out[s + 1]].view(3, n_out[s])),
+            _LazyViews(rows, lambda s: bv[off_in[s]:off_in[s + 1]]),
+            _LazyViews(rows, (lambda s: bw[off_out[s]:off_out[s + 1]]) if bw is not None else (lambda s: None)),
+            n_in, n_out, bufs["mode"])
 
 
 class DeviceSystem(object):
@@ -179,30 +238,7 @@ class DeviceSystem(object):
 
     @staticmethod
     def views(bufs):
-        (xs, ks, vs, ws) = ([], [], [], [])
-        pitch = bufs.get("pitch", 0)
-        if pitch:
-            rows = len(bufs["n_in"])
-            n = bufs["n_in"][0]
-            xv = bufs["x_hit"].view(rows, 3, pitch)
-            kv = bufs["k_out"].view(rows, 3, pitch)
-            vv = bufs["valid"].view(rows, pitch)
-            wv = None if bufs["valid_out"] is None else bufs["valid_out"].view(rows, pitch)
-            for s in range(rows):
-                xs.append(xv[s, :, :n])
-                ks.append(kv[s, :, :n])
-                vs.append(vv[s, :n])
-                ws.append(None if wv is None else wv[s, :n])
-            return TraceResult(xs, ks, vs, ws, bufs["n_in"], bufs["n_out"], bufs["mode"])
-        (oi, oo) = (0, 0)
-        for (ni, no) in zip(bufs["n_in"], bufs["n_out"]):
-            xs.append(bufs["x_hit"][3 * oi:3 * (oi + ni)].view(3, ni))
-            vs.append(bufs["valid"][oi:oi + ni])
-            ks.append(bufs["k_out"][3 * oo:3 * (oo + no)].view(3, no))
-            ws.append(None if bufs["valid_out"] is None else bufs["valid_out"][oo:oo + no])
-            oi += ni
-            oo += no
-        return TraceResult(xs, ks, vs, ws, bufs["n_in"], bufs["n_out"], bufs["mode"])
+        return TraceResult.from_buffers(bufs)
 
     # -- per-surface plugin granularity -------------------------------------
     def propagate(self, surface, x, k, direction=None, e_re=None, e_im=None,

@@ -89,11 +89,11 @@ class UnsupportedError(Exception):
 # --------------------------------------------------------------------------
 
 def _mat33(m):
-    return [[float(v) for v in row] for row in np.asarray(m, dtype=float).reshape(3, 3)]
+    return np.asarray(m, dtype=float).reshape(3, 3).tolist()
 
 
 def _vec3(v):
-    return [float(c) for c in np.asarray(v, dtype=float).reshape(3)]
+    return np.asarray(v, dtype=float).reshape(3).tolist()
 
 
 def describe_shape(shape):
