@@ -41,3 +41,11 @@ def test_smoke_benchmark(gpu_device, capsys):
     from demos import demo_benchmark
     demo_benchmark.main(20000)
     assert "ray-surface-operations per second" in capsys.readouterr().out
+
+
+def test_smoke_optimize_asphere(gpu_device):
+    """parameter changes through FloatVariable.set_value reach the device table on the next
+    seqtrace; the merit function decreases"""
+    from demos import demo_optimize_asphere
+    (m0, m1) = demo_optimize_asphere.main(maxiter=150)
+    assert m1 < 0.5 * m0
