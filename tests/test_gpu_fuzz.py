@@ -1,0 +1,101 @@
+"""Randomised parity: HIP engine vs the (reference-pinned) NumPy oracle on seeded random
+systems -- random conic / asphere / biconic / XY shapes, tilted and decentred frames, apertures,
+indices, mirrors -- every ray, every surface, masks included."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import _golden
+from oracle import seqtrace_np as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def rot(rng, amp):
+    (a, b, c) = rng.uniform(-amp, amp, 3)
+    rx = np.array([[1, 0, 0], [0, math.cos(a), -math.sin(a)], [0, math.sin(a), math.cos(a)]])
+    ry = np.array([[math.cos(b), 0, math.sin(b)], [0, 1, 0], [-math.sin(b), 0, math.cos(b)]])
+    rz = np.array([[math.cos(c), -math.sin(c), 0], [math.sin(c), math.cos(c), 0], [0, 0, 1]])
+    return rz.dot(ry).dot(rx)
+
+
+def random_shape(rng, kind):
+    c = rng.uniform(-1, 1) / rng.uniform(25, 120)
+    if kind == 0:
+        return {"type": "conic", "curv": c, "cc": rng.choice([0.0, rng.uniform(-2, 1.5)])}
+    if kind == 1:
+        return {"type": "asphere", "curv": c, "cc": rng.uniform(-1.5, 0.5),
+                "coeffs": [rng.uniform(-1, 1) * 1e-4, rng.uniform(-1, 1) * 1e-7, rng.uniform(-1, 1) * 1e-10]}
+    if kind == 2:
+        return {"type": "biconic", "curvx": c, "curvy": c * rng.uniform(0.5, 1.5), "ccx": rng.uniform(-1, 0.5),
+                "ccy": rng.uniform(-1, 0.5), "coeffs": [[rng.uniform(-1, 1) * 1e-5, rng.uniform(-0.5, 0.5)]]}
+    return {"type": "xypoly", "normradius": 10.0,
+            "terms": [[2, 0, rng.uniform(-0.1, 0.1)], [0, 2, rng.uniform(-0.1, 0.1)], [1, 1, rng.uniform(-0.02, 0.02)],
+                      [3, 0, rng.uniform(-0.01, 0.01)], [2, 2, rng.uniform(-0.005, 0.005)]]}
+
+
+def random_table(rng, n_surf, tilted, explicit, mirrors):
+    recs = []
+    z = 0.0
+    n_cur = 1.0
+    for s in range(n_surf):
+        z += rng.uniform(3.0, 12.0)
+        kind = int(rng.randint(0, 4)) if explicit else 0
+        Bs = rot(rng, 0.08) if tilted else np.eye(3)
+        g = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), z]) if tilted else np.array([0., 0., z])
+        own_ap_frame = tilted and rng.rand() < 0.5
+        Ba = rot(rng, 0.3) if own_ap_frame else Bs
+        ga = g + (np.array([0.2, -0.1, 0.0]) if own_ap_frame else 0.0)
+        apk = int(rng.randint(0, 3))
+        ap = [{"type": "none"}, {"type": "circular", "minradius": 0.0 if rng.rand() < 0.7 else 0.5,
+                                 "maxradius": rng.uniform(5.0, 9.0)},
+              {"type": "rectangular", "width": rng.uniform(9, 16), "height": rng.uniform(9, 16)}][apk]
+        mirror = mirrors and (s in (1, 2)) and kind == 0
+        if not mirror:
+            n_cur = 1.0 if (s % 2 == 1) else rng.uniform(1.4, 1.9)
+        recs.append({"shape": random_shape(rng, kind), "B_shape": Bs.tolist(), "g_shape": g.tolist(),
+                     "aperture": ap, "B_ap": np.asarray(Ba).tolist(), "g_ap": np.asarray(ga).tolist(),
+                     "interaction": "mirror" if mirror else "refract",
+                     "material": {"type": "isotropic", "n": float(n_cur)},
+                     "B_mat": (rot(rng, 0.5) if tilted else np.eye(3)).tolist()})
+        if mirror:
+            z -= rng.uniform(12.0, 20.0)      # the next surface sits behind the mirror
+    return recs
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_systems_match_oracle(gpu_device, seed):
+    from pyrate_amd import engine
+    rng = np.random.RandomState(1000 + seed)
+    tilted = seed % 2 == 1
+    explicit = seed % 3 != 0
+    mirrors = seed % 4 == 3
+    recs = random_table(rng, int(rng.randint(3, 8)), tilted, explicit, mirrors)
+    n = int(rng.choice([257, 1000, 1535]))
+    x0 = np.vstack((rng.uniform(-6, 6, n), rng.uniform(-6, 6, n), np.full(n, -2.0)))
+    u = np.vstack((rng.uniform(-0.12, 0.12, n), rng.uniform(-0.12, 0.12, n), np.ones(n)))
+    k0 = u / np.sqrt(np.sum(u ** 2, axis=0))
+    e0 = np.cross(k0, np.array([1., 0.3, 0.]), axisa=0, axisb=0).T.copy() + 1j * 0.2 * np.cross(
+        k0, np.array([0., 1., 0.2]), axisa=0, axisb=0).T
+    with np.errstate(all="ignore"):
+        out = oracle.trace(recs, x0, k0, e0)
+    sysd = engine.DeviceSystem(recs, 0)
+    res = sysd.trace(engine.to_device_rays(x0, gpu_device), engine.to_device_rays(k0, gpu_device),
+                     engine.to_device_rays(e0.real, gpu_device), engine.to_device_rays(e0.imag, gpu_device))
+    ncmp = 0
+    for s in range(len(recs)):
+        vo = out[s]["valid"]
+        assert np.array_equal(res.valid[s].cpu().numpy().astype(bool), vo), (seed, s)
+        wo = out[s]["valid_out"]
+        assert np.array_equal(res.valid_out[s].cpu().numpy().astype(bool), wo), (seed, s)
+        xo = out[s]["x_hit"][:, vo]
+        if xo.shape[1]:
+            err = np.abs(res.x_hit[s].cpu().numpy()[:, vo] - xo) / _golden.relative_scale(xo)
+            assert err.max() < 1e-10, (seed, s, err.max())
+        ko = out[s]["k_out"][:, wo]
+        if ko.shape[1]:
+            assert np.abs(res.k_out[s].cpu().numpy()[:, wo] - ko).max() < 1e-10, (seed, s)
+        ncmp += int(wo.sum())
+    assert ncmp > 0
