@@ -210,3 +210,49 @@ def test_dropin_seqtrace_on_duck_typed_objects(api):
                                        rayID=np.arange(case.x0.shape[1]), wave=case.wave)
     rpaths = dropin.seqtrace(plain_system, ref_bundle, seq)
     assert_paths_match(rpaths[0], case.raw_bundles)
+
+
+def test_raybundle_api_contract(api):
+    """RayBundle data contract of the reference (ray.py:34-115): shapes, defaults, rayID,
+    cumulative valid on append, deepcopy independence, device-tensor inputs"""
+    import copy
+    import torch
+    n = 7
+    x0 = np.arange(3 * n, dtype=float).reshape(3, n)
+    k0 = np.tile(np.array([[0.], [0.], [1.]]), (1, n))
+    rb = api.RayBundle(x0, k0, None)
+    assert rb.x.shape == (1, 3, n) and rb.k.shape == (1, 3, n) and rb.valid.shape == (1, n)
+    assert rb.valid.dtype == bool and rb.valid.all()
+    assert np.array_equal(rb.rayID, np.arange(n))
+    assert np.array_equal(rb.Efield[0], np.vstack((np.zeros(n), np.ones(n), np.zeros(n))))     # ray.py:71-73
+    assert rb.wave == 0.5876e-3 and rb.splitted is False
+    v1 = np.array([1, 1, 0, 1, 1, 1, 1], dtype=bool)
+    rb.append(x0 + 1, k0, None, v1)
+    v2 = np.array([1, 0, 1, 1, 1, 1, 1], dtype=bool)
+    rb.append(x0 + 2, k0, None, v2)
+    assert rb.x.shape == (3, 3, n)
+    assert np.array_equal(rb.valid[2], v1 & v2)                  # cumulative (ray.py:100)
+    rb2 = copy.deepcopy(rb)
+    rb2.append(x0 + 3, k0, None, np.ones(n, dtype=bool))
+    assert rb.x.shape[0] == 3 and rb2.x.shape[0] == 4            # independent histories
+    ids = np.array([10, 11, 12, 13, 14, 15, 16])
+    rb3 = api.RayBundle(x0, k0.astype(complex), np.ones((3, n)) * (1 + 1j), rayID=ids, wave=0.6e-3, splitted=True)
+    assert np.array_equal(rb3.rayID, ids) and np.iscomplexobj(rb3.k) and np.iscomplexobj(rb3.Efield)
+    assert rb3.splitted and rb3.wave == 0.6e-3
+    dev = rb.device
+    rb4 = api.RayBundle(torch.from_numpy(x0).to(dev), torch.from_numpy(k0).to(dev), None)
+    assert np.array_equal(rb4.x[0], x0) and rb4.x_dev().is_cuda
+    with pytest.raises(ValueError):
+        api.RayBundle(x0, k0[:, :3], None)
+    with pytest.raises(NotImplementedError):
+        api.RayBundle(x0, k0 + 0.1j, None)                       # absorbing media: out of scope
+
+
+def test_custom_ray_ids_survive_compaction(api):
+    case = _golden.load_case("doublet_clipped")
+    (s, seq) = zoo.doublet(api)
+    ids = np.arange(case.x0.shape[1]) * 3 + 100
+    ib = api.RayBundle(x0=case.x0, k0=case.k0, Efield0=case.E0, rayID=ids, wave=case.wave)
+    rp = s.seqtrace(ib, seq)[0]
+    for (rb, ref) in zip(rp.raybundles, case.raw_bundles):
+        assert np.array_equal(rb.rayID, ref["id"] * 3 + 100)
