@@ -14,4 +14,4 @@ for mode in (0,1):
     res=[sysd.trace_timed(x0,k0,bufs,50,e0d) for rep in range(4)]
     out.append(("path" if mode==0 else "image", ["%.4f"%r for r in res]))
     del bufs
-print("NT",os.environ.get('PRT_NT'), "RPT1",os.environ.get('PRT_RPT1'), out)
+print("PRT_LDS_TABLE", os.environ.get("PRT_LDS_TABLE"), out)

@@ -1,3 +1,6 @@
+# A/B of non-temporal loads/stores in k_trace_iso.  Needs an experimental build that exports
+# prt_set_experiment(flags) (bit0 NT stores, bit1 NT loads) -- the switch is not part of the shipped
+# kernel; results are quoted in DESIGN.md section 5.
 import sys, ctypes, torch
 sys.path.insert(0,'.')
 from pyrate_amd import engine, systems, _lib
