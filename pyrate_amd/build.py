@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["prt.hip"]
-HEADERS = ["prt_device.h", "prt_aniso.h", os.path.join("..", "..", "include", "prt.h")]
+HEADERS = ["prt_kernels.h", "prt_device.h", "prt_aniso.h", os.path.join("..", "..", "include", "prt.h")]
 OUT = os.path.join(CSRC, "libprt.so")
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
                "-Wall", "-Wno-unused-function"]

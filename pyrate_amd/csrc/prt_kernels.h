@@ -1,0 +1,719 @@
+// prt_kernels.h -- the __global__ kernels of libprt.so (launched from prt.hip).
+//
+//   k_trace_iso<MODE,VEC_IN,VEC_OUT,EXPLICIT,LDS_TAB>  whole isotropic sequence in one launch
+//   k_trace_general<MODE>                              whole sequence through crystals (leaf re-tracing)
+//   k_propagate / k_interact_iso / k_interact_aniso    one plugin-granular step
+//   k_shape_eval, k_efield_perp, k_poynting_dir, k_path_sums
+//   k_moments_partial / k_moments_final                deterministic bundle moments
+//   k_compact_count / k_compact_scan / k_compact_scatter   order-preserving compaction
+//   k_rectgrid_mask / k_rectgrid_scatter               RectGrid raster + collimated bundle
+#pragma once
+#include "prt_device.h"
+#include "prt_aniso.h"
+
+#define PRT_BLOCK 256
+#define CMP_ITEMS 4  // mask bytes per thread in the compaction / raster kernels
+#define CMP_TILE (PRT_BLOCK * CMP_ITEMS)
+
+// ---------------------------------------------------------------------------
+// ray load / store helpers for the fused march.  Arrays are component-major rows
+// with a row PITCH (in elements): element (row r, ray i) lives at r*pitch + i.
+// A thread owns the two adjacent rays i, i+1.  With an even pitch and a 16-byte
+// aligned base every row is 16-B aligned and one dwordx4 access moves both rays
+// (VEC = true); otherwise two 8-B accesses with a tail guard.
+//
+// Row alignment decides the achievable HBM WRITE bandwidth: with rows that do not
+// start on a 128-B line a wave's 1-KiB store is split over partial lines and the
+// 72-stream path write drops from ~6.3 to ~3.9-4.7 TB/s (measured, DESIGN.md
+// "row pitch").  prt_recommended_pitch() rounds the pitch to 4 KiB.
+// ---------------------------------------------------------------------------
+typedef double prt_double2 __attribute__((ext_vector_type(2)));
+
+template <bool VEC>
+struct rayio {
+    // second = false: ray i+1 does not exist (odd N tail) -> duplicate ray i
+    static PRT_DEV void load(const double *__restrict__ a, int64_t pitch, int64_t i, bool second,
+                             vec3 v[2]) {
+        if (VEC) {
+            const prt_double2 x = *reinterpret_cast<const prt_double2 *>(a + i);
+            const prt_double2 y = *reinterpret_cast<const prt_double2 *>(a + pitch + i);
+            const prt_double2 z = *reinterpret_cast<const prt_double2 *>(a + 2 * pitch + i);
+            v[0] = v3(x.x, y.x, z.x);
+            v[1] = v3(x.y, y.y, z.y);
+        } else {
+            v[0] = v3(a[i], a[pitch + i], a[2 * pitch + i]);
+            v[1] = second ? v3(a[i + 1], a[pitch + i + 1], a[2 * pitch + i + 1]) : v[0];
+        }
+    }
+    static PRT_DEV void store(double *__restrict__ a, int64_t pitch, int64_t i, bool second,
+                              const vec3 v[2]) {
+        if (VEC) {
+            *reinterpret_cast<prt_double2 *>(a + i) = prt_double2{v[0].x, v[1].x};
+            *reinterpret_cast<prt_double2 *>(a + pitch + i) = prt_double2{v[0].y, v[1].y};
+            *reinterpret_cast<prt_double2 *>(a + 2 * pitch + i) = prt_double2{v[0].z, v[1].z};
+        } else {
+            a[i] = v[0].x;
+            a[pitch + i] = v[0].y;
+            a[2 * pitch + i] = v[0].z;
+            if (second) {
+                a[i + 1] = v[1].x;
+                a[pitch + i + 1] = v[1].y;
+                a[2 * pitch + i + 1] = v[1].z;
+            }
+        }
+    }
+    static PRT_DEV void store_mask(uint8_t *__restrict__ m, int64_t i, bool second, const bool b[2]) {
+        if (VEC) {
+            *reinterpret_cast<uint16_t *>(m + i) = (uint16_t)((b[0] ? 1u : 0u) | (b[1] ? 0x100u : 0u));
+        } else {
+            m[i] = b[0] ? 1 : 0;
+            if (second) m[i + 1] = b[1] ? 1 : 0;
+        }
+    }
+};
+
+// first-segment direction selector
+//   e_mode 0: d = k/|k|        1: E = (0,1,0) (ray.py:71-73)     2: E given (re [, im])
+template <bool VEC>
+PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
+                             const double *__restrict__ e_im, int64_t pitch, int64_t i, bool second,
+                             const vec3 k[2], vec3 d[2]) {
+    if (e_mode == 0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) d[r] = normalized(k[r]);
+    } else if (e_mode == 1) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) d[r] = poynting_dir(k[r], v3(0, 1, 0), v3(0, 0, 0));
+    } else {
+        vec3 er[2], ei[2];
+        rayio<VEC>::load(e_re, pitch, i, second, er);
+        if (e_im) {
+            rayio<VEC>::load(e_im, pitch, i, second, ei);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) ei[r] = v3(0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) d[r] = poynting_dir(k[r], er[r], ei[r]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fused isotropic march: OpticalElement.seqtrace's loop (optical_element.py:336-375)
+// ---------------------------------------------------------------------------
+// LDS_TAB = true is the measured alternative of DESIGN.md ("surface table placement"): the block
+// first copies the table into LDS and the march reads the records from there (ds_read broadcast
+// into VGPRs) instead of through the scalar cache (s_load into SGPRs).  Kept only for that A/B
+// (PRT_LDS_TABLE=1); it is slower and uses more VGPRs.
+#define PRT_LDS_TAB_MAX 16
+// EXPLICIT = false: the host guarantees that every shape of the table is a Conic, and the
+// Newton / polynomial code of the explicit shapes is compiled out (fewer VGPRs: one more wave
+// per SIMD for the all-conic systems such as the double Gauss).
+template <int MODE, bool VEC_IN, bool VEC_OUT, bool EXPLICIT = true, bool LDS_TAB = false>
+__global__ __launch_bounds__(PRT_BLOCK) void k_trace_iso(
+    const prt_surface_t *__restrict__ tab_g, int32_t S, int64_t N, int64_t in_pitch,
+    const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
+    const double *__restrict__ e_im, int32_t e_mode, int64_t out_pitch,
+    double *__restrict__ xh_out, double *__restrict__ k_out, uint8_t *__restrict__ valid_out_hit,
+    uint8_t *__restrict__ valid_out_refr) {
+    const prt_surface_t *__restrict__ tab = tab_g;
+    if (LDS_TAB) {
+        __shared__ prt_surface_t lds_tab[PRT_LDS_TAB_MAX];
+        const int words = S * (int)(sizeof(prt_surface_t) / 8);
+        const double *src = reinterpret_cast<const double *>(tab_g);
+        double *dst = reinterpret_cast<double *>(lds_tab);
+        for (int w = threadIdx.x; w < words; w += PRT_BLOCK) dst[w] = src[w];
+        __syncthreads();
+        tab = lds_tab;
+    }
+    const int64_t i = ((int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x) * 2;
+    if (i >= N) return;
+    const bool second = (i + 1 < N);
+
+    vec3 x[2], k[2], d[2];
+    bool valid[2] = {true, true};
+    rayio<VEC_IN>::load(x0, in_pitch, i, second, x);
+    rayio<VEC_IN>::load(k0, in_pitch, i, second, k);
+    first_direction<VEC_IN>(e_mode, e_re, e_im, in_pitch, i, second, k, d);
+    double d2 = 1.0;  // |d|^2: unit Poynting direction on the first segment
+
+    for (int32_t s = 0; s < S; ++s) {
+        const prt_surface_t *__restrict__ sf = tab + s;
+        bool vhit[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            vec3 xh, p, g;
+            double g2;
+            propagate_step<EXPLICIT>(sf, x[r], d[r], d2, xh, p, g, g2, valid[r]);
+            vhit[r] = valid[r];
+            const vec3 n = normal_from_grad<EXPLICIT>(sf, g, g2);
+            interact_isotropic(sf, n, k[r], valid[r]);
+            x[r] = xh;
+            // after an isotropic interaction E is perpendicular to k, so the Poynting
+            // direction (ray.py:136-152) is parallel to k; the next intersection takes the
+            // unnormalised k with |k|^2 = n_after^2 (conic_t / explicit_t are homogeneous in d)
+            d[r] = k[r];
+        }
+        d2 = sf->n_after * sf->n_after;
+
+        if (MODE == PRT_MODE_PATH || s == S - 1) {
+            const int64_t so = (MODE == PRT_MODE_PATH) ? (int64_t)s : 0;
+            rayio<VEC_OUT>::store(xh_out + so * 3 * out_pitch, out_pitch, i, second, x);
+            rayio<VEC_OUT>::store(k_out + so * 3 * out_pitch, out_pitch, i, second, k);
+            rayio<VEC_OUT>::store_mask(valid_out_hit + so * out_pitch, i, second, vhit);
+            if (valid_out_refr)
+                rayio<VEC_OUT>::store_mask(valid_out_refr + so * out_pitch, i, second, valid);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fused march through tables that contain anisotropic media (ray doubling).  Thread i owns
+// input ray i and ALL its descendants: with A anisotropic interfaces there are 2^A leaves;
+// leaf L (bit j = which of the two transmitted solutions is followed at the j-th crystal
+// interface) is traced from the start, so no per-ray stack is needed (recomputation instead
+// of 2^A live states; 20 instead of 12 surface steps for the doublet of config 4, but one
+// launch, no intermediate arrays, no direction buffers).  A prefix shared by several leaves
+// is WRITTEN only by the leaf whose remaining bits are zero.  Outputs use the concatenated
+// layout of include/prt.h (rays of a split bundle stacked [sol2, sol3] like np.hstack,
+// material_anisotropic.py:89): at a level with a doublings, leaf L sits at i + N (L mod 2^a).
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(PRT_BLOCK) void k_trace_general(
+    const prt_surface_t *__restrict__ tab, int32_t S, int32_t A, int64_t N,
+    const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
+    const double *__restrict__ e_im, int32_t e_mode, double *__restrict__ xh_out,
+    double *__restrict__ k_out, uint8_t *__restrict__ valid_out_hit,
+    uint8_t *__restrict__ valid_out_refr) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const vec3 xs = v3(x0[i], x0[N + i], x0[2 * N + i]);
+    const vec3 ks = v3(k0[i], k0[N + i], k0[2 * N + i]);
+    vec3 ds;
+    {
+        vec3 kk[2] = {ks, ks};
+        vec3 dd[2];
+        first_direction<false>(e_mode, e_re, e_im, N, i, false, kk, dd);
+        ds = dd[0];
+    }
+    const int64_t leaves = (int64_t)1 << A;
+    for (int64_t L = 0; L < leaves; ++L) {
+        vec3 x = xs, k = ks, d = ds;
+        double d2 = 1.0;
+        bool valid = true;  // cumulative mask carried into the next propagate
+        int a = 0;          // doublings so far
+        int64_t off_in = 0, off_out = 0;
+        for (int32_t s = 0; s < S; ++s) {
+            const prt_surface_t *__restrict__ sf = tab + s;
+            const int64_t n_in = N << a;
+            const int64_t idx_in = i + N * (L & (((int64_t)1 << a) - 1));
+            const bool alive = valid;
+            vec3 xh, p, g;
+            double g2;
+            propagate_step(sf, x, d, d2, xh, p, g, g2, valid);
+            const bool last = (s == S - 1);
+            if ((L >> a) == 0 && (MODE == PRT_MODE_PATH || last)) {
+                double *xo = xh_out + ((MODE == PRT_MODE_PATH) ? 3 * off_in : 0);
+                xo[idx_in] = xh.x;
+                xo[n_in + idx_in] = xh.y;
+                xo[2 * n_in + idx_in] = xh.z;
+                valid_out_hit[((MODE == PRT_MODE_PATH) ? off_in : 0) + idx_in] = valid ? 1 : 0;
+            }
+            int a_out = a;
+            if (sf->mat_type == PRT_MAT_ANISOTROPIC) {
+                aniso_solution sol[2];
+                interact_anisotropic(sf, p, k, sol);
+                const bool second = ((L >> a) & 1) != 0;
+                k = second ? sol[1].k : sol[0].k;
+                d = second ? sol[1].d : sol[0].d;
+                d2 = 1.0;
+                valid = alive;  // no validity filtering at a crystal interface (ray.py:68)
+                a_out = a + 1;
+            } else {
+                const vec3 n = normal_from_grad(sf, g, g2);
+                interact_isotropic(sf, n, k, valid);
+                d = k;
+                d2 = sf->n_after * sf->n_after;
+            }
+            const int64_t n_out = N << a_out;
+            if ((L >> a_out) == 0 && (MODE == PRT_MODE_PATH || last)) {
+                const int64_t idx_out = i + N * (L & (((int64_t)1 << a_out) - 1));
+                double *ko = k_out + ((MODE == PRT_MODE_PATH) ? 3 * off_out : 0);
+                ko[idx_out] = k.x;
+                ko[n_out + idx_out] = k.y;
+                ko[2 * n_out + idx_out] = k.z;
+                if (valid_out_refr)
+                    valid_out_refr[((MODE == PRT_MODE_PATH) ? off_out : 0) + idx_out] = valid ? 1 : 0;
+            }
+            x = xh;
+            off_in += n_in;
+            off_out += n_out;
+            a = a_out;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-surface kernels (the plugin-granular API, and the march through
+// anisotropic systems).  x is read modulo n_src so that the two children of a
+// split ray share their parent's hit point without a copy.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(PRT_BLOCK) void k_propagate(
+    const prt_surface_t *__restrict__ sf, int64_t N, int64_t n_src,
+    const double *__restrict__ x_in, const double *__restrict__ k_in,
+    const double *__restrict__ dir_in, const double *__restrict__ e_re,
+    const double *__restrict__ e_im, int32_t e_mode, const uint8_t *__restrict__ valid_in,
+    double *__restrict__ xh_out, uint8_t *__restrict__ valid_out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const int64_t j = (n_src == N) ? i : (i % n_src);
+    const vec3 x = v3(x_in[j], x_in[n_src + j], x_in[2 * n_src + j]);
+    vec3 d;
+    if (dir_in) {
+        d = v3(dir_in[i], dir_in[N + i], dir_in[2 * N + i]);
+    } else {
+        const vec3 kk = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
+        vec3 k[2] = {kk, kk};
+        vec3 dd[2];
+        first_direction<false>(e_mode, e_re, e_im, N, i, false, k, dd);
+        d = dd[0];
+    }
+    bool valid = valid_in ? (valid_in[i] != 0) : true;
+    vec3 xh, p, g;
+    double g2;
+    propagate_step(sf, x, d, 1.0, xh, p, g, g2, valid);
+    xh_out[i] = xh.x;
+    xh_out[N + i] = xh.y;
+    xh_out[2 * N + i] = xh.z;
+    valid_out[i] = valid ? 1 : 0;
+}
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_interact_iso(
+    const prt_surface_t *__restrict__ sf, int64_t N, const double *__restrict__ xh_in,
+    const double *__restrict__ k_in, const uint8_t *__restrict__ valid_in,
+    double *__restrict__ k_out, double *__restrict__ dir_out, uint8_t *__restrict__ valid_out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const vec3 xh = v3(xh_in[i], xh_in[N + i], xh_in[2 * N + i]);
+    vec3 k = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
+    bool valid = valid_in ? (valid_in[i] != 0) : true;
+    const vec3 p = to_shape_frame(sf, xh);
+    interact_isotropic(sf, normal_in_material_frame(sf, p), k, valid);
+    k_out[i] = k.x;
+    k_out[N + i] = k.y;
+    k_out[2 * N + i] = k.z;
+    if (dir_out) {
+        const vec3 d = normalized(k);
+        dir_out[i] = d.x;
+        dir_out[N + i] = d.y;
+        dir_out[2 * N + i] = d.z;
+    }
+    if (valid_out) valid_out[i] = valid ? 1 : 0;
+}
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_interact_aniso(
+    const prt_surface_t *__restrict__ sf, int64_t N, const double *__restrict__ xh_in,
+    const double *__restrict__ k_in, const uint8_t *__restrict__ alive_in,
+    double *__restrict__ k_out, double *__restrict__ dir_out, double *__restrict__ e_re_out,
+    double *__restrict__ e_im_out, uint8_t *__restrict__ valid_out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const vec3 xh = v3(xh_in[i], xh_in[N + i], xh_in[2 * N + i]);
+    const vec3 k = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
+    const vec3 p = to_shape_frame(sf, xh);
+    // The reference's anisotropic refract does no validity filtering: every ray that is
+    // still IN the bundle gets two children in a fresh all-valid bundle (ray.py:68).
+    // In the dense representation "in the bundle" = alive_in (the mask the previous
+    // compaction used); rays compacted away earlier must stay dead.
+    const uint8_t alive = alive_in ? alive_in[i] : (uint8_t)1;
+    aniso_solution sol[2];
+    interact_anisotropic(sf, p, k, sol);
+    const int64_t M = 2 * N;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int64_t o = i + b * N;  // np.hstack((sol2, sol3)), material_anisotropic.py:89
+        k_out[o] = sol[b].k.x;
+        k_out[M + o] = sol[b].k.y;
+        k_out[2 * M + o] = sol[b].k.z;
+        dir_out[o] = sol[b].d.x;
+        dir_out[M + o] = sol[b].d.y;
+        dir_out[2 * M + o] = sol[b].d.z;
+        if (e_re_out) {
+            e_re_out[o] = sol[b].er.x;
+            e_re_out[M + o] = sol[b].er.y;
+            e_re_out[2 * M + o] = sol[b].er.z;
+        }
+        if (e_im_out) {
+            e_im_out[o] = sol[b].ei.x;
+            e_im_out[M + o] = sol[b].ei.y;
+            e_im_out[2 * M + o] = sol[b].ei.z;
+        }
+        if (valid_out) valid_out[o] = alive;
+    }
+}
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_shape_eval(const prt_surface_t *__restrict__ sf,
+                                                          int64_t N, const double *__restrict__ x,
+                                                          const double *__restrict__ y,
+                                                          double *__restrict__ sag,
+                                                          double *__restrict__ grad) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const double xx = x[i], yy = y[i];
+    if (sag) sag[i] = shape_sag(sf, xx, yy);
+    if (grad) {
+        vec3 g;
+        if (sf->shape_type == PRT_SHAPE_CONIC) {
+            // Conic.getGrad as the reference evaluates it (surface_shape.py:229-235)
+            const double z = conic_sag(sf->curv, sf->cc, xx * xx + yy * yy);
+            g = v3(-sf->curv * xx, -sf->curv * yy, 1.0 - sf->curv * z * (1.0 + sf->cc));
+        } else {
+            g = shape_grad(sf, xx, yy);
+        }
+        grad[i] = g.x;
+        grad[N + i] = g.y;
+        grad[2 * N + i] = g.z;
+    }
+}
+
+// A unit E field perpendicular to k for bundles leaving an isotropic interface.  The
+// reference takes the singular vector of the smallest singular value of
+// -k^2 I + k k^T + n^2 I (material_isotropic.py:72-128), which is an ARBITRARY unit
+// vector of the 2-d null space {E : E.k = 0}; this picks E = unit(k x a), a = the
+// coordinate axis least aligned with k.  Not on the x/k parity contract.
+__global__ __launch_bounds__(PRT_BLOCK) void k_efield_perp(int64_t N, const double *__restrict__ k_in,
+                                                           double *__restrict__ e_out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const vec3 k = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
+    const double ax = fabs(k.x), ay = fabs(k.y), az = fabs(k.z);
+    const vec3 a = (ay <= ax && ay <= az) ? v3(0, 1, 0) : ((ax <= az) ? v3(1, 0, 0) : v3(0, 0, 1));
+    const vec3 e = normalized(cross(k, a));
+    e_out[i] = e.x;
+    e_out[N + i] = e.y;
+    e_out[2 * N + i] = e.z;
+}
+
+// RayBundle.returnKtoD (ray.py:136-152) for one stored point: unit Poynting direction from
+// (k, E); e_mode as in first_direction (0: k/|k|, 1: E = ey, 2: E given).
+__global__ __launch_bounds__(PRT_BLOCK) void k_poynting_dir(int64_t N, const double *__restrict__ k_in,
+                                                            const double *__restrict__ e_re,
+                                                            const double *__restrict__ e_im,
+                                                            int32_t e_mode,
+                                                            double *__restrict__ d_out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const vec3 kk = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
+    vec3 k[2] = {kk, kk};
+    vec3 dd[2];
+    first_direction<false>(e_mode, e_re, e_im, N, i, false, k, dd);
+    d_out[i] = dd[0].x;
+    d_out[N + i] = dd[0].y;
+    d_out[2 * N + i] = dd[0].z;
+}
+
+// RayBundleAnalysis.get_arc_length / get_phase_difference (analysis/ray_analysis.py:136-163):
+// per ray, sum over consecutive stored points p of |x_{p+1} - x_p|  (mode 0) or of
+// x_{p+1}.k_{p+1} - x_p.k_p (mode 1).  xs / ks: device tables of P pointers to tight (3,N) arrays.
+__global__ __launch_bounds__(PRT_BLOCK) void k_path_sums(int32_t P, int64_t N,
+                                                         const double *const *__restrict__ xs,
+                                                         const double *const *__restrict__ ks,
+                                                         int32_t mode, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    double acc = 0.0;
+    vec3 xa = v3(xs[0][i], xs[0][N + i], xs[0][2 * N + i]);
+    double pa = 0.0;
+    if (mode == 1) pa = dot(xa, v3(ks[0][i], ks[0][N + i], ks[0][2 * N + i]));
+    for (int p = 1; p < P; ++p) {
+        const vec3 xb = v3(xs[p][i], xs[p][N + i], xs[p][2 * N + i]);
+        if (mode == 0) {
+            const vec3 dlt = v3(xb.x - xa.x, xb.y - xa.y, xb.z - xa.z);
+            acc += sqrt(dot(dlt, dlt));
+        } else {
+            const double pb = dot(xb, v3(ks[p][i], ks[p][N + i], ks[p][2 * N + i]));
+            acc += pb - pa;
+            pa = pb;
+        }
+        xa = xb;
+    }
+    out[i] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// bundle moments: count, sum (x - ref), sum (x - ref)^2 per component over the rays whose
+// mask byte is non-zero (all rays if mask == NULL).  Two deterministic stages (fixed
+// summation order, no atomics): grid-stride partials per block, then one block adds the
+// partials.  Feeds RayBundleAnalysis.get_centroid_position / get_rms_spot_size
+// (analysis/ray_analysis.py:44-86) and turns the multi-GPU image-plane exchange into a
+// 7-double all-reduce.
+// ---------------------------------------------------------------------------
+#define MOM_VALUES 7
+__global__ __launch_bounds__(PRT_BLOCK) void k_moments_partial(int64_t N, int64_t pitch,
+                                                               const double *__restrict__ x,
+                                                               const uint8_t *__restrict__ mask,
+                                                               int32_t mode, double rx, double ry,
+                                                               double rz,
+                                                               const double *__restrict__ ref_dev,
+                                                               int32_t ref_kind,
+                                                               double *__restrict__ partials) {
+    // ref_kind 1: ref_dev holds the reference point (3 doubles); 2: ref_dev holds a moments
+    // vector {count, sum x, ...} (e.g. all-reduced over the ranks) -> reference = centroid
+    if (ref_kind == 1) {
+        rx = ref_dev[0];
+        ry = ref_dev[1];
+        rz = ref_dev[2];
+    } else if (ref_kind == 2) {
+        const double inv = 1.0 / (ref_dev[0] + 1e-17);  // numerical_tolerance, ray_analysis.py:55
+        rx = ref_dev[1] * inv;
+        ry = ref_dev[2] * inv;
+        rz = ref_dev[3] * inv;
+    }
+    double acc[MOM_VALUES] = {0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x; i < N;
+         i += (int64_t)gridDim.x * PRT_BLOCK) {
+        if (mask && !mask[i]) continue;
+        double dx = x[i], dy = x[pitch + i], dz = x[2 * pitch + i];
+        if (mode == 0) {  // points relative to ref
+            dx -= rx;
+            dy -= ry;
+            dz -= rz;
+        } else {  // unit directions (ray.py:136-152 for E perpendicular to k), optionally x ref
+            const vec3 u = normalized(v3(dx, dy, dz));
+            dx = u.x;
+            dy = u.y;
+            dz = u.z;
+            if (mode == 2) {
+                const vec3 c = cross(u, v3(rx, ry, rz));
+                dx = c.x;
+                dy = c.y;
+                dz = c.z;
+            }
+        }
+        acc[0] += 1.0;
+        acc[1] += dx;
+        acc[2] += dy;
+        acc[3] += dz;
+        acc[4] += dx * dx;
+        acc[5] += dy * dy;
+        acc[6] += dz * dz;
+    }
+    __shared__ double sh[PRT_BLOCK / 64][MOM_VALUES];
+#pragma unroll
+    for (int q = 0; q < MOM_VALUES; ++q) {
+        double v = acc[q];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < MOM_VALUES) {
+        double v = 0.0;
+        for (int w = 0; w < PRT_BLOCK / 64; ++w) v += sh[w][threadIdx.x];
+        partials[(int64_t)blockIdx.x * MOM_VALUES + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_moments_final(int nblocks_,
+                                                             const double *__restrict__ partials,
+                                                             double *__restrict__ out) {
+    // fixed summation order: thread t adds blocks t, t+256, ...; then a fixed-shape tree
+    __shared__ double sh[PRT_BLOCK][MOM_VALUES];
+    double acc[MOM_VALUES] = {0, 0, 0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks_; b += PRT_BLOCK)
+#pragma unroll
+        for (int q = 0; q < MOM_VALUES; ++q) acc[q] += partials[(int64_t)b * MOM_VALUES + q];
+#pragma unroll
+    for (int q = 0; q < MOM_VALUES; ++q) sh[threadIdx.x][q] = acc[q];
+    __syncthreads();
+    for (int stride = PRT_BLOCK / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride)
+#pragma unroll
+            for (int q = 0; q < MOM_VALUES; ++q) sh[threadIdx.x][q] += sh[threadIdx.x + stride][q];
+        __syncthreads();
+    }
+    if (threadIdx.x < MOM_VALUES) out[threadIdx.x] = sh[0][threadIdx.x];
+}
+
+// Order-preserving slot assignment inside one CMP_TILE (= 4 sub-tiles of PRT_BLOCK consecutive
+// elements; thread t owns elements q*PRT_BLOCK + t, so loads and stores are lane-consecutive):
+// ballot + popcount per wave, then a prefix over the 4 x 4 (sub-tile, wave) counts.
+// keep[q] in -> pos[q] out (offset of the element among the tile's survivors).
+PRT_DEV void tile_slots(const bool keep[CMP_ITEMS], int pos[CMP_ITEMS]) {
+    __shared__ int cnt[CMP_ITEMS][PRT_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int rank[CMP_ITEMS];
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        const unsigned long long b = __ballot(keep[q]);
+        rank[q] = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) cnt[q][wave] = __popcll(b);
+    }
+    __syncthreads();
+    int run = 0;
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+#pragma unroll
+        for (int w = 0; w < PRT_BLOCK / 64; ++w) {
+            if (w == wave) pos[q] = run + rank[q];
+            run += cnt[q][w];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// compaction: per-block popcount -> single-block scan of block totals -> scatter
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_compact_count(const uint8_t *__restrict__ mask,
+                                                             int64_t N,
+                                                             int64_t *__restrict__ block_sums) {
+    __shared__ int wsum[PRT_BLOCK / 64];
+    const int64_t tile = (int64_t)blockIdx.x * CMP_TILE;
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        const int64_t idx = tile + q * PRT_BLOCK + threadIdx.x;
+        if (idx < N && mask[idx]) ++c;
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < PRT_BLOCK / 64; ++w) t += wsum[w];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of block_sums in place; total -> block_sums[nb]
+__global__ __launch_bounds__(PRT_BLOCK) void k_compact_scan(int64_t *__restrict__ block_sums,
+                                                            int64_t nb) {
+    __shared__ int64_t part[PRT_BLOCK];
+    const int64_t chunk = (nb + PRT_BLOCK - 1) / PRT_BLOCK;
+    const int64_t lo = (int64_t)threadIdx.x * chunk;
+    const int64_t hi = (lo + chunk < nb) ? lo + chunk : nb;
+    int64_t s = 0;
+    for (int64_t q = lo; q < hi; ++q) s += block_sums[q];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t run = 0;
+        for (int q = 0; q < PRT_BLOCK; ++q) {
+            const int64_t v = part[q];
+            part[q] = run;
+            run += v;
+        }
+        block_sums[nb] = run;
+    }
+    __syncthreads();
+    int64_t run = part[threadIdx.x];
+    for (int64_t q = lo; q < hi; ++q) {
+        const int64_t v = block_sums[q];
+        block_sums[q] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_compact_scatter(
+    const uint8_t *__restrict__ mask, int64_t N, const int64_t *__restrict__ block_offs,
+    int32_t n_arrays, const double *const *__restrict__ src, double *const *__restrict__ dst,
+    const int64_t *__restrict__ id_src, int64_t *__restrict__ id_dst,
+    const uint8_t *__restrict__ u8_src, uint8_t *__restrict__ u8_dst) {
+    const int64_t tile = (int64_t)blockIdx.x * CMP_TILE;
+    bool keep[CMP_ITEMS];
+    int pos[CMP_ITEMS];
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        const int64_t idx = tile + q * PRT_BLOCK + threadIdx.x;
+        keep[q] = (idx < N) && mask[idx];
+    }
+    tile_slots(keep, pos);
+    const int64_t off = block_offs[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        if (!keep[q]) continue;
+        const int64_t idx = tile + q * PRT_BLOCK + threadIdx.x;
+        const int64_t o = off + pos[q];
+        for (int a = 0; a < n_arrays; ++a) dst[a][o] = src[a][idx];
+        if (id_src) id_dst[o] = id_src[idx];
+        if (u8_src) u8_dst[o] = u8_src[idx];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// device-side bundle generation: RectGrid.getGrid (sampling2d/raster.py:40-60) +
+// OpticalSystemAnalysis.collimated_bundle (analysis/optical_system_analysis.py:83-122).
+// The raster is reproduced BIT-EXACTLY: numpy.linspace is i*step + start with two
+// roundings and the last sample forced to `stop`; the disk test is x*x + y*y <= 1 with
+// separate roundings -- hence the explicit _rn intrinsics (no FMA contraction).
+// ---------------------------------------------------------------------------
+// a*b and a+b rounded separately: HIP's __dmul_rn/__dadd_rn are plain operators that hipcc
+// contracts into FMAs, so contraction is switched off per statement instead
+PRT_DEV double mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+PRT_DEV double add_rn(double a, double b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+PRT_DEV double lin_sample(int64_t i, int64_t n, double start, double step, double stop) {
+    return (i == n - 1) ? stop : add_rn(mul_rn((double)i, step), start);
+}
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_rectgrid_mask(int64_t n, double start, double step,
+                                                             double stop,
+                                                             uint8_t *__restrict__ mask) {
+    const int64_t idx = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (idx >= n * n) return;
+    const int64_t iy = idx / n, ix = idx - iy * n;  // np.meshgrid(x1d, x1d): x varies fastest
+    const double x = lin_sample(ix, n, start, step, stop), y = lin_sample(iy, n, start, step, stop);
+    mask[idx] = (add_rn(mul_rn(x, x), mul_rn(y, y)) <= 1.0) ? 1 : 0;
+}
+
+struct collimated_params {
+    double radius, startx, starty, startz;
+    double k[3], e[3];
+};
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_rectgrid_scatter(
+    const uint8_t *__restrict__ mask, int64_t n, double start, double step, double stop,
+    const int64_t *__restrict__ block_offs, int64_t lo, int64_t hi, collimated_params prm,
+    int64_t pitch, double *__restrict__ x_out, double *__restrict__ k_out,
+    double *__restrict__ e_out) {
+    const int64_t total = n * n;
+    const int64_t tile = (int64_t)blockIdx.x * CMP_TILE;
+    bool keep[CMP_ITEMS];
+    int pos[CMP_ITEMS];
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        const int64_t idx = tile + q * PRT_BLOCK + threadIdx.x;
+        keep[q] = (idx < total) && mask[idx];
+    }
+    tile_slots(keep, pos);
+    const int64_t off = block_offs[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        if (!keep[q]) continue;
+        const int64_t p = off + pos[q];
+        if (p < lo || p >= hi) continue;
+        const int64_t idx = tile + q * PRT_BLOCK + threadIdx.x;
+        const int64_t iy = idx / n, ix = idx - iy * n;
+        const double px = lin_sample(ix, n, start, step, stop);
+        const double py = lin_sample(iy, n, start, step, stop);
+        const int64_t o = p - lo;
+        // origin = radius * p + start (optical_system_analysis.py:106-108), two roundings
+        x_out[o] = add_rn(mul_rn(prm.radius, px), prm.startx);
+        x_out[pitch + o] = add_rn(mul_rn(prm.radius, py), prm.starty);
+        x_out[2 * pitch + o] = prm.startz;
+        k_out[o] = prm.k[0];
+        k_out[pitch + o] = prm.k[1];
+        k_out[2 * pitch + o] = prm.k[2];
+        if (e_out) {
+            e_out[o] = prm.e[0];
+            e_out[pitch + o] = prm.e[1];
+            e_out[2 * pitch + o] = prm.e[2];
+        }
+    }
+}
+

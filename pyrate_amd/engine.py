@@ -292,8 +292,8 @@ class DeviceSystem(object):
 def compact(mask, arrays, ids=None, flags=None):
     """Order-preserving ``[:, mask]`` on the device (material_isotropic.py:194-199).
     arrays: list of (R_i, N) float64 tensors; ids: optional (N,) int64; flags: optional
-    (N,) uint8.  Returns (list of compacted tensors, compacted ids or None) and, when
-    ``flags`` is given, a third element with the compacted flags."""
+    (N,) uint8.  Returns (list of compacted tensors, compacted ids or None, compacted flags
+    or None); the tensors are row-pitched views of one allocation."""
     lib = _lib.load()
     n = mask.shape[0]
     dev = mask.device
@@ -324,9 +324,8 @@ def compact(mask, arrays, ids=None, flags=None):
         out.append(tmp[r0:r0 + rr, :m])        # row-pitched view (pitch n), no second copy
         r0 += rr
     idc = idt[:m].contiguous() if ids is not None else None
-    if flags is not None:
-        return out, idc, flt[:m].contiguous()
-    return out, idc
+    flc = flt[:m].contiguous() if flags is not None else None
+    return out, idc, flc
 
 
 def bundle_moments(x, mask=None, ref=None, mode=0):

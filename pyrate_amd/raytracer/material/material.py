@@ -70,7 +70,7 @@ def interact_bundle(material, raybundle, surface, mirror, splitup):
     if not aniso:
         (k_out, _d, valid_out, _, _) = sysd.interact(0, x_hit, k, valid_in=raybundle._valid[-1])
         # return only valid rays (material_isotropic.py:194-199), on the device
-        ((xc, kc), idc) = engine.compact(valid_out, [x_hit, k_out], ids)
+        ((xc, kc), idc, _) = engine.compact(valid_out, [x_hit, k_out], ids)
         ones = torch.ones(xc.shape[1], dtype=torch.uint8, device=dev)
         return (RayBundle._from_device([xc], [kc], [ones], idc, raybundle.wave, dev,
                                        dir_from_k=True, k_complex=raybundle._k_complex),)

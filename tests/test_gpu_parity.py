@@ -133,12 +133,12 @@ def test_compaction_matches_boolean_indexing(gpu_device):
         x = torch.rand((3, n), generator=g, dtype=torch.float64).to(gpu_device)
         k = torch.rand((3, n), generator=g, dtype=torch.float64).to(gpu_device)
         ids = torch.arange(n, dtype=torch.int64, device=gpu_device)
-        ((xc, kc), idc) = engine.compact(mask, [x, k], ids)
+        ((xc, kc), idc, _) = engine.compact(mask, [x, k], ids)
         mb = mask.bool()
         assert torch.equal(xc, x[:, mb]) and torch.equal(kc, k[:, mb]) and torch.equal(idc, ids[mb])
     # empty / all-false
     mask = torch.zeros(100, dtype=torch.uint8, device=gpu_device)
-    ((xc,), _) = engine.compact(mask, [torch.ones((3, 100), dtype=torch.float64, device=gpu_device)])
+    ((xc,), _, _) = engine.compact(mask, [torch.ones((3, 100), dtype=torch.float64, device=gpu_device)])
     assert xc.shape == (3, 0)
 
 
