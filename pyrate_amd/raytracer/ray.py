@@ -275,6 +275,26 @@ class RayBundle(object):
     def __deepcopy__(self, memo):
         return self.clone()
 
+    # -- small conveniences of the reference API (ray.py:118-134, 156-161); they work on the
+    #    NumPy views with the frame's 3x3 host transforms, like the reference
+    def returnLocalComponents(self, lc, num):
+        return (lc.returnGlobalToLocalPoints(self.x[num]), lc.returnGlobalToLocalDirections(self.k[num]),
+                lc.returnGlobalToLocalDirections(self.Efield[num]))
+
+    def returnLocalD(self, lc, num):
+        return lc.returnGlobalToLocalDirections(self.returnKtoD()[num])
+
+    def appendLocalComponents(self, lc, xloc, kloc, Eloc, valid):
+        self.append(lc.returnLocalToGlobalPoints(xloc), lc.returnLocalToGlobalDirections(kloc),
+                    lc.returnLocalToGlobalDirections(Eloc), valid)
+
+    def getLocalSurfaceNormal(self, surface, material, xglob):
+        """unit surface normal at global points, expressed in the material's frame; the shape
+        gradient is evaluated on the GPU (Shape.getNormal -> prt_shape_eval)"""
+        xlocshape = surface.shape.lc.returnGlobalToLocalPoints(xglob)
+        nlocshape = surface.shape.getNormal(xlocshape[0], xlocshape[1])
+        return material.lc.returnOtherToActualDirections(nlocshape, surface.shape.lc)
+
     def direction_dev(self, num=-1):
         """unit Poynting direction of stored point ``num`` on the device (ray.py:136-152)"""
         self._ensure()

@@ -256,3 +256,34 @@ def test_custom_ray_ids_survive_compaction(api):
     rp = s.seqtrace(ib, seq)[0]
     for (rb, ref) in zip(rp.raybundles, case.raw_bundles):
         assert np.array_equal(rb.rayID, ref["id"] * 3 + 100)
+
+
+def test_raybundle_local_helpers(api):
+    """returnLocalComponents / returnLocalD / getLocalSurfaceNormal (ray.py:118-161)"""
+    (s, seq) = zoo.tilted(api)
+    case = _golden.load_case("tilted_frames")
+    rp = s.seqtrace(bundle_of(api, case), seq)[0]
+    rb = rp.raybundles[2]                       # bundle created at surface s1
+    surf = s.elements["tilted"].surfaces["s1"]
+    mat = s.elements["tilted"].materials["glass"]
+    (xl, kl, el) = rb.returnLocalComponents(surf.shape.lc, 0)
+    # the hit points lie on the conic in the shape frame
+    z = oracle_sag(case.table[0]["shape"], xl[0], xl[1])
+    assert np.allclose(xl[2], z, rtol=0, atol=1e-12)
+    n = rb.getLocalSurfaceNormal(surf, mat, rb.x[0])
+    assert np.allclose(np.sum(n * n, axis=0), 1.0)
+    # Snell in the material frame: the tangential component of k is continuous
+    k_in = mat.lc.returnGlobalToLocalDirections(np.real(rp.raybundles[1].k[1]))[:, rp.raybundles[1].valid[1]]
+    ids_in = rp.raybundles[1].rayID[rp.raybundles[1].valid[1]]
+    sel = np.isin(ids_in, rb.rayID)
+    k_out = mat.lc.returnGlobalToLocalDirections(np.real(rb.k[0]))
+    t_in = k_in[:, sel] - np.sum(k_in[:, sel] * n, axis=0) * n
+    t_out = k_out - np.sum(k_out * n, axis=0) * n
+    assert np.allclose(t_in, t_out, rtol=0, atol=1e-12)
+    d = rb.returnLocalD(surf.shape.lc, 0)
+    assert np.allclose(np.sum(d * d, axis=0), 1.0)
+
+
+def oracle_sag(shape, x, y):
+    from oracle import seqtrace_np
+    return seqtrace_np.shape_sag(shape, x, y)
