@@ -99,3 +99,46 @@ def test_random_systems_match_oracle(gpu_device, seed):
             assert np.abs(res.k_out[s].cpu().numpy()[:, wo] - ko).max() < 1e-10, (seed, s)
         ncmp += int(wo.sum())
     assert ncmp > 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_crystals_match_oracle(gpu_device, seed):
+    """random real symmetric epsilon tensors (isotropic / uniaxial / biaxial, arbitrarily
+    rotated) in the doublet: wave vectors of all split rays vs the oracle (scipy.linalg.eig
+    like the reference), order of the two transmitted solutions included"""
+    from pyrate_amd import engine, systems
+    rng = np.random.RandomState(500 + seed)
+
+    def eps():
+        kind = seed % 3
+        R = rot(rng, 1.0)
+        if kind == 0:
+            pv = np.full(3, rng.uniform(1.4, 1.8) ** 2)
+        elif kind == 1:
+            (no, ne) = (rng.uniform(1.45, 1.7), rng.uniform(1.45, 1.7))
+            pv = np.array([no ** 2, no ** 2, ne ** 2])
+        else:
+            pv = np.sort(rng.uniform(1.45, 1.75, 3)) ** 2
+        return R.dot(np.diag(pv)).dot(R.T)
+    recs = systems.aniso_doublet_records(eps(), eps())
+    (o, k, e0) = systems.double_gauss_bundle(300, rpup=10.0, z0=-5.0, field_deg=float(rng.uniform(-4, 4)))
+    with np.errstate(all="ignore"):
+        out = oracle.trace(recs, o, k, e0)
+    sysd = engine.DeviceSystem(recs, 0)
+    res = sysd.trace(engine.to_device_rays(o, gpu_device), engine.to_device_rays(k, gpu_device),
+                     engine.to_device_rays(e0, gpu_device))
+    degenerate = seed % 3 == 0
+    for s in range(len(recs)):
+        xo = out[s]["x_hit"]
+        v = out[s]["valid"] & np.all(np.isfinite(xo), axis=0)
+        xd = res.x_hit[s].cpu().numpy()
+        kd = res.k_out[s].cpu().numpy()
+        ko = np.real(out[s]["k_out"])
+        fin = np.all(np.isfinite(ko), axis=0)
+        if degenerate:
+            # eps = e I: both transmitted solutions share k; hit points agree whatever the order
+            assert np.abs(xd[:, v] - xo[:, v]).max() < 1e-9
+            assert np.abs(kd[:, fin] - ko[:, fin]).max() < 1e-9
+        else:
+            assert np.abs(xd[:, v] - xo[:, v]).max() < 1e-9, (seed, s)
+            assert np.abs(kd[:, fin] - ko[:, fin]).max() < 1e-10, (seed, s)
