@@ -207,6 +207,44 @@ def case_aniso():
     dump_case("aniso_doublet_biaxial", s, seq, disk_bundle(60, 11.43, -5.0, field_deg=-2.0))
 
 
+DISPERSION_PAGES = {
+    # public catalogue coefficients (SCHOTT N-BK7 Sellmeier; the others are synthetic pages that
+    # exercise every formula type of raytracer/material/material_glasscat.py:318-446)
+    "formula1_nbk7": {"DATA": [{"type": "formula 1", "wavelength_range": "0.3 2.5",
+                                "coefficients": "0 1.03961212 0.0774641951 0.231792344 0.141485249 1.01046945 10.1764754"}],
+                      "SPECS": {"nd": 1.5168}},
+    "formula2": {"DATA": [{"type": "formula 2", "wavelength_range": "0.3 2.5",
+                           "coefficients": "0 1.03961212 0.00600069867 0.231792344 0.0200179144 1.01046945 103.560653"}]},
+    "formula3": {"DATA": [{"type": "formula 3", "wavelength_range": "0.4 1.6",
+                           "coefficients": "2.2718929 -0.010108077 2 0.010592509 -2 0.00020816965 -4 -7.6472538e-06 -6 4.9240991e-07 -8"}]},
+    "formula4_9": {"DATA": [{"type": "formula 4", "wavelength_range": "0.4 2.0",
+                             "coefficients": "2.7 0.45 2 0.12 1 0.9 2 9.0 2"}]},
+    "formula4_11": {"DATA": [{"type": "formula 4", "wavelength_range": "0.4 2.0",
+                              "coefficients": "2.7 0.45 2 0.12 1 0.9 2 9.0 2 -0.01 2 0.001 -2"}]},
+    "formula5": {"DATA": [{"type": "formula 5", "wavelength_range": "0.4 1.0",
+                           "coefficients": "1.5 0.004 -2 0.00002 -4"}]},
+    "formula6": {"DATA": [{"type": "formula 6", "wavelength_range": "0.3 1.7",
+                           "coefficients": "0 0.05792105 238.0185 0.00167917 57.362"}]},
+    "formula7": {"DATA": [{"type": "formula 7", "wavelength_range": "0.4 2.0",
+                           "coefficients": "1.6 0.01 0.0002 -0.002 -0.00001"}]},
+    "tabulated_n": {"DATA": [{"type": "tabulated n", "data": "0.4 1.53\n0.5 1.52\n0.6 1.515\n0.8 1.51\n"}]},
+}
+
+
+def case_dispersion():
+    """n(wavelength) of the reference's CatalogMaterial for every dispersion formula type"""
+    from pyrateoptics.raytracer.material.material_glasscat import CatalogMaterial
+    lc = LocalCoordinates.p(name="disp")
+    waves_mm = [0.45e-3, 0.4861e-3, 0.5876e-3, 0.6563e-3, 0.78e-3]
+    out = {"pages": DISPERSION_PAGES, "waves_mm": waves_mm, "n": {}}
+    for (key, page) in DISPERSION_PAGES.items():
+        mat = CatalogMaterial.p(lc, page)
+        out["n"][key] = [float(np.real(mat.get_optical_index(None, w))) for w in waves_mm]
+    with open(os.path.join(OUT, "dispersion.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("dispersion.json: %d pages x %d wavelengths" % (len(DISPERSION_PAGES), len(waves_mm)))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     np.random.seed(0)
@@ -220,6 +258,7 @@ def main():
     case_hud()
     case_two_elements()
     case_aniso()
+    case_dispersion()
 
 
 if __name__ == "__main__":

@@ -46,6 +46,12 @@ def build_simple_optical_element(lc0, builduplist, material_db_path="", name="")
                 key = mat.name
                 elem.addMaterial(key, mat)
                 mat = key
+            elif isinstance(mat, dict) and "DATA" in mat:
+                # a refractiveindex.info page dictionary (pyrateoptics/__init__.py:193-196)
+                from .raytracer.material.material_glasscat import CatalogMaterial
+                key = str(mat.get("SPECS", {}).get("nd", "catalog_" + surf_name))
+                elem.addMaterial(key, CatalogMaterial.p(lc, mat))
+                mat = key
             elif isinstance(mat, dict) and "eps" in mat:
                 key = "anisotropic_" + surf_name
                 elem.addMaterial(key, AnisotropicMaterial.p(lc, np.array(mat["eps"]), name=key))

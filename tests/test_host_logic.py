@@ -212,3 +212,26 @@ def test_no_product_module_imports_the_oracle():
         src = open(path).read()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
         assert "seqtrace_np" not in src and "seqtrace_c" not in src, path
+
+
+def test_catalog_material_dispersion_matches_reference(api):
+    """CatalogMaterial n(wavelength) for every dispersion formula type == the reference's
+    material_glasscat.py (values generated by oracle/make_golden.py: tests/golden/dispersion.json);
+    N-BK7: nd = 1.5168 (public SCHOTT value)"""
+    from pyrate_amd.raytracer.material.material_glasscat import CatalogMaterial
+    gold = json.load(open(os.path.join(_golden.GOLDEN_DIR, "dispersion.json")))
+    lc = api.LocalCoordinates.p(name="d")
+    for (key, page) in gold["pages"].items():
+        mat = CatalogMaterial.p(lc, page)
+        n = [mat.get_optical_index(None, w) for w in gold["waves_mm"]]
+        assert np.allclose(n, gold["n"][key], rtol=1e-15, atol=0), key
+    bk7 = CatalogMaterial.p(lc, gold["pages"]["formula1_nbk7"])
+    assert abs(bk7.get_optical_index(None, 0.5875618e-3) - 1.5168) < 2e-5
+    with pytest.raises(Exception):
+        bk7.get_optical_index(None, 5e-3)                    # wavelength out of range
+    # a catalogue dictionary as material in the builders (pyrateoptics/__init__.py:193-196)
+    (s, seq) = api.build_simple_optical_system([
+        ({"shape": "Conic", "curv": 0.01}, {"decz": 1.0}, gold["pages"]["formula1_nbk7"], "f", {}),
+        ({"shape": "Conic"}, {"decz": 3.0}, None, "b", {})])
+    recs = st.flatten_sequence(s, seq, 0.5876e-3)[0]
+    assert abs(recs[0]["material"]["n"] - gold["n"]["formula1_nbk7"][2]) < 1e-15
