@@ -35,6 +35,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PREWARM_LAUNCHES = 30
 
 
 def algorithmic_bytes(n_rays, n_surfaces, with_e0=True):
@@ -214,6 +215,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # device wake-up (not one of the W warm-up steps): after idle the first ~25 ms of launches run
+    # at ramping clocks (per-launch trace in DESIGN.md section 5); 30 plain launches of the same
+    # kernel bring the chip to its steady state before anything is counted
+    for _ in range(PREWARM_LAUNCHES):
+        sysd.trace_into(x0, k0, bufs[0], e0d)
+    torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     finish(args.warmup - 1)
@@ -270,7 +277,7 @@ def main():
                                     "bundle ray-sharded over the GPUs, BASELINE configs[4]"),
                        "rays_per_gpu": n_local, "rays_total": n_total, "surfaces": S,
                        "mode": args.mode, "sharding": "rays" if n_gpus > 1 else "none",
-                       "wavelengths": len(sysds),
+                       "wavelengths": len(sysds), "prewarm_launches": PREWARM_LAUNCHES,
                        "image_plane_exchange": {
                            "per_step": ("device spot statistics + two 7-double all-reduces, overlapped"
                                         if do_stats else ("image-plane all-gather 49 B/ray" if do_step_gather

@@ -35,6 +35,24 @@ static int32_t fail(int32_t code, const char *what, hipError_t e = hipSuccess) {
     return code;
 }
 
+// Entry points run on `device` but leave the calling thread's current device untouched (the
+// host framework -- torch -- tracks its own notion of the current device).
+struct device_guard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit device_guard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+        else if (err == hipSuccess) prev = -1;  // nothing to restore
+    }
+    ~device_guard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define PRT_ON_DEVICE(dev)                                                            \
+    device_guard guard_((dev));                                                       \
+    if (guard_.err != hipSuccess) return fail(PRT_ERR_DEVICE, "hipSetDevice", guard_.err)
+
 #define HIP_TRY(call)                                                   \
     do {                                                                \
         hipError_t e_ = (call);                                         \
@@ -153,7 +171,7 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(PRT_ERR_NO_DEVICE, "no HIP device visible", e);
     if (device < 0 || device >= ndev) return fail(PRT_ERR_INVALID_ARG, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
+    PRT_ON_DEVICE(device);
     prt_system *sys = new (std::nothrow) prt_system();
     if (!sys) return fail(PRT_ERR_NOMEM, "host alloc");
     sys->device = device;
@@ -189,7 +207,7 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
 
 int32_t prt_system_destroy(prt_system_t *sys) {
     if (!sys) return PRT_OK;
-    (void)hipSetDevice(sys->device);
+    device_guard guard_(sys->device);
     (void)hipFree(sys->d_table);
     delete[] sys->h_table;
     delete sys;
@@ -334,7 +352,7 @@ int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const d
     if (in_pitch == 0) in_pitch = n0;
     if (in_pitch < n0 || (out_pitch != 0 && out_pitch < n0))
         return fail(PRT_ERR_INVALID_ARG, "prt_trace: pitch smaller than the ray count");
-    HIP_TRY(hipSetDevice(sys->device));
+    PRT_ON_DEVICE(sys->device);
     hipStream_t st = (hipStream_t)stream;
     if (!sys->all_isotropic) {
         if (out_pitch != 0 || in_pitch != n0)
@@ -391,7 +409,7 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
                         uint8_t *valid_out, void *stream, int32_t iters, double *ms_avg) {
     if (!ms_avg || iters <= 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace_timed");
     if (!sys) return fail(PRT_ERR_INVALID_ARG, "null system");
-    HIP_TRY(hipSetDevice(sys->device));
+    PRT_ON_DEVICE(sys->device);
     hipStream_t st = (hipStream_t)stream;
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
@@ -425,7 +443,7 @@ int32_t prt_propagate(const prt_system_t *sys, int32_t surface, int64_t n, const
     if (n == 0) return PRT_OK;
     if (!x || (!k && !dir) || !x_hit || !valid)
         return fail(PRT_ERR_INVALID_ARG, "prt_propagate: null pointer");
-    HIP_TRY(hipSetDevice(sys->device));
+    PRT_ON_DEVICE(sys->device);
     hipLaunchKernelGGL(k_propagate, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                        (hipStream_t)stream, sys->d_table + surface, n, n, x, k, dir, e_re, e_im,
                        e_mode_of(e_re, use_default_e), valid_in, x_hit, valid);
@@ -440,7 +458,7 @@ int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const 
         return fail(PRT_ERR_INVALID_ARG, "prt_interact: bad system / surface / count");
     if (n == 0) return PRT_OK;
     if (!x_hit || !k || !k_out) return fail(PRT_ERR_INVALID_ARG, "prt_interact: null pointer");
-    HIP_TRY(hipSetDevice(sys->device));
+    PRT_ON_DEVICE(sys->device);
     const prt_surface_t *rec = sys->h_table + surface;
     if (rec->mat_type == PRT_MAT_ANISOTROPIC) {
         if (!dir_out) return fail(PRT_ERR_INVALID_ARG, "prt_interact: anisotropic needs dir_out");
@@ -462,7 +480,7 @@ int32_t prt_shape_eval(const prt_system_t *sys, int32_t surface, int64_t n, cons
         return fail(PRT_ERR_INVALID_ARG, "prt_shape_eval: bad system / surface / count");
     if (n == 0) return PRT_OK;
     if (!x || !y) return fail(PRT_ERR_INVALID_ARG, "prt_shape_eval: null pointer");
-    HIP_TRY(hipSetDevice(sys->device));
+    PRT_ON_DEVICE(sys->device);
     hipLaunchKernelGGL(k_shape_eval, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                        (hipStream_t)stream, sys->d_table + surface, n, x, y, sag, grad);
     HIP_TRY(hipGetLastError());
@@ -473,7 +491,7 @@ int32_t prt_efield_perp(int32_t device, int64_t n, const double *k, double *e_ou
     if (n < 0) return fail(PRT_ERR_INVALID_ARG, "prt_efield_perp: negative count");
     if (n == 0) return PRT_OK;
     if (!k || !e_out) return fail(PRT_ERR_INVALID_ARG, "prt_efield_perp: null pointer");
-    HIP_TRY(hipSetDevice(device));
+    PRT_ON_DEVICE(device);
     hipLaunchKernelGGL(k_efield_perp, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                        (hipStream_t)stream, n, k, e_out);
     HIP_TRY(hipGetLastError());
@@ -516,7 +534,7 @@ static int32_t rect_grid_scan(int64_t nray, hipStream_t st, int64_t *n_per_dim, 
 int32_t prt_rect_grid_count(int32_t device, int64_t nray, int64_t *n_per_dim, int64_t *n_in_disk,
                             void *stream) {
     if (nray < 1 || !n_per_dim || !n_in_disk) return fail(PRT_ERR_INVALID_ARG, "prt_rect_grid_count");
-    HIP_TRY(hipSetDevice(device));
+    PRT_ON_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     double start, step, stop;
     uint8_t *d_mask = nullptr;
@@ -536,7 +554,7 @@ int32_t prt_collimated_bundle(int32_t device, int64_t nray, int64_t lo, int64_t 
     if (!x_out || !k_out) return fail(PRT_ERR_INVALID_ARG, "prt_collimated_bundle: null pointer");
     if (pitch == 0) pitch = hi - lo;
     if (pitch < hi - lo) return fail(PRT_ERR_INVALID_ARG, "prt_collimated_bundle: pitch < hi - lo");
-    HIP_TRY(hipSetDevice(device));
+    PRT_ON_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     double start, step, stop;
     uint8_t *d_mask = nullptr;
@@ -569,7 +587,7 @@ int32_t prt_poynting_dir(int32_t device, int64_t n, const double *k, const doubl
     if (n < 0) return fail(PRT_ERR_INVALID_ARG, "prt_poynting_dir: negative count");
     if (n == 0) return PRT_OK;
     if (!k || !d_out) return fail(PRT_ERR_INVALID_ARG, "prt_poynting_dir: null pointer");
-    HIP_TRY(hipSetDevice(device));
+    PRT_ON_DEVICE(device);
     hipLaunchKernelGGL(k_poynting_dir, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                        (hipStream_t)stream, n, k, e_re, e_im, e_mode_of(e_re, use_default_e), d_out);
     HIP_TRY(hipGetLastError());
@@ -582,7 +600,7 @@ int32_t prt_path_sums(int32_t device, int32_t n_points, int64_t n, const double 
         return fail(PRT_ERR_INVALID_ARG, "prt_path_sums: bad argument");
     if (n == 0) return PRT_OK;
     if (!xs || !out || (mode == 1 && !ks)) return fail(PRT_ERR_INVALID_ARG, "prt_path_sums: null pointer");
-    HIP_TRY(hipSetDevice(device));
+    PRT_ON_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     const double **d_tab = nullptr;
     HIP_TRY(hipMallocAsync((void **)&d_tab, sizeof(void *) * 2 * n_points, st));
@@ -608,7 +626,7 @@ int32_t prt_bundle_moments(int32_t device, int64_t n, int64_t pitch, const doubl
     if (!x) return fail(PRT_ERR_INVALID_ARG, "prt_bundle_moments: null pointer");
     if (pitch == 0) pitch = n;
     if (pitch < n) return fail(PRT_ERR_INVALID_ARG, "prt_bundle_moments: pitch < n");
-    HIP_TRY(hipSetDevice(device));
+    PRT_ON_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     int nb = (int)((n + PRT_BLOCK * 8 - 1) / (PRT_BLOCK * 8));
     if (nb > 2048) nb = 2048;
@@ -643,7 +661,7 @@ int32_t prt_bundle_moments_async(int32_t device, int64_t n, int64_t pitch, const
     if (n > 0 && !x) return fail(PRT_ERR_INVALID_ARG, "prt_bundle_moments_async: null pointer");
     if (pitch == 0) pitch = n;
     if (pitch < n) return fail(PRT_ERR_INVALID_ARG, "prt_bundle_moments_async: pitch < n");
-    HIP_TRY(hipSetDevice(device));
+    PRT_ON_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     int nb = (int)((n + PRT_BLOCK * 8 - 1) / (PRT_BLOCK * 8));
     if (nb > 2048) nb = 2048;
