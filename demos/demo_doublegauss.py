@@ -10,7 +10,6 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
-import numpy as np
 
 from pyrate_amd import systems
 from pyrate_amd.builders import build_rotationally_symmetric_optical_system
