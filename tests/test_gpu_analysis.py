@@ -172,3 +172,32 @@ def test_return_k_to_d_and_phase_difference(gpu_device):
     d2 = rb2.returnKtoD()[0]
     ref2 = np.vstack((k0[0], np.zeros(n), k0[2]))
     assert np.allclose(d2, ref2 / np.sqrt(np.sum(ref2 ** 2, axis=0)), rtol=0, atol=1e-14)
+
+
+def test_async_spot_statistics_and_gather_single_rank(gpu_device):
+    """the device-resident statistics pipeline and the image-plane gather of the multi-GPU bench
+    path, on one rank (no process group): same numbers as the synchronous reductions"""
+    from pyrate_amd import engine
+    from pyrate_amd import distributed as pdist
+    case = _golden.load_case("double_gauss_wide")
+    sysd = engine.DeviceSystem(case.table, 0)
+    res = sysd.trace(engine.to_device_rays(case.x0, gpu_device), engine.to_device_rays(case.k0, gpu_device),
+                     engine.to_device_rays(case.E0, gpu_device))
+    (x, k, v) = (res.x_hit[-1], res.k_out[-1], res.valid_out[-1])
+    st = pdist.SpotStatistics(gpu_device)
+    st.start(x, v)
+    (cnt, cen, rms) = st.result()
+    (cnt2, cen2, rms2) = pdist.global_spot_statistics(x, v)
+    assert cnt == cnt2 == 277
+    assert np.allclose(cen, cen2, rtol=0, atol=1e-14) and abs(rms - rms2) < 1e-14
+    m = v.cpu().numpy().astype(bool)
+    xs = x.cpu().numpy()[:, m]
+    c = xs.mean(axis=1)
+    assert np.allclose(cen, c, rtol=1e-13) and abs(rms - np.sqrt(((xs - c[:, None]) ** 2).sum() / (m.sum() - 1))) < 1e-13
+    g = pdist.ImagePlaneGather(x.shape[1], gpu_device)
+    g.start(x, k, v)
+    (gx, gk, gv) = g.finish()
+    import torch
+    assert torch.equal(torch.nan_to_num(gx), torch.nan_to_num(x)) and torch.equal(gv, v)
+    assert torch.equal(torch.nan_to_num(gk), torch.nan_to_num(k))
+    assert pdist.shard_range(x.shape[1], 0, 1) == (0, x.shape[1])
