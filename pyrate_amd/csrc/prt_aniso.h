@@ -47,7 +47,6 @@ PRT_DEV double cabs2(cplx a) { return a.re * a.re + a.im * a.im; }
 PRT_DEV vec3 cross(const vec3 &a, const vec3 &b) {
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-PRT_DEV vec3 sym_mat_vec(const double *__restrict__ e, const vec3 &v) { return mat_vec(e, v); }
 
 // quartic coefficients, calcXiPolynomialNorm (material.py:501-566), real eps
 PRT_DEV void xi_polynomial(const double *__restrict__ eps, const vec3 &n, const vec3 &kpa,

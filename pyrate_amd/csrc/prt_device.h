@@ -80,8 +80,6 @@ PRT_DEV double fast_rsqrt(double x) {
     return r;
 }
 
-PRT_DEV bool finite3(const vec3 &v) { return isfinite(v.x) && isfinite(v.y) && isfinite(v.z); }
-
 // ---------------------------------------------------------------------------
 // first-segment direction: RayBundle.returnKtoD, ray.py:136-152
 //   S = Re(|E|^2 k - (E.k) conj(E)),  d = S/|S|      (k real)
