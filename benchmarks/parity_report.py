@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Per-case parity numbers of the HIP engine against the reference's golden vectors
+(tests/golden/*.npz): max relative error of hit points, max absolute error of wave vectors,
+number of compared ray-surface points.  The pass/fail version of this is tests/test_gpu_parity.py."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+import _golden
+from test_oracle_golden import explicit_tolerance
+from pyrate_amd import engine
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    print("%-34s %5s %7s %12s %12s %s" % ("case", "surf", "rays", "max rel dx", "max abs dk", "note"))
+    for name in _golden.ALL_CASES:
+        case = _golden.load_case(name)
+        sysd = engine.DeviceSystem(case.table, 0)
+        e = np.asarray(case.E0)
+        res = sysd.trace(engine.to_device_rays(case.x0, dev), engine.to_device_rays(case.k0, dev),
+                         engine.to_device_rays(e.real, dev),
+                         engine.to_device_rays(e.imag, dev) if np.iscomplexobj(e) else None)
+        dense = _golden.dense_from_engine(res)
+        explicit = name in _golden.EXPLICIT_CASES
+        r = _golden.compare_dense_to_reference(case, dense, rtol_x=1.0, atol_k=1.0,
+                                               explicit_tol=explicit_tolerance if explicit else None)
+        raw = _golden.compare_dense_to_reference(case, dense, rtol_x=1.0, atol_k=1.0) if explicit else r
+        note = ""
+        if explicit:
+            note = "raw (reference fsolve xtol=1e-6): dx %.1e dk %.1e" % (raw["max_rel_x"], raw["max_abs_k"])
+        print("%-34s %5d %7d %12.2e %12.2e %s" % (name, case.n_surfaces, case.x0.shape[1], r["max_rel_x"],
+                                                  r["max_abs_k"], note))
+
+
+if __name__ == "__main__":
+    main()
