@@ -340,6 +340,10 @@ PRT_DEV void propagate_step(const prt_surface_t *__restrict__ sf, const vec3 &x,
         bool nonconv;
         double fx, fy;
         t = explicit_t(sf, r0, dl, nonconv, fx, fy);  // reference: valid all True (surface_shape.py:462)
+        // A ray whose Newton iteration hit the cap has no trustworthy hit point.  The mask after
+        // propagate stays reference-compatible (True); the NaN hit point makes the normal NaN, so
+        // the ray is dropped by the finite-normal test of the following refraction.
+        if (nonconv) t = __builtin_nan("");
         p = v3(r0.x + dl.x * t, r0.y + dl.y * t, r0.z + dl.z * t);
         g = v3(-fx, -fy, 1.0);
         g2 = fx * fx + fy * fy + 1.0;
