@@ -155,6 +155,17 @@ int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const d
                   uint8_t *valid_out, void *stream);
 
 /*
+ * prt_trace in the concatenated layout (tight inputs) that also returns the E field of the rays
+ * leaving every crystal interface: e_out_re / e_out_im (may be NULL) have the layout of k_out;
+ * blocks of isotropic surfaces are left untouched (there E is not computed, see prt_efield_perp).  This is what
+ * AnisotropicMaterial.refract stores in the new RayBundle (material_anisotropic.py:91-99).
+ */
+int32_t prt_trace_fields(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,
+                         const double *e0_re, const double *e0_im, int32_t mode, double *x_hit,
+                         double *k_out, double *e_out_re, double *e_out_im, uint8_t *valid,
+                         uint8_t *valid_out, void *stream);
+
+/*
  * Material.propagate(raybundle, surface): intersect + aperture for one surface.
  *   x, k (3,n); dir (3,n) unit ray directions or NULL (then e_re/e_im as in
  *   prt_trace, or k/|k| if e_re is NULL and use_default_e == 0).

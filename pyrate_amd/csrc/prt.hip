@@ -235,8 +235,8 @@ static bool aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 // march through a table that contains anisotropic media: one launch pair per surface
 static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *x0,
                              const double *k0, const double *e_re, const double *e_im,
-                             int32_t mode, double *x_hit, double *k_out, uint8_t *valid,
-                             uint8_t *valid_out, hipStream_t st) {
+                             int32_t mode, double *x_hit, double *k_out, double *e_out,
+                             double *e_out_im, uint8_t *valid, uint8_t *valid_out, hipStream_t st) {
     const int S = sys->n_surfaces;
     // scratch: directions after anisotropic interfaces, plus ping-pong state in IMAGE mode
     int64_t n_final = n0;
@@ -306,7 +306,12 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
         if (aniso) {
             hipLaunchKernelGGL(k_interact_aniso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                                st, sys->d_table + s, n, xh_dst, cur_k, cur_valid, k_dst, dir_dst,
-                               (double *)nullptr, (double *)nullptr, vo_dst);
+                               (e_out && mode == PRT_MODE_PATH) ? e_out + 3 * off_out
+                                                               : ((e_out && last) ? e_out : (double *)nullptr),
+                               (e_out_im && mode == PRT_MODE_PATH)
+                                   ? e_out_im + 3 * off_out
+                                   : ((e_out_im && last) ? e_out_im : (double *)nullptr),
+                               vo_dst);
             cur_dir = dir_dst;
         } else {
             hipLaunchKernelGGL(k_interact_iso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st,
@@ -339,10 +344,10 @@ int64_t prt_recommended_pitch(int64_t n) {
     return (n + 511) / 512 * 512;  // 4 KiB of doubles: every row starts on a 128-B line
 }
 
-int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
-                  const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
-                  int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
-                  uint8_t *valid_out, void *stream) {
+static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
+                          const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
+                          int64_t out_pitch, double *x_hit, double *k_out, double *e_out,
+                          double *e_out_im, uint8_t *valid, uint8_t *valid_out, void *stream) {
     if (!sys || n0 < 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace: null system / negative count");
     if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE)
         return fail(PRT_ERR_INVALID_ARG, "prt_trace: bad mode");
@@ -371,17 +376,17 @@ int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const d
         // 0.44 vs 0.54 ms) but not when every interface runs the iterative quartic solver
         // (biaxial: 0.60 vs 0.54 ms with the Bairstow solver), nor for many interfaces.
         if (per_surface || general_eps || n_aniso > 4)
-            return trace_general(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, valid, valid_out, st);
+            return trace_general(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, e_out, e_out_im, valid, valid_out, st);
         const dim3 grid(nblocks(n0, PRT_BLOCK)), block(PRT_BLOCK);
         const int32_t e_mode_g = e_mode_of(e0_re, 1);
         if (mode == PRT_MODE_PATH)
             hipLaunchKernelGGL((k_trace_general<PRT_MODE_PATH>), grid, block, 0, st, sys->d_table,
                                sys->n_surfaces, n_aniso, n0, x0, k0, e0_re, e0_im, e_mode_g, x_hit, k_out,
-                               valid, valid_out);
+                               e_out, e_out_im, valid, valid_out);
         else
             hipLaunchKernelGGL((k_trace_general<PRT_MODE_IMAGE>), grid, block, 0, st, sys->d_table,
                                sys->n_surfaces, n_aniso, n0, x0, k0, e0_re, e0_im, e_mode_g, x_hit, k_out,
-                               valid, valid_out);
+                               e_out, e_out_im, valid, valid_out);
         HIP_TRY(hipGetLastError());
         return PRT_OK;
     }
@@ -401,6 +406,23 @@ int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const d
                                          x_hit, k_out, valid, valid_out, vec_in, vec_out, st);
     HIP_TRY(hipGetLastError());
     return PRT_OK;
+}
+
+int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
+                  const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
+                  int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
+                  uint8_t *valid_out, void *stream) {
+    return trace_core(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out,
+                      (double *)nullptr, (double *)nullptr, valid, valid_out, stream);
+}
+
+int32_t prt_trace_fields(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,
+                         const double *e0_re, const double *e0_im, int32_t mode, double *x_hit,
+                         double *k_out, double *e_out_re, double *e_out_im, uint8_t *valid,
+                         uint8_t *valid_out, void *stream) {
+    if (!e_out_re) return fail(PRT_ERR_INVALID_ARG, "prt_trace_fields: e_out_re is NULL");
+    return trace_core(sys, n0, 0, x0, k0, e0_re, e0_im, mode, 0, x_hit, k_out, e_out_re, e_out_im, valid,
+                      valid_out, stream);
 }
 
 int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_general(
     const prt_surface_t *__restrict__ tab, int32_t S, int32_t A, int64_t N,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, double *__restrict__ xh_out,
-    double *__restrict__ k_out, uint8_t *__restrict__ valid_out_hit,
+    double *__restrict__ k_out, double *__restrict__ e_out, double *__restrict__ e_out_im,
+    uint8_t *__restrict__ valid_out_hit,
     uint8_t *__restrict__ valid_out_refr) {
     const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
     if (i >= N) return;
@@ -220,12 +221,16 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_general(
                 valid_out_hit[((MODE == PRT_MODE_PATH) ? off_in : 0) + idx_in] = valid ? 1 : 0;
             }
             int a_out = a;
-            if (sf->mat_type == PRT_MAT_ANISOTROPIC) {
+            vec3 efield = v3(0, 0, 0), efield_im = v3(0, 0, 0);
+            const bool crystal = sf->mat_type == PRT_MAT_ANISOTROPIC;
+            if (crystal) {
                 aniso_solution sol[2];
                 interact_anisotropic(sf, p, k, sol);
                 const bool second = ((L >> a) & 1) != 0;
                 k = second ? sol[1].k : sol[0].k;
                 d = second ? sol[1].d : sol[0].d;
+                efield = second ? sol[1].er : sol[0].er;
+                efield_im = second ? sol[1].ei : sol[0].ei;
                 d2 = 1.0;
                 valid = alive;  // no validity filtering at a crystal interface (ray.py:68)
                 a_out = a + 1;
@@ -242,6 +247,18 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_general(
                 ko[idx_out] = k.x;
                 ko[n_out + idx_out] = k.y;
                 ko[2 * n_out + idx_out] = k.z;
+                if (e_out && crystal) {  // E of the rays leaving a crystal interface (same layout as k_out)
+                    double *eo = e_out + ((MODE == PRT_MODE_PATH) ? 3 * off_out : 0);
+                    eo[idx_out] = efield.x;
+                    eo[n_out + idx_out] = efield.y;
+                    eo[2 * n_out + idx_out] = efield.z;
+                    if (e_out_im) {
+                        double *ei = e_out_im + ((MODE == PRT_MODE_PATH) ? 3 * off_out : 0);
+                        ei[idx_out] = efield_im.x;
+                        ei[n_out + idx_out] = efield_im.y;
+                        ei[2 * n_out + idx_out] = efield_im.z;
+                    }
+                }
                 if (valid_out_refr)
                     valid_out_refr[((MODE == PRT_MODE_PATH) ? off_out : 0) + idx_out] = valid ? 1 : 0;
             }

@@ -9,10 +9,11 @@ device-resident ``RayBundle`` / ``RayPath``.
     rpaths = dropin.seqtrace(s, initialbundle, seq)        # s: pyrateoptics OpticalSystem
     x_img = rpaths[0].raybundles[-1].x[-1]                 # reference shapes, lazily copied
 
-All-isotropic sequences only (one fused launch); sequences through ``AnisotropicMaterial`` need this
-package's material classes (``pyrate_amd.raytracer``), whose ``refract`` runs on the GPU.
+Sequences through ``AnisotropicMaterial`` are traced the same way when ``splitup`` is False (ray
+doubling in the dense path arrays); ``splitup=True`` (one RayPath per branch) needs this package's
+material classes (``pyrate_amd.raytracer``), whose ``refract`` forks on the GPU.
 """
-from .raytracer.optical_system import seqtrace_fused
+from .raytracer.optical_system import MAX_FUSED_CRYSTALS, seqtrace_fused
 from .raytracer.ray import RayBundle
 from .surface_table import UnsupportedError, flatten_sequence
 
@@ -32,8 +33,9 @@ def seqtrace(system, initialbundle, elementsequence, splitup=False, device=None)
     (records, lengths) = flatten_sequence(system, elementsequence, ib.wave)
     if not records:
         raise UnsupportedError("empty sequence")
-    if any(r["material"]["type"] != "isotropic" for r in records):
+    crystals = sum(r["material"]["type"] != "isotropic" for r in records)
+    if crystals and (splitup or crystals > MAX_FUSED_CRYSTALS or ib._dir is not None):
         if hasattr(system, "_seqtrace_generic"):
             return system._seqtrace_generic(ib, elementsequence, splitup)
-        raise UnsupportedError("sequences through anisotropic media need pyrate_amd's material classes")
+        raise UnsupportedError("splitup through anisotropic media needs pyrate_amd's material classes")
     return [seqtrace_fused(ib, records, lengths)]

@@ -83,7 +83,8 @@ class TraceResult(object):
     In image mode the lists have one entry (the last surface).
     """
 
-    def __init__(self, x_hit, k_out, valid, valid_out, n_in, n_out, mode):
+    def __init__(self, x_hit, k_out, valid, valid_out, n_in, n_out, mode, e_out=None):
+        self.e_out = e_out            # per surface (re, im) behind crystal interfaces (trace(want_fields))
         self.x_hit = x_hit
         self.k_out = k_out
         self.valid = valid
@@ -115,12 +116,17 @@ class TraceResult(object):
         for (ni, no) in zip(n_in, n_out):
             off_in.append(off_in[-1] + ni)
             off_out.append(off_out[-1] + no)
+        e_views = None
+        if bufs.get("e_re") is not None:
+            (er, ei) = (bufs["e_re"], bufs["e_im"])
+            e_views = _LazyViews(rows, lambda s: (er[3 * off_out[s]:3 * off_out[s + 1]].view(3, n_out[s]),
+                                                  ei[3 * off_out[s]:3 * off_out[s + 1]].view(3, n_out[s])))
         return cls(
             _LazyViews(rows, lambda s: bx[3 * off_in[s]:3 * off_in[s + 1]].view(3, n_in[s])),
             _LazyViews(rows, lambda s: bk[3 * off_out[s]:3 * off_out[s + 1]].view(3, n_out[s])),
             _LazyViews(rows, lambda s: bv[off_in[s]:off_in[s + 1]]),
             _LazyViews(rows, (lambda s: bw[off_out[s]:off_out[s + 1]]) if bw is not None else (lambda s: None)),
-            n_in, n_out, bufs["mode"])
+            n_in, n_out, bufs["mode"], e_out=e_views)
 
 
 class DeviceSystem(object):
@@ -159,7 +165,7 @@ class DeviceSystem(object):
         _lib.check(self.lib.prt_system_ray_counts(self._h, n0, n_in, n_out))
         return list(n_in), list(n_out)
 
-    def alloc_outputs(self, n0, mode=_lib.MODE_PATH, with_valid_out=True, pitch=None):
+    def alloc_outputs(self, n0, mode=_lib.MODE_PATH, with_valid_out=True, pitch=None, want_fields=False):
         """Output buffers for trace_into.  All-isotropic tables get ROW-PITCHED arrays
         ((S,3,pitch) / (S,pitch), pitch = prt_recommended_pitch(n0) unless given: rows aligned
         to 128-B lines are worth ~35 % HBM write bandwidth); tables with anisotropic media get
@@ -182,6 +188,11 @@ class DeviceSystem(object):
             valid=torch.empty(nv, dtype=torch.uint8, device=dev),
             valid_out=(torch.empty(nw, dtype=torch.uint8, device=dev) if with_valid_out else None),
             n_in=n_in, n_out=n_out, mode=mode, pitch=pitch)
+        if want_fields:
+            if self.all_isotropic:
+                raise ValueError("E fields are produced at crystal interfaces only")
+            bufs["e_re"] = torch.zeros(nk, dtype=torch.float64, device=dev)
+            bufs["e_im"] = torch.zeros(nk, dtype=torch.float64, device=dev)
         return bufs
 
     # -- whole sequence ----------------------------------------------------
@@ -190,6 +201,13 @@ class DeviceSystem(object):
         n0 = x0.shape[1]
         if not self.all_isotropic:      # per-surface march: tight arrays
             (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
+        if bufs.get("e_re") is not None:
+            _lib.check(self.lib.prt_trace_fields(self._h, n0, _ptr(x0), _ptr(k0), _ptr(e0_re), _ptr(e0_im),
+                                                 bufs["mode"], _ptr(bufs["x_hit"]), _ptr(bufs["k_out"]),
+                                                 _ptr(bufs["e_re"]), _ptr(bufs["e_im"]),
+                                                 _ptr(bufs["valid"]), _ptr(bufs["valid_out"]),
+                                                 _stream_handle(self.device)))
+            return
         in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
         _lib.check(self.lib.prt_trace(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
                                       _ptr(e0_im), bufs["mode"], bufs["pitch"], _ptr(bufs["x_hit"]),
@@ -221,7 +239,7 @@ class DeviceSystem(object):
                                             _stream_handle(self.device), iters, ctypes.byref(ms)))
         return ms.value
 
-    def trace(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH):
+    def trace(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH, want_fields=False):
         """OpticalSystem.seqtrace on device tensors; returns a TraceResult of views."""
         n0 = x0.shape[1]
         pitches = set()
@@ -232,7 +250,7 @@ class DeviceSystem(object):
             # mixed pitches, or the per-surface march (tight arrays): tight copies
             (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
         with torch.cuda.device(self.device):
-            bufs = self.alloc_outputs(n0, mode)
+            bufs = self.alloc_outputs(n0, mode, want_fields=want_fields)
             self.trace_into(x0, k0, bufs, e0_re, e0_im)
         return self.views(bufs)
 

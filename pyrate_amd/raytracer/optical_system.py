@@ -3,14 +3,15 @@
 (raytracer/optical_system.py:42-94).
 
 ``seqtrace(initialbundle, elementsequence, splitup=False) -> list[RayPath]``:
-* all-isotropic sequence: the whole sequence is flattened into one surface table and
-  traced by ONE fused HIP launch (prt_trace, path mode).  The returned RayBundles are
-  lazily compacted views into the dense device arrays (see ray.py) and reproduce the
-  reference's bundle structure, including the bundle that appears twice at every element
-  boundary (optical_element.py:330, ray.py:218-219).
-* sequences through anisotropic media (ray doubling, ``splitup`` forking, E fields):
-  the reference's own element / surface loops run on top of the per-surface HIP entry
-  points (optical_element.py).
+* the whole sequence is flattened into one surface table and traced by ONE engine call
+  (prt_trace, path mode; prt_trace_fields when the sequence crosses anisotropic media, whose
+  interfaces double the ray count).  The returned RayBundles are lazily compacted views into
+  the dense device arrays (see ray.py) and reproduce the reference's bundle structure,
+  including the bundle that appears twice at every element boundary
+  (optical_element.py:330, ray.py:218-219).
+* ``splitup=True`` through anisotropic media (one RayPath per branch) and bundles that
+  already carry invalid rays: the reference's own element / surface loops run on top of the
+  per-surface HIP entry points (optical_element.py).
 """
 import torch
 
@@ -53,8 +54,9 @@ class OpticalSystem(LocalCoordinatesTreeBase):
         # e.g. [("elem1", [("surf1", {}), ("surf2", {"is_mirror": True})]), ("elem2", [...])]
         (records, lengths) = flatten_sequence(self, elementsequence, initialbundle.wave)
         initialbundle._ensure()
-        fused_ok = all(r["material"]["type"] == "isotropic" for r in records) \
-            and initialbundle._dir is None and len(records) > 0
+        crystals = sum(r["material"]["type"] == "anisotropic" for r in records)
+        fused_ok = initialbundle._dir is None and len(records) > 0 \
+            and (crystals == 0 or (not splitup and crystals <= MAX_FUSED_CRYSTALS))
         if fused_ok and len(initialbundle._valid) > 1 and not bool(initialbundle._valid[-1].all()):
             fused_ok = False      # a bundle that already carries invalid rays: per-surface path
         if fused_ok:
@@ -80,30 +82,24 @@ class OpticalSystem(LocalCoordinatesTreeBase):
         return seqtrace_fused(ib, records, lengths)
 
 
+MAX_FUSED_CRYSTALS = 6      # 2**6 rays per initial ray in the dense path arrays
+
+
 def seqtrace_fused(ib, records, lengths):
-    """One fused launch for an all-isotropic flattened sequence -> RayPath with the reference's
-    bundle structure (lazy, device-resident).  Needs only the surface-table records, so it
-    serves any object graph ``flatten_sequence`` understands (this package's classes or real
-    pyrateoptics objects, see pyrate_amd/dropin.py)."""
+    """One engine trace (prt_trace / prt_trace_fields) for a flattened sequence -> RayPath with
+    the reference's bundle structure (lazy, device-resident).  Needs only the surface-table
+    records, so it serves any object graph ``flatten_sequence`` understands (this package's
+    classes or real pyrateoptics objects, see pyrate_amd/dropin.py)."""
+    if any(r["material"]["type"] == "anisotropic" for r in records):
+        return _seqtrace_fused_crystal(ib, records, lengths)
     dev = ib.device
     sysd = _dispatch.system_for(records, dev)
     S = len(records)
     x0 = ib._x[-1]
     k0 = ib._k[-1]
-    (e_re, e_im) = (None, None)
-    if ib._dir_from_k:
-        e_re = engine.efield_perp(k0)          # E perpendicular to k: Poynting direction = k/|k|
-    elif ib._e[-1] is not None:
-        (e_re, e_im) = ib._e[-1]
+    (e_re, e_im) = _initial_fields(ib, k0)
     res = sysd.trace(x0, k0, e_re, e_im, mode=_lib.MODE_PATH)
-    n = x0.shape[1]
-    if ib._ray_id is None:
-        ids0 = torch.arange(n, dtype=torch.int64, device=dev)
-    elif isinstance(ib._ray_id, torch.Tensor):
-        ids0 = ib._ray_id.to(dev)
-    else:
-        import numpy as np
-        ids0 = torch.from_numpy(np.ascontiguousarray(ib._ray_id, dtype=np.int64)).to(dev)
+    ids0 = _ids_on_device(ib, x0.shape[1], dev)
     wave = ib.wave
     kc = ib._k_complex
 
@@ -138,6 +134,10 @@ def seqtrace_fused(ib, records, lengths):
         return thunk
 
     bundles = [b0] + [RayBundle._lazy(make_thunk(j), wave, dev) for j in range(1, S + 1)]
+    return _assemble_path(bundles, lengths, res)
+
+
+def _assemble_path(bundles, lengths, res):
     path = RayPath(bundles[0])
     idx = 0
     for L in lengths:
@@ -147,3 +147,95 @@ def seqtrace_fused(ib, records, lengths):
         idx += L
     path.dense = res                                  # dense device arrays for GPU consumers
     return path
+
+
+def _initial_fields(ib, k0):
+    if ib._dir_from_k:
+        return engine.efield_perp(k0), None    # E perpendicular to k: Poynting direction = k/|k|
+    if ib._e[-1] is not None:
+        return ib._e[-1]
+    return None, None
+
+
+def _ids_on_device(ib, n, dev):
+    if ib._ray_id is None:
+        return torch.arange(n, dtype=torch.int64, device=dev)
+    if isinstance(ib._ray_id, torch.Tensor):
+        return ib._ray_id.to(dev)
+    import numpy as np
+    return torch.from_numpy(np.ascontiguousarray(ib._ray_id, dtype=np.int64)).to(dev)
+
+
+def _seqtrace_fused_crystal(ib, records, lengths):
+    """Sequences through anisotropic media without ``splitup``: one engine trace in the
+    concatenated dense layout (ray count doubles behind every crystal interface, [sol2, sol3]
+    stacking), E of the doubled rays from prt_trace_fields.  Bundle j is carved lazily out of
+    the dense arrays of surface j-1: the rays the reference still carries there are the dense
+    slots with ``valid_out`` set (behind a crystal interface: every ray that was not compacted
+    away earlier, since AnisotropicMaterial.refract keeps all rays and restarts validity,
+    material_anisotropic.py:91-99; behind an isotropic one: the valid rays,
+    material_isotropic.py:194-199)."""
+    dev = ib.device
+    sysd = _dispatch.system_for(records, dev)
+    S = len(records)
+    x0 = ib._x[-1]
+    k0 = ib._k[-1]
+    (e_re, e_im) = _initial_fields(ib, k0)
+    res = sysd.trace(x0, k0, e_re, e_im, mode=_lib.MODE_PATH, want_fields=True)
+    n = x0.shape[1]
+    wave = ib.wave
+    crystal = [r["material"]["type"] == "anisotropic" for r in records]
+    first_crystal = crystal.index(True)
+    ids_cache = {0: _ids_on_device(ib, n, dev)}
+
+    def dense_ids(level):
+        # ids of the dense slots after ``level`` doublings: [ids, ids] per crystal interface
+        if level not in ids_cache:
+            prev = dense_ids(level - 1)
+            ids_cache[level] = torch.cat((prev, prev))
+        return ids_cache[level]
+
+    b0 = ib.clone()
+    b0._append_device(res.x_hit[0], res.valid[0] * ib._valid[-1])
+
+    def make_thunk(j):
+        s = j - 1
+        level = sum(crystal[:s + 1])
+
+        def thunk(b):
+            mask = res.valid_out[s]
+            xs = res.x_hit[s]
+            if crystal[s]:
+                xs = torch.cat((xs, xs), dim=1)
+            arrays = [xs, res.k_out[s]]
+            if crystal[s]:
+                arrays += list(res.e_out[s])
+            flags = None
+            if j < S:
+                arrays.append(res.x_hit[j])
+                flags = res.valid[j]
+            out = engine.compact(mask, arrays, dense_ids(level), flags)
+            arr = out[0]
+            (cx, ck) = (arr[0], arr[1])
+            e = (arr[2], arr[3]) if crystal[s] else None
+            m = cx.shape[1]
+            b._x = [cx]
+            b._k = [ck]
+            b._valid = [torch.ones(m, dtype=torch.uint8, device=dev)]
+            b._e = [e]
+            if j < S:
+                b._x.append(arr[-1])
+                b._k.append(ck)
+                b._valid.append(out[2])
+                b._e.append(e)
+            b._ray_id = out[1]
+            b._n = m
+            b._k_complex = True if s >= first_crystal else ib._k_complex
+        return thunk
+
+    bundles = [b0]
+    for j in range(1, S + 1):
+        b = RayBundle._lazy(make_thunk(j), wave, dev, splitted=crystal[j - 1])
+        b._dir_from_k = not crystal[j - 1]
+        bundles.append(b)
+    return _assemble_path(bundles, lengths, res)

@@ -133,6 +133,27 @@ def test_seqtrace_anisotropic(api, name, which, stop):
     assert np.nanmax(np.abs(res)) < 1e-12
 
 
+@pytest.mark.parametrize("which,stop", [("isoeps", None), ("uni", None), ("uni", 8.0)])
+def test_seqtrace_anisotropic_dense_path_equals_plugin_path(api, which, stop):
+    """one engine trace + lazily carved bundles == the per-surface propagate / refract loop"""
+    case = _golden.load_case("aniso_doublet_uniaxial_stopped" if stop else "aniso_doublet_uniaxial_clipped")
+    (s, seq) = aniso_system(api, which, stop)
+    dense = s.seqtrace(bundle_of(api, case), seq)[0]
+    assert dense.dense is not None and dense.dense.e_out is not None
+    plugin = s._seqtrace_generic(bundle_of(api, case), seq, False)[0]
+    assert len(dense.raybundles) == len(plugin.raybundles)
+    for (a, b) in zip(dense.raybundles, plugin.raybundles):
+        assert a.splitted == b.splitted
+        assert np.array_equal(a.rayID, b.rayID)
+        assert np.array_equal(a.valid, b.valid)
+        assert a.k.dtype == b.k.dtype
+        assert np.allclose(a.x, b.x, rtol=0, atol=1e-12, equal_nan=True)
+        assert np.allclose(a.k, b.k, rtol=0, atol=1e-13, equal_nan=True)
+        if a.splitted:
+            assert np.allclose(a.Efield, b.Efield, rtol=0, atol=1e-12, equal_nan=True)
+            assert np.allclose(a.returnKtoD(), b.returnKtoD(), rtol=0, atol=1e-12, equal_nan=True)
+
+
 def test_seqtrace_anisotropic_splitup_forks_four_paths(api):
     case = _golden.load_case("aniso_doublet_uniaxial_split")
     (s, seq) = aniso_system(api, "uni")
