@@ -207,6 +207,18 @@ def case_aniso():
     dump_case("aniso_doublet_biaxial", s, seq, disk_bundle(60, 11.43, -5.0, field_deg=-2.0))
 
 
+def case_aniso_mirror():
+    # reflection inside a crystal (two doublings: refraction into the slab, mirror at its rear face),
+    # then refraction out into the isotropic background
+    c = systems.CALCITE_TILTED
+    eps = systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"])
+    (s, seq) = zoo.crystal_mirror(REFAPI, eps)
+    dump_case("aniso_mirror_uniaxial", s, seq, disk_bundle(60, 4.0, -5.0, field_deg=3.0))
+    dump_case("aniso_mirror_uniaxial_split", s, seq, disk_bundle(30, 4.0, -5.0), splitup=True)
+    (s, seq) = zoo.crystal_mirror(REFAPI, biaxial_eps(), tilt_deg=7.0)
+    dump_case("aniso_mirror_biaxial", s, seq, disk_bundle(60, 4.0, -5.0, field_deg=-2.0))
+
+
 DISPERSION_PAGES = {
     # public catalogue coefficients (SCHOTT N-BK7 Sellmeier; the others are synthetic pages that
     # exercise every formula type of raytracer/material/material_glasscat.py:318-446)
@@ -258,6 +270,7 @@ def main():
     case_hud()
     case_two_elements()
     case_aniso()
+    case_aniso_mirror()
     case_dispersion()
 
 

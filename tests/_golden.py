@@ -24,7 +24,8 @@ EXPLICIT_CASES = ["asphere_mild_axis", "asphere_mild_field5", "asphere_strong_ax
                   "asphere_strong_field5", "xypoly_axis", "xypoly_field5", "biconic_axis",
                   "biconic_field5", "hud_biconic_mirrors"]
 ANISO_CASES = ["aniso_doublet_isoeps", "aniso_doublet_uniaxial", "aniso_doublet_biaxial",
-               "aniso_doublet_uniaxial_clipped", "aniso_doublet_uniaxial_stopped"]
+               "aniso_doublet_uniaxial_clipped", "aniso_doublet_uniaxial_stopped",
+               "aniso_mirror_uniaxial", "aniso_mirror_biaxial"]
 ALL_CASES = ISO_CASES + EXPLICIT_CASES + ANISO_CASES
 
 

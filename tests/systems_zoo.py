@@ -94,6 +94,35 @@ def aniso_doublet(api, eps1, eps2, stop_radius=None):
                    lambda lc: api.AnisotropicMaterial.p(lc, eps2, name="crystal2"), stop_radius)
 
 
+def crystal_mirror(api, eps, tilt_deg=10.0):
+    """crystal slab whose rear face is a mirror INSIDE the crystal (reflection in an anisotropic
+    medium: the two backward solutions, material_anisotropic.py:115-155); the folded beam leaves
+    the crystal into the background at a tilted exit plane.  Geometry after
+    demos/demo_anisotropic_mirror.py (flat faces, 10 deg tilts)."""
+    t = tilt_deg * math.pi / 180.
+    s = api.OpticalSystem.p()
+    lc0 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="stop", decz=1.0),
+                                     refname=s.rootcoordinatesystem.name)
+    lc1 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="front", decz=10.0), refname=lc0.name)
+    lc2 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="rear", decz=5.0, tiltx=t),
+                                     refname=lc1.name)
+    lc3 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="exit", decz=-5.0, tiltx=-t),
+                                     refname=lc2.name)
+    elem = api.OpticalElement.p(lc0, name="slab")
+    elem.addMaterial("crystal", api.AnisotropicMaterial.p(lc1, eps, name="crystal"))
+    elem.addSurface("stop", api.Surface.p(lc0), (None, None))
+    elem.addSurface("front", api.Surface.p(lc1, shape=api.Conic.p(lc1, curv=0.0),
+                                           aperture=api.CircularAperture.p(lc1, maxradius=10.0)),
+                    (None, "crystal"))
+    elem.addSurface("rear", api.Surface.p(lc2, shape=api.Conic.p(lc2, curv=0.0),
+                                          aperture=api.CircularAperture.p(lc2, maxradius=10.0)),
+                    ("crystal", "crystal"))
+    elem.addSurface("exit", api.Surface.p(lc3), ("crystal", None))
+    s.addElement("slab", elem)
+    seq = [("slab", [("stop", {}), ("front", {}), ("rear", {"is_mirror": True}), ("exit", {})])]
+    return (s, seq)
+
+
 def tilted(api):
     """decentred / tilted frames (both tilt orders), a tilted material frame, a rectangular
     aperture in its own rotated frame, an annular circular aperture, a ModelGlass."""

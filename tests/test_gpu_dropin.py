@@ -154,6 +154,28 @@ def test_seqtrace_anisotropic_dense_path_equals_plugin_path(api, which, stop):
             assert np.allclose(a.returnKtoD(), b.returnKtoD(), rtol=0, atol=1e-12, equal_nan=True)
 
 
+@pytest.mark.parametrize("name,tilt", [("aniso_mirror_uniaxial", 10.0), ("aniso_mirror_biaxial", 7.0)])
+def test_seqtrace_crystal_mirror(api, name, tilt):
+    """reflection inside a crystal (backward solution pair), dense path and plugin path"""
+    case = _golden.load_case(name)
+    eps = np.asarray(case.table[1]["material"]["eps_re"])
+    (s, seq) = zoo.crystal_mirror(api, eps, tilt_deg=tilt)
+    rp = s.seqtrace(bundle_of(api, case), seq)
+    assert len(rp) == 1 and rp[0].raybundles[-1].num_rays == 4 * case.x0.shape[1]
+    assert_paths_match(rp[0], case.raw_bundles)
+    assert_paths_match(s._seqtrace_generic(bundle_of(api, case), seq, False)[0], case.raw_bundles)
+
+
+def test_seqtrace_crystal_mirror_splitup(api):
+    case = _golden.load_case("aniso_mirror_uniaxial_split")
+    eps = np.asarray(case.table[1]["material"]["eps_re"])
+    (s, seq) = zoo.crystal_mirror(api, eps)
+    rpaths = s.seqtrace(bundle_of(api, case), seq, splitup=True)
+    assert len(rpaths) == case.npaths == 4
+    for (rp, ref) in zip(rpaths, _raw_paths(case)):
+        assert_paths_match(rp, ref)
+
+
 def test_seqtrace_anisotropic_splitup_forks_four_paths(api):
     case = _golden.load_case("aniso_doublet_uniaxial_split")
     (s, seq) = aniso_system(api, "uni")
