@@ -113,12 +113,20 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: dry run of the multi-rank path on ONE GPU (all ranks share cuda:0, "
                          "the gather is staged through host memory); not a measurement")
+    ap.add_argument("--force-multi", action="store_true",
+                    help="run the N>1 code path (5 wavelengths, side-stream all-reduces, final all-gather) "
+                         "with whatever world size there is, also 1: RCCL smoke test on a 1-GPU box")
     args = ap.parse_args()
+    if args.force_multi:
+        os.environ["PRT_FORCE_COLLECTIVES"] = "1"
+        for (k, v) in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29512")):
+            os.environ.setdefault(k, v)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_multi
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
@@ -127,7 +135,7 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -142,7 +150,7 @@ def main():
     # through the (d, F, C) indices; step i traces wavelength i % 5.
     records = systems.double_gauss_records()
     S = len(records)
-    if world > 1:
+    if use_dist:
         record_sets = [systems.double_gauss_records(w) for w in systems.DOUBLE_GAUSS_WAVES_MM]
     else:
         record_sets = [records]
@@ -156,7 +164,7 @@ def main():
     sysds = [engine.DeviceSystem(r, local_rank) for r in record_sets]
     sysd = sysds[0]
     mode = _lib.MODE_PATH if args.mode == "path" else _lib.MODE_IMAGE
-    multi = n_gpus > 1
+    multi = use_dist
     # N > 1 (BASELINE configs[4]): every step ends with the device-side image-plane spot
     # statistics of the sharded bundle (two 7-double all-reduces instead of moving the image
     # plane), issued on a side stream so that they overlap the next step's
@@ -216,7 +224,7 @@ def main():
         torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     # device wake-up (not one of the W warm-up steps): after idle the first ~25 ms of launches run
@@ -239,7 +247,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=(dev if args.backend == "nccl" else "cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -318,7 +326,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -7,8 +7,18 @@ gather: every rank contributes (x_img, k_img) (6, n) float64 + valid (n) uint8
 ``torch.distributed`` backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU
 tests).  rayIDs are implicit: rank r owns ``shard_range(N, r, world)``.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _collectives_needed(group=None):
+    """more than one rank -- or PRT_FORCE_COLLECTIVES=1 with an initialised process group, which
+    sends the single-rank case through the collectives too (RCCL smoke test on a 1-GPU box)"""
+    if not dist.is_initialized():
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("PRT_FORCE_COLLECTIVES", "0") == "1"
 
 
 def shard_range(n_total, rank, world):
@@ -60,7 +70,7 @@ class ImagePlaneGather(object):
         self.send_v[:n].copy_(valid, non_blocking=True)
         if self.stage_on_host and x_img.is_cuda:
             torch.cuda.current_stream(x_img.device).synchronize()     # D2H staging complete
-        if self.world == 1:
+        if not _collectives_needed(self.group):
             self.recv_f[0].copy_(self.send_f, non_blocking=True)
             self.recv_v[0].copy_(self.send_v, non_blocking=True)
             self._work = []
@@ -100,7 +110,7 @@ def global_spot_statistics(x_img, valid=None, group=None, moments_fn=None):
     dev = x_img.device
 
     def allreduce(vec):
-        if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        if not _collectives_needed(group):
             return vec
         t = torch.tensor(vec, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -127,7 +137,7 @@ class SpotStatistics(object):
         self.engine = engine
         self.group = group
         self.ws = engine.MomentsWorkspace(device, n_results=2)
-        self.multi = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.multi = _collectives_needed(group)
 
     def start(self, x_img, valid):
         eng = self.engine
