@@ -219,6 +219,25 @@ def case_aniso_mirror():
     dump_case("aniso_mirror_biaxial", s, seq, disk_bundle(60, 4.0, -5.0, field_deg=-2.0))
 
 
+def case_zmx():
+    """tests/lenssystem.ZMX of the reference (a data file its smoke test holds, smoke_test.py:105)
+    through the reference's ZMXParser: 13 even aspheres / planes, two coordinate breaks, BK7 given
+    as a ConstantIndexGlass.  The file itself is committed beside the vectors as the input fixture."""
+    import shutil
+    from pyrateoptics.raytracer.io.zmx import ZMXParser
+    src = os.path.join(REF, "tests", "lenssystem.ZMX")
+    dst = os.path.join(OUT, "lenssystem.ZMX")
+    shutil.copyfile(src, dst)
+    zp = ZMXParser(dst, name="ZMXParser")
+    lctmp = LocalCoordinates.p("tmp")
+    (s, seq) = zp.create_optical_system({"BK7": ConstantIndexGlass.p(lctmp, 1.5168)})
+    dump_case("zmx_lenssystem", s, seq, disk_bundle(100, 7.0, 0.0, field_deg=1.0, wave=0.55e-3))
+    with open(os.path.join(OUT, "zmx_lenssystem_field.json"), "w") as f:
+        fd = zp.read_field()
+        json.dump({"field": fd, "bundles": zp.create_initial_bundle(),
+                   "name_notes": list(zp.read_name_and_notes())}, f, indent=1)
+
+
 DISPERSION_PAGES = {
     # public catalogue coefficients (SCHOTT N-BK7 Sellmeier; the others are synthetic pages that
     # exercise every formula type of raytracer/material/material_glasscat.py:318-446)
@@ -271,6 +290,7 @@ def main():
     case_two_elements()
     case_aniso()
     case_aniso_mirror()
+    case_zmx()
     case_dispersion()
 
 

@@ -22,7 +22,7 @@ ISO_CASES = ["doublet", "doublet_clipped", "double_gauss_axis", "double_gauss_fi
              "tilted_frames", "mirrors", "two_elements"]
 EXPLICIT_CASES = ["asphere_mild_axis", "asphere_mild_field5", "asphere_strong_axis",
                   "asphere_strong_field5", "xypoly_axis", "xypoly_field5", "biconic_axis",
-                  "biconic_field5", "hud_biconic_mirrors"]
+                  "biconic_field5", "hud_biconic_mirrors", "zmx_lenssystem"]
 ANISO_CASES = ["aniso_doublet_isoeps", "aniso_doublet_uniaxial", "aniso_doublet_biaxial",
                "aniso_doublet_uniaxial_clipped", "aniso_doublet_uniaxial_stopped",
                "aniso_mirror_uniaxial", "aniso_mirror_biaxial"]

@@ -92,6 +92,18 @@ def test_seqtrace_explicit_shape(api):
     assert_paths_match(rpaths[0], case.raw_bundles, loose_x=1e-9)
 
 
+def test_seqtrace_of_imported_zmx_prescription(api):
+    """lenssystem.ZMX (the reference's own test file) -> this package's ZMXParser -> seqtrace:
+    bundle by bundle what the reference's parser + trace returned"""
+    import os
+    from pyrate_amd.raytracer.io.zmx import ZMXParser
+    case = _golden.load_case("zmx_lenssystem")
+    zp = ZMXParser(os.path.join(_golden.GOLDEN_DIR, "lenssystem.ZMX"))
+    (s, seq) = zp.create_optical_system({"BK7": api.ConstantIndexGlass.p(api.LocalCoordinates.p(name="t"), 1.5168)})
+    rpaths = s.seqtrace(bundle_of(api, case), seq)
+    assert_paths_match(rpaths[0], case.raw_bundles, loose_x=1e-8)    # 13 fsolve surfaces in a row
+
+
 def test_plugin_granular_path_matches_fused(api):
     """OpticalElement.seqtrace (Material.propagate / refract per surface + device compaction)
     gives the same RayPath as the fused launch"""
