@@ -276,6 +276,40 @@ def case_dispersion():
     print("dispersion.json: %d pages x %d wavelengths" % (len(DISPERSION_PAGES), len(waves_mm)))
 
 
+def case_glasscatalog():
+    """the reference's GlassCatalog browsing a miniature database (tests/systems_zoo.py writes it
+    from the dispersion pages above): index structure, name searches, n of catalogue materials,
+    and a system built from glass NAMES through material_db_path"""
+    import tempfile
+    from pyrateoptics import build_rotationally_symmetric_optical_system
+    from pyrateoptics.raytracer.material.material_glasscat import GlassCatalog
+    with tempfile.TemporaryDirectory() as tmp:
+        names = zoo.write_mini_glass_database(tmp, DISPERSION_PAGES)
+        gcat = GlassCatalog(tmp)
+        lc = LocalCoordinates.p(name="gc")
+        out = {"names": names, "shelves": gcat.get_shelves(),
+               "books": {sh: gcat.get_books(sh) for sh in gcat.get_shelves()},
+               "pages": {sh: {b: gcat.get_pages(sh, b) for b in gcat.get_books(sh)} for sh in gcat.get_shelves()},
+               "long_names": {k: list(v) for (k, v) in gcat.get_dict_of_long_names().items()},
+               "find_FORMULA4": sorted(gcat.find_pages_with_long_name("FORMULA4").keys()),
+               "n_dline": {key: float(np.real(gcat.create_material_from_long_name(lc, names[key])
+                                              .get_optical_index(None, DLINE))) for key in names}}
+        try:
+            gcat.material_dict_from_long_name("FORMULA")
+        except Exception as err:
+            out["error_similar"] = str(err)
+        try:
+            gcat.material_dict_from_long_name("no such glass")
+        except Exception as err:
+            out["error_none"] = str(err)
+        tuples = zoo.catalog_doublet_tuples(names)
+        (s, seq) = build_rotationally_symmetric_optical_system(tuples, material_db_path=tmp)
+        dump_case("catalog_doublet", s, seq, disk_bundle(80, 9.0, -5.0, field_deg=2.0, wave=0.6563e-3))
+    with open(os.path.join(OUT, "glasscatalog.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("glasscatalog.json: %d pages" % len(names))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     np.random.seed(0)
@@ -292,6 +326,7 @@ def main():
     case_aniso_mirror()
     case_zmx()
     case_dispersion()
+    case_glasscatalog()
 
 
 if __name__ == "__main__":

@@ -2,8 +2,8 @@
 (pyrateoptics/__init__.py:83-258): build_rotationally_symmetric_optical_system,
 build_simple_optical_element, build_simple_optical_system.  Materials may be None
 (background), a number (ConstantIndexGlass), a dict {"eps": 3x3}
-(AnisotropicMaterial) or a ready Material object; the refractiveindex.info catalogue
-is out of scope (SURVEY.md section 2 #7b)."""
+(AnisotropicMaterial), a refractiveindex.info page dictionary, a ready Material object, or a
+glass name looked up in the database under ``material_db_path`` (GlassCatalog)."""
 import numpy as np
 
 from .raytracer.globalconstants import numerical_tolerance
@@ -30,6 +30,7 @@ def build_simple_optical_element(lc0, builduplist, material_db_path="", name="")
     elem = OpticalElement.p(lc0, name=name)
     refname = lc0.name
     lastmat = None
+    gcat = None
     surflist_for_sequence = []
     for (surfdict, coordbreakdict, mat, surf_name, optdict) in builduplist:
         surfdict = dict(surfdict)
@@ -60,10 +61,16 @@ def build_simple_optical_element(lc0, builduplist, material_db_path="", name="")
                 try:
                     n = float(mat)
                 except (ValueError, TypeError):
-                    raise Exception("glass catalogue materials (%r) are out of scope; pass an index "
-                                    "or a Material object" % (mat,))
-                mat = "constantindexglass_" + str(mat)
-                elem.addMaterial(mat, ConstantIndexGlass.p(lc, n=n))
+                    if not isinstance(mat, str):
+                        raise Exception("material %r: pass an index, a glass name, a page dictionary "
+                                        "or a Material object" % (mat,))
+                    if gcat is None:
+                        from .raytracer.material.material_glasscat import GlassCatalog
+                        gcat = GlassCatalog(material_db_path)
+                    elem.addMaterial(mat, gcat.create_material_from_long_name(lc, mat))
+                else:
+                    mat = "constantindexglass_" + str(mat)
+                    elem.addMaterial(mat, ConstantIndexGlass.p(lc, n=n))
         elem.addSurface(surf_name, actsurf, (lastmat, mat))
         lastmat = mat
         refname = lc.name

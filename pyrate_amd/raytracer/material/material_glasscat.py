@@ -1,13 +1,16 @@
 """``CatalogMaterial``: isotropic medium described by one page of the refractiveindex.info
 database, given as the page's dictionary (reference: raytracer/material/material_glasscat.py:290-529).
 Only the scalar dispersion n(wavelength) is needed -- it enters the trace as one number per
-(material, bundle) -- so this is host-side arithmetic; the database files themselves and the
-catalogue browser (``GlassCatalog``) are out of scope (the database submodule is not part of the
-reference checkout).
+(material, bundle) -- so this is host-side arithmetic.  ``GlassCatalog`` is the browser of a
+refractiveindex.info database checkout (``library.yml`` + ``data/*.yml``; reference :36-287); the
+database itself is an un-vendored submodule of the reference, so the tests build a miniature
+database with the same file structure.
 
 Dispersion formulas follow the refractiveindex.info definitions (wavelength in micrometres):
 formula 1 Sellmeier, 2 Sellmeier-2, 3 polynomial, 4 RefractiveIndex.INFO, 5 Cauchy, 6 gases,
 7 Herzberger, and "tabulated n" (linear interpolation)."""
+import os
+
 import numpy as np
 
 from .material_isotropic import IsotropicMaterial
@@ -38,6 +41,90 @@ def _n_formula(typ, c, w):
         a = c[3:]
         return c[0] + c[1] / den + c[2] / den ** 2 + np.sum(a * w ** (2 * np.arange(len(a)) + 2))
     raise Exception("Bad dispersion function type: " + str(typ))
+
+
+class GlassCatalog(object):
+    """shelf -> book -> page index of a refractiveindex.info database directory"""
+
+    def __init__(self, database_basepath, name=""):
+        self.name = name
+        self.database_basepath = database_basepath
+        self.librarydict = self.read_library(os.path.join(database_basepath, "library.yml"))
+
+    @staticmethod
+    def read_yml_file(ymlfilename):
+        """parsed YAML of the file, [] when it cannot be opened (reference :64-78)"""
+        import yaml
+        try:
+            with open(ymlfilename, "r") as fh:
+                return yaml.safe_load(fh)
+        except IOError:
+            return []
+
+    @staticmethod
+    def _index(entries, key):
+        """list of dicts -> dict keyed by entry[key]; entries without the key (DIVIDER rows) are
+        dropped"""
+        out = {}
+        for entry in entries or []:
+            if key in entry:
+                entry = dict(entry)
+                out[entry.pop(key)] = entry
+        return out
+
+    def read_library(self, library_yml_filename):
+        lib = self._index(self.read_yml_file(library_yml_filename), "SHELF")
+        for shelf in lib.values():
+            shelf["content"] = self._index(shelf.get("content"), "BOOK")
+            for book in shelf["content"].values():
+                book["content"] = self._index(book.get("content"), "PAGE")
+        return lib
+
+    # -- browsing ------------------------------------------------------------------
+    def get_shelves(self):
+        return list(self.librarydict.keys())
+
+    def get_books(self, shelf):
+        return list(self.librarydict[shelf]["content"].keys())
+
+    def get_pages(self, shelf, book):
+        return list(self.librarydict[shelf]["content"][book]["content"].keys())
+
+    def get_page_long_name(self, shelf, book, page):
+        return self.librarydict[shelf]["content"][book]["content"][page]["name"]
+
+    def get_dict_of_long_names(self):
+        """{long glass name: (shelf, book, page)}; of two pages with one name the later wins"""
+        out = {}
+        for shelf in self.get_shelves():
+            for book in self.get_books(shelf):
+                for page in self.get_pages(shelf, book):
+                    out[self.get_page_long_name(shelf, book, page)] = (shelf, book, page)
+        return out
+
+    def find_pages_with_long_name(self, searchterm):
+        return {name: where for (name, where) in self.get_dict_of_long_names().items()
+                if name.find(searchterm) != -1}
+
+    # -- pages -----------------------------------------------------------------------
+    def get_material_dict(self, shelf, book, page):
+        entry = self.librarydict[shelf]["content"][book]["content"][page]
+        return self.read_yml_file(os.path.join(self.database_basepath, "data", entry["data"]))
+
+    def material_dict_from_long_name(self, glass_name):
+        allpages = self.get_dict_of_long_names()
+        if glass_name not in allpages:
+            msg = "glass name " + str(glass_name) + " not found."
+            similar = self.find_pages_with_long_name(glass_name)
+            if similar:
+                msg += " Did you mean: " + str(list(similar.keys()))
+            else:
+                msg += " No glass names containing this string found."
+            raise Exception(msg)
+        return self.get_material_dict(*allpages[glass_name])
+
+    def create_material_from_long_name(self, localcoordinates, glass_name):
+        return CatalogMaterial.p(localcoordinates, self.material_dict_from_long_name(glass_name))
 
 
 class CatalogMaterial(IsotropicMaterial):

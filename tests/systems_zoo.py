@@ -230,3 +230,45 @@ def two_element_system(api):
     s.addElement("e2", e2)
     seq = [("e1", [("a", {}), ("b", {})]), ("e2", [("c", {}), ("d", {}), ("img", {})])]
     return (s, seq)
+
+
+def write_mini_glass_database(basepath, pages):
+    """A miniature refractiveindex.info checkout (library.yml + data/<shelf>/<book>/<page>.yml) built
+    from page dictionaries ``{key: page}``: shelves / books / pages / DIVIDER rows like the real
+    library file, long names "<KEY> (TEST)".  Returns {key: long name}."""
+    import os
+    import yaml
+    keys = sorted(pages.keys())
+    names = {}
+    shelves = [{"SHELF": "glass", "name": "GLASS - glasses", "content": [{"DIVIDER": "Test glasses"}]},
+               {"SHELF": "other", "name": "OTHER - miscellaneous", "content": []}]
+    for (i, key) in enumerate(keys):
+        shelf = shelves[0] if i % 3 != 2 else shelves[1]
+        book = key.split("_")[0]
+        rel = "%s/%s/%s.yml" % (shelf["SHELF"], book, key)
+        names[key] = "%s (TEST)" % key.upper()
+        entry = {"PAGE": key, "name": names[key], "data": rel}
+        for b in shelf["content"]:
+            if b.get("BOOK") == book:
+                b["content"].append(entry)
+                break
+        else:
+            shelf["content"].append({"BOOK": book, "name": book.upper(),
+                                     "content": [{"DIVIDER": "pages"}, entry]})
+        full = os.path.join(basepath, "data", rel)
+        os.makedirs(os.path.dirname(full), exist_ok=True)
+        with open(full, "w") as f:
+            yaml.safe_dump(pages[key], f)
+    with open(os.path.join(basepath, "library.yml"), "w") as f:
+        yaml.safe_dump(shelves, f)
+    return names
+
+
+def catalog_doublet_tuples(names):
+    """cemented doublet whose two glasses are given by catalogue NAME (resolved through
+    material_db_path, pyrateoptics/__init__.py:183-196)"""
+    return [(0.0, 0.0, 0.0, None, "stop", {"is_stop": True}),
+            (62.8, 0.0, 3.0, names["formula1_nbk7"], "front", {}),
+            (-45.7, 0.0, 4.0, names["formula2"], "cement", {}),
+            (-128.2, 0.0, 2.5, None, "rear", {}),
+            (0.0, 0.0, 97.2, None, "image", {})]

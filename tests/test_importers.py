@@ -83,3 +83,47 @@ def test_zmx_text_variants(api, tmp_path):
     f.write_text(text.replace("TYPE BICONICX", "TYPE GRID_SAG"))
     with pytest.raises(UnsupportedError):
         zmx.ZMXParser(str(f)).create_optical_system()
+
+
+# ---- refractiveindex.info catalogue browser ------------------------------------------------
+@pytest.fixture(scope="module")
+def minidb(tmp_path_factory):
+    pages = json.load(open(os.path.join(_golden.GOLDEN_DIR, "dispersion.json")))["pages"]
+    tmp = str(tmp_path_factory.mktemp("rii_db"))
+    return (tmp, zoo.write_mini_glass_database(tmp, pages))
+
+
+def test_glass_catalog_equals_reference_browser(api, minidb):
+    from pyrate_amd.raytracer.material.material_glasscat import GlassCatalog
+    (tmp, names) = minidb
+    ref = json.load(open(os.path.join(_golden.GOLDEN_DIR, "glasscatalog.json")))
+    assert names == ref["names"]
+    gcat = GlassCatalog(tmp)
+    assert gcat.get_shelves() == ref["shelves"]
+    assert {sh: gcat.get_books(sh) for sh in gcat.get_shelves()} == ref["books"]
+    assert {sh: {b: gcat.get_pages(sh, b) for b in gcat.get_books(sh)} for sh in gcat.get_shelves()} == ref["pages"]
+    assert {k: list(v) for (k, v) in gcat.get_dict_of_long_names().items()} == ref["long_names"]
+    assert sorted(gcat.find_pages_with_long_name("FORMULA4").keys()) == ref["find_FORMULA4"]
+    lc = api.LocalCoordinates.p(name="gc")
+    for (key, n_ref) in ref["n_dline"].items():
+        n = gcat.create_material_from_long_name(lc, names[key]).get_optical_index(None, 0.5876e-3)
+        assert abs(np.real(n) - n_ref) < 1e-14
+    with pytest.raises(Exception) as e1:
+        gcat.material_dict_from_long_name("FORMULA")
+    assert str(e1.value) == ref["error_similar"]
+    with pytest.raises(Exception) as e2:
+        gcat.material_dict_from_long_name("no such glass")
+    assert str(e2.value) == ref["error_none"]
+    assert GlassCatalog(os.path.join(tmp, "missing")).get_shelves() == []
+
+
+def test_system_from_glass_names_equals_reference(api, minidb):
+    (tmp, names) = minidb
+    case = _golden.load_case("catalog_doublet")
+    (s, seq) = api.build_rotationally_symmetric_optical_system(zoo.catalog_doublet_tuples(names),
+                                                               material_db_path=tmp)
+    (recs, _) = flatten_sequence(s, seq, case.wave)
+    _assert_tables_equal(recs, case.table)
+    with pytest.raises(Exception):
+        api.build_rotationally_symmetric_optical_system(
+            [(10.0, 0.0, 0.0, "UNKNOWN GLASS", "a", {})], material_db_path=tmp)
