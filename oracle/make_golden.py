@@ -310,6 +310,50 @@ def case_glasscatalog():
     print("glasscatalog.json: %d pages" % len(names))
 
 
+def _spd_numbers(psys):
+    spd = psys.spd
+    return {"spd": {k: float(getattr(spd, k)()) for k in ("pp_obj", "pp_img", "thick", "entpup", "expup",
+                                                          "distance_entpup_objplane", "distance_expup_imgplane",
+                                                          "objNA", "imgNA")},
+            "psys": {"entpup": float(psys.entpup), "expup": float(psys.expup), "efl": float(psys.efl),
+                     "NAimg": float(psys.NAimg), "NAobj": float(psys.NAobj), "entpup_rad": float(psys.entpup_rad),
+                     "img_dist": float(psys.img_dist()), "obj_dist": float(psys.obj_dist()),
+                     "field_size_obj": float(psys.field_size_obj()), "field_size_img": float(psys.field_size_img()),
+                     "img_angle": float(psys.img_angle()), "mag": float(psys.mag()),
+                     "rear_focus": float(psys.rear_focus()), "front_focus": float(psys.front_focus())},
+            "surfaces": [[float(sf.curv), float(l.spaces[j].thick), l.spaces[j].medium, l.name + " " + sf.name,
+                          bool(sf.is_stop)] for l in spd.lenses for (j, sf) in enumerate(l.surfs)]}
+
+
+def case_spd():
+    """the reference's SPD importer: (i) end to end on a synthetic WinLens file of the double Gauss
+    (tests/systems_zoo.py writes it) with a miniature glass database -> traced golden case;
+    (ii) its first-order numbers and surface lists for the three files under demos/data (expected
+    outputs only; the files themselves stay in the reference)"""
+    import contextlib
+    import io
+    import tempfile
+    from pyrateoptics.raytracer.io.spd import SPDParser
+    from pyrateoptics.raytracer.material.material_glasscat import GlassCatalog
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        spdfile = os.path.join(tmp, "synthetic_double_gauss.spd")
+        zoo.synthetic_double_gauss_spd(spdfile)
+        zoo.write_spd_glass_database(tmp)
+        with contextlib.redirect_stdout(io.StringIO()):
+            sp = SPDParser(spdfile, name="synthetic")
+            (s, seq) = sp.create_optical_system(options={"gcat": GlassCatalog(tmp), "db_path": tmp})
+        out["synthetic"] = _spd_numbers(sp.psys)
+        dump_case("spd_double_gauss_Fline", s, seq, disk_bundle(100, 5.0, -10.0, field_deg=3.0, wave=486.1e-6))
+    for name in ("double_gauss_rudolph_1897_v2.spd", "Thorlabs_AC127_050_A.spd", "Thorlabs_LBF254_050_A.spd"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            sp = SPDParser(os.path.join(REF, "demos", "data", name), name=name)
+        out[name] = _spd_numbers(sp.psys)
+    with open(os.path.join(OUT, "spd_importer.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("spd_importer.json: %s" % ", ".join(out.keys()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     np.random.seed(0)
@@ -325,6 +369,7 @@ def main():
     case_aniso()
     case_aniso_mirror()
     case_zmx()
+    case_spd()
     case_dispersion()
     case_glasscatalog()
 

@@ -2,7 +2,8 @@
 (pyrateoptics/__init__.py:83-258): build_rotationally_symmetric_optical_system,
 build_simple_optical_element, build_simple_optical_system.  Materials may be None
 (background), a number (ConstantIndexGlass), a dict {"eps": 3x3}
-(AnisotropicMaterial), a refractiveindex.info page dictionary, a ready Material object, or a
+(AnisotropicMaterial), a dict {"conrady": (n0, A, B)} (ModelGlass), a refractiveindex.info page
+dictionary, a ready Material object, or a
 glass name looked up in the database under ``material_db_path`` (GlassCatalog)."""
 import numpy as np
 
@@ -52,6 +53,12 @@ def build_simple_optical_element(lc0, builduplist, material_db_path="", name="")
                 from .raytracer.material.material_glasscat import CatalogMaterial
                 key = str(mat.get("SPECS", {}).get("nd", "catalog_" + surf_name))
                 elem.addMaterial(key, CatalogMaterial.p(lc, mat))
+                mat = key
+            elif isinstance(mat, dict) and "conrady" in mat:
+                # Conrady model glass n = n0 + A/wave + B/wave**3.5 (prescription importers)
+                from .raytracer.material.material_isotropic import ModelGlass
+                key = "modelglass_" + str(mat.get("name", surf_name))
+                elem.addMaterial(key, ModelGlass.p(lc, tuple(mat["conrady"]), name=key))
                 mat = key
             elif isinstance(mat, dict) and "eps" in mat:
                 key = "anisotropic_" + surf_name

@@ -272,3 +272,158 @@ def catalog_doublet_tuples(names):
             (-45.7, 0.0, 4.0, names["formula2"], "cement", {}),
             (-128.2, 0.0, 2.5, None, "rear", {}),
             (0.0, 0.0, 97.2, None, "image", {})]
+
+
+def paraxial_summary(tuples, obj_dist, stop_radius, obj_angle_deg=5.0):
+    """First-order data of a rotationally symmetric prescription given as builder tuples
+    (r, cc, thickness_before, n_after | None, name, opts): y-nu matrices -> the summary rows a
+    WinLens SPD file carries (efl, principal planes via l / l', pupils, field)."""
+    def surf_matrix(r, n1, n2):
+        c = 0.0 if (r == 0 or abs(r) > 1e15) else 1. / r
+        return np.array([[1., 0.], [-(n2 - n1) * c, 1.]])
+
+    def gap_matrix(t, n):
+        return np.array([[1., t / n], [0., 1.]])
+
+    surfs = tuples[:-1]                                   # without the image plane
+    mats = []
+    n = 1.0
+    for (r, _, t, n_after, _, opts) in surfs:
+        n2 = 1.0 if n_after is None else float(n_after)
+        mats.append((gap_matrix(t, n), surf_matrix(r, n, n2), opts.get("is_stop", False)))
+        n = n2
+    total = np.eye(2)
+    istop = [i for (i, m) in enumerate(mats) if m[2]][0]
+    front = np.eye(2)
+    for (i, (g, s, _)) in enumerate(mats):
+        total = s.dot(g).dot(total) if i > 0 else s.dot(total)
+        if i == istop:
+            front = total.copy()
+    rear = total.dot(np.linalg.inv(front))                # stop -> last surface
+    (A, B, C, D) = (total[0, 0], total[0, 1], total[1, 0], total[1, 1])
+    efl = -1. / C
+    pp_obj = (D - 1.) / C
+    pp_img = (1. - A) / C
+    thick = sum(t for (_, _, t, _, _, _) in surfs[1:])
+    img_dist = 1. / (1. / efl + 1. / (obj_dist - pp_obj)) + pp_img
+    mag = (img_dist - pp_img) / (obj_dist - pp_obj)
+    # entrance pupil: object point z_e (from the first surface) imaged onto the stop by the front group
+    (a, b, c, d) = front.ravel()
+    z_e = b / a                                            # y_stop = a*y - ... = 0 for rays from (z_e, axis)
+    m_e = 1. / a if abs(a) > 1e-300 else 1.0              # stop height / pupil height
+    entpup = z_e
+    entpup_rad = abs(stop_radius / (a - c * 0.0)) if a != 0 else stop_radius
+    (a2, b2, c2, d2) = rear.ravel()
+    expup = -b2 / d2                                       # from the last surface
+    expup_rad = abs(stop_radius * (a2 - b2 * c2 / d2))
+    obj_height = math.tan(math.radians(obj_angle_deg)) * (entpup - obj_dist)
+    img_height = mag * obj_height
+    img_angle = math.degrees(math.atan(-img_height / (expup - img_dist)))
+    out = dict(efl=efl, mag=mag, obj_dist=obj_dist, img_dist=img_dist, l=obj_dist - pp_obj,
+               ldash=img_dist - pp_img, track=thick + img_dist - obj_dist, stop_rad=stop_radius,
+               entpup_rad=entpup_rad, expup_rad=expup_rad, obj_angle=obj_angle_deg,
+               obj_height=obj_height, img_angle=img_angle, img_height=img_height)
+    return {k: float(v) for (k, v) in out.items()}
+
+
+def write_synthetic_spd(path, groups, stop_after, glass_indices, waves_nm, summary, gaps):
+    """Writes a WinLens-SPD-shaped CSV file (component rows, LENS blocks with Surf / Space /
+    GlassIndex rows, paraxial summary rows) for lens groups ``[[(radius, free_radius), ...], ...]``
+    with glass names / thicknesses ``glass_indices[group] = [(name, thickness, (n_d, n_F, n_C)), ...]``,
+    a stop component behind group ``stop_after`` and air gaps ``gaps`` behind every component."""
+    def q(s):
+        return '"%s"' % s
+    rows = [",".join([q("-- Version 5.0 file --"), q("01-01-2024")]), ",".join([q("synthetic"), q(""), "1"]),
+            "#FALSE#", "0,#FALSE#,#FALSE#,#FALSE#,0",
+            ",".join(["%d,1,0,0" % len(waves_nm)] + ["%r" % w for w in waves_nm])]
+    comp_no = 0
+    gap_iter = iter(gaps)
+
+    def component_row(label, kind, nsurf, gap):
+        cells = [q(str(comp_no)), q(label), "#TRUE#", q("Nom" if kind else ""), q(kind), str(nsurf),
+                 q("0, %r" % gap), "#TRUE#", q(""), q(""), q(""), q(""), q(""), q("air"), q(" "), q(""), q(""),
+                 q("NonSH"), q(""), "0"]
+        return ",".join(cells)
+
+    for (g, surfs) in enumerate(groups):
+        comp_no += 1
+        rows.append(component_row("   ", "lens", len(surfs), next(gap_iter)))
+        rows.append(q(" LENS %d" % comp_no))
+        for (j, (radius, free_radius)) in enumerate(surfs):
+            rows.append(",".join([q("   Surf  %d" % (j + 1)), q("sphere"), "0", "%r" % radius, "#TRUE#", q(""),
+                                  q(""), "0", "%r" % waves_nm[0], "%r" % free_radius, "0", q(""), q(""), q(""),
+                                  q("FALSE"), q("FALSE|0|")]))
+            if j < len(surfs) - 1:
+                (gname, thickness, nn) = glass_indices[g][j]
+                rows.append(",".join([q("   Space %d" % (j + 1)), "%r" % thickness, q(""), q(gname),
+                                      q("Schott                        ")] + [q("")] * 7))
+                rows.append(",".join([q("      GlassIndex")] + ["%r" % v for v in nn] + [q(""), q("")]))
+        rows.append(q(" LENS %d End" % comp_no))
+        if g == stop_after:
+            comp_no += 1
+            rows.append(component_row("Stop", "", 0, next(gap_iter)).replace("#TRUE#", "#FALSE#", 1))
+    sm = summary
+    rows += [",".join([q("Defocus"), "0", "0", q("")]),
+             ",".join([q("Waveband")] + ["%r" % w for w in waves_nm]),
+             ",".join([q("efl"), "%r" % sm["efl"]]),
+             ",".join([q("ObjDist"), "%r" % sm["obj_dist"], q("   ImagDist"), "%r" % sm["img_dist"]]),
+             ",".join([q("l"), "%r" % sm["l"], q("   l'"), "%r" % sm["ldash"]]),
+             ",".join([q("Mag"), "%r" % sm["mag"], q("   AngMag"), "0"]),
+             ",".join([q("Track"), "%r" % sm["track"]]),
+             ",".join([q("ObjNa"), "0.0065", q("   ImagNa"), "0.0513", q("Stop Rad"), "%r" % sm["stop_rad"]]),
+             ",".join([q("Entr Pup Rad"), "%r" % sm["entpup_rad"], q("Exit Pup Rad"), "%r" % sm["expup_rad"]]),
+             ",".join([q("ObjAngle"), "%r" % sm["obj_angle"], q("   ObjHeight"), "%r" % sm["obj_height"]]),
+             ",".join([q("ImagAngle"), "%r" % sm["img_angle"], q("ImagHeight"), "%r" % sm["img_height"]]),
+             ",".join(["400", "800", "632.8", ".001", ".8057059", "805.7059", "587.56", "0", "0", "0"]),
+             q("synthetic.SPD")]
+    with open(path, "w", newline="") as f:
+        f.write("\r\n".join(rows) + "\r\n")
+
+
+def synthetic_double_gauss_spd(path):
+    """the double Gauss of pyrate_amd.systems written as an SPD file; returns the builder tuples
+    (d-line indices) it corresponds to"""
+    from pyrate_amd import systems
+    tuples = systems.double_gauss_tuples()
+    by_nd = {v[0]: (k, v) for (k, v) in systems.DOUBLE_GAUSS_GLASSES.items()}
+    summary = paraxial_summary(tuples, -1000.0, 5.0)
+    t = [tp[2] for tp in tuples]                           # thickness before surface i
+    r = [tp[0] for tp in tuples]
+    n = [tp[3] for tp in tuples]
+
+    def glass(i):
+        (name, nn) = by_nd[n[i]]
+        return (name, t[i + 1], nn)
+    groups = [[(r[0], 12.0), (r[1], 12.0), (r[2], 12.0)], [(r[3], 12.0), (r[4], 12.0)],
+              [(r[6], 12.0), (r[7], 12.0)], [(r[8], 12.0), (r[9], 12.0), (r[10], 12.0)]]
+    glass_indices = [[glass(0), glass(1)], [glass(3)], [glass(6)], [glass(8), glass(9)]]
+    gaps = [t[3], t[5], t[6], t[8], 0.0]                   # behind lens 1, lens 2, stop, lens 3, lens 4
+    write_synthetic_spd(path, groups, 1, glass_indices, [round(w * 1e6, 4) for w in systems.DOUBLE_GAUSS_WAVES_MM], summary, gaps)
+    return tuples
+
+
+def write_spd_glass_database(basepath):
+    """refractiveindex.info-shaped database holding the three glasses of the double Gauss as
+    "formula 5" pages (n = c0 + c1 w**-1 + c2 w**-3.5, w in um: the Conrady model through the
+    d, F, C indices); F5 additionally sits where the reference's SPD importer looks for it by
+    shelf / book / page (io/spd.py:890-893)."""
+    import os
+    import yaml
+    from pyrate_amd import systems
+    books = {}
+    for (name, nn) in systems.DOUBLE_GAUSS_GLASSES.items():
+        (n0, a, b) = systems.conrady_fit(*nn)
+        page = {"DATA": [{"type": "formula 5", "wavelength_range": "0.35 1.1",
+                          "coefficients": "%r %r -1 %r -3.5" % (float(n0), float(a) * 1e3, float(b) * 1e3 ** 3.5)}],
+                "SPECS": {"nd": float(nn[0])}}
+        book = "SCHOTT-F" if name == "F5" else "SCHOTT-" + name.split("-")[0][:1]
+        rel = "glass/schott/%s.yml" % name
+        books.setdefault(book, []).append({"PAGE": name, "name": name, "data": rel})
+        full = os.path.join(basepath, "data", rel)
+        os.makedirs(os.path.dirname(full), exist_ok=True)
+        with open(full, "w") as f:
+            yaml.safe_dump(page, f)
+    lib = [{"SHELF": "glass", "name": "GLASS", "content":
+            [{"BOOK": b, "name": b, "content": pages} for (b, pages) in sorted(books.items())]}]
+    with open(os.path.join(basepath, "library.yml"), "w") as f:
+        yaml.safe_dump(lib, f)

@@ -104,6 +104,18 @@ def test_seqtrace_of_imported_zmx_prescription(api):
     assert_paths_match(rpaths[0], case.raw_bundles, loose_x=1e-8)    # 13 fsolve surfaces in a row
 
 
+def test_seqtrace_of_imported_spd_prescription(api, tmp_path):
+    """synthetic WinLens SPD file of the double Gauss -> SPDParser (glasses from the file's own
+    GlassIndex rows) -> seqtrace at the F line == what the reference's importer + trace returned"""
+    from pyrate_amd.raytracer.io.spd import SPDParser
+    case = _golden.load_case("spd_double_gauss_Fline")
+    f = str(tmp_path / "dg.spd")
+    zoo.synthetic_double_gauss_spd(f)
+    (s, seq) = SPDParser(f).create_optical_system()
+    rpaths = s.seqtrace(bundle_of(api, case), seq)
+    assert_paths_match(rpaths[0], case.raw_bundles)
+
+
 def test_plugin_granular_path_matches_fused(api):
     """OpticalElement.seqtrace (Material.propagate / refract per surface + device compaction)
     gives the same RayPath as the fused launch"""

@@ -127,3 +127,75 @@ def test_system_from_glass_names_equals_reference(api, minidb):
     with pytest.raises(Exception):
         api.build_rotationally_symmetric_optical_system(
             [(10.0, 0.0, 0.0, "UNKNOWN GLASS", "a", {})], material_db_path=tmp)
+
+
+# ---- WinLens SPD importer ---------------------------------------------------------------------
+def _spd_numbers(psys):
+    spd = psys.spd
+    return {"spd": {k: float(getattr(spd, k)()) for k in ("pp_obj", "pp_img", "thick", "entpup", "expup",
+                                                          "distance_entpup_objplane", "distance_expup_imgplane",
+                                                          "objNA", "imgNA")},
+            "psys": {"entpup": psys.entpup, "expup": psys.expup, "efl": psys.efl, "NAimg": psys.NAimg,
+                     "NAobj": psys.NAobj, "entpup_rad": psys.entpup_rad, "img_dist": psys.img_dist(),
+                     "obj_dist": psys.obj_dist(), "field_size_obj": psys.field_size_obj(),
+                     "field_size_img": psys.field_size_img(), "img_angle": psys.img_angle(), "mag": psys.mag(),
+                     "rear_focus": psys.rear_focus(), "front_focus": psys.front_focus()},
+            "surfaces": [[r, t, sp.medium, name, stop] for (r, t, sp, name, stop) in spd.surface_rows()]}
+
+
+def _assert_spd_numbers(mine, ref):
+    for grp in ("spd", "psys"):
+        assert set(mine[grp]) == set(ref[grp])
+        for (k, v) in ref[grp].items():
+            assert mine[grp][k] == pytest.approx(v, rel=1e-13, abs=1e-13), (grp, k)
+    assert len(mine["surfaces"]) == len(ref["surfaces"])
+    for (a, b) in zip(mine["surfaces"], ref["surfaces"]):
+        assert a[0] == b[0] and a[1] == b[1] and a[2:] == b[2:], (a, b)
+
+
+@pytest.fixture(scope="module")
+def spd_setup(tmp_path_factory):
+    tmp = str(tmp_path_factory.mktemp("spd"))
+    spdfile = os.path.join(tmp, "synthetic_double_gauss.spd")
+    zoo.synthetic_double_gauss_spd(spdfile)
+    zoo.write_spd_glass_database(tmp)
+    return (tmp, spdfile)
+
+
+def test_spd_importer_equals_reference_importer(api, spd_setup):
+    from pyrate_amd.raytracer.io.spd import SPDParser
+    from pyrate_amd.raytracer.material.material_glasscat import GlassCatalog
+    (tmp, spdfile) = spd_setup
+    ref = json.load(open(os.path.join(_golden.GOLDEN_DIR, "spd_importer.json")))
+    sp = SPDParser(spdfile, name="synthetic")
+    _assert_spd_numbers(_spd_numbers(sp.psys), ref["synthetic"])
+    assert sp.psys.spd.wavelengths_nm == [587.6, 486.1, 656.3, 440.0, 700.0] and sp.psys.spd.stop_radius == 5.0
+    case = _golden.load_case("spd_double_gauss_Fline")
+    # (i) glasses by name through the catalogue, like the reference
+    (s, seq) = sp.create_optical_system(options={"gcat": GlassCatalog(tmp), "db_path": tmp})
+    (recs, lengths) = flatten_sequence(s, seq, case.wave)
+    assert lengths == case.elem_lengths
+    _assert_tables_equal(recs, case.table)
+    # (ii) no catalogue: Conrady model through the file's own GlassIndex rows
+    (s2, seq2) = sp.create_optical_system()
+    (recs2, _) = flatten_sequence(s2, seq2, case.wave)
+    for (a, b) in zip(recs2, case.table):
+        assert a["material"]["n"] == pytest.approx(b["material"]["n"], abs=1e-13)
+        assert a["shape"] == b["shape"] and a["g_shape"] == b["g_shape"]
+    # (iii) explicit overrides
+    (s3, seq3) = sp.create_optical_system(matdict={"F5": 1.6, "LLF1": 1.55, "N-KF9": 1.52})
+    (recs3, _) = flatten_sequence(s3, seq3, case.wave)
+    assert [r["material"]["n"] for r in recs3[:5]] == [1.52, 1.55, 1.0, 1.6, 1.0]
+
+
+def test_spd_importer_on_the_reference_data_files():
+    from pyrate_amd.raytracer.io.spd import SPDParser
+    ref = json.load(open(os.path.join(_golden.GOLDEN_DIR, "spd_importer.json")))
+    datadir = os.path.join(os.environ.get("PYRATE_REFERENCE", "/root/reference"), "demos", "data")
+    if not os.path.isdir(datadir):
+        pytest.skip("the reference checkout (and its demos/data/*.spd) is not on this machine")
+    for name in ("double_gauss_rudolph_1897_v2.spd", "Thorlabs_AC127_050_A.spd", "Thorlabs_LBF254_050_A.spd"):
+        sp = SPDParser(os.path.join(datadir, name))
+        _assert_spd_numbers(_spd_numbers(sp.psys), ref[name])
+        (s, seq) = sp.create_optical_system()
+        assert len(seq[0][1]) == len(ref[name]["surfaces"]) + 1
