@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--no-stats", action="store_true", help="N>1: skip the per-step spot statistics all-reduce")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="N>1: all-gather the image plane (49 B/ray) after every step instead of once")
+    ap.add_argument("--two-pass-stats", action="store_true",
+                    help="N>1: per-step spot statistics from two extra passes over the image plane and two "
+                         "all-reduces (default: moments reduced inside the trace kernel, one all-reduce)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["path", "image"], default="path")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -165,20 +168,27 @@ def main():
     sysd = sysds[0]
     mode = _lib.MODE_PATH if args.mode == "path" else _lib.MODE_IMAGE
     multi = use_dist
-    # N > 1 (BASELINE configs[4]): every step ends with the device-side image-plane spot
-    # statistics of the sharded bundle (two 7-double all-reduces instead of moving the image
-    # plane), issued on a side stream so that they overlap the next step's
-    # trace.  The full image plane is all-gathered ONCE after the K timed steps ("the final
+    # N > 1 (BASELINE configs[4]): every step ends with the image-plane spot statistics of the
+    # sharded bundle (an all-reduce of moments instead of moving the image plane).
+    # The trace kernel reduces its shard's moments itself (prt_trace_moments, no extra pass over
+    # the arrays); the one 7-double all-reduce runs on a side stream and overlaps the next step's
+    # trace.  (--two-pass-stats: the generic form, two reduction passes + two all-reduces.)
+    # The full image plane is all-gathered ONCE after the K timed steps ("the final
     # image-plane gather"); it is not a step, so it is timed separately and reported as
     # config.image_plane_exchange.final_gather_ms.  --gather-every-step moves the 49 B/ray
     # all-gather into every (timed) step instead.
     do_stats = multi and not args.no_stats
     do_final_gather = multi and not args.no_gather and not args.gather_every_step
     do_step_gather = multi and args.gather_every_step
-    nbuf = 2 if (do_stats or do_step_gather) else 1
-    bufs = [sysd.alloc_outputs(n_local, mode) for _ in range(nbuf)]
+    fused_stats = do_stats and not args.two_pass_stats
+    nbuf = 2 if (do_stats or do_step_gather) else 1          # in-flight side-stream jobs
+    # the side stream of the fused form only touches 7-double vectors, so the 6-GB path buffers need
+    # no double buffering (alternating between two of them costs ~6 % write bandwidth, measured:
+    # scratch/moments_cost.py)
+    n_out_bufs = 1 if (fused_stats and not do_step_gather) else nbuf
+    bufs = [sysd.alloc_outputs(n_local, mode) for _ in range(n_out_bufs)]
     host_staged = (args.backend == "gloo")
-    stats = [pdist.SpotStatistics(dev) for _ in range(nbuf)] if do_stats else []
+    stats = [pdist.SpotStatistics(dev, n_rays=n_local) for _ in range(nbuf)] if do_stats else []
     gathers = [pdist.ImagePlaneGather(n_total, dev, stage_on_host=host_staged)
                for _ in range(nbuf if do_step_gather else 1)] if (do_step_gather or do_final_gather) else []
     comm_stream = torch.cuda.Stream(device=dev) if multi else None
@@ -189,14 +199,20 @@ def main():
         b = i % nbuf
         if side_done[b] is not None:
             main_stream.wait_event(side_done[b])      # buffer pair b is free again
-        sysds[i % len(sysds)].trace_into(x0, k0, bufs[b], e0d)
+        ob = bufs[b % n_out_bufs]
+        if fused_stats:
+            stats[b].trace_and_start(sysds[i % len(sysds)], x0, k0, ob, e0d)
+        else:
+            sysds[i % len(sysds)].trace_into(x0, k0, ob, e0d)
         if do_stats or do_step_gather:
             ev = torch.cuda.Event()
             ev.record(main_stream)
-            v = sysd.views(bufs[b])
+            v = sysd.views(ob)
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
-                if do_stats:
+                if fused_stats:
+                    stats[b].reduce()
+                elif do_stats:
                     stats[b].start(v.x_hit[-1], v.valid_out[-1])
                 if do_step_gather:
                     gathers[b].wait()
@@ -208,7 +224,7 @@ def main():
 
     def final_gather(last_step):
         """the one-off image-plane all-gather of the last traced bundle (49 B/ray)"""
-        v = sysd.views(bufs[last_step % nbuf])
+        v = sysd.views(bufs[(last_step % nbuf) % n_out_bufs])
         ev = torch.cuda.Event()
         ev.record(main_stream)
         with torch.cuda.stream(comm_stream):
@@ -302,7 +318,9 @@ def main():
                        "mode": args.mode, "sharding": "rays" if n_gpus > 1 else "none",
                        "wavelengths": len(sysds), "prewarm_launches": PREWARM_LAUNCHES,
                        "image_plane_exchange": {
-                           "per_step": ("device spot statistics + two 7-double all-reduces, overlapped"
+                           "per_step": (("spot moments reduced inside the trace kernel + one 7-double all-reduce "
+                                         "(side stream)" if fused_stats else
+                                         "device spot statistics (two passes) + two 7-double all-reduces, overlapped")
                                         if do_stats else ("image-plane all-gather 49 B/ray" if do_step_gather
                                                           else "none")),
                            "final": ("image-plane all-gather 49 B/ray, once after the K timed steps"

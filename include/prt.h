@@ -155,6 +155,24 @@ int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const d
                   uint8_t *valid_out, void *stream);
 
 /*
+ * prt_trace for all-isotropic tables that also reduces the image-plane moments of the traced
+ * bundle in the same launch: out7_dev = {count, sum v (3), sum v*v (3)}, v = last hit point - ref,
+ * over the rays still valid after the last interaction (= valid_out of the last surface).
+ * ref3 (host, 3 doubles) may be NULL: the vertex of the last surface.  From these sums the caller
+ * gets centroid = ref + S1/n and RMS spot radius^2 = (sum S2 - |S1|^2/n)/(n-1), the quantities of
+ * RayBundleAnalysis.get_centroid_position / get_rms_spot_size (analysis/ray_analysis.py:44-86);
+ * being plain sums they combine over ray shards with ONE 7-double all-reduce.  The summation
+ * order is fixed (bit-reproducible).  scratch_dev: prt_trace_moments_scratch_doubles(n0) doubles.
+ * Asynchronous on `stream`.
+ */
+int64_t prt_trace_moments_scratch_doubles(int64_t n0);
+int32_t prt_trace_moments(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
+                          const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
+                          int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
+                          uint8_t *valid_out, const double *ref3, double *out7_dev,
+                          double *scratch_dev, void *stream);
+
+/*
  * prt_trace in the concatenated layout (tight inputs) that also returns the E field of the rays
  * leaving every crystal interface: e_out_re / e_out_im (may be NULL) have the layout of k_out;
  * blocks of isotropic surfaces are left untouched (there E is not computed, see prt_efield_perp).  This is what

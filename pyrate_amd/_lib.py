@@ -102,6 +102,12 @@ PROTOTYPES["prt_trace_fields"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int
                                                   c_double_p, c_double_p, c_double_p, c_u8_p, c_u8_p,
                                                   c_stream])
 
+PROTOTYPES["prt_trace_moments_scratch_doubles"] = (ctypes.c_int64, [ctypes.c_int64])
+PROTOTYPES["prt_trace_moments"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_double_p,
+                                                   c_double_p, c_double_p, c_double_p, ctypes.c_int32,
+                                                   ctypes.c_int64, c_double_p, c_double_p, c_u8_p, c_u8_p,
+                                                   c_double_p, c_double_p, c_double_p, c_stream])
+
 _lib = None
 
 

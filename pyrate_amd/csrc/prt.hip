@@ -425,6 +425,86 @@ int32_t prt_trace_fields(const prt_system_t *sys, int64_t n0, const double *x0, 
                       valid_out, stream);
 }
 
+int64_t prt_trace_moments_scratch_doubles(int64_t n0) {
+    if (n0 < 0) return 0;
+    // one row per 512 rays + the rows of k_moments_stage
+    const int64_t rows = (n0 + 2 * PRT_BLOCK - 1) / (2 * PRT_BLOCK);
+    const int64_t fused = (int64_t)MOM_VALUES * (rows + (rows + PRT_BLOCK - 1) / PRT_BLOCK);
+    const int64_t two_kernel = prt_moments_scratch_doubles(n0);
+    return fused > two_kernel ? fused : two_kernel;
+}
+
+int32_t prt_trace_moments(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
+                          const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
+                          int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
+                          uint8_t *valid_out, const double *ref3, double *out7_dev,
+                          double *scratch_dev, void *stream) {
+    if (!sys || n0 < 0 || !out7_dev || !scratch_dev)
+        return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: bad argument");
+    if (!sys->all_isotropic)
+        return fail(PRT_ERR_UNSUPPORTED, "prt_trace_moments: isotropic tables only (use prt_trace + prt_bundle_moments)");
+    if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE)
+        return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: bad mode");
+    if (n0 > 0 && (!x0 || !k0 || !x_hit || !k_out || !valid))
+        return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: null pointer");
+    if (in_pitch == 0) in_pitch = n0;
+    if (out_pitch == 0) out_pitch = n0;
+    if (in_pitch < n0 || out_pitch < n0)
+        return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: pitch smaller than the ray count");
+    PRT_ON_DEVICE(sys->device);
+    hipStream_t st = (hipStream_t)stream;
+    const prt_surface_t *last = sys->h_table + (sys->n_surfaces - 1);
+    // reference point of the sums: the vertex of the last surface unless the caller names one
+    const double rx = ref3 ? ref3[0] : last->g_shape[0];
+    const double ry = ref3 ? ref3[1] : last->g_shape[1];
+    const double rz = ref3 ? ref3[2] : last->g_shape[2];
+    const bool vec_in = (in_pitch % 2 == 0) && aligned16(x0) && aligned16(k0) &&
+                        (!e0_re || aligned16(e0_re)) && (!e0_im || aligned16(e0_im));
+    const bool vec_out = (out_pitch % 2 == 0) && aligned16(x_hit) && aligned16(k_out) &&
+                         ((((uintptr_t)valid) & 1u) == 0) &&
+                         (!valid_out || (((uintptr_t)valid_out) & 1u) == 0) &&
+                         (n0 % 2 == 0 || out_pitch > n0);
+    if (n0 > 0 && vec_in && vec_out) {
+        const unsigned nb = (unsigned)nblocks(n0, PRT_BLOCK * 2);
+        const dim3 grid(nb), block(PRT_BLOCK);
+        const int32_t e_mode = e_mode_of(e0_re, 1);
+#define PRT_LAUNCH_M(MODE_, EX)                                                                           \
+    hipLaunchKernelGGL((k_trace_iso<MODE_, true, true, EX, false, true>), grid, block, 0, st, sys->d_table, \
+                       sys->n_surfaces, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch, x_hit,     \
+                       k_out, valid, valid_out, rx, ry, rz, scratch_dev)
+        if (mode == PRT_MODE_PATH) {
+            if (sys->all_conic) PRT_LAUNCH_M(PRT_MODE_PATH, false);
+            else PRT_LAUNCH_M(PRT_MODE_PATH, true);
+        } else {
+            if (sys->all_conic) PRT_LAUNCH_M(PRT_MODE_IMAGE, false);
+            else PRT_LAUNCH_M(PRT_MODE_IMAGE, true);
+        }
+#undef PRT_LAUNCH_M
+        const unsigned ng = (nb + PRT_BLOCK - 1) / PRT_BLOCK;
+        double *stage = scratch_dev + (int64_t)MOM_VALUES * nb;
+        hipLaunchKernelGGL(k_moments_stage, dim3(ng), dim3(PRT_BLOCK), 0, st, (int)nb, scratch_dev, stage);
+        hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, (int)ng, stage, out7_dev);
+        HIP_TRY(hipGetLastError());
+        return PRT_OK;
+    }
+    // unaligned / odd-pitch buffers: the plain trace followed by the two-kernel reduction
+    int32_t rc = prt_trace(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out, valid,
+                           valid_out, stream);
+    if (rc != PRT_OK) return rc;
+    const int64_t row = (mode == PRT_MODE_PATH) ? (int64_t)(sys->n_surfaces - 1) : 0;
+    const uint8_t *mask = valid_out ? valid_out + row * out_pitch : nullptr;
+    if (!mask) return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: valid_out is required for unaligned buffers");
+    int nbk = (int)((n0 + PRT_BLOCK * 8 - 1) / (PRT_BLOCK * 8));
+    if (nbk > 2048) nbk = 2048;
+    if (nbk < 1) nbk = 1;
+    hipLaunchKernelGGL(k_moments_partial, dim3(nbk), dim3(PRT_BLOCK), 0, st, n0, out_pitch,
+                       x_hit + row * 3 * out_pitch, mask, 0, rx, ry, rz, (const double *)nullptr, 0,
+                       scratch_dev);
+    hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, nbk, scratch_dev, out7_dev);
+    HIP_TRY(hipGetLastError());
+    return PRT_OK;
+}
+
 int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
                         const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
                         int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,

@@ -109,13 +109,21 @@ PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
 // EXPLICIT = false: the host guarantees that every shape of the table is a Conic, and the
 // Newton / polynomial code of the explicit shapes is compiled out (fewer VGPRs: one more wave
 // per SIMD for the all-conic systems such as the double Gauss).
-template <int MODE, bool VEC_IN, bool VEC_OUT, bool EXPLICIT = true, bool LDS_TAB = false>
+// MOMENTS = true additionally reduces the image-plane spot moments of the bundle inside the same
+// launch: every block writes {count, sum v, sum v*v} (v = last hit point - mref, rays still valid
+// after the last interaction) of its 512 rays to moment_partials[blockIdx.x*7..]; k_moments_final
+// sums the blocks in a fixed order.  This is RayBundleAnalysis' centroid / RMS spot input
+// (analysis/ray_analysis.py:44-86) without a second pass over the image-plane arrays.
+#define MOM_VALUES 7
+template <int MODE, bool VEC_IN, bool VEC_OUT, bool EXPLICIT = true, bool LDS_TAB = false,
+          bool MOMENTS = false>
 __global__ __launch_bounds__(PRT_BLOCK) void k_trace_iso(
     const prt_surface_t *__restrict__ tab_g, int32_t S, int64_t N, int64_t in_pitch,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, int64_t out_pitch,
     double *__restrict__ xh_out, double *__restrict__ k_out, uint8_t *__restrict__ valid_out_hit,
-    uint8_t *__restrict__ valid_out_refr) {
+    uint8_t *__restrict__ valid_out_refr, double mref_x = 0.0, double mref_y = 0.0,
+    double mref_z = 0.0, double *__restrict__ moment_partials = nullptr) {
     const prt_surface_t *__restrict__ tab = tab_g;
     if (LDS_TAB) {
         __shared__ prt_surface_t lds_tab[PRT_LDS_TAB_MAX];
@@ -127,11 +135,12 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_iso(
         tab = lds_tab;
     }
     const int64_t i = ((int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x) * 2;
-    if (i >= N) return;
+    if (!MOMENTS && i >= N) return;
     const bool second = (i + 1 < N);
 
     vec3 x[2], k[2], d[2];
     bool valid[2] = {true, true};
+    if (i < N) {  // (always true without MOMENTS; with MOMENTS the tail threads join the reduction)
     rayio<VEC_IN>::load(x0, in_pitch, i, second, x);
     rayio<VEC_IN>::load(k0, in_pitch, i, second, k);
     first_direction<VEC_IN>(e_mode, e_re, e_im, in_pitch, i, second, k, d);
@@ -163,6 +172,36 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_iso(
             rayio<VEC_OUT>::store_mask(valid_out_hit + so * out_pitch, i, second, vhit);
             if (valid_out_refr)
                 rayio<VEC_OUT>::store_mask(valid_out_refr + so * out_pitch, i, second, valid);
+        }
+    }
+    }  // i < N
+    if (MOMENTS) {
+        double acc[MOM_VALUES] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (i + r < N && valid[r]) {
+                const double vx = x[r].x - mref_x, vy = x[r].y - mref_y, vz = x[r].z - mref_z;
+                acc[0] += 1.0;
+                acc[1] += vx;
+                acc[2] += vy;
+                acc[3] += vz;
+                acc[4] += vx * vx;
+                acc[5] += vy * vy;
+                acc[6] += vz * vz;
+            }
+        }
+        __shared__ double sh[PRT_BLOCK / 64][MOM_VALUES];
+#pragma unroll
+        for (int q = 0; q < MOM_VALUES; ++q) {
+            double v = acc[q];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][q] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < MOM_VALUES) {
+            double v = 0.0;
+            for (int w = 0; w < PRT_BLOCK / 64; ++w) v += sh[w][threadIdx.x];
+            moment_partials[(int64_t)blockIdx.x * MOM_VALUES + threadIdx.x] = v;
         }
     }
 }
@@ -465,7 +504,6 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_path_sums(int32_t P, int64_t N,
 // (analysis/ray_analysis.py:44-86) and turns the multi-GPU image-plane exchange into a
 // 7-double all-reduce.
 // ---------------------------------------------------------------------------
-#define MOM_VALUES 7
 __global__ __launch_bounds__(PRT_BLOCK) void k_moments_partial(int64_t N, int64_t pitch,
                                                                const double *__restrict__ x,
                                                                const uint8_t *__restrict__ mask,
@@ -549,6 +587,27 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_moments_final(int nblocks_,
         __syncthreads();
     }
     if (threadIdx.x < MOM_VALUES) out[threadIdx.x] = sh[0][threadIdx.x];
+}
+
+// First stage for many rows (the fused march leaves one row per 512 rays): block g tree-reduces
+// rows [g*256, (g+1)*256) in LDS (fixed shape) and writes row g of `stage`; k_moments_final then
+// adds the few stage rows.
+__global__ __launch_bounds__(PRT_BLOCK) void k_moments_stage(int nrows,
+                                                             const double *__restrict__ partials,
+                                                             double *__restrict__ stage) {
+    __shared__ double sh[PRT_BLOCK][MOM_VALUES];
+    const int row = blockIdx.x * PRT_BLOCK + threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < MOM_VALUES; ++q)
+        sh[threadIdx.x][q] = (row < nrows) ? partials[(int64_t)row * MOM_VALUES + q] : 0.0;
+    __syncthreads();
+    for (int stride = PRT_BLOCK / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride)
+#pragma unroll
+            for (int q = 0; q < MOM_VALUES; ++q) sh[threadIdx.x][q] += sh[threadIdx.x + stride][q];
+        __syncthreads();
+    }
+    if (threadIdx.x < MOM_VALUES) stage[(int64_t)blockIdx.x * MOM_VALUES + threadIdx.x] = sh[0][threadIdx.x];
 }
 
 // Order-preserving slot assignment inside one CMP_TILE (= 4 sub-tiles of PRT_BLOCK consecutive

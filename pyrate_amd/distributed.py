@@ -127,20 +127,24 @@ def global_spot_statistics(x_img, valid=None, group=None, moments_fn=None):
 
 
 class SpotStatistics(object):
-    """Asynchronous, device-resident version of ``global_spot_statistics`` for stream pipelines:
-    ``start`` enqueues (current stream) pass 1 -> all-reduce -> pass 2 about the global centroid ->
-    all-reduce, with no host synchronisation; ``result`` syncs and returns
-    (count, centroid (3,), rms).  One instance per in-flight bundle."""
+    """Asynchronous, device-resident version of ``global_spot_statistics`` for stream pipelines.
+    Two forms: ``start`` enqueues (current stream) pass 1 -> all-reduce -> pass 2 about the global
+    centroid -> all-reduce over existing image-plane arrays; ``trace_and_start`` + ``reduce`` lets
+    the trace kernel produce the moments (no extra pass over the arrays) and needs one all-reduce.
+    No host synchronisation in either; ``result`` syncs and returns (count, centroid (3,), rms).
+    One instance per in-flight bundle."""
 
-    def __init__(self, device, group=None):
+    def __init__(self, device, group=None, n_rays=0):
         from . import engine
         self.engine = engine
         self.group = group
-        self.ws = engine.MomentsWorkspace(device, n_results=2)
+        self.ws = engine.MomentsWorkspace(device, n_results=2, n_rays=n_rays)
         self.multi = _collectives_needed(group)
+        self._fused_ref = None
 
     def start(self, x_img, valid):
         eng = self.engine
+        self._fused_ref = None
         m1 = eng.bundle_moments_async(x_img, valid, self.ws, slot=0)
         if self.multi:
             dist.all_reduce(m1, op=dist.ReduceOp.SUM, group=self.group)     # stream-ordered (NCCL)
@@ -148,8 +152,22 @@ class SpotStatistics(object):
         if self.multi:
             dist.all_reduce(m2, op=dist.ReduceOp.SUM, group=self.group)
 
+    def trace_and_start(self, sysd, x0, k0, bufs, e0_re=None, e0_im=None):
+        """Fused form: the trace kernel itself reduces the shard's moments about the vertex of the
+        last surface (prt_trace_moments); ONE 7-double all-reduce combines the shards.  Call on the
+        stream the trace should run on; ``reduce()`` may be issued on another stream afterwards."""
+        self._fused_ref = sysd.moments_reference()
+        return sysd.trace_moments_into(x0, k0, bufs, self.ws, slot=0, e0_re=e0_re, e0_im=e0_im)
+
+    def reduce(self):
+        """the all-reduce of the fused form (current stream)"""
+        if self.multi:
+            dist.all_reduce(self.ws.out[0], op=dist.ReduceOp.SUM, group=self.group)
+
     def result(self):
         import numpy as np
+        if self._fused_ref is not None:
+            return self.engine.spot_from_moments(self.ws.out[0].cpu().numpy(), self._fused_ref)
         m1 = self.ws.out[0].cpu().numpy()
         m2 = self.ws.out[1].cpu().numpy()
         count = m1[0]

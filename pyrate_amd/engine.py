@@ -214,6 +214,27 @@ class DeviceSystem(object):
                                       _ptr(bufs["k_out"]), _ptr(bufs["valid"]),
                                       _ptr(bufs["valid_out"]), _stream_handle(self.device)))
 
+    def trace_moments_into(self, x0, k0, bufs, ws, slot=0, e0_re=None, e0_im=None, ref=None):
+        """trace_into + the image-plane moments of the traced bundle from the same launch
+        (prt_trace_moments): ws.out[slot] = {count, sum v, sum v*v}, v = x_img - ref (default: vertex
+        of the last surface), over the rays valid after the last surface.  See ``spot_from_moments``."""
+        n0 = x0.shape[1]
+        need = self.lib.prt_trace_moments_scratch_doubles(n0)
+        if ws.scratch.numel() < need:
+            raise ValueError("MomentsWorkspace too small: construct it with n_rays >= %d" % n0)
+        in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
+        ref3 = None if ref is None else (ctypes.c_double * 3)(*[float(v) for v in ref])
+        _lib.check(self.lib.prt_trace_moments(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
+                                              _ptr(e0_im), bufs["mode"], bufs["pitch"], _ptr(bufs["x_hit"]),
+                                              _ptr(bufs["k_out"]), _ptr(bufs["valid"]),
+                                              _ptr(bufs["valid_out"]), ref3, _ptr(ws.out[slot]),
+                                              _ptr(ws.scratch), _stream_handle(self.device)))
+        return ws.out[slot]
+
+    def moments_reference(self):
+        """default reference point of trace_moments_into: global vertex of the last surface"""
+        return [float(v) for v in self.records[-1]["g_shape"]]
+
     @staticmethod
     def _in_pitch(x0, k0, e0_re, e0_im):
         if x0.shape[1] == 0:
@@ -403,10 +424,13 @@ def collimated_bundle_device(nray, radius, start, kvec, evec, device, lo=0, hi=N
 class MomentsWorkspace(object):
     """device scratch + result vectors for bundle_moments_async (no allocation per call)"""
 
-    def __init__(self, device, n_results=2):
+    def __init__(self, device, n_results=2, n_rays=0):
+        """n_rays: size the scratch for DeviceSystem.trace_moments_into of bundles up to n_rays"""
         lib = _lib.load()
         self.device = device
-        self.scratch = torch.empty(lib.prt_moments_scratch_doubles(0), dtype=torch.float64, device=device)
+        self.scratch = torch.empty(max(lib.prt_moments_scratch_doubles(0),
+                                       lib.prt_trace_moments_scratch_doubles(n_rays)),
+                                   dtype=torch.float64, device=device)
         self.out = [torch.zeros(7, dtype=torch.float64, device=device) for _ in range(n_results)]
 
 
@@ -422,6 +446,18 @@ def bundle_moments_async(x, mask, ws, slot=0, mode=0, ref_dev=None, ref_kind=0):
                                                 _ptr(ref_dev), ref_kind, _ptr(ws.out[slot]),
                                                 _ptr(ws.scratch), _stream_handle(x.device)))
     return ws.out[slot]
+
+
+def spot_from_moments(m, ref):
+    """(count, centroid (3,), rms spot radius about the centroid) from one-pass moments
+    {n, S1, S2} taken about ``ref``: centroid = ref + S1/n, rms^2 = (sum S2 - |S1|^2/n)/(n - 1)
+    -- the estimators of RayBundleAnalysis (analysis/ray_analysis.py:44-86; same 1e-17 guards)."""
+    import numpy as np
+    m = np.asarray(m, dtype=float)
+    n = m[0]
+    c = m[1:4] / (n + 1e-17)
+    ss = float(np.sum(m[4:7]) - n * np.sum(c * c))
+    return n, np.asarray(ref, dtype=float) + c, float(np.sqrt(max(ss, 0.0) / (n - 1 + 1e-17)))
 
 
 def poynting_dir(k, e_re=None, e_im=None, default_e=False):

@@ -67,6 +67,15 @@ def _worker(rank, world, port, n_total, q):
         cen_ref = x[:, m].sum(axis=1) / m.sum()
         rms_ref = np.sqrt(((x[:, m] - cen_ref[:, None]) ** 2).sum() / (m.sum() - 1))
         ok = ok and cnt == m.sum() and bool(np.allclose(cen, cen_ref, rtol=1e-13)) and abs(rms - rms_ref) < 1e-13
+        # one-pass form of the fused trace kernel: shard moments about a common reference point,
+        # ONE all-reduce, then spot_from_moments
+        from pyrate_amd.engine import spot_from_moments
+        ref = np.array([0.4, 0.5, 0.6])
+        (c1, s1, s2) = np_moments(torch.from_numpy(x[:, lo:hi].copy()), torch.from_numpy(v[lo:hi].copy()), ref)
+        t = torch.from_numpy(np.concatenate(([c1], s1, s2)))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        (cnt1, cen1, rms1) = spot_from_moments(t.numpy(), ref)
+        ok = ok and cnt1 == m.sum() and bool(np.allclose(cen1, cen_ref, rtol=1e-13)) and abs(rms1 - rms_ref) < 1e-12
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

@@ -201,3 +201,56 @@ def test_async_spot_statistics_and_gather_single_rank(gpu_device):
     assert torch.equal(torch.nan_to_num(gx), torch.nan_to_num(x)) and torch.equal(gv, v)
     assert torch.equal(torch.nan_to_num(gk), torch.nan_to_num(k))
     assert pdist.shard_range(x.shape[1], 0, 1) == (0, x.shape[1])
+
+
+def test_trace_moments_equals_two_pass_statistics(gpu_device):
+    """prt_trace_moments: moments from inside the trace launch == RayBundleAnalysis-style two-pass
+    statistics of the image plane; identical path outputs; bit-reproducible; unaligned fallback"""
+    import torch
+    from pyrate_amd import engine, systems, _lib
+    recs = systems.double_gauss_records()
+    sysd = engine.DeviceSystem(recs, 0)
+    (x0, k0, e0, _) = systems.double_gauss_bundle_device(200000, gpu_device, field_deg=4.0, rpup=25.0)
+    n = x0.shape[1]
+    ws = engine.MomentsWorkspace(gpu_device, n_results=2, n_rays=n)
+    for mode in (_lib.MODE_PATH, _lib.MODE_IMAGE):
+        bufs = sysd.alloc_outputs(n, mode)
+        ref = sysd.alloc_outputs(n, mode)
+        sysd.trace_into(x0, k0, ref, e0)
+        m = sysd.trace_moments_into(x0, k0, bufs, ws, slot=0, e0_re=e0).cpu().numpy().copy()
+        for key in ("x_hit", "k_out"):
+            vb = sysd.views(bufs)
+            vr = sysd.views(ref)
+            assert torch.equal(getattr(vb, key)[-1].contiguous().view(torch.int64),
+                               getattr(vr, key)[-1].contiguous().view(torch.int64))       # bitwise (NaN rows too)
+        assert torch.equal(sysd.views(bufs).valid_out[-1], sysd.views(ref).valid_out[-1])
+        v = sysd.views(ref)
+        (cnt, cen, rms) = engine.spot_from_moments(m, sysd.moments_reference())
+        valid = v.valid_out[-1].cpu().numpy().astype(bool)
+        x = v.x_hit[-1].cpu().numpy()[:, valid]
+        assert 0 < cnt == valid.sum() < n                   # the wide bundle is vignetted
+        c_ref = x.mean(axis=1)
+        rms_ref = np.sqrt(np.sum((x - c_ref[:, None]) ** 2) / (x.shape[1] - 1))
+        c_ref = np.array([math.fsum(row) for row in x]) / x.shape[1]          # exactly rounded sums
+        rms_ref = math.sqrt(math.fsum(((x - c_ref[:, None]) ** 2).ravel()) / (x.shape[1] - 1))
+        assert np.allclose(cen, c_ref, rtol=0, atol=1e-10)
+        assert abs(rms - rms_ref) < 1e-10 * rms_ref
+        m2 = sysd.trace_moments_into(x0, k0, bufs, ws, slot=1, e0_re=e0).cpu().numpy()
+        assert np.array_equal(m, m2)                        # fixed summation order
+    # odd ray count with tight (unaligned rows) buffers -> trace + two-kernel reduction inside the library
+    n_odd = 9999
+    lo = n // 2
+    xo = x0[:, lo:lo + n_odd].contiguous()
+    ko = k0[:, lo:lo + n_odd].contiguous()
+    eo = e0[:, lo:lo + n_odd].contiguous()
+    bufs = sysd.alloc_outputs(n_odd, _lib.MODE_PATH, pitch=n_odd)
+    m = sysd.trace_moments_into(xo, ko, bufs, ws, slot=0, e0_re=eo).cpu().numpy()
+    v = sysd.views(bufs)
+    valid = v.valid_out[-1].cpu().numpy().astype(bool)
+    x = v.x_hit[-1].cpu().numpy()[:, valid]
+    (cnt, cen, rms) = engine.spot_from_moments(m, sysd.moments_reference())
+    assert cnt == valid.sum() and np.allclose(cen, x.mean(axis=1), rtol=0, atol=1e-10)
+    # crystals: not offered
+    sysa = engine.DeviceSystem(systems.aniso_doublet_records(), 0)
+    with pytest.raises(_lib.PrtError):
+        sysa.trace_moments_into(xo, ko, sysa.alloc_outputs(n_odd), ws)
