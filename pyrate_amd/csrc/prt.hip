@@ -365,28 +365,22 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
                         "prt_trace: tables with anisotropic media use the concatenated layout (pitch 0)");
         static const bool per_surface = getenv("PRT_GENERAL_PER_SURFACE") != nullptr;
         int n_aniso = 0;
-        bool general_eps = false;
         for (int s = 0; s < sys->n_surfaces; ++s)
-            if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC) {
-                ++n_aniso;
-                if (sys->h_table[s].aniso_class == PRT_ANISO_GENERAL) general_eps = true;
-            }
-        // The fused march re-traces shared prefixes (2^A leaves per thread).  That pays for the
-        // closed-form crystal classes (measured, 1e6 rays through the doublet of config 4:
-        // 0.44 vs 0.54 ms) but not when every interface runs the iterative quartic solver
-        // (biaxial: 0.60 vs 0.54 ms with the Bairstow solver), nor for many interfaces.
-        if (per_surface || general_eps || n_aniso > 4)
+            if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC) ++n_aniso;
+        // The fused march re-traces shared prefixes (2^(A-1) passes per thread).  Measured at 1e6
+        // rays through the doublet of config 4 against the per-surface march: uniaxial 0.28 vs
+        // 0.41 ms, one biaxial crystal 0.32 vs 0.42 ms, two biaxial crystals 0.35 vs 0.43 ms; for
+        // many interfaces the recomputation grows like 2^(A-1) S and the per-surface march wins.
+        if (per_surface || n_aniso > 4)
             return trace_general(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, e_out, e_out_im, valid, valid_out, st);
         const dim3 grid(nblocks(n0, PRT_BLOCK)), block(PRT_BLOCK);
         const int32_t e_mode_g = e_mode_of(e0_re, 1);
-        if (mode == PRT_MODE_PATH)
-            hipLaunchKernelGGL((k_trace_general<PRT_MODE_PATH>), grid, block, 0, st, sys->d_table,
-                               sys->n_surfaces, n_aniso, n0, x0, k0, e0_re, e0_im, e_mode_g, x_hit, k_out,
-                               e_out, e_out_im, valid, valid_out);
-        else
-            hipLaunchKernelGGL((k_trace_general<PRT_MODE_IMAGE>), grid, block, 0, st, sys->d_table,
-                               sys->n_surfaces, n_aniso, n0, x0, k0, e0_re, e0_im, e_mode_g, x_hit, k_out,
-                               e_out, e_out_im, valid, valid_out);
+#define PRT_LAUNCH_G(KERNEL, MODE_)                                                                     \
+    hipLaunchKernelGGL((KERNEL<MODE_>), grid, block, 0, st, sys->d_table, sys->n_surfaces, n_aniso, n0, \
+                       x0, k0, e0_re, e0_im, e_mode_g, x_hit, k_out, e_out, e_out_im, valid, valid_out)
+        if (mode == PRT_MODE_PATH) PRT_LAUNCH_G(k_trace_general, PRT_MODE_PATH);
+        else PRT_LAUNCH_G(k_trace_general, PRT_MODE_IMAGE);
+#undef PRT_LAUNCH_G
         HIP_TRY(hipGetLastError());
         return PRT_OK;
     }

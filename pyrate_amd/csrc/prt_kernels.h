@@ -208,13 +208,17 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_iso(
 
 // ---------------------------------------------------------------------------
 // fused march through tables that contain anisotropic media (ray doubling).  Thread i owns
-// input ray i and ALL its descendants: with A anisotropic interfaces there are 2^A leaves;
-// leaf L (bit j = which of the two transmitted solutions is followed at the j-th crystal
-// interface) is traced from the start, so no per-ray stack is needed (recomputation instead
-// of 2^A live states; 20 instead of 12 surface steps for the doublet of config 4, but one
-// launch, no intermediate arrays, no direction buffers).  A prefix shared by several leaves
-// is WRITTEN only by the leaf whose remaining bits are zero.  Outputs use the concatenated
-// layout of include/prt.h (rays of a split bundle stacked [sol2, sol3] like np.hstack,
+// input ray i and ALL its descendants: with A anisotropic interfaces there are 2^A leaves,
+// leaf L having bit j = which of the two transmitted solutions is followed at the j-th crystal
+// interface.  No per-ray stack: a pass follows ONE choice at each of the first A-1 crystal
+// interfaces (2^(A-1) passes, each traced from the start) and keeps BOTH solutions of the last
+// one, marching the two children side by side through the remaining (isotropic) surfaces.
+// Recomputation instead of 2^A live states: config 4 (A = 2) costs 4 interface solves + 14
+// surface steps per input ray (minimum 3 + 12; tracing every leaf from the start, the first
+// version of this kernel, cost 8 + 20 and 0.34 instead of 0.28 ms), in one launch, with no
+// intermediate arrays and no direction buffers.  A prefix shared by several leaves is WRITTEN
+// only by the pass whose remaining bits are zero.  Outputs use the concatenated layout of
+// include/prt.h (rays of a split bundle stacked [sol2, sol3] like np.hstack,
 // material_anisotropic.py:89): at a level with a doublings, leaf L sits at i + N (L mod 2^a).
 // ---------------------------------------------------------------------------
 template <int MODE>
@@ -223,8 +227,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_general(
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, double *__restrict__ xh_out,
     double *__restrict__ k_out, double *__restrict__ e_out, double *__restrict__ e_out_im,
-    uint8_t *__restrict__ valid_out_hit,
-    uint8_t *__restrict__ valid_out_refr) {
+    uint8_t *__restrict__ valid_out_hit, uint8_t *__restrict__ valid_out_refr) {
     const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
     if (i >= N) return;
     const vec3 xs = v3(x0[i], x0[N + i], x0[2 * N + i]);
@@ -236,72 +239,107 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_general(
         first_direction<false>(e_mode, e_re, e_im, N, i, false, kk, dd);
         ds = dd[0];
     }
-    const int64_t leaves = (int64_t)1 << A;
-    for (int64_t L = 0; L < leaves; ++L) {
-        vec3 x = xs, k = ks, d = ds;
+    const int64_t passes = (int64_t)1 << (A - 1);
+    for (int64_t P = 0; P < passes; ++P) {
+        vec3 x[2], k[2], d[2];
+        bool valid[2] = {true, true};
+        x[0] = xs;
+        k[0] = ks;
+        d[0] = ds;
         double d2 = 1.0;
-        bool valid = true;  // cumulative mask carried into the next propagate
-        int a = 0;          // doublings so far
+        int a = 0;         // doublings so far
+        int nstate = 1;    // 2 behind the last crystal interface
         int64_t off_in = 0, off_out = 0;
         for (int32_t s = 0; s < S; ++s) {
             const prt_surface_t *__restrict__ sf = tab + s;
-            const int64_t n_in = N << a;
-            const int64_t idx_in = i + N * (L & (((int64_t)1 << a) - 1));
-            const bool alive = valid;
-            vec3 xh, p, g;
-            double g2;
-            propagate_step(sf, x, d, d2, xh, p, g, g2, valid);
             const bool last = (s == S - 1);
-            if ((L >> a) == 0 && (MODE == PRT_MODE_PATH || last)) {
-                double *xo = xh_out + ((MODE == PRT_MODE_PATH) ? 3 * off_in : 0);
-                xo[idx_in] = xh.x;
-                xo[n_in + idx_in] = xh.y;
-                xo[2 * n_in + idx_in] = xh.z;
-                valid_out_hit[((MODE == PRT_MODE_PATH) ? off_in : 0) + idx_in] = valid ? 1 : 0;
-            }
-            int a_out = a;
-            vec3 efield = v3(0, 0, 0), efield_im = v3(0, 0, 0);
+            const bool store = (MODE == PRT_MODE_PATH || last);
             const bool crystal = sf->mat_type == PRT_MAT_ANISOTROPIC;
-            if (crystal) {
-                aniso_solution sol[2];
-                interact_anisotropic(sf, p, k, sol);
-                const bool second = ((L >> a) & 1) != 0;
-                k = second ? sol[1].k : sol[0].k;
-                d = second ? sol[1].d : sol[0].d;
-                efield = second ? sol[1].er : sol[0].er;
-                efield_im = second ? sol[1].ei : sol[0].ei;
-                d2 = 1.0;
-                valid = alive;  // no validity filtering at a crystal interface (ray.py:68)
-                a_out = a + 1;
-            } else {
-                const vec3 n = normal_from_grad(sf, g, g2);
-                interact_isotropic(sf, n, k, valid);
-                d = k;
-                d2 = sf->n_after * sf->n_after;
-            }
+            const int64_t n_in = N << a;
+            const int a_out = crystal ? a + 1 : a;
             const int64_t n_out = N << a_out;
-            if ((L >> a_out) == 0 && (MODE == PRT_MODE_PATH || last)) {
-                const int64_t idx_out = i + N * (L & (((int64_t)1 << a_out) - 1));
-                double *ko = k_out + ((MODE == PRT_MODE_PATH) ? 3 * off_out : 0);
-                ko[idx_out] = k.x;
-                ko[n_out + idx_out] = k.y;
-                ko[2 * n_out + idx_out] = k.z;
-                if (e_out && crystal) {  // E of the rays leaving a crystal interface (same layout as k_out)
-                    double *eo = e_out + ((MODE == PRT_MODE_PATH) ? 3 * off_out : 0);
-                    eo[idx_out] = efield.x;
-                    eo[n_out + idx_out] = efield.y;
-                    eo[2 * n_out + idx_out] = efield.z;
-                    if (e_out_im) {
-                        double *ei = e_out_im + ((MODE == PRT_MODE_PATH) ? 3 * off_out : 0);
-                        ei[idx_out] = efield_im.x;
-                        ei[n_out + idx_out] = efield_im.y;
-                        ei[2 * n_out + idx_out] = efield_im.z;
+            const int64_t base_in = (MODE == PRT_MODE_PATH) ? off_in : 0;
+            const int64_t base_out = (MODE == PRT_MODE_PATH) ? off_out : 0;
+            double *xo = xh_out + 3 * base_in;
+            double *ko = k_out + 3 * base_out;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (c >= nstate) continue;
+                // leaf index of this state: bits 0..A-2 = P, bit A-1 = c
+                const int64_t L = P + ((int64_t)c << (A - 1));
+                const int64_t idx_in = i + N * (L & (((int64_t)1 << a) - 1));
+                const bool alive = valid[c];
+                vec3 xh, p, g;
+                double g2;
+                propagate_step(sf, x[c], d[c], d2, xh, p, g, g2, valid[c]);
+                if ((L >> a) == 0 && store) {
+                    xo[idx_in] = xh.x;
+                    xo[n_in + idx_in] = xh.y;
+                    xo[2 * n_in + idx_in] = xh.z;
+                    valid_out_hit[base_in + idx_in] = valid[c] ? 1 : 0;
+                }
+                x[c] = xh;
+                if (crystal) {  // only reached with nstate == 1 (c == 0)
+                    aniso_solution sol[2];
+                    interact_anisotropic(sf, p, k[0], sol);
+                    valid[0] = alive;  // no validity filtering at a crystal interface (ray.py:68)
+                    const bool keep_both = (a == A - 1);
+                    const int pick = (int)((P >> a) & 1);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        // child b lives at leaf bits (..., bit a = b); written by the pass that owns it
+                        const int64_t Lb = (P & (((int64_t)1 << a) - 1)) + ((int64_t)b << a);
+                        const bool mine = keep_both ? true : (b == pick && (P >> a_out) == 0);
+                        if (mine && store) {
+                            const int64_t idx_out = i + N * Lb;
+                            ko[idx_out] = sol[b].k.x;
+                            ko[n_out + idx_out] = sol[b].k.y;
+                            ko[2 * n_out + idx_out] = sol[b].k.z;
+                            if (e_out) {
+                                double *eo = e_out + 3 * base_out;
+                                eo[idx_out] = sol[b].er.x;
+                                eo[n_out + idx_out] = sol[b].er.y;
+                                eo[2 * n_out + idx_out] = sol[b].er.z;
+                                if (e_out_im) {
+                                    double *ei = e_out_im + 3 * base_out;
+                                    ei[idx_out] = sol[b].ei.x;
+                                    ei[n_out + idx_out] = sol[b].ei.y;
+                                    ei[2 * n_out + idx_out] = sol[b].ei.z;
+                                }
+                            }
+                            if (valid_out_refr) valid_out_refr[base_out + idx_out] = alive ? 1 : 0;
+                        }
+                    }
+                    if (keep_both) {
+                        k[1] = sol[1].k;
+                        d[1] = sol[1].d;
+                        x[1] = xh;
+                        valid[1] = alive;
+                        k[0] = sol[0].k;
+                        d[0] = sol[0].d;
+                    } else {
+                        k[0] = pick ? sol[1].k : sol[0].k;
+                        d[0] = pick ? sol[1].d : sol[0].d;
+                    }
+                } else {
+                    const vec3 n = normal_from_grad(sf, g, g2);
+                    interact_isotropic(sf, n, k[c], valid[c]);
+                    d[c] = k[c];
+                    if ((L >> a_out) == 0 && store) {
+                        const int64_t idx_out = i + N * (L & (((int64_t)1 << a_out) - 1));
+                        ko[idx_out] = k[c].x;
+                        ko[n_out + idx_out] = k[c].y;
+                        ko[2 * n_out + idx_out] = k[c].z;
+                        if (valid_out_refr) valid_out_refr[base_out + idx_out] = valid[c] ? 1 : 0;
                     }
                 }
-                if (valid_out_refr)
-                    valid_out_refr[((MODE == PRT_MODE_PATH) ? off_out : 0) + idx_out] = valid ? 1 : 0;
             }
-            x = xh;
+            if (crystal) {
+                d2 = 1.0;
+                if (a == A - 1) nstate = 2;
+            } else {
+                d2 = sf->n_after * sf->n_after;
+            }
             off_in += n_in;
             off_out += n_out;
             a = a_out;

@@ -142,3 +142,41 @@ def test_random_crystals_match_oracle(gpu_device, seed):
         else:
             assert np.abs(xd[:, v] - xo[:, v]).max() < 1e-9, (seed, s)
             assert np.abs(kd[:, fin] - ko[:, fin]).max() < 1e-10, (seed, s)
+
+
+def test_many_crystal_interfaces_use_the_per_surface_march(gpu_device):
+    """five crystal slabs in a row (32 leaves per input ray): beyond four anisotropic interfaces
+    prt_trace switches from the fused kernel to the per-surface march; both against the oracle,
+    and the two engine paths against each other on a three-slab stack"""
+    from pyrate_amd import engine, systems
+    rng = np.random.RandomState(77)
+
+    def eps():
+        R = rot(rng, 1.0)
+        (no, ne) = (rng.uniform(1.5, 1.7), rng.uniform(1.5, 1.7))
+        return R.dot(np.diag([no ** 2, no ** 2, ne ** 2])).dot(R.T)
+
+    def stack(m):
+        bl = [({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True})]
+        for j in range(m):
+            bl.append(({"shape": "Conic", "curv": (0.004 if j % 2 else -0.003)}, {"decz": 4.0},
+                       {"eps": eps()}, "slab%d" % j, {}))
+        bl.append(({"shape": "Conic", "curv": 0.002}, {"decz": 4.0}, None, "exit", {}))
+        bl.append(({"shape": "Conic"}, {"decz": 30.0}, None, "image", {}))
+        return systems.simple_system_records(bl)
+
+    (o, k, e0) = systems.double_gauss_bundle(40, rpup=3.0, z0=-5.0, field_deg=2.0)
+    dev_rays = [engine.to_device_rays(a, gpu_device, pitched=False) for a in (o, k, e0)]
+    for m in (3, 5):
+        recs = stack(m)
+        with np.errstate(all="ignore"):
+            out = oracle.trace(recs, o, k, e0)
+        res = engine.DeviceSystem(recs, 0).trace(*dev_rays)
+        assert res.x_hit[-1].shape[1] == o.shape[1] * 2 ** m
+        for s in range(len(recs)):
+            v = out[s]["valid"] & np.all(np.isfinite(out[s]["x_hit"]), axis=0)
+            assert np.array_equal(res.valid[s].cpu().numpy().astype(bool)[v], out[s]["valid"][v])
+            assert np.abs(res.x_hit[s].cpu().numpy()[:, v] - out[s]["x_hit"][:, v]).max() < 1e-9, (m, s)
+            ko = np.real(out[s]["k_out"])
+            fin = np.all(np.isfinite(ko), axis=0)
+            assert np.abs(res.k_out[s].cpu().numpy()[:, fin] - ko[:, fin]).max() < 1e-10, (m, s)
