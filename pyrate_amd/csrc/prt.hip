@@ -59,6 +59,33 @@ struct device_guard {
         if (e_ != hipSuccess) return fail(PRT_ERR_DEVICE, #call, e_);   \
     } while (0)
 
+// Stream-ordered scratch memory that is returned on every exit path (also the error returns).
+struct stream_scratch {
+    hipStream_t st;
+    void *ptrs[16];
+    int n = 0;
+    explicit stream_scratch(hipStream_t s) : st(s) {}
+    template <typename T>
+    hipError_t get(T **out, size_t bytes) {
+        *out = nullptr;
+        if (n >= 16) return hipErrorOutOfMemory;
+        hipError_t e = hipMallocAsync((void **)out, bytes ? bytes : 1, st);
+        if (e == hipSuccess) ptrs[n++] = (void *)*out;
+        return e;
+    }
+    ~stream_scratch() {
+        for (int i = 0; i < n; ++i) (void)hipFreeAsync(ptrs[i], st);
+    }
+};
+
+struct event_pair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~event_pair() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
@@ -245,14 +272,15 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
     double *dirbuf[2] = {nullptr, nullptr};
     double *xbuf[2] = {nullptr, nullptr}, *kbuf[2] = {nullptr, nullptr};
     uint8_t *vbuf[2] = {nullptr, nullptr}, *wbuf[2] = {nullptr, nullptr};
-    HIP_TRY(hipMallocAsync((void **)&dirbuf[0], sizeof(double) * 3 * n_final, st));
-    HIP_TRY(hipMallocAsync((void **)&dirbuf[1], sizeof(double) * 3 * n_final, st));
+    stream_scratch scratch(st);
+    HIP_TRY(scratch.get(&dirbuf[0], sizeof(double) * 3 * n_final));
+    HIP_TRY(scratch.get(&dirbuf[1], sizeof(double) * 3 * n_final));
     if (mode == PRT_MODE_IMAGE) {
         for (int b = 0; b < 2; ++b) {
-            HIP_TRY(hipMallocAsync((void **)&xbuf[b], sizeof(double) * 3 * n_final, st));
-            HIP_TRY(hipMallocAsync((void **)&kbuf[b], sizeof(double) * 3 * n_final, st));
-            HIP_TRY(hipMallocAsync((void **)&vbuf[b], n_final, st));
-            HIP_TRY(hipMallocAsync((void **)&wbuf[b], n_final, st));
+            HIP_TRY(scratch.get(&xbuf[b], sizeof(double) * 3 * n_final));
+            HIP_TRY(scratch.get(&kbuf[b], sizeof(double) * 3 * n_final));
+            HIP_TRY(scratch.get(&vbuf[b], n_final));
+            HIP_TRY(scratch.get(&wbuf[b], n_final));
         }
     }
     uint8_t *vo_scratch = nullptr;  // valid_out storage when the caller passed NULL in PATH mode
@@ -265,7 +293,7 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
         }
     }
     if (mode == PRT_MODE_PATH && !valid_out) {
-        HIP_TRY(hipMallocAsync((void **)&vo_scratch, tot_out, st));
+        HIP_TRY(scratch.get(&vo_scratch, tot_out));
         valid_out = vo_scratch;
     }
 
@@ -328,15 +356,7 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
         n = n_o;
     }
     HIP_TRY(hipGetLastError());
-    for (int b = 0; b < 2; ++b) {
-        HIP_TRY(hipFreeAsync(dirbuf[b], st));
-        if (xbuf[b]) HIP_TRY(hipFreeAsync(xbuf[b], st));
-        if (kbuf[b]) HIP_TRY(hipFreeAsync(kbuf[b], st));
-        if (vbuf[b]) HIP_TRY(hipFreeAsync(vbuf[b], st));
-        if (wbuf[b]) HIP_TRY(hipFreeAsync(wbuf[b], st));
-    }
-    if (vo_scratch) HIP_TRY(hipFreeAsync(vo_scratch, st));
-    return PRT_OK;
+    return PRT_OK;  // `scratch` is returned to the stream's pool here (stream-ordered)
 }
 
 int64_t prt_recommended_pitch(int64_t n) {
@@ -507,25 +527,19 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
     if (!sys) return fail(PRT_ERR_INVALID_ARG, "null system");
     PRT_ON_DEVICE(sys->device);
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t a, b;
-    HIP_TRY(hipEventCreate(&a));
-    HIP_TRY(hipEventCreate(&b));
-    HIP_TRY(hipEventRecord(a, st));
+    event_pair ev;
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+    HIP_TRY(hipEventRecord(ev.a, st));
     for (int it = 0; it < iters; ++it) {
         int32_t rc = prt_trace(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out,
                                valid, valid_out, stream);
-        if (rc != PRT_OK) {
-            (void)hipEventDestroy(a);
-            (void)hipEventDestroy(b);
-            return rc;
-        }
+        if (rc != PRT_OK) return rc;
     }
-    HIP_TRY(hipEventRecord(b, st));
-    HIP_TRY(hipEventSynchronize(b));
+    HIP_TRY(hipEventRecord(ev.b, st));
+    HIP_TRY(hipEventSynchronize(ev.b));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
+    HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
     *ms_avg = (double)ms / iters;
     return PRT_OK;
 }
@@ -699,7 +713,8 @@ int32_t prt_path_sums(int32_t device, int32_t n_points, int64_t n, const double 
     PRT_ON_DEVICE(device);
     hipStream_t st = (hipStream_t)stream;
     const double **d_tab = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&d_tab, sizeof(void *) * 2 * n_points, st));
+    stream_scratch scratch_(st);
+    HIP_TRY(scratch_.get(&d_tab, sizeof(void *) * 2 * n_points));
     HIP_TRY(hipMemcpyAsync((void *)d_tab, xs, sizeof(void *) * n_points, hipMemcpyHostToDevice, st));
     if (ks)
         HIP_TRY(hipMemcpyAsync((void *)(d_tab + n_points), ks, sizeof(void *) * n_points,
@@ -708,7 +723,6 @@ int32_t prt_path_sums(int32_t device, int32_t n_points, int64_t n, const double 
                        (const double *const *)d_tab, (const double *const *)(d_tab + n_points), mode, out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));   // the host pointer tables must outlive the copies
-    HIP_TRY(hipFreeAsync((void *)d_tab, st));
     return PRT_OK;
 }
 
@@ -728,7 +742,8 @@ int32_t prt_bundle_moments(int32_t device, int64_t n, int64_t pitch, const doubl
     if (nb > 2048) nb = 2048;
     if (nb < 1) nb = 1;
     double *scratch = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&scratch, sizeof(double) * MOM_VALUES * (nb + 1), st));
+    stream_scratch scratch_(st);
+    HIP_TRY(scratch_.get(&scratch, sizeof(double) * MOM_VALUES * (nb + 1)));
     const double rx = ref ? ref[0] : 0.0, ry = ref ? ref[1] : 0.0, rz = ref ? ref[2] : 0.0;
     hipLaunchKernelGGL(k_moments_partial, dim3(nb), dim3(PRT_BLOCK), 0, st, n, pitch, x, mask, mode, rx,
                        ry, rz, (const double *)nullptr, 0, scratch);
@@ -738,7 +753,6 @@ int32_t prt_bundle_moments(int32_t device, int64_t n, int64_t pitch, const doubl
     HIP_TRY(hipMemcpyAsync(out7, scratch + (int64_t)nb * MOM_VALUES, sizeof(double) * MOM_VALUES,
                            hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipFreeAsync(scratch, st));
     return PRT_OK;
 }
 
