@@ -70,3 +70,49 @@ class RayBundleAnalysis(object):
             return np.zeros(self.raybundle.num_rays)
         rb = self.raybundle
         return engine.path_sums([rb._x[p] for p in idx], [rb._k[p] for p in idx], mode=1).cpu().numpy()
+
+
+class RayPathAnalysis(object):
+    """Optical path quantities along a whole RayPath (reference :169-213): per-ray sums of the
+    bundles' arc lengths / phase differences.  Like in the reference this needs every bundle of
+    the path to hold the same rays (no ray lost on the way); the sums stay on the device until
+    the end."""
+    kind = "raypathanalysis"
+
+    def __init__(self, raypath, name=""):
+        self.raypath = raypath
+        self.name = name
+
+    def _sum(self, first, last, mode):
+        bundles = self.raypath.raybundles
+        total = None
+        for rb in bundles[first:last]:
+            rb._ensure()
+            if len(rb._x) < 2:
+                continue
+            if mode == 0:
+                part = engine.path_sums(list(rb._x), mode=0)
+            else:
+                part = engine.path_sums(list(rb._x), list(rb._k), mode=1)
+            if total is not None and part.shape != total.shape:
+                raise ValueError("operands could not be broadcast together with shapes %s %s"
+                                 % (tuple(total.shape), tuple(part.shape)))
+            total = part if total is None else total + part
+        if total is None:
+            return np.zeros(bundles[0].num_rays)
+        return total.cpu().numpy()
+
+    def get_arc_length(self, first=0, last=None):
+        return self._sum(first, last, 0)
+
+    def get_phase_difference(self, first=0, last=None):
+        return self._sum(first, last, 1)
+
+    def get_relative_phase_difference(self, first=0, last=None, referenceray=None, wavelength=None):
+        """phase difference relative to a chief ray, optionally in units of the wavelength"""
+        out = self.get_phase_difference(first=first, last=last)
+        if referenceray is not None:
+            out = out - out[referenceray]
+        if wavelength is not None:
+            out = out / wavelength
+        return out

@@ -254,3 +254,29 @@ def test_trace_moments_equals_two_pass_statistics(gpu_device):
     sysa = engine.DeviceSystem(systems.aniso_doublet_records(), 0)
     with pytest.raises(_lib.PrtError):
         sysa.trace_moments_into(xo, ko, sysa.alloc_outputs(n_odd), ws)
+
+
+def test_ray_path_analysis_opd(gpu_device):
+    """RayPathAnalysis (ray_analysis.py:169-213) over a traced path == the reference's formulas
+    evaluated on the reference's own bundles of the same system"""
+    from pyrate_amd.raytracer.analysis.ray_analysis import RayPathAnalysis
+    api = zoo.mirror_api()
+    case = _golden.load_case("doublet")
+    (s, seq) = zoo.doublet(api)
+    rp = s.seqtrace(api.RayBundle(x0=case.x0, k0=case.k0, Efield0=case.E0, wave=case.wave), seq)[0]
+    arc = np.zeros(case.x0.shape[1])
+    ph = np.zeros(case.x0.shape[1])
+    for b in case.raw_bundles:
+        (x, k) = (b["x"], np.real(b["k"]))
+        arc += np.sum(np.sqrt(np.sum((x[1:] - x[:-1]) ** 2, axis=1)), axis=0)
+        ph += np.sum(np.sum(x[1:] * k[1:] - x[:-1] * k[:-1], axis=1), axis=0)
+    rpa = RayPathAnalysis(rp)
+    assert np.allclose(rpa.get_arc_length(), arc, rtol=1e-13)
+    assert np.allclose(rpa.get_phase_difference(), ph, rtol=1e-12, atol=1e-12)
+    rel = rpa.get_relative_phase_difference(referenceray=3, wavelength=case.wave)
+    assert rel[3] == 0.0 and np.allclose(rel, (ph - ph[3]) / case.wave, rtol=1e-9, atol=1e-6)
+    # a path that loses rays on the way cannot be summed ray by ray (the reference fails the same way)
+    clipped = _golden.load_case("doublet_clipped")
+    rp2 = s.seqtrace(api.RayBundle(x0=clipped.x0, k0=clipped.k0, Efield0=clipped.E0, wave=clipped.wave), seq)[0]
+    with pytest.raises(ValueError):
+        RayPathAnalysis(rp2).get_arc_length()
