@@ -95,3 +95,37 @@ class OpticalSystemAnalysis(object):
 
     def trace(self, **kwargs):
         return [self.opticalsystem.seqtrace(ib, self.sequence, **kwargs) for ib in self.initial_bundles]
+
+    # ---- convenience wrappers (:193-303); results leave the device only here -----------------
+    def trace_3d_global(self, x0, k0, wave=standard_wavelength, **kwargs):
+        """trace from given start points / wave vectors (E = ey); per field point, per ray path:
+        [(x, k) at the start of every bundle], global coordinates"""
+        self.initial_bundles = [RayBundle(x0=x0, k0=k0, Efield0=None, wave=wave)]
+        return [[[(rb.x[0], rb.k[0]) for rb in rp.raybundles] for rp in fp] for fp in self.trace(**kwargs)]
+
+    def _flat_surfaces(self):
+        out = []
+        for (elem, elemseq) in self.sequence:
+            out += [self.opticalsystem.elements[elem].surfaces[surf] for (surf, _) in elemseq]
+        return out
+
+    def trace_3d_local(self, **kwargs):
+        """as trace_3d_global, each (x, k) pair in the frame of the surface it is paired with
+        (zip of the flattened sequence with the path's bundles, like the reference)"""
+        surfs = self._flat_surfaces()
+        return [[[(sf.rootcoordinatesystem.returnGlobalToLocalPoints(X),
+                   sf.rootcoordinatesystem.returnGlobalToLocalDirections(K))
+                  for (sf, (X, K)) in zip(surfs, rp)] for rp in fp]
+                for fp in self.trace_3d_global(**kwargs)]
+
+    def trace_2d_local(self, **kwargs):
+        """footprints: the x, y components of trace_3d_local"""
+        return [[[(X[:2], K[:2]) for (X, K) in rp] for rp in fp] for fp in self.trace_3d_local(**kwargs)]
+
+    def get_spot(self, raypath):
+        """(image-plane points in the last surface's frame (2, N), RMS spot radius about the centroid)"""
+        from .ray_analysis import RayBundleAnalysis
+        last_surf = self._flat_surfaces()[-1]
+        last_bundle = raypath.raybundles[-1]
+        local = last_surf.rootcoordinatesystem.returnGlobalToLocalPoints(last_bundle.x[-1])
+        return (local[0:2, :], RayBundleAnalysis(last_bundle).get_rms_spot_size_centroid())

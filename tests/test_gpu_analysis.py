@@ -280,3 +280,28 @@ def test_ray_path_analysis_opd(gpu_device):
     rp2 = s.seqtrace(api.RayBundle(x0=clipped.x0, k0=clipped.k0, Efield0=clipped.E0, wave=clipped.wave), seq)[0]
     with pytest.raises(ValueError):
         RayPathAnalysis(rp2).get_arc_length()
+
+
+def test_optical_system_analysis_convenience_traces(gpu_device):
+    """trace_3d_global / trace_3d_local / trace_2d_local / get_spot (optical_system_analysis.py:193-303)"""
+    from pyrate_amd.raytracer.analysis.optical_system_analysis import OpticalSystemAnalysis
+    api = zoo.mirror_api()
+    case = _golden.load_case("doublet")
+    (s, seq) = zoo.doublet(api)
+    osa = OpticalSystemAnalysis(s, seq)
+    g = osa.trace_3d_global(case.x0, np.real(case.k0), wave=case.wave)
+    assert len(g) == 1 and len(g[0]) == 1 and len(g[0][0]) == len(case.raw_bundles)
+    for ((X, K), ref) in zip(g[0][0], case.raw_bundles):
+        assert np.allclose(X, ref["x"][0], rtol=0, atol=1e-11) and np.allclose(K, np.real(ref["k"][0]), atol=1e-12)
+    loc = osa.trace_3d_local(x0=case.x0, k0=np.real(case.k0), wave=case.wave)
+    two = osa.trace_2d_local(x0=case.x0, k0=np.real(case.k0), wave=case.wave)
+    surfs = osa._flat_surfaces()
+    for (j, ((Xl, Kl), (X, K))) in enumerate(zip(loc[0][0], g[0][0])):
+        lc = surfs[j].rootcoordinatesystem
+        assert np.allclose(Xl, lc.returnGlobalToLocalPoints(X)) and np.allclose(two[0][0][j][0], Xl[:2])
+    rp = osa.trace()[0][0]
+    (xy, rms) = osa.get_spot(rp)
+    img = case.raw_bundles[-1]["x"][-1]
+    c = img.mean(axis=1)
+    assert xy.shape == (2, img.shape[1])
+    assert abs(rms - np.sqrt(np.sum((img - c[:, None]) ** 2) / (img.shape[1] - 1))) < 1e-12
