@@ -221,8 +221,11 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_iso(
 // include/prt.h (rays of a split bundle stacked [sol2, sol3] like np.hstack,
 // material_anisotropic.py:89): at a level with a doublings, leaf L sits at i + N (L mod 2^a).
 // ---------------------------------------------------------------------------
+// 3 waves/SIMD: the register allocator lands at 170 VGPRs on its own (2 waves); capping it at 168
+// costs three spilled dwords and gains 11 % (0.277 -> 0.246 ms); 4 waves (128 VGPRs, 160 B of
+// scratch) is slower than either (0.36 ms).
 template <int MODE>
-__global__ __launch_bounds__(PRT_BLOCK) void k_trace_general(
+__global__ __launch_bounds__(PRT_BLOCK, 3) void k_trace_general(
     const prt_surface_t *__restrict__ tab, int32_t S, int32_t A, int64_t N,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, double *__restrict__ xh_out,
