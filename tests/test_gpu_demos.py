@@ -49,3 +49,26 @@ def test_smoke_optimize_asphere(gpu_device):
     from demos import demo_optimize_asphere
     (m0, m1) = demo_optimize_asphere.main(maxiter=150)
     assert m1 < 0.5 * m0
+
+
+def test_smoke_zmx(gpu_device, capsys):
+    """demos/demo_zmx.py on the reference's own lenssystem.ZMX: four object-height fields"""
+    from demos import demo_zmx
+    res = demo_zmx.main(nrays=500)
+    assert len(res) == 4 and all(n > 0 for (n, _) in res)
+    assert capsys.readouterr().out.count("RMS spot") == 4
+
+
+def test_smoke_spd(gpu_device, tmp_path, capsys):
+    """demos/demo_spd.py on a synthetic WinLens file of the double Gauss: the traced chief-ray
+    heights follow the file's paraxial image heights"""
+    import systems_zoo as zoo
+    from demos import demo_spd
+    f = str(tmp_path / "dg.spd")
+    zoo.synthetic_double_gauss_spd(f)
+    res = demo_spd.main(f, nrays=500)
+    assert len(res) == 9
+    for (fpy, cy, rms) in res:
+        assert rms < 0.2
+    out = capsys.readouterr().out
+    assert "efl 115.74" in out
