@@ -501,6 +501,32 @@ def efield_perp(k):
     return e
 
 
+PINNED_D2H_MIN_BYTES = 1 << 20
+
+
+def stack_to_host(tensors):
+    """(P, R, N) NumPy array of P equally shaped device tensors (R, N) -- the reference's array
+    layout.  Large results are copied straight into ONE page-locked buffer (torch's caching host
+    allocator; the returned array is a view of it), which avoids the pageable-memory bounce of
+    ``.cpu()`` and the extra np.stack copy."""
+    import numpy as np
+    tensors = list(tensors)
+    if not tensors:
+        return np.zeros((0,))
+    t0 = tensors[0]
+    nbytes = len(tensors) * t0.numel() * t0.element_size()
+    if not t0.is_cuda or nbytes < PINNED_D2H_MIN_BYTES:
+        return np.stack([t.cpu().numpy() for t in tensors])
+    try:
+        out = torch.empty((len(tensors),) + tuple(t0.shape), dtype=t0.dtype, pin_memory=True)
+    except RuntimeError:          # no page-locked memory left: pageable copies
+        return np.stack([t.cpu().numpy() for t in tensors])
+    for (p, t) in enumerate(tensors):
+        out[p].copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t0.device).synchronize()
+    return out.numpy()
+
+
 def to_device_rays(a, device, pitched=True):
     """numpy (3, N) real or zero-imaginary complex -> float64 device tensor.  With
     ``pitched`` the rows live in a (3, prt_recommended_pitch(N)) allocation (the returned

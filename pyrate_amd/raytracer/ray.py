@@ -146,7 +146,7 @@ class RayBundle(object):
     # -- reference-shaped NumPy views ------------------------------------------
     def _stack(self, key, tensors):
         if key not in self._cache:
-            self._cache[key] = np.stack([t.cpu().numpy() for t in tensors])
+            self._cache[key] = engine.stack_to_host(tensors)
         return self._cache[key]
 
     @property
@@ -310,7 +310,7 @@ class RayBundle(object):
         """unit Poynting directions for all stored points, (P,3,N) (ray.py:136-152); computed
         on the device (prt_poynting_dir), returned as NumPy like the reference"""
         self._ensure()
-        return np.stack([self.direction_dev(p).cpu().numpy() for p in range(len(self._x))])
+        return engine.stack_to_host([self.direction_dev(p) for p in range(len(self._x))])
 
 
 class RayPath(object):
