@@ -46,8 +46,8 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 1
-#define PRT_MAX_COEFFS 40 /* asphere A2.. coefficients or XY-polynomial terms */
+#define PRT_ABI_VERSION 2
+#define PRT_MAX_COEFFS 128 /* asphere A2.. coefficients and / or XY-polynomial terms */
 
 /* ---- error codes ---------------------------------------------------- */
 #define PRT_OK 0
@@ -58,7 +58,15 @@ extern "C" {
 #define PRT_ERR_NOMEM (-5)
 
 /* ---- enums (int32 in the POD) --------------------------------------- */
-enum { PRT_SHAPE_CONIC = 0, PRT_SHAPE_ASPHERE = 1, PRT_SHAPE_XYPOLY = 2, PRT_SHAPE_BICONIC = 3 };
+enum {
+    PRT_SHAPE_CONIC = 0,
+    PRT_SHAPE_ASPHERE = 1,
+    PRT_SHAPE_XYPOLY = 2,  /* also the Zernike shapes: the host expands them into monomials */
+    PRT_SHAPE_BICONIC = 3,
+    PRT_SHAPE_COMBO = 4    /* asphere_scale * asphere(x, y) + xy polynomial: LinearCombination of
+                              explicit shapes whose frames differ by translations
+                              (surface_shape.py:709-775) */
+};
 enum { PRT_AP_NONE = 0, PRT_AP_CIRCULAR = 1, PRT_AP_RECTANGULAR = 2 };
 enum { PRT_REFRACT = 0, PRT_MIRROR = 1 };
 enum { PRT_MAT_ISOTROPIC = 0, PRT_MAT_ANISOTROPIC = 1 };
@@ -106,6 +114,10 @@ typedef struct prt_surface {
      * c = aniso_axis (unit, material frame);  GENERAL: anything else. */
     double aniso_eo, aniso_ee, aniso_axis[3];
     double curv_y, cc_y; /* biconic: curvature and conic constant of the y section         */
+    /* COMBO: coeffs[0 .. n_asphere) are the asphere's A2, A4, ...; coeffs[n_asphere .. n_coeffs)
+     * with xpow / ypow are the XY terms; the conic + asphere part is multiplied by asphere_scale */
+    int32_t n_asphere, pad_;
+    double asphere_scale;
 } prt_surface_t;
 
 typedef struct prt_system prt_system_t; /* opaque: device copy of a surface table */

@@ -50,7 +50,8 @@ from pyrateoptics.raytracer.optical_element import OpticalElement  # noqa: E402
 from pyrateoptics.raytracer.optical_system import OpticalSystem  # noqa: E402
 from pyrateoptics.raytracer.ray import RayBundle  # noqa: E402
 from pyrateoptics.raytracer.surface import Surface  # noqa: E402
-from pyrateoptics.raytracer.surface_shape import Asphere, Conic, XYPolynomials  # noqa: E402
+from pyrateoptics.raytracer.surface_shape import (Asphere, Conic, LinearCombination, XYPolynomials,  # noqa: E402
+                                                   ZernikeANSI, ZernikeFringe)
 from pyrateoptics.sampling2d import raster  # noqa: E402
 
 from pyrate_amd import systems  # noqa: E402
@@ -105,6 +106,7 @@ def disk_bundle(nrays, rpup, z0, field_deg=0.0, wave=DLINE, efield="kxex", yshif
 REFAPI = types.SimpleNamespace(
     OpticalSystem=OpticalSystem, OpticalElement=OpticalElement, LocalCoordinates=LocalCoordinates,
     Surface=Surface, Conic=Conic, Asphere=Asphere, XYPolynomials=XYPolynomials,
+    ZernikeFringe=ZernikeFringe, ZernikeANSI=ZernikeANSI, LinearCombination=LinearCombination,
     CircularAperture=CircularAperture, RectangularAperture=RectangularAperture,
     ConstantIndexGlass=ConstantIndexGlass, ModelGlass=ModelGlass,
     AnisotropicMaterial=AnisotropicMaterial, RayBundle=RayBundle,
@@ -153,6 +155,44 @@ def case_biconic():
     (s, seq) = build_simple_optical_system(zoo.biconic_builduplist())
     dump_case("biconic_axis", s, seq, disk_bundle(96, 8.0, -5.0))
     dump_case("biconic_field5", s, seq, disk_bundle(96, 8.0, -5.0, field_deg=5.0))
+
+
+def case_zernike():
+    """Zernike series surfaces (fringe and ANSI indexing) in transmission, a decentred
+    LinearCombination(Asphere + ZernikeFringe) mirror, and the reference's getSag / getGrad of these
+    shapes on scattered points (no point at the origin of a Zernike frame: 0/0 there)"""
+    (s, seq) = build_simple_optical_system(zoo.zernike_builduplist("Fringe"))
+    dump_case("zernike_fringe_field3", s, seq, disk_bundle(80, 7.5, -5.0, field_deg=3.0))
+    (s, seq) = build_simple_optical_system(zoo.zernike_builduplist("ANSI"))
+    dump_case("zernike_ansi_field2", s, seq, disk_bundle(80, 7.5, -5.0, field_deg=-2.0))
+    (s, seq) = zoo.zernike_combination_system(REFAPI)
+    dump_case("zernike_combination_mirror", s, seq, disk_bundle(80, 8.0, 0.0, field_deg=1.5))
+    rng = np.random.RandomState(4)
+    (x, y) = (rng.uniform(-8, 8, 64), rng.uniform(-8, 8, 64))
+    out = {"x": x, "y": y}
+    lc = LocalCoordinates.p(name="zshape")
+    lcz = lc.addChild(LocalCoordinates.p(name="zshape_dec", decx=0.7, decy=-1.1))
+    shapes = {"fringe": ZernikeFringe.p(lc, normradius=9.0, coefficients=zoo.ZERNIKE_FRINGE_COEFFS),
+              "ansi": ZernikeANSI.p(lc, normradius=9.0, coefficients=zoo.ZERNIKE_ANSI_COEFFS),
+              "combination": LinearCombination.p(lc, list_of_coefficients_and_shapes=[
+                  (0.8, Asphere.p(lc, curv=-1. / 90., cc=-0.8, coefficients=[0.0, 2e-6])),
+                  (1.3, ZernikeFringe.p(lcz, normradius=12.0, coefficients=zoo.ZERNIKE_FRINGE_COEFFS[:12]))])}
+    from pyrate_amd.surface_table import describe_shape
+    recs = {}
+    for (key, sh) in shapes.items():
+        out[key + "_sag"] = sh.getSag(x, y)
+        out[key + "_grad"] = sh.getGrad(x, y)
+        # derivative of the reference's OWN sag by a 4th-order central difference (its gradzernike
+        # is not that derivative for m != 0, see oracle/seqtrace_np.py: zernike_grad)
+        h = 1e-3
+        out[key + "_dsag_dx"] = (-sh.getSag(x + 2 * h, y) + 8 * sh.getSag(x + h, y) - 8 * sh.getSag(x - h, y)
+                                 + sh.getSag(x - 2 * h, y)) / (12 * h)
+        out[key + "_dsag_dy"] = (-sh.getSag(x, y + 2 * h) + 8 * sh.getSag(x, y + h) - 8 * sh.getSag(x, y - h)
+                                 + sh.getSag(x, y - 2 * h)) / (12 * h)
+        recs[key] = describe_shape(sh)
+    out["records_json"] = np.array(json.dumps(recs))
+    np.savez_compressed(os.path.join(OUT, "zernike_shapes.npz"), **out)
+    print("zernike_shapes.npz: %s" % ", ".join(shapes.keys()))
 
 
 def case_tilted():
@@ -362,6 +402,7 @@ def main():
     case_asphere()
     case_xypoly()
     case_biconic()
+    case_zernike()
     case_tilted()
     case_mirror()
     case_hud()

@@ -23,6 +23,8 @@ c_double_p = ctypes.c_void_p      # device pointers travel as raw addresses
 c_u8_p = ctypes.c_void_p
 c_stream = ctypes.c_void_p
 
+ABI_VERSION = 2          # PRT_ABI_VERSION of include/prt.h
+
 # name -> (restype, argtypes); must list every symbol declared in include/prt.h
 PROTOTYPES = {
     "prt_abi_version": (ctypes.c_int32, []),
@@ -145,6 +147,9 @@ def load():
                               % (LIB_PATH, name))
         fn.restype = restype
         fn.argtypes = argtypes
+    if lib.prt_abi_version() != ABI_VERSION:
+        raise ImportError("pyrate_amd: %s has ABI version %d, this package needs %d (stale build?)"
+                          % (LIB_PATH, lib.prt_abi_version(), ABI_VERSION))
     if lib.prt_sizeof_surface() != ctypes.sizeof(PrtSurface):
         raise ImportError("pyrate_amd: prt_surface_t layout mismatch: C %d bytes, ctypes %d"
                           % (lib.prt_sizeof_surface(), ctypes.sizeof(PrtSurface)))

@@ -161,13 +161,17 @@ const char *prt_last_error(void) { return g_err; }
 
 static int32_t check_record(const prt_surface_t *r, int idx) {
     char msg[128];
-    if (r->shape_type < PRT_SHAPE_CONIC || r->shape_type > PRT_SHAPE_BICONIC) {
+    if (r->shape_type < PRT_SHAPE_CONIC || r->shape_type > PRT_SHAPE_COMBO) {
         snprintf(msg, sizeof msg, "surface %d: unknown shape_type %d", idx, r->shape_type);
         return fail(PRT_ERR_UNSUPPORTED, msg);
     }
     if (r->n_coeffs < 0 || r->n_coeffs > PRT_MAX_COEFFS ||
         (r->shape_type == PRT_SHAPE_BICONIC && 2 * r->n_coeffs > PRT_MAX_COEFFS)) {
         snprintf(msg, sizeof msg, "surface %d: n_coeffs %d out of range", idx, r->n_coeffs);
+        return fail(PRT_ERR_INVALID_ARG, msg);
+    }
+    if (r->shape_type == PRT_SHAPE_COMBO && (r->n_asphere < 0 || r->n_asphere > r->n_coeffs)) {
+        snprintf(msg, sizeof msg, "surface %d: n_asphere %d out of range", idx, r->n_asphere);
         return fail(PRT_ERR_INVALID_ARG, msg);
     }
     if (r->ap_type < PRT_AP_NONE || r->ap_type > PRT_AP_RECTANGULAR ||

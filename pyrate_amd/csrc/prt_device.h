@@ -160,13 +160,12 @@ PRT_DEV double conic_sag(double c, double cc, double r2) {
 //   F  = c r2/(1+sq) + sum_n a_n r2^(n+1)
 //   Fx = x (c/sq + sum_n 2(n+1) a_n r2^n),   gradient of z-F = (-Fx, -Fy, 1)
 // Horner in r2 (the reference sums the powers; same polynomial).
-PRT_DEV void asphere_eval(const prt_surface_t *__restrict__ sf, double x, double y, double &F,
+PRT_DEV void asphere_eval(const prt_surface_t *__restrict__ sf, int nc, double x, double y, double &F,
                           double &dFdr2x2 /* Fx = x * this */) {
     const double c = sf->curv, cc = sf->cc;
     const double r2 = x * x + y * y;
     const double sq = fast_sqrt(1.0 - c * c * (1.0 + cc) * r2);
     double p = 0.0, dp = 0.0;  // p = sum a_n r2^n ; dp = sum (n+1) a_n r2^n
-    const int nc = sf->n_coeffs;
     for (int n = nc - 1; n >= 0; --n) {
         const double a = sf->coeffs[n];
         p = p * r2 + a;
@@ -179,13 +178,12 @@ PRT_DEV void asphere_eval(const prt_surface_t *__restrict__ sf, double x, double
 // XYPolynomials.F / gradF, surface_shape.py:785-807.  coeffs[] already hold
 // c / normradius^(i+j) (host side).  Powers by repeated multiplication with
 // wave-uniform trip counts.
-PRT_DEV void xypoly_eval(const prt_surface_t *__restrict__ sf, double x, double y, double &F,
-                         double &Fx, double &Fy) {
+PRT_DEV void xypoly_eval(const prt_surface_t *__restrict__ sf, int t0, int nt, double x, double y,
+                         double &F, double &Fx, double &Fy) {
     F = 0.0;
     Fx = 0.0;
     Fy = 0.0;
-    const int nt = sf->n_coeffs;
-    for (int t = 0; t < nt; ++t) {
+    for (int t = t0; t < nt; ++t) {
         const int i = sf->xpow[t], j = sf->ypow[t];
         const double c = sf->coeffs[t];
         double xm1 = 1.0, ym1 = 1.0;  // x^(i-1), y^(j-1)
@@ -234,13 +232,23 @@ PRT_DEV void explicit_eval(const prt_surface_t *__restrict__ sf, double x, doubl
                            double &Fx, double &Fy) {
     if (sf->shape_type == PRT_SHAPE_ASPHERE) {
         double m;
-        asphere_eval(sf, x, y, F, m);
+        asphere_eval(sf, sf->n_coeffs, x, y, F, m);
         Fx = x * m;
         Fy = y * m;
     } else if (sf->shape_type == PRT_SHAPE_BICONIC) {
         biconic_eval(sf, x, y, F, Fx, Fy);
+    } else if (sf->shape_type == PRT_SHAPE_COMBO) {
+        // LinearCombination.F / gradF (surface_shape.py:713-748) of one conic / asphere part and
+        // polynomial parts, merged by the host: scale * asphere + sum c_ij x^i y^j
+        double Fa, m;
+        asphere_eval(sf, sf->n_asphere, x, y, Fa, m);
+        xypoly_eval(sf, sf->n_asphere, sf->n_coeffs, x, y, F, Fx, Fy);
+        const double sc = sf->asphere_scale;
+        F += sc * Fa;
+        Fx += sc * x * m;
+        Fy += sc * y * m;
     } else {
-        xypoly_eval(sf, x, y, F, Fx, Fy);
+        xypoly_eval(sf, 0, sf->n_coeffs, x, y, F, Fx, Fy);
     }
 }
 

@@ -11,8 +11,8 @@ graph with the reference's conventions:
 * ``TYPE`` STANDARD -> Conic, EVENASPH -> Asphere with ``PARM 1..8`` as A2..A16,
   BICONICX -> Biconic (``PARM 1`` = Rx, ``PARM 2`` = ccx), COORDBRK -> a shapeless surface in a
   frame with ``PARM 1..5`` = decx, decy, tiltx, tilty, tiltz [deg] and ``PARM 6`` = order flag
-  (zmx.py:788-814); Zernike fringe sag and grid sag surfaces are outside the engine's shape
-  set and raise ``UnsupportedError``;
+  (zmx.py:788-814), FZERNSAG -> LinearCombination of an Asphere and a decentred ZernikeFringe
+  (:723-760); grid sag surfaces are outside the engine's shape set and raise ``UnsupportedError``;
 * ``GLAS MIRROR`` -> ``is_mirror`` with the medium unchanged; a name found in ``matdict`` ->
   that material; model glasses (code 1) -> ConstantIndexGlass(nd) when vd = 0, otherwise a
   Conrady ModelGlass on the normal line (the reference's ``calcCoefficientsFrom_nd_vd`` calls a
@@ -37,7 +37,7 @@ from ..material.material_isotropic import ConstantIndexGlass, ModelGlass
 from ..optical_element import OpticalElement
 from ..optical_system import OpticalSystem
 from ..surface import Surface
-from ..surface_shape import Asphere, Biconic, Conic
+from ..surface_shape import Asphere, Biconic, Conic, LinearCombination, ZernikeFringe
 
 
 def conrady_from_nd_vd(nd, vd, PgF=None):
@@ -222,9 +222,23 @@ class ZMXParser(object):
             rx = parm.get(1, 0.0)
             return Biconic.p(lc, curvy=curv, ccy=conic,
                              curvx=(0.0 if abs(rx) < 1e-16 else 1. / rx), ccx=parm.get(2, 0.0))
-        if typ in ("FZERNSAG", "GRID_SAG"):
-            raise UnsupportedError("ZMX surface type %s (surface %d) is outside the engine's shape set "
-                                   "(Conic, Asphere, Biconic, XYPolynomials)" % (typ, surf.number))
+        if typ == "FZERNSAG":
+            # Zernike fringe sag = even asphere + fringe Zernike series in a decentred frame
+            # (PARM 9, 10); XDAT 1 = number of terms, XDAT 2 = norm radius, XDAT 3.. = coefficients
+            # (zmx.py:723-760)
+            xdat = surf.numbered("XDAT", (float, int, int, float))
+            numterms = int(xdat[1][0])
+            normradius = xdat[2][0]
+            zcoeffs = [xdat[i + 3][0] if (i + 3) in xdat else 0.0 for i in range(numterms)]
+            lcz = lc.addChild(LocalCoordinates.p(name="surf%d_zerndec" % surf.number,
+                                                 decx=parm.get(9, 0.0), decy=parm.get(10, 0.0)))
+            return LinearCombination.p(lc, list_of_coefficients_and_shapes=[
+                (1.0, Asphere.p(lc, curv=curv, cc=conic, name="surf%d_zernasph" % surf.number)),
+                (1.0, ZernikeFringe.p(lcz, normradius=normradius, coefficients=zcoeffs,
+                                      name="surf%d_zernike" % surf.number))])
+        if typ == "GRID_SAG":
+            raise UnsupportedError("ZMX surface type GRID_SAG (surface %d) is outside the engine's shape set"
+                                   % surf.number)
         return None                                       # COORDBRK and unknown types: plane
 
     def create_optical_system(self, matdict=None, options=None, elementname="zmxelem"):

@@ -32,9 +32,13 @@ import ctypes
 
 import numpy as np
 
-PRT_MAX_COEFFS = 40
+from . import polyshape
 
-SHAPE_CODES = {"conic": 0, "asphere": 1, "xypoly": 2, "biconic": 3}
+PRT_MAX_COEFFS = 128
+
+# record type -> prt_surface_t.shape_type ("zernike" is expanded into monomials, "combination" into
+# one conic / asphere part plus monomials: see pack_record)
+SHAPE_CODES = {"conic": 0, "asphere": 1, "xypoly": 2, "biconic": 3, "zernike": 2, "combination": 4}
 AP_CODES = {"none": 0, "circular": 1, "rectangular": 2}
 INTERACTION_CODES = {"refract": 0, "mirror": 1}
 MAT_CODES = {"isotropic": 0, "anisotropic": 1}
@@ -77,6 +81,9 @@ class PrtSurface(ctypes.Structure):
         ("aniso_axis", ctypes.c_double * 3),
         ("curv_y", ctypes.c_double),
         ("cc_y", ctypes.c_double),
+        ("n_asphere", ctypes.c_int32),
+        ("pad_", ctypes.c_int32),
+        ("asphere_scale", ctypes.c_double),
     ]
 
 
@@ -112,8 +119,27 @@ def describe_shape(shape):
         (curvx, curvy, ccx, ccy, coeffs) = shape.getBiconicParameters()
         return {"type": "biconic", "curvx": float(curvx), "curvy": float(curvy), "ccx": float(ccx),
                 "ccy": float(ccy), "coeffs": [[float(a), float(b)] for (a, b) in coeffs]}
+    if kind in ("shape_ZernikeFringe", "shape_ZernikeANSI"):
+        (normradius, zcoeffs) = shape.getZernikeParameters()
+        return {"type": "zernike", "indexing": "fringe" if kind.endswith("Fringe") else "ansi",
+                "normradius": float(normradius), "coeffs": [float(c) for c in zcoeffs]}
+    if kind == "shape_LinearCombination":
+        # sum_i c_i F_i evaluated in each part's own frame (surface_shape.py:713-730); the frames may
+        # differ from the combination's by a translation only
+        parts = []
+        for (coefficient, part) in zip(shape.annotations["list_shape_coefficients"], shape.list_shapes):
+            rel = np.asarray(shape.lc.localbasis).T.dot(np.asarray(part.lc.localbasis))
+            if not np.allclose(rel, np.eye(3), rtol=0, atol=1e-14):
+                raise UnsupportedError("LinearCombination: part %r is rotated against the combination's "
+                                       "frame" % getattr(part, "name", part))
+            offset = np.asarray(shape.lc.localbasis).T.dot(
+                np.asarray(part.lc.globalcoordinates) - np.asarray(shape.lc.globalcoordinates))
+            parts.append({"coefficient": float(coefficient), "offset": _vec3(offset),
+                          "shape": describe_shape(part)})
+        return {"type": "combination", "parts": parts}
     raise UnsupportedError("shape kind %r is outside the HIP engine's scope "
-                           "(Conic, Asphere, Biconic, XYPolynomials)" % (kind,))
+                           "(Conic, Asphere, Biconic, XYPolynomials, ZernikeFringe, ZernikeANSI, "
+                           "LinearCombination of those)" % (kind,))
 
 
 def describe_aperture(aperture):
@@ -221,6 +247,51 @@ def _is_identity(m):
     return bool(np.array_equal(np.asarray(m, dtype=float).reshape(3, 3), np.eye(3)))
 
 
+def _store_monomials(r, mono, first):
+    keys = sorted(k for (k, c) in mono.items() if c != 0.0)
+    if first + len(keys) > PRT_MAX_COEFFS:
+        raise UnsupportedError("polynomial surface with more than %d terms" % PRT_MAX_COEFFS)
+    for (q, (i, j)) in enumerate(keys):
+        r.xpow[first + q], r.ypow[first + q] = i, j
+        r.coeffs[first + q] = mono[(i, j)]
+    r.n_coeffs = first + len(keys)
+
+
+def _pack_combination(r, shape):
+    """LinearCombination -> asphere_scale * asphere(x, y) + sum c_ij x^i y^j: at most one conic /
+    asphere part (centred on the combination's axis), any number of polynomial parts (XYPolynomials,
+    Zernike) whose translated frames are absorbed by expanding p(x - dx, y - dy); the z offsets of
+    the frames and of nothing else add a constant."""
+    mono = {}
+    asph = None
+    for part in shape["parts"]:
+        (c, (dx, dy, dz), sh) = (part["coefficient"], part["offset"], part["shape"])
+        if sh["type"] in ("conic", "asphere"):
+            if asph is not None or dx != 0.0 or dy != 0.0:
+                raise UnsupportedError("LinearCombination: one conic / asphere part, centred on the axis")
+            asph = (c, sh)
+        elif sh["type"] == "xypoly":
+            polyshape.add_scaled(mono, polyshape.shifted(polyshape.xy_terms(sh["normradius"], sh["terms"]),
+                                                         dx, dy), c)
+        elif sh["type"] == "zernike":
+            polyshape.add_scaled(mono, polyshape.shifted(
+                polyshape.zernike_terms(sh["indexing"], sh["normradius"], sh["coeffs"]), dx, dy), c)
+        else:
+            raise UnsupportedError("LinearCombination of a %s shape" % sh["type"])
+        if dz != 0.0:
+            mono[(0, 0)] = mono.get((0, 0), 0.0) + c * dz
+    (r.curv, r.cc, r.n_asphere, r.asphere_scale) = (0.0, 0.0, 0, 0.0)
+    if asph is not None:
+        (c, sh) = asph
+        coeffs = list(sh.get("coeffs", []))
+        while coeffs and coeffs[-1] == 0.0:
+            coeffs.pop()
+        (r.curv, r.cc, r.n_asphere, r.asphere_scale) = (sh["curv"], sh["cc"], len(coeffs), c)
+        for (q, a) in enumerate(coeffs):
+            r.coeffs[q] = a
+    _store_monomials(r, mono, r.n_asphere)
+
+
 def pack_record(rec, out=None):
     r = out if out is not None else PrtSurface()
     shape = rec["shape"]
@@ -246,7 +317,7 @@ def pack_record(rec, out=None):
         for (q, (a, b)) in enumerate(pairs):
             r.coeffs[2 * q] = a
             r.coeffs[2 * q + 1] = b
-    else:
+    elif shape["type"] == "xypoly":
         terms = shape["terms"]
         if len(terms) > PRT_MAX_COEFFS:
             raise UnsupportedError("XY polynomial with more than %d terms" % PRT_MAX_COEFFS)
@@ -257,6 +328,12 @@ def pack_record(rec, out=None):
                 raise UnsupportedError("negative power in XY polynomial")
             r.xpow[q], r.ypow[q] = int(i), int(j)
             r.coeffs[q] = c * (1. / nr ** (int(i) + int(j)))   # surface_shape.py:791
+    elif shape["type"] == "zernike":
+        mono = polyshape.zernike_terms(shape["indexing"], shape["normradius"], shape["coeffs"])
+        r.curv, r.cc = 0.0, 0.0
+        _store_monomials(r, mono, 0)
+    else:
+        _pack_combination(r, shape)
     ap = rec["aperture"]
     r.ap_type = AP_CODES[ap["type"]]
     if ap["type"] == "circular":

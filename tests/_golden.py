@@ -23,11 +23,21 @@ ISO_CASES = ["doublet", "doublet_clipped", "double_gauss_axis", "double_gauss_fi
              "spd_double_gauss_Fline"]
 EXPLICIT_CASES = ["asphere_mild_axis", "asphere_mild_field5", "asphere_strong_axis",
                   "asphere_strong_field5", "xypoly_axis", "xypoly_field5", "biconic_axis",
-                  "biconic_field5", "hud_biconic_mirrors", "zmx_lenssystem"]
+                  "biconic_field5", "hud_biconic_mirrors", "zmx_lenssystem",
+                  "zernike_fringe_field3", "zernike_ansi_field2", "zernike_combination_mirror"]
 ANISO_CASES = ["aniso_doublet_isoeps", "aniso_doublet_uniaxial", "aniso_doublet_biaxial",
                "aniso_doublet_uniaxial_clipped", "aniso_doublet_uniaxial_stopped",
                "aniso_mirror_uniaxial", "aniso_mirror_biaxial"]
 ALL_CASES = ISO_CASES + EXPLICIT_CASES + ANISO_CASES
+
+# The reference's Zernike gradient (surface_shape.py:1073-1084) is not the derivative of its own sag
+# for terms with m != 0 (angular part divided by rho instead of rho**2; pinned by
+# test_zernike_and_combination_shapes_equal_reference), so its surface normals -- and everything
+# behind the refraction / reflection at such a surface -- are not a parity target.  Value: index of
+# the first surface of the case with such a shape; the comparison against the reference covers the
+# hit points up to and including that surface, the rest is covered by HIP-vs-oracle.
+REFERENCE_NORMAL_DEFECT = {"zernike_fringe_field3": 2, "zernike_ansi_field2": 2,
+                           "zernike_combination_mirror": 0}
 
 
 class Case(object):
@@ -121,6 +131,7 @@ def compare_dense_to_reference(case, dense, rtol_x=1e-10, atol_k=1e-10, explicit
     max_abs_k = 0.0
     ncmp = 0
     extra_x = None          # per reference-slot extra absolute tolerance (explicit shapes)
+    last_trusted = REFERENCE_NORMAL_DEFECT.get(case.name)
     for s in range(S):
         B = b[s + 1]
         d = dense[s]
@@ -145,6 +156,8 @@ def compare_dense_to_reference(case, dense, rtol_x=1e-10, atol_k=1e-10, explicit
             rel = np.max(err / scale)
             max_rel_x = max(max_rel_x, float(rel))
             ncmp += int(np.sum(cmp_mask))
+        if last_trusted is not None and s == last_trusted:
+            break
         # ---- the bundle created by refract / reflect at this surface
         Bn = b[s + 2]
         aniso = case.table[s]["material"]["type"] == "anisotropic"

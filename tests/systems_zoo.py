@@ -21,7 +21,8 @@ def mirror_api():
         OpticalSystem=optical_system.OpticalSystem, OpticalElement=optical_element.OpticalElement,
         LocalCoordinates=localcoordinates.LocalCoordinates, Surface=surface.Surface,
         Conic=surface_shape.Conic, Asphere=surface_shape.Asphere, XYPolynomials=surface_shape.XYPolynomials,
-        Biconic=surface_shape.Biconic,
+        Biconic=surface_shape.Biconic, ZernikeFringe=surface_shape.ZernikeFringe,
+        ZernikeANSI=surface_shape.ZernikeANSI, LinearCombination=surface_shape.LinearCombination,
         CircularAperture=aperture.CircularAperture, RectangularAperture=aperture.RectangularAperture,
         ConstantIndexGlass=material_isotropic.ConstantIndexGlass, ModelGlass=material_isotropic.ModelGlass,
         AnisotropicMaterial=material_anisotropic.AnisotropicMaterial, RayBundle=ray.RayBundle,
@@ -165,6 +166,47 @@ def xypoly_builduplist():
          {"decz": 12.0}, None, "back", {}),
         ({"shape": "Conic"}, {"decz": 80.0}, None, "image", {}),
     ]
+
+
+ZERNIKE_FRINGE_COEFFS = [0.0, 0.02, -0.015, 0.04, -0.03, 0.02, 0.012, -0.01, 0.008, 0.0, 0.004, -0.003,
+                         0.0025, 0.002, -0.0015, 0.001, 0.0, 0.0008, -0.0006, 0.0005, 0.0, 0.0004, -0.0003,
+                         0.0002, 0.00015]
+ZERNIKE_ANSI_COEFFS = [0.0, -0.01, 0.02, 0.015, 0.03, -0.02, 0.006, -0.005, 0.004, 0.003, 0.002, -0.0015,
+                       0.001, 0.0008, -0.0005]
+
+
+def zernike_builduplist(indexing="Fringe"):
+    """a freeform back surface given as a Zernike series (25 fringe / 15 ANSI terms, up to 8th order)"""
+    coeffs = ZERNIKE_FRINGE_COEFFS if indexing == "Fringe" else ZERNIKE_ANSI_COEFFS
+    return [
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
+        ({"shape": "Conic", "curv": 1. / 60.}, {"decz": 5.0}, 1.5168, "front", {}),
+        ({"shape": "Zernike" + indexing, "normradius": 9.0, "coefficients": coeffs},
+         {"decz": 10.0}, None, "back", {}),
+        ({"shape": "Conic"}, {"decz": 70.0}, None, "image", {}),
+    ]
+
+
+def zernike_combination_system(api):
+    """Zemax-style "Zernike fringe sag" mirror: LinearCombination of a conic asphere and a fringe
+    Zernike series in a decentred frame (the object graph zmx.py:723-760 builds), used in reflection"""
+    s = api.OpticalSystem.p(name="zcombo")
+    lc0 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="obj", decz=0.0),
+                                     refname=s.rootcoordinatesystem.name)
+    lc1 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="mirror", decz=40.0, tiltx=0.12), refname=lc0.name)
+    lcz = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="mirror_zern", decx=0.7, decy=-1.1),
+                                     refname=lc1.name)
+    lc2 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="img", decz=-35.0, tiltx=0.12), refname=lc1.name)
+    shape = api.LinearCombination.p(lc1, list_of_coefficients_and_shapes=[
+        (1.0, api.Asphere.p(lc1, curv=-1. / 90., cc=-0.8, coefficients=[0.0, 2e-6])),
+        (1.0, api.ZernikeFringe.p(lcz, normradius=12.0, coefficients=[0.0, 0.01, -0.02, 0.03, 0.015, -0.01,
+                                                                      0.006, 0.004, -0.003]))])
+    elem = api.OpticalElement.p(lc0, name="zc")
+    elem.addSurface("mirror", api.Surface.p(lc1, shape=shape,
+                                            aperture=api.CircularAperture.p(lc1, maxradius=11.0)), (None, None))
+    elem.addSurface("img", api.Surface.p(lc2), (None, None))
+    s.addElement("zc", elem)
+    return (s, [("zc", [("mirror", {"is_mirror": True}), ("img", {})])])
 
 
 def biconic_builduplist():

@@ -305,3 +305,29 @@ def test_optical_system_analysis_convenience_traces(gpu_device):
     c = img.mean(axis=1)
     assert xy.shape == (2, img.shape[1])
     assert abs(rms - np.sqrt(np.sum((img - c[:, None]) ** 2) / (img.shape[1] - 1))) < 1e-12
+
+
+def test_zernike_shape_evaluation_on_the_device(gpu_device):
+    """getSag of ZernikeFringe, ZernikeANSI and a decentred LinearCombination (monomial expansion
+    on the device) == the reference's values on scattered points; getGrad == the derivative of the
+    reference's sag"""
+    import json
+    import os
+    api = zoo.mirror_api()
+    z = np.load(os.path.join(_golden.GOLDEN_DIR, "zernike_shapes.npz"))
+    (x, y) = (z["x"], z["y"])
+    lc = api.LocalCoordinates.p(name="zshape")
+    lcz = lc.addChild(api.LocalCoordinates.p(name="zshape_dec", decx=0.7, decy=-1.1))
+    shapes = {"fringe": api.ZernikeFringe.p(lc, normradius=9.0, coefficients=zoo.ZERNIKE_FRINGE_COEFFS),
+              "ansi": api.ZernikeANSI.p(lc, normradius=9.0, coefficients=zoo.ZERNIKE_ANSI_COEFFS),
+              "combination": api.LinearCombination.p(lc, list_of_coefficients_and_shapes=[
+                  (0.8, api.Asphere.p(lc, curv=-1. / 90., cc=-0.8, coefficients=[0.0, 2e-6])),
+                  (1.3, api.ZernikeFringe.p(lcz, normradius=12.0, coefficients=zoo.ZERNIKE_FRINGE_COEFFS[:12]))])}
+    for (key, sh) in shapes.items():
+        assert np.allclose(sh.getSag(x, y), z[key + "_sag"], rtol=0, atol=1e-13), key
+        g = sh.getGrad(x, y)              # = -d(sag)/dx, -d(sag)/dy, 1 of the reference's sag (see _golden.py)
+        assert np.allclose(-g[0], z[key + "_dsag_dx"], rtol=0, atol=1e-12), key
+        assert np.allclose(-g[1], z[key + "_dsag_dy"], rtol=0, atol=1e-12), key
+        assert np.all(g[2] == 1.0)
+    # finite at the origin of the Zernike frame (the reference's polar formula is 0/0 there)
+    assert np.all(np.isfinite(shapes["fringe"].getGrad(np.zeros(1), np.zeros(1))))

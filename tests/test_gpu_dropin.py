@@ -116,6 +116,33 @@ def test_seqtrace_of_imported_spd_prescription(api, tmp_path):
     assert_paths_match(rpaths[0], case.raw_bundles)
 
 
+@pytest.mark.parametrize("name,builder", [
+    ("zernike_fringe_field3", lambda api: api.build_simple_optical_system(zoo.zernike_builduplist("Fringe"))),
+    ("zernike_ansi_field2", lambda api: api.build_simple_optical_system(zoo.zernike_builduplist("ANSI"))),
+    ("zernike_combination_mirror", lambda api: zoo.zernike_combination_system(api)),
+])
+def test_seqtrace_zernike_surfaces(api, name, builder):
+    """bundles up to the hit points ON the Zernike surface == the reference's; behind it the
+    reference refracts with a normal that is not its surface's normal (_golden.REFERENCE_NORMAL_DEFECT),
+    so the rest of the path is checked against the oracle"""
+    from oracle import seqtrace_np as oracle
+    case = _golden.load_case(name)
+    (s, seq) = builder(api)
+    rp = s.seqtrace(bundle_of(api, case), seq)[0]
+    nb = _golden.REFERENCE_NORMAL_DEFECT[name] + 2           # bundles whose points are all trusted
+    head = type(rp)(rp.raybundles[0])
+    head.raybundles = rp.raybundles[:nb]
+    assert_paths_match(head, case.raw_bundles[:nb], loose_x=1e-7)      # reference: fsolve, xtol 1e-6
+    assert len(rp.raybundles) == len(case.raw_bundles)
+    with np.errstate(all="ignore"):
+        out = oracle.trace(case.table, case.x0, case.k0, case.E0)
+    img = rp.raybundles[-1]
+    ok = out[-1]["valid"] if len(case.table) == 1 else out[-2]["valid_out"]
+    assert img.num_rays == int(np.sum(ok))
+    assert np.allclose(img.x[0], out[-1]["x_hit"][:, ok], rtol=0, atol=1e-10)
+    assert np.allclose(np.real(img.k[0]), np.real(out[-1]["k_out"])[:, ok], rtol=0, atol=1e-12)
+
+
 def test_plugin_granular_path_matches_fused(api):
     """OpticalElement.seqtrace (Material.propagate / refract per surface + device compaction)
     gives the same RayPath as the fused launch"""

@@ -80,6 +80,17 @@ def test_zmx_text_variants(api, tmp_path):
     mat = s.elements["zmxelem"].materials[[k for k in s.elements["zmxelem"].materials if "surf2" in k][0]]
     d = mat.get_optical_index(None, 0.4861327e-3) - mat.get_optical_index(None, 0.6562725e-3)
     assert d == pytest.approx((1.5168 - 1) / 64.17, rel=2e-3)
+    # Zernike fringe sag: asphere + fringe series in a frame decentred by PARM 9 / 10
+    zern = text.replace("TYPE BICONICX", "TYPE FZERNSAG").replace(
+        "  PARM 1 80.0", "  PARM 9 0.5\n  PARM 10 -0.25\n  XDAT 1 4 0 0 1.0\n  XDAT 2 6.0 0 0 1.0\n"
+                         "  XDAT 3 0.0 0 0 1.0\n  XDAT 4 0.01 0 0 1.0\n  XDAT 5 -0.02 0 0 1.0\n  XDAT 6 0.03 0 0 1.0")
+    f.write_text(zern)
+    (sz, seqz) = zmx.ZMXParser(str(f)).create_optical_system()
+    rz = flatten_sequence(sz, seqz, 0.5876e-3)[0][1]["shape"]
+    assert rz["type"] == "combination" and [p["shape"]["type"] for p in rz["parts"]] == ["asphere", "zernike"]
+    assert rz["parts"][1]["offset"] == [0.5, -0.25, 0.0]
+    assert rz["parts"][1]["shape"] == {"type": "zernike", "indexing": "fringe", "normradius": 6.0,
+                                       "coeffs": [0.0, 0.01, -0.02, 0.03]}
     f.write_text(text.replace("TYPE BICONICX", "TYPE GRID_SAG"))
     with pytest.raises(UnsupportedError):
         zmx.ZMXParser(str(f)).create_optical_system()
