@@ -311,7 +311,6 @@ def test_zernike_shape_evaluation_on_the_device(gpu_device):
     """getSag of ZernikeFringe, ZernikeANSI and a decentred LinearCombination (monomial expansion
     on the device) == the reference's values on scattered points; getGrad == the derivative of the
     reference's sag"""
-    import json
     import os
     api = zoo.mirror_api()
     z = np.load(os.path.join(_golden.GOLDEN_DIR, "zernike_shapes.npz"))

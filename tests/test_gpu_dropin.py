@@ -13,7 +13,6 @@ import pytest
 import _golden
 import systems_zoo as zoo
 from pyrate_amd import systems
-from test_oracle_golden import explicit_tolerance
 
 pytestmark = pytest.mark.gpu
 
