@@ -379,8 +379,20 @@ def pack_record(rec, out=None):
     return r
 
 
+_PACKED = {}            # JSON of a record -> bytes of its prt_surface_t (an optimiser loop changes one
+_PACKED_MAX = 256       # surface per evaluation; the others are reused)
+
+
 def pack_table(records):
-    table = (PrtSurface * len(records))()
-    for (q, rec) in enumerate(records):
-        pack_record(rec, table[q])
-    return table
+    import json
+    blobs = []
+    for rec in records:
+        key = json.dumps(rec, sort_keys=True)
+        blob = _PACKED.get(key)
+        if blob is None:
+            blob = bytes(pack_record(rec))
+            if len(_PACKED) >= _PACKED_MAX:
+                _PACKED.clear()
+            _PACKED[key] = blob
+        blobs.append(blob)
+    return (PrtSurface * len(records)).from_buffer_copy(b"".join(blobs))

@@ -5,7 +5,6 @@ import math
 
 import numpy as np
 import pytest
-import torch
 
 import _golden
 from oracle import seqtrace_np as oracle
@@ -31,6 +30,23 @@ def random_shape(rng, kind):
     if kind == 2:
         return {"type": "biconic", "curvx": c, "curvy": c * rng.uniform(0.5, 1.5), "ccx": rng.uniform(-1, 0.5),
                 "ccy": rng.uniform(-1, 0.5), "coeffs": [[rng.uniform(-1, 1) * 1e-5, rng.uniform(-0.5, 0.5)]]}
+    if kind == 4:
+        nterm = int(rng.randint(4, 26))
+        return {"type": "zernike", "indexing": "fringe" if rng.rand() < 0.5 else "ansi",
+                "normradius": float(rng.uniform(8.0, 12.0)),
+                "coeffs": [float(rng.uniform(-1, 1) * 0.03 / (1 + j)) for j in range(nterm)]}
+    if kind == 5:
+        return {"type": "combination", "parts": [
+            {"coefficient": float(rng.uniform(0.7, 1.2)), "offset": [0.0, 0.0, 0.0],
+             "shape": {"type": "asphere", "curv": c, "cc": rng.uniform(-1.2, 0.3),
+                       "coeffs": [0.0, rng.uniform(-1, 1) * 1e-6]}},
+            {"coefficient": float(rng.uniform(0.5, 1.5)),
+             "offset": [float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), float(rng.uniform(-0.05, 0.05))],
+             "shape": {"type": "zernike", "indexing": "fringe", "normradius": 10.0,
+                       "coeffs": [float(rng.uniform(-1, 1) * 0.02 / (1 + j)) for j in range(9)]}},
+            {"coefficient": 1.0, "offset": [float(rng.uniform(-0.5, 0.5)), 0.0, 0.0],
+             "shape": {"type": "xypoly", "normradius": 10.0,
+                       "terms": [[2, 1, rng.uniform(-0.01, 0.01)], [0, 3, rng.uniform(-0.01, 0.01)]]}}]}
     return {"type": "xypoly", "normradius": 10.0,
             "terms": [[2, 0, rng.uniform(-0.1, 0.1)], [0, 2, rng.uniform(-0.1, 0.1)], [1, 1, rng.uniform(-0.02, 0.02)],
                       [3, 0, rng.uniform(-0.01, 0.01)], [2, 2, rng.uniform(-0.005, 0.005)]]}
@@ -42,7 +58,7 @@ def random_table(rng, n_surf, tilted, explicit, mirrors):
     n_cur = 1.0
     for s in range(n_surf):
         z += rng.uniform(3.0, 12.0)
-        kind = int(rng.randint(0, 4)) if explicit else 0
+        kind = int(rng.randint(0, 6)) if explicit else 0
         Bs = rot(rng, 0.08) if tilted else np.eye(3)
         g = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), z]) if tilted else np.array([0., 0., z])
         own_ap_frame = tilted and rng.rand() < 0.5
