@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 2
+#define PRT_ABI_VERSION 3
 #define PRT_MAX_COEFFS 128 /* asphere A2.. coefficients and / or XY-polynomial terms */
 
 /* ---- error codes ---------------------------------------------------- */
@@ -63,9 +63,11 @@ enum {
     PRT_SHAPE_ASPHERE = 1,
     PRT_SHAPE_XYPOLY = 2,  /* also the Zernike shapes: the host expands them into monomials */
     PRT_SHAPE_BICONIC = 3,
-    PRT_SHAPE_COMBO = 4    /* asphere_scale * asphere(x, y) + xy polynomial: LinearCombination of
+    PRT_SHAPE_COMBO = 4,   /* asphere_scale * asphere(x, y) + xy polynomial: LinearCombination of
                               explicit shapes whose frames differ by translations
                               (surface_shape.py:709-775) */
+    PRT_SHAPE_GRIDSAG = 5  /* bicubic tensor-product B-spline through a sag grid (GridSag,
+                              surface_shape.py:861-925: scipy RectBivariateSpline = FITPACK) */
 };
 enum { PRT_AP_NONE = 0, PRT_AP_CIRCULAR = 1, PRT_AP_RECTANGULAR = 2 };
 enum { PRT_REFRACT = 0, PRT_MIRROR = 1 };
@@ -118,6 +120,12 @@ typedef struct prt_surface {
      * with xpow / ypow are the XY terms; the conic + asphere part is multiplied by asphere_scale */
     int32_t n_asphere, pad_;
     double asphere_scale;
+    /* GRIDSAG: the spline in FITPACK's (tx, ty, c) form, degree 3 in both directions.  aux points to
+     * grid_nx knots tx, then grid_ny knots ty, then (grid_nx-4)*(grid_ny-4) coefficients (row-major,
+     * x index first).  prt_system_create takes a HOST pointer here and keeps its own device copy;
+     * the caller's array is not referenced after the call. */
+    int32_t grid_nx, grid_ny;
+    const double *aux;
 } prt_surface_t;
 
 typedef struct prt_system prt_system_t; /* opaque: device copy of a surface table */

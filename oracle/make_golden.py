@@ -50,7 +50,7 @@ from pyrateoptics.raytracer.optical_element import OpticalElement  # noqa: E402
 from pyrateoptics.raytracer.optical_system import OpticalSystem  # noqa: E402
 from pyrateoptics.raytracer.ray import RayBundle  # noqa: E402
 from pyrateoptics.raytracer.surface import Surface  # noqa: E402
-from pyrateoptics.raytracer.surface_shape import (Asphere, Conic, LinearCombination, XYPolynomials,  # noqa: E402
+from pyrateoptics.raytracer.surface_shape import (Asphere, Conic, GridSag, LinearCombination, XYPolynomials,  # noqa: E402
                                                    ZernikeANSI, ZernikeFringe)
 from pyrateoptics.sampling2d import raster  # noqa: E402
 
@@ -106,7 +106,7 @@ def disk_bundle(nrays, rpup, z0, field_deg=0.0, wave=DLINE, efield="kxex", yshif
 REFAPI = types.SimpleNamespace(
     OpticalSystem=OpticalSystem, OpticalElement=OpticalElement, LocalCoordinates=LocalCoordinates,
     Surface=Surface, Conic=Conic, Asphere=Asphere, XYPolynomials=XYPolynomials,
-    ZernikeFringe=ZernikeFringe, ZernikeANSI=ZernikeANSI, LinearCombination=LinearCombination,
+    ZernikeFringe=ZernikeFringe, ZernikeANSI=ZernikeANSI, LinearCombination=LinearCombination, GridSag=GridSag,
     CircularAperture=CircularAperture, RectangularAperture=RectangularAperture,
     ConstantIndexGlass=ConstantIndexGlass, ModelGlass=ModelGlass,
     AnisotropicMaterial=AnisotropicMaterial, RayBundle=RayBundle,
@@ -193,6 +193,23 @@ def case_zernike():
     out["records_json"] = np.array(json.dumps(recs))
     np.savez_compressed(os.path.join(OUT, "zernike_shapes.npz"), **out)
     print("zernike_shapes.npz: %s" % ", ".join(shapes.keys()))
+
+
+def case_gridsag():
+    """GridSag: traced system + the reference's getSag / getGrad on scattered points, some of
+    them outside the grid (FITPACK clamps the arguments)"""
+    (s, seq) = zoo.gridsag_system(REFAPI)
+    dump_case("gridsag_field2", s, seq, disk_bundle(80, 7.0, -3.0, field_deg=2.0))
+    lc = LocalCoordinates.p(name="gshape")
+    sh = GridSag.p(lc, zoo.gridsag_data())
+    rng = np.random.RandomState(9)
+    (x, y) = (rng.uniform(-10.5, 10.5, 96), rng.uniform(-9.5, 9.5, 96))
+    x[:4] = [-10.0, 10.0, 0.0, 9.999999]
+    y[:4] = [-9.0, 9.0, 0.0, -8.999999]
+    from pyrate_amd.surface_table import describe_shape
+    np.savez_compressed(os.path.join(OUT, "gridsag_shape.npz"), x=x, y=y, sag=sh.getSag(x, y),
+                        grad=sh.getGrad(x, y), record_json=np.array(json.dumps(describe_shape(sh))))
+    print("gridsag_shape.npz")
 
 
 def case_tilted():
@@ -403,6 +420,7 @@ def main():
     case_xypoly()
     case_biconic()
     case_zernike()
+    case_gridsag()
     case_tilted()
     case_mirror()
     case_hud()

@@ -22,8 +22,21 @@ struct prt_system {
     int32_t all_isotropic;
     int32_t all_conic;
     prt_surface_t *d_table;  // device copy
-    prt_surface_t *h_table;  // host copy (for dispatch decisions)
+    prt_surface_t *h_table;  // host copy (for dispatch decisions; its aux pointers are device pointers)
+    double **d_aux;          // per surface: device copy of the GRIDSAG spline data (or nullptr)
 };
+
+static void free_system(prt_system *sys) {
+    if (!sys) return;
+    if (sys->d_aux) {
+        for (int s = 0; s < sys->n_surfaces; ++s)
+            if (sys->d_aux[s]) (void)hipFree(sys->d_aux[s]);
+        delete[] sys->d_aux;
+    }
+    if (sys->d_table) (void)hipFree(sys->d_table);
+    delete[] sys->h_table;
+    delete sys;
+}
 
 static thread_local char g_err[512] = "";
 
@@ -161,13 +174,17 @@ const char *prt_last_error(void) { return g_err; }
 
 static int32_t check_record(const prt_surface_t *r, int idx) {
     char msg[128];
-    if (r->shape_type < PRT_SHAPE_CONIC || r->shape_type > PRT_SHAPE_COMBO) {
+    if (r->shape_type < PRT_SHAPE_CONIC || r->shape_type > PRT_SHAPE_GRIDSAG) {
         snprintf(msg, sizeof msg, "surface %d: unknown shape_type %d", idx, r->shape_type);
         return fail(PRT_ERR_UNSUPPORTED, msg);
     }
     if (r->n_coeffs < 0 || r->n_coeffs > PRT_MAX_COEFFS ||
         (r->shape_type == PRT_SHAPE_BICONIC && 2 * r->n_coeffs > PRT_MAX_COEFFS)) {
         snprintf(msg, sizeof msg, "surface %d: n_coeffs %d out of range", idx, r->n_coeffs);
+        return fail(PRT_ERR_INVALID_ARG, msg);
+    }
+    if (r->shape_type == PRT_SHAPE_GRIDSAG && (r->grid_nx < 8 || r->grid_ny < 8 || !r->aux)) {
+        snprintf(msg, sizeof msg, "surface %d: grid sag needs >= 8 knots per direction and its data", idx);
         return fail(PRT_ERR_INVALID_ARG, msg);
     }
     if (r->shape_type == PRT_SHAPE_COMBO && (r->n_asphere < 0 || r->n_asphere > r->n_coeffs)) {
@@ -207,9 +224,11 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     if (!sys) return fail(PRT_ERR_NOMEM, "host alloc");
     sys->device = device;
     sys->n_surfaces = n_surfaces;
+    sys->d_table = nullptr;
     sys->h_table = new (std::nothrow) prt_surface_t[n_surfaces];
-    if (!sys->h_table) {
-        delete sys;
+    sys->d_aux = new (std::nothrow) double *[n_surfaces]();
+    if (!sys->h_table || !sys->d_aux) {
+        free_system(sys);
         return fail(PRT_ERR_NOMEM, "host alloc");
     }
     memcpy(sys->h_table, table, sizeof(prt_surface_t) * n_surfaces);
@@ -218,18 +237,28 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     for (int s = 0; s < n_surfaces; ++s) {
         if (table[s].mat_type != PRT_MAT_ISOTROPIC) sys->all_isotropic = 0;
         if (table[s].shape_type != PRT_SHAPE_CONIC) sys->all_conic = 0;
+        sys->h_table[s].aux = nullptr;
+        if (table[s].shape_type == PRT_SHAPE_GRIDSAG) {  // private device copy of the spline data
+            const size_t n = (size_t)table[s].grid_nx + (size_t)table[s].grid_ny +
+                             (size_t)(table[s].grid_nx - 4) * (size_t)(table[s].grid_ny - 4);
+            e = hipMalloc((void **)&sys->d_aux[s], sizeof(double) * n);
+            if (e == hipSuccess)
+                e = hipMemcpy(sys->d_aux[s], table[s].aux, sizeof(double) * n, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                free_system(sys);
+                return fail(PRT_ERR_NOMEM, "grid sag data", e);
+            }
+            sys->h_table[s].aux = sys->d_aux[s];
+        }
     }
     e = hipMalloc((void **)&sys->d_table, sizeof(prt_surface_t) * n_surfaces);
     if (e != hipSuccess) {
-        delete[] sys->h_table;
-        delete sys;
+        free_system(sys);
         return fail(PRT_ERR_NOMEM, "hipMalloc(table)", e);
     }
-    e = hipMemcpy(sys->d_table, table, sizeof(prt_surface_t) * n_surfaces, hipMemcpyHostToDevice);
+    e = hipMemcpy(sys->d_table, sys->h_table, sizeof(prt_surface_t) * n_surfaces, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-        (void)hipFree(sys->d_table);
-        delete[] sys->h_table;
-        delete sys;
+        free_system(sys);
         return fail(PRT_ERR_DEVICE, "hipMemcpy(table)", e);
     }
     *out = sys;
@@ -239,9 +268,7 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
 int32_t prt_system_destroy(prt_system_t *sys) {
     if (!sys) return PRT_OK;
     device_guard guard_(sys->device);
-    (void)hipFree(sys->d_table);
-    delete[] sys->h_table;
-    delete sys;
+    free_system(sys);
     return PRT_OK;
 }
 

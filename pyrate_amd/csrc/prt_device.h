@@ -227,6 +227,75 @@ PRT_DEV void biconic_eval(const prt_surface_t *__restrict__ sf, double x, double
     }
 }
 
+// GridSag.F / gradF, surface_shape.py:865-873: scipy's RectBivariateSpline.ev(x, y[, dx | dy]) =
+// FITPACK bispev / parder on the (tx, ty, c) form.  Arguments outside the knot range are clamped to
+// it (bispev); the knot interval is located by bisection; the four non-zero cubic basis functions
+// and their derivatives come from the Cox-de Boor recurrence (FITPACK fpbspl).
+PRT_DEV int bspline_interval(const double *__restrict__ t, int n, double x) {
+    int lo = 3, hi = n - 5;  // t[lo] <= x < t[lo+1], lo in [3, n-5]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (x >= t[mid]) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+PRT_DEV void bspline_basis3(const double *__restrict__ t, int l, double x, double b[4], double db[4]) {
+    // degree 1
+    const double t0 = t[l], t1 = t[l + 1];
+    const double i1 = fast_rcp(t1 - t0);
+    const double b1_0 = (t1 - x) * i1, b1_1 = (x - t0) * i1;
+    // degree 2 (three functions on knots l-1 .. l+2)
+    const double tm1 = t[l - 1], t2 = t[l + 2];
+    const double f0 = b1_0 * fast_rcp(t1 - tm1), f1 = b1_1 * fast_rcp(t2 - t0);
+    const double b2_0 = f0 * (t1 - x);
+    const double b2_1 = f0 * (x - tm1) + f1 * (t2 - x);
+    const double b2_2 = f1 * (x - t0);
+    // degree 3 and its derivative: B'_{i,3} = 3 (B_{i,2}/(t_{i+3}-t_i) - B_{i+1,2}/(t_{i+4}-t_{i+1}))
+    const double tm2 = t[l - 2], t3 = t[l + 3];
+    const double g0 = b2_0 * fast_rcp(t1 - tm2), g1 = b2_1 * fast_rcp(t2 - tm1), g2 = b2_2 * fast_rcp(t3 - t0);
+    b[0] = g0 * (t1 - x);
+    b[1] = g0 * (x - tm2) + g1 * (t2 - x);
+    b[2] = g1 * (x - tm1) + g2 * (t3 - x);
+    b[3] = g2 * (x - t0);
+    db[0] = -3.0 * g0;
+    db[1] = 3.0 * (g0 - g1);
+    db[2] = 3.0 * (g1 - g2);
+    db[3] = 3.0 * g2;
+}
+
+PRT_DEV void gridsag_eval(const prt_surface_t *__restrict__ sf, double x, double y, double &F,
+                          double &Fx, double &Fy) {
+    const int nx = sf->grid_nx, ny = sf->grid_ny;
+    const double *__restrict__ tx = sf->aux;
+    const double *__restrict__ ty = tx + nx;
+    const double *__restrict__ c = ty + ny;
+    const double xc = fmin(fmax(x, tx[3]), tx[nx - 4]);
+    const double yc = fmin(fmax(y, ty[3]), ty[ny - 4]);
+    const int lx = bspline_interval(tx, nx, xc), ly = bspline_interval(ty, ny, yc);
+    double bx[4], dbx[4], by[4], dby[4];
+    bspline_basis3(tx, lx, xc, bx, dbx);
+    bspline_basis3(ty, ly, yc, by, dby);
+    const int ncy = ny - 4;
+    F = 0.0;
+    Fx = 0.0;
+    Fy = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double *__restrict__ row = c + (int64_t)(lx - 3 + i) * ncy + (ly - 3);
+        double s = 0.0, sy = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double v = row[j];
+            s += by[j] * v;
+            sy += dby[j] * v;
+        }
+        F += bx[i] * s;
+        Fx += dbx[i] * s;
+        Fy += bx[i] * sy;
+    }
+}
+
 // explicit z = F(x,y) shapes: value and in-plane derivatives
 PRT_DEV void explicit_eval(const prt_surface_t *__restrict__ sf, double x, double y, double &F,
                            double &Fx, double &Fy) {
@@ -237,6 +306,8 @@ PRT_DEV void explicit_eval(const prt_surface_t *__restrict__ sf, double x, doubl
         Fy = y * m;
     } else if (sf->shape_type == PRT_SHAPE_BICONIC) {
         biconic_eval(sf, x, y, F, Fx, Fy);
+    } else if (sf->shape_type == PRT_SHAPE_GRIDSAG) {
+        gridsag_eval(sf, x, y, F, Fx, Fy);
     } else if (sf->shape_type == PRT_SHAPE_COMBO) {
         // LinearCombination.F / gradF (surface_shape.py:713-748) of one conic / asphere part and
         // polynomial parts, merged by the host: scale * asphere + sum c_ij x^i y^j

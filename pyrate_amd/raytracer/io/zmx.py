@@ -12,7 +12,7 @@ graph with the reference's conventions:
   BICONICX -> Biconic (``PARM 1`` = Rx, ``PARM 2`` = ccx), COORDBRK -> a shapeless surface in a
   frame with ``PARM 1..5`` = decx, decy, tiltx, tilty, tiltz [deg] and ``PARM 6`` = order flag
   (zmx.py:788-814), FZERNSAG -> LinearCombination of an Asphere and a decentred ZernikeFringe
-  (:723-760); grid sag surfaces are outside the engine's shape set and raise ``UnsupportedError``;
+  (:723-760), GRID_SAG -> GridSag through the file's sag samples (:761-786);
 * ``GLAS MIRROR`` -> ``is_mirror`` with the medium unchanged; a name found in ``matdict`` ->
   that material; model glasses (code 1) -> ConstantIndexGlass(nd) when vd = 0, otherwise a
   Conrady ModelGlass on the normal line (the reference's ``calcCoefficientsFrom_nd_vd`` calls a
@@ -37,7 +37,7 @@ from ..material.material_isotropic import ConstantIndexGlass, ModelGlass
 from ..optical_element import OpticalElement
 from ..optical_system import OpticalSystem
 from ..surface import Surface
-from ..surface_shape import Asphere, Biconic, Conic, LinearCombination, ZernikeFringe
+from ..surface_shape import Asphere, Biconic, Conic, GridSag, LinearCombination, ZernikeFringe
 
 
 def conrady_from_nd_vd(nd, vd, PgF=None):
@@ -237,8 +237,18 @@ class ZMXParser(object):
                 (1.0, ZernikeFringe.p(lcz, normradius=normradius, coefficients=zcoeffs,
                                       name="surf%d_zernike" % surf.number))])
         if typ == "GRID_SAG":
-            raise UnsupportedError("ZMX surface type GRID_SAG (surface %d) is outside the engine's shape set"
-                                   % surf.number)
+            # GDAT nx ny dx dy, GARR n sag dzdx dzdy d2zdxdy (only the sag column is used; zmx.py:761-786)
+            import numpy as np
+            (nx, ny, dx, dy) = surf.first("GDAT", (int, int, float, float))
+            garr = surf.numbered("GARR", (float, float, float, float))
+            sag = np.array([garr[key][0] for key in sorted(garr.keys())])
+            xvec = np.linspace(-nx * dx * 0.5, nx * dx * 0.5, nx)
+            yvec = np.linspace(-ny * dy * 0.5, ny * dy * 0.5, ny)
+            # samples run along x, row by row from the top (+y) row down.  (The reference reshapes
+            # to (nx, ny), which coincides with this for the square grids it can handle and fails
+            # in RectBivariateSpline for the others.)
+            zgrid = np.flipud(sag.reshape(ny, nx)).T
+            return GridSag.p(lc, (xvec, yvec, zgrid))
         return None                                       # COORDBRK and unknown types: plane
 
     def create_optical_system(self, matdict=None, options=None, elementname="zmxelem"):

@@ -1,7 +1,7 @@
 """
 Surface shapes with the reference's interface (raytracer/surface_shape.py): ``Conic``
 (:158-325), ``Asphere`` (:520-606), ``Biconic`` (:609-706), ``LinearCombination`` (:709-775),
-``XYPolynomials`` (:780-858), ``ZernikeFringe`` / ``ZernikeANSI`` (:927-1143).  ``intersect`` and the
+``XYPolynomials`` (:780-858), ``GridSag`` (:861-925), ``ZernikeFringe`` / ``ZernikeANSI`` (:927-1143).  ``intersect`` and the
 ``getSag`` / ``getGrad`` / ``getNormal`` evaluations run on the GPU through
 ``prt_propagate`` / ``prt_shape_eval``; these classes hold parameters and frames.
 
@@ -251,6 +251,25 @@ class LinearCombination(ExplicitShape):
         return obj
 
 
-accessible_shapes = {"shape_Conic": Conic, "shape_Asphere": Asphere, "shape_Biconic": Biconic,
+class GridSag(ExplicitShape):
+    """sag given on a rectangular grid, interpolated by a bicubic spline (surface_shape.py:861-925).
+    The spline is built once on the host with the reference's tool (scipy RectBivariateSpline =
+    FITPACK); its knots and B-spline coefficients go to the device, which evaluates the same
+    tensor-product B-spline (Cox-de Boor) for sag and gradient."""
+    kind = "shape_GridSag"
+
+    @classmethod
+    def p(cls, lc, xlin_ylin_zgrid, tol=1e-4, iterations=10, name=""):
+        from scipy.interpolate import RectBivariateSpline
+        (xlinspace, ylinspace, zgrid) = xlin_ylin_zgrid
+        obj = cls(lc, [], tol=tol, iterations=iterations, name=name)
+        obj.annotations["xlinspace"] = np.asarray(xlinspace).tolist()
+        obj.annotations["ylinspace"] = np.asarray(ylinspace).tolist()
+        obj.annotations["zgrid"] = np.asarray(zgrid).tolist()
+        obj.interpolant = RectBivariateSpline(np.asarray(xlinspace), np.asarray(ylinspace), np.asarray(zgrid))
+        return obj
+
+
+accessible_shapes = {"shape_GridSag": GridSag, "shape_Conic": Conic, "shape_Asphere": Asphere, "shape_Biconic": Biconic,
                      "shape_XYPolynomials": XYPolynomials, "shape_ZernikeFringe": ZernikeFringe,
                      "shape_ZernikeANSI": ZernikeANSI, "shape_LinearCombination": LinearCombination}

@@ -38,7 +38,8 @@ PRT_MAX_COEFFS = 128
 
 # record type -> prt_surface_t.shape_type ("zernike" is expanded into monomials, "combination" into
 # one conic / asphere part plus monomials: see pack_record)
-SHAPE_CODES = {"conic": 0, "asphere": 1, "xypoly": 2, "biconic": 3, "zernike": 2, "combination": 4}
+SHAPE_CODES = {"conic": 0, "asphere": 1, "xypoly": 2, "biconic": 3, "zernike": 2, "combination": 4,
+               "gridsag": 5}
 AP_CODES = {"none": 0, "circular": 1, "rectangular": 2}
 INTERACTION_CODES = {"refract": 0, "mirror": 1}
 MAT_CODES = {"isotropic": 0, "anisotropic": 1}
@@ -84,6 +85,9 @@ class PrtSurface(ctypes.Structure):
         ("n_asphere", ctypes.c_int32),
         ("pad_", ctypes.c_int32),
         ("asphere_scale", ctypes.c_double),
+        ("grid_nx", ctypes.c_int32),
+        ("grid_ny", ctypes.c_int32),
+        ("aux", ctypes.c_void_p),
     ]
 
 
@@ -123,6 +127,20 @@ def describe_shape(shape):
         (normradius, zcoeffs) = shape.getZernikeParameters()
         return {"type": "zernike", "indexing": "fringe" if kind.endswith("Fringe") else "ansi",
                 "normradius": float(normradius), "coeffs": [float(c) for c in zcoeffs]}
+    if kind == "shape_GridSag":
+        # the reference interpolates the grid with scipy's RectBivariateSpline (surface_shape.py:915-925);
+        # the spline itself -- FITPACK knots and B-spline coefficients -- is what the device evaluates
+        spline = getattr(shape, "interpolant", None)
+        if spline is None:
+            from scipy.interpolate import RectBivariateSpline
+            ann = shape.annotations
+            spline = RectBivariateSpline(np.array(ann["xlinspace"]), np.array(ann["ylinspace"]),
+                                         np.array(ann["zgrid"]))
+        (tx, ty, c) = spline.tck[:3]
+        if tuple(spline.degrees) != (3, 3):
+            raise UnsupportedError("GridSag: bicubic splines only")
+        return {"type": "gridsag", "tx": [float(v) for v in tx], "ty": [float(v) for v in ty],
+                "c": [float(v) for v in c]}
     if kind == "shape_LinearCombination":
         # sum_i c_i F_i evaluated in each part's own frame (surface_shape.py:713-730); the frames may
         # differ from the combination's by a translation only
@@ -328,6 +346,15 @@ def pack_record(rec, out=None):
                 raise UnsupportedError("negative power in XY polynomial")
             r.xpow[q], r.ypow[q] = int(i), int(j)
             r.coeffs[q] = c * (1. / nr ** (int(i) + int(j)))   # surface_shape.py:791
+    elif shape["type"] == "gridsag":
+        (tx, ty, c) = (shape["tx"], shape["ty"], shape["c"])
+        if len(c) != (len(tx) - 4) * (len(ty) - 4):
+            raise UnsupportedError("GridSag: coefficient count does not match the knot vectors")
+        aux = np.ascontiguousarray(np.concatenate((tx, ty, c)), dtype=np.float64)
+        (r.curv, r.cc, r.n_coeffs) = (0.0, 0.0, 0)
+        (r.grid_nx, r.grid_ny) = (len(tx), len(ty))
+        r.aux = aux.ctypes.data
+        r._keepalive = aux           # prt_system_create copies the data; until then the array must live
     elif shape["type"] == "zernike":
         mono = polyshape.zernike_terms(shape["indexing"], shape["normradius"], shape["coeffs"])
         r.curv, r.cc = 0.0, 0.0
@@ -386,13 +413,18 @@ _PACKED_MAX = 256       # surface per evaluation; the others are reused)
 def pack_table(records):
     import json
     blobs = []
+    keep = []
     for rec in records:
         key = json.dumps(rec, sort_keys=True)
-        blob = _PACKED.get(key)
-        if blob is None:
-            blob = bytes(pack_record(rec))
+        hit = _PACKED.get(key)
+        if hit is None:
+            r = pack_record(rec)
+            hit = (bytes(r), getattr(r, "_keepalive", None))
             if len(_PACKED) >= _PACKED_MAX:
                 _PACKED.clear()
-            _PACKED[key] = blob
-        blobs.append(blob)
-    return (PrtSurface * len(records)).from_buffer_copy(b"".join(blobs))
+            _PACKED[key] = hit
+        blobs.append(hit[0])
+        keep.append(hit[1])
+    table = (PrtSurface * len(records)).from_buffer_copy(b"".join(blobs))
+    table._keepalive = keep          # arrays the records' aux pointers refer to
+    return table

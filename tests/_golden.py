@@ -24,7 +24,8 @@ ISO_CASES = ["doublet", "doublet_clipped", "double_gauss_axis", "double_gauss_fi
 EXPLICIT_CASES = ["asphere_mild_axis", "asphere_mild_field5", "asphere_strong_axis",
                   "asphere_strong_field5", "xypoly_axis", "xypoly_field5", "biconic_axis",
                   "biconic_field5", "hud_biconic_mirrors", "zmx_lenssystem",
-                  "zernike_fringe_field3", "zernike_ansi_field2", "zernike_combination_mirror"]
+                  "zernike_fringe_field3", "zernike_ansi_field2", "zernike_combination_mirror",
+                  "gridsag_field2"]
 ANISO_CASES = ["aniso_doublet_isoeps", "aniso_doublet_uniaxial", "aniso_doublet_biaxial",
                "aniso_doublet_uniaxial_clipped", "aniso_doublet_uniaxial_stopped",
                "aniso_mirror_uniaxial", "aniso_mirror_biaxial"]

@@ -23,6 +23,7 @@ def mirror_api():
         Conic=surface_shape.Conic, Asphere=surface_shape.Asphere, XYPolynomials=surface_shape.XYPolynomials,
         Biconic=surface_shape.Biconic, ZernikeFringe=surface_shape.ZernikeFringe,
         ZernikeANSI=surface_shape.ZernikeANSI, LinearCombination=surface_shape.LinearCombination,
+        GridSag=surface_shape.GridSag,
         CircularAperture=aperture.CircularAperture, RectangularAperture=aperture.RectangularAperture,
         ConstantIndexGlass=material_isotropic.ConstantIndexGlass, ModelGlass=material_isotropic.ModelGlass,
         AnisotropicMaterial=material_anisotropic.AnisotropicMaterial, RayBundle=ray.RayBundle,
@@ -207,6 +208,32 @@ def zernike_combination_system(api):
     elem.addSurface("img", api.Surface.p(lc2), (None, None))
     s.addElement("zc", elem)
     return (s, [("zc", [("mirror", {"is_mirror": True}), ("img", {})])])
+
+
+def gridsag_data():
+    """a smooth freeform sampled on a 25 x 21 grid (not an exact polynomial of the spline's degree)"""
+    x = np.linspace(-10.0, 10.0, 25)
+    y = np.linspace(-9.0, 9.0, 21)
+    (X, Y) = np.meshgrid(x, y, indexing="ij")
+    Z = -0.004 * (X ** 2 + 1.3 * Y ** 2) + 0.08 * np.sin(0.25 * X) * np.cos(0.2 * Y) + 1e-5 * X ** 3 * Y
+    return (x, y, Z)
+
+
+def gridsag_system(api):
+    """front plane, freeform back surface given as a sag grid (GridSag), tilted image plane"""
+    s = api.OpticalSystem.p(name="gridsag")
+    lc0 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="obj", decz=0.0),
+                                     refname=s.rootcoordinatesystem.name)
+    lc1 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="front", decz=5.0), refname=lc0.name)
+    lc2 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="back", decz=8.0, tiltx=0.03), refname=lc1.name)
+    lc3 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="img", decz=60.0), refname=lc2.name)
+    elem = api.OpticalElement.p(lc0, name="gs")
+    elem.addMaterial("glass", api.ConstantIndexGlass.p(lc1, 1.5168))
+    elem.addSurface("front", api.Surface.p(lc1, shape=api.Conic.p(lc1, curv=0.0)), (None, "glass"))
+    elem.addSurface("back", api.Surface.p(lc2, shape=api.GridSag.p(lc2, gridsag_data())), ("glass", None))
+    elem.addSurface("img", api.Surface.p(lc3), (None, None))
+    s.addElement("gs", elem)
+    return (s, [("gs", [("front", {}), ("back", {}), ("img", {})])])
 
 
 def biconic_builduplist():

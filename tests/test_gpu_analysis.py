@@ -330,3 +330,14 @@ def test_zernike_shape_evaluation_on_the_device(gpu_device):
         assert np.all(g[2] == 1.0)
     # finite at the origin of the Zernike frame (the reference's polar formula is 0/0 there)
     assert np.all(np.isfinite(shapes["fringe"].getGrad(np.zeros(1), np.zeros(1))))
+
+
+def test_gridsag_shape_evaluation_on_the_device(gpu_device):
+    """bicubic B-spline on the device == scipy / FITPACK in the reference: sag and gradient on
+    scattered points incl. grid corners and points outside the grid (clamped arguments)"""
+    import os
+    api = zoo.mirror_api()
+    z = np.load(os.path.join(_golden.GOLDEN_DIR, "gridsag_shape.npz"))
+    sh = api.GridSag.p(api.LocalCoordinates.p(name="gshape"), zoo.gridsag_data())
+    assert np.allclose(sh.getSag(z["x"], z["y"]), z["sag"], rtol=0, atol=2e-15)
+    assert np.allclose(sh.getGrad(z["x"], z["y"]), z["grad"], rtol=0, atol=2e-14)

@@ -142,6 +142,13 @@ def test_seqtrace_zernike_surfaces(api, name, builder):
     assert np.allclose(np.real(img.k[0]), np.real(out[-1]["k_out"])[:, ok], rtol=0, atol=1e-12)
 
 
+def test_seqtrace_gridsag_surface(api):
+    case = _golden.load_case("gridsag_field2")
+    (s, seq) = zoo.gridsag_system(api)
+    rpaths = s.seqtrace(bundle_of(api, case), seq)
+    assert_paths_match(rpaths[0], case.raw_bundles, loose_x=1e-8)      # reference: fsolve, xtol 1e-4
+
+
 def test_plugin_granular_path_matches_fused(api):
     """OpticalElement.seqtrace (Material.propagate / refract per surface + device compaction)
     gives the same RayPath as the fused launch"""

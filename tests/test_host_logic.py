@@ -107,10 +107,10 @@ def test_structural_errors_raise_like_the_reference(api):
 
 
 def test_unsupported_shapes_are_rejected():
-    class GridSag(object):
-        kind = "shape_GridSag"
+    class UserDll(object):
+        kind = "shape_ZMXDLLShape"
     with pytest.raises(st.UnsupportedError):
-        st.describe_shape(GridSag())
+        st.describe_shape(UserDll())
 
 
 def test_pack_table_flags_and_coefficients():
@@ -156,7 +156,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(_lib.PROTOTYPES.keys())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.prt_abi_version() == 2
+    assert lib.prt_abi_version() == 3
     assert lib.prt_sizeof_surface() == ctypes.sizeof(st.PrtSurface)
     assert lib.prt_strerror(-2) == b"unsupported shape/material"
     # argument validation happens before any device work
@@ -292,3 +292,17 @@ def test_mirror_zernike_tables_equal_reference(api):
     _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("zernike_ansi_field2").table)
     (s, seq) = zoo.zernike_combination_system(api)
     _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("zernike_combination_mirror").table)
+
+
+def test_gridsag_oracle_and_table(api):
+    """GridSag: oracle (scipy spline rebuilt from the record's knots / coefficients) == the
+    reference's getSag / getGrad; the mirror class flattens to the reference's record"""
+    from oracle import seqtrace_np as oracle
+    z = np.load(os.path.join(_golden.GOLDEN_DIR, "gridsag_shape.npz"))
+    rec = json.loads(str(z["record_json"]))
+    assert np.array_equal(oracle.shape_sag(rec, z["x"], z["y"]), z["sag"])
+    assert np.array_equal(oracle.shape_grad(rec, z["x"], z["y"]), z["grad"])
+    (s, seq) = zoo.gridsag_system(api)
+    _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("gridsag_field2").table)
+    table = st.pack_table(_golden.load_case("gridsag_field2").table)
+    assert table[1].shape_type == 5 and table[1].grid_nx == 29 and table[1].grid_ny == 25 and table[1].aux

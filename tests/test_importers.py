@@ -91,9 +91,19 @@ def test_zmx_text_variants(api, tmp_path):
     assert rz["parts"][1]["offset"] == [0.5, -0.25, 0.0]
     assert rz["parts"][1]["shape"] == {"type": "zernike", "indexing": "fringe", "normradius": 6.0,
                                        "coeffs": [0.0, 0.01, -0.02, 0.03]}
-    f.write_text(text.replace("TYPE BICONICX", "TYPE GRID_SAG"))
-    with pytest.raises(UnsupportedError):
-        zmx.ZMXParser(str(f)).create_optical_system()
+    # grid sag: GDAT nx ny dx dy + one GARR line per sample -> bicubic spline through the samples
+    (nx, ny) = (9, 8)
+    garr = "\n".join("  GARR %d %.6e 0 0 0" % (q + 1, 1e-3 * ((q % ny) - 3.5) ** 2 + 2e-3 * ((q // ny) - 4) ** 2)
+                     for q in range(nx * ny))
+    f.write_text(text.replace("TYPE BICONICX", "TYPE GRID_SAG").replace(
+        "  PARM 1 80.0", "  GDAT %d %d 1.0 1.25\n%s" % (nx, ny, garr)))
+    (sg, seqg) = zmx.ZMXParser(str(f)).create_optical_system()
+    rg = flatten_sequence(sg, seqg, 0.5876e-3)[0][1]["shape"]
+    assert rg["type"] == "gridsag" and len(rg["tx"]) == nx + 4 and len(rg["ty"]) == ny + 4
+    assert len(rg["c"]) == nx * ny
+    f.write_text(text.replace("TYPE BICONICX", "TYPE USERSURF"))
+    (su, sequ) = zmx.ZMXParser(str(f)).create_optical_system()            # unknown types: a plane, like the reference
+    assert flatten_sequence(su, sequ, 0.5876e-3)[0][1]["shape"] == {"type": "conic", "curv": 0.0, "cc": 0.0}
 
 
 # ---- refractiveindex.info catalogue browser ------------------------------------------------
