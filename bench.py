@@ -125,6 +125,13 @@ def main():
         for (k, v) in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29512")):
             os.environ.setdefault(k, v)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_multi:
+        # started as a plain `python bench.py --gpus N`: become the one-process-per-GPU launch the
+        # contract describes (torch.distributed.run on this node, rendezvous on 127.0.0.1)
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                                  "--master-port", os.environ.get("MASTER_PORT", "29577"),
+                                  os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
