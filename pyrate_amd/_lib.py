@@ -13,7 +13,8 @@ import os
 from .surface_table import PrtSurface
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libprt.so")
+# PRT_LIBRARY: an alternative build of the same ABI (A/B experiments); default: the in-tree library
+LIB_PATH = os.environ.get("PRT_LIBRARY") or os.path.join(_HERE, "csrc", "libprt.so")
 
 PRT_OK = 0
 MODE_PATH = 0

@@ -11,7 +11,9 @@
 #include "prt_device.h"
 #include "prt_aniso.h"
 
+#ifndef PRT_BLOCK
 #define PRT_BLOCK 256
+#endif
 #define CMP_ITEMS 4  // mask bytes per thread in the compaction / raster kernels
 #define CMP_TILE (PRT_BLOCK * CMP_ITEMS)
 
@@ -119,7 +121,10 @@ PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
 // of the allocator's 7 is worth 5 % there (0.47 -> 0.446 ms); path mode is HBM bound and unaffected.
 template <int MODE, bool VEC_IN, bool VEC_OUT, bool EXPLICIT = true, bool LDS_TAB = false,
           bool MOMENTS = false>
-__global__ __launch_bounds__(PRT_BLOCK, (MODE == PRT_MODE_IMAGE && !EXPLICIT && !LDS_TAB) ? 8 : 1) void k_trace_iso(
+#ifndef PRT_PATH_WAVES
+#define PRT_PATH_WAVES 1
+#endif
+__global__ __launch_bounds__(PRT_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE == PRT_MODE_IMAGE ? 8 : PRT_PATH_WAVES) : 1) void k_trace_iso(
     const prt_surface_t *__restrict__ tab_g, int32_t S, int64_t N, int64_t in_pitch,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, int64_t out_pitch,
