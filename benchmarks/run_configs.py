@@ -137,7 +137,8 @@ def main():
     for nr in (100, 10000, int(1e6 * scale), int(1e7 * scale)):
         (o, k, e0) = systems.double_gauss_bundle(nr)
         ib = RayBundle(o, k, e0, wave=systems.DLINE)
-        s.seqtrace(ib, seq)
+        for _ in range(3):                 # the first calls after a change of size pay one-off costs
+            s.seqtrace(ib, seq)
         torch.cuda.synchronize()
         reps = 20 if nr <= 10000 else 3
         t0 = time.perf_counter()
