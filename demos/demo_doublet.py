@@ -54,7 +54,7 @@ def build():
 def main(nrays=20, rast=None):
     (s, sysseq) = build()
     r2 = raytrace(s, sysseq, nrays, {"startz": -5, "radius": 11.43,
-                                     "raster": rast or raster.MeridionalFan()}, wave=wavelength)[0]
+                                     "raster": rast or raster.MeridionalFan()}, wave=wavelength)[0][0]
     img = r2.raybundles[-1]
     ra = RayBundleAnalysis(img)
     print("doublet: %d rays reach the image plane, RMS spot radius %.6f mm, centroid %s"

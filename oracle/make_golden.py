@@ -212,6 +212,23 @@ def case_gridsag():
     print("gridsag_shape.npz")
 
 
+def case_prism():
+    """demo_prism.py: the reference's ``raytrace`` convenience (OpticalSystemAnalysis.aim with a
+    MeridionalFan raster, start offset and field angle) at a red and a blue wavelength"""
+    from pyrateoptics import raytrace
+    (s, seq) = zoo.prism(REFAPI)
+    for (tag, wave) in (("red", 0.700e-3), ("blue", 0.470e-3)):
+        rd = dict(zoo.PRISM_RAYS)
+        rd["raster"] = raster.MeridionalFan()
+        osa = OpticalSystemAnalysis(s, seq)
+        osa.aim(20, rd, bundletype="collimated", wave=wave)
+        ib = osa.initial_bundles[0]
+        dump_case("prism_" + tag, s, seq, RayBundle(np.array(ib.x[0]), np.array(ib.k[0]), np.array(ib.Efield[0]),
+                                                    wave=wave))
+        rp = raytrace(s, seq, 20, rd, wave=wave)[0][0]
+        assert np.array_equal(rp.raybundles[-1].x, osa.trace()[0][0].raybundles[-1].x)
+
+
 def case_tilted():
     (s, seq) = zoo.tilted(REFAPI)
     dump_case("tilted_frames", s, seq, disk_bundle(300, 6.5, -3.0, field_deg=2.0, wave=0.6563e-3))
@@ -421,6 +438,7 @@ def main():
     case_biconic()
     case_zernike()
     case_gridsag()
+    case_prism()
     case_tilted()
     case_mirror()
     case_hud()

@@ -99,7 +99,8 @@ def build_simple_optical_system(builduplist, material_db_path="", name=""):
 
 
 def raytrace(s, seq, numrays, rays_dict, bundletype="collimated", traceoptions=None, wave=None):
-    """convenience entry of the README / demos (pyrateoptics/__init__.py:457-465)"""
+    """convenience entry of the README / demos (pyrateoptics/__init__.py:457-465): one list of
+    RayPaths per initial bundle, i.e. ``raytrace(...)[0]`` is what the demos pass to ``draw``"""
     from .raytracer.analysis.optical_system_analysis import OpticalSystemAnalysis
     from .raytracer.globalconstants import standard_wavelength
     if traceoptions is None:
@@ -107,4 +108,4 @@ def raytrace(s, seq, numrays, rays_dict, bundletype="collimated", traceoptions=N
     osa = OpticalSystemAnalysis(s, seq)
     osa.aim(numrays, rays_dict, bundletype=bundletype,
             wave=standard_wavelength if wave is None else wave)
-    return osa.trace(**traceoptions)[0]
+    return osa.trace(**traceoptions)

@@ -210,6 +210,35 @@ def zernike_combination_system(api):
     return (s, [("zc", [("mirror", {"is_mirror": True}), ("img", {})])])
 
 
+def prism(api):
+    """dispersing prism: two plane faces tilted by +-30 degrees about a common centre, Conrady
+    ModelGlass (demos/demo_prism.py geometry)"""
+    deg = math.pi / 180.
+    s = api.OpticalSystem.p()
+    lc0 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="stop", decz=0.0),
+                                     refname=s.rootcoordinatesystem.name)
+    lcc = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="prismcenter", decz=50.0), refname=lc0.name)
+    lc1 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="surf1", decz=-10.0, tiltx=30. * deg),
+                                     refname=lcc.name)
+    lc2 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="surf2", decz=10.0, tiltx=-30. * deg),
+                                     refname=lcc.name)
+    lc3 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="image", decz=50.0), refname=lcc.name)
+    elem = api.OpticalElement.p(lc0, name="prism")
+    elem.addMaterial("glass", api.ModelGlass.p(lc1))
+    elem.addSurface("stop", api.Surface.p(lc0), (None, None))
+    elem.addSurface("surf1", api.Surface.p(lc1, shape=api.Conic.p(lc1, curv=0),
+                                           aperture=api.CircularAperture.p(lc1, maxradius=20.0)), (None, "glass"))
+    elem.addSurface("surf2", api.Surface.p(lc2, shape=api.Conic.p(lc2, curv=0),
+                                           aperture=api.CircularAperture.p(lc2, maxradius=20.0)), ("glass", None))
+    elem.addSurface("image", api.Surface.p(lc3), (None, None))
+    s.addElement("prism", elem)
+    seq = [("prism", [("stop", {"is_stop": True}), ("surf1", {}), ("surf2", {}), ("image", {})])]
+    return (s, seq)
+
+
+PRISM_RAYS = {"radius": 5.0, "startz": -5., "starty": -20., "anglex": 23 * math.pi / 180.}
+
+
 def gridsag_data():
     """a smooth freeform sampled on a 25 x 21 grid (not an exact polynomial of the spline's degree)"""
     x = np.linspace(-10.0, 10.0, 25)

@@ -97,9 +97,9 @@ def test_raytrace_convenience_readme_example(gpu_device):
     from pyrate_amd.builders import build_rotationally_symmetric_optical_system, raytrace
     (s, seq) = build_rotationally_symmetric_optical_system(
         [(100., 0, 20., 1.5, "front", {}), (-100., 0, 5., None, "back", {}), (0, 0, 100., None, "image", {})])
-    r = raytrace(s, seq, 11, {"radius": 9.0})
-    assert len(r) == 1 and len(r[0].raybundles) == 5
-    img = r[0].raybundles[-1]
+    r = raytrace(s, seq, 11, {"radius": 9.0})          # [bundle][ray path], like the reference
+    assert len(r) == 1 and len(r[0]) == 1 and len(r[0][0].raybundles) == 5
+    img = r[0][0].raybundles[-1]
     assert img.x.shape == (1, 3, 12)
     assert np.allclose(img.x[-1][:, 0], [6.0134358655051567e-02, 1.8040307596514893e-01, 125.0], rtol=0, atol=1e-12)
     assert np.allclose(np.real(img.k[-1][:, 0]), [0.02810922264455102, 0.08432766793365307, 0.9960415232424753],
@@ -341,3 +341,22 @@ def test_gridsag_shape_evaluation_on_the_device(gpu_device):
     sh = api.GridSag.p(api.LocalCoordinates.p(name="gshape"), zoo.gridsag_data())
     assert np.allclose(sh.getSag(z["x"], z["y"]), z["sag"], rtol=0, atol=2e-15)
     assert np.allclose(sh.getGrad(z["x"], z["y"]), z["grad"], rtol=0, atol=2e-14)
+
+
+@pytest.mark.parametrize("tag,wave", [("red", 0.700e-3), ("blue", 0.470e-3)])
+def test_raytrace_prism_like_the_reference_demo(gpu_device, tag, wave):
+    """demos/demo_prism.py through ``raytrace``: MeridionalFan raster, start offset, field angle,
+    ModelGlass dispersion -- initial bundle and every traced bundle == the reference's"""
+    from pyrate_amd.builders import raytrace
+    from pyrate_amd.sampling2d import raster
+    from test_gpu_dropin import assert_paths_match
+    api = zoo.mirror_api()
+    case = _golden.load_case("prism_" + tag)
+    (s, seq) = zoo.prism(api)
+    rd = dict(zoo.PRISM_RAYS)
+    rd["raster"] = raster.MeridionalFan()
+    r = raytrace(s, seq, 20, rd, wave=wave)
+    rp = r[0][0]
+    assert np.allclose(rp.raybundles[0].x[0], case.x0, rtol=0, atol=1e-14)
+    assert np.allclose(np.real(rp.raybundles[0].k[0]), np.real(case.k0), rtol=0, atol=1e-15)
+    assert_paths_match(rp, case.raw_bundles)
