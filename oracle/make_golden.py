@@ -229,6 +229,30 @@ def case_prism():
         assert np.array_equal(rp.raybundles[-1].x, osa.trace()[0][0].raybundles[-1].x)
 
 
+def case_rasters():
+    """pupil rasters of the reference (sampling2d/raster.py): the deterministic ones point by point,
+    the random ones by count statistics under a fixed NumPy seed"""
+    out = {}
+    for (key, obj, args) in (("rect_300", raster.RectGrid(), (300,)), ("rect_17", raster.RectGrid(), (17,)),
+                             ("hex_200", raster.HexGrid(), (200,)), ("hex_31", raster.HexGrid(), (31,)),
+                             ("meridional_9_0", raster.MeridionalFan(), (9, 0.)),
+                             ("meridional_8_30", raster.MeridionalFan(), (8, 30.)),
+                             ("sagital_7_0", raster.SagitalFan(), (7, 0.)),
+                             ("sagital_6_45", raster.SagitalFan(), (6, 45.)),
+                             ("chiefcoma_20", raster.ChiefAndComa(), (1, 20.)),
+                             ("single", raster.Single(), (1, 0.25, -0.5)),
+                             ("circular_100_eq", raster.CircularGrid(), (100, True)),
+                             ("circular_50_area", raster.CircularGrid(), (50, False))):
+        (x, y) = obj.getGrid(*args)
+        out[key] = {"x": [float(v) for v in x], "y": [float(v) for v in y]}
+    np.random.seed(12345)
+    (x, y) = raster.RandomGrid().getGrid(500)
+    out["random_500_seed12345"] = {"x": [float(v) for v in x], "y": [float(v) for v in y]}
+    with open(os.path.join(OUT, "rasters.json"), "w") as f:
+        json.dump(out, f)
+    print("rasters.json: %d rasters" % len(out))
+
+
 def case_tilted():
     (s, seq) = zoo.tilted(REFAPI)
     dump_case("tilted_frames", s, seq, disk_bundle(300, 6.5, -3.0, field_deg=2.0, wave=0.6563e-3))
@@ -439,6 +463,7 @@ def main():
     case_zernike()
     case_gridsag()
     case_prism()
+    case_rasters()
     case_tilted()
     case_mirror()
     case_hud()

@@ -1,0 +1,1 @@
+from . import raster  # noqa: F401

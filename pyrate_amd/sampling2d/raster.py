@@ -1,8 +1,15 @@
 """Pupil rasters -> (xpup, ypup) in the unit disk (reference: sampling2d/raster.py:37-164).
-Deterministic input generators for the trace ("identical pupil samples"); host side."""
+Input generators for the trace ("identical pupil samples"); host side.  ``RectGrid`` also exists
+on the device (prt_collimated_bundle, bit-identical).  Angles ``phi`` are in degrees like in the
+reference."""
 import math
 
 import numpy as np
+
+
+def _inside_unit_disk(x, y):
+    keep = (x ** 2 + y ** 2) <= 1
+    return (x[keep], y[keep])
 
 
 class RectGrid(object):
@@ -12,30 +19,98 @@ class RectGrid(object):
         dx = 1. / n_per_dim
         x1d = np.linspace(-1 + .25 * dx, 1 - .25 * dx, n_per_dim)
         (xpup, ypup) = np.meshgrid(x1d, x1d)
-        xpup = np.reshape(xpup, n_per_dim ** 2)
-        ypup = np.reshape(ypup, n_per_dim ** 2)
-        ind = (xpup ** 2 + ypup ** 2) <= 1
-        return (xpup[ind], ypup[ind])
+        return _inside_unit_disk(np.reshape(xpup, n_per_dim ** 2), np.reshape(ypup, n_per_dim ** 2))
+
+
+class HexGrid(RectGrid):
+    def getGrid(self, nray):
+        """hexagonal raster = two interleaved rectangular lattices (lattice + basis), each clipped
+        to the disk and stacked one after the other"""
+        nx = int(round(math.sqrt(2 * math.sqrt(3) * nray / math.pi) + 1))
+        x1d = np.linspace(-1, 1, nx)
+        y1d = x1d * math.sqrt(3)
+        (xa, ya) = np.meshgrid(x1d, y1d)
+        xb = xa + 0.5 * (x1d[1] - x1d[0])
+        yb = ya + 0.5 * (y1d[1] - y1d[0])
+        (xa, ya) = _inside_unit_disk(xa.reshape(nx ** 2), ya.reshape(nx ** 2))
+        (xb, yb) = _inside_unit_disk(xb.reshape(nx ** 2), yb.reshape(nx ** 2))
+        return (np.hstack((xa, xb)), np.hstack((ya, yb)))
+
+
+class RandomGrid(RectGrid):
+    def getGrid(self, nray):
+        """uniformly random points of the square, clipped to the disk (global NumPy generator,
+        x drawn before y, like the reference)"""
+        nsquare = int(round(nray * 4.0 / math.pi))
+        xpup = 2. * np.random.random(nsquare) - 1.
+        ypup = 2. * np.random.random(nsquare) - 1.
+        return _inside_unit_disk(xpup, ypup)
+
+
+class PoissonDiskSampling(RectGrid):
+    def getGrid(self, nray, tries=30):
+        """blue-noise points with a minimum mutual distance of 1/sqrt(4 nray / pi) (Bridson's
+        algorithm on [-1, 1]^2, clipped to the disk).  The reference uses its own Poisson2D dart
+        thrower on the same square with the same distance; both are random, so only the point
+        statistics agree."""
+        n_per_dim = int(round(math.sqrt(nray * 4.0 / math.pi)))
+        r = 1. / n_per_dim
+        cell = r / math.sqrt(2.)
+        ncell = int(math.ceil(2.0 / cell))
+        grid = -np.ones((ncell, ncell), dtype=int)
+        pts = []
+        active = []
+
+        def put(p):
+            pts.append(p)
+            active.append(len(pts) - 1)
+            grid[int(p[0] / cell), int(p[1] / cell)] = len(pts) - 1
+
+        put(np.random.random(2) * 2.0)
+        while active:
+            pick = active[np.random.randint(len(active))]
+            base = pts[pick]
+            for _ in range(tries):
+                rad = r * (1. + np.random.random())
+                ang = 2. * math.pi * np.random.random()
+                cand = base + rad * np.array([math.cos(ang), math.sin(ang)])
+                if not (0. <= cand[0] < 2. and 0. <= cand[1] < 2.):
+                    continue
+                (ci, cj) = (int(cand[0] / cell), int(cand[1] / cell))
+                near = grid[max(ci - 2, 0):ci + 3, max(cj - 2, 0):cj + 3].ravel()
+                if all(np.sum((pts[q] - cand) ** 2) >= r * r for q in near if q >= 0):
+                    put(cand)
+                    break
+            else:
+                active.remove(pick)
+        sample = np.array(pts) - 1.0
+        return _inside_unit_disk(sample[:, 0], sample[:, 1])
 
 
 class MeridionalFan(RectGrid):
     def getGrid(self, nray, phi=0.):
-        """fan along the y axis (rotated by phi)"""
-        rpup = np.linspace(-1, 1, nray)
-        return (-rpup * math.sin(phi), rpup * math.cos(phi))
+        """fan along the y axis, rotated by phi [deg] towards -x"""
+        t = np.linspace(-1, 1, nray)
+        alpha = phi / 180. * math.pi
+        return (t * -math.sin(alpha), t * math.cos(alpha))
 
 
-class SagittalFan(RectGrid):
+class SagitalFan(RectGrid):
+    """(spelling of the reference)"""
+
     def getGrid(self, nray, phi=0.):
-        return MeridionalFan().getGrid(nray, phi + math.pi / 2)
+        return MeridionalFan().getGrid(nray, phi - 90.)
+
+
+SagittalFan = SagitalFan
 
 
 class ChiefAndComa(RectGrid):
     def getGrid(self, nray, phi=0.):
-        """chief ray plus meridional and sagittal coma rays (5 points)"""
-        xpup = np.array([0., 0., 0., 1., -1.])
-        ypup = np.array([0., 1., -1., 0., 0.])
-        return (xpup * math.cos(phi) - ypup * math.sin(phi), xpup * math.sin(phi) + ypup * math.cos(phi))
+        """chief ray (twice) and the four marginal rays of the meridional / sagittal sections"""
+        alpha = phi / 180. * math.pi
+        (sa, ca) = (math.sin(alpha), math.cos(alpha))
+        return (np.array([0, 0, -sa, sa, ca, -ca], dtype=float), np.array([0, 0, ca, -ca, sa, -sa], dtype=float))
 
 
 class Single(RectGrid):
@@ -43,5 +118,19 @@ class Single(RectGrid):
         self.xpup = xpup
         self.ypup = ypup
 
-    def getGrid(self, nray):
-        return (np.array([self.xpup]), np.array([self.ypup]))
+    def getGrid(self, nray, xpup=None, ypup=None):
+        return (np.array([self.xpup if xpup is None else xpup]),
+                np.array([self.ypup if ypup is None else ypup]))
+
+
+class CircularGrid(RectGrid):
+    def getGrid(self, nray, requidistant=True):
+        """polar raster: sqrt(nray) radii x sqrt(nray) azimuths; requidistant=False spaces the radii
+        for nearly equal area elements"""
+        n = int(round(math.sqrt(nray)))
+        r = np.linspace(0, 1, num=n)
+        if not requidistant:
+            r = np.sqrt(r)
+        phi = np.linspace(0, 2. * math.pi, num=n, endpoint=False)
+        (rr, pp) = np.meshgrid(r, phi)
+        return ((rr * np.cos(pp)).flatten(), (rr * np.sin(pp)).flatten())

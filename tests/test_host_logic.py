@@ -306,3 +306,31 @@ def test_gridsag_oracle_and_table(api):
     _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("gridsag_field2").table)
     table = st.pack_table(_golden.load_case("gridsag_field2").table)
     assert table[1].shape_type == 5 and table[1].grid_nx == 29 and table[1].grid_ny == 25 and table[1].aux
+
+
+def test_pupil_rasters_equal_reference():
+    """every raster of sampling2d/raster.py: same points in the same order (the random one under
+    the same NumPy seed); Poisson-disk: minimum distance and coverage"""
+    from pyrate_amd.sampling2d import raster
+    ref = json.load(open(os.path.join(_golden.GOLDEN_DIR, "rasters.json")))
+    cases = {"rect_300": (raster.RectGrid(), (300,)), "rect_17": (raster.RectGrid(), (17,)),
+             "hex_200": (raster.HexGrid(), (200,)), "hex_31": (raster.HexGrid(), (31,)),
+             "meridional_9_0": (raster.MeridionalFan(), (9, 0.)), "meridional_8_30": (raster.MeridionalFan(), (8, 30.)),
+             "sagital_7_0": (raster.SagitalFan(), (7, 0.)), "sagital_6_45": (raster.SagitalFan(), (6, 45.)),
+             "chiefcoma_20": (raster.ChiefAndComa(), (1, 20.)), "single": (raster.Single(), (1, 0.25, -0.5)),
+             "circular_100_eq": (raster.CircularGrid(), (100, True)),
+             "circular_50_area": (raster.CircularGrid(), (50, False))}
+    for (key, (obj, args)) in cases.items():
+        (x, y) = obj.getGrid(*args)
+        assert np.array_equal(x, np.array(ref[key]["x"])) and np.array_equal(y, np.array(ref[key]["y"])), key
+    np.random.seed(12345)
+    (x, y) = raster.RandomGrid().getGrid(500)
+    assert np.array_equal(x, np.array(ref["random_500_seed12345"]["x"]))
+    assert np.array_equal(y, np.array(ref["random_500_seed12345"]["y"]))
+    np.random.seed(3)
+    (x, y) = raster.PoissonDiskSampling().getGrid(300)
+    r = 1. / int(round(math.sqrt(300 * 4.0 / math.pi)))
+    d2 = (x[:, None] - x[None, :]) ** 2 + (y[:, None] - y[None, :]) ** 2 + np.eye(len(x))
+    assert d2.min() >= r * r * (1 - 1e-12) and np.all(x ** 2 + y ** 2 <= 1)
+    assert len(x) > 150            # (the minimum distance 1/n_per_dim packs about 2.6 nray points, in the reference too)
+    assert raster.Single(0.1, 0.2).getGrid(1) == (np.array([0.1]), np.array([0.2]))
