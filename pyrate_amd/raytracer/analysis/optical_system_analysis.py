@@ -96,6 +96,25 @@ class OpticalSystemAnalysis(object):
     def trace(self, **kwargs):
         return [self.opticalsystem.seqtrace(ib, self.sequence, **kwargs) for ib in self.initial_bundles]
 
+    def set_sequence(self, seq):
+        self.sequence = seq
+
+    def get_sequence(self):
+        return self.sequence
+
+    def get_footprint(self):
+        """placeholder of the reference (:272-281)"""
+        return np.array([0, 0])
+
+    def get_matrices(self, **kwargs):
+        raise NotImplementedError()
+
+    def prettyprint(self):
+        for (elem, elemseq) in self.sequence:
+            print(elem)
+            for (surf, opts) in elemseq:
+                print("    " + surf + " " + str(opts))
+
     # ---- convenience wrappers (:193-303); results leave the device only here -----------------
     def trace_3d_global(self, x0, k0, wave=standard_wavelength, **kwargs):
         """trace from given start points / wave vectors (E = ey); per field point, per ray path:

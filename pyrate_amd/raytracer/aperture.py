@@ -3,6 +3,8 @@ themselves are evaluated per ray inside the HIP propagate step; these classes on
 carry the parameters and the frame, with the reference's constructor signatures."""
 import math
 
+import numpy as np
+
 from .variables import Named
 
 
@@ -22,6 +24,14 @@ class BaseAperture(Named):
     def get_typical_dimension(self):
         return self.annotations["typicaldimension"]
 
+    # host-side form of the predicate for callers that hold NumPy points in the aperture frame
+    # (aperture.py:71-88); the trace itself evaluates it inside the kernels (aperture_ok)
+    def get_boolean_function(self):
+        return lambda x, y: np.ones_like(x, dtype=bool)
+
+    def are_points_in_aperture(self, x_intersection, y_intersection):
+        return self.get_boolean_function()(np.asarray(x_intersection), np.asarray(y_intersection))
+
 
 class CircularAperture(BaseAperture):
     kind = "aperture_Circular"
@@ -31,6 +41,10 @@ class CircularAperture(BaseAperture):
         return cls(lc, {"maxradius": maxradius, "minradius": minradius,
                         "typicaldimension": maxradius}, name=name)
 
+    def get_boolean_function(self):
+        (rmin, rmax) = (self.annotations["minradius"], self.annotations["maxradius"])
+        return lambda x, y: (x ** 2 + y ** 2 >= rmin ** 2) * (x ** 2 + y ** 2 <= rmax ** 2)
+
 
 class RectangularAperture(BaseAperture):
     kind = "aperture_Rectangle"
@@ -39,6 +53,10 @@ class RectangularAperture(BaseAperture):
     def p(cls, lc, width=1.0, height=1.0, name="", *_):
         return cls(lc, {"width": width, "height": height,
                         "typicaldimension": math.sqrt(width ** 2 + height ** 2)}, name=name)
+
+    def get_boolean_function(self):
+        (w, h) = (self.annotations["width"], self.annotations["height"])
+        return lambda x, y: (x >= -w * 0.5) * (x <= w * 0.5) * (y >= -h * 0.5) * (y <= h * 0.5)
 
 
 ACCESSIBLE_APERTURES = {None: BaseAperture, "CircularAperture": CircularAperture,

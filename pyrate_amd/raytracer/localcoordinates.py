@@ -55,6 +55,9 @@ class LocalCoordinates(Named):
     def children(self):
         return self._children
 
+    def getChildren(self):
+        return self._children
+
     def addChild(self, childlc):
         childlc.parent = self
         childlc.update()
@@ -92,6 +95,28 @@ class LocalCoordinates(Named):
         if tiltThenDecenter == 0:
             return np.dot(rz, np.dot(ry, rx))
         return np.dot(rx, np.dot(ry, rz))
+
+    @staticmethod
+    def FactorMatrixXYZ(mat):
+        """angles of R = Rx(tx) Ry(ty) Rz(tz) (Euler factorisation; localcoordinates.py:182-204)"""
+        if mat[0, 2] < 1:
+            if mat[0, 2] > -1:
+                return (math.atan2(-mat[1, 2], mat[2, 2]), math.asin(mat[0, 2]), math.atan2(-mat[0, 1], mat[0, 0]))
+            return (-math.atan2(mat[1, 0], mat[1, 1]), -math.pi / 2, 0.)
+        return (math.atan2(mat[1, 0], mat[1, 1]), math.pi / 2, 0.)
+
+    @staticmethod
+    def FactorMatrixZYX(mat):
+        """angles of R = Rz(tz) Ry(ty) Rx(tx), returned as (tx, ty, tz) (localcoordinates.py:206-228)"""
+        if mat[2, 0] < 1:
+            if mat[2, 0] > -1:
+                return (math.atan2(mat[2, 1], mat[2, 2]), math.asin(-mat[2, 0]), math.atan2(mat[1, 0], mat[0, 0]))
+            return (0., math.pi / 2, -math.atan2(-mat[1, 2], mat[1, 1]))
+        return (0., -math.pi / 2, math.atan2(-mat[1, 2], mat[1, 1]))
+
+    def calculateTiltFromMatrix(self, mat, tiltThenDecenter=0):
+        """inverse of calculateMatrixFromTilt"""
+        return self.FactorMatrixZYX(mat) if tiltThenDecenter == 0 else self.FactorMatrixXYZ(mat)
 
     def calculate(self):
         self.localdecenter = np.array([self.decx(), self.decy(), self.decz()])
@@ -140,6 +165,30 @@ class LocalCoordinates(Named):
 
     def returnOtherToActualDirections(self, otherdirs, lcother):
         return self.returnGlobalToLocalDirections(lcother.returnLocalToGlobalDirections(otherdirs))
+
+
+def _tensor_transform(basis, tensors):
+    """B T B^T for a stack of 3x3 tensors given as (3, 3, N)"""
+    return np.einsum("lj,jin,ki->lkn", basis, np.asarray(tensors), basis)
+
+
+LocalCoordinates.returnLocalToGlobalTensors = lambda self, t: _tensor_transform(self.localbasis, t)
+LocalCoordinates.returnGlobalToLocalTensors = lambda self, t: _tensor_transform(self.localbasis.T, t)
+LocalCoordinates.returnActualToOtherTensors = \
+    lambda self, t, other: other.returnGlobalToLocalTensors(self.returnLocalToGlobalTensors(t))
+LocalCoordinates.returnOtherToActualTensors = \
+    lambda self, t, other: self.returnGlobalToLocalTensors(other.returnLocalToGlobalTensors(t))
+
+
+def _pprint(self, n=0):
+    """tree of frame names with their global origins (localcoordinates.py:451-463)"""
+    s = n * "    " + self.name + " (" + str(self.globalcoordinates) + ")\n"
+    for ch in self._children:
+        s += ch.pprint(n + 1)
+    return s
+
+
+LocalCoordinates.pprint = _pprint
 
 
 class LocalCoordinatesTreeBase(Named):

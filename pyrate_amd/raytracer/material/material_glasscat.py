@@ -72,6 +72,17 @@ class GlassCatalog(object):
                 out[entry.pop(key)] = entry
         return out
 
+    convert_list_to_dict = _index
+
+    def get_material_dict_nd_vd_pgf(self, nd_value=1.51680, vd_value=64.17, pgf_value=0.5349):
+        raise NotImplementedError()          # not implemented in the reference either (:268-287)
+
+    def get_material_dict_nd_vd(self, nd_value=1.51680, vd_value=64.17):
+        raise NotImplementedError()
+
+    def get_material_dict_schott_code(self, schott_code=517642):
+        raise NotImplementedError()
+
     def read_library(self, library_yml_filename):
         lib = self._index(self.read_yml_file(library_yml_filename), "SHELF")
         for shelf in lib.values():

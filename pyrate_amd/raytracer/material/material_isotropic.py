@@ -44,3 +44,26 @@ class ModelGlass(IsotropicMaterial):
 
     def get_optical_index(self, x, wave):
         return self.n0() + self.A() / wave + self.B() / (wave ** 3.5)
+
+    # Conrady coefficients from catalogue numbers.  The reference's versions of these three
+    # (material_isotropic.py:311-353) call a setter that does not exist and swap A and B; these set
+    # the coefficients of the formulas their docstrings describe.
+    def calcCoefficientsFrom_nd_vd_PgF(self, nd=1.51680, vd=64.17, PgF=0.5349):
+        nF_minus_nC = (nd - 1.) / vd
+        b_um = 0.454670392956 * nF_minus_nC * (PgF - 0.445154791693)
+        a_um = 1.87513751845 * nF_minus_nC - b_um * 15.2203074842
+        self.n0.set_value(nd - 1.70194862906 * a_um - 6.43150432188 * b_um)
+        self.A.set_value(a_um * 1e-3)
+        self.B.set_value(b_um * (1e-3) ** 3.5)
+
+    def calcCoefficientsFrom_nd_vd(self, nd=1.51680, vd=64.17):
+        self.calcCoefficientsFrom_nd_vd_PgF(nd, vd, 0.6438 - 0.001682 * vd)
+
+    def calcCoefficientsFromSchottCode(self, schottCode=517642):
+        """six-digit code: first three digits 1000 (nd - 1), last three 10 vd; anything else is
+        replaced by N-BK7 like in the reference"""
+        if isinstance(schottCode, int) and 1e5 <= schottCode < 1e6:
+            (nd, vd) = (1 + 0.001 * (schottCode // 1000), 0.1 * (schottCode % 1000))
+        else:
+            (nd, vd) = (1.51680, 64.17)
+        self.calcCoefficientsFrom_nd_vd(nd, vd)

@@ -41,6 +41,22 @@ class Surface(LocalCoordinatesTreeBase):
             raise Exception("Aperture coordinate system should be connected to surface coordinate system")
         self._aperture = apert
 
+    # accessor spellings of the reference (surface.py:73-114)
+    def getShape(self):
+        return self.shape
+
+    def setShape(self, shape):
+        self.shape = shape
+
+    def getAperture(self):
+        return self.aperture
+
+    def setAperture(self, apert):
+        self.aperture = apert
+
+    def getCentralCurvature(self):
+        return self.shape.getCentralCurvature()
+
     def intersect(self, raybundle, remove_rays_outside_aperture=True):
         """intersection + aperture vignetting; mutates the bundle (surface.py:116-135)"""
         from .material.material import propagate_bundle

@@ -100,6 +100,14 @@ class ExplicitShape(Shape):
         self.annotations["tol"] = tol
         self.annotations["iterations"] = iterations
 
+    # the reference's hooks of an explicit shape (surface_shape.py:434-465): z = F(x, y) and the
+    # gradient of z - F; evaluated on the GPU like getSag / getGrad
+    def F(self, x, y):
+        return self.getSag(x, y)
+
+    def gradF(self, x, y, z=None):
+        return self.getGrad(x, y)
+
 
 class Asphere(ExplicitShape):
     kind = "shape_Asphere"

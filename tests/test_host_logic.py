@@ -334,3 +334,32 @@ def test_pupil_rasters_equal_reference():
     assert d2.min() >= r * r * (1 - 1e-12) and np.all(x ** 2 + y ** 2 <= 1)
     assert len(x) > 150            # (the minimum distance 1/n_per_dim packs about 2.6 nray points, in the reference too)
     assert raster.Single(0.1, 0.2).getGrid(1) == (np.array([0.1]), np.array([0.2]))
+
+
+def test_small_api_completions(api):
+    """aperture predicates, Euler factorisations, tensor transforms, Surface accessors, ModelGlass
+    from catalogue numbers"""
+    lc = api.LocalCoordinates.p(name="f", decx=0.3, tiltx=0.2, tilty=-0.1, tiltz=0.4)
+    child = lc.addChild(api.LocalCoordinates.p(name="c", decz=2.0, tilty=0.3, tiltThenDecenter=1))
+    assert lc.getChildren() == [child] and "c (" in lc.pprint()
+    for order in (0, 1):
+        m = lc.calculateMatrixFromTilt(0.2, -0.1, 0.4, order)
+        assert np.allclose(lc.calculateTiltFromMatrix(m, order), (0.2, -0.1, 0.4), atol=1e-15)
+    t = np.random.RandomState(1).rand(3, 3, 5)
+    g = child.returnLocalToGlobalTensors(t)
+    assert np.allclose(g[:, :, 2], child.localbasis.dot(t[:, :, 2]).dot(child.localbasis.T))
+    assert np.allclose(child.returnGlobalToLocalTensors(g), t)
+    assert np.allclose(lc.returnOtherToActualTensors(child.returnActualToOtherTensors(t, lc), lc), lc.returnGlobalToLocalTensors(child.returnLocalToGlobalTensors(t)))
+    (x, y) = (np.array([0., 3., 5.1, -2.]), np.array([0., 4., 0., 2.]))
+    assert list(api.CircularAperture.p(lc, maxradius=5., minradius=1.).are_points_in_aperture(x, y)) == [False, True, False, True]
+    assert list(api.RectangularAperture.p(lc, width=6., height=5.).are_points_in_aperture(x, y)) == [True, False, False, True]
+    from pyrate_amd.raytracer.aperture import BaseAperture
+    assert BaseAperture.p(lc).are_points_in_aperture(x, y).all()
+    surf = api.Surface.p(lc, shape=api.Conic.p(lc, curv=0.02))
+    assert surf.getShape() is surf.shape and surf.getAperture() is surf.aperture and surf.getCentralCurvature() == 0.02
+    mg = api.ModelGlass.p(lc)
+    mg.calcCoefficientsFrom_nd_vd(1.5168, 64.17)
+    (nd, nF, nC) = [mg.get_optical_index(None, w) for w in (0.5875618e-3, 0.4861327e-3, 0.6562725e-3)]
+    assert abs(nd - 1.5168) < 2e-6 and abs((nd - 1) / (nF - nC) - 64.17) < 0.05
+    mg.calcCoefficientsFromSchottCode(517642)
+    assert abs(mg.get_optical_index(None, 0.5875618e-3) - 1.517) < 2e-6
