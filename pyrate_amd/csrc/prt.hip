@@ -426,11 +426,22 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
             return trace_general(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, e_out, e_out_im, valid, valid_out, st);
         const dim3 grid(nblocks(n0, PRT_BLOCK)), block(PRT_BLOCK);
         const int32_t e_mode_g = e_mode_of(e0_re, 1);
-#define PRT_LAUNCH_G(KERNEL, MODE_)                                                                     \
-    hipLaunchKernelGGL((KERNEL<MODE_>), grid, block, 0, st, sys->d_table, sys->n_surfaces, n_aniso, n0, \
-                       x0, k0, e0_re, e0_im, e_mode_g, x_hit, k_out, e_out, e_out_im, valid, valid_out)
-        if (mode == PRT_MODE_PATH) PRT_LAUNCH_G(k_trace_general, PRT_MODE_PATH);
-        else PRT_LAUNCH_G(k_trace_general, PRT_MODE_IMAGE);
+        bool general_eps = false;
+        for (int s = 0; s < sys->n_surfaces; ++s)
+            if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC &&
+                sys->h_table[s].aniso_class == PRT_ANISO_GENERAL)
+                general_eps = true;
+#define PRT_LAUNCH_G(MODE_, GEN_)                                                                        \
+    hipLaunchKernelGGL((k_trace_general<MODE_, GEN_>), grid, block, 0, st, sys->d_table, sys->n_surfaces, \
+                       n_aniso, n0, x0, k0, e0_re, e0_im, e_mode_g, x_hit, k_out, e_out, e_out_im, valid, \
+                       valid_out)
+        if (mode == PRT_MODE_PATH) {
+            if (general_eps) PRT_LAUNCH_G(PRT_MODE_PATH, true);
+            else PRT_LAUNCH_G(PRT_MODE_PATH, false);
+        } else {
+            if (general_eps) PRT_LAUNCH_G(PRT_MODE_IMAGE, true);
+            else PRT_LAUNCH_G(PRT_MODE_IMAGE, false);
+        }
 #undef PRT_LAUNCH_G
         HIP_TRY(hipGetLastError());
         return PRT_OK;

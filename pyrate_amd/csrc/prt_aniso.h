@@ -215,6 +215,9 @@ PRT_DEV vec3 null_vector(const vec3 &r0, const vec3 &r1, const vec3 &r2, int var
 // The four (xi, E, S.n) solutions for one ray, then the reference's ordering.
 // p: hit point in the shape frame; k: incoming wave vector (global).
 // out[0], out[1]: refract -> sorted solutions 2, 3; mirror -> -(0), -(1).
+// GENERAL = false: the host guarantees that no crystal of the table needs the quartic solver (all
+// epsilon tensors isotropic or uniaxial) and that code is compiled out.
+template <bool GENERAL = true>
 PRT_DEV void interact_anisotropic(const prt_surface_t *__restrict__ sf, const vec3 &p,
                                   const vec3 &k_glob, aniso_solution out[2]) {
     const vec3 n = normal_in_material_frame(sf, p);
@@ -250,6 +253,9 @@ PRT_DEV void interact_anisotropic(const prt_surface_t *__restrict__ sf, const ve
         xi[1] = fmin(x1, x2); xi[3] = fmax(x1, x2);
         if (!isfinite(disc)) { xi[1] = xi[3] = __builtin_nan(""); }
         variant[0] = 0; variant[2] = 0; variant[1] = 1; variant[3] = 1;
+    } else if (!GENERAL) {
+        xi[0] = xi[1] = xi[2] = xi[3] = __builtin_nan("");
+        variant[0] = variant[1] = variant[2] = variant[3] = 0;
     } else {
         double pc[5];
         xi_polynomial(eps, n, kpa, pc);

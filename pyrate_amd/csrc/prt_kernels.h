@@ -231,7 +231,7 @@ __global__ __launch_bounds__(PRT_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE == PRT_M
 // 3 waves/SIMD: the register allocator lands at 170 VGPRs on its own (2 waves); capping it at 168
 // costs three spilled dwords and gains 11 % (0.277 -> 0.246 ms); 4 waves (128 VGPRs, 160 B of
 // scratch) is slower than either (0.36 ms).
-template <int MODE>
+template <int MODE, bool GENERAL = true>
 __global__ __launch_bounds__(PRT_BLOCK, 3) void k_trace_general(
     const prt_surface_t *__restrict__ tab, int32_t S, int32_t A, int64_t N,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(PRT_BLOCK, 3) void k_trace_general(
                 x[c] = xh;
                 if (crystal) {  // only reached with nstate == 1 (c == 0)
                     aniso_solution sol[2];
-                    interact_anisotropic(sf, p, k[0], sol);
+                    interact_anisotropic<GENERAL>(sf, p, k[0], sol);
                     valid[0] = alive;  // no validity filtering at a crystal interface (ray.py:68)
                     const bool keep_both = (a == A - 1);
                     const int pick = (int)((P >> a) & 1);
