@@ -363,3 +363,36 @@ def test_small_api_completions(api):
     assert abs(nd - 1.5168) < 2e-6 and abs((nd - 1) / (nF - nC) - 64.17) < 0.05
     mg.calcCoefficientsFromSchottCode(517642)
     assert abs(mg.get_optical_index(None, 0.5875618e-3) - 1.517) < 2e-6
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/prt.h compiles as C99 (the boundary is a C ABI, not a C++ one) and a C program
+    links against libprt.so"""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi_check.c"
+    src.write_text("""#include <stddef.h>
+#include "prt.h"
+int main(void) {
+    prt_surface_t table[2];
+    prt_system_t *sys = NULL;
+    (void)table;
+    if (prt_abi_version() != PRT_ABI_VERSION) return 1;
+    if (prt_sizeof_surface() != (int32_t)sizeof(prt_surface_t)) return 2;
+    (void)sys;
+    return 0;
+}
+""")
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "pyrate_amd", "csrc")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)],
+                   check=True)
+    exe = tmp_path / "abi_check"
+    subprocess.run([gcc, "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lprt",
+                    "-Wl,-rpath," + libdir], check=True)
+    # sizeof / version agree between the C compiler's view of the header and the library
+    # (runs without a GPU: neither call touches the device)
+    assert subprocess.run([str(exe)]).returncode == 0
