@@ -103,7 +103,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--rays", type=int, default=10_000_000, help="requested rays per GPU")
+    ap.add_argument("--rays", type=int, default=None,
+                    help="requested rays per GPU (default: 1e7 at N = 1 = BASELINE configs[1]; 1.25e7 at N > 1, "
+                         "so that 8 GPUs trace the 1e8-ray bundle of configs[4])")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the final image-plane all-gather")
     ap.add_argument("--no-stats", action="store_true", help="N>1: skip the per-step spot statistics all-reduce")
     ap.add_argument("--gather-every-step", action="store_true",
@@ -133,6 +135,8 @@ def main():
                                   "--master-port", os.environ.get("MASTER_PORT", "29577"),
                                   os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.rays is None:
+        args.rays = 10_000_000 if (world == 1 and not args.force_multi) else 12_500_000
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_multi
@@ -320,7 +324,8 @@ def main():
                                     "BASELINE configs[1]") if n_gpus == 1 else
                                    ("demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 double "
                                     "Gauss), 5 wavelengths cycled (Conrady indices), RectGrid disk "
-                                    "bundle ray-sharded over the GPUs, BASELINE configs[4]"),
+                                    "bundle ray-sharded over the GPUs (1.25e7 rays per GPU: the 1e8-ray bundle at "
+                                    "8 GPUs), BASELINE configs[4]"),
                        "rays_per_gpu": n_local, "rays_total": n_total, "surfaces": S,
                        "mode": args.mode, "sharding": "rays" if n_gpus > 1 else "none",
                        "wavelengths": len(sysds), "prewarm_launches": PREWARM_LAUNCHES,
