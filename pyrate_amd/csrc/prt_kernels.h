@@ -124,6 +124,9 @@ template <int MODE, bool VEC_IN, bool VEC_OUT, bool EXPLICIT = true, bool LDS_TA
 #ifndef PRT_PATH_WAVES
 #define PRT_PATH_WAVES 1
 #endif
+#ifdef PRT_PATH_WAVES_MAX   // experiment: cap the occupancy of every march instantiation
+__attribute__((amdgpu_waves_per_eu(1, PRT_PATH_WAVES_MAX)))
+#endif
 __global__ __launch_bounds__(PRT_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE == PRT_MODE_IMAGE ? 8 : PRT_PATH_WAVES) : 1) void k_trace_iso(
     const prt_surface_t *__restrict__ tab_g, int32_t S, int64_t N, int64_t in_pitch,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
