@@ -38,11 +38,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PREWARM_LAUNCHES = 30
 
 
-def algorithmic_bytes(n_rays, n_surfaces, with_e0=True):
+def algorithmic_bytes(n_rays, n_surfaces, with_e0=True, record_bytes=49):
     """HBM bytes the fused path-mode march must move per launch:
-    read x0, k0 (+E0) once: 48 (+24) B/ray; write per surface x_hit 24 + k_out 24 +
-    valid 1 + valid_out 1 = 50 B/ray."""
-    return n_rays * ((72 if with_e0 else 48) + 50 * n_surfaces)
+    read x0, k0 (+E0) once: 48 (+24) B/ray; write per surface x_hit 24 + k_out 24 + one byte holding
+    both masks (valid | valid_out << 1) = 49 B/ray -- SURVEY 8d's ray-surface record -- or 50 B with
+    the masks in two separate arrays."""
+    return n_rays * ((72 if with_e0 else 48) + record_bytes * n_surfaces)
 
 
 def cpu_baseline(records, o, k, e0, n_all=None, chunk=100_000):
@@ -113,6 +114,9 @@ def main():
     ap.add_argument("--two-pass-stats", action="store_true",
                     help="N>1: per-step spot statistics from two extra passes over the image plane and two "
                          "all-reduces (default: moments reduced inside the trace kernel, one all-reduce)")
+    ap.add_argument("--two-mask-arrays", action="store_true",
+                    help="write valid and valid_out as two byte arrays (50 B per record) instead of one "
+                         "byte of packed flags (49 B, default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["path", "image"], default="path")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -197,7 +201,9 @@ def main():
     # no double buffering (alternating between two of them costs ~6 % write bandwidth, measured:
     # scratch/moments_cost.py)
     n_out_bufs = 1 if (fused_stats and not do_step_gather) else nbuf
-    bufs = [sysd.alloc_outputs(n_local, mode) for _ in range(n_out_bufs)]
+    packed = not args.two_mask_arrays
+    record_bytes = 49 if packed else 50
+    bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed) for _ in range(n_out_bufs)]
     host_staged = (args.backend == "gloo")
     stats = [pdist.SpotStatistics(dev, n_rays=n_local) for _ in range(nbuf)] if do_stats else []
     gathers = [pdist.ImagePlaneGather(n_total, dev, stage_on_host=host_staged)
@@ -300,16 +306,16 @@ def main():
     value = ops_total / elapsed
     if rank == 0:
         if args.mode == "path":
-            alg = algorithmic_bytes(n_local, S)
+            alg = algorithmic_bytes(n_local, S, record_bytes=record_bytes)
         else:
-            alg = n_local * (72 + 50)
+            alg = n_local * (72 + record_bytes)
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                ent = tj.get("%s_%d" % (args.mode, n_local))
+                ent = tj.get("%s_%d%s" % (args.mode, n_local, "" if packed else "_two_masks"))
                 if ent:
                     traffic = ent["bytes_per_launch"]
             except Exception:
@@ -327,7 +333,9 @@ def main():
                                     "bundle ray-sharded over the GPUs (1.25e7 rays per GPU: the 1e8-ray bundle at "
                                     "8 GPUs), BASELINE configs[4]"),
                        "rays_per_gpu": n_local, "rays_total": n_total, "surfaces": S,
-                       "mode": args.mode, "sharding": "rays" if n_gpus > 1 else "none",
+                       "mode": args.mode, "record_bytes": record_bytes,
+                       "masks": "valid | valid_out << 1 in one byte" if packed else "two byte arrays",
+                       "sharding": "rays" if n_gpus > 1 else "none",
                        "wavelengths": len(sysds), "prewarm_launches": PREWARM_LAUNCHES,
                        "image_plane_exchange": {
                            "per_step": (("spot moments reduced inside the trace kernel + one 7-double all-reduce "

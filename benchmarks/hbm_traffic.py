@@ -35,7 +35,7 @@ def main():
     fetch = 2.0 * fetch_kb * 1024.0
     write = write_kb * 1024.0
     alg_r = n * 72
-    alg_w = n * 50 * S
+    alg_w = n * 49 * S            # x_hit 24 + k_out 24 + one byte of packed mask flags per record
     out = {"path_%d" % n: {
         "bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
         "FETCH_SIZE_avg_kb": fetch_kb, "WRITE_SIZE_avg_kb": write_kb,

@@ -82,6 +82,11 @@ enum { PRT_ANISO_GENERAL = 0, PRT_ANISO_ISOTROPIC = 1, PRT_ANISO_UNIAXIAL = 2 };
 /* trace modes */
 #define PRT_MODE_PATH 0  /* write hit point / outgoing k / valid at every surface */
 #define PRT_MODE_IMAGE 1 /* write only the last surface's                          */
+/* OR-ed into the mode of prt_trace / prt_trace_timed / prt_trace_moments (all-isotropic tables):
+ * the two masks of a ray-surface record share one byte, valid[i] = (valid after intersect +
+ * aperture) | (valid after the interaction) << 1, and valid_out is not written (may be NULL):
+ * 49 instead of 50 bytes and one store stream less per surface */
+#define PRT_MODE_FLAGS 2
 
 /*
  * One record per traced surface, in sequence order (the flattened

@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("PRT_LIBRARY") or os.path.join(_HERE, "csrc", "libprt.
 PRT_OK = 0
 MODE_PATH = 0
 MODE_IMAGE = 1
+MODE_FLAGS = 2          # OR-ed in: both masks of a record in one byte (include/prt.h)
 
 c_double_p = ctypes.c_void_p      # device pointers travel as raw addresses
 c_u8_p = ctypes.c_void_p

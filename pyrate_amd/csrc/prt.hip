@@ -116,12 +116,13 @@ static void launch_trace_iso(const prt_system_t *sys, int64_t n0, int64_t in_pit
                              const double *k0, const double *e_re, const double *e_im,
                              int32_t e_mode, int64_t out_pitch, double *x_hit, double *k_out,
                              uint8_t *valid, uint8_t *valid_out, bool vec_in, bool vec_out,
-                             hipStream_t st) {
+                             int32_t packed_flags, hipStream_t st) {
     const dim3 grid(nblocks(n0, PRT_BLOCK * 2)), block(PRT_BLOCK);
 #define PRT_LAUNCH_E(VI, VO, EX)                                                                 \
     hipLaunchKernelGGL((k_trace_iso<MODE, VI, VO, EX>), grid, block, 0, st, sys->d_table,        \
                        sys->n_surfaces, n0, in_pitch, x0, k0, e_re, e_im, e_mode, out_pitch,     \
-                       x_hit, k_out, valid, valid_out)
+                       x_hit, k_out, valid, valid_out, 0.0, 0.0, 0.0, (double *)nullptr,         \
+                       packed_flags)
 #define PRT_LAUNCH(VI, VO)                 \
     do {                                   \
         if (sys->all_conic)                \
@@ -133,7 +134,7 @@ static void launch_trace_iso(const prt_system_t *sys, int64_t n0, int64_t in_pit
     if (vec_in && vec_out && lds_table && sys->all_conic && sys->n_surfaces <= PRT_LDS_TAB_MAX)
         hipLaunchKernelGGL((k_trace_iso<MODE, true, true, false, true>), grid, block, 0, st, sys->d_table,
                            sys->n_surfaces, n0, in_pitch, x0, k0, e_re, e_im, e_mode, out_pitch, x_hit,
-                           k_out, valid, valid_out);
+                           k_out, valid, valid_out, 0.0, 0.0, 0.0, (double *)nullptr, packed_flags);
     else if (vec_in && vec_out)
         PRT_LAUNCH(true, true);
     else if (vec_in)
@@ -400,8 +401,12 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
                           int64_t out_pitch, double *x_hit, double *k_out, double *e_out,
                           double *e_out_im, uint8_t *valid, uint8_t *valid_out, void *stream) {
     if (!sys || n0 < 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace: null system / negative count");
+    const int32_t packed_flags = (mode & PRT_MODE_FLAGS) ? 1 : 0;
+    if (mode >= 0) mode &= ~PRT_MODE_FLAGS;
     if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE)
         return fail(PRT_ERR_INVALID_ARG, "prt_trace: bad mode");
+    if (packed_flags && !sys->all_isotropic)
+        return fail(PRT_ERR_UNSUPPORTED, "prt_trace: PRT_MODE_FLAGS needs an all-isotropic table");
     if (n0 == 0) return PRT_OK;  // empty bundle: nothing to do (buffers may be NULL)
     if (!x0 || !k0 || !x_hit || !k_out || !valid)
         return fail(PRT_ERR_INVALID_ARG, "prt_trace: null pointer");
@@ -450,16 +455,17 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
     const int32_t e_mode = e_mode_of(e0_re, 1);
     const bool vec_in = (in_pitch % 2 == 0) && aligned16(x0) && aligned16(k0) &&
                         (!e0_re || aligned16(e0_re)) && (!e0_im || aligned16(e0_im));
+    if (packed_flags) valid_out = nullptr;
     const bool vec_out = (out_pitch % 2 == 0) && aligned16(x_hit) && aligned16(k_out) &&
                          ((((uintptr_t)valid) & 1u) == 0) &&
                          (!valid_out || (((uintptr_t)valid_out) & 1u) == 0) &&
                          (n0 % 2 == 0 || out_pitch > n0);  // odd N: the tail lane's 2nd ray lands in the padding
     if (mode == PRT_MODE_PATH)
         launch_trace_iso<PRT_MODE_PATH>(sys, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch,
-                                        x_hit, k_out, valid, valid_out, vec_in, vec_out, st);
+                                        x_hit, k_out, valid, valid_out, vec_in, vec_out, packed_flags, st);
     else
         launch_trace_iso<PRT_MODE_IMAGE>(sys, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch,
-                                         x_hit, k_out, valid, valid_out, vec_in, vec_out, st);
+                                         x_hit, k_out, valid, valid_out, vec_in, vec_out, packed_flags, st);
     HIP_TRY(hipGetLastError());
     return PRT_OK;
 }
@@ -499,6 +505,10 @@ int32_t prt_trace_moments(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
         return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: bad argument");
     if (!sys->all_isotropic)
         return fail(PRT_ERR_UNSUPPORTED, "prt_trace_moments: isotropic tables only (use prt_trace + prt_bundle_moments)");
+    const int32_t mode_in = mode;
+    const int32_t packed_flags = (mode & PRT_MODE_FLAGS) ? 1 : 0;
+    if (mode >= 0) mode &= ~PRT_MODE_FLAGS;
+    if (packed_flags) valid_out = nullptr;
     if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE)
         return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: bad mode");
     if (n0 > 0 && (!x0 || !k0 || !x_hit || !k_out || !valid))
@@ -527,7 +537,7 @@ int32_t prt_trace_moments(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
 #define PRT_LAUNCH_M(MODE_, EX)                                                                           \
     hipLaunchKernelGGL((k_trace_iso<MODE_, true, true, EX, false, true>), grid, block, 0, st, sys->d_table, \
                        sys->n_surfaces, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch, x_hit,     \
-                       k_out, valid, valid_out, rx, ry, rz, scratch_dev)
+                       k_out, valid, valid_out, rx, ry, rz, scratch_dev, packed_flags)
         if (mode == PRT_MODE_PATH) {
             if (sys->all_conic) PRT_LAUNCH_M(PRT_MODE_PATH, false);
             else PRT_LAUNCH_M(PRT_MODE_PATH, true);
@@ -544,7 +554,9 @@ int32_t prt_trace_moments(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
         return PRT_OK;
     }
     // unaligned / odd-pitch buffers: the plain trace followed by the two-kernel reduction
-    int32_t rc = prt_trace(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out, valid,
+    if (packed_flags)
+        return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: PRT_MODE_FLAGS needs aligned, even-pitch buffers");
+    int32_t rc = prt_trace(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode_in, out_pitch, x_hit, k_out, valid,
                            valid_out, stream);
     if (rc != PRT_OK) return rc;
     const int64_t row = (mode == PRT_MODE_PATH) ? (int64_t)(sys->n_surfaces - 1) : 0;

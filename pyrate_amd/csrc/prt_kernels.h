@@ -64,6 +64,18 @@ struct rayio {
             }
         }
     }
+    // two masks packed into one byte per ray: bit 0 = lo, bit 1 = hi (PRT_MODE_FLAGS)
+    static PRT_DEV void store_flags(uint8_t *__restrict__ m, int64_t i, bool second, const bool lo[2],
+                                    const bool hi[2]) {
+        const unsigned f0 = (lo[0] ? 1u : 0u) | (hi[0] ? 2u : 0u);
+        const unsigned f1 = (lo[1] ? 1u : 0u) | (hi[1] ? 2u : 0u);
+        if (VEC) {
+            *reinterpret_cast<uint16_t *>(m + i) = (uint16_t)(f0 | (f1 << 8));
+        } else {
+            m[i] = (uint8_t)f0;
+            if (second) m[i + 1] = (uint8_t)f1;
+        }
+    }
     static PRT_DEV void store_mask(uint8_t *__restrict__ m, int64_t i, bool second, const bool b[2]) {
         if (VEC) {
             *reinterpret_cast<uint16_t *>(m + i) = (uint16_t)((b[0] ? 1u : 0u) | (b[1] ? 0x100u : 0u));
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(PRT_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE == PRT_M
     const double *__restrict__ e_im, int32_t e_mode, int64_t out_pitch,
     double *__restrict__ xh_out, double *__restrict__ k_out, uint8_t *__restrict__ valid_out_hit,
     uint8_t *__restrict__ valid_out_refr, double mref_x = 0.0, double mref_y = 0.0,
-    double mref_z = 0.0, double *__restrict__ moment_partials = nullptr) {
+    double mref_z = 0.0, double *__restrict__ moment_partials = nullptr, int32_t packed_flags = 0) {
     const prt_surface_t *__restrict__ tab = tab_g;
     if (LDS_TAB) {
         __shared__ prt_surface_t lds_tab[PRT_LDS_TAB_MAX];
@@ -179,9 +191,13 @@ __global__ __launch_bounds__(PRT_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE == PRT_M
             const int64_t so = (MODE == PRT_MODE_PATH) ? (int64_t)s : 0;
             rayio<VEC_OUT>::store(xh_out + so * 3 * out_pitch, out_pitch, i, second, x);
             rayio<VEC_OUT>::store(k_out + so * 3 * out_pitch, out_pitch, i, second, k);
-            rayio<VEC_OUT>::store_mask(valid_out_hit + so * out_pitch, i, second, vhit);
-            if (valid_out_refr)
-                rayio<VEC_OUT>::store_mask(valid_out_refr + so * out_pitch, i, second, valid);
+            if (packed_flags) {
+                rayio<VEC_OUT>::store_flags(valid_out_hit + so * out_pitch, i, second, vhit, valid);
+            } else {
+                rayio<VEC_OUT>::store_mask(valid_out_hit + so * out_pitch, i, second, vhit);
+                if (valid_out_refr)
+                    rayio<VEC_OUT>::store_mask(valid_out_refr + so * out_pitch, i, second, valid);
+            }
         }
     }
     }  // i < N

@@ -13,6 +13,10 @@ from . import _lib
 from .surface_table import pack_table
 
 
+def _mode_word(bufs):
+    return bufs["mode"] | (_lib.MODE_FLAGS if bufs.get("packed_flags") else 0)
+
+
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -85,6 +89,7 @@ class TraceResult(object):
 
     def __init__(self, x_hit, k_out, valid, valid_out, n_in, n_out, mode, e_out=None):
         self.e_out = e_out            # per surface (re, im) behind crystal interfaces (trace(want_fields))
+        self.flags = None             # per surface packed mask bytes (alloc_outputs(packed_flags=True))
         self.x_hit = x_hit
         self.k_out = k_out
         self.valid = valid
@@ -107,6 +112,15 @@ class TraceResult(object):
 
             def mask(buf):
                 return lambda s: buf[s * pitch:s * pitch + n]
+            if bufs.get("packed_flags"):
+                # one byte per record: bit 0 = valid, bit 1 = valid_out; the 0/1 masks are derived
+                # on first access (and cached by _LazyViews)
+                flags = mask(bv)
+                res = cls(_LazyViews(rows, rays(bx)), _LazyViews(rows, rays(bk)),
+                          _LazyViews(rows, lambda s: flags(s) & 1), _LazyViews(rows, lambda s: flags(s) >> 1),
+                          n_in, n_out, bufs["mode"])
+                res.flags = _LazyViews(rows, flags)
+                return res
             return cls(_LazyViews(rows, rays(bx)), _LazyViews(rows, rays(bk)), _LazyViews(rows, mask(bv)),
                        _LazyViews(rows, (mask(bw) if bw is not None else (lambda s: None))),
                        n_in, n_out, bufs["mode"])
@@ -165,11 +179,16 @@ class DeviceSystem(object):
         _lib.check(self.lib.prt_system_ray_counts(self._h, n0, n_in, n_out))
         return list(n_in), list(n_out)
 
-    def alloc_outputs(self, n0, mode=_lib.MODE_PATH, with_valid_out=True, pitch=None, want_fields=False):
+    def alloc_outputs(self, n0, mode=_lib.MODE_PATH, with_valid_out=True, pitch=None, want_fields=False,
+                      packed_flags=False):
         """Output buffers for trace_into.  All-isotropic tables get ROW-PITCHED arrays
         ((S,3,pitch) / (S,pitch), pitch = prt_recommended_pitch(n0) unless given: rows aligned
         to 128-B lines are worth ~35 % HBM write bandwidth); tables with anisotropic media get
         the concatenated layout (pitch 0)."""
+        if packed_flags:
+            if not self.all_isotropic:
+                raise ValueError("packed mask flags need an all-isotropic table")
+            with_valid_out = False
         (n_in, n_out) = self.ray_counts(n0)
         if mode == _lib.MODE_IMAGE:
             n_in, n_out = n_in[-1:], n_out[-1:]
@@ -187,7 +206,7 @@ class DeviceSystem(object):
             k_out=torch.empty(nk, dtype=torch.float64, device=dev),
             valid=torch.empty(nv, dtype=torch.uint8, device=dev),
             valid_out=(torch.empty(nw, dtype=torch.uint8, device=dev) if with_valid_out else None),
-            n_in=n_in, n_out=n_out, mode=mode, pitch=pitch)
+            n_in=n_in, n_out=n_out, mode=mode, pitch=pitch, packed_flags=bool(packed_flags))
         if want_fields:
             if self.all_isotropic:
                 raise ValueError("E fields are produced at crystal interfaces only")
@@ -210,7 +229,7 @@ class DeviceSystem(object):
             return
         in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
         _lib.check(self.lib.prt_trace(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
-                                      _ptr(e0_im), bufs["mode"], bufs["pitch"], _ptr(bufs["x_hit"]),
+                                      _ptr(e0_im), _mode_word(bufs), bufs["pitch"], _ptr(bufs["x_hit"]),
                                       _ptr(bufs["k_out"]), _ptr(bufs["valid"]),
                                       _ptr(bufs["valid_out"]), _stream_handle(self.device)))
 
@@ -225,7 +244,7 @@ class DeviceSystem(object):
         in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
         ref3 = None if ref is None else (ctypes.c_double * 3)(*[float(v) for v in ref])
         _lib.check(self.lib.prt_trace_moments(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
-                                              _ptr(e0_im), bufs["mode"], bufs["pitch"], _ptr(bufs["x_hit"]),
+                                              _ptr(e0_im), _mode_word(bufs), bufs["pitch"], _ptr(bufs["x_hit"]),
                                               _ptr(bufs["k_out"]), _ptr(bufs["valid"]),
                                               _ptr(bufs["valid_out"]), ref3, _ptr(ws.out[slot]),
                                               _ptr(ws.scratch), _stream_handle(self.device)))
@@ -254,13 +273,14 @@ class DeviceSystem(object):
             (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
         in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
         _lib.check(self.lib.prt_trace_timed(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
-                                            _ptr(e0_im), bufs["mode"], bufs["pitch"],
+                                            _ptr(e0_im), _mode_word(bufs), bufs["pitch"],
                                             _ptr(bufs["x_hit"]), _ptr(bufs["k_out"]),
                                             _ptr(bufs["valid"]), _ptr(bufs["valid_out"]),
                                             _stream_handle(self.device), iters, ctypes.byref(ms)))
         return ms.value
 
-    def trace(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH, want_fields=False):
+    def trace(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH, want_fields=False,
+              packed_flags=False):
         """OpticalSystem.seqtrace on device tensors; returns a TraceResult of views."""
         n0 = x0.shape[1]
         pitches = set()
@@ -271,7 +291,8 @@ class DeviceSystem(object):
             # mixed pitches, or the per-surface march (tight arrays): tight copies
             (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
         with torch.cuda.device(self.device):
-            bufs = self.alloc_outputs(n0, mode, want_fields=want_fields)
+            bufs = self.alloc_outputs(n0, mode, want_fields=want_fields,
+                                      packed_flags=packed_flags and self.all_isotropic)
             self.trace_into(x0, k0, bufs, e0_re, e0_im)
         return self.views(bufs)
 

@@ -98,7 +98,7 @@ def seqtrace_fused(ib, records, lengths):
     x0 = ib._x[-1]
     k0 = ib._k[-1]
     (e_re, e_im) = _initial_fields(ib, k0)
-    res = sysd.trace(x0, k0, e_re, e_im, mode=_lib.MODE_PATH)
+    res = sysd.trace(x0, k0, e_re, e_im, mode=_lib.MODE_PATH, packed_flags=True)
     ids0 = _ids_on_device(ib, x0.shape[1], dev)
     wave = ib.wave
     kc = ib._k_complex

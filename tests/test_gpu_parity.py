@@ -304,3 +304,27 @@ def test_error_codes_and_unsupported_tables(gpu_device):
     bufa["pitch"] = 512
     with pytest.raises(_lib.PrtError):
         sysa.trace_into(x, x, bufa)                        # crystals use the concatenated layout
+
+
+@pytest.mark.parametrize("name", ["double_gauss_wide", "tilted_frames", "asphere_strong_field5"])
+def test_packed_mask_flags_equal_the_two_mask_arrays(name, gpu_device):
+    """PRT_MODE_FLAGS: valid | valid_out << 1 in one byte per record == the two separate arrays;
+    hit points and wave vectors bit-identical; path and image mode; crystals refuse the mode"""
+    from pyrate_amd import _lib, engine, systems
+    case = _golden.load_case(name)
+    sysd = engine.DeviceSystem(case.table, 0)
+    x0 = engine.to_device_rays(case.x0, gpu_device)
+    k0 = engine.to_device_rays(case.k0, gpu_device)
+    e = np.asarray(case.E0)
+    e_re = engine.to_device_rays(e.real, gpu_device)
+    for mode in (_lib.MODE_PATH, _lib.MODE_IMAGE):
+        a = sysd.trace(x0, k0, e_re, mode=mode)
+        b = sysd.trace(x0, k0, e_re, mode=mode, packed_flags=True)
+        assert b.flags is not None and int(b.flags[0].max()) <= 3
+        for s in range(len(a.x_hit)):
+            assert torch.equal(a.valid[s], b.valid[s]) and torch.equal(a.valid_out[s], b.valid_out[s])
+            assert torch.equal(a.x_hit[s].contiguous().view(torch.int64), b.x_hit[s].contiguous().view(torch.int64))
+            assert torch.equal(a.k_out[s].contiguous().view(torch.int64), b.k_out[s].contiguous().view(torch.int64))
+    sysa = engine.DeviceSystem(systems.aniso_doublet_records(), 0)
+    with pytest.raises(ValueError):
+        sysa.alloc_outputs(16, packed_flags=True)
