@@ -63,6 +63,36 @@ class OpticalSystem(LocalCoordinatesTreeBase):
             return [self._seqtrace_fused(initialbundle, records, lengths)]
         return self._seqtrace_generic(initialbundle, elementsequence, splitup)
 
+    def image_moments(self, initialbundle, elementsequence):
+        """Extension (not in the reference): moments of the image-plane points of an all-isotropic
+        sequence WITHOUT materialising the ray path -- one image-mode launch that also reduces
+        {count, sum v, sum v*v}, v = image point - vertex of the last surface, over the rays that
+        arrive (prt_trace_moments); 7 doubles cross PCIe.  Returns (moments (7,), reference point (3,)).
+        ``engine.spot_from_moments`` turns them into RayBundleAnalysis' centroid / RMS spot size; merit
+        functions of optimiser loops can use the sums directly."""
+        (records, _) = flatten_sequence(self, elementsequence, initialbundle.wave)
+        if any(r["material"]["type"] != "isotropic" for r in records):
+            raise Exception("image_moments: isotropic sequences only")
+        initialbundle._ensure()
+        dev = initialbundle.device
+        sysd = _dispatch.system_for(records, dev)
+        x0 = initialbundle._x[-1]
+        k0 = initialbundle._k[-1]
+        (e_re, e_im) = _initial_fields(initialbundle, k0)
+        n = x0.shape[1]
+        key = (dev.index, n)
+        cache = OpticalSystem._moment_buffers
+        if key not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            cache[key] = (sysd.alloc_outputs(n, _lib.MODE_IMAGE, packed_flags=True),
+                          engine.MomentsWorkspace(dev, n_results=1, n_rays=n))
+        (bufs, ws) = cache[key]
+        m = sysd.trace_moments_into(x0, k0, bufs, ws, slot=0, e0_re=e_re, e0_im=e_im)
+        return (m.cpu().numpy(), sysd.moments_reference())
+
+    _moment_buffers = {}
+
     def _seqtrace_generic(self, initialbundle, elementsequence, splitup):
         rpaths = [RayPath(initialbundle.clone())]      # do not modify initialbundle (:74)
         for (elem, subseq) in elementsequence:

@@ -49,6 +49,9 @@ def test_smoke_optimize_asphere(gpu_device):
     from demos import demo_optimize_asphere
     (m0, m1) = demo_optimize_asphere.main(maxiter=150)
     assert m1 < 0.5 * m0
+    # same loop with the merit taken from OpticalSystem.image_moments (no path, 7 doubles back)
+    (f0, f1) = demo_optimize_asphere.main(maxiter=150, fast=True)
+    assert abs(f0 - m0) < 1e-9 * m0 and f1 < 0.5 * f0
 
 
 def test_smoke_zmx(gpu_device, capsys):
