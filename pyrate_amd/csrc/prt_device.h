@@ -424,6 +424,9 @@ PRT_DEV void propagate_step(const prt_surface_t *__restrict__ sf, const vec3 &x,
         // the ray is dropped by the finite-normal test of the following refraction.
         if (nonconv) t = __builtin_nan("");
         p = v3(r0.x + dl.x * t, r0.y + dl.y * t, r0.z + dl.z * t);
+        // (fx, fy are the derivatives at the last iterate: finite even when t is not -- poison them
+        // so that the gradient is what the reference would compute AT the NaN point)
+        if (!isfinite(t)) fx = __builtin_nan("");
         g = v3(-fx, -fy, 1.0);
         g2 = fx * fx + fy * fy + 1.0;
     }

@@ -328,3 +328,36 @@ def test_packed_mask_flags_equal_the_two_mask_arrays(name, gpu_device):
     sysa = engine.DeviceSystem(systems.aniso_doublet_records(), 0)
     with pytest.raises(ValueError):
         sysa.alloc_outputs(16, packed_flags=True)
+
+
+def test_nan_hit_points_on_explicit_shapes_are_dropped_by_the_refraction(gpu_device):
+    """A ray that leaves the domain of an explicit shape (sqrt of a negative number) or whose Newton
+    iteration does not settle has a NaN hit point.  Without an aperture the mask after the propagate
+    stays True (reference: surface_shape.py:462); the surface normal at a NaN point is NaN, so the
+    refraction must drop the ray -- in the fused march too, where the normal comes from the
+    derivatives of the last Newton iterate."""
+    from pyrate_amd import engine, systems
+    recs = systems.simple_system_records([
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
+        ({"shape": "Asphere", "curv": 1. / 9., "cc": 0.4, "coefficients": [1e-4, -2e-6]}, {"decz": 4.0}, 1.6, "front", {}),
+        ({"shape": "Conic", "curv": -1. / 30.}, {"decz": 6.0}, None, "back", {}),
+        ({"shape": "Conic"}, {"decz": 30.0}, None, "image", {})])
+    (o, k, e0) = systems.double_gauss_bundle(600, rpup=12.0, z0=-3.0, field_deg=4.0)
+    with np.errstate(all="ignore"):
+        out = oracle.trace(recs, o, k, e0)
+    res = engine.DeviceSystem(recs, 0).trace(*[engine.to_device_rays(a, gpu_device) for a in (o, k, e0)])
+    x1 = res.x_hit[1].cpu().numpy()
+    nan_hit = ~np.all(np.isfinite(x1), axis=0)
+    assert nan_hit.sum() > 20 and (~nan_hit).sum() > 100
+    assert res.valid[1].cpu().numpy().astype(bool)[nan_hit].all()              # mask after propagate: True
+    assert not res.valid_out[1].cpu().numpy().astype(bool)[nan_hit].any()      # dropped by the refraction
+    for s in range(len(recs)):
+        assert np.array_equal(res.valid[s].cpu().numpy().astype(bool), out[s]["valid"]), s
+        assert np.array_equal(res.valid_out[s].cpu().numpy().astype(bool), out[s]["valid_out"]), s
+    # and through the per-surface entry points
+    sysd = engine.DeviceSystem(recs, 0)
+    (xh, v) = sysd.propagate(1, res.x_hit[0], res.k_out[0])
+    (k2, _d, vo, _, _) = sysd.interact(1, xh, res.k_out[0], valid_in=v)
+    nan2 = ~np.all(np.isfinite(xh.cpu().numpy()), axis=0)      # (a few borderline rays may differ from the
+    assert nan2.sum() > 20                                       #  fused march: other scaling of the direction)
+    assert not vo.cpu().numpy().astype(bool)[nan2].any()
