@@ -331,8 +331,13 @@ PRT_DEV void interact_anisotropic(const prt_surface_t *__restrict__ sf, const ve
     // argsort ascending by S.n (material.py:147); NaNs last like numpy.  Compare-exchange
     // network on (key, id) pairs held in registers (indexing sn[] by a sorted index would put
     // the arrays in scratch memory).
+    // An evanescent mode (complex xi, NaN here) carries no energy flux through the interface: the
+    // reference computes S.n ~ 0 for it, which places it BETWEEN the backward (S.n < 0) and the
+    // forward (S.n > 0) propagating modes.  Sorting its key as 0 keeps a propagating partner in
+    // the slot the reference puts it in (e.g. one transmitted mode totally reflected: [NaN, real]).
     int id0 = 0, id1 = 1, id2 = 2, id3 = 3;
-    double s0 = sn[0], s1 = sn[1], s2 = sn[2], s3 = sn[3];
+    double s0 = isnan(sn[0]) ? 0.0 : sn[0], s1 = isnan(sn[1]) ? 0.0 : sn[1];
+    double s2 = isnan(sn[2]) ? 0.0 : sn[2], s3 = isnan(sn[3]) ? 0.0 : sn[3];
 #define PRT_CSWAP(ka, kb, ia, ib)                                   \
     {                                                               \
         const bool sw = (kb < ka) || (isnan(ka) && !isnan(kb));     \

@@ -196,3 +196,37 @@ def test_many_crystal_interfaces_use_the_per_surface_march(gpu_device):
             ko = np.real(out[s]["k_out"])
             fin = np.all(np.isfinite(ko), axis=0)
             assert np.abs(res.k_out[s].cpu().numpy()[:, fin] - ko[:, fin]).max() < 1e-10, (m, s)
+
+
+def test_partially_evanescent_crystal_interface_keeps_the_propagating_mode_in_its_slot(gpu_device):
+    """dense glass -> strongly birefringent crystal at steep incidence: one of the two transmitted
+    modes is evanescent (complex xi; NaN in the engine), the other propagates.  The reference orders the
+    modes by S.n, where an evanescent mode has S.n ~ 0, i.e. sits between the backward and the forward
+    propagating ones -- so the propagating transmitted mode is the SECOND of the pair [sol2, sol3]."""
+    from pyrate_amd import engine, systems
+    eps = systems.uniaxial_eps(1.35, 2.1, (1.0, 0.0, 0.0))
+    recs = systems.simple_system_records([
+        ({"shape": "Conic"}, {"decz": 0.0}, 1.9, "entry", {}),
+        ({"shape": "Conic", "curv": 0.0}, {"decz": 5.0}, {"eps": eps}, "crystal", {}),
+        ({"shape": "Conic"}, {"decz": 5.0}, None, "exit", {})], background_n=1.9)
+    n = 64
+    ang = np.linspace(0.2, 1.1, n)                         # 11 .. 63 degrees inside the glass
+    x0 = np.vstack((np.zeros(n), np.zeros(n), np.full(n, -1.0)))
+    k0 = 1.9 * np.vstack((np.sin(ang) * 0.6, np.sin(ang) * 0.8, np.cos(ang)))
+    e0 = np.cross(k0, np.array([1., 0.3, 0.]), axisa=0, axisb=0).T.copy()
+    with np.errstate(all="ignore"):
+        out = oracle.trace(recs, x0, k0, e0)
+    res = engine.DeviceSystem(recs, 0).trace(*[engine.to_device_rays(a, gpu_device, pitched=False)
+                                               for a in (x0, k0, e0)])
+    ko = out[1]["k_out"]
+    kd = res.k_out[1].cpu().numpy()
+    real_mode = np.all(np.abs(np.imag(ko)) < 1e-12, axis=0) & np.all(np.isfinite(np.real(ko)), axis=0)
+    evan = ~real_mode
+    # the scenario is there: rays with exactly one propagating transmitted mode, and it is slot [n:]
+    one_mode = evan[:n] & real_mode[n:]
+    assert one_mode.sum() > 5 and not (real_mode[:n] & evan[n:]).any()
+    assert np.abs(kd[:, real_mode] - np.real(ko)[:, real_mode]).max() < 1e-12
+    assert np.all(np.isnan(kd[:, evan]))
+    # ... and those rays arrive at the exit face where the reference's arrive
+    xe = res.x_hit[2].cpu().numpy()
+    assert np.abs(xe[:, real_mode] - out[2]["x_hit"][:, real_mode]).max() < 1e-11
