@@ -1,0 +1,146 @@
+#!/usr/bin/env python
+"""
+TEST INFRASTRUCTURE -- runs only in the build container (needs /root/reference).
+
+Random systems built with the REAL reference classes, traced by the reference, against the NumPy
+oracle on the surface table flattened from the very same objects: the oracle's pin beyond the
+committed golden cases (random tilted frames, apertures, mirrors, ModelGlass, crystals with random
+uniaxial / biaxial tensors, consecutive mirrors inside crystals, steep incidence with partially
+evanescent crystal modes).
+
+    python oracle/fuzz_vs_reference.py [n_systems] [first_seed]
+"""
+import sys
+import os
+import types
+
+sys.argv = sys.argv[:3]
+_n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+_first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import make_golden as mg            # noqa: E402  (imports the reference with the NumPy-2 shim)
+import numpy as np                  # noqa: E402
+
+sys.path.insert(0, os.path.join(mg.ROOT, "tests"))
+import _golden                      # noqa: E402
+from oracle import seqtrace_np as oracle          # noqa: E402
+from test_oracle_golden import explicit_tolerance  # noqa: E402
+
+A = mg.REFAPI
+
+
+def random_eps(rng):
+    (a, b, c) = rng.uniform(-1.5, 1.5, 3)
+    lc = A.LocalCoordinates.p(name="e", tiltx=a, tilty=b, tiltz=c)
+    lc.update()
+    R = lc.localbasis
+    if rng.rand() < 0.5:
+        (no, ne) = (rng.uniform(1.3, 2.1), rng.uniform(1.3, 2.1))
+        pv = [no ** 2, no ** 2, ne ** 2]
+    else:
+        pv = list(np.sort(rng.uniform(1.3, 2.1, 3)) ** 2)
+    return R.dot(np.diag(pv)).dot(R.T)
+
+
+def random_system(rng, crystals):
+    s = A.OpticalSystem.p()
+    lc_prev = s.addLocalCoordinateSystem(A.LocalCoordinates.p(name="obj", decz=0.0),
+                                         refname=s.rootcoordinatesystem.name)
+    elem = A.OpticalElement.p(lc_prev, name="e")
+    nsurf = int(rng.randint(2, 6))
+    seq = []
+    last_mat = None
+    in_crystal = False
+    for j in range(nsurf):
+        tilted = rng.rand() < 0.5
+        kw = dict(decz=float(rng.uniform(3, 9)))
+        if tilted:
+            kw.update(decx=float(rng.uniform(-0.3, 0.3)), tiltx=float(rng.uniform(-0.12, 0.12)),
+                      tilty=float(rng.uniform(-0.12, 0.12)), tiltThenDecenter=int(rng.randint(0, 2)))
+        lc = s.addLocalCoordinateSystem(A.LocalCoordinates.p(name="s%d" % j, **kw), refname=lc_prev.name)
+        curv = float(rng.uniform(-1, 1) / rng.uniform(12, 80))
+        if (not crystals) and rng.rand() < 0.25:
+            shape = A.Asphere.p(lc, curv=curv, cc=float(rng.uniform(-1.5, 0.5)),
+                                coefficients=[float(rng.uniform(-1, 1) * 1e-4), float(rng.uniform(-1, 1) * 1e-7)])
+        else:
+            shape = A.Conic.p(lc, curv=curv, cc=float(rng.choice([0.0, rng.uniform(-1.5, 1.0)])))
+        aper = None
+        if rng.rand() < 0.4:
+            aper = A.CircularAperture.p(lc, maxradius=float(rng.uniform(2.5, 7.0)))
+        surf = A.Surface.p(lc, shape=shape, aperture=aper)
+        mirror = j > 0 and rng.rand() < 0.2
+        if mirror:
+            mat = last_mat
+        elif j == nsurf - 1:
+            mat = None
+        elif crystals and rng.rand() < 0.7:
+            mat = "c%d" % j
+            lcm = s.addLocalCoordinateSystem(A.LocalCoordinates.p(name="m%d" % j, tiltx=float(rng.uniform(-0.5, 0.5))),
+                                             refname=lc.name)
+            elem.addMaterial(mat, A.AnisotropicMaterial.p(lcm, random_eps(rng)))
+        else:
+            mat = "g%d" % j
+            elem.addMaterial(mat, A.ConstantIndexGlass.p(lc, float(rng.uniform(1.3, 1.9))) if rng.rand() < 0.7
+                             else A.ModelGlass.p(lc))
+        elem.addSurface("s%d" % j, surf, (last_mat, mat))
+        seq.append(("s%d" % j, {"is_mirror": True} if mirror else {}))
+        if mirror:
+            # the following surface lies behind the mirror
+            pass
+        last_mat = mat
+        lc_prev = lc
+    s.addElement("e", elem)
+    return (s, [("e", seq)])
+
+
+def main():
+    bad = []
+    ncmp = 0
+    for seed in range(_first, _first + _n):
+        rng = np.random.RandomState(21000 + seed)
+        crystals = seed % 2 == 1
+        try:
+            (s, seq) = random_system(rng, crystals)
+            n = 24
+            x0 = np.vstack((rng.uniform(-2.5, 2.5, n), rng.uniform(-2.5, 2.5, n), np.full(n, -1.0)))
+            steep = 0.45 if crystals else 0.2
+            u = np.vstack((rng.uniform(-steep, steep, n), rng.uniform(-steep, steep, n), np.ones(n)))
+            k0 = u / np.sqrt(np.sum(u ** 2, axis=0))
+            e0 = np.cross(k0, np.array([1., 0.3, 0.]), axisa=0, axisb=0).T.copy()
+            bundle = A.RayBundle(x0, k0, e0, wave=0.55e-3)
+            (records, lengths) = mg.flatten_sequence(s, seq, bundle.wave)
+            with np.errstate(all="ignore"):
+                rpaths = s.seqtrace(bundle, seq)
+            rb = rpaths[0].raybundles
+            case = types.SimpleNamespace(name="fuzz%d" % seed, table=records, n_surfaces=len(records),
+                                         x0=x0, k0=k0, E0=e0, elem_lengths=lengths)
+            case.bundles = [dict(x=np.array(b.x), k=np.array(b.k), valid=np.array(b.valid), id=np.array(b.rayID))
+                            for b in rb]
+            with np.errstate(all="ignore"):
+                out = oracle.trace(records, x0, k0, e0)
+            # evanescent descendants have complex k in the reference: compare only while every k is real
+            if any(np.any(np.abs(np.imag(b["k"])) > 1e-9) for b in case.bundles):
+                kind = "complex-k"
+                # still compare the leading part: cut the case at the first bundle with complex k
+                first = [i for (i, b) in enumerate(case.bundles) if np.any(np.abs(np.imag(b["k"])) > 1e-9)][0]
+                upto = first - 2            # surfaces whose outgoing bundle is still real
+                if upto < 1:
+                    continue
+                case.n_surfaces = upto
+                case.table = records[:upto]
+                case.bundles = case.bundles[:upto + 2]
+                out = out[:upto]
+            r = _golden.compare_dense_to_reference(case, _golden.dense_from_oracle(out), rtol_x=1e-9, atol_k=1e-9,
+                                                   explicit_tol=explicit_tolerance)
+            ncmp += r["n_compared"]
+        except AssertionError as exc:
+            bad.append((seed, "crystals" if crystals else "isotropic", str(exc)[:160]))
+        except Exception as exc:
+            bad.append((seed, "exception", repr(exc)[:200]))
+    print("systems %d, compared ray-surfaces %d, failures %d" % (_n, ncmp, len(bad)))
+    for b in bad[:30]:
+        print(b)
+
+
+if __name__ == "__main__":
+    main()

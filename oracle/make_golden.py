@@ -212,6 +212,14 @@ def case_gridsag():
     print("gridsag_shape.npz")
 
 
+def case_evanescent():
+    """steep incidence from a dense medium onto a crystal: one transmitted mode is evanescent (complex
+    k in the reference) -- pins WHICH slot of the doubled bundle holds the propagating mode"""
+    (s, seq) = zoo.evanescent_slab(REFAPI)
+    (x0, k0, e0) = zoo.evanescent_bundle_arrays()
+    dump_case("aniso_partial_evanescent", s, seq, RayBundle(x0, k0, e0, wave=0.55e-3))
+
+
 def case_prism():
     """demo_prism.py: the reference's ``raytrace`` convenience (OpticalSystemAnalysis.aim with a
     MeridionalFan raster, start offset and field angle) at a red and a blue wavelength"""
@@ -470,6 +478,7 @@ def main():
     case_two_elements()
     case_aniso()
     case_aniso_mirror()
+    case_evanescent()
     case_zmx()
     case_spd()
     case_dispersion()

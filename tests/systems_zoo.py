@@ -210,6 +210,33 @@ def zernike_combination_system(api):
     return (s, [("zc", [("mirror", {"is_mirror": True}), ("img", {})])])
 
 
+def evanescent_slab(api):
+    """plane crystal slab (uniaxial, n_o = 1.35, n_e = 2.1, axis along x) immersed in a dense
+    medium (n = 1.9): beyond ~45 degrees one of the two transmitted modes is evanescent"""
+    from pyrate_amd import systems
+    eps = systems.uniaxial_eps(1.35, 2.1, (1.0, 0.0, 0.0))
+    s = api.OpticalSystem.p(matbackground=api.ConstantIndexGlass.p(api.LocalCoordinates.p(name="bg"), 1.9))
+    lc0 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="entry", decz=0.0),
+                                     refname=s.rootcoordinatesystem.name)
+    lc1 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="crystal", decz=5.0), refname=lc0.name)
+    lc2 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="exit", decz=5.0), refname=lc1.name)
+    elem = api.OpticalElement.p(lc0, name="e")
+    elem.addMaterial("c", api.AnisotropicMaterial.p(lc1, eps))
+    elem.addSurface("entry", api.Surface.p(lc0), (None, None))
+    elem.addSurface("crystal", api.Surface.p(lc1), (None, "c"))
+    elem.addSurface("exit", api.Surface.p(lc2), ("c", None))
+    s.addElement("e", elem)
+    return (s, [("e", [("entry", {}), ("crystal", {}), ("exit", {})])])
+
+
+def evanescent_bundle_arrays(n=32):
+    ang = np.linspace(0.2, 1.1, n)
+    x0 = np.vstack((np.zeros(n), np.zeros(n), np.full(n, -1.0)))
+    k0 = 1.9 * np.vstack((np.sin(ang) * 0.6, np.sin(ang) * 0.8, np.cos(ang)))
+    e0 = np.cross(k0, np.array([1., 0.3, 0.]), axisa=0, axisb=0).T.copy()
+    return (x0, k0, e0)
+
+
 def prism(api):
     """dispersing prism: two plane faces tilted by +-30 degrees about a common centre, Conrady
     ModelGlass (demos/demo_prism.py geometry)"""

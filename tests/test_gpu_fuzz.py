@@ -227,6 +227,16 @@ def test_partially_evanescent_crystal_interface_keeps_the_propagating_mode_in_it
     assert one_mode.sum() > 5 and not (real_mode[:n] & evan[n:]).any()
     assert np.abs(kd[:, real_mode] - np.real(ko)[:, real_mode]).max() < 1e-12
     assert np.all(np.isnan(kd[:, evan]))
+    # the same against the reference's own bundle (golden case of the same slab)
+    import systems_zoo as zoo
+    case = _golden.load_case("aniso_partial_evanescent")
+    (xg, kg, eg) = zoo.evanescent_bundle_arrays()
+    rg = engine.DeviceSystem(case.table, 0).trace(*[engine.to_device_rays(a, gpu_device, pitched=False)
+                                                    for a in (xg, kg, eg)])
+    kref = case.raw_bundles[3]["k"][0]
+    real_ref = np.all(np.abs(np.imag(kref)) < 1e-12, axis=0)
+    kdg = rg.k_out[1].cpu().numpy()
+    assert np.abs(kdg[:, real_ref] - np.real(kref)[:, real_ref]).max() < 1e-12 and np.all(np.isnan(kdg[:, ~real_ref]))
     # ... and those rays arrive at the exit face where the reference's arrive
     xe = res.x_hit[2].cpu().numpy()
     assert np.abs(xe[:, real_mode] - out[2]["x_hit"][:, real_mode]).max() < 1e-11
