@@ -50,7 +50,7 @@ from pyrateoptics.raytracer.optical_element import OpticalElement  # noqa: E402
 from pyrateoptics.raytracer.optical_system import OpticalSystem  # noqa: E402
 from pyrateoptics.raytracer.ray import RayBundle  # noqa: E402
 from pyrateoptics.raytracer.surface import Surface  # noqa: E402
-from pyrateoptics.raytracer.surface_shape import (Asphere, Conic, GridSag, LinearCombination, XYPolynomials,  # noqa: E402
+from pyrateoptics.raytracer.surface_shape import (Asphere, Biconic, Conic, GridSag, LinearCombination, XYPolynomials,  # noqa: E402
                                                    ZernikeANSI, ZernikeFringe)
 from pyrateoptics.sampling2d import raster  # noqa: E402
 
@@ -105,7 +105,7 @@ def disk_bundle(nrays, rpup, z0, field_deg=0.0, wave=DLINE, efield="kxex", yshif
 # ---------------------------------------------------------------------------
 REFAPI = types.SimpleNamespace(
     OpticalSystem=OpticalSystem, OpticalElement=OpticalElement, LocalCoordinates=LocalCoordinates,
-    Surface=Surface, Conic=Conic, Asphere=Asphere, XYPolynomials=XYPolynomials,
+    Surface=Surface, Conic=Conic, Asphere=Asphere, Biconic=Biconic, XYPolynomials=XYPolynomials,
     ZernikeFringe=ZernikeFringe, ZernikeANSI=ZernikeANSI, LinearCombination=LinearCombination, GridSag=GridSag,
     CircularAperture=CircularAperture, RectangularAperture=RectangularAperture,
     ConstantIndexGlass=ConstantIndexGlass, ModelGlass=ModelGlass,
