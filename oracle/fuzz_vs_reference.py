@@ -90,6 +90,25 @@ def random_system(rng, crystals):
         last_mat = mat
         lc_prev = lc
     s.addElement("e", elem)
+    if rng.rand() < 0.35:
+        # visit surfaces more than once / out of order (folded paths, ghost-like sequences): exercises
+        # the material bookkeeping of OpticalElement.seqtrace (optical_element.py:336-375), which
+        # switches media by identity and only at refractions
+        extra = []
+        for _ in range(int(rng.randint(1, 4))):
+            (name, _) = seq[int(rng.randint(0, len(seq)))]
+            extra.append((name, {"is_mirror": True} if rng.rand() < 0.5 else {}))
+        seq = seq + extra
+    if rng.rand() < 0.3:
+        # a second element sharing the frame tree: the medium starts again from the background
+        lc_b = s.addLocalCoordinateSystem(A.LocalCoordinates.p(name="b0", decz=float(rng.uniform(3, 8))), refname=lc_prev.name)
+        elem2 = A.OpticalElement.p(lc_b, name="e2")
+        elem2.addMaterial("g", A.ConstantIndexGlass.p(lc_b, float(rng.uniform(1.4, 1.8))))
+        lc_c = s.addLocalCoordinateSystem(A.LocalCoordinates.p(name="b1", decz=float(rng.uniform(2, 5))), refname=lc_b.name)
+        elem2.addSurface("f", A.Surface.p(lc_b, shape=A.Conic.p(lc_b, curv=float(rng.uniform(-0.02, 0.02)))), (None, "g"))
+        elem2.addSurface("r", A.Surface.p(lc_c, shape=A.Conic.p(lc_c, curv=float(rng.uniform(-0.02, 0.02)))), ("g", None))
+        s.addElement("e2", elem2)
+        return (s, [("e", seq), ("e2", [("f", {}), ("r", {})])])
     return (s, [("e", seq)])
 
 
@@ -114,8 +133,19 @@ def main():
             rb = rpaths[0].raybundles
             case = types.SimpleNamespace(name="fuzz%d" % seed, table=records, n_surfaces=len(records),
                                          x0=x0, k0=k0, E0=e0, elem_lengths=lengths)
-            case.bundles = [dict(x=np.array(b.x), k=np.array(b.k), valid=np.array(b.valid), id=np.array(b.rayID))
-                            for b in rb]
+            allb = [dict(x=np.array(b.x), k=np.array(b.k), valid=np.array(b.valid), id=np.array(b.rayID))
+                    for b in rb]
+            # canonical list [b0, b0, b1, ..., bS]: drop the duplicate at every further element boundary
+            keep = []
+            pos = 0
+            for (e, L) in enumerate(lengths):
+                if e == 0:
+                    keep += [pos, pos + 1]
+                pos += 1
+                keep += list(range(pos + 1, pos + 1 + L))
+                pos += L
+            assert pos + 1 == len(allb), (pos, len(allb))
+            case.bundles = [allb[i] for i in keep]
             with np.errstate(all="ignore"):
                 out = oracle.trace(records, x0, k0, e0)
             # evanescent descendants have complex k in the reference: compare only while every k is real
