@@ -240,3 +240,118 @@ def test_partially_evanescent_crystal_interface_keeps_the_propagating_mode_in_it
     # ... and those rays arrive at the exit face where the reference's arrive
     xe = res.x_hit[2].cpu().numpy()
     assert np.abs(xe[:, real_mode] - out[2]["x_hit"][:, real_mode]).max() < 1e-11
+
+
+# ---------------------------------------------------------------------------------------------
+# extreme systems (a slice of the one-off stress fuzzers under scratch/ that found two defects)
+# ---------------------------------------------------------------------------------------------
+_plain_random_shape = random_shape
+
+
+def harsh_shape(rng, kind):
+    c = rng.uniform(-1, 1) / rng.uniform(6, 40)
+    if kind == 0:
+        return {"type": "conic", "curv": c, "cc": rng.choice([0.0, rng.uniform(-3, 3)])}
+    if kind == 1:
+        return {"type": "asphere", "curv": c, "cc": rng.uniform(-2.5, 1.5),
+                "coeffs": [rng.uniform(-1, 1) * 1e-3, rng.uniform(-1, 1) * 1e-5, rng.uniform(-1, 1) * 1e-8]}
+    return _plain_random_shape(rng, kind)
+
+
+def compare_with_oracle(recs, x0, k0, e0, device, tight=False, tol=1e-9, newton_slack=3):
+    """HIP vs oracle on every surface; rays behind an evanescent crystal mode (complex k in the oracle,
+    NaN in the engine) and the few rays whose Newton iteration ends at the cap on one side only are
+    excluded from then on.  Returns the number of compared wave vectors."""
+    from pyrate_amd import engine
+    with np.errstate(all="ignore"):
+        out = oracle.trace(recs, x0, k0, e0)
+    res = engine.DeviceSystem(recs, 0).trace(*[engine.to_device_rays(a, device, pitched=not tight)
+                                               for a in (x0, k0, e0)])
+    taint = np.zeros(x0.shape[1], dtype=bool)
+    alive = np.ones(x0.shape[1], dtype=bool)       # rays the reference still carries (not compacted away)
+    ncmp = 0
+    for s in range(len(recs)):
+        xo = out[s]["x_hit"]
+        xd = res.x_hit[s].cpu().numpy()
+        fin_o = np.all(np.isfinite(xo), axis=0)
+        fin_d = np.all(np.isfinite(xd), axis=0)
+        border = (fin_o != fin_d) & ~taint & alive
+        assert border.sum() <= newton_slack, (s, "finite hit points differ", int(border.sum()))
+        taint = taint | border
+        v = out[s]["valid"] & fin_o & ~taint
+        assert np.array_equal(res.valid[s].cpu().numpy().astype(bool)[~taint], out[s]["valid"][~taint]), (s, "valid")
+        if v.any():
+            assert (np.abs(xd[:, v] - xo[:, v]) / _golden.relative_scale(xo[:, v])).max() < tol, (s, "x")
+        ko = np.real(out[s]["k_out"])
+        kd = res.k_out[s].cpu().numpy()
+        if ko.shape[1] == 2 * taint.shape[0]:
+            taint = np.concatenate((taint, taint))
+        alive = out[s]["valid_out"].astype(bool)
+        taint = taint | ~np.all(np.abs(np.imag(out[s]["k_out"])) < 1e-12, axis=0)
+        wd = res.valid_out[s].cpu().numpy().astype(bool)
+        assert np.array_equal(wd[~taint], out[s]["valid_out"][~taint]), (s, "valid_out")
+        fin = np.all(np.isfinite(ko), axis=0) & out[s]["valid_out"] & ~taint
+        if fin.any():
+            assert np.abs(kd[:, fin] - ko[:, fin]).max() < tol, (s, "k")
+        ncmp += int(fin.sum())
+    return ncmp
+
+
+def wide_bundle(rng, n, r, ang):
+    x0 = np.vstack((rng.uniform(-r, r, n), rng.uniform(-r, r, n), np.full(n, -2.0)))
+    u = np.vstack((rng.uniform(-ang, ang, n), rng.uniform(-ang, ang, n), np.ones(n)))
+    k0 = u / np.sqrt(np.sum(u ** 2, axis=0))
+    return (x0, k0, np.cross(k0, np.array([1., 0.3, 0.]), axisa=0, axisb=0).T.copy())
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_extreme_systems_match_oracle(gpu_device, seed, monkeypatch):
+    """strong curvatures (misses, total internal reflection, NaN domains of the explicit shapes),
+    large tilts, bundles far wider than the apertures"""
+    import test_gpu_fuzz as this
+    rng = np.random.RandomState(7000 + seed)
+    monkeypatch.setattr(this, "random_shape", harsh_shape)
+    recs = random_table(rng, int(rng.randint(3, 9)), seed % 2 == 1, seed % 3 != 0, seed % 4 == 3)
+    monkeypatch.undo()
+    compare_with_oracle(recs, *wide_bundle(rng, 777, 9.0, 0.35), gpu_device)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_extreme_crystal_stacks_match_oracle(gpu_device, seed):
+    """1-3 crystal interfaces with strong birefringence (uniaxial / biaxial), tilted surface and
+    material frames, mirrors INSIDE crystals, steep rays (partially evanescent interfaces)"""
+    rng = np.random.RandomState(9000 + seed)
+
+    def eps():
+        R = rot(rng, 1.5)
+        if rng.randint(1, 3) == 1:
+            (no, ne) = (rng.uniform(1.3, 2.2), rng.uniform(1.3, 2.2))
+            pv = np.array([no ** 2, no ** 2, ne ** 2])
+        else:
+            pv = np.sort(rng.uniform(1.3, 2.2, 3)) ** 2
+        return R.dot(np.diag(pv)).dot(R.T)
+    ncry = int(rng.randint(1, 4))
+    tilted = seed % 2 == 0
+    recs = []
+    z = 0.0
+    in_crystal = False
+    for s in range(ncry + 2):
+        z += rng.uniform(3.0, 8.0)
+        Bs = rot(rng, 0.15) if tilted else np.eye(3)
+        g = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), z]) if tilted else np.array([0., 0., z])
+        mirror = in_crystal and rng.rand() < 0.3
+        if s < ncry or mirror:
+            e = eps() if not mirror else np.asarray(recs[-1]["material"]["eps_re"])
+            mat = {"type": "anisotropic", "eps_re": e.tolist(), "eps_im": np.zeros((3, 3)).tolist()}
+            in_crystal = True
+        else:
+            mat = {"type": "isotropic", "n": 1.0 if s == ncry + 1 else float(rng.uniform(1.0, 1.8))}
+            in_crystal = False
+        recs.append({"shape": {"type": "conic", "curv": rng.uniform(-1, 1) / rng.uniform(15, 80),
+                               "cc": float(rng.choice([0.0, rng.uniform(-1.5, 1.0)]))},
+                     "B_shape": Bs.tolist(), "g_shape": g.tolist(), "aperture": {"type": "none"},
+                     "B_ap": Bs.tolist(), "g_ap": g.tolist(), "interaction": "mirror" if mirror else "refract",
+                     "material": mat, "B_mat": (rot(rng, 0.8) if tilted else np.eye(3)).tolist()})
+        if mirror:
+            z -= rng.uniform(6.0, 14.0)
+    assert compare_with_oracle(recs, *wide_bundle(rng, 200, 3.0, 0.3), gpu_device, tight=True, tol=1e-8) > 0
