@@ -180,20 +180,47 @@ PRT_DEV void asphere_eval(const prt_surface_t *__restrict__ sf, int nc, double x
 // wave-uniform trip counts.
 PRT_DEV void xypoly_eval(const prt_surface_t *__restrict__ sf, int t0, int nt, double x, double y,
                          double &F, double &Fx, double &Fy) {
+    // The host stores the terms sorted by (i, j), so the powers are built incrementally: x^i advances
+    // when i does, y^j restarts with every new i -- about (#terms + degree^2 / 2) multiplications per
+    // evaluation instead of sum (i + j) (a 25-term Zernike series: 45 monomials up to degree 8).
+    // Any other order still evaluates correctly (the running powers restart when an index drops).
     F = 0.0;
     Fx = 0.0;
     Fy = 0.0;
+    int ip = 0, jp = 0;
+    double xp = 1.0, xpm1 = 0.0;  // x^ip, x^(ip-1) (0 for ip = 0: d/dx of a constant)
+    double yp = 1.0, ypm1 = 0.0;
     for (int t = t0; t < nt; ++t) {
         const int i = sf->xpow[t], j = sf->ypow[t];
         const double c = sf->coeffs[t];
-        double xm1 = 1.0, ym1 = 1.0;  // x^(i-1), y^(j-1)
-        for (int q = 1; q < i; ++q) xm1 *= x;
-        for (int q = 1; q < j; ++q) ym1 *= y;
-        const double xi = (i >= 1) ? xm1 * x : 1.0;
-        const double yj = (j >= 1) ? ym1 * y : 1.0;
-        F += xi * yj * c;
-        if (i >= 1) Fx += (double)i * xm1 * yj * c;
-        if (j >= 1) Fy += (double)j * xi * ym1 * c;
+        if (i != ip) {
+            if (i < ip) {
+                ip = 0;
+                xp = 1.0;
+                xpm1 = 0.0;
+            }
+            while (ip < i) {
+                xpm1 = xp;
+                xp *= x;
+                ++ip;
+            }
+            jp = 0;
+            yp = 1.0;
+            ypm1 = 0.0;
+        }
+        if (j < jp) {
+            jp = 0;
+            yp = 1.0;
+            ypm1 = 0.0;
+        }
+        while (jp < j) {
+            ypm1 = yp;
+            yp *= y;
+            ++jp;
+        }
+        F += c * xp * yp;
+        Fx += c * (double)i * xpm1 * yp;
+        Fy += c * (double)j * xp * ypm1;
     }
 }
 

@@ -336,7 +336,7 @@ def pack_record(rec, out=None):
             r.coeffs[2 * q] = a
             r.coeffs[2 * q + 1] = b
     elif shape["type"] == "xypoly":
-        terms = shape["terms"]
+        terms = sorted(shape["terms"], key=lambda t: (int(t[0]), int(t[1])))     # device: incremental powers
         if len(terms) > PRT_MAX_COEFFS:
             raise UnsupportedError("XY polynomial with more than %d terms" % PRT_MAX_COEFFS)
         nr = shape["normradius"]
