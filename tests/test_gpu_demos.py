@@ -75,3 +75,15 @@ def test_smoke_spd(gpu_device, tmp_path, capsys):
         assert rms < 0.2
     out = capsys.readouterr().out
     assert "efl 115.74" in out
+
+
+def test_smoke_prism(gpu_device, capsys):
+    from demos import demo_prism
+    out = demo_prism.main()
+    assert out["blue"] != out["red"] and "dispersion" in capsys.readouterr().out
+
+
+def test_smoke_anisotropic_mirror(gpu_device, capsys):
+    from demos import demo_anisotropic_mirror
+    (forks, stacked) = demo_anisotropic_mirror.main(10)
+    assert len(forks) == 4 and stacked.raybundles[-1].num_rays == 4 * forks[0].raybundles[-1].num_rays
