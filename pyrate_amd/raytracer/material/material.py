@@ -5,7 +5,6 @@
 entry points (prt_propagate / prt_interact / prt_compact) are called for the
 plugin-granular API; whole sequences go through ``OpticalSystem.seqtrace`` -> prt_trace.
 """
-import numpy as np
 import torch
 
 from ... import engine
@@ -47,16 +46,6 @@ def propagate_bundle(raybundle, shape, aperture):
     raybundle._append_device(x_hit, valid)
 
 
-def _ids_on_device(raybundle):
-    rid = raybundle._ray_id
-    dev = raybundle.device
-    if rid is None:
-        return torch.arange(raybundle._x[-1].shape[1], dtype=torch.int64, device=dev)
-    if isinstance(rid, torch.Tensor):
-        return rid.to(dev)
-    return torch.from_numpy(np.ascontiguousarray(rid, dtype=np.int64)).to(dev)
-
-
 def interact_bundle(material, raybundle, surface, mirror, splitup):
     """Material.refract / reflect for a device bundle -> tuple of new RayBundles"""
     raybundle._ensure()
@@ -66,7 +55,7 @@ def interact_bundle(material, raybundle, surface, mirror, splitup):
     x_hit = raybundle._x[-1]
     k = raybundle._k[-1]
     aniso = sysd.records[0]["material"]["type"] == "anisotropic"
-    ids = _ids_on_device(raybundle)
+    ids = raybundle.ray_ids_dev()
     if not aniso:
         (k_out, _d, valid_out, _, _) = sysd.interact(0, x_hit, k, valid_in=raybundle._valid[-1])
         # return only valid rays (material_isotropic.py:194-199), on the device

@@ -129,7 +129,7 @@ def seqtrace_fused(ib, records, lengths):
     k0 = ib._k[-1]
     (e_re, e_im) = _initial_fields(ib, k0)
     res = sysd.trace(x0, k0, e_re, e_im, mode=_lib.MODE_PATH, packed_flags=True)
-    ids0 = _ids_on_device(ib, x0.shape[1], dev)
+    ids0 = ib.ray_ids_dev()
     wave = ib.wave
     kc = ib._k_complex
 
@@ -187,15 +187,6 @@ def _initial_fields(ib, k0):
     return None, None
 
 
-def _ids_on_device(ib, n, dev):
-    if ib._ray_id is None:
-        return torch.arange(n, dtype=torch.int64, device=dev)
-    if isinstance(ib._ray_id, torch.Tensor):
-        return ib._ray_id.to(dev)
-    import numpy as np
-    return torch.from_numpy(np.ascontiguousarray(ib._ray_id, dtype=np.int64)).to(dev)
-
-
 def _seqtrace_fused_crystal(ib, records, lengths):
     """Sequences through anisotropic media without ``splitup``: one engine trace in the
     concatenated dense layout (ray count doubles behind every crystal interface, [sol2, sol3]
@@ -216,7 +207,7 @@ def _seqtrace_fused_crystal(ib, records, lengths):
     wave = ib.wave
     crystal = [r["material"]["type"] == "anisotropic" for r in records]
     first_crystal = crystal.index(True)
-    ids_cache = {0: _ids_on_device(ib, n, dev)}
+    ids_cache = {0: ib.ray_ids_dev()}
 
     def dense_ids(level):
         # ids of the dense slots after ``level`` doublings: [ids, ids] per crystal interface

@@ -212,6 +212,16 @@ class RayBundle(object):
         self._ensure()
         return self._x[0].shape[1]
 
+    def ray_ids_dev(self):
+        """rayID as an int64 device tensor (arange when the bundle was created without ids)"""
+        self._ensure()
+        rid = self._ray_id
+        if rid is None:
+            return torch.arange(self._x[-1].shape[1], dtype=torch.int64, device=self.device)
+        if isinstance(rid, torch.Tensor):
+            return rid.to(self.device)
+        return torch.from_numpy(np.ascontiguousarray(rid, dtype=np.int64)).to(self.device)
+
     # -- device accessors (no PCIe traffic) ---------------------------------------
     def x_dev(self, num=-1):
         self._ensure()
