@@ -19,4 +19,7 @@ def __getattr__(name):
                 "build_simple_optical_system", "raytrace"):
         from . import builders
         return getattr(builders, name)
+    if name in ("GlassCatalog", "CatalogMaterial"):
+        from .raytracer.material import material_glasscat
+        return getattr(material_glasscat, name)
     raise AttributeError(name)
