@@ -41,9 +41,18 @@ class ImagePlaneGather(object):
     most one ray; the tail is padding).  ``start()`` packs on the caller's current
     stream and launches the two collectives asynchronously; ``finish()`` returns
     (x (3,N), k (3,N), valid (N,)) views in global ray order.
+
+    Crystals (SURVEY.md 8e "Anisotropic"): every anisotropic interface doubles the rays inside
+    the shard, so a rank holds ``branches`` * n_local image points laid out [branch][local ray]
+    (the engine's dense doubling order, = the reference's hstack of the two solutions applied
+    once per crystal).  Concatenating shards would give [rank][branch][ray]; ``finish()``
+    returns [branch][global ray] instead -- exactly the arrays a single-GPU trace of the whole
+    bundle produces -- and ``ray_id()`` / ``branch()`` give the join keys (rayID = global index
+    of the initial ray).  ``with_fields`` adds the E vectors (re, im) to the exchange.
     """
 
-    def __init__(self, n_total, device, group=None, stage_on_host=False):
+    def __init__(self, n_total, device, group=None, stage_on_host=False, branches=1,
+                 with_fields=False):
         """stage_on_host: exchange through pinned host buffers (for the ``gloo`` backend, which
         cannot all-gather device tensors; used by the single-GPU dry run of the multi-rank
         bench path -- the production path is RCCL on device buffers)."""
@@ -52,22 +61,29 @@ class ImagePlaneGather(object):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.n_total = n_total
+        self.branches = int(branches)
+        self.rows = 12 if with_fields else 6
         self.sizes = shard_sizes(n_total, self.world)
         self.n_max = max(self.sizes) if self.sizes else 0
         self.device = device
         bdev = torch.device("cpu") if stage_on_host else device
-        self.send_f = torch.zeros((6, self.n_max), dtype=torch.float64, device=bdev)
-        self.send_v = torch.zeros(self.n_max, dtype=torch.uint8, device=bdev)
-        self.recv_f = torch.empty((self.world, 6, self.n_max), dtype=torch.float64, device=bdev)
-        self.recv_v = torch.empty((self.world, self.n_max), dtype=torch.uint8, device=bdev)
+        (m, r) = (self.branches, self.rows)
+        self.send_f = torch.zeros((r, m, self.n_max), dtype=torch.float64, device=bdev)
+        self.send_v = torch.zeros((m, self.n_max), dtype=torch.uint8, device=bdev)
+        self.recv_f = torch.empty((self.world, r, m, self.n_max), dtype=torch.float64, device=bdev)
+        self.recv_v = torch.empty((self.world, m, self.n_max), dtype=torch.uint8, device=bdev)
         self._work = []
 
-    def start(self, x_img, k_img, valid):
-        n = x_img.shape[1]
-        assert n == self.sizes[self.rank], "shard size mismatch"
-        self.send_f[0:3, :n].copy_(x_img, non_blocking=True)
-        self.send_f[3:6, :n].copy_(k_img, non_blocking=True)
-        self.send_v[:n].copy_(valid, non_blocking=True)
+    def start(self, x_img, k_img, valid, e_re=None, e_im=None):
+        m = self.branches
+        n = x_img.shape[1] // m
+        assert n == self.sizes[self.rank] and x_img.shape[1] == m * n, "shard size mismatch"
+        self.send_f[0:3, :, :n].copy_(x_img.view(3, m, n), non_blocking=True)
+        self.send_f[3:6, :, :n].copy_(k_img.view(3, m, n), non_blocking=True)
+        if self.rows == 12:
+            self.send_f[6:9, :, :n].copy_(e_re.view(3, m, n), non_blocking=True)
+            self.send_f[9:12, :, :n].copy_(e_im.view(3, m, n), non_blocking=True)
+        self.send_v[:, :n].copy_(valid.view(m, n), non_blocking=True)
         if self.stage_on_host and x_img.is_cuda:
             torch.cuda.current_stream(x_img.device).synchronize()     # D2H staging complete
         if not _collectives_needed(self.group):
@@ -86,15 +102,37 @@ class ImagePlaneGather(object):
             w.wait()
         self._work = []
 
-    def finish(self):
+    def _gathered(self):
         self.wait()
+        (m, r) = (self.branches, self.rows)
         if all(s == self.n_max for s in self.sizes):
-            f = self.recv_f.permute(1, 0, 2).reshape(6, self.world * self.n_max)
-            v = self.recv_v.reshape(-1)
+            # [rank][row][branch][ray] -> [row][branch][rank][ray] = [row][branch][global ray]
+            f = self.recv_f.permute(1, 2, 0, 3).reshape(r, m * self.world * self.n_max)
+            v = self.recv_v.permute(1, 0, 2).reshape(-1)
         else:
-            f = torch.cat([self.recv_f[r, :, :s] for (r, s) in enumerate(self.sizes)], dim=1)
-            v = torch.cat([self.recv_v[r, :s] for (r, s) in enumerate(self.sizes)])
+            f = torch.cat([self.recv_f[q, :, :, :s] for (q, s) in enumerate(self.sizes)],
+                          dim=2).reshape(r, m * self.n_total)
+            v = torch.cat([self.recv_v[q, :, :s] for (q, s) in enumerate(self.sizes)],
+                          dim=1).reshape(-1)
+        return f, v
+
+    def finish(self):
+        (f, v) = self._gathered()
         return f[0:3], f[3:6], v
+
+    def finish_with_fields(self):
+        """(x, k, valid, E_re, E_im) -- needs with_fields=True"""
+        assert self.rows == 12
+        (f, v) = self._gathered()
+        return f[0:3], f[3:6], v, f[6:9], f[9:12]
+
+    def ray_id(self):
+        """rayID of every gathered column (global index of its initial ray)"""
+        return torch.arange(self.n_total, dtype=torch.int64).repeat(self.branches)
+
+    def branch(self):
+        """doubling branch of every gathered column: bit a = solution picked at crystal a"""
+        return torch.arange(self.branches, dtype=torch.int64).repeat_interleave(self.n_total)
 
 
 def global_spot_statistics(x_img, valid=None, group=None, moments_fn=None):

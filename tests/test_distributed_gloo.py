@@ -76,6 +76,30 @@ def _worker(rank, world, port, n_total, q):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         (cnt1, cen1, rms1) = spot_from_moments(t.numpy(), ref)
         ok = ok and cnt1 == m.sum() and bool(np.allclose(cen1, cen_ref, rtol=1e-13)) and abs(rms1 - rms_ref) < 1e-12
+        # crystals: rays double inside the shard ([branch][local ray]); the gather returns the
+        # single-GPU order [branch][global ray] with rayID / branch join keys
+        for (m, fields) in ((2, False), (4, True)):
+            gx = rng.rand(3, m, n_total)
+            gk = rng.rand(3, m, n_total)
+            ge = rng.rand(6, m, n_total)
+            gv = (rng.rand(m, n_total) > 0.5).astype(np.uint8)
+            def loc(a):
+                return torch.from_numpy(np.ascontiguousarray(a[..., lo:hi]).reshape(a.shape[:-2] + (-1,)))
+            g2 = pdist.ImagePlaneGather(n_total, torch.device("cpu"), branches=m, with_fields=fields)
+            if fields:
+                g2.start(loc(gx), loc(gk), loc(gv), loc(ge[0:3]), loc(ge[3:6]))
+                (ax, ak, av, aer, aei) = g2.finish_with_fields()
+                ok = ok and bool(np.array_equal(aer.numpy(), ge[0:3].reshape(3, -1))
+                                 and np.array_equal(aei.numpy(), ge[3:6].reshape(3, -1)))
+            else:
+                g2.start(loc(gx), loc(gk), loc(gv))
+                (ax, ak, av) = g2.finish()
+            ok = ok and bool(np.array_equal(ax.numpy(), gx.reshape(3, -1))
+                             and np.array_equal(ak.numpy(), gk.reshape(3, -1))
+                             and np.array_equal(av.numpy(), gv.reshape(-1)))
+            rid = g2.ray_id().numpy()
+            br = g2.branch().numpy()
+            ok = ok and bool(np.array_equal(ax.numpy()[0], gx[0][br, rid]))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

@@ -361,3 +361,47 @@ def test_nan_hit_points_on_explicit_shapes_are_dropped_by_the_refraction(gpu_dev
     nan2 = ~np.all(np.isfinite(xh.cpu().numpy()), axis=0)      # (a few borderline rays may differ from the
     assert nan2.sum() > 20                                       #  fused march: other scaling of the direction)
     assert not vo.cpu().numpy().astype(bool)[nan2].any()
+
+
+def test_sharded_crystal_trace_reassembles_to_the_whole_bundle(gpu_device):
+    """SURVEY.md 8e "Anisotropic": rays double inside each shard; ImagePlaneGather's reordering
+    ([rank][branch][ray] -> [branch][global ray]) gives exactly the arrays of the unsharded trace
+    (two 'ranks' emulated on one GPU by filling the receive buffers directly), with E fields"""
+    from pyrate_amd import distributed as pdist, engine, systems, _lib
+    c = systems.CALCITE_TILTED
+    eps = systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"])
+    sysa = engine.DeviceSystem(systems.aniso_doublet_records(eps, 1.3 * eps), 0)
+    (o, k) = systems.collimated_bundle(1290, 11.43, -5.0, angley=0.02)
+    n = o.shape[1]
+    assert n % 2 == 1
+    x0 = engine.to_device_rays(o, gpu_device)
+    k0 = engine.to_device_rays(k, gpu_device)
+    er = engine.to_device_rays(np.cross(k, np.array([1.0, 0.0, 0.0]), axis=0), gpu_device)
+    whole = sysa.trace(x0, k0, er, mode=_lib.MODE_IMAGE, want_fields=True)
+    m = whole.x_hit[-1].shape[1] // n
+    assert m == 4 and whole.x_hit[-1].shape[1] == m * n
+    world = 2
+    g = pdist.ImagePlaneGather(n, gpu_device, branches=m, with_fields=True)
+    g.world = world
+    g.sizes = pdist.shard_sizes(n, world)
+    g.n_max = max(g.sizes)
+    g.recv_f = torch.zeros((world, 12, m, g.n_max), dtype=torch.float64, device=gpu_device)
+    g.recv_v = torch.zeros((world, m, g.n_max), dtype=torch.uint8, device=gpu_device)
+    for r in range(world):
+        (lo, hi) = pdist.shard_range(n, r, world)
+        part = sysa.trace(x0[:, lo:hi].contiguous(), k0[:, lo:hi].contiguous(), er[:, lo:hi].contiguous(),
+                          mode=_lib.MODE_IMAGE, want_fields=True)
+        nl = hi - lo
+        (e_re, e_im) = part.e_out[-1]
+        for (row, t) in ((0, part.x_hit[-1]), (3, part.k_out[-1]), (6, e_re), (9, e_im)):
+            g.recv_f[r, row:row + 3, :, :nl] = t.reshape(3, m, nl)
+        g.recv_v[r, :, :nl] = part.valid_out[-1].reshape(m, nl)
+    (gx, gk, gv, ger, gei) = g.finish_with_fields()
+    (w_re, w_im) = whole.e_out[-1]
+
+    def same(a, b):
+        return torch.equal(a.contiguous().view(torch.int64), b.contiguous().view(torch.int64))
+    assert same(gx, whole.x_hit[-1]) and same(gk, whole.k_out[-1])
+    assert same(ger, w_re) and same(gei, w_im)
+    assert torch.equal(gv, whole.valid_out[-1])
+    assert int(g.ray_id()[n + 5]) == 5 and int(g.branch()[n + 5]) == 1
