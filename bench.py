@@ -21,6 +21,7 @@ definition, demos/demo_benchmark.py:82-85).
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -99,7 +100,23 @@ def cpu_baseline(records, o, k, e0, n_all=None, chunk=100_000):
             "host_cpus": os.cpu_count()}
 
 
+def _flush_c_stdio():
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def _stdout_of_other_ranks_to_stderr():
+    """under torch.distributed.run every rank shares one stdout pipe; only rank 0 reports, so what
+    libraries print on the other ranks (RCCL's banner) goes to stderr instead"""
+    if int(os.environ.get("RANK", "0")) != 0:
+        sys.stdout.flush()
+        os.dup2(2, 1)
+
+
 def main():
+    _stdout_of_other_ranks_to_stderr()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -362,11 +379,15 @@ def main():
                                                e0d[:, :m].cpu().numpy(), n_all=n_local)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-        sys.stdout.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio
+        # (block-buffered on a pipe, so it would otherwise surface at exit, after the line)
+        _flush_c_stdio()
+        print(json.dumps(out))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
