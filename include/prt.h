@@ -307,7 +307,8 @@ int32_t prt_bundle_moments_async(int32_t device, int64_t n, int64_t pitch, const
  * tables themselves are HOST arrays of device pointers), plus an optional int64
  * id row and an optional uint8 row.  *n_kept (host) receives the survivor count.  Synchronises the
  * stream (the count is returned to the host).  scratch: device buffer of at
- * least prt_compact_scratch_bytes(n) bytes.
+ * least prt_compact_scratch_bytes(n) bytes.  Runs on the device that owns `mask`
+ * (all arrays and the stream must belong to it); the caller's current device is left as it was.
  */
 int64_t prt_compact_scratch_bytes(int64_t n);
 int32_t prt_compact(int64_t n, const uint8_t *mask, int32_t n_arrays, const double *const *src,

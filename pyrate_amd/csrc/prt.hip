@@ -853,6 +853,13 @@ int32_t prt_compact(int64_t n, const uint8_t *mask, int32_t n_arrays, const doub
         return fail(PRT_ERR_INVALID_ARG, "prt_compact: bad argument");
     *n_kept = 0;
     if (n == 0) return PRT_OK;
+    // no device argument: the arrays say where they live
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, mask) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(PRT_ERR_INVALID_ARG, "prt_compact: mask is not a device pointer");
+    }
+    PRT_ON_DEVICE(attr.device);
     hipStream_t st = (hipStream_t)stream;
     const int64_t nb = (n + CMP_TILE - 1) / CMP_TILE;
     int64_t *sums = (int64_t *)scratch;
