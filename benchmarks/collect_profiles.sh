@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> "$OUT/rocprof_write.err"
 python benchmarks/hbm_traffic.py "$OUT" > "$OUT/hbm_traffic.json" 2> "$OUT/hbm_traffic.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/configs_stats" -- python benchmarks/run_configs.py > "$OUT/run_configs.jsonl" 2> "$OUT/run_configs.err"
-python benchmarks/parity_report.py > "$OUT/parity_report.txt" 2> "$OUT/parity_report.err"
+python tests/parity_report.py > "$OUT/parity_report.txt" 2> "$OUT/parity_report.err"
 # keep only the summaries (the raw traces are large)
 find "$OUT" -name "*kernel_stats.csv" | while read f; do cp "$f" "$OUT/$(basename $(dirname $(dirname "$f")))_kernel_stats.csv"; done
 find "$OUT" -name "*counter_collection.csv" | while read f; do head -200 "$f" > "$OUT/$(basename $(dirname $(dirname "$f")))_counter_head.csv"; done

@@ -1,13 +1,14 @@
 #!/usr/bin/env python
 """Per-case parity numbers of the HIP engine against the reference's golden vectors
 (tests/golden/*.npz): max relative error of hit points, max absolute error of wave vectors,
-number of compared ray-surface points.  The pass/fail version of this is tests/test_gpu_parity.py."""
+number of compared ray-surface points.  The pass/fail version of this is tests/test_gpu_parity.py.
+Test infrastructure (it uses the golden vectors and the oracle's tolerance helper), hence under tests/."""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))      # _golden, test_oracle_golden
 
 import numpy as np
 import torch
