@@ -18,15 +18,21 @@ from pyrate_amd import systems
 from pyrate_amd.raytracer.analysis.optical_system_analysis import OpticalSystemAnalysis
 from pyrate_amd.raytracer.analysis.ray_analysis import RayBundleAnalysis
 from pyrate_amd.sampling2d import raster
-
-sys.path.insert(0, os.path.join(_ROOT, "tests"))
+from pyrate_amd.builders import build_simple_optical_system
 
 wavelength = 0.5876e-3
 
 
 def build(eps1, eps2):
-    import systems_zoo as zoo
-    return zoo.aniso_doublet(zoo.mirror_api(), eps1, eps2)
+    """the cemented doublet of the reference demo (:55-121); {"eps": tensor} = AnisotropicMaterial"""
+    def lens_aperture():
+        return {"type": "CircularAperture", "maxradius": 12.7}
+    return build_simple_optical_system([
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
+        ({"shape": "Conic", "curv": 1. / 62.8, "aperture": lens_aperture()}, {"decz": -1.048}, {"eps": eps1}, "front", {}),
+        ({"shape": "Conic", "curv": -1. / 45.7, "aperture": lens_aperture()}, {"decz": 4.0}, {"eps": eps2}, "cement", {}),
+        ({"shape": "Conic", "curv": -1. / 128.2, "aperture": lens_aperture()}, {"decz": 2.5}, None, "rear", {}),
+        ({"shape": "Conic"}, {"decz": 97.2}, None, "image", {})])
 
 
 def main(nrays=11):
