@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--two-pass-stats", action="store_true",
                     help="N>1: per-step spot statistics from two extra passes over the image plane and two "
                          "all-reduces (default: moments reduced inside the trace kernel, one all-reduce)")
+    ap.add_argument("--placement-candidates", type=int, default=8,
+                    help="output allocations to choose from by timing the march into each (1 = take the first)")
     ap.add_argument("--two-mask-arrays", action="store_true",
                     help="write valid and valid_out as two byte arrays (50 B per record) instead of one "
                          "byte of packed flags (49 B, default)")
@@ -220,7 +222,23 @@ def main():
     n_out_bufs = 1 if (fused_stats and not do_step_gather) else nbuf
     packed = not args.two_mask_arrays
     record_bytes = 49 if packed else 50
-    bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed) for _ in range(n_out_bufs)]
+    # Output placement: the march's write bandwidth depends reproducibly on where x_hit and k_out sit
+    # in HBM relative to each other (DESIGN.md section 5 "placement"), so -- like any caller that
+    # re-uses its output arrays -- the bench lets the engine choose the pair from a small pool by
+    # timing (untimed set-up, after a device wake-up).  --placement-candidates 1 = first allocation.
+    placement = None
+    if args.placement_candidates > 1 and n_out_bufs == 1:
+        warm = sysd.alloc_outputs(n_local, mode, packed_flags=packed)
+        for _ in range(PREWARM_LAUNCHES):
+            sysd.trace_into(x0, k0, warm, e0d)
+        torch.cuda.synchronize()
+        del warm
+        (b0, placement) = sysd.alloc_outputs_tuned(x0, k0, e0d, mode=mode, packed_flags=packed,
+                                                   candidates=args.placement_candidates)
+        bufs = [b0]
+        torch.cuda.empty_cache()
+    else:
+        bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed) for _ in range(n_out_bufs)]
     host_staged = (args.backend == "gloo")
     stats = [pdist.SpotStatistics(dev, n_rays=n_local) for _ in range(nbuf)] if do_stats else []
     gathers = [pdist.ImagePlaneGather(n_total, dev, stage_on_host=host_staged)
@@ -354,6 +372,13 @@ def main():
                        "masks": "valid | valid_out << 1 in one byte" if packed else "two byte arrays",
                        "sharding": "rays" if n_gpus > 1 else "none",
                        "wavelengths": len(sysds), "prewarm_launches": PREWARM_LAUNCHES,
+                       "output_placement": ({"policy": "x_hit / k_out pair chosen from a pool of %d arrays by timing "
+                                                       "the march during set-up" % args.placement_candidates,
+                                             "first_pair_ms": round(placement["first_pair_ms"], 4),
+                                             "best_pair_ms": round(placement["best_pair_ms"], 4),
+                                             "k_scan_ms": [round(t, 4) for t in placement["k_scan_ms"]],
+                                             "x_scan_ms": [round(t, 4) for t in placement["x_scan_ms"]]}
+                                            if placement else {"policy": "first allocation"}),
                        "image_plane_exchange": {
                            "per_step": (("spot moments reduced inside the trace kernel + one 7-double all-reduce "
                                          "(side stream)" if fused_stats else

@@ -214,6 +214,46 @@ class DeviceSystem(object):
             bufs["e_im"] = torch.zeros(nk, dtype=torch.float64, device=dev)
         return bufs
 
+    def alloc_outputs_tuned(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH, packed_flags=False,
+                            candidates=8, iters=4):
+        """Output buffers for a bundle that will be traced many times into the same arrays (an
+        optimiser loop, a wavelength / field sweep, bench.py), placed by measurement.
+
+        The write bandwidth of the path-mode march is a reproducible property of WHERE x_hit and
+        k_out sit in HBM relative to each other: device memory falls into regions (tens of GB) such
+        that two arrays from the same region are written at ~5.2 TB/s and two arrays from different
+        regions at ~6.4 TB/s (same process, same layout, +-0.5 % per pair; a sequential fill runs at
+        6.7 TB/s everywhere -- DESIGN.md section 5 "placement").  The regions are not visible in
+        the virtual addresses, so the pair is found by timing: a pool of ``candidates`` arrays is
+        allocated, k_out is chosen against the first array as x_hit, then x_hit against that k_out
+        (2 * candidates - 3 short measurements), and the rest of the pool is released.
+
+        Returns (bufs, report) with report = {"first_pair_ms", "best_pair_ms", "k_scan_ms", "x_scan_ms"}."""
+        n0 = x0.shape[1]
+        first = self.alloc_outputs(n0, mode, packed_flags=packed_flags)
+        m = max(2, int(candidates))
+        if not self.all_isotropic or mode != _lib.MODE_PATH:
+            ms = self.trace_timed(x0, k0, first, iters, e0_re, e0_im)
+            return first, {"first_pair_ms": ms, "best_pair_ms": ms, "k_scan_ms": [], "x_scan_ms": []}
+        words = first["x_hit"].numel()
+        pool = [first["x_hit"], first["k_out"]]
+        pool += [torch.empty(words, dtype=torch.float64, device=self.device) for _ in range(m - 2)]
+
+        def timed(i, j):
+            b = dict(first, x_hit=pool[i], k_out=pool[j])
+            self.trace_timed(x0, k0, b, 2, e0_re, e0_im)
+            return self.trace_timed(x0, k0, b, iters, e0_re, e0_im)
+
+        k_scan = [timed(0, j) for j in range(1, m)]
+        jb = 1 + min(range(m - 1), key=lambda q: k_scan[q])
+        xs = [i for i in range(m) if i != jb]
+        x_scan = [k_scan[jb - 1] if i == 0 else timed(i, jb) for i in xs]
+        ib = xs[min(range(len(xs)), key=lambda q: x_scan[q])]
+        bufs = dict(first, x_hit=pool[ib], k_out=pool[jb])
+        del pool
+        return bufs, {"first_pair_ms": k_scan[0], "best_pair_ms": min(x_scan), "k_scan_ms": k_scan,
+                      "x_scan_ms": x_scan}
+
     # -- whole sequence ----------------------------------------------------
     def trace_into(self, x0, k0, bufs, e0_re=None, e0_im=None):
         """Asynchronous launch into preallocated buffers (see alloc_outputs)."""

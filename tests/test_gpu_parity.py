@@ -405,3 +405,21 @@ def test_sharded_crystal_trace_reassembles_to_the_whole_bundle(gpu_device):
     assert same(ger, w_re) and same(gei, w_im)
     assert torch.equal(gv, whole.valid_out[-1])
     assert int(g.ray_id()[n + 5]) == 5 and int(g.branch()[n + 5]) == 1
+
+
+def test_tuned_output_allocation_is_an_ordinary_buffer_set(gpu_device):
+    """alloc_outputs_tuned: picks the x_hit / k_out arrays from a pool by timing the march; the result is a
+    normal buffer set (same outputs as a plain trace, bit for bit)"""
+    from pyrate_amd import engine, systems, _lib
+    sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
+    (o, k, e0) = systems.double_gauss_bundle(20000)
+    (x0, k0, e0d) = [engine.to_device_rays(a, gpu_device) for a in (o, k, e0)]
+    (bufs, rep) = sysd.alloc_outputs_tuned(x0, k0, e0d, packed_flags=True, candidates=4, iters=2)
+    assert len(rep["k_scan_ms"]) == 3 and len(rep["x_scan_ms"]) == 3
+    assert 0 < rep["best_pair_ms"] <= rep["first_pair_ms"]
+    sysd.trace_into(x0, k0, bufs, e0d)
+    a = sysd.views(bufs)
+    b = sysd.trace(x0, k0, e0d, packed_flags=True)
+    for s_ in range(12):
+        assert torch.equal(a.x_hit[s_].contiguous().view(torch.int64), b.x_hit[s_].contiguous().view(torch.int64))
+        assert torch.equal(a.flags[s_], b.flags[s_])
