@@ -215,7 +215,7 @@ class DeviceSystem(object):
         return bufs
 
     def alloc_outputs_tuned(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH, packed_flags=False,
-                            candidates=8, iters=4):
+                            candidates=8, iters=3):
         """Output buffers for a bundle that will be traced many times into the same arrays (an
         optimiser loop, a wavelength / field sweep, bench.py), placed by measurement.
 
@@ -241,7 +241,7 @@ class DeviceSystem(object):
 
         def timed(i, j):
             b = dict(first, x_hit=pool[i], k_out=pool[j])
-            self.trace_timed(x0, k0, b, 2, e0_re, e0_im)
+            self.trace_timed(x0, k0, b, 1, e0_re, e0_im)
             return self.trace_timed(x0, k0, b, iters, e0_re, e0_im)
 
         k_scan = [timed(0, j) for j in range(1, m)]
