@@ -117,7 +117,7 @@ static void launch_trace_iso(const prt_system_t *sys, int64_t n0, int64_t in_pit
                              int32_t e_mode, int64_t out_pitch, double *x_hit, double *k_out,
                              uint8_t *valid, uint8_t *valid_out, bool vec_in, bool vec_out,
                              int32_t packed_flags, hipStream_t st) {
-    const dim3 grid(nblocks(n0, PRT_BLOCK * 2)), block(PRT_BLOCK);
+    const dim3 grid(nblocks(n0, PRT_MARCH_BLOCK * 2)), block(PRT_MARCH_BLOCK);
 #define PRT_LAUNCH_E(VI, VO, EX)                                                                 \
     hipLaunchKernelGGL((k_trace_iso<MODE, VI, VO, EX>), grid, block, 0, st, sys->d_table,        \
                        sys->n_surfaces, n0, in_pitch, x0, k0, e_re, e_im, e_mode, out_pitch,     \
@@ -489,8 +489,8 @@ int32_t prt_trace_fields(const prt_system_t *sys, int64_t n0, const double *x0, 
 
 int64_t prt_trace_moments_scratch_doubles(int64_t n0) {
     if (n0 < 0) return 0;
-    // one row per 512 rays + the rows of k_moments_stage
-    const int64_t rows = (n0 + 2 * PRT_BLOCK - 1) / (2 * PRT_BLOCK);
+    // one row per march block (2 * PRT_MARCH_BLOCK rays) + the rows of k_moments_stage
+    const int64_t rows = (n0 + 2 * PRT_MARCH_BLOCK - 1) / (2 * PRT_MARCH_BLOCK);
     const int64_t fused = (int64_t)MOM_VALUES * (rows + (rows + PRT_BLOCK - 1) / PRT_BLOCK);
     const int64_t two_kernel = prt_moments_scratch_doubles(n0);
     return fused > two_kernel ? fused : two_kernel;
@@ -531,8 +531,8 @@ int32_t prt_trace_moments(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
                          (!valid_out || (((uintptr_t)valid_out) & 1u) == 0) &&
                          (n0 % 2 == 0 || out_pitch > n0);
     if (n0 > 0 && vec_in && vec_out) {
-        const unsigned nb = (unsigned)nblocks(n0, PRT_BLOCK * 2);
-        const dim3 grid(nb), block(PRT_BLOCK);
+        const unsigned nb = (unsigned)nblocks(n0, PRT_MARCH_BLOCK * 2);
+        const dim3 grid(nb), block(PRT_MARCH_BLOCK);
         const int32_t e_mode = e_mode_of(e0_re, 1);
 #define PRT_LAUNCH_M(MODE_, EX)                                                                           \
     hipLaunchKernelGGL((k_trace_iso<MODE_, true, true, EX, false, true>), grid, block, 0, st, sys->d_table, \

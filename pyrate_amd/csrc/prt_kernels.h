@@ -136,10 +136,17 @@ template <int MODE, bool VEC_IN, bool VEC_OUT, bool EXPLICIT = true, bool LDS_TA
 #ifndef PRT_PATH_WAVES
 #define PRT_PATH_WAVES 1
 #endif
+// Block size of the fused isotropic march only.  A/B of builds on the SAME arrays in one process
+// (scratch/ab_same_buffers.py; placement alone is worth +-10 %): path mode 64 threads 1.038-1.043,
+// 128 threads 1.035-1.046, 256 threads 1.055-1.062, 512 threads 1.078-1.080 ms; image mode
+// indifferent.  The write-bound march prefers many small blocks (finer-grained refill of the CUs).
+#ifndef PRT_MARCH_BLOCK
+#define PRT_MARCH_BLOCK 128
+#endif
 #ifdef PRT_PATH_WAVES_MAX   // experiment: cap the occupancy of every march instantiation
 __attribute__((amdgpu_waves_per_eu(1, PRT_PATH_WAVES_MAX)))
 #endif
-__global__ __launch_bounds__(PRT_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE == PRT_MODE_IMAGE ? 8 : PRT_PATH_WAVES) : 1) void k_trace_iso(
+__global__ __launch_bounds__(PRT_MARCH_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE == PRT_MODE_IMAGE ? 8 : PRT_PATH_WAVES) : 1) void k_trace_iso(
     const prt_surface_t *__restrict__ tab_g, int32_t S, int64_t N, int64_t in_pitch,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, int64_t out_pitch,
@@ -152,11 +159,11 @@ __global__ __launch_bounds__(PRT_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE == PRT_M
         const int words = S * (int)(sizeof(prt_surface_t) / 8);
         const double *src = reinterpret_cast<const double *>(tab_g);
         double *dst = reinterpret_cast<double *>(lds_tab);
-        for (int w = threadIdx.x; w < words; w += PRT_BLOCK) dst[w] = src[w];
+        for (int w = threadIdx.x; w < words; w += PRT_MARCH_BLOCK) dst[w] = src[w];
         __syncthreads();
         tab = lds_tab;
     }
-    const int64_t i = ((int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x) * 2;
+    const int64_t i = ((int64_t)blockIdx.x * PRT_MARCH_BLOCK + threadIdx.x) * 2;
     if (!MOMENTS && i >= N) return;
     const bool second = (i + 1 < N);
 
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(PRT_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE == PRT_M
                 acc[6] += vz * vz;
             }
         }
-        __shared__ double sh[PRT_BLOCK / 64][MOM_VALUES];
+        __shared__ double sh[PRT_MARCH_BLOCK / 64][MOM_VALUES];
 #pragma unroll
         for (int q = 0; q < MOM_VALUES; ++q) {
             double v = acc[q];
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(PRT_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE == PRT_M
         __syncthreads();
         if (threadIdx.x < MOM_VALUES) {
             double v = 0.0;
-            for (int w = 0; w < PRT_BLOCK / 64; ++w) v += sh[w][threadIdx.x];
+            for (int w = 0; w < PRT_MARCH_BLOCK / 64; ++w) v += sh[w][threadIdx.x];
             moment_partials[(int64_t)blockIdx.x * MOM_VALUES + threadIdx.x] = v;
         }
     }
