@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--two-pass-stats", action="store_true",
                     help="N>1: per-step spot statistics from two extra passes over the image plane and two "
                          "all-reduces (default: moments reduced inside the trace kernel, one all-reduce)")
-    ap.add_argument("--placement-candidates", type=int, default=8,
+    ap.add_argument("--placement-candidates", type=int, default=12,
                     help="output allocations to choose from by timing the march into each (1 = take the first)")
     ap.add_argument("--two-mask-arrays", action="store_true",
                     help="write valid and valid_out as two byte arrays (50 B per record) instead of one "

@@ -215,7 +215,7 @@ class DeviceSystem(object):
         return bufs
 
     def alloc_outputs_tuned(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH, packed_flags=False,
-                            candidates=8, iters=3):
+                            candidates=12, iters=3, spread=0.5):
         """Output buffers for a bundle that will be traced many times into the same arrays (an
         optimiser loop, a wavelength / field sweep, bench.py), placed by measurement.
 
@@ -237,7 +237,18 @@ class DeviceSystem(object):
             return first, {"first_pair_ms": ms, "best_pair_ms": ms, "k_scan_ms": [], "x_scan_ms": []}
         words = first["x_hit"].numel()
         pool = [first["x_hit"], first["k_out"]]
-        pool += [torch.empty(words, dtype=torch.float64, device=self.device) for _ in range(m - 2)]
+        # the candidates are spread over the free HBM (untouched spacer allocations in between, at
+        # most ``spread`` of what is free): arrays that behave differently come from different
+        # parts of the memory, a run of consecutive allocations is often all of one kind
+        (free_b, _) = torch.cuda.mem_get_info(self.device)
+        room = spread * free_b - (m - 2) * words * 8
+        gap = int(max(0, min(16e9, room / max(1, m - 2))))
+        spacers = []
+        for _ in range(m - 2):
+            if gap >= (1 << 26):
+                spacers.append(torch.empty(gap, dtype=torch.uint8, device=self.device))
+            pool.append(torch.empty(words, dtype=torch.float64, device=self.device))
+        del spacers
 
         def timed(i, j):
             b = dict(first, x_hit=pool[i], k_out=pool[j])
@@ -251,6 +262,7 @@ class DeviceSystem(object):
         ib = xs[min(range(len(xs)), key=lambda q: x_scan[q])]
         bufs = dict(first, x_hit=pool[ib], k_out=pool[jb])
         del pool
+        torch.cuda.empty_cache()          # hand the unused candidates and spacers back to the driver
         return bufs, {"first_pair_ms": k_scan[0], "best_pair_ms": min(x_scan), "k_scan_ms": k_scan,
                       "x_scan_ms": x_scan}
 
