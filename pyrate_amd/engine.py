@@ -241,6 +241,7 @@ class DeviceSystem(object):
         # most ``spread`` of what is free): arrays that behave differently come from different
         # parts of the memory, a run of consecutive allocations is often all of one kind
         (free_b, _) = torch.cuda.mem_get_info(self.device)
+        m = min(m, 2 + int(0.8 * free_b // (words * 8)))      # bundles that nearly fill the HBM: fewer candidates
         room = spread * free_b - (m - 2) * words * 8
         gap = int(max(0, min(16e9, room / max(1, m - 2))))
         spacers = []
