@@ -245,11 +245,15 @@ class DeviceSystem(object):
         room = spread * free_b - (m - 2) * words * 8
         gap = int(max(0, min(16e9, room / max(1, m - 2))))
         spacers = []
-        for _ in range(m - 2):
-            if gap >= (1 << 26):
-                spacers.append(torch.empty(gap, dtype=torch.uint8, device=self.device))
-            pool.append(torch.empty(words, dtype=torch.float64, device=self.device))
+        try:
+            for _ in range(m - 2):
+                if gap >= (1 << 26):
+                    spacers.append(torch.empty(gap, dtype=torch.uint8, device=self.device))
+                pool.append(torch.empty(words, dtype=torch.float64, device=self.device))
+        except torch.cuda.OutOfMemoryError:
+            pass                              # somebody else took the memory meanwhile: a smaller pool
         del spacers
+        m = len(pool)
 
         def timed(i, j):
             b = dict(first, x_hit=pool[i], k_out=pool[j])
