@@ -215,7 +215,7 @@ class DeviceSystem(object):
         return bufs
 
     def alloc_outputs_tuned(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH, packed_flags=False,
-                            candidates=12, iters=3, spread=0.5):
+                            candidates=12, iters=3, spread=0.8):
         """Output buffers for a bundle that will be traced many times into the same arrays (an
         optimiser loop, a wavelength / field sweep, bench.py), placed by measurement.
 
@@ -243,7 +243,7 @@ class DeviceSystem(object):
         (free_b, _) = torch.cuda.mem_get_info(self.device)
         m = min(m, 2 + int(0.8 * free_b // (words * 8)))      # bundles that nearly fill the HBM: fewer candidates
         room = spread * free_b - (m - 2) * words * 8
-        gap = int(max(0, min(16e9, room / max(1, m - 2))))
+        gap = int(max(0, min(24e9, room / max(1, m - 2))))
         spacers = []
         try:
             for _ in range(m - 2):
