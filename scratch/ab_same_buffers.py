@@ -9,6 +9,18 @@ sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
 n = x0.shape[1]
 (bufs, rep) = sysd.alloc_outputs_tuned(x0, k0, e0d, packed_flags=True)
 print("placement: first pair %.4f, chosen %.4f" % (rep["first_pair_ms"], rep["best_pair_ms"]))
+# a pair of the slow kind for comparison: fresh arrays until one is found
+bad = None
+keep = []
+for _ in range(12):
+    c = sysd.alloc_outputs(n, _lib.MODE_PATH, packed_flags=True)
+    keep.append(c)
+    sysd.trace_timed(x0, k0, c, 1, e0d)
+    t = sysd.trace_timed(x0, k0, c, 3, e0d)
+    if t > 1.2:
+        bad = c
+        print("slow pair found: %.4f" % t)
+        break
 img = sysd.alloc_outputs(n, _lib.MODE_IMAGE, packed_flags=True)
 libs = {"in-tree": (sysd.lib, sysd._h)}
 for path in sorted(glob.glob("scratch/variants/libprt_*.so")):
@@ -33,6 +45,6 @@ def timed(lib, h, b, iters):
 
 timed(*libs["in-tree"], bufs, 40)
 for rep in range(3):
-    for (tag, b, it) in (("path ", bufs, 20), ("image", img, 30)):
+    for (tag, b, it) in (("path ", bufs, 20), ("image", img, 30)) + ((("slow ", bad, 20),) if bad else ()):
         print(tag + " " + "  ".join("%s %.4f" % (name, (timed(lib, h, b, 2), timed(lib, h, b, it))[1])
                                     for (name, (lib, h)) in libs.items()), flush=True)
