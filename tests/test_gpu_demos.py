@@ -87,3 +87,29 @@ def test_smoke_anisotropic_mirror(gpu_device, capsys):
     from demos import demo_anisotropic_mirror
     (forks, stacked) = demo_anisotropic_mirror.main(10)
     assert len(forks) == 4 and stacked.raybundles[-1].num_rays == 4 * forks[0].raybundles[-1].num_rays
+
+
+def test_bench_contract_line(gpu_device):
+    """bench.py prints ONE JSON line, last on stdout, with the keys the driver reads (small bundle)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rays", "300000", "--steps", "4",
+                          "--warmup", "2", "--placement-candidates", "3"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = out.stdout.strip().splitlines()[-1]
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["dtype"] == "f64" and "workload" in d["config"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in d["roofline"], key
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in d["cpu_baseline"], key
+    assert d["value"] > 1e8 and d["cpu_baseline"]["kind"] == "port"
