@@ -377,7 +377,8 @@ def main():
                                              "first_pair_ms": round(placement["first_pair_ms"], 4),
                                              "best_pair_ms": round(placement["best_pair_ms"], 4),
                                              "k_scan_ms": [round(t, 4) for t in placement["k_scan_ms"]],
-                                             "x_scan_ms": [round(t, 4) for t in placement["x_scan_ms"]]}
+                                             "x_scan_ms": [round(t, 4) for t in placement["x_scan_ms"]],
+                                             "k_rescan_ms": [round(t, 4) for t in placement["k_rescan_ms"]]}
                                             if placement else {"policy": "first allocation"}),
                        "image_plane_exchange": {
                            "per_step": (("spot moments reduced inside the trace kernel + one 7-double all-reduce "
