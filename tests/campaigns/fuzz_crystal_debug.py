@@ -2,7 +2,7 @@ import sys, math, re
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch
 np.set_printoptions(precision=15, linewidth=220)
-src = open('scratch/fuzz_crystal_stress.py').read()
+src = open('tests/campaigns/fuzz_crystal_stress.py').read()
 # reuse the generator: execute the loop body for one seed
 head = src[:src.index("bad = []; ntot = 0")]
 exec(head)

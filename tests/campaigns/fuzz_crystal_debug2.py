@@ -2,7 +2,7 @@ import sys, math
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch
 np.set_printoptions(precision=12, linewidth=220)
-src = open('scratch/fuzz_crystal_stress.py').read()
+src = open('tests/campaigns/fuzz_crystal_stress.py').read()
 exec(src[:src.index("bad = []; ntot = 0")])
 body = src[src.index("    rng = np.random.RandomState(9000 + seed)"):src.index("    try:\n        with np.errstate")]
 seed = 240

@@ -8,7 +8,7 @@ from oracle import seqtrace_np as oracle
 from pyrate_amd.raytracer.optical_system import seqtrace_fused
 from pyrate_amd.raytracer.ray import RayBundle
 import test_gpu_fuzz as tf
-src = open('scratch/fuzz_crystal_stress.py').read()
+src = open('tests/campaigns/fuzz_crystal_stress.py').read()
 crystal_body = src[src.index("    rng = np.random.RandomState(9000 + seed)"):src.index("    n = 200\n")]
 bad = []; nb = 0
 

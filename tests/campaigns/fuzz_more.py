@@ -66,7 +66,7 @@ for seed in range(200):
         r["g_shape"][2] = 2 * z - r["g_shape"][2]; r["g_ap"][2] = 2 * z - r["g_ap"][2]
     tot += compare(recs, *bundle(rng, 300), ("mirror-any-shape", seed), bad)
 # (b) explicit shapes as crystal interfaces
-src = open('scratch/fuzz_crystal_stress.py').read()
+src = open('tests/campaigns/fuzz_crystal_stress.py').read()
 crystal_body = src[src.index("    rng = np.random.RandomState(9000 + seed)"):src.index("    n = 200\n")]
 for seed in range(150):
     exec("if True:\n" + crystal_body)
