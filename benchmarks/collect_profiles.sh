@@ -14,6 +14,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> "$OUT/rocprof_write.err"
 python benchmarks/kernel_trace_summary.py "$OUT/stats" > "$OUT/bench_path_kernel_trace_summary.json" 2> "$OUT/kernel_trace_summary.err"
 python benchmarks/hbm_traffic.py "$OUT" > "$OUT/hbm_traffic.json" 2> "$OUT/hbm_traffic.err"
+# (the 1.25e7-ray shard of the multi-GPU runs has its own entry in profiles/hbm_traffic.json: scratch/pmc_125.sh)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/configs_stats" -- python benchmarks/run_configs.py > "$OUT/run_configs.jsonl" 2> "$OUT/run_configs.err"
 python tests/parity_report.py > "$OUT/parity_report.txt" 2> "$OUT/parity_report.err"
 # keep only the summaries (the raw traces are large)
