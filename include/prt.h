@@ -316,9 +316,11 @@ int32_t prt_compact(int64_t n, const uint8_t *mask, int32_t n_arrays, const doub
                     const uint8_t *u8_src, uint8_t *u8_dst, void *scratch, int64_t *n_kept,
                     void *stream);
 
-/* Timing helper for bench.py: runs prt_trace `iters` times on `stream` between
- * two HIP events recorded on that stream and returns the average milliseconds
- * per launch in *ms_avg. */
+/* Timing helper: runs prt_trace `iters` times on `stream` between two HIP events recorded on that
+ * stream and returns the average milliseconds per launch in *ms_avg.  Used by bench.py for
+ * roofline.kernel_ms and by callers that place their output arrays by measurement (the write bandwidth
+ * of the path-mode march depends on where x_hit and k_out sit in HBM relative to each other --
+ * DESIGN.md section 5 "Placement"). */
 int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
                         const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
                         int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
