@@ -423,3 +423,40 @@ def test_tuned_output_allocation_is_an_ordinary_buffer_set(gpu_device):
     for s_ in range(12):
         assert torch.equal(a.x_hit[s_].contiguous().view(torch.int64), b.x_hit[s_].contiguous().view(torch.int64))
         assert torch.equal(a.flags[s_], b.flags[s_])
+
+
+@pytest.mark.parametrize("kind", ["uniaxial", "biaxial"])
+def test_crystal_solutions_satisfy_the_wave_equation_at_full_size(kind, gpu_device):
+    """size-independent property (reference: tests/test_material.py:38-401): behind every crystal
+    interface the (k, E) pairs the device solver returns obey k x (k x E) + eps E = 0, at BASELINE
+    config 4's size (1e6 rays -> 2e6 / 4e6 solutions)"""
+    import math
+    from pyrate_amd import engine, systems, _lib
+    c = systems.CALCITE_TILTED
+    if kind == "uniaxial":
+        (e1, e2) = (systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"]),
+                    systems.uniaxial_eps(1.6727, 1.60, (math.sin(0.2), 0.0, math.cos(0.2))))
+    else:
+        (e1, e2) = (np.diag([1.55 ** 2, 1.60 ** 2, 1.68 ** 2]), np.diag([1.62 ** 2, 1.66 ** 2, 1.70 ** 2]))
+    sysd = engine.DeviceSystem(systems.aniso_doublet_records(e1, e2), 0)
+    (o, k) = systems.collimated_bundle(1000000, 11.43, -5.0, angley=0.03)
+    e0 = np.cross(k, np.array([1., 0., 0.]), axisa=0, axisb=0).T.copy()
+    (x0, k0, e0d) = [engine.to_device_rays(a, gpu_device) for a in (o, k, e0)]
+    res = sysd.trace(x0, k0, e0d, mode=_lib.MODE_PATH, want_fields=True)
+    checked = 0
+    for (s, eps) in ((1, e1), (2, e2)):
+        kk = res.k_out[s]
+        (er, ei) = res.e_out[s]
+        ok = res.valid_out[s].bool()
+        epst = torch.tensor(np.asarray(eps, dtype=float), dtype=torch.float64, device=gpu_device)
+        worst = 0.0
+        for e in (er, ei):
+            kxe = torch.linalg.cross(kk, e, dim=0)
+            r = torch.linalg.cross(kk, kxe, dim=0) + epst @ e
+            rel = torch.linalg.norm(r, dim=0) / (torch.linalg.norm(e, dim=0) + 1e-300)
+            rel = torch.where(ok & (torch.linalg.norm(e, dim=0) > 0), rel, torch.zeros_like(rel))
+            worst = max(worst, float(rel.max()))
+        assert int(ok.sum()) > 0.9 * ok.numel()
+        assert worst < 1e-9, (s, worst)
+        checked += int(ok.sum())
+    assert checked > 5e6
