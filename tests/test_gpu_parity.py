@@ -460,3 +460,44 @@ def test_crystal_solutions_satisfy_the_wave_equation_at_full_size(kind, gpu_devi
         assert worst < 1e-9, (s, worst)
         checked += int(ok.sum())
     assert checked > 5e6
+
+
+def test_double_gauss_trace_is_reversible_at_full_size(gpu_device):
+    """size-independent property at BASELINE configs[1]'s size: send the image-plane rays of the 1e7-ray
+    double Gauss trace back through the mirrored prescription (surfaces in reverse order, z -> z_img - z,
+    radii negated, indices of the media on the other side) and they arrive on the first lens surface where
+    they started, with the reversed incoming wave vector"""
+    from pyrate_amd import engine, systems, _lib
+    tup = systems.double_gauss_tuples()
+    S = len(tup)
+    fwd = engine.DeviceSystem(systems.double_gauss_records(), 0)
+    (o, k, e0) = systems.double_gauss_bundle(10000000, field_deg=3.0)
+    n = o.shape[1]
+    (x0, k0, e0d) = [engine.to_device_rays(a, gpu_device) for a in (o, k, e0)]
+    path = fwd.trace(x0, k0, e0d, mode=_lib.MODE_PATH, packed_flags=True)
+    ok = path.valid_out[S - 1].bool()
+    assert int(ok.sum()) > 0.99 * n
+    z_img = sum(t[2] for t in tup)
+    rev = []
+    for i in range(S):
+        j = S - 1 - i
+        (r, cc, _, _, name, _) = tup[j]
+        gap = 0.0 if i == 0 else tup[j + 1][2]
+        n_after = tup[j - 1][3] if j >= 1 else None
+        rev.append((-r, cc, gap, n_after, "rev_" + name, {}))
+    back = engine.DeviceSystem(systems.simple_system_records(systems.rotsym_builduplist(rev)), 0)
+    x_img = path.x_hit[S - 1]
+    k_img = path.k_out[S - 1]
+    xs = torch.stack((x_img[0], x_img[1], z_img - x_img[2])).contiguous()       # on the mirrored image plane (z' = 0)
+    ks = torch.stack((-k_img[0], -k_img[1], k_img[2])).contiguous()
+    es = torch.linalg.cross(ks, torch.tensor([1.0, 0.0, 0.0], dtype=torch.float64, device=gpu_device)[:, None].expand(3, n),
+                            dim=0).contiguous()
+    res = back.trace(xs, ks, es, mode=_lib.MODE_IMAGE)
+    good = ok & res.valid_out[0].bool()
+    assert int(good.sum()) == int(ok.sum())
+    x_first = path.x_hit[0]
+    want_x = torch.stack((x_first[0], x_first[1], z_img - x_first[2]))
+    want_k = torch.stack((-k0[0], -k0[1], k0[2]))
+    dx = (res.x_hit[0] - want_x).abs().max(dim=0).values
+    dk = (res.k_out[0] - want_k).abs().max(dim=0).values
+    assert float(dx[good].max()) < 1e-9 and float(dk[good].max()) < 1e-11
