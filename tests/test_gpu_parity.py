@@ -501,3 +501,23 @@ def test_double_gauss_trace_is_reversible_at_full_size(gpu_device):
     dx = (res.x_hit[0] - want_x).abs().max(dim=0).values
     dk = (res.k_out[0] - want_k).abs().max(dim=0).values
     assert float(dx[good].max()) < 1e-9 and float(dk[good].max()) < 1e-11
+
+
+def test_double_gauss_trace_scales_exactly_with_powers_of_two(gpu_device):
+    """geometric similarity, bit for bit: the prescription and the bundle scaled by 2 (an exact operation
+    in binary floating point: radii, gaps, ray origins) give hit points exactly twice as large and
+    identical wave vectors and masks, for all 1e7 rays at all 12 surfaces"""
+    from pyrate_amd import engine, systems, _lib
+    tup = systems.double_gauss_tuples()
+    big = [(2.0 * r, cc, 2.0 * t, n_after, name, opts) for (r, cc, t, n_after, name, opts) in tup]
+    a = engine.DeviceSystem(systems.double_gauss_records(), 0)
+    b = engine.DeviceSystem(systems.simple_system_records(systems.rotsym_builduplist(big)), 0)
+    (o, k, e0) = systems.double_gauss_bundle(10000000, field_deg=4.0)
+    (x0, k0, e0d) = [engine.to_device_rays(v, gpu_device) for v in (o, k, e0)]
+    pa = a.trace(x0, k0, e0d, mode=_lib.MODE_PATH, packed_flags=True)
+    pb = b.trace((2.0 * x0).contiguous(), k0, e0d, mode=_lib.MODE_PATH, packed_flags=True)
+    for s in range(len(tup)):
+        assert torch.equal(pa.flags[s], pb.flags[s])
+        m = pa.valid_out[s].bool()
+        assert torch.equal((2.0 * pa.x_hit[s])[:, m], pb.x_hit[s][:, m]), s
+        assert torch.equal(pa.k_out[s][:, m], pb.k_out[s][:, m]), s
