@@ -8,7 +8,13 @@ CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["prt.hip"]
 HEADERS = ["prt_kernels.h", "prt_device.h", "prt_aniso.h", os.path.join("..", "..", "include", "prt.h")]
 OUT = os.path.join(CSRC, "libprt.so")
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+# -ffp-contract=on: FMA contraction decided per source expression (the device default, "fast", lets the
+# optimiser contract across statements, and it did so differently for the two rays a march thread
+# owns: 37 % of the double Gauss rays differed by up to 2 ulp depending on whether their global index was
+# even or odd).  With "on" a ray's result does not depend on its position in the bundle, so a sharded
+# trace equals the unsharded one bit for bit whatever the shard boundaries; no measurable cost
+# (scratch/slot_probe.py, scratch/ab_same_buffers.py).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=on",
                "-Wall", "-Wno-unused-function"]
 
 
@@ -23,7 +29,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

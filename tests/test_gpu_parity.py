@@ -521,3 +521,52 @@ def test_double_gauss_trace_scales_exactly_with_powers_of_two(gpu_device):
         m = pa.valid_out[s].bool()
         assert torch.equal((2.0 * pa.x_hit[s])[:, m], pb.x_hit[s][:, m]), s
         assert torch.equal(pa.k_out[s][:, m], pb.k_out[s][:, m]), s
+
+
+def test_eight_shards_reassemble_to_the_whole_trace_at_full_size(gpu_device):
+    """the multi-GPU decomposition by construction: the 1e7-ray bundle generated and traced
+    as 8 contiguous shards (each 'rank' builds only its slice of the raster on the device, as bench.py does)
+    and reassembled by ImagePlaneGather's ordering equals the unsharded trace bit for bit"""
+    from pyrate_amd import distributed as pdist, engine, systems, _lib
+    sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
+    (x0, k0, e0d, n) = systems.double_gauss_bundle_device(10000000, gpu_device, field_deg=2.0)
+    whole = sysd.trace(x0, k0, e0d, mode=_lib.MODE_IMAGE, packed_flags=True)
+    world = 8
+    g = pdist.ImagePlaneGather(n, gpu_device)
+    g.world = world
+    g.sizes = pdist.shard_sizes(n, world)
+    g.n_max = max(g.sizes)
+    g.recv_f = torch.zeros((world, 6, 1, g.n_max), dtype=torch.float64, device=gpu_device)
+    g.recv_v = torch.zeros((world, 1, g.n_max), dtype=torch.uint8, device=gpu_device)
+    for r in range(world):
+        (lo, hi) = pdist.shard_range(n, r, world)
+        (xs, ks, es, total) = systems.double_gauss_bundle_device(10000000, gpu_device, field_deg=2.0, lo=lo, hi=hi)
+        assert total == n and xs.shape[1] == hi - lo
+        part = sysd.trace(xs, ks, es, mode=_lib.MODE_IMAGE, packed_flags=True)
+        g.recv_f[r, 0:3, 0, :hi - lo] = part.x_hit[0]
+        g.recv_f[r, 3:6, 0, :hi - lo] = part.k_out[0]
+        g.recv_v[r, 0, :hi - lo] = part.valid_out[0]
+    (gx, gk, gv) = g.finish()
+
+    def same(a, b):
+        return torch.equal(a.contiguous().view(torch.int64), b.contiguous().view(torch.int64))
+    assert same(gx, whole.x_hit[0]) and same(gk, whole.k_out[0]) and torch.equal(gv, whole.valid_out[0])
+
+
+@pytest.mark.parametrize("system", ["double_gauss", "asphere"])
+def test_a_rays_result_does_not_depend_on_its_position_in_the_bundle(system, gpu_device):
+    """a march thread owns two rays; the arithmetic of both must be identical, so that tracing the bundle
+    shifted by one ray (every ray changes its slot) gives the same bits -- the property that makes a
+    sharded trace equal the unsharded one for any shard boundary (build flag -ffp-contract=on)"""
+    from pyrate_amd import engine, systems, _lib
+    recs = systems.double_gauss_records() if system == "double_gauss" else \
+        systems.asphere_records(coefficients=(1e-3, -1e-6, 1e-8), curv=-1. / 30., cc=-1.5)
+    sysd = engine.DeviceSystem(recs, 0)
+    (x0, k0, e0d, n) = systems.double_gauss_bundle_device(400000, gpu_device, field_deg=2.0)
+    for mode in (_lib.MODE_IMAGE, _lib.MODE_PATH):
+        a = sysd.trace(x0, k0, e0d, mode=mode)
+        b = sysd.trace(x0[:, 1:].contiguous(), k0[:, 1:].contiguous(), e0d[:, 1:].contiguous(), mode=mode)
+        for s in range(len(a.x_hit)):
+            assert torch.equal(a.x_hit[s][:, 1:].contiguous().view(torch.int64), b.x_hit[s].contiguous().view(torch.int64))
+            assert torch.equal(a.k_out[s][:, 1:].contiguous().view(torch.int64), b.k_out[s].contiguous().view(torch.int64))
+            assert torch.equal(a.valid_out[s][1:], b.valid_out[s])
