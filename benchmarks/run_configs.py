@@ -27,12 +27,8 @@ def emit(**kw):
 
 
 def timed_trace(sysd, x0, k0, e0, mode, iters, warm=5):
-    if sysd.all_isotropic and mode == _lib.MODE_PATH and x0.shape[1] >= 1000000:
-        # path arrays placed by measurement (DESIGN.md section 5 "Placement"), two mask arrays
-        (bufs, _) = sysd.alloc_outputs_tuned(x0, k0, e0, mode=mode)
-        torch.cuda.empty_cache()
-    else:
-        bufs = sysd.alloc_outputs(x0.shape[1], mode)
+    # big isotropic path arrays come from the placement-aware arena (the default of alloc_outputs)
+    bufs = sysd.alloc_outputs(x0.shape[1], mode)
     for _ in range(warm):
         sysd.trace_into(x0, k0, bufs, e0)
     torch.cuda.synchronize()

@@ -25,7 +25,7 @@ c_double_p = ctypes.c_void_p      # device pointers travel as raw addresses
 c_u8_p = ctypes.c_void_p
 c_stream = ctypes.c_void_p
 
-ABI_VERSION = 3          # PRT_ABI_VERSION of include/prt.h
+ABI_VERSION = 4          # PRT_ABI_VERSION of include/prt.h
 
 # name -> (restype, argtypes); must list every symbol declared in include/prt.h
 PROTOTYPES = {
@@ -111,6 +111,17 @@ PROTOTYPES["prt_trace_moments"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_in
                                                    c_double_p, c_double_p, c_double_p, ctypes.c_int32,
                                                    ctypes.c_int64, c_double_p, c_double_p, c_u8_p, c_u8_p,
                                                    c_double_p, c_double_p, c_double_p, c_stream])
+
+PROTOTYPES["prt_arena_create"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)])
+PROTOTYPES["prt_arena_destroy"] = (ctypes.c_int32, [ctypes.c_void_p])
+PROTOTYPES["prt_arena_alloc"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64),
+                                                 ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32),
+                                                 ctypes.c_int32, c_stream])
+PROTOTYPES["prt_arena_free"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p])
+PROTOTYPES["prt_arena_trim"] = (ctypes.c_int32, [ctypes.c_void_p])
+PROTOTYPES["prt_arena_kind_of"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)])
+PROTOTYPES["prt_arena_stats"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int32,
+                                                 ctypes.POINTER(ctypes.c_double), ctypes.c_int32])
 
 _lib = None
 

@@ -1,13 +1,17 @@
 """Build the in-tree HIP library: hipcc --offload-arch=gfx950 -> pyrate_amd/csrc/libprt.so."""
+import hashlib
+import json
 import os
 import shutil
 import subprocess
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["prt.hip"]
-HEADERS = ["prt_kernels.h", "prt_device.h", "prt_aniso.h", os.path.join("..", "..", "include", "prt.h")]
+HEADERS = ["prt_kernels.h", "prt_device.h", "prt_aniso.h", "prt_placed.h", os.path.join("..", "..", "include", "prt.h")]
 OUT = os.path.join(CSRC, "libprt.so")
+INFO = os.path.join(CSRC, "libprt.build.json")     # written by the build, travels with the .so
 # -ffp-contract=on: FMA contraction decided per source expression (the device default, "fast", lets the
 # optimiser contract across statements, and it did so differently for the two rays a march thread
 # owns: 37 % of the double Gauss rays differed by up to 2 ulp depending on whether their global index was
@@ -34,19 +38,61 @@ def needs_build():
 
 
 def build_all(force=False, verbose=True):
-    """Compile libprt.so for gfx950 (cross-compiles without a GPU)."""
-    if not force and not needs_build():
-        return OUT
+    """Compile libprt.so for gfx950 (cross-compiles without a GPU).  ``force`` rebuilds whenever a
+    compiler is there (what ``__graft_entry__.build()`` asks for: the build check must compile, not
+    find a file); otherwise only when a source is newer than the library."""
     hipcc = find_hipcc()
     if hipcc is None:
         if os.path.exists(OUT):
-            return OUT          # prebuilt .so travelled with the snapshot
+            return OUT          # prebuilt .so travelled with the snapshot, no compiler on this box
         raise RuntimeError("hipcc not found and %s is not built" % OUT)
+    if not force and not needs_build():
+        return OUT
     cmd = [hipcc] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=CSRC)
+    with open(INFO, "w") as f:
+        json.dump({"hipcc": hipcc_version(hipcc), "flags": HIPCC_FLAGS, "sha256_16": library_hash(),
+                   "built_unix": int(time.time())}, f)
     return OUT
+
+
+def hipcc_version(hipcc=None):
+    hipcc = hipcc or find_hipcc()
+    if hipcc is None:
+        return None
+    out = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+    for line in out.splitlines():
+        if line.startswith("HIP version"):
+            return line.split(":", 1)[1].strip()
+    return out.splitlines()[0].strip() if out else None
+
+
+def library_hash():
+    """first 16 hex digits of the SHA-256 of libprt.so (None if it is not built)"""
+    if not os.path.exists(OUT):
+        return None
+    h = hashlib.sha256()
+    with open(OUT, "rb") as f:
+        for block in iter(lambda: f.read(1 << 20), b""):
+            h.update(block)
+    return h.hexdigest()[:16]
+
+
+def build_info():
+    """what bench.py puts into its JSON line: hash of the library that is loaded, and the compiler
+    that produced it (from the side file the build writes; None if the library came from elsewhere)"""
+    info = {"libprt_sha256_16": library_hash(), "hipcc": None}
+    try:
+        with open(INFO) as f:
+            rec = json.load(f)
+        if rec.get("sha256_16") == info["libprt_sha256_16"]:
+            info["hipcc"] = rec.get("hipcc")
+            info["built_unix"] = rec.get("built_unix")
+    except (OSError, ValueError):
+        pass
+    return info
 
 
 if __name__ == "__main__":

@@ -99,6 +99,8 @@ struct event_pair {
     }
 };
 
+#include "prt_placed.h"
+
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------

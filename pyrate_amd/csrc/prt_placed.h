@@ -1,0 +1,459 @@
+// prt_placed.h -- placement-aware device memory for the path arrays (include/prt.h "arena").
+// Included by prt.hip (one translation unit; uses its fail / HIP_TRY / device_guard helpers).
+//
+// What it is for (measured: benchmarks/vmm_placement_probe.hip, profiles/r02_vmm_placement_probe.txt,
+// DESIGN.md section 5 "Placement"): the physical HBM of an MI355X falls into THREE kinds of memory, each
+// one third of the capacity in 1-GiB-aligned runs.  72 concurrent write streams (the path-mode march:
+// 12 surfaces x 6 rows) run at 5.6-5.7 TB/s when all of them land in one kind and at 7.0 TB/s when
+// x_hit lies in one kind and k_out in another -- every one of 6 216 chunk pairs tried falls on one of
+// the two values.  Which kind an allocation gets is decided by the driver's physical allocator and is
+// not visible in virtual addresses, so hipMalloc'ed output arrays are a lottery (round 1: 62-81 % of
+// the HBM peak for the same binary).
+//
+// The arena takes physical memory itself, in 1-GiB slabs (hipMemCreate), finds every slab's kind with a
+// 2-ms write probe against one representative slab per kind, and builds each requested buffer out of
+// slabs of ONE kind, mapped to contiguous virtual addresses (hipMemMap); the buffers of one request
+// get different kinds.  Slabs and mapped buffers are cached for reuse.
+#pragma once
+#include <mutex>
+#include <vector>
+#include <algorithm>
+
+#define PRT_SLAB_BYTES ((size_t)1 << 30)
+#define PRT_ARENA_PROBE_ROWS 72
+
+struct prt_probe_rows {
+    double *p[PRT_ARENA_PROBE_ROWS];
+};
+
+// the store structure of k_trace_iso's path mode without its arithmetic: every lane writes 16 B to
+// each of the 72 rows
+__global__ __launch_bounds__(128) void k_arena_probe(prt_probe_rows rows, int64_t n, double v) {
+    const int64_t i = ((int64_t)blockIdx.x * 128 + threadIdx.x) * 2;
+    if (i >= n) return;
+    double2 val = make_double2(v + (double)i, v - (double)i);
+    for (int r = 0; r < PRT_ARENA_PROBE_ROWS; ++r) {
+        *(double2 *)(rows.p[r] + i) = val;
+        val.x += 1.0;
+    }
+}
+
+struct prt_slab {
+    hipMemGenericAllocationHandle_t handle;
+    int32_t kind;
+};
+
+struct prt_placed_buffer {
+    void *va = nullptr;
+    size_t bytes = 0;              // mapped size (whole slabs)
+    int32_t kind = -1;
+    bool in_use = false;
+    std::vector<prt_slab> slabs;
+};
+
+struct prt_arena {
+    int32_t device = 0;
+    std::mutex mu;
+    int32_t n_kinds = 0;
+    // one slab per kind stays mapped for good and is never handed out: the probe writes into it
+    prt_slab rep[PRT_ARENA_MAX_KINDS];
+    void *rep_va[PRT_ARENA_MAX_KINDS] = {nullptr, nullptr, nullptr, nullptr};
+    void *probe_va = nullptr;      // where a slab under test is mapped
+    std::vector<prt_slab> free_slabs;
+    std::vector<prt_placed_buffer *> buffers;      // in use and cached
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    hipMemAllocationProp prop;
+    hipMemAccessDesc access;
+    // statistics
+    int64_t n_probes = 0, n_created = 0, n_released = 0;
+    double probe_ms_total = 0.0;
+    double bw_same = 0.0, bw_cross = 0.0;          // last probe rates seen, GB/s
+};
+
+static hipError_t arena_map(prt_arena *a, void *va, const prt_slab &s) {
+    hipError_t e = hipMemMap(va, PRT_SLAB_BYTES, 0, s.handle, 0);
+    if (e != hipSuccess) return e;
+    return hipMemSetAccess(va, PRT_SLAB_BYTES, &a->access, 1);
+}
+
+// GB/s of the 72-row writer with rows [0,36) in slab memory `lo` and rows [36,72) in `hi`
+static hipError_t arena_probe_rate(prt_arena *a, double *lo, double *hi, int64_t row_len, hipStream_t st,
+                                   double *gbs) {
+    prt_probe_rows rows;
+    for (int r = 0; r < 36; ++r) rows.p[r] = lo + (int64_t)r * row_len;
+    for (int r = 0; r < 36; ++r) rows.p[36 + r] = hi + (int64_t)r * row_len;
+    const dim3 grid((unsigned)((row_len / 2 + 127) / 128)), block(128);
+    float best = 1e30f;
+    hipLaunchKernelGGL(k_arena_probe, grid, block, 0, st, rows, row_len, 1.0);      // warm-up
+    for (int it = 0; it < 3; ++it) {
+        hipError_t e = hipEventRecord(a->ev_a, st);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_arena_probe, grid, block, 0, st, rows, row_len, 1.0);
+        if ((e = hipEventRecord(a->ev_b, st)) != hipSuccess) return e;
+        if ((e = hipEventSynchronize(a->ev_b)) != hipSuccess) return e;
+        float ms = 0.f;
+        if ((e = hipEventElapsedTime(&ms, a->ev_a, a->ev_b)) != hipSuccess) return e;
+        best = std::min(best, ms);
+        a->probe_ms_total += ms;
+    }
+    a->n_probes += 1;
+    *gbs = 72.0 * row_len * 8 / 1e6 / best;
+    return hipGetLastError();
+}
+
+// Kind of a slab that is mapped at `mem`: the representative it is SLOW with.  The yardstick is the
+// slab against itself (both halves of the streams inside it = one kind by construction): a pair of
+// different kinds runs 1.23x faster than that, a pair of the same kind at the same rate.
+static hipError_t arena_classify(prt_arena *a, double *mem, hipStream_t st, int32_t *kind) {
+    const int64_t half_len = (int64_t)(PRT_SLAB_BYTES / 72 / 8) / 512 * 512;
+    const int64_t full_len = (int64_t)(PRT_SLAB_BYTES / 36 / 8) / 512 * 512;
+    double self = 0.0;
+    hipError_t e = arena_probe_rate(a, mem, mem + 36 * half_len, half_len, st, &self);
+    if (e != hipSuccess) return e;
+    a->bw_same = self;
+    for (int q = 0; q < a->n_kinds; ++q) {
+        double pair = 0.0;
+        if ((e = arena_probe_rate(a, (double *)a->rep_va[q], mem, full_len, st, &pair)) != hipSuccess) return e;
+        if (pair < 1.10 * self) {
+            *kind = q;
+            return hipSuccess;
+        }
+        a->bw_cross = pair;
+    }
+    *kind = a->n_kinds;        // fast with every known kind: a new one
+    return hipSuccess;
+}
+
+// One more slab from the driver, classified.  A slab of a new kind becomes that kind's representative
+// (ret_is_rep) and is not available for buffers.
+static hipError_t arena_new_slab(prt_arena *a, hipStream_t st, prt_slab *out, bool *became_rep) {
+    *became_rep = false;
+    size_t free_b = 0, total_b = 0;
+    hipError_t e = hipMemGetInfo(&free_b, &total_b);
+    if (e != hipSuccess) return e;
+    if (free_b < 3 * PRT_SLAB_BYTES) return hipErrorOutOfMemory;      // leave the last GiBs to others
+    prt_slab s;
+    s.kind = -1;
+    if ((e = hipMemCreate(&s.handle, PRT_SLAB_BYTES, &a->prop, 0)) != hipSuccess) return e;
+    a->n_created += 1;
+    if ((e = arena_map(a, a->probe_va, s)) != hipSuccess) {
+        (void)hipMemRelease(s.handle);
+        return e;
+    }
+    int32_t kind = -1;
+    e = arena_classify(a, (double *)a->probe_va, st, &kind);
+    (void)hipMemUnmap(a->probe_va, PRT_SLAB_BYTES);
+    if (e != hipSuccess) {
+        (void)hipMemRelease(s.handle);
+        return e;
+    }
+    if (kind == a->n_kinds && a->n_kinds < PRT_ARENA_MAX_KINDS) {
+        void *va = nullptr;
+        if ((e = hipMemAddressReserve(&va, PRT_SLAB_BYTES, (size_t)2 << 20, nullptr, 0)) != hipSuccess ||
+            (e = arena_map(a, va, s)) != hipSuccess) {
+            (void)hipMemRelease(s.handle);
+            return e;
+        }
+        s.kind = kind;
+        a->rep[kind] = s;
+        a->rep_va[kind] = va;
+        a->n_kinds += 1;
+        *became_rep = true;
+    } else {
+        s.kind = std::min(kind, PRT_ARENA_MAX_KINDS - 1);
+    }
+    *out = s;
+    return hipSuccess;
+}
+
+static void arena_release_slab(prt_arena *a, const prt_slab &s) {
+    (void)hipMemRelease(s.handle);
+    a->n_released += 1;
+}
+
+static void arena_unmap_buffer(prt_arena *a, prt_placed_buffer *b, bool keep_slabs) {
+    if (b->va) {
+        (void)hipMemUnmap(b->va, b->bytes);
+        (void)hipMemAddressFree(b->va, b->bytes);
+    }
+    for (const prt_slab &s : b->slabs) {
+        if (keep_slabs) a->free_slabs.push_back(s);
+        else arena_release_slab(a, s);
+    }
+    b->slabs.clear();
+    b->va = nullptr;
+}
+
+static int64_t arena_count_free(const prt_arena *a, int32_t kind) {
+    int64_t n = 0;
+    for (const prt_slab &s : a->free_slabs) n += (s.kind == kind);
+    return n;
+}
+
+// cached (mapped, unused) buffer of exactly this size and kind
+static prt_placed_buffer *arena_cached_buffer(prt_arena *a, size_t n_slabs, int32_t kind) {
+    for (prt_placed_buffer *b : a->buffers)
+        if (!b->in_use && b->kind == kind && b->slabs.size() == n_slabs) return b;
+    return nullptr;
+}
+
+static int64_t arena_count_cached(const prt_arena *a, size_t n_slabs, int32_t kind) {
+    int64_t n = 0;
+    for (const prt_placed_buffer *b : a->buffers)
+        n += (!b->in_use && b->kind == kind && b->slabs.size() == n_slabs);
+    return n;
+}
+
+static hipError_t arena_build_buffer(prt_arena *a, size_t n_slabs, int32_t kind, prt_placed_buffer **out) {
+    prt_placed_buffer *b = new (std::nothrow) prt_placed_buffer;
+    if (!b) return hipErrorOutOfMemory;
+    b->bytes = n_slabs * PRT_SLAB_BYTES;
+    b->kind = kind;
+    hipError_t e = hipMemAddressReserve(&b->va, b->bytes, (size_t)2 << 20, nullptr, 0);
+    if (e != hipSuccess) {
+        delete b;
+        return e;
+    }
+    for (size_t i = 0; i < a->free_slabs.size() && b->slabs.size() < n_slabs;) {
+        if (a->free_slabs[i].kind == kind) {
+            b->slabs.push_back(a->free_slabs[i]);
+            a->free_slabs.erase(a->free_slabs.begin() + i);
+        } else {
+            ++i;
+        }
+    }
+    for (size_t i = 0; i < b->slabs.size() && e == hipSuccess; ++i)
+        e = hipMemMap((char *)b->va + i * PRT_SLAB_BYTES, PRT_SLAB_BYTES, 0, b->slabs[i].handle, 0);
+    if (e == hipSuccess) e = hipMemSetAccess(b->va, b->bytes, &a->access, 1);
+    if (e != hipSuccess || b->slabs.size() != n_slabs) {
+        arena_unmap_buffer(a, b, true);
+        delete b;
+        return e != hipSuccess ? e : hipErrorOutOfMemory;
+    }
+    a->buffers.push_back(b);
+    *out = b;
+    return hipSuccess;
+}
+
+extern "C" {
+
+int32_t prt_arena_create(int32_t device, prt_arena_t **out) {
+    if (!out) return fail(PRT_ERR_INVALID_ARG, "prt_arena_create: null out");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(PRT_ERR_NO_DEVICE, "no HIP device");
+    if (device < 0 || device >= count) return fail(PRT_ERR_INVALID_ARG, "prt_arena_create: bad device");
+    PRT_ON_DEVICE(device);
+    prt_arena *a = new (std::nothrow) prt_arena;
+    if (!a) return fail(PRT_ERR_NOMEM, "prt_arena_create: host memory");
+    a->device = device;
+    memset(&a->prop, 0, sizeof a->prop);
+    a->prop.type = hipMemAllocationTypePinned;
+    a->prop.location.type = hipMemLocationTypeDevice;
+    a->prop.location.id = device;
+    memset(&a->access, 0, sizeof a->access);
+    a->access.location = a->prop.location;
+    a->access.flags = hipMemAccessFlagsProtReadWrite;
+    hipError_t e = hipEventCreate(&a->ev_a);
+    if (e == hipSuccess) e = hipEventCreate(&a->ev_b);
+    if (e == hipSuccess) e = hipMemAddressReserve(&a->probe_va, PRT_SLAB_BYTES, (size_t)2 << 20, nullptr, 0);
+    if (e != hipSuccess) {
+        if (a->ev_a) (void)hipEventDestroy(a->ev_a);
+        if (a->ev_b) (void)hipEventDestroy(a->ev_b);
+        delete a;
+        return fail(PRT_ERR_DEVICE, "prt_arena_create", e);
+    }
+    *out = a;
+    return PRT_OK;
+}
+
+int32_t prt_arena_trim(prt_arena_t *a) {
+    if (!a) return fail(PRT_ERR_INVALID_ARG, "prt_arena_trim: null arena");
+    PRT_ON_DEVICE(a->device);
+    std::lock_guard<std::mutex> lock(a->mu);
+    HIP_TRY(hipDeviceSynchronize());
+    for (size_t i = 0; i < a->buffers.size();) {
+        prt_placed_buffer *b = a->buffers[i];
+        if (!b->in_use) {
+            arena_unmap_buffer(a, b, false);
+            delete b;
+            a->buffers.erase(a->buffers.begin() + i);
+        } else {
+            ++i;
+        }
+    }
+    for (const prt_slab &s : a->free_slabs) arena_release_slab(a, s);
+    a->free_slabs.clear();
+    return PRT_OK;
+}
+
+int32_t prt_arena_destroy(prt_arena_t *a) {
+    if (!a) return PRT_OK;
+    {
+        PRT_ON_DEVICE(a->device);
+        (void)hipDeviceSynchronize();
+        for (prt_placed_buffer *b : a->buffers) {
+            arena_unmap_buffer(a, b, false);
+            delete b;
+        }
+        a->buffers.clear();
+        for (const prt_slab &s : a->free_slabs) arena_release_slab(a, s);
+        for (int q = 0; q < a->n_kinds; ++q) {
+            (void)hipMemUnmap(a->rep_va[q], PRT_SLAB_BYTES);
+            (void)hipMemAddressFree(a->rep_va[q], PRT_SLAB_BYTES);
+            arena_release_slab(a, a->rep[q]);
+        }
+        (void)hipMemAddressFree(a->probe_va, PRT_SLAB_BYTES);
+        (void)hipEventDestroy(a->ev_a);
+        (void)hipEventDestroy(a->ev_b);
+    }
+    delete a;
+    return PRT_OK;
+}
+
+int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, void **ptrs, int32_t *kinds,
+                        int32_t max_hunt_slabs, void *stream) {
+    if (!a || n_parts <= 0 || n_parts > 8 || !bytes || !ptrs)
+        return fail(PRT_ERR_INVALID_ARG, "prt_arena_alloc: bad arguments");
+    for (int i = 0; i < n_parts; ++i) {
+        if (bytes[i] <= 0) return fail(PRT_ERR_INVALID_ARG, "prt_arena_alloc: part sizes must be positive");
+        ptrs[i] = nullptr;
+    }
+    if (max_hunt_slabs < 0) max_hunt_slabs = 128;
+    PRT_ON_DEVICE(a->device);
+    std::lock_guard<std::mutex> lock(a->mu);
+    hipStream_t st = (hipStream_t)stream;
+    size_t need[8];
+    for (int i = 0; i < n_parts; ++i) need[i] = ((size_t)bytes[i] + PRT_SLAB_BYTES - 1) / PRT_SLAB_BYTES;
+
+    // Assignment of kinds to parts: the first two parts (x_hit, k_out -- the two halves of the write
+    // streams) must differ; further parts take a kind nobody uses yet if one is at hand, otherwise
+    // whatever has room.  A part is served by a cached buffer of its size and kind, or by free slabs.
+    // Greedy over the parts in order; returns false if a part cannot be served.
+    int32_t chosen[8];
+    auto assign = [&](bool strict) {
+        int64_t slabs_taken[PRT_ARENA_MAX_KINDS] = {0, 0, 0, 0};
+        bool from_cache[8];
+        bool used[PRT_ARENA_MAX_KINDS] = {false, false, false, false};
+        for (int i = 0; i < n_parts; ++i) {
+            int best = -1;
+            bool best_cached = false;
+            for (int pass = 0; pass < 2 && best < 0; ++pass) {     // pass 0: kinds no earlier part uses
+                if (pass == 1 && strict && i < 2) break;           // the first two parts must differ
+                for (int q = 0; q < a->n_kinds && best < 0; ++q) {
+                    if (pass == 0 && used[q]) continue;
+                    int64_t cached_taken = 0;
+                    for (int j = 0; j < i; ++j)
+                        cached_taken += (chosen[j] == q && need[j] == need[i] && from_cache[j]);
+                    if (arena_count_cached(a, need[i], q) > cached_taken) {
+                        best = q;
+                        best_cached = true;
+                    } else if (arena_count_free(a, q) - slabs_taken[q] >= (int64_t)need[i]) {
+                        best = q;
+                    }
+                }
+            }
+            if (best < 0) return false;
+            chosen[i] = best;
+            from_cache[i] = best_cached;
+            used[best] = true;
+            if (!best_cached) slabs_taken[best] += (int64_t)need[i];
+        }
+        return true;
+    };
+
+    // hunt: take slabs from the driver until the strict assignment works (or the hunt budget is spent)
+    const bool want_two_kinds = n_parts >= 2;
+    int32_t hunted = 0;
+    hipError_t hunt_err = hipSuccess;
+    while (!assign(want_two_kinds)) {
+        size_t total_need = 0;
+        for (int i = 0; i < n_parts; ++i) total_need += need[i];
+        if (hunted >= (int32_t)total_need + max_hunt_slabs) break;
+        prt_slab s;
+        bool became_rep = false;
+        hunt_err = arena_new_slab(a, st, &s, &became_rep);
+        if (hunt_err != hipSuccess) break;
+        if (!became_rep) a->free_slabs.push_back(s);
+        ++hunted;
+    }
+    bool ok = assign(want_two_kinds);
+    if (!ok) ok = assign(false);              // not enough memory of a second kind: one kind it is
+    if (!ok) {
+        if (hunt_err != hipSuccess && hunt_err != hipErrorOutOfMemory)
+            return fail(PRT_ERR_DEVICE, "prt_arena_alloc: taking memory from the driver", hunt_err);
+        return fail(PRT_ERR_NOMEM, "prt_arena_alloc: not enough free device memory");
+    }
+    prt_placed_buffer *got[8];
+    for (int i = 0; i < n_parts; ++i) {
+        prt_placed_buffer *b = arena_cached_buffer(a, need[i], chosen[i]);
+        if (!b) {
+            hipError_t e = arena_build_buffer(a, need[i], chosen[i], &b);
+            if (e != hipSuccess) {
+                for (int j = 0; j < i; ++j) got[j]->in_use = false;
+                return fail(e == hipErrorOutOfMemory ? PRT_ERR_NOMEM : PRT_ERR_DEVICE,
+                            "prt_arena_alloc: mapping a buffer", e);
+            }
+        }
+        b->in_use = true;
+        got[i] = b;
+    }
+    for (int i = 0; i < n_parts; ++i) {
+        ptrs[i] = got[i]->va;
+        if (kinds) kinds[i] = got[i]->kind;
+    }
+    // slabs the hunt took beyond what was needed go back to the driver right away (they are all of
+    // kinds that are plentiful); slabs of buffers that were used once stay cached until prt_arena_trim
+    if (hunted > 0) {
+        for (const prt_slab &s : a->free_slabs) arena_release_slab(a, s);
+        a->free_slabs.clear();
+    }
+    return PRT_OK;
+}
+
+int32_t prt_arena_free(prt_arena_t *a, void *ptr) {
+    if (!a || !ptr) return fail(PRT_ERR_INVALID_ARG, "prt_arena_free: null argument");
+    PRT_ON_DEVICE(a->device);
+    std::lock_guard<std::mutex> lock(a->mu);
+    for (prt_placed_buffer *b : a->buffers)
+        if (b->va == ptr && b->in_use) {
+            // work that still uses the buffer must be finished before somebody else gets it
+            HIP_TRY(hipDeviceSynchronize());
+            b->in_use = false;        // stays mapped: the next request of this size and kind takes it as it is
+            return PRT_OK;
+        }
+    return fail(PRT_ERR_INVALID_ARG, "prt_arena_free: not a buffer of this arena");
+}
+
+int32_t prt_arena_kind_of(prt_arena_t *a, const void *ptr, int32_t *kind) {
+    if (!a || !ptr || !kind) return fail(PRT_ERR_INVALID_ARG, "prt_arena_kind_of: null argument");
+    std::lock_guard<std::mutex> lock(a->mu);
+    for (prt_placed_buffer *b : a->buffers)
+        if ((const char *)ptr >= (const char *)b->va && (const char *)ptr < (const char *)b->va + b->bytes) {
+            *kind = b->kind;
+            return PRT_OK;
+        }
+    return fail(PRT_ERR_INVALID_ARG, "prt_arena_kind_of: not inside a buffer of this arena");
+}
+
+int32_t prt_arena_stats(prt_arena_t *a, int64_t *out, int32_t n_out, double *rates, int32_t n_rates) {
+    if (!a || (!out && n_out > 0)) return fail(PRT_ERR_INVALID_ARG, "prt_arena_stats: null argument");
+    std::lock_guard<std::mutex> lock(a->mu);
+    int64_t v[12] = {0};
+    v[0] = a->n_kinds;
+    v[1] = a->n_probes;
+    v[2] = a->n_created;
+    v[3] = a->n_released;
+    v[4] = (int64_t)a->free_slabs.size();
+    for (const prt_placed_buffer *b : a->buffers) {
+        (b->in_use ? v[5] : v[6]) += (int64_t)b->slabs.size();
+        if (b->kind >= 0 && b->kind < PRT_ARENA_MAX_KINDS) v[8 + b->kind] += (int64_t)b->slabs.size();
+    }
+    v[7] = (int64_t)(PRT_SLAB_BYTES);
+    for (int i = 0; i < n_out && i < 12; ++i) out[i] = v[i];
+    double r[3] = {a->bw_same, a->bw_cross, a->probe_ms_total};
+    for (int i = 0; i < n_rates && i < 3; ++i) rates[i] = r[i];
+    return PRT_OK;
+}
+
+}  // extern "C"

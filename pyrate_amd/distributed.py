@@ -3,9 +3,10 @@ Multi-GPU: rays are independent, so a bundle is sharded into
 contiguous slices of the initial (3, N) arrays, one process per GPU, and traced
 with no data-path collective.  The only exchange step is the final image-plane
 gather: every rank contributes (x_img, k_img) (6, n) float64 + valid (n) uint8
-= 49 B/ray and receives the whole image plane (RCCL all-gather over xGMI;
-``torch.distributed`` backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU
-tests).  rayIDs are implicit: rank r owns ``shard_range(N, r, world)``.
+= 49 B/ray and receives the whole image plane (RCCL all-gather over xGMI, row by row
+straight into the final [row][global ray] layout; ``torch.distributed`` backend "nccl"
+is RCCL on ROCm; "gloo" is used by the CPU tests).  rayIDs are implicit: rank r owns
+``shard_range(N, r, world)``.
 """
 import os
 
@@ -21,81 +22,124 @@ def _collectives_needed(group=None):
     return dist.get_world_size(group) > 1 or os.environ.get("PRT_FORCE_COLLECTIVES", "0") == "1"
 
 
+def shard_stride(n_total, world):
+    """rays per rank: every rank but the last owns exactly this many"""
+    return -(-n_total // world) if world > 0 else 0
+
+
 def shard_range(n_total, rank, world):
-    """contiguous, ordered, near-equal slices: [lo, hi) of rank ``rank``"""
-    base = n_total // world
-    rem = n_total % world
-    lo = rank * base + min(rank, rem)
-    hi = lo + base + (1 if rank < rem else 0)
-    return lo, hi
+    """Contiguous, ordered slices of EQUAL STRIDE: rank r owns [r*n_pad, min((r+1)*n_pad, N)) with
+    n_pad = ceil(N / world) -- only the last rank is short (by less than ``world`` rays).  With one
+    common stride, ray i of rank r is global ray r*n_pad + i, so an all-gather of one row lands in
+    global ray order as it is (ImagePlaneGather needs no repacking)."""
+    n_pad = shard_stride(n_total, world)
+    lo = min(rank * n_pad, n_total)
+    return lo, min(lo + n_pad, n_total)
 
 
 def shard_sizes(n_total, world):
     return [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
 
 
-class ImagePlaneGather(object):
-    """All-gather of the image-plane arrays of a ray-sharded trace.
+def _row_of(t2d, row, start, n, n_pad):
+    """1-d tensor of n_pad elements that starts at t2d[row, start]: the n rays of a shard's row plus
+    whatever follows them in memory up to the common stride (padding of a pitched row, the next
+    branch, the next row -- never looked at by anybody).  None if the storage ends before that."""
+    if n_pad == n:
+        return t2d[row, start:start + n]
+    off = t2d.storage_offset() + row * t2d.stride(0) + start * t2d.stride(1)
+    room = t2d.untyped_storage().nbytes() // t2d.element_size() - off
+    if t2d.stride(1) != 1 or room < n_pad:
+        return None
+    return t2d.as_strided((n_pad,), (1,), off)
 
-    Buffers are allocated once for ``n_local_max`` rays per rank (shards differ by at
-    most one ray; the tail is padding).  ``start()`` packs on the caller's current
-    stream and launches the two collectives asynchronously; ``finish()`` returns
-    (x (3,N), k (3,N), valid (N,)) views in global ray order.
+
+class ImagePlaneGather(object):
+    """All-gather of the image-plane arrays of a ray-sharded trace, straight into the final layout.
+
+    The receive buffers ARE the result: ``recv_f`` (rows, branches, world * n_pad) float64 and
+    ``recv_v`` (branches, world * n_pad) uint8, with n_pad = ``shard_stride``.  Every row of a rank's
+    image-plane arrays is the input of one ``all_gather_into_tensor`` whose output is the matching
+    row of the receive buffer -- rank r's rays land at [r*n_pad, r*n_pad + n_r), which is global ray
+    order, so there is no send-side packing and no reassembly afterwards (7 collectives of
+    8 B x n_pad per rank for an isotropic bundle, issued back to back on one stream).  The inputs
+    are views of the trace's own output arrays; a row whose storage ends before the common stride
+    (the last rank's last row in a tight layout) goes through a small padded staging row instead.
+    ``finish()`` returns (x (3,N), k (3,N), valid (N,)) views in global ray order.
 
     Crystals (SURVEY.md 8e "Anisotropic"): every anisotropic interface doubles the rays inside
     the shard, so a rank holds ``branches`` * n_local image points laid out [branch][local ray]
     (the engine's dense doubling order, = the reference's hstack of the two solutions applied
-    once per crystal).  Concatenating shards would give [rank][branch][ray]; ``finish()``
-    returns [branch][global ray] instead -- exactly the arrays a single-GPU trace of the whole
-    bundle produces -- and ``ray_id()`` / ``branch()`` give the join keys (rayID = global index
-    of the initial ray).  ``with_fields`` adds the E vectors (re, im) to the exchange.
+    once per crystal).  ``finish()`` returns [branch][global ray] -- exactly the arrays a
+    single-GPU trace of the whole bundle produces (a view when N is a multiple of the world
+    size, one compacting copy otherwise) -- and ``ray_id()`` / ``branch()`` give the join keys
+    (rayID = global index of the initial ray).  ``with_fields`` adds the E vectors (re, im).
     """
 
     def __init__(self, n_total, device, group=None, stage_on_host=False, branches=1,
-                 with_fields=False):
-        """stage_on_host: exchange through pinned host buffers (for the ``gloo`` backend, which
-        cannot all-gather device tensors; used by the single-GPU dry run of the multi-rank
-        bench path -- the production path is RCCL on device buffers)."""
+                 with_fields=False, world=None, rank=None):
+        """stage_on_host: exchange through host buffers (for the ``gloo`` backend, which cannot
+        all-gather device tensors; used by the single-GPU dry run of the multi-rank bench path --
+        the production path is RCCL on device buffers).  ``world`` / ``rank``: override the process
+        group's (single-process emulation of a sharded run, see ``deposit``)."""
         self.group = group
         self.stage_on_host = stage_on_host
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
         self.n_total = n_total
         self.branches = int(branches)
         self.rows = 12 if with_fields else 6
         self.sizes = shard_sizes(n_total, self.world)
-        self.n_max = max(self.sizes) if self.sizes else 0
+        self.n_pad = shard_stride(n_total, self.world)
         self.device = device
-        bdev = torch.device("cpu") if stage_on_host else device
+        self.bdev = torch.device("cpu") if stage_on_host else device
         (m, r) = (self.branches, self.rows)
-        self.send_f = torch.zeros((r, m, self.n_max), dtype=torch.float64, device=bdev)
-        self.send_v = torch.zeros((m, self.n_max), dtype=torch.uint8, device=bdev)
-        self.recv_f = torch.empty((self.world, r, m, self.n_max), dtype=torch.float64, device=bdev)
-        self.recv_v = torch.empty((self.world, m, self.n_max), dtype=torch.uint8, device=bdev)
+        self.recv_f = torch.zeros((r, m, self.world * self.n_pad), dtype=torch.float64, device=self.bdev)
+        self.recv_v = torch.zeros((m, self.world * self.n_pad), dtype=torch.uint8, device=self.bdev)
+        self._stage = {}          # (row, branch) -> padded staging row, only where a view cannot serve
         self._work = []
 
-    def start(self, x_img, k_img, valid, e_re=None, e_im=None):
+    def _sources(self, x_img, k_img, valid, e_re, e_im, n):
+        """per (row, branch): the n_pad-element input of its collective"""
         m = self.branches
-        n = x_img.shape[1] // m
-        assert n == self.sizes[self.rank] and x_img.shape[1] == m * n, "shard size mismatch"
-        self.send_f[0:3, :, :n].copy_(x_img.view(3, m, n), non_blocking=True)
-        self.send_f[3:6, :, :n].copy_(k_img.view(3, m, n), non_blocking=True)
-        if self.rows == 12:
-            self.send_f[6:9, :, :n].copy_(e_re.view(3, m, n), non_blocking=True)
-            self.send_f[9:12, :, :n].copy_(e_im.view(3, m, n), non_blocking=True)
-        self.send_v[:, :n].copy_(valid.view(m, n), non_blocking=True)
-        if self.stage_on_host and x_img.is_cuda:
-            torch.cuda.current_stream(x_img.device).synchronize()     # D2H staging complete
+        assert x_img.shape[1] == m * n, "shard size mismatch"
+        arrays = [x_img, k_img] + ([e_re, e_im] if self.rows == 12 else [])
+        v2d = valid.reshape(1, -1)
+        out = []
+        for b in range(m):
+            for (row, (t, c)) in enumerate([(t, c) for t in arrays for c in range(3)] + [(v2d, 0)]):
+                src = None if self.stage_on_host else _row_of(t, c, b * n, n, self.n_pad)
+                if src is None:
+                    key = (row, b)
+                    st = self._stage.get(key)
+                    if st is None:
+                        st = self._stage[key] = torch.zeros(self.n_pad, dtype=t.dtype, device=self.bdev)
+                    st[:n].copy_(t[c, b * n:(b + 1) * n], non_blocking=True)
+                    src = st
+                out.append((row, b, src))
+        return out
+
+    def _dest(self, row, b):
+        return self.recv_v[b] if row == self.rows else self.recv_f[row, b]
+
+    def deposit(self, rank, x_img, k_img, valid, e_re=None, e_im=None):
+        """what the collectives do with rank ``rank``'s contribution, as local copies: the
+        single-rank path, and the way one process emulates a sharded run shard by shard"""
+        n = self.sizes[rank]
+        for (row, b, src) in self._sources(x_img, k_img, valid, e_re, e_im, n):
+            self._dest(row, b)[rank * self.n_pad:rank * self.n_pad + n].copy_(src[:n], non_blocking=True)
+
+    def start(self, x_img, k_img, valid, e_re=None, e_im=None):
+        n = self.sizes[self.rank]
         if not _collectives_needed(self.group):
-            self.recv_f[0].copy_(self.send_f, non_blocking=True)
-            self.recv_v[0].copy_(self.send_v, non_blocking=True)
+            self.deposit(self.rank, x_img, k_img, valid, e_re, e_im)
             self._work = []
             return
-        w1 = dist.all_gather_into_tensor(self.recv_f.view(-1), self.send_f.view(-1),
-                                          group=self.group, async_op=True)
-        w2 = dist.all_gather_into_tensor(self.recv_v.view(-1), self.send_v.view(-1),
-                                          group=self.group, async_op=True)
-        self._work = [w1, w2]
+        srcs = self._sources(x_img, k_img, valid, e_re, e_im, n)
+        if self.stage_on_host and x_img.is_cuda:
+            torch.cuda.current_stream(x_img.device).synchronize()     # D2H staging complete
+        self._work = [dist.all_gather_into_tensor(self._dest(row, b), src, group=self.group, async_op=True)
+                      for (row, b, src) in srcs]
 
     def wait(self):
         for w in self._work:
@@ -104,17 +148,12 @@ class ImagePlaneGather(object):
 
     def _gathered(self):
         self.wait()
-        (m, r) = (self.branches, self.rows)
-        if all(s == self.n_max for s in self.sizes):
-            # [rank][row][branch][ray] -> [row][branch][rank][ray] = [row][branch][global ray]
-            f = self.recv_f.permute(1, 2, 0, 3).reshape(r, m * self.world * self.n_max)
-            v = self.recv_v.permute(1, 0, 2).reshape(-1)
-        else:
-            f = torch.cat([self.recv_f[q, :, :, :s] for (q, s) in enumerate(self.sizes)],
-                          dim=2).reshape(r, m * self.n_total)
-            v = torch.cat([self.recv_v[q, :, :s] for (q, s) in enumerate(self.sizes)],
-                          dim=1).reshape(-1)
-        return f, v
+        (m, r, n) = (self.branches, self.rows, self.n_total)
+        f = self.recv_f[:, :, :n]
+        v = self.recv_v[:, :n]
+        if m == 1:
+            return f[:, 0], v[0]                 # (rows, N) view, row pitch world * n_pad
+        return f.reshape(r, m * n), v.reshape(m * n)
 
     def finish(self):
         (f, v) = self._gathered()

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import placed
 from .surface_table import pack_table
 
 
@@ -180,11 +181,19 @@ class DeviceSystem(object):
         return list(n_in), list(n_out)
 
     def alloc_outputs(self, n0, mode=_lib.MODE_PATH, with_valid_out=True, pitch=None, want_fields=False,
-                      packed_flags=False):
+                      packed_flags=False, placement="auto", extra_bytes=()):
         """Output buffers for trace_into.  All-isotropic tables get ROW-PITCHED arrays
         ((S,3,pitch) / (S,pitch), pitch = prt_recommended_pitch(n0) unless given: rows aligned
         to 128-B lines are worth ~35 % HBM write bandwidth); tables with anisotropic media get
-        the concatenated layout (pitch 0)."""
+        the concatenated layout (pitch 0).
+
+        ``placement``: where the memory comes from.  "arena": x_hit and k_out are built from physical
+        HBM slabs of two DIFFERENT kinds (``pyrate_amd.placed``; the march then writes at 7.0 instead
+        of 5.6 TB/s); "torch": the torch allocator (whatever kind it happens to
+        get); "auto" (default): the arena for path-mode outputs of all-isotropic tables from
+        ``placed.PLACED_MIN_BYTES`` on, torch otherwise.  ``extra_bytes``: further buffers to take from
+        the arena in the same request (returned as uint8 tensors in ``bufs["extra"]``; they get a
+        third kind of memory when one is at hand) -- only with arena placement."""
         if packed_flags:
             if not self.all_isotropic:
                 raise ValueError("packed mask flags need an all-isotropic table")
@@ -201,86 +210,42 @@ class DeviceSystem(object):
         else:
             pitch = 0
             (nx, nk, nv, nw) = (3 * sum(n_in), 3 * sum(n_out), sum(n_in), sum(n_out))
-        bufs = dict(
-            x_hit=torch.empty(nx, dtype=torch.float64, device=dev),
-            k_out=torch.empty(nk, dtype=torch.float64, device=dev),
-            valid=torch.empty(nv, dtype=torch.uint8, device=dev),
-            valid_out=(torch.empty(nw, dtype=torch.uint8, device=dev) if with_valid_out else None),
-            n_in=n_in, n_out=n_out, mode=mode, pitch=pitch, packed_flags=bool(packed_flags))
+        if not with_valid_out:
+            nw = 0
+        if placement == "auto":
+            big = 8 * (nx + nk) + nv + nw >= placed.PLACED_MIN_BYTES
+            placement = "arena" if (self.all_isotropic and mode == _lib.MODE_PATH and big) else "torch"
+        if placement not in ("arena", "torch"):
+            raise ValueError("placement must be 'auto', 'arena' or 'torch'")
+        if placement == "arena":
+            # part 0: x_hit, then the mask bytes (each on a 4-KiB boundary); part 1: k_out
+            def up(v):
+                return -(-v // 4096) * 4096
+            (off_v, off_w) = (up(8 * nx), up(up(8 * nx) + nv))
+            arena = placed.PlacedArena.for_device(dev.index)
+            (parts, kinds) = arena.alloc([off_w + nw, 8 * nk] + [int(b) for b in extra_bytes])
+            bufs = dict(
+                x_hit=parts[0][:8 * nx].view(torch.float64),
+                k_out=parts[1][:8 * nk].view(torch.float64),
+                valid=parts[0][off_v:off_v + nv],
+                valid_out=(parts[0][off_w:off_w + nw] if with_valid_out else None),
+                extra=parts[2:], placement={"policy": "arena", "kinds": kinds})
+        else:
+            if extra_bytes:
+                raise ValueError("extra_bytes needs arena placement")
+            bufs = dict(
+                x_hit=torch.empty(nx, dtype=torch.float64, device=dev),
+                k_out=torch.empty(nk, dtype=torch.float64, device=dev),
+                valid=torch.empty(nv, dtype=torch.uint8, device=dev),
+                valid_out=(torch.empty(nw, dtype=torch.uint8, device=dev) if with_valid_out else None),
+                extra=[], placement={"policy": "torch"})
+        bufs.update(n_in=n_in, n_out=n_out, mode=mode, pitch=pitch, packed_flags=bool(packed_flags))
         if want_fields:
             if self.all_isotropic:
                 raise ValueError("E fields are produced at crystal interfaces only")
             bufs["e_re"] = torch.zeros(nk, dtype=torch.float64, device=dev)
             bufs["e_im"] = torch.zeros(nk, dtype=torch.float64, device=dev)
         return bufs
-
-    def alloc_outputs_tuned(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH, packed_flags=False,
-                            candidates=12, iters=3, spread=0.8):
-        """Output buffers for a bundle that will be traced many times into the same arrays (an
-        optimiser loop, a wavelength / field sweep, bench.py), placed by measurement.
-
-        The write bandwidth of the path-mode march is a reproducible property of WHERE x_hit and
-        k_out sit in HBM relative to each other: device memory falls into regions (tens of GB) such
-        that two arrays from the same region are written at ~5.2 TB/s and two arrays from different
-        regions at ~6.4 TB/s (same process, same layout, +-0.5 % per pair; a sequential fill runs at
-        6.7 TB/s everywhere -- DESIGN.md section 5 "placement").  The regions are not visible in
-        the virtual addresses, so the pair is found by timing: a pool of ``candidates`` arrays is
-        allocated, k_out is chosen against the first array as x_hit, then x_hit against that k_out
-        (about 3 * candidates short measurements), and the rest of the pool is released.
-
-        Returns (bufs, report) with report = {"first_pair_ms", "best_pair_ms", "k_scan_ms", "x_scan_ms",
-        "k_rescan_ms"}."""
-        n0 = x0.shape[1]
-        first = self.alloc_outputs(n0, mode, packed_flags=packed_flags)
-        m = max(2, int(candidates))
-        if not self.all_isotropic or mode != _lib.MODE_PATH:
-            ms = self.trace_timed(x0, k0, first, iters, e0_re, e0_im)
-            return first, {"first_pair_ms": ms, "best_pair_ms": ms, "k_scan_ms": [], "x_scan_ms": [],
-                           "k_rescan_ms": []}
-        words = first["x_hit"].numel()
-        pool = [first["x_hit"], first["k_out"]]
-        # the candidates are spread over the free HBM (untouched spacer allocations in between, at
-        # most ``spread`` of what is free): arrays that behave differently come from different
-        # parts of the memory, a run of consecutive allocations is often all of one kind
-        (free_b, _) = torch.cuda.mem_get_info(self.device)
-        m = min(m, 2 + int(0.8 * free_b // (words * 8)))      # bundles that nearly fill the HBM: fewer candidates
-        room = spread * free_b - (m - 2) * words * 8
-        gap = int(max(0, min(24e9, room / max(1, m - 2))))
-        spacers = []
-        try:
-            for _ in range(m - 2):
-                if gap >= (1 << 26):
-                    spacers.append(torch.empty(gap, dtype=torch.uint8, device=self.device))
-                pool.append(torch.empty(words, dtype=torch.float64, device=self.device))
-        except torch.cuda.OutOfMemoryError:
-            pass                              # somebody else took the memory meanwhile: a smaller pool
-        del spacers
-        m = len(pool)
-
-        def timed(i, j):
-            b = dict(first, x_hit=pool[i], k_out=pool[j])
-            self.trace_timed(x0, k0, b, 1, e0_re, e0_im)
-            return self.trace_timed(x0, k0, b, iters, e0_re, e0_im)
-
-        k_scan = [timed(0, j) for j in range(1, m)]
-        jb = 1 + min(range(m - 1), key=lambda q: k_scan[q])
-        xs = [i for i in range(m) if i != jb]
-        x_scan = [k_scan[jb - 1] if i == 0 else timed(i, jb) for i in xs]
-        ib = xs[min(range(len(xs)), key=lambda q: x_scan[q])]
-        best = min(x_scan)
-        # one more pass over k_out against the chosen x_hit (the first pass ran against array 0)
-        k_rescan = []
-        if ib != 0:
-            js = [j for j in range(m) if j != ib and j != jb]
-            k_rescan = [timed(ib, j) for j in js]
-            q = min(range(len(js)), key=lambda t: k_rescan[t]) if js else None
-            if q is not None and k_rescan[q] < 0.997 * best:
-                (jb, best) = (js[q], k_rescan[q])
-        bufs = dict(first, x_hit=pool[ib], k_out=pool[jb])
-        del pool
-        torch.cuda.empty_cache()          # hand the unused candidates and spacers back to the driver
-        return bufs, {"first_pair_ms": k_scan[0], "best_pair_ms": best, "k_scan_ms": k_scan,
-                      "x_scan_ms": x_scan, "k_rescan_ms": k_rescan}
 
     # -- whole sequence ----------------------------------------------------
     def trace_into(self, x0, k0, bufs, e0_re=None, e0_im=None):

@@ -1,0 +1,173 @@
+"""Placement-aware device memory for the path arrays: host side of ``prt_arena_*`` (include/prt.h).
+
+The HBM of an MI355X consists of three kinds of physical memory; the path-mode march writes at
+7.0 TB/s when ``x_hit`` and ``k_out`` lie in two different kinds and at 5.6-5.7 TB/s when they share
+one (DESIGN.md section 5 "Placement"; ``benchmarks/vmm_placement_probe.hip``).  ``hipMalloc`` / the torch
+allocator give no control over that, so the engine takes the memory for large path arrays from a
+``PlacedArena``, which builds every buffer from 1-GiB physical slabs of one known kind.
+
+The buffers are handed out as ordinary torch tensors (zero copy) that own their arena buffer: when the
+last view dies the buffer goes back to the arena, which keeps it mapped for the next trace of that size.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+from . import _lib
+
+SLAB_BYTES = 1 << 30
+# below this many output bytes a trace keeps using the torch allocator: small path arrays live in the
+# L2 / Infinity Cache for most of the march, and a 1-GiB slab per array would be mostly padding
+PLACED_MIN_BYTES = int(os.environ.get("PRT_PLACED_MIN_BYTES", 768 << 20))
+
+
+class _Block(object):
+    """One arena buffer; exposes ``__cuda_array_interface__`` so that torch can wrap it without a copy
+    and keeps a reference to this object for as long as any tensor uses the memory."""
+
+    def __init__(self, arena, ptr, nbytes, kind):
+        self.arena = arena
+        self.ptr = ptr
+        self.nbytes = nbytes
+        self.kind = kind
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2,
+                "strides": None}
+
+    def __del__(self):
+        try:
+            self.arena._release(self.ptr)
+        except Exception:           # interpreter shutdown: the process takes the memory with it
+            pass
+
+
+# ---- DLPack route (used if torch cannot adopt the pointer through __cuda_array_interface__) --------
+class _DLDevice(ctypes.Structure):
+    _fields_ = [("device_type", ctypes.c_int), ("device_id", ctypes.c_int)]
+
+
+class _DLDataType(ctypes.Structure):
+    _fields_ = [("code", ctypes.c_uint8), ("bits", ctypes.c_uint8), ("lanes", ctypes.c_uint16)]
+
+
+class _DLTensor(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("device", _DLDevice), ("ndim", ctypes.c_int),
+                ("dtype", _DLDataType), ("shape", ctypes.POINTER(ctypes.c_int64)),
+                ("strides", ctypes.POINTER(ctypes.c_int64)), ("byte_offset", ctypes.c_uint64)]
+
+
+class _DLManagedTensor(ctypes.Structure):
+    pass
+
+
+_DLDeleter = ctypes.CFUNCTYPE(None, ctypes.POINTER(_DLManagedTensor))
+_DLManagedTensor._fields_ = [("dl_tensor", _DLTensor), ("manager_ctx", ctypes.c_void_p),
+                             ("deleter", _DLDeleter)]
+_KDLROCM = 10
+_dl_alive = {}            # address of the managed tensor -> (managed tensor, shape array, block)
+_dl_lock = threading.Lock()
+
+
+@_DLDeleter
+def _dl_delete(mt_ptr):
+    with _dl_lock:
+        _dl_alive.pop(ctypes.addressof(mt_ptr.contents), None)
+
+
+def _dlpack_tensor(block, device_index):
+    shape = (ctypes.c_int64 * 1)(block.nbytes)
+    mt = _DLManagedTensor()
+    mt.dl_tensor.data = block.ptr
+    mt.dl_tensor.device = _DLDevice(_KDLROCM, device_index)
+    mt.dl_tensor.ndim = 1
+    mt.dl_tensor.dtype = _DLDataType(1, 8, 1)           # kDLUInt, 8 bits
+    mt.dl_tensor.shape = shape
+    mt.dl_tensor.strides = None
+    mt.dl_tensor.byte_offset = 0
+    mt.manager_ctx = None
+    mt.deleter = _dl_delete
+    with _dl_lock:
+        _dl_alive[ctypes.addressof(mt)] = (mt, shape, block)
+    new_capsule = ctypes.pythonapi.PyCapsule_New
+    new_capsule.restype = ctypes.py_object
+    new_capsule.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p]
+    capsule = new_capsule(ctypes.addressof(mt), b"dltensor", None)
+    return torch.utils.dlpack.from_dlpack(capsule)
+
+
+class PlacedArena(object):
+    """``prt_arena_t`` of one device (one per process and device: ``PlacedArena.for_device``)."""
+
+    _instances = {}
+    _instances_lock = threading.Lock()
+
+    def __init__(self, device_index):
+        self.lib = _lib.load()
+        self.device_index = int(device_index)
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.prt_arena_create(self.device_index, ctypes.byref(handle)))
+        self._h = handle
+        self._wrap = os.environ.get("PRT_PLACED_WRAP", "")       # "", "cai" or "dlpack"
+
+    @classmethod
+    def for_device(cls, device_index):
+        with cls._instances_lock:
+            arena = cls._instances.get(device_index)
+            if arena is None:
+                arena = cls._instances[device_index] = cls(device_index)
+            return arena
+
+    def _release(self, ptr):
+        if self._h:
+            self.lib.prt_arena_free(self._h, ctypes.c_void_p(ptr))
+
+    def _tensor(self, block):
+        dev = torch.device("cuda", self.device_index)
+        if self._wrap in ("", "cai"):
+            try:
+                t = torch.as_tensor(block, device=dev)
+                if t.data_ptr() == block.ptr and t.device == dev:
+                    self._wrap = "cai"
+                    return t
+            except Exception:
+                if self._wrap == "cai":
+                    raise
+        self._wrap = "dlpack"
+        return _dlpack_tensor(block, self.device_index)
+
+    def alloc(self, sizes, max_hunt_slabs=-1):
+        """Buffers of ``sizes`` bytes as uint8 tensors, plus their kind indices.  The first two land in
+        two different kinds of memory whenever the device has two to offer."""
+        n = len(sizes)
+        c_sizes = (ctypes.c_int64 * n)(*[int(s) for s in sizes])
+        ptrs = (ctypes.c_void_p * n)()
+        kinds = (ctypes.c_int32 * n)()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)
+        _lib.check(self.lib.prt_arena_alloc(self._h, n, c_sizes, ptrs, kinds, int(max_hunt_slabs), stream))
+        out = []
+        for i in range(n):
+            rounded = -(-int(sizes[i]) // SLAB_BYTES) * SLAB_BYTES
+            block = _Block(self, ptrs[i], rounded, int(kinds[i]))
+            out.append(self._tensor(block))
+        return out, [int(k) for k in kinds]
+
+    def kind_of(self, tensor):
+        kind = ctypes.c_int32(-1)
+        rc = self.lib.prt_arena_kind_of(self._h, ctypes.c_void_p(tensor.data_ptr()), ctypes.byref(kind))
+        return int(kind.value) if rc == 0 else None
+
+    def trim(self):
+        _lib.check(self.lib.prt_arena_trim(self._h))
+
+    def stats(self):
+        v = (ctypes.c_int64 * 12)()
+        r = (ctypes.c_double * 3)()
+        _lib.check(self.lib.prt_arena_stats(self._h, v, 12, r, 3))
+        return {"kinds_seen": v[0], "probes": v[1], "slabs_created": v[2], "slabs_released": v[3],
+                "slabs_free": v[4], "slabs_in_use": v[5], "slabs_cached": v[6], "slab_bytes": v[7],
+                "slabs_per_kind": [v[8], v[9], v[10], v[11]], "probe_same_kind_GBps": r[0],
+                "probe_cross_kind_GBps": r[1], "probe_ms_total": r[2], "tensor_wrap": self._wrap}

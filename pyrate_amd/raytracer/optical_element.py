@@ -54,27 +54,41 @@ class OpticalElement(LocalCoordinatesTreeBase):
         """material after refraction, by identity comparison (:109-126)"""
         return mat2 if (mat1 is current_mat) else mat1
 
+    def _trace_plan(self, sequence, background_medium):
+        """Resolve a surface sequence into trace steps before any ray is touched: for every
+        entry the surface, the medium the rays travel in on their way to it, the medium that
+        deflects them there and whether the deflection is a refraction.  A mirror leaves the
+        rays in the medium they came in; a refracting surface hands them to whichever of its
+        two media they are not in (identity comparison, like the reference)."""
+        plan = []
+        medium = background_medium
+        for (surfkey, options) in sequence:
+            surface = self.surfaces[surfkey]
+            refracts = not options.get("is_mirror", False)
+            arriving_in = medium
+            if refracts:
+                sides = [self.materials.get(key, background_medium)
+                         for key in self.annotations["surf_mat_connection"][surfkey]]
+                medium = self.findoutWhichMaterial(sides[0], sides[1], medium)
+            plan.append((surface, arriving_in, medium, refracts))
+        return plan
+
     def seqtrace(self, raybundle, sequence, background_medium, splitup=False):
-        current_material = background_medium
-        rpaths = [RayPath(raybundle)]
-        for (surfkey, surfoptions) in sequence:
-            refract_flag = not surfoptions.get("is_mirror", False)
-            rpaths_new = []
-            current_surface = self.surfaces[surfkey]
-            (mnmat, pnmat) = self.annotations["surf_mat_connection"][surfkey]
-            mnmat = self.materials.get(mnmat, background_medium)
-            pnmat = self.materials.get(pnmat, background_medium)
-            for rp in rpaths:
-                current_material.propagate(rp.raybundles[-1], current_surface)
-            if refract_flag:
-                current_material = self.findoutWhichMaterial(mnmat, pnmat, current_material)
-            deflect = current_material.refract if refract_flag else current_material.reflect
-            for rp in rpaths:
-                raybundles = deflect(rp.raybundles[-1], current_surface, splitup=splitup)
-                for rb in raybundles[1:]:
-                    rpathprime = rp.clone()
-                    rpathprime.appendRayBundle(rb)
-                    rpaths_new.append(rpathprime)
-                rp.appendRayBundle(raybundles[0])
-            rpaths = rpaths + rpaths_new
-        return rpaths
+        """Plugin-granular trace of one element: per step one propagate and one refract / reflect
+        call on every open ray path; a deflection that returns several bundles (``splitup`` at a
+        crystal interface) forks the path, forks are appended behind the existing paths."""
+        paths = [RayPath(raybundle)]
+        for (surface, arriving_in, deflecting, refracts) in self._trace_plan(sequence, background_medium):
+            forks = []
+            for path in paths:
+                head = path.raybundles[-1]
+                arriving_in.propagate(head, surface)
+                deflect = deflecting.refract if refracts else deflecting.reflect
+                (first, *others) = deflect(head, surface, splitup=splitup)
+                for bundle in others:
+                    fork = path.clone()
+                    fork.appendRayBundle(bundle)
+                    forks.append(fork)
+                path.appendRayBundle(first)
+            paths.extend(forks)
+        return paths

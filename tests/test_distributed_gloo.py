@@ -20,7 +20,11 @@ def test_shard_ranges_partition_the_bundle():
             for (a, b) in zip(spans[:-1], spans[1:]):
                 assert a[1] == b[0]
             sizes = [hi - lo for (lo, hi) in spans]
-            assert max(sizes) - min(sizes) <= 1
+            # equal stride: rank r starts at r * n_pad (clamped), so a gathered row is in global order
+            n_pad = pdist.shard_stride(n, world)
+            assert world * n_pad - n < world
+            assert all(lo == min(r * n_pad, n) for (r, (lo, _)) in enumerate(spans))
+            assert sizes == [max(0, min(n_pad, n - r * n_pad)) for r in range(world)]
             assert sizes == pdist.shard_sizes(n, world)
 
 

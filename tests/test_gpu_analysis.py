@@ -360,21 +360,3 @@ def test_raytrace_prism_like_the_reference_demo(gpu_device, tag, wave):
     assert np.allclose(rp.raybundles[0].x[0], case.x0, rtol=0, atol=1e-14)
     assert np.allclose(np.real(rp.raybundles[0].k[0]), np.real(case.k0), rtol=0, atol=1e-15)
     assert_paths_match(rp, case.raw_bundles)
-
-
-def test_shape_analysis_sag_tables(gpu_device, tmp_path):
-    """ShapeAnalysis (surface_shape_analysis.py:33-85): sag tables of a conic == its closed form;
-    save / load / compare round trip"""
-    from pyrate_amd.raytracer.analysis.surface_shape_analysis import ShapeAnalysis
-    api = zoo.mirror_api()
-    (c, cc) = (1. / 35., -0.7)
-    sa = ShapeAnalysis(api.Conic.p(api.LocalCoordinates.p(name="sa"), curv=c, cc=cc))
-    (xl, yl) = (np.linspace(-5, 5, 11), np.linspace(-4, 4, 9))
-    (X, Y, Z) = sa.generate_sag_matrices(xl, yl)
-    r2 = X ** 2 + Y ** 2
-    assert X.shape == (9, 11) and np.allclose(Z, c * r2 / (1 + np.sqrt(1 - (1 + cc) * c * c * r2)), rtol=0, atol=1e-15)
-    table = sa.generate_sag_table(xl, yl)
-    assert table.shape == (3, 99)
-    f = str(tmp_path / "sag.txt")
-    sa.save_sag_table(f, xl, yl)
-    assert np.abs(sa.compare_with_sag_table(sa.load_sag_table(f))).max() < 1e-15

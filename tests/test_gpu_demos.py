@@ -97,7 +97,7 @@ def test_bench_contract_line(gpu_device):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rays", "300000", "--steps", "4",
-                          "--warmup", "2", "--placement-candidates", "3"],
+                          "--warmup", "2"],
                          capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     line = out.stdout.strip().splitlines()[-1]

@@ -156,7 +156,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(_lib.PROTOTYPES.keys())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.prt_abi_version() == 3
+    assert lib.prt_abi_version() == _lib.ABI_VERSION == 4
     assert lib.prt_sizeof_surface() == ctypes.sizeof(st.PrtSurface)
     assert lib.prt_strerror(-2) == b"unsupported shape/material"
     # argument validation happens before any device work
@@ -164,6 +164,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert lib.prt_trace(None, 0, 0, None, None, None, None, 0, 0, None, None, None, None, None) == -1
     assert lib.prt_recommended_pitch(9994476) == 9994752 and lib.prt_recommended_pitch(512) == 512
     assert lib.prt_compact_scratch_bytes(0) > 0
+    assert lib.prt_arena_alloc(None, 0, None, None, None, -1, None) == -1 and lib.prt_arena_free(None, None) == -1
 
 
 def test_localcoordinates_roundtrips(api):
