@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""A/B of libprt builds in ONE process on the SAME arrays (scratch/variants/libprt_<name>.so, built with
+extra -D flags), path mode and image mode of the double Gauss march.  The path arrays come from the
+placement-aware arena (x_hit and k_out in two different kinds of HBM): the regime the product runs in.
+
+    python benchmarks/ab_variants.py [torch]      # "torch": arrays from the torch allocator instead
+"""
+import ctypes
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+
+from pyrate_amd import engine, systems, _lib
+
+dev = torch.device("cuda", 0)
+sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
+(x0, k0, e0d, n) = systems.double_gauss_bundle_device(10000000, dev)
+placement = "torch" if len(sys.argv) > 1 and sys.argv[1] == "torch" else "arena"
+bufs = sysd.alloc_outputs(n, packed_flags=True, placement=placement)
+img = sysd.alloc_outputs(n, _lib.MODE_IMAGE, packed_flags=True)
+libs = {"in-tree": (sysd.lib, sysd._h)}
+for path in sorted(glob.glob(os.path.join(ROOT, "scratch", "variants", "libprt_*.so"))):
+    lib = ctypes.CDLL(os.path.abspath(path))
+    for name in ("prt_system_create", "prt_trace_timed", "prt_system_destroy"):
+        (res, args) = _lib.PROTOTYPES[name]
+        getattr(lib, name).restype = res
+        getattr(lib, name).argtypes = args
+    h = ctypes.c_void_p()
+    assert lib.prt_system_create(sysd._table, sysd.n_surfaces, 0, ctypes.byref(h)) == 0
+    libs[os.path.basename(path)[7:-3]] = (lib, h)
+st = engine._stream_handle(dev)
+P = engine._ptr
+
+
+def timed(lib, h, b, iters):
+    ms = ctypes.c_double()
+    rc = lib.prt_trace_timed(h, n, sysd._in_pitch(x0, k0, e0d, None), P(x0), P(k0), P(e0d), None,
+                             engine._mode_word(b), b["pitch"], P(b["x_hit"]), P(b["k_out"]), P(b["valid"]),
+                             None, st, iters, ctypes.byref(ms))
+    assert rc == 0, rc
+    return ms.value
+
+
+timed(*libs["in-tree"], bufs, 40)
+out = {"placement": bufs["placement"], "path_ms": {k: [] for k in libs}, "image_ms": {k: [] for k in libs}}
+for rep in range(4):
+    for (tag, b, it) in (("path_ms", bufs, 20), ("image_ms", img, 30)):
+        for (name, (lib, h)) in libs.items():
+            timed(lib, h, b, 2)
+            out[tag][name].append(round(timed(lib, h, b, it), 4))
+print(json.dumps(out))

@@ -53,6 +53,17 @@ __global__ __launch_bounds__(128) void k_read(Rows rows, int nrows, int64_t n, d
     if (acc.x + acc.y == 12345.678) sink[0] = acc.x;
 }
 
+// the traffic of the path-mode march without its arithmetic: every lane loads 16 B from each of the
+// `nin` input rows (x0, k0, E0: 9 rows), then stores 16 B to each of the 72 output rows
+struct InRows { const double* p[9]; };
+__global__ __launch_bounds__(128) void k_march_traffic(InRows in, int nin, Rows rows, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 128 + threadIdx.x) * 2;
+    if (i >= n) return;
+    d2 val = {0.0, 0.0};
+    for (int r = 0; r < nin; ++r) val += *(const d2*)(in.p[r] + i);
+    for (int r = 0; r < MAXROWS; ++r) { *(d2*)(rows.p[r] + i) = val; val += 1.0; }
+}
+
 // rows [0, nrows/2) are read, rows [nrows/2, nrows) written (36 load + 36 store streams)
 __global__ __launch_bounds__(128) void k_copy(Rows rows, int nrows, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * 128 + threadIdx.x) * 2;
@@ -286,12 +297,41 @@ int main(int argc, char** argv) {
     }
     fflush(stdout);
 
+    // E6: the march's traffic mix (9 load streams = 11 % of the bytes + 72 store streams), no arithmetic:
+    // the structural floor of k_trace_iso's path mode, by where the inputs live
+    {
+        const dim3 grid((unsigned)((L / 2 + 127) / 128));
+        // a chunk of a third kind: fast with both A and its fast partner
+        int64_t cThird = -1;
+        for (int b = 1; b < m && cThird < 0; ++b)
+            if (S[b] != cFast && S[b] != cSlow && M[b] < 0.9 * M[worstb] && M[(size_t)bestb * m + b] < 0.9 * M[worstb])
+                cThird = S[b];
+        struct { const char* name; int64_t out_a, out_b, in_c; } cases6[] = {
+            {"outputs same kind, inputs in that kind   ", cA, cSlow, cSlow + 1 < nch ? cSlow + 1 : cSlow},
+            {"outputs two kinds, inputs with x_hit     ", cA, cFast, cA + 1},
+            {"outputs two kinds, inputs in a third kind", cA, cFast, cThird}};
+        for (auto& q : cases6) {
+            if (q.in_c < 0) { printf("E6 %s: no third kind among the sampled chunks\n", q.name); continue; }
+            Rows r = pair_rows(q.out_a, q.out_b);
+            InRows in;
+            for (int k = 0; k < 9; ++k) in.p[k] = chunk(q.in_c) + (int64_t)k * L;      // (9 rows fit: 36 per chunk)
+            float t0 = time_launch([&] { hipLaunchKernelGGL(k_march_traffic, grid, dim3(128), 0, 0, in, 0, r, L); }, 2, 5);
+            float t9 = time_launch([&] { hipLaunchKernelGGL(k_march_traffic, grid, dim3(128), 0, 0, in, 9, r, L); }, 2, 5);
+            printf("E6 %s (out %lld|%lld, in %lld): stores only %.3f TB/s; 9 load + 72 store streams %.3f TB/s (%.4f ms)\n",
+                   q.name, (long long)q.out_a, (long long)q.out_b, (long long)q.in_c, gb / t0,
+                   (72.0 + 9.0) * L * 8 / 1e9 / t9, t9);
+        }
+    }
+    fflush(stdout);
+
     // E4: arrays striped over two kinds in 2-MiB pieces.  One chunk of each kind is given back to the
-    // driver and taken again as 512 handles of 2 MiB.  Every piece is mapped twice: at an address of its own
-    // (where it is tagged) and inside one of two virtual chunks -- layout 0: each virtual chunk is rebuilt
-    // from the pieces of its own source; layout 1: pieces alternate between the two sources, so both
-    // virtual chunks are half/half mixes.  The tags read back through the virtual chunks prove what is
-    // mapped where; the pieces' kinds are checked against the reference chunks.
+    // driver and taken again as 512 handles of 2 MiB.  Every piece is mapped at an address of its own
+    // (where it is tagged) and inside a "virtual chunk" -- layout 0: each virtual chunk is built from the
+    // pieces of its own source; layout 1: pieces alternate between the two sources, so both virtual
+    // chunks are half/half mixes.  The tags read back through the virtual chunks prove what is mapped
+    // where.  `fresh` = every layout gets newly reserved addresses; `reused` = layout 1 is mapped over
+    // the addresses layout 0 had (after hipMemUnmap) -- the case in which this ROCm stack keeps
+    // translating to the OLD pages.
     {
         const size_t PIECE = (size_t)2 << 20; const int NP = (int)(CH / PIECE);
         int64_t src[2] = {cA + 1 < nch ? cA + 1 : cA, cFast};
@@ -307,42 +347,52 @@ int main(int argc, char** argv) {
             for (int k = 0; k < NP; ++k) CHECK(hipMemMap((char*)own_va[s] + (size_t)k * PIECE, PIECE, 0, pieces[s][k], 0));
             CHECK(hipMemSetAccess(own_va[s], CH, &acc, 1));
         }
-        for (int layout = 0; layout < 2; ++layout) {
+        void* vc[2] = {nullptr, nullptr};      // the two virtual chunks
+        struct { const char* name; int layout; bool fresh; } runs[] = {
+            {"layout 0 (own pieces), fresh addresses", 0, true},
+            {"layout 1 (alternating pieces), fresh addresses", 1, true},
+            {"layout 0 (own pieces), fresh addresses", 0, true},
+            {"layout 1 (alternating pieces), mapped over the addresses of the run before (after hipMemUnmap)", 1, false}};
+        for (auto& run : runs) {
             for (int s = 0; s < 2; ++s) {
+                if (vc[s]) CHECK(hipMemUnmap(vc[s], CH));
+                if (run.fresh) CHECK(hipMemAddressReserve(&vc[s], CH, PIECE, nullptr, 0));      // old range: left alone
                 for (int k = 0; k < NP; ++k) {
-                    const int from = layout == 0 ? s : (k + s) % 2;
-                    CHECK(hipMemMap((char*)va + src[s] * CH + (size_t)k * PIECE, PIECE, 0, pieces[from][k], 0));
+                    const int from = run.layout == 0 ? s : (k + s) % 2;
+                    CHECK(hipMemMap((char*)vc[s] + (size_t)k * PIECE, PIECE, 0, pieces[from][k], 0));
                 }
-                CHECK(hipMemSetAccess((char*)va + src[s] * CH, CH, &acc, 1));
+                CHECK(hipMemSetAccess(vc[s], CH, &acc, 1));
             }
-            for (int s = 0; s < 2; ++s) hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, chunk(src[s]), (int64_t)(CH / 8), 0.0);
-            // tag through the pieces' own addresses, read through the virtual chunks
+            double* c0 = (double*)vc[0]; double* c1 = (double*)vc[1];
+            for (int s = 0; s < 2; ++s) hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, (double*)vc[s], (int64_t)(CH / 8), 0.0);
             for (int s = 0; s < 2; ++s)
                 for (int k = 0; k < 4; ++k)
-                    hipLaunchKernelGGL(k_tag, dim3(1), dim3(1), 0, 0, (double*)((char*)own_va[s] + (size_t)k * PIECE), 100.0 * s + k);
+                    hipLaunchKernelGGL(k_tag, dim3(1), dim3(1), 0, 0, (double*)((char*)own_va[s] + (size_t)k * PIECE), 100.0 * s + k + 1000.0);
             for (int s = 0; s < 2; ++s)
                 for (int k = 0; k < 4; ++k)
-                    hipLaunchKernelGGL(k_peek, dim3(1), dim3(1), 0, 0, (const double*)((char*)va + src[s] * CH + (size_t)k * PIECE), peek, 4 * s + k);
+                    hipLaunchKernelGGL(k_peek, dim3(1), dim3(1), 0, 0, (const double*)((char*)vc[s] + (size_t)k * PIECE), peek, 4 * s + k);
             double hp[8]; CHECK(hipMemcpy(hp, peek, sizeof hp, hipMemcpyDeviceToHost));
-            printf("E4 layout %s\n   tags (100*source + piece) seen in the first 4 pieces of virtual chunk %lld: %g %g %g %g   of %lld: %g %g %g %g\n",
-                   layout == 0 ? "0: own pieces" : "1: pieces alternate between the two sources",
-                   (long long)src[0], hp[0], hp[1], hp[2], hp[3], (long long)src[1], hp[4], hp[5], hp[6], hp[7]);
-            float t = time_rows(pair_rows(src[0], src[1]), 72, L, 2, 5);
-            printf("   pair (%lld,%lld): %.3f TB/s\n", (long long)src[0], (long long)src[1], gb / t);
+            printf("E4 %s\n   tags (1000 + 100*source + piece) seen in the first 4 pieces of virtual chunk 0: %g %g %g %g   of 1: %g %g %g %g\n",
+                   run.name, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], hp[6], hp[7]);
+            auto two = [&](double* lo, double* hi) {
+                Rows r;
+                for (int k = 0; k < 36; ++k) r.p[k] = lo + (int64_t)k * L;
+                for (int k = 0; k < 36; ++k) r.p[36 + k] = hi + (int64_t)k * L;
+                return r;
+            };
+            printf("   virtual chunk 0 | virtual chunk 1: %.3f TB/s\n", gb / time_rows(two(c0, c1), 72, L, 2, 5));
             for (int s = 0; s < 2; ++s)
                 for (int r = 0; r < 4; ++r) {
                     if (refs[r] == src[0] || refs[r] == src[1]) continue;
-                    float t2 = time_rows(pair_rows(refs[r], src[s]), 72, L, 2, 5);
-                    printf("   virtual chunk %lld vs reference chunk %lld: %.3f TB/s\n", (long long)src[s], (long long)refs[r], gb / t2);
+                    printf("   reference chunk %lld | virtual chunk %d: %.3f TB/s\n", (long long)refs[r], s,
+                           gb / time_rows(two(chunk(refs[r]), (double*)vc[s]), 72, L, 2, 5));
                 }
             {
                 Rows r; const int64_t L2 = L / 2 / 512 * 512;
-                for (int k = 0; k < 72; ++k) r.p[k] = chunk(src[0]) + (int64_t)k * L2;
-                float t3 = time_rows(r, 72, L2, 2, 5);
-                printf("   all 72 rows inside virtual chunk %lld: %.3f TB/s\n", (long long)src[0], 72.0 * L2 * 8 / 1e9 / t3);
+                for (int k = 0; k < 72; ++k) r.p[k] = c0 + (int64_t)k * L2;
+                printf("   all 72 rows inside virtual chunk 0: %.3f TB/s\n", 72.0 * L2 * 8 / 1e9 / time_rows(r, 72, L2, 2, 5));
             }
             CHECK(hipDeviceSynchronize());
-            for (int s = 0; s < 2; ++s) CHECK(hipMemUnmap((char*)va + src[s] * CH, CH));
         }
     }
     printf("done\n");

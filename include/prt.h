@@ -83,9 +83,10 @@ enum { PRT_ANISO_GENERAL = 0, PRT_ANISO_ISOTROPIC = 1, PRT_ANISO_UNIAXIAL = 2 };
 #define PRT_MODE_PATH 0  /* write hit point / outgoing k / valid at every surface */
 #define PRT_MODE_IMAGE 1 /* write only the last surface's                          */
 /* OR-ed into the mode of prt_trace / prt_trace_timed / prt_trace_moments (all-isotropic tables):
- * the two masks of a ray-surface record share one byte, valid[i] = (valid after intersect +
- * aperture) | (valid after the interaction) << 1, and valid_out is not written (may be NULL):
- * 49 instead of 50 bytes and one store stream less per surface */
+ * the masks of a ray-surface record share one byte, valid[i] = (valid after intersect +
+ * aperture) | (valid after the interaction) << 1 | (Newton iteration cap hit, see nonconv) << 2,
+ * and valid_out is not written (may be NULL): 49 instead of 50 bytes and one store stream less
+ * per surface */
 #define PRT_MODE_FLAGS 2
 
 /*
@@ -133,7 +134,10 @@ typedef struct prt_surface {
     const double *aux;
 } prt_surface_t;
 
-typedef struct prt_system prt_system_t; /* opaque: device copy of a surface table */
+/* opaque: a surface table on the device.  prt_system_create repacks the records: what the kernels
+ * read is 504 bytes per surface (the coefficient arrays above become pointers into one side array
+ * holding only the entries in use; csrc/prt_device.h prt_dev_surface). */
+typedef struct prt_system prt_system_t;
 
 /* ---- library / device ----------------------------------------------- */
 int32_t prt_abi_version(void);
@@ -168,6 +172,13 @@ int32_t prt_system_ray_counts(const prt_system_t *sys, int64_t n0, int64_t *n_in
  *                 k_out = concat_s (3,n_out[s]), valid_out = concat_s (n_out[s]).
  *   mode IMAGE:   the same four arrays for the last surface only.
  *   valid_out may be NULL.
+ *   nonconv (may be NULL; layout of valid): 1 where the Newton iteration of an explicit shape
+ *   (Asphere, Biconic, XYPolynomials, ...) ended at its iteration cap instead of converging, 0
+ *   elsewhere.  The reference has no such mask -- ExplicitShape.intersect reports valid = True for
+ *   every ray, converged or not (surface_shape.py:462) -- and `valid` stays reference-compatible: a
+ *   capped ray keeps valid = 1, gets a NaN hit point and is dropped by the next refraction.  nonconv is
+ *   what lets a caller tell such a ray from one that left the domain of the shape.
+ *   With PRT_MODE_FLAGS the same bit is also bit 2 of the flags byte (no extra array needed).
  *   valid is the reference's cumulative mask after intersect + aperture
  *   (ray.py:100, surface.py:135); valid_out additionally ANDs the refraction
  *   checks (material_isotropic.py:183) -- it is what [:, valid] compaction uses.
@@ -177,7 +188,7 @@ int64_t prt_recommended_pitch(int64_t n); /* n rounded up to 512 elements (4 KiB
 int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
                   const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
                   int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
-                  uint8_t *valid_out, void *stream);
+                  uint8_t *valid_out, uint8_t *nonconv, void *stream);
 
 /*
  * prt_trace for all-isotropic tables that also reduces the image-plane moments of the traced
@@ -212,12 +223,13 @@ int32_t prt_trace_fields(const prt_system_t *sys, int64_t n0, const double *x0, 
  * Material.propagate(raybundle, surface): intersect + aperture for one surface.
  *   x, k (3,n); dir (3,n) unit ray directions or NULL (then e_re/e_im as in
  *   prt_trace, or k/|k| if e_re is NULL and use_default_e == 0).
- *   valid_in (n) or NULL (= all valid).  Writes x_hit (3,n), valid (n).
+ *   valid_in (n) or NULL (= all valid).  Writes x_hit (3,n), valid (n) and, if nonconv is
+ *   not NULL, nonconv (n) as described at prt_trace.
  */
 int32_t prt_propagate(const prt_system_t *sys, int32_t surface, int64_t n, const double *x,
                       const double *k, const double *dir, const double *e_re, const double *e_im,
                       int32_t use_default_e, const uint8_t *valid_in, double *x_hit,
-                      uint8_t *valid, void *stream);
+                      uint8_t *valid, uint8_t *nonconv, void *stream);
 
 /*
  * Material.refract / reflect at one surface (which one: table[surface].interaction).
@@ -262,6 +274,40 @@ int32_t prt_rect_grid_count(int32_t device, int64_t nray, int64_t *n_per_dim, in
 int32_t prt_collimated_bundle(int32_t device, int64_t nray, int64_t lo, int64_t hi,
                               const prt_collimated_t *prm, int64_t pitch, double *x_out,
                               double *k_out, double *e_out, void *stream);
+
+/*
+ * The other deterministic pupil rasters (sampling2d/raster.py:62-164) and the divergent bundle
+ * (OpticalSystemAnalysis.divergent_bundle, analysis/optical_system_analysis.py:124-165).  A raster is
+ * given as an outer product of 1-d HOST tables: point (i, j), i = 0..ni-1 slow, j = 0..nj-1 fast
+ * (the order of np.meshgrid(..).reshape / .flatten), is px = xa[j]*xb[i], py = ya[j]*yb[i]; with
+ * `clip` only points with px*px + py*py <= 1 are kept (order kept).  The host computes the tables
+ * exactly as the reference does, so the samples are the reference's bit for bit:
+ *   RectGrid        xa = x1d, xb = 1, ya = 1, yb = x1d, clip              (raster.py:40-60)
+ *   HexGrid         two such lattices (base and shifted), clipped, one after the other  (:62-92)
+ *   MeridionalFan   ni = nray, nj = 1: xa = {-sin a}, xb = t, ya = {cos a}, yb = t      (:125-131)
+ *   CircularGrid    xa = ya = radii, xb = cos(phi_i), yb = sin(phi_i)                    (:148-164)
+ * prt_raster_bundle writes rays [lo, hi) of the (clipped) raster into (3, pitch) arrays:
+ *   kind 0, collimated: origin = radius*p + start; k, e constant (prt_collimated_bundle's rule)
+ *   kind 1, divergent:  origin = start; unit vector (sin(angley + radius*px) cos(anglex + radius*py),
+ *           sin(anglex + radius*py), cos(angley + radius*px) cos(anglex + radius*py)), k = index * unit,
+ *           E = the unit vector perpendicular to k that prt_efield_perp picks
+ *   p_out (optional, (2, pitch)): the pupil samples themselves.
+ */
+typedef struct prt_raster {
+    int64_t ni, nj;
+    const double *xa, *xb, *ya, *yb; /* HOST arrays: xa, ya nj entries; xb, yb ni entries */
+    int32_t clip, pad_;
+} prt_raster_t;
+typedef struct prt_bundle {
+    int32_t kind, pad_;              /* 0 collimated, 1 divergent */
+    double radius, start[3], anglex, angley;
+    double index;                    /* divergent: refractive index of the background medium */
+    double k[3], e[3];               /* collimated: wave vector and E field of every ray */
+} prt_bundle_t;
+int32_t prt_raster_count(int32_t device, const prt_raster_t *raster, int64_t *n_points, void *stream);
+int32_t prt_raster_bundle(int32_t device, const prt_raster_t *raster, int64_t lo, int64_t hi,
+                          const prt_bundle_t *prm, int64_t pitch, double *x_out, double *k_out,
+                          double *e_out, double *p_out, void *stream);
 
 /* RayBundle.returnKtoD (raytracer/ray.py:136-152) for one stored point: unit Poynting
  * directions d_out (3,n) from k (3,n) and E (e_re / e_im (3,n) or NULL; NULL e_re means E = ey
@@ -356,8 +402,11 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
  *   prt_arena_kind_of kind index of a pointer inside one of the arena's buffers.
  *   prt_arena_stats   out[0..12): kinds seen, probes run, slabs created, slabs released, free slabs,
  *                     slabs in use, slabs cached, slab size in bytes, slabs per kind (4 entries);
- *                     rates[0..3): last same-kind probe rate, last cross-kind probe rate (GB/s),
- *                     total probe time (ms).
+ *                     rates[0..4): last same-kind probe rate, last cross-kind probe rate (GB/s),
+ *                     total probe time (ms), bytes of address space reserved so far.
+ * Address space: the arena maps every virtual address at most once and never returns a range to the
+ * runtime -- with ROCm 7.0 / 7.2 a range that is unmapped and mapped again keeps translating to the old
+ * physical pages (csrc/prt_placed.h).  Only address space leaks (1 GiB per slab tested), not memory.
  * Thread-safe (one lock per arena).
  */
 #define PRT_ARENA_MAX_KINDS 4

@@ -261,6 +261,35 @@ def case_rasters():
     print("rasters.json: %d rasters" % len(out))
 
 
+def case_divergent_bundles():
+    """OpticalSystemAnalysis.divergent_bundle / collimated_bundle of the reference (optical_system_analysis.py:
+    83-165) on its deterministic rasters, in air and in a dense background medium: origins, wave vectors (the
+    reference gets them from a per-ray eigenproblem, material.py:456-499) and E fields (for the E . k = 0 check)"""
+    out = {}
+    (s_air, seq_air) = zoo.doublet(REFAPI)
+    s_dense = OpticalSystem.p(matbackground=ConstantIndexGlass.p(LocalCoordinates.p(name="bg"), 1.33))
+    rasters = {"rect_60": (raster.RectGrid(), 60), "hex_45": (raster.HexGrid(), 45),
+               "meridional_9": (raster.MeridionalFan(), 9), "sagital_8": (raster.SagitalFan(), 8),
+               "circular_49": (raster.CircularGrid(), 49)}
+    for (rkey, (robj, nray)) in rasters.items():
+        for (mkey, system) in (("air", s_air), ("n133", s_dense)):
+            osa = OpticalSystemAnalysis(system, seq_air if system is s_air else [])
+            for (bkey, fn, props) in (
+                    ("divergent", osa.divergent_bundle, {"startx": 0.3, "starty": -0.2, "startz": -7.0,
+                                                         "radius": 0.35, "anglex": 0.05, "angley": -0.12}),
+                    ("collimated", osa.collimated_bundle, {"startx": 0.3, "starty": -0.2, "startz": -7.0,
+                                                           "radius": 4.5, "anglex": 0.05, "angley": -0.12})):
+                (o, k, e) = fn(nray, dict(props, raster=robj), wave=DLINE)
+                assert np.abs(np.imag(k)).max() < 1e-12
+                out["%s_%s_%s" % (bkey, rkey, mkey)] = {
+                    "raster": rkey, "nray": nray, "bundle": bkey, "index": 1.0 if mkey == "air" else 1.33,
+                    "props": props, "x": np.real(o).tolist(), "k": np.real(k).tolist(),
+                    "e_re": np.real(e).tolist(), "e_im": np.imag(e).tolist()}
+    with open(os.path.join(OUT, "bundles.json"), "w") as f:
+        json.dump(out, f)
+    print("bundles.json: %d bundles" % len(out))
+
+
 def case_tilted():
     (s, seq) = zoo.tilted(REFAPI)
     dump_case("tilted_frames", s, seq, disk_bundle(300, 6.5, -3.0, field_deg=2.0, wave=0.6563e-3))
@@ -472,6 +501,7 @@ def main():
     case_gridsag()
     case_prism()
     case_rasters()
+    case_divergent_bundles()
     case_tilted()
     case_mirror()
     case_hud()

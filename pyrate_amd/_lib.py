@@ -44,7 +44,7 @@ PROTOTYPES = {
     "prt_recommended_pitch": (ctypes.c_int64, [ctypes.c_int64]),
     "prt_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_double_p,
                                    c_double_p, c_double_p, c_double_p, ctypes.c_int32,
-                                   ctypes.c_int64, c_double_p, c_double_p, c_u8_p, c_u8_p,
+                                   ctypes.c_int64, c_double_p, c_double_p, c_u8_p, c_u8_p, c_u8_p,
                                    c_stream]),
     "prt_trace_timed": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                          c_double_p, c_double_p, c_double_p, c_double_p,
@@ -53,7 +53,7 @@ PROTOTYPES = {
                                          ctypes.POINTER(ctypes.c_double)]),
     "prt_propagate": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                        c_double_p, c_double_p, c_double_p, c_double_p,
-                                       c_double_p, ctypes.c_int32, c_u8_p, c_double_p, c_u8_p,
+                                       c_double_p, ctypes.c_int32, c_u8_p, c_double_p, c_u8_p, c_u8_p,
                                        c_stream]),
     "prt_interact": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                       c_double_p, c_double_p, c_u8_p, c_double_p, c_double_p,
@@ -88,6 +88,25 @@ PROTOTYPES["prt_collimated_bundle"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.c
                                                        ctypes.c_int64, ctypes.POINTER(PrtCollimated),
                                                        ctypes.c_int64, c_double_p, c_double_p,
                                                        c_double_p, c_stream])
+
+class PrtRaster(ctypes.Structure):
+    """ctypes mirror of prt_raster_t"""
+    _fields_ = [("ni", ctypes.c_int64), ("nj", ctypes.c_int64), ("xa", ctypes.c_void_p), ("xb", ctypes.c_void_p),
+                ("ya", ctypes.c_void_p), ("yb", ctypes.c_void_p), ("clip", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+
+
+class PrtBundle(ctypes.Structure):
+    """ctypes mirror of prt_bundle_t"""
+    _fields_ = [("kind", ctypes.c_int32), ("pad_", ctypes.c_int32), ("radius", ctypes.c_double),
+                ("start", ctypes.c_double * 3), ("anglex", ctypes.c_double), ("angley", ctypes.c_double),
+                ("index", ctypes.c_double), ("k", ctypes.c_double * 3), ("e", ctypes.c_double * 3)]
+
+
+PROTOTYPES["prt_raster_count"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.POINTER(PrtRaster),
+                                                  ctypes.POINTER(ctypes.c_int64), c_stream])
+PROTOTYPES["prt_raster_bundle"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.POINTER(PrtRaster), ctypes.c_int64,
+                                                   ctypes.c_int64, ctypes.POINTER(PrtBundle), ctypes.c_int64,
+                                                   c_double_p, c_double_p, c_double_p, c_double_p, c_stream])
 
 PROTOTYPES["prt_poynting_dir"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p,
                                                   c_double_p, ctypes.c_int32, c_double_p, c_stream])

@@ -41,8 +41,21 @@ def build_simple_optical_element(lc0, builduplist, material_db_path="", name="")
         aperture = surfdict.pop("aperture", None)
         if shapetype not in accessible_shapes:
             raise Exception("shape %s is outside the HIP engine's scope" % shapetype)
-        actsurf = Surface.p(lc, name=surf_name + "_surf", aperture=aperture,
-                            shape=accessible_shapes[shapetype].p(lc, name=name + "_shape", **surfdict))
+        if shapetype == "shape_LinearCombination":
+            # the builder's documented special case (pyrateoptics/__init__.py:146-168): the parts come as
+            # (coefficient, surface dictionary) pairs and are turned into shapes in the surface's frame
+            parts = []
+            for (num, (coefficient, part)) in enumerate(surfdict.get("list_of_coefficients_and_shapes", []), 1):
+                part = dict(part)
+                part_type = "shape_" + part.pop("shape", "Conic")
+                if part_type not in accessible_shapes:
+                    raise Exception("shape %s is outside the HIP engine's scope" % part_type)
+                parts.append((coefficient, accessible_shapes[part_type].p(lc, name="%s_shape%d" % (name, num), **part)))
+            shape = accessible_shapes[shapetype].p(lc, name=surf_name + "_linearcombi",
+                                                   list_of_coefficients_and_shapes=parts)
+        else:
+            shape = accessible_shapes[shapetype].p(lc, name=name + "_shape", **surfdict)
+        actsurf = Surface.p(lc, name=surf_name + "_surf", aperture=aperture, shape=shape)
         if mat is not None:
             if isinstance(mat, Material):
                 key = mat.name

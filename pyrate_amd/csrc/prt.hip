@@ -21,18 +21,14 @@ struct prt_system {
     int32_t n_surfaces;
     int32_t all_isotropic;
     int32_t all_conic;
-    prt_surface_t *d_table;  // device copy
-    prt_surface_t *h_table;  // host copy (for dispatch decisions; its aux pointers are device pointers)
-    double **d_aux;          // per surface: device copy of the GRIDSAG spline data (or nullptr)
+    prt_dev_surface *d_table;  // device records (prt_device.h: the caller's records repacked, 504 B each)
+    prt_surface_t *h_table;    // host copy of the caller's records (dispatch decisions)
+    void *d_side;              // one device array: the coefficients / term powers / spline data in use
 };
 
 static void free_system(prt_system *sys) {
     if (!sys) return;
-    if (sys->d_aux) {
-        for (int s = 0; s < sys->n_surfaces; ++s)
-            if (sys->d_aux[s]) (void)hipFree(sys->d_aux[s]);
-        delete[] sys->d_aux;
-    }
+    if (sys->d_side) (void)hipFree(sys->d_side);
     if (sys->d_table) (void)hipFree(sys->d_table);
     delete[] sys->h_table;
     delete sys;
@@ -118,13 +114,13 @@ static void launch_trace_iso(const prt_system_t *sys, int64_t n0, int64_t in_pit
                              const double *k0, const double *e_re, const double *e_im,
                              int32_t e_mode, int64_t out_pitch, double *x_hit, double *k_out,
                              uint8_t *valid, uint8_t *valid_out, bool vec_in, bool vec_out,
-                             int32_t packed_flags, hipStream_t st) {
+                             int32_t packed_flags, uint8_t *nonconv, hipStream_t st) {
     const dim3 grid(nblocks(n0, PRT_MARCH_BLOCK * 2)), block(PRT_MARCH_BLOCK);
 #define PRT_LAUNCH_E(VI, VO, EX)                                                                 \
     hipLaunchKernelGGL((k_trace_iso<MODE, VI, VO, EX>), grid, block, 0, st, sys->d_table,        \
                        sys->n_surfaces, n0, in_pitch, x0, k0, e_re, e_im, e_mode, out_pitch,     \
                        x_hit, k_out, valid, valid_out, 0.0, 0.0, 0.0, (double *)nullptr,         \
-                       packed_flags)
+                       packed_flags, nonconv)
 #define PRT_LAUNCH(VI, VO)                 \
     do {                                   \
         if (sys->all_conic)                \
@@ -228,41 +224,98 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     sys->device = device;
     sys->n_surfaces = n_surfaces;
     sys->d_table = nullptr;
+    sys->d_side = nullptr;
     sys->h_table = new (std::nothrow) prt_surface_t[n_surfaces];
-    sys->d_aux = new (std::nothrow) double *[n_surfaces]();
-    if (!sys->h_table || !sys->d_aux) {
+    prt_dev_surface *recs = new (std::nothrow) prt_dev_surface[n_surfaces];
+    if (!sys->h_table || !recs) {
+        delete[] recs;
         free_system(sys);
         return fail(PRT_ERR_NOMEM, "host alloc");
     }
     memcpy(sys->h_table, table, sizeof(prt_surface_t) * n_surfaces);
     sys->all_isotropic = 1;
     sys->all_conic = 1;
+    // side array: per surface its doubles (coefficients, or the grid-sag spline) then, 8-byte
+    // aligned, its (x power, y power) pairs
+    auto n_doubles = [](const prt_surface_t &r) -> size_t {
+        if (r.shape_type == PRT_SHAPE_GRIDSAG)
+            return (size_t)r.grid_nx + (size_t)r.grid_ny + (size_t)(r.grid_nx - 4) * (size_t)(r.grid_ny - 4);
+        return (size_t)r.n_coeffs * (r.shape_type == PRT_SHAPE_BICONIC ? 2 : 1);
+    };
+    auto n_pows = [](const prt_surface_t &r) -> size_t {
+        return (r.shape_type == PRT_SHAPE_XYPOLY || r.shape_type == PRT_SHAPE_COMBO) ? 2 * (size_t)r.n_coeffs : 0;
+    };
+    size_t side_bytes = 0;
+    for (int s = 0; s < n_surfaces; ++s)
+        side_bytes += 8 * n_doubles(table[s]) + 8 * ((n_pows(table[s]) + 1) / 2);
+    char *h_side = new (std::nothrow) char[side_bytes + 8];
+    if (!h_side) {
+        delete[] recs;
+        free_system(sys);
+        return fail(PRT_ERR_NOMEM, "host alloc");
+    }
+    e = hipMalloc(&sys->d_side, side_bytes + 8);
+    if (e != hipSuccess) {
+        delete[] recs;
+        delete[] h_side;
+        free_system(sys);
+        return fail(PRT_ERR_NOMEM, "hipMalloc(coefficients)", e);
+    }
+    size_t off = 0;
     for (int s = 0; s < n_surfaces; ++s) {
-        if (table[s].mat_type != PRT_MAT_ISOTROPIC) sys->all_isotropic = 0;
-        if (table[s].shape_type != PRT_SHAPE_CONIC) sys->all_conic = 0;
-        sys->h_table[s].aux = nullptr;
-        if (table[s].shape_type == PRT_SHAPE_GRIDSAG) {  // private device copy of the spline data
-            const size_t n = (size_t)table[s].grid_nx + (size_t)table[s].grid_ny +
-                             (size_t)(table[s].grid_nx - 4) * (size_t)(table[s].grid_ny - 4);
-            e = hipMalloc((void **)&sys->d_aux[s], sizeof(double) * n);
-            if (e == hipSuccess)
-                e = hipMemcpy(sys->d_aux[s], table[s].aux, sizeof(double) * n, hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                free_system(sys);
-                return fail(PRT_ERR_NOMEM, "grid sag data", e);
-            }
-            sys->h_table[s].aux = sys->d_aux[s];
+        const prt_surface_t &r = table[s];
+        prt_dev_surface &d = recs[s];
+        if (r.mat_type != PRT_MAT_ISOTROPIC) sys->all_isotropic = 0;
+        if (r.shape_type != PRT_SHAPE_CONIC) sys->all_conic = 0;
+        memset(&d, 0, sizeof d);
+        d.shape_type = r.shape_type;
+        d.n_coeffs = r.n_coeffs;
+        d.ap_type = r.ap_type;
+        d.interaction = r.interaction;
+        d.mat_type = r.mat_type;
+        d.frame_flags = r.frame_flags;
+        d.newton_maxit = r.newton_maxit;
+        d.aniso_class = r.aniso_class;
+        d.n_asphere = r.n_asphere;
+        d.grid_nx = r.grid_nx;
+        d.grid_ny = r.grid_ny;
+        d.curv = r.curv;
+        d.cc = r.cc;
+        memcpy(d.B_shape, r.B_shape, sizeof d.B_shape);
+        memcpy(d.g_shape, r.g_shape, sizeof d.g_shape);
+        memcpy(d.B_ap, r.B_ap, sizeof d.B_ap);
+        memcpy(d.g_ap, r.g_ap, sizeof d.g_ap);
+        d.ap_p0 = r.ap_p0;
+        d.ap_p1 = r.ap_p1;
+        memcpy(d.B_mat, r.B_mat, sizeof d.B_mat);
+        d.n_after = r.n_after;
+        memcpy(d.eps_re, r.eps_re, sizeof d.eps_re);
+        d.aniso_eo = r.aniso_eo;
+        d.aniso_ee = r.aniso_ee;
+        memcpy(d.aniso_axis, r.aniso_axis, sizeof d.aniso_axis);
+        d.curv_y = r.curv_y;
+        d.cc_y = r.cc_y;
+        d.asphere_scale = r.asphere_scale;
+        const size_t nd = n_doubles(r), np = n_pows(r);
+        d.coeffs = (const double *)((char *)sys->d_side + off);
+        memcpy(h_side + off, r.shape_type == PRT_SHAPE_GRIDSAG ? (const void *)r.aux : (const void *)r.coeffs, 8 * nd);
+        off += 8 * nd;
+        d.pows = (const int32_t *)((char *)sys->d_side + off);
+        for (size_t t = 0; t < np / 2; ++t) {
+            ((int32_t *)(h_side + off))[2 * t] = r.xpow[t];
+            ((int32_t *)(h_side + off))[2 * t + 1] = r.ypow[t];
         }
+        off += 8 * ((np + 1) / 2);
     }
-    e = hipMalloc((void **)&sys->d_table, sizeof(prt_surface_t) * n_surfaces);
+    e = hipMemcpy(sys->d_side, h_side, side_bytes + 8, hipMemcpyHostToDevice);
+    delete[] h_side;
+    if (e == hipSuccess) e = hipMalloc((void **)&sys->d_table, sizeof(prt_dev_surface) * n_surfaces);
+    if (e == hipSuccess)
+        e = hipMemcpy(sys->d_table, recs, sizeof(prt_dev_surface) * n_surfaces, hipMemcpyHostToDevice);
+    delete[] recs;
     if (e != hipSuccess) {
         free_system(sys);
-        return fail(PRT_ERR_NOMEM, "hipMalloc(table)", e);
-    }
-    e = hipMemcpy(sys->d_table, sys->h_table, sizeof(prt_surface_t) * n_surfaces, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        free_system(sys);
-        return fail(PRT_ERR_DEVICE, "hipMemcpy(table)", e);
+        return fail(PRT_ERR_DEVICE, "prt_system_create: table upload", e);
     }
     *out = sys;
     return PRT_OK;
@@ -297,7 +350,8 @@ static bool aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *x0,
                              const double *k0, const double *e_re, const double *e_im,
                              int32_t mode, double *x_hit, double *k_out, double *e_out,
-                             double *e_out_im, uint8_t *valid, uint8_t *valid_out, hipStream_t st) {
+                             double *e_out_im, uint8_t *valid, uint8_t *valid_out, uint8_t *nonconv,
+                             hipStream_t st) {
     const int S = sys->n_surfaces;
     // scratch: directions after anisotropic interfaces, plus ping-pong state in IMAGE mode
     int64_t n_final = n0;
@@ -363,7 +417,9 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
         hipLaunchKernelGGL(k_propagate, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st,
                            sys->d_table + s, n, n_src, cur_x, cur_k, cur_dir,
                            (s == 0) ? e_re : nullptr, (s == 0) ? e_im : nullptr,
-                           (s == 0) ? e_mode : 0, cur_valid, xh_dst, v_dst);
+                           (s == 0) ? e_mode : 0, cur_valid, xh_dst, v_dst,
+                           !nonconv ? (uint8_t *)nullptr
+                                    : (mode == PRT_MODE_PATH ? nonconv + off_in : (last ? nonconv : (uint8_t *)nullptr)));
         double *dir_dst = dirbuf[s & 1];
         if (aniso) {
             hipLaunchKernelGGL(k_interact_aniso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
@@ -401,7 +457,8 @@ int64_t prt_recommended_pitch(int64_t n) {
 static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
                           const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
                           int64_t out_pitch, double *x_hit, double *k_out, double *e_out,
-                          double *e_out_im, uint8_t *valid, uint8_t *valid_out, void *stream) {
+                          double *e_out_im, uint8_t *valid, uint8_t *valid_out, uint8_t *nonconv,
+                          void *stream) {
     if (!sys || n0 < 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace: null system / negative count");
     const int32_t packed_flags = (mode & PRT_MODE_FLAGS) ? 1 : 0;
     if (mode >= 0) mode &= ~PRT_MODE_FLAGS;
@@ -430,7 +487,8 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
         // 0.41 ms, one biaxial crystal 0.32 vs 0.42 ms, two biaxial crystals 0.35 vs 0.43 ms; for
         // many interfaces the recomputation grows like 2^(A-1) S and the per-surface march wins.
         if (per_surface || n_aniso > 4)
-            return trace_general(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, e_out, e_out_im, valid, valid_out, st);
+            return trace_general(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, e_out, e_out_im, valid, valid_out,
+                                 nonconv, st);
         const dim3 grid(nblocks(n0, PRT_BLOCK)), block(PRT_BLOCK);
         const int32_t e_mode_g = e_mode_of(e0_re, 1);
         bool general_eps = false;
@@ -441,7 +499,7 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
 #define PRT_LAUNCH_G(MODE_, GEN_)                                                                        \
     hipLaunchKernelGGL((k_trace_general<MODE_, GEN_>), grid, block, 0, st, sys->d_table, sys->n_surfaces, \
                        n_aniso, n0, x0, k0, e0_re, e0_im, e_mode_g, x_hit, k_out, e_out, e_out_im, valid, \
-                       valid_out)
+                       valid_out, nonconv)
         if (mode == PRT_MODE_PATH) {
             if (general_eps) PRT_LAUNCH_G(PRT_MODE_PATH, true);
             else PRT_LAUNCH_G(PRT_MODE_PATH, false);
@@ -462,12 +520,15 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
                          ((((uintptr_t)valid) & 1u) == 0) &&
                          (!valid_out || (((uintptr_t)valid_out) & 1u) == 0) &&
                          (n0 % 2 == 0 || out_pitch > n0);  // odd N: the tail lane's 2nd ray lands in the padding
+    if (nonconv && sys->all_conic)  // closed-form intersections only: nothing can hit an iteration cap
+        HIP_TRY(hipMemsetAsync(nonconv, 0, (size_t)(mode == PRT_MODE_PATH ? sys->n_surfaces : 1) * (size_t)out_pitch, st));
+    const bool vec_nc = !nonconv || (((uintptr_t)nonconv) & 1u) == 0;
     if (mode == PRT_MODE_PATH)
-        launch_trace_iso<PRT_MODE_PATH>(sys, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch,
-                                        x_hit, k_out, valid, valid_out, vec_in, vec_out, packed_flags, st);
+        launch_trace_iso<PRT_MODE_PATH>(sys, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch, x_hit, k_out,
+                                        valid, valid_out, vec_in, vec_out && vec_nc, packed_flags, nonconv, st);
     else
-        launch_trace_iso<PRT_MODE_IMAGE>(sys, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch,
-                                         x_hit, k_out, valid, valid_out, vec_in, vec_out, packed_flags, st);
+        launch_trace_iso<PRT_MODE_IMAGE>(sys, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch, x_hit, k_out,
+                                         valid, valid_out, vec_in, vec_out && vec_nc, packed_flags, nonconv, st);
     HIP_TRY(hipGetLastError());
     return PRT_OK;
 }
@@ -475,9 +536,9 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
 int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
                   const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
                   int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
-                  uint8_t *valid_out, void *stream) {
+                  uint8_t *valid_out, uint8_t *nonconv, void *stream) {
     return trace_core(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out,
-                      (double *)nullptr, (double *)nullptr, valid, valid_out, stream);
+                      (double *)nullptr, (double *)nullptr, valid, valid_out, nonconv, stream);
 }
 
 int32_t prt_trace_fields(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,
@@ -486,7 +547,7 @@ int32_t prt_trace_fields(const prt_system_t *sys, int64_t n0, const double *x0, 
                          uint8_t *valid_out, void *stream) {
     if (!e_out_re) return fail(PRT_ERR_INVALID_ARG, "prt_trace_fields: e_out_re is NULL");
     return trace_core(sys, n0, 0, x0, k0, e0_re, e0_im, mode, 0, x_hit, k_out, e_out_re, e_out_im, valid,
-                      valid_out, stream);
+                      valid_out, (uint8_t *)nullptr, stream);
 }
 
 int64_t prt_trace_moments_scratch_doubles(int64_t n0) {
@@ -559,7 +620,7 @@ int32_t prt_trace_moments(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
     if (packed_flags)
         return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: PRT_MODE_FLAGS needs aligned, even-pitch buffers");
     int32_t rc = prt_trace(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode_in, out_pitch, x_hit, k_out, valid,
-                           valid_out, stream);
+                           valid_out, (uint8_t *)nullptr, stream);
     if (rc != PRT_OK) return rc;
     const int64_t row = (mode == PRT_MODE_PATH) ? (int64_t)(sys->n_surfaces - 1) : 0;
     const uint8_t *mask = valid_out ? valid_out + row * out_pitch : nullptr;
@@ -589,7 +650,7 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
     HIP_TRY(hipEventRecord(ev.a, st));
     for (int it = 0; it < iters; ++it) {
         int32_t rc = prt_trace(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out,
-                               valid, valid_out, stream);
+                               valid, valid_out, (uint8_t *)nullptr, stream);
         if (rc != PRT_OK) return rc;
     }
     HIP_TRY(hipEventRecord(ev.b, st));
@@ -603,7 +664,7 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
 int32_t prt_propagate(const prt_system_t *sys, int32_t surface, int64_t n, const double *x,
                       const double *k, const double *dir, const double *e_re, const double *e_im,
                       int32_t use_default_e, const uint8_t *valid_in, double *x_hit,
-                      uint8_t *valid, void *stream) {
+                      uint8_t *valid, uint8_t *nonconv, void *stream) {
     if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0)
         return fail(PRT_ERR_INVALID_ARG, "prt_propagate: bad system / surface / count");
     if (n == 0) return PRT_OK;
@@ -612,7 +673,7 @@ int32_t prt_propagate(const prt_system_t *sys, int32_t surface, int64_t n, const
     PRT_ON_DEVICE(sys->device);
     hipLaunchKernelGGL(k_propagate, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                        (hipStream_t)stream, sys->d_table + surface, n, n, x, k, dir, e_re, e_im,
-                       e_mode_of(e_re, use_default_e), valid_in, x_hit, valid);
+                       e_mode_of(e_re, use_default_e), valid_in, x_hit, valid, nonconv);
     HIP_TRY(hipGetLastError());
     return PRT_OK;
 }
@@ -746,6 +807,93 @@ int32_t prt_collimated_bundle(int32_t device, int64_t nray, int64_t lo, int64_t 
     if (d_mask) (void)hipFreeAsync(d_mask, st);
     if (d_sums) (void)hipFreeAsync(d_sums, st);
     return rc;
+}
+
+// device copies of a raster's tables + mask + block offsets; released on every exit path
+struct raster_scan {
+    hipStream_t st;
+    double *d_tab = nullptr;
+    uint8_t *d_mask = nullptr;
+    int64_t *d_sums = nullptr;
+    int64_t nb = 0, total = 0;
+    raster_tables t;
+    explicit raster_scan(hipStream_t s) : st(s) {}
+    ~raster_scan() {
+        if (d_tab) (void)hipFreeAsync(d_tab, st);
+        if (d_mask) (void)hipFreeAsync(d_mask, st);
+        if (d_sums) (void)hipFreeAsync(d_sums, st);
+    }
+    int32_t run(const prt_raster_t *r) {
+        if (!r || r->ni < 1 || r->nj < 1 || !r->xa || !r->xb || !r->ya || !r->yb)
+            return fail(PRT_ERR_INVALID_ARG, "raster: null table / empty raster");
+        if (r->ni > ((int64_t)1 << 40) / r->nj) return fail(PRT_ERR_INVALID_ARG, "raster: too many points");
+        const int64_t pts = r->ni * r->nj;
+        nb = (pts + CMP_TILE - 1) / CMP_TILE;
+        const size_t nt = (size_t)(2 * r->ni + 2 * r->nj);
+        HIP_TRY(hipMallocAsync((void **)&d_tab, sizeof(double) * nt, st));
+        HIP_TRY(hipMallocAsync((void **)&d_mask, (size_t)pts, st));
+        HIP_TRY(hipMallocAsync((void **)&d_sums, sizeof(int64_t) * (size_t)(nb + 1), st));
+        t.ni = r->ni;
+        t.nj = r->nj;
+        t.xa = d_tab;
+        t.ya = d_tab + r->nj;
+        t.xb = d_tab + 2 * r->nj;
+        t.yb = d_tab + 2 * r->nj + r->ni;
+        HIP_TRY(hipMemcpyAsync((void *)t.xa, r->xa, sizeof(double) * r->nj, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((void *)t.ya, r->ya, sizeof(double) * r->nj, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((void *)t.xb, r->xb, sizeof(double) * r->ni, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((void *)t.yb, r->yb, sizeof(double) * r->ni, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_raster_mask, dim3(nblocks(pts, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st, t, r->clip, d_mask);
+        hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nb), dim3(PRT_BLOCK), 0, st, d_mask, pts, d_sums);
+        hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(PRT_BLOCK), 0, st, d_sums, nb);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&total, d_sums + nb, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));   // the count is needed on the host; the caller's tables may go
+        return PRT_OK;
+    }
+};
+
+int32_t prt_raster_count(int32_t device, const prt_raster_t *raster, int64_t *n_points, void *stream) {
+    if (!n_points) return fail(PRT_ERR_INVALID_ARG, "prt_raster_count: null output");
+    PRT_ON_DEVICE(device);
+    raster_scan scan((hipStream_t)stream);
+    int32_t rc = scan.run(raster);
+    if (rc == PRT_OK) *n_points = scan.total;
+    return rc;
+}
+
+int32_t prt_raster_bundle(int32_t device, const prt_raster_t *raster, int64_t lo, int64_t hi,
+                          const prt_bundle_t *prm, int64_t pitch, double *x_out, double *k_out,
+                          double *e_out, double *p_out, void *stream) {
+    if (!prm || lo < 0 || hi < lo || prm->kind < 0 || prm->kind > 1)
+        return fail(PRT_ERR_INVALID_ARG, "prt_raster_bundle: bad argument");
+    if (hi == lo) return PRT_OK;
+    if (!x_out || !k_out) return fail(PRT_ERR_INVALID_ARG, "prt_raster_bundle: null pointer");
+    if (pitch == 0) pitch = hi - lo;
+    if (pitch < hi - lo) return fail(PRT_ERR_INVALID_ARG, "prt_raster_bundle: pitch < hi - lo");
+    PRT_ON_DEVICE(device);
+    hipStream_t st = (hipStream_t)stream;
+    raster_scan scan(st);
+    int32_t rc = scan.run(raster);
+    if (rc != PRT_OK) return rc;
+    if (hi > scan.total) return fail(PRT_ERR_INVALID_ARG, "prt_raster_bundle: hi beyond the raster");
+    bundle_params bp;
+    bp.kind = prm->kind;
+    bp.radius = prm->radius;
+    bp.startx = prm->start[0];
+    bp.starty = prm->start[1];
+    bp.startz = prm->start[2];
+    bp.anglex = prm->anglex;
+    bp.angley = prm->angley;
+    bp.index = prm->index;
+    for (int q = 0; q < 3; ++q) {
+        bp.k[q] = prm->k[q];
+        bp.e[q] = prm->e[q];
+    }
+    hipLaunchKernelGGL(k_raster_bundle, dim3((unsigned)scan.nb), dim3(PRT_BLOCK), 0, st, scan.d_mask, scan.t,
+                       scan.d_sums, lo, hi, bp, pitch, x_out, k_out, e_out, p_out);
+    HIP_TRY(hipGetLastError());
+    return PRT_OK;
 }
 
 int32_t prt_poynting_dir(int32_t device, int64_t n, const double *k, const double *e_re,

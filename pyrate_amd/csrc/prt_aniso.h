@@ -218,7 +218,7 @@ PRT_DEV vec3 null_vector(const vec3 &r0, const vec3 &r1, const vec3 &r2, int var
 // GENERAL = false: the host guarantees that no crystal of the table needs the quartic solver (all
 // epsilon tensors isotropic or uniaxial) and that code is compiled out.
 template <bool GENERAL = true>
-PRT_DEV void interact_anisotropic(const prt_surface_t *__restrict__ sf, const vec3 &p,
+PRT_DEV void interact_anisotropic(const prt_dev_surface *__restrict__ sf, const vec3 &p,
                                   const vec3 &k_glob, aniso_solution out[2]) {
     const vec3 n = normal_in_material_frame(sf, p);
     const bool mat_id = sf->frame_flags & PRT_FRAME_MAT_IDENTITY;

@@ -21,6 +21,29 @@
 
 #define PRT_DEV __device__ __forceinline__
 
+// The record the kernels read: prt_surface_t (include/prt.h, what a caller fills in) repacked by
+// prt_system_create -- same field names, but the coefficient arrays (3 x PRT_MAX_COEFFS entries, 2 KB)
+// are replaced by pointers into one side array on the device that holds only the entries in use, and
+// fields the kernels never look at (eps_im) are gone.  504 bytes per surface instead of 2.7 KB; a
+// 12-surface table is 6 KB and stays in the scalar cache whatever else runs.
+struct prt_dev_surface {
+    int32_t shape_type, n_coeffs, ap_type, interaction, mat_type, frame_flags, newton_maxit, aniso_class;
+    int32_t n_asphere, grid_nx, grid_ny, pad_;
+    double curv, cc;
+    const double *coeffs;  // n_coeffs doubles (biconic: 2 n_coeffs); GRIDSAG: knots tx, ty, coefficients
+    const int32_t *pows;   // xypoly / combo terms: x power of term t at [2t], y power at [2t + 1]
+    double B_shape[9], g_shape[3];
+    double B_ap[9], g_ap[3];
+    double ap_p0, ap_p1;
+    double B_mat[9];
+    double n_after;
+    double eps_re[9];
+    double aniso_eo, aniso_ee, aniso_axis[3];
+    double curv_y, cc_y;
+    double asphere_scale;
+};
+static_assert(sizeof(prt_dev_surface) < 512, "device surface record grew beyond 512 bytes");
+
 struct vec3 {
     double x, y, z;
 };
@@ -160,7 +183,7 @@ PRT_DEV double conic_sag(double c, double cc, double r2) {
 //   F  = c r2/(1+sq) + sum_n a_n r2^(n+1)
 //   Fx = x (c/sq + sum_n 2(n+1) a_n r2^n),   gradient of z-F = (-Fx, -Fy, 1)
 // Horner in r2 (the reference sums the powers; same polynomial).
-PRT_DEV void asphere_eval(const prt_surface_t *__restrict__ sf, int nc, double x, double y, double &F,
+PRT_DEV void asphere_eval(const prt_dev_surface *__restrict__ sf, int nc, double x, double y, double &F,
                           double &dFdr2x2 /* Fx = x * this */) {
     const double c = sf->curv, cc = sf->cc;
     const double r2 = x * x + y * y;
@@ -178,7 +201,7 @@ PRT_DEV void asphere_eval(const prt_surface_t *__restrict__ sf, int nc, double x
 // XYPolynomials.F / gradF, surface_shape.py:785-807.  coeffs[] already hold
 // c / normradius^(i+j) (host side).  Powers by repeated multiplication with
 // wave-uniform trip counts.
-PRT_DEV void xypoly_eval(const prt_surface_t *__restrict__ sf, int t0, int nt, double x, double y,
+PRT_DEV void xypoly_eval(const prt_dev_surface *__restrict__ sf, int t0, int nt, double x, double y,
                          double &F, double &Fx, double &Fy) {
     // The host stores the terms sorted by (i, j), so the powers are built incrementally: x^i advances
     // when i does, y^j restarts with every new i -- about (#terms + degree^2 / 2) multiplications per
@@ -191,7 +214,7 @@ PRT_DEV void xypoly_eval(const prt_surface_t *__restrict__ sf, int t0, int nt, d
     double xp = 1.0, xpm1 = 0.0;  // x^ip, x^(ip-1) (0 for ip = 0: d/dx of a constant)
     double yp = 1.0, ypm1 = 0.0;
     for (int t = t0; t < nt; ++t) {
-        const int i = sf->xpow[t], j = sf->ypow[t];
+        const int i = sf->pows[2 * t], j = sf->pows[2 * t + 1];
         const double c = sf->coeffs[t];
         if (i != ip) {
             if (i < ip) {
@@ -228,7 +251,7 @@ PRT_DEV void xypoly_eval(const prt_surface_t *__restrict__ sf, int t0, int nt, d
 //   F = (cx x^2 + cy y^2)/(1+sq) + sum_n a_n w_n^(n+1),  w_n = r2 - b_n (x^2 - y^2)
 //   sq = sqrt(1 - cx^2 (1+ccx) x^2 - cy^2 (1+ccy) y^2)
 //   Fx = cx x (cx (1+ccx) u + 2 (sq+1) sq) / ((sq+1)^2 sq) + sum 2 a_n (n+1) x (1-b_n) w_n^n   (u = cx x^2 + cy y^2)
-PRT_DEV void biconic_eval(const prt_surface_t *__restrict__ sf, double x, double y, double &F,
+PRT_DEV void biconic_eval(const prt_dev_surface *__restrict__ sf, double x, double y, double &F,
                           double &Fx, double &Fy) {
     const double cx = sf->curv, ccx = sf->cc, cy = sf->curv_y, ccy = sf->cc_y;
     const double x2 = x * x, y2 = y * y;
@@ -291,10 +314,10 @@ PRT_DEV void bspline_basis3(const double *__restrict__ t, int l, double x, doubl
     db[3] = 3.0 * g2;
 }
 
-PRT_DEV void gridsag_eval(const prt_surface_t *__restrict__ sf, double x, double y, double &F,
+PRT_DEV void gridsag_eval(const prt_dev_surface *__restrict__ sf, double x, double y, double &F,
                           double &Fx, double &Fy) {
     const int nx = sf->grid_nx, ny = sf->grid_ny;
-    const double *__restrict__ tx = sf->aux;
+    const double *__restrict__ tx = sf->coeffs;
     const double *__restrict__ ty = tx + nx;
     const double *__restrict__ c = ty + ny;
     const double xc = fmin(fmax(x, tx[3]), tx[nx - 4]);
@@ -324,7 +347,7 @@ PRT_DEV void gridsag_eval(const prt_surface_t *__restrict__ sf, double x, double
 }
 
 // explicit z = F(x,y) shapes: value and in-plane derivatives
-PRT_DEV void explicit_eval(const prt_surface_t *__restrict__ sf, double x, double y, double &F,
+PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, double x, double y, double &F,
                            double &Fx, double &Fy) {
     if (sf->shape_type == PRT_SHAPE_ASPHERE) {
         double m;
@@ -360,7 +383,7 @@ PRT_DEV void explicit_eval(const prt_surface_t *__restrict__ sf, double x, doubl
 // iteration was <= 1e-15, so they are the derivatives at the root to rounding and the
 // normal does not need another evaluation of the shape.
 // The convergence scale is in units of |d| (d may be k, |k| = n ~ 1..2).
-PRT_DEV double explicit_t(const prt_surface_t *__restrict__ sf, const vec3 &r0, const vec3 &d,
+PRT_DEV double explicit_t(const prt_dev_surface *__restrict__ sf, const vec3 &r0, const vec3 &d,
                           bool &nonconv, double &gx, double &gy) {
     double t = 0.0;
     bool done = false;
@@ -389,14 +412,14 @@ PRT_DEV double explicit_t(const prt_surface_t *__restrict__ sf, const vec3 &r0, 
 }
 
 // gradient of the implicit surface function in the shape frame (not normalised)
-PRT_DEV vec3 shape_grad(const prt_surface_t *__restrict__ sf, double x, double y) {
+PRT_DEV vec3 shape_grad(const prt_dev_surface *__restrict__ sf, double x, double y) {
     if (sf->shape_type == PRT_SHAPE_CONIC) return conic_grad(sf->curv, sf->cc, x, y);
     double F, Fx, Fy;
     explicit_eval(sf, x, y, F, Fx, Fy);
     return v3(-Fx, -Fy, 1.0);
 }
 
-PRT_DEV double shape_sag(const prt_surface_t *__restrict__ sf, double x, double y) {
+PRT_DEV double shape_sag(const prt_dev_surface *__restrict__ sf, double x, double y) {
     if (sf->shape_type == PRT_SHAPE_CONIC) return conic_sag(sf->curv, sf->cc, x * x + y * y);
     double F, Fx, Fy;
     explicit_eval(sf, x, y, F, Fx, Fy);
@@ -406,7 +429,7 @@ PRT_DEV double shape_sag(const prt_surface_t *__restrict__ sf, double x, double 
 // ---------------------------------------------------------------------------
 // aperture.py:71-139
 // ---------------------------------------------------------------------------
-PRT_DEV bool aperture_ok(const prt_surface_t *__restrict__ sf, double x, double y) {
+PRT_DEV bool aperture_ok(const prt_dev_surface *__restrict__ sf, double x, double y) {
     if (sf->ap_type == PRT_AP_CIRCULAR) {
         const double r2 = x * x + y * y;
         return (r2 >= sf->ap_p0 * sf->ap_p0) && (r2 <= sf->ap_p1 * sf->ap_p1);
@@ -426,8 +449,9 @@ PRT_DEV bool aperture_ok(const prt_surface_t *__restrict__ sf, double x, double 
 //        g (unnormalised surface gradient at p, shape frame) and g2 = |g|^2 as by-products
 //   d may be any positive multiple of the unit direction, d2 = d.d
 template <bool EXPLICIT = true>
-PRT_DEV void propagate_step(const prt_surface_t *__restrict__ sf, const vec3 &x, const vec3 &d,
-                            double d2, vec3 &xh, vec3 &p, vec3 &g, double &g2, bool &valid) {
+PRT_DEV void propagate_step(const prt_dev_surface *__restrict__ sf, const vec3 &x, const vec3 &d,
+                            double d2, vec3 &xh, vec3 &p, vec3 &g, double &g2, bool &valid, bool &nonconv) {
+    nonconv = false;
     const int ff = sf->frame_flags;
     vec3 r0 = v3(x.x - sf->g_shape[0], x.y - sf->g_shape[1], x.z - sf->g_shape[2]);
     vec3 dl = d;
@@ -443,12 +467,12 @@ PRT_DEV void propagate_step(const prt_surface_t *__restrict__ sf, const vec3 &x,
         p = v3(r0.x + dl.x * t, r0.y + dl.y * t, r0.z + dl.z * t);
         g = conic_grad_on_surface(sf->curv, sf->cc, p, g2);
     } else {
-        bool nonconv;
         double fx, fy;
         t = explicit_t(sf, r0, dl, nonconv, fx, fy);  // reference: valid all True (surface_shape.py:462)
         // A ray whose Newton iteration hit the cap has no trustworthy hit point.  The mask after
         // propagate stays reference-compatible (True); the NaN hit point makes the normal NaN, so
-        // the ray is dropped by the finite-normal test of the following refraction.
+        // the ray is dropped by the finite-normal test of the following refraction.  `nonconv` is
+        // what tells such a ray from one that left the domain of the shape.
         if (nonconv) t = __builtin_nan("");
         p = v3(r0.x + dl.x * t, r0.y + dl.y * t, r0.z + dl.z * t);
         // (fx, fy are the derivatives at the last iterate: finite even when t is not -- poison them
@@ -475,7 +499,7 @@ PRT_DEV void propagate_step(const prt_surface_t *__restrict__ sf, const vec3 &x,
 }
 
 // shape-frame hit point from a global one (used when interact is called on its own)
-PRT_DEV vec3 to_shape_frame(const prt_surface_t *__restrict__ sf, const vec3 &xh) {
+PRT_DEV vec3 to_shape_frame(const prt_dev_surface *__restrict__ sf, const vec3 &xh) {
     vec3 r = v3(xh.x - sf->g_shape[0], xh.y - sf->g_shape[1], xh.z - sf->g_shape[2]);
     if (!(sf->frame_flags & PRT_FRAME_SHAPE_IDENTITY)) r = matT_vec(sf->B_shape, r);
     return r;
@@ -485,7 +509,7 @@ PRT_DEV vec3 to_shape_frame(const prt_surface_t *__restrict__ sf, const vec3 &xh
 // Shape.getNormal (surface_shape.py:100-112) + RayBundle.getLocalSurfaceNormal (ray.py:156-161).
 // Spheres have |g| = 1 identically (conic_grad_on_surface): no normalisation.
 template <bool EXPLICIT = true>
-PRT_DEV vec3 normal_from_grad(const prt_surface_t *__restrict__ sf, const vec3 &g, double g2) {
+PRT_DEV vec3 normal_from_grad(const prt_dev_surface *__restrict__ sf, const vec3 &g, double g2) {
     vec3 n = g;
     if (!((!EXPLICIT || sf->shape_type == PRT_SHAPE_CONIC) && sf->cc == 0.0)) {
         const double r = fast_rsqrt(g2);
@@ -499,7 +523,7 @@ PRT_DEV vec3 normal_from_grad(const prt_surface_t *__restrict__ sf, const vec3 &
 
 // the same for an arbitrary point of the shape frame (per-surface API: the caller's points
 // need not lie on the surface, so the sag is evaluated like the reference does)
-PRT_DEV vec3 normal_in_material_frame(const prt_surface_t *__restrict__ sf, const vec3 &p) {
+PRT_DEV vec3 normal_in_material_frame(const prt_dev_surface *__restrict__ sf, const vec3 &p) {
     vec3 g = shape_grad(sf, p.x, p.y);
     const double inv = 1.0 / sqrt(dot(g, g));
     vec3 n = v3(g.x * inv, g.y * inv, g.z * inv);
@@ -513,7 +537,7 @@ PRT_DEV vec3 normal_in_material_frame(const prt_surface_t *__restrict__ sf, cons
 // IsotropicMaterial.refract / reflect, material_isotropic.py:137-236
 //   k global in -> k global out; valid &= (n2^2 - kin.kin > 0) & finite(normal)
 // ---------------------------------------------------------------------------
-PRT_DEV void interact_isotropic(const prt_surface_t *__restrict__ sf, const vec3 &n, vec3 &k,
+PRT_DEV void interact_isotropic(const prt_dev_surface *__restrict__ sf, const vec3 &n, vec3 &k,
                                 bool &valid) {
     const bool mat_id = sf->frame_flags & PRT_FRAME_MAT_IDENTITY;
     vec3 k1 = k;

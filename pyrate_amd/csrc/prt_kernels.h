@@ -7,6 +7,7 @@
 //   k_moments_partial / k_moments_final                deterministic bundle moments
 //   k_compact_count / k_compact_scan / k_compact_scatter   order-preserving compaction
 //   k_rectgrid_mask / k_rectgrid_scatter               RectGrid raster + collimated bundle
+//   k_raster_mask / k_raster_bundle                    any outer-product raster + collimated / divergent bundle
 #pragma once
 #include "prt_device.h"
 #include "prt_aniso.h"
@@ -50,9 +51,15 @@ struct rayio {
     static PRT_DEV void store(double *__restrict__ a, int64_t pitch, int64_t i, bool second,
                               const vec3 v[2]) {
         if (VEC) {
+#ifdef PRT_NT_STORES   // experiment (benchmarks/ab_variants.py): non-temporal hint on the path stores
+            __builtin_nontemporal_store(prt_double2{v[0].x, v[1].x}, reinterpret_cast<prt_double2 *>(a + i));
+            __builtin_nontemporal_store(prt_double2{v[0].y, v[1].y}, reinterpret_cast<prt_double2 *>(a + pitch + i));
+            __builtin_nontemporal_store(prt_double2{v[0].z, v[1].z}, reinterpret_cast<prt_double2 *>(a + 2 * pitch + i));
+#else
             *reinterpret_cast<prt_double2 *>(a + i) = prt_double2{v[0].x, v[1].x};
             *reinterpret_cast<prt_double2 *>(a + pitch + i) = prt_double2{v[0].y, v[1].y};
             *reinterpret_cast<prt_double2 *>(a + 2 * pitch + i) = prt_double2{v[0].z, v[1].z};
+#endif
         } else {
             a[i] = v[0].x;
             a[pitch + i] = v[0].y;
@@ -64,11 +71,11 @@ struct rayio {
             }
         }
     }
-    // two masks packed into one byte per ray: bit 0 = lo, bit 1 = hi (PRT_MODE_FLAGS)
+    // the masks of a record packed into one byte per ray: bit 0 = lo, bit 1 = hi, bit 2 = nc (PRT_MODE_FLAGS)
     static PRT_DEV void store_flags(uint8_t *__restrict__ m, int64_t i, bool second, const bool lo[2],
-                                    const bool hi[2]) {
-        const unsigned f0 = (lo[0] ? 1u : 0u) | (hi[0] ? 2u : 0u);
-        const unsigned f1 = (lo[1] ? 1u : 0u) | (hi[1] ? 2u : 0u);
+                                    const bool hi[2], const bool nc[2]) {
+        const unsigned f0 = (lo[0] ? 1u : 0u) | (hi[0] ? 2u : 0u) | (nc[0] ? 4u : 0u);
+        const unsigned f1 = (lo[1] ? 1u : 0u) | (hi[1] ? 2u : 0u) | (nc[1] ? 4u : 0u);
         if (VEC) {
             *reinterpret_cast<uint16_t *>(m + i) = (uint16_t)(f0 | (f1 << 8));
         } else {
@@ -147,16 +154,17 @@ template <int MODE, bool VEC_IN, bool VEC_OUT, bool EXPLICIT = true, bool LDS_TA
 __attribute__((amdgpu_waves_per_eu(1, PRT_PATH_WAVES_MAX)))
 #endif
 __global__ __launch_bounds__(PRT_MARCH_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE == PRT_MODE_IMAGE ? 8 : PRT_PATH_WAVES) : 1) void k_trace_iso(
-    const prt_surface_t *__restrict__ tab_g, int32_t S, int64_t N, int64_t in_pitch,
+    const prt_dev_surface *__restrict__ tab_g, int32_t S, int64_t N, int64_t in_pitch,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, int64_t out_pitch,
     double *__restrict__ xh_out, double *__restrict__ k_out, uint8_t *__restrict__ valid_out_hit,
     uint8_t *__restrict__ valid_out_refr, double mref_x = 0.0, double mref_y = 0.0,
-    double mref_z = 0.0, double *__restrict__ moment_partials = nullptr, int32_t packed_flags = 0) {
-    const prt_surface_t *__restrict__ tab = tab_g;
+    double mref_z = 0.0, double *__restrict__ moment_partials = nullptr, int32_t packed_flags = 0,
+    uint8_t *__restrict__ nonconv_out = nullptr) {
+    const prt_dev_surface *__restrict__ tab = tab_g;
     if (LDS_TAB) {
-        __shared__ prt_surface_t lds_tab[PRT_LDS_TAB_MAX];
-        const int words = S * (int)(sizeof(prt_surface_t) / 8);
+        __shared__ prt_dev_surface lds_tab[PRT_LDS_TAB_MAX];
+        const int words = S * (int)(sizeof(prt_dev_surface) / 8);
         const double *src = reinterpret_cast<const double *>(tab_g);
         double *dst = reinterpret_cast<double *>(lds_tab);
         for (int w = threadIdx.x; w < words; w += PRT_MARCH_BLOCK) dst[w] = src[w];
@@ -176,14 +184,15 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE ==
     double d2 = 1.0;  // |d|^2: unit Poynting direction on the first segment
 
     for (int32_t s = 0; s < S; ++s) {
-        const prt_surface_t *__restrict__ sf = tab + s;
+        const prt_dev_surface *__restrict__ sf = tab + s;
         bool vhit[2];
+        bool ncv[2];  // Newton hit its iteration cap at this surface (explicit shapes only)
         vec3 nrm[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             vec3 xh, p, g;
             double g2;
-            propagate_step<EXPLICIT>(sf, x[r], d[r], d2, xh, p, g, g2, valid[r]);
+            propagate_step<EXPLICIT>(sf, x[r], d[r], d2, xh, p, g, g2, valid[r], ncv[r]);
             vhit[r] = valid[r];
             nrm[r] = normal_from_grad<EXPLICIT>(sf, g, g2);
             x[r] = xh;
@@ -209,12 +218,14 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE ==
             const int64_t so = (MODE == PRT_MODE_PATH) ? (int64_t)s : 0;
             rayio<VEC_OUT>::store(k_out + so * 3 * out_pitch, out_pitch, i, second, k);
             if (packed_flags) {
-                rayio<VEC_OUT>::store_flags(valid_out_hit + so * out_pitch, i, second, vhit, valid);
+                rayio<VEC_OUT>::store_flags(valid_out_hit + so * out_pitch, i, second, vhit, valid, ncv);
             } else {
                 rayio<VEC_OUT>::store_mask(valid_out_hit + so * out_pitch, i, second, vhit);
                 if (valid_out_refr)
                     rayio<VEC_OUT>::store_mask(valid_out_refr + so * out_pitch, i, second, valid);
             }
+            if (EXPLICIT && nonconv_out)
+                rayio<VEC_OUT>::store_mask(nonconv_out + so * out_pitch, i, second, ncv);
         }
     }
     }  // i < N
@@ -269,11 +280,12 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE ==
 // scratch) is slower than either (0.36 ms).
 template <int MODE, bool GENERAL = true>
 __global__ __launch_bounds__(PRT_BLOCK, 3) void k_trace_general(
-    const prt_surface_t *__restrict__ tab, int32_t S, int32_t A, int64_t N,
+    const prt_dev_surface *__restrict__ tab, int32_t S, int32_t A, int64_t N,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, double *__restrict__ xh_out,
     double *__restrict__ k_out, double *__restrict__ e_out, double *__restrict__ e_out_im,
-    uint8_t *__restrict__ valid_out_hit, uint8_t *__restrict__ valid_out_refr) {
+    uint8_t *__restrict__ valid_out_hit, uint8_t *__restrict__ valid_out_refr,
+    uint8_t *__restrict__ nonconv_out = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
     if (i >= N) return;
     const vec3 xs = v3(x0[i], x0[N + i], x0[2 * N + i]);
@@ -297,7 +309,7 @@ __global__ __launch_bounds__(PRT_BLOCK, 3) void k_trace_general(
         int nstate = 1;    // 2 behind the last crystal interface
         int64_t off_in = 0, off_out = 0;
         for (int32_t s = 0; s < S; ++s) {
-            const prt_surface_t *__restrict__ sf = tab + s;
+            const prt_dev_surface *__restrict__ sf = tab + s;
             const bool last = (s == S - 1);
             const bool store = (MODE == PRT_MODE_PATH || last);
             const bool crystal = sf->mat_type == PRT_MAT_ANISOTROPIC;
@@ -317,12 +329,14 @@ __global__ __launch_bounds__(PRT_BLOCK, 3) void k_trace_general(
                 const bool alive = valid[c];
                 vec3 xh, p, g;
                 double g2;
-                propagate_step(sf, x[c], d[c], d2, xh, p, g, g2, valid[c]);
+                bool ncv;
+                propagate_step(sf, x[c], d[c], d2, xh, p, g, g2, valid[c], ncv);
                 if ((L >> a) == 0 && store) {
                     xo[idx_in] = xh.x;
                     xo[n_in + idx_in] = xh.y;
                     xo[2 * n_in + idx_in] = xh.z;
                     valid_out_hit[base_in + idx_in] = valid[c] ? 1 : 0;
+                    if (nonconv_out) nonconv_out[base_in + idx_in] = ncv ? 1 : 0;
                 }
                 x[c] = xh;
                 if (crystal) {  // only reached with nstate == 1 (c == 0)
@@ -399,11 +413,11 @@ __global__ __launch_bounds__(PRT_BLOCK, 3) void k_trace_general(
 // split ray share their parent's hit point without a copy.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(PRT_BLOCK) void k_propagate(
-    const prt_surface_t *__restrict__ sf, int64_t N, int64_t n_src,
+    const prt_dev_surface *__restrict__ sf, int64_t N, int64_t n_src,
     const double *__restrict__ x_in, const double *__restrict__ k_in,
     const double *__restrict__ dir_in, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, const uint8_t *__restrict__ valid_in,
-    double *__restrict__ xh_out, uint8_t *__restrict__ valid_out) {
+    double *__restrict__ xh_out, uint8_t *__restrict__ valid_out, uint8_t *__restrict__ nonconv_out = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
     if (i >= N) return;
     const int64_t j = (n_src == N) ? i : (i % n_src);
@@ -421,15 +435,17 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_propagate(
     bool valid = valid_in ? (valid_in[i] != 0) : true;
     vec3 xh, p, g;
     double g2;
-    propagate_step(sf, x, d, 1.0, xh, p, g, g2, valid);
+    bool ncv;
+    propagate_step(sf, x, d, 1.0, xh, p, g, g2, valid, ncv);
     xh_out[i] = xh.x;
     xh_out[N + i] = xh.y;
     xh_out[2 * N + i] = xh.z;
     valid_out[i] = valid ? 1 : 0;
+    if (nonconv_out) nonconv_out[i] = ncv ? 1 : 0;
 }
 
 __global__ __launch_bounds__(PRT_BLOCK) void k_interact_iso(
-    const prt_surface_t *__restrict__ sf, int64_t N, const double *__restrict__ xh_in,
+    const prt_dev_surface *__restrict__ sf, int64_t N, const double *__restrict__ xh_in,
     const double *__restrict__ k_in, const uint8_t *__restrict__ valid_in,
     double *__restrict__ k_out, double *__restrict__ dir_out, uint8_t *__restrict__ valid_out) {
     const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
@@ -452,7 +468,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_interact_iso(
 }
 
 __global__ __launch_bounds__(PRT_BLOCK) void k_interact_aniso(
-    const prt_surface_t *__restrict__ sf, int64_t N, const double *__restrict__ xh_in,
+    const prt_dev_surface *__restrict__ sf, int64_t N, const double *__restrict__ xh_in,
     const double *__restrict__ k_in, const uint8_t *__restrict__ alive_in,
     double *__restrict__ k_out, double *__restrict__ dir_out, double *__restrict__ e_re_out,
     double *__restrict__ e_im_out, uint8_t *__restrict__ valid_out) {
@@ -492,7 +508,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_interact_aniso(
     }
 }
 
-__global__ __launch_bounds__(PRT_BLOCK) void k_shape_eval(const prt_surface_t *__restrict__ sf,
+__global__ __launch_bounds__(PRT_BLOCK) void k_shape_eval(const prt_dev_surface *__restrict__ sf,
                                                           int64_t N, const double *__restrict__ x,
                                                           const double *__restrict__ y,
                                                           double *__restrict__ sag,
@@ -877,3 +893,100 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_rectgrid_scatter(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Pupil rasters that are outer products of 1-d tables (sampling2d/raster.py:37-164) and the two
+// bundle types built on them (analysis/optical_system_analysis.py:83-165).  Point (i, j) -- i slow,
+// j fast, the order of np.meshgrid(...).reshape / .flatten -- is
+//     px = xa[j] * xb[i],   py = ya[j] * yb[i]
+// with the 1-d tables computed on the host exactly as the reference computes them (np.linspace,
+// math.sin of the fan angle, ...), so that the samples are the reference's bit for bit: RectGrid and
+// the two lattices of HexGrid (a table and a table of ones), CircularGrid (radii x cos / sin of the
+// azimuths), Meridional / SagitalFan (a 1 x n raster).  clip: keep px*px + py*py <= 1, order kept.
+// ---------------------------------------------------------------------------
+struct raster_tables {
+    const double *xa, *xb, *ya, *yb;  // device copies: xa, ya have nj entries, xb, yb ni
+    int64_t ni, nj;
+};
+
+PRT_DEV void raster_point(const raster_tables &t, int64_t idx, double &px, double &py) {
+    const int64_t i = idx / t.nj, j = idx - i * t.nj;
+    px = mul_rn(t.xa[j], t.xb[i]);
+    py = mul_rn(t.ya[j], t.yb[i]);
+}
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_raster_mask(raster_tables t, int32_t clip,
+                                                           uint8_t *__restrict__ mask) {
+    const int64_t idx = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (idx >= t.ni * t.nj) return;
+    double px, py;
+    raster_point(t, idx, px, py);
+    mask[idx] = (!clip || add_rn(mul_rn(px, px), mul_rn(py, py)) <= 1.0) ? 1 : 0;
+}
+
+struct bundle_params {
+    int32_t kind;  // 0 collimated, 1 divergent
+    double radius, startx, starty, startz, anglex, angley, index;
+    double k[3], e[3];  // collimated: the bundle's wave vector and E field
+};
+
+__global__ __launch_bounds__(PRT_BLOCK) void k_raster_bundle(
+    const uint8_t *__restrict__ mask, raster_tables t, const int64_t *__restrict__ block_offs, int64_t lo,
+    int64_t hi, bundle_params prm, int64_t pitch, double *__restrict__ x_out, double *__restrict__ k_out,
+    double *__restrict__ e_out, double *__restrict__ p_out) {
+    const int64_t total = t.ni * t.nj;
+    const int64_t tile = (int64_t)blockIdx.x * CMP_TILE;
+    bool keep[CMP_ITEMS];
+    int pos[CMP_ITEMS];
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        const int64_t idx = tile + q * PRT_BLOCK + threadIdx.x;
+        keep[q] = (idx < total) && mask[idx];
+    }
+    tile_slots(keep, pos);
+    const int64_t off = block_offs[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < CMP_ITEMS; ++q) {
+        if (!keep[q]) continue;
+        const int64_t p = off + pos[q];
+        if (p < lo || p >= hi) continue;
+        double px, py;
+        raster_point(t, tile + q * PRT_BLOCK + threadIdx.x, px, py);
+        const int64_t o = p - lo;
+        if (p_out) {
+            p_out[o] = px;
+            p_out[pitch + o] = py;
+        }
+        vec3 k, e;
+        if (prm.kind == 0) {
+            // origin = radius * p + start (optical_system_analysis.py:106-108), two roundings
+            x_out[o] = add_rn(mul_rn(prm.radius, px), prm.startx);
+            x_out[pitch + o] = add_rn(mul_rn(prm.radius, py), prm.starty);
+            x_out[2 * pitch + o] = prm.startz;
+            k = v3(prm.k[0], prm.k[1], prm.k[2]);
+            e = v3(prm.e[0], prm.e[1], prm.e[2]);
+        } else {
+            // every ray starts at the source point; directions fan out over the pupil angles
+            // (optical_system_analysis.py:150-158); k = n * unit vector
+            x_out[o] = prm.startx;
+            x_out[pitch + o] = prm.starty;
+            x_out[2 * pitch + o] = prm.startz;
+            const double ay = add_rn(prm.angley, mul_rn(prm.radius, px));
+            const double ax = add_rn(prm.anglex, mul_rn(prm.radius, py));
+            const double cax = cos(ax);
+            k = v3(mul_rn(prm.index, mul_rn(sin(ay), cax)), mul_rn(prm.index, sin(ax)),
+                   mul_rn(prm.index, mul_rn(cos(ay), cax)));
+            // E: the unit vector perpendicular to k that prt_efield_perp picks
+            const double fx = fabs(k.x), fy = fabs(k.y), fz = fabs(k.z);
+            const vec3 a = (fy <= fx && fy <= fz) ? v3(0, 1, 0) : ((fx <= fz) ? v3(1, 0, 0) : v3(0, 0, 1));
+            e = normalized(cross(k, a));
+        }
+        k_out[o] = k.x;
+        k_out[pitch + o] = k.y;
+        k_out[2 * pitch + o] = k.z;
+        if (e_out) {
+            e_out[o] = e.x;
+            e_out[pitch + o] = e.y;
+            e_out[2 * pitch + o] = e.z;
+        }
+    }
+}

@@ -14,6 +14,16 @@
 // 2-ms write probe against one representative slab per kind, and builds each requested buffer out of
 // slabs of ONE kind, mapped to contiguous virtual addresses (hipMemMap); the buffers of one request
 // get different kinds.  Slabs and mapped buffers are cached for reuse.
+//
+// One rule shapes the code: A VIRTUAL ADDRESS IS MAPPED ONCE AND NEVER AGAIN.  With this ROCm stack
+// (7.0 / 7.2) a range that is unmapped (hipMemUnmap) and then mapped to other physical memory keeps
+// translating to the OLD pages: data written through addresses of their own never showed up through
+// the remapped range, and probe stores issued through a re-used range landed in a live path array
+// (profiles/r02b_vmm_placement_probe.txt, experiment E4; found by the exact-similarity test).  So every
+// mapping -- a slab under test, a representative, a buffer -- gets a freshly reserved range, and ranges
+// are not handed back to the runtime (hipMemAddressFree would allow the next reservation to return the
+// same addresses).  Address space is the only thing that leaks: 1 GiB of it per slab tested, out of
+// the 128 TiB a process has.
 #pragma once
 #include <mutex>
 #include <vector>
@@ -58,7 +68,9 @@ struct prt_arena {
     // one slab per kind stays mapped for good and is never handed out: the probe writes into it
     prt_slab rep[PRT_ARENA_MAX_KINDS];
     void *rep_va[PRT_ARENA_MAX_KINDS] = {nullptr, nullptr, nullptr, nullptr};
-    void *probe_va = nullptr;      // where a slab under test is mapped
+    int32_t last_kind = 0;         // kind of the previous slab: slabs come in long runs of one kind
+    double self_rate = 0.0;        // yardstick of the current hunt: a slab against itself, GB/s
+    int64_t va_reserved = 0;       // bytes of address space taken so far (never returned, see above)
     std::vector<prt_slab> free_slabs;
     std::vector<prt_placed_buffer *> buffers;      // in use and cached
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -69,6 +81,19 @@ struct prt_arena {
     double probe_ms_total = 0.0;
     double bw_same = 0.0, bw_cross = 0.0;          // last probe rates seen, GB/s
 };
+
+// a range of addresses nothing was ever mapped to
+// (slab-aligned: the runtime ignores the alignment argument beyond 2 MiB, so a slab more is reserved and
+// the start rounded up -- a 1-GiB slab at a 1-GiB aligned address can be mapped by the largest page
+// table fragments)
+static hipError_t arena_fresh_va(prt_arena *a, void **va, size_t bytes) {
+    void *raw = nullptr;
+    hipError_t e = hipMemAddressReserve(&raw, bytes + PRT_SLAB_BYTES, PRT_SLAB_BYTES, nullptr, 0);
+    if (e != hipSuccess) return e;
+    a->va_reserved += (int64_t)(bytes + PRT_SLAB_BYTES);
+    *va = (void *)(((uintptr_t)raw + PRT_SLAB_BYTES - 1) / PRT_SLAB_BYTES * PRT_SLAB_BYTES);
+    return hipSuccess;
+}
 
 static hipError_t arena_map(prt_arena *a, void *va, const prt_slab &s) {
     hipError_t e = hipMemMap(va, PRT_SLAB_BYTES, 0, s.handle, 0);
@@ -101,20 +126,24 @@ static hipError_t arena_probe_rate(prt_arena *a, double *lo, double *hi, int64_t
     return hipGetLastError();
 }
 
-// Kind of a slab that is mapped at `mem`: the representative it is SLOW with.  The yardstick is the
-// slab against itself (both halves of the streams inside it = one kind by construction): a pair of
-// different kinds runs 1.23x faster than that, a pair of the same kind at the same rate.
+// Kind of a slab that is mapped at `mem`: the representative it is SLOW with.  The yardstick is a slab
+// against itself (both halves of the streams inside it = one kind by construction; measured once per
+// hunt): a pair of different kinds runs 1.23x faster than that, a pair of the same kind at the same
+// rate.  The previous slab's kind is tried first -- the driver hands out long runs of one kind.
 static hipError_t arena_classify(prt_arena *a, double *mem, hipStream_t st, int32_t *kind) {
     const int64_t half_len = (int64_t)(PRT_SLAB_BYTES / 72 / 8) / 512 * 512;
     const int64_t full_len = (int64_t)(PRT_SLAB_BYTES / 36 / 8) / 512 * 512;
-    double self = 0.0;
-    hipError_t e = arena_probe_rate(a, mem, mem + 36 * half_len, half_len, st, &self);
-    if (e != hipSuccess) return e;
-    a->bw_same = self;
-    for (int q = 0; q < a->n_kinds; ++q) {
+    hipError_t e;
+    if (a->self_rate <= 0.0) {
+        if ((e = arena_probe_rate(a, mem, mem + 36 * half_len, half_len, st, &a->self_rate)) != hipSuccess) return e;
+        a->bw_same = a->self_rate;
+    }
+    for (int t = 0; t < a->n_kinds; ++t) {
+        const int q = (t == 0) ? a->last_kind : (t <= a->last_kind ? t - 1 : t);
         double pair = 0.0;
         if ((e = arena_probe_rate(a, (double *)a->rep_va[q], mem, full_len, st, &pair)) != hipSuccess) return e;
-        if (pair < 1.10 * self) {
+        if (pair < 1.10 * a->self_rate) {
+            a->bw_same = pair;
             *kind = q;
             return hipSuccess;
         }
@@ -124,8 +153,9 @@ static hipError_t arena_classify(prt_arena *a, double *mem, hipStream_t st, int3
     return hipSuccess;
 }
 
-// One more slab from the driver, classified.  A slab of a new kind becomes that kind's representative
-// (ret_is_rep) and is not available for buffers.
+// One more slab from the driver, classified.  It is mapped for the test at addresses of its own; a
+// slab of a new kind stays there as that kind's representative (became_rep) and is not available for
+// buffers, any other is unmapped again (and will be mapped elsewhere, never there).
 static hipError_t arena_new_slab(prt_arena *a, hipStream_t st, prt_slab *out, bool *became_rep) {
     *became_rep = false;
     size_t free_b = 0, total_b = 0;
@@ -136,32 +166,29 @@ static hipError_t arena_new_slab(prt_arena *a, hipStream_t st, prt_slab *out, bo
     s.kind = -1;
     if ((e = hipMemCreate(&s.handle, PRT_SLAB_BYTES, &a->prop, 0)) != hipSuccess) return e;
     a->n_created += 1;
-    if ((e = arena_map(a, a->probe_va, s)) != hipSuccess) {
+    void *va = nullptr;
+    if ((e = arena_fresh_va(a, &va, PRT_SLAB_BYTES)) != hipSuccess || (e = arena_map(a, va, s)) != hipSuccess) {
         (void)hipMemRelease(s.handle);
         return e;
     }
     int32_t kind = -1;
-    e = arena_classify(a, (double *)a->probe_va, st, &kind);
-    (void)hipMemUnmap(a->probe_va, PRT_SLAB_BYTES);
+    e = arena_classify(a, (double *)va, st, &kind);
     if (e != hipSuccess) {
+        (void)hipMemUnmap(va, PRT_SLAB_BYTES);
         (void)hipMemRelease(s.handle);
         return e;
     }
     if (kind == a->n_kinds && a->n_kinds < PRT_ARENA_MAX_KINDS) {
-        void *va = nullptr;
-        if ((e = hipMemAddressReserve(&va, PRT_SLAB_BYTES, (size_t)2 << 20, nullptr, 0)) != hipSuccess ||
-            (e = arena_map(a, va, s)) != hipSuccess) {
-            (void)hipMemRelease(s.handle);
-            return e;
-        }
         s.kind = kind;
         a->rep[kind] = s;
         a->rep_va[kind] = va;
         a->n_kinds += 1;
         *became_rep = true;
     } else {
+        (void)hipMemUnmap(va, PRT_SLAB_BYTES);
         s.kind = std::min(kind, PRT_ARENA_MAX_KINDS - 1);
     }
+    a->last_kind = s.kind;
     *out = s;
     return hipSuccess;
 }
@@ -172,10 +199,7 @@ static void arena_release_slab(prt_arena *a, const prt_slab &s) {
 }
 
 static void arena_unmap_buffer(prt_arena *a, prt_placed_buffer *b, bool keep_slabs) {
-    if (b->va) {
-        (void)hipMemUnmap(b->va, b->bytes);
-        (void)hipMemAddressFree(b->va, b->bytes);
-    }
+    if (b->va) (void)hipMemUnmap(b->va, b->bytes);      // the addresses are retired, not handed back
     for (const prt_slab &s : b->slabs) {
         if (keep_slabs) a->free_slabs.push_back(s);
         else arena_release_slab(a, s);
@@ -209,7 +233,7 @@ static hipError_t arena_build_buffer(prt_arena *a, size_t n_slabs, int32_t kind,
     if (!b) return hipErrorOutOfMemory;
     b->bytes = n_slabs * PRT_SLAB_BYTES;
     b->kind = kind;
-    hipError_t e = hipMemAddressReserve(&b->va, b->bytes, (size_t)2 << 20, nullptr, 0);
+    hipError_t e = arena_fresh_va(a, &b->va, b->bytes);
     if (e != hipSuccess) {
         delete b;
         return e;
@@ -256,7 +280,6 @@ int32_t prt_arena_create(int32_t device, prt_arena_t **out) {
     a->access.flags = hipMemAccessFlagsProtReadWrite;
     hipError_t e = hipEventCreate(&a->ev_a);
     if (e == hipSuccess) e = hipEventCreate(&a->ev_b);
-    if (e == hipSuccess) e = hipMemAddressReserve(&a->probe_va, PRT_SLAB_BYTES, (size_t)2 << 20, nullptr, 0);
     if (e != hipSuccess) {
         if (a->ev_a) (void)hipEventDestroy(a->ev_a);
         if (a->ev_b) (void)hipEventDestroy(a->ev_b);
@@ -300,10 +323,8 @@ int32_t prt_arena_destroy(prt_arena_t *a) {
         for (const prt_slab &s : a->free_slabs) arena_release_slab(a, s);
         for (int q = 0; q < a->n_kinds; ++q) {
             (void)hipMemUnmap(a->rep_va[q], PRT_SLAB_BYTES);
-            (void)hipMemAddressFree(a->rep_va[q], PRT_SLAB_BYTES);
             arena_release_slab(a, a->rep[q]);
         }
-        (void)hipMemAddressFree(a->probe_va, PRT_SLAB_BYTES);
         (void)hipEventDestroy(a->ev_a);
         (void)hipEventDestroy(a->ev_b);
     }
@@ -364,6 +385,7 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
 
     // hunt: take slabs from the driver until the strict assignment works (or the hunt budget is spent)
     const bool want_two_kinds = n_parts >= 2;
+    a->self_rate = 0.0;            // re-measured by the first slab this call takes from the driver
     int32_t hunted = 0;
     hipError_t hunt_err = hipSuccess;
     while (!assign(want_two_kinds)) {
@@ -405,8 +427,19 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
     // slabs the hunt took beyond what was needed go back to the driver right away (they are all of
     // kinds that are plentiful); slabs of buffers that were used once stay cached until prt_arena_trim
     if (hunted > 0) {
-        for (const prt_slab &s : a->free_slabs) arena_release_slab(a, s);
-        a->free_slabs.clear();
+        // ... except a few per kind (8 GiB): the next request, of another size, then starts with both
+        // kinds at hand instead of walking through the same run of one kind again
+        int64_t kept[PRT_ARENA_MAX_KINDS] = {0, 0, 0, 0};
+        std::vector<prt_slab> keep;
+        for (const prt_slab &s : a->free_slabs) {
+            if (kept[s.kind] < 8) {
+                kept[s.kind] += 1;
+                keep.push_back(s);
+            } else {
+                arena_release_slab(a, s);
+            }
+        }
+        a->free_slabs.swap(keep);
     }
     return PRT_OK;
 }
@@ -451,8 +484,8 @@ int32_t prt_arena_stats(prt_arena_t *a, int64_t *out, int32_t n_out, double *rat
     }
     v[7] = (int64_t)(PRT_SLAB_BYTES);
     for (int i = 0; i < n_out && i < 12; ++i) out[i] = v[i];
-    double r[3] = {a->bw_same, a->bw_cross, a->probe_ms_total};
-    for (int i = 0; i < n_rates && i < 3; ++i) rates[i] = r[i];
+    double r[4] = {a->bw_same, a->bw_cross, a->probe_ms_total, (double)a->va_reserved};
+    for (int i = 0; i < n_rates && i < 4; ++i) rates[i] = r[i];
     return PRT_OK;
 }
 

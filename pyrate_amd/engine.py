@@ -91,6 +91,7 @@ class TraceResult(object):
     def __init__(self, x_hit, k_out, valid, valid_out, n_in, n_out, mode, e_out=None):
         self.e_out = e_out            # per surface (re, im) behind crystal interfaces (trace(want_fields))
         self.flags = None             # per surface packed mask bytes (alloc_outputs(packed_flags=True))
+        self.nonconv = None           # per surface: Newton ended at its iteration cap (want_nonconv / packed flags)
         self.x_hit = x_hit
         self.k_out = k_out
         self.valid = valid
@@ -118,13 +119,17 @@ class TraceResult(object):
                 # on first access (and cached by _LazyViews)
                 flags = mask(bv)
                 res = cls(_LazyViews(rows, rays(bx)), _LazyViews(rows, rays(bk)),
-                          _LazyViews(rows, lambda s: flags(s) & 1), _LazyViews(rows, lambda s: flags(s) >> 1),
+                          _LazyViews(rows, lambda s: flags(s) & 1), _LazyViews(rows, lambda s: (flags(s) >> 1) & 1),
                           n_in, n_out, bufs["mode"])
                 res.flags = _LazyViews(rows, flags)
+                res.nonconv = _LazyViews(rows, lambda s: (flags(s) >> 2) & 1)
                 return res
-            return cls(_LazyViews(rows, rays(bx)), _LazyViews(rows, rays(bk)), _LazyViews(rows, mask(bv)),
-                       _LazyViews(rows, (mask(bw) if bw is not None else (lambda s: None))),
-                       n_in, n_out, bufs["mode"])
+            res = cls(_LazyViews(rows, rays(bx)), _LazyViews(rows, rays(bk)), _LazyViews(rows, mask(bv)),
+                      _LazyViews(rows, (mask(bw) if bw is not None else (lambda s: None))),
+                      n_in, n_out, bufs["mode"])
+            if bufs.get("nonconv") is not None:
+                res.nonconv = _LazyViews(rows, mask(bufs["nonconv"]))
+            return res
         # concatenated layout (tables with anisotropic media)
         off_in = [0]
         off_out = [0]
@@ -136,12 +141,16 @@ class TraceResult(object):
             (er, ei) = (bufs["e_re"], bufs["e_im"])
             e_views = _LazyViews(rows, lambda s: (er[3 * off_out[s]:3 * off_out[s + 1]].view(3, n_out[s]),
                                                   ei[3 * off_out[s]:3 * off_out[s + 1]].view(3, n_out[s])))
-        return cls(
+        res = cls(
             _LazyViews(rows, lambda s: bx[3 * off_in[s]:3 * off_in[s + 1]].view(3, n_in[s])),
             _LazyViews(rows, lambda s: bk[3 * off_out[s]:3 * off_out[s + 1]].view(3, n_out[s])),
             _LazyViews(rows, lambda s: bv[off_in[s]:off_in[s + 1]]),
             _LazyViews(rows, (lambda s: bw[off_out[s]:off_out[s + 1]]) if bw is not None else (lambda s: None)),
             n_in, n_out, bufs["mode"], e_out=e_views)
+        if bufs.get("nonconv") is not None:
+            bn = bufs["nonconv"]
+            res.nonconv = _LazyViews(rows, lambda s: bn[off_in[s]:off_in[s + 1]])
+        return res
 
 
 class DeviceSystem(object):
@@ -181,7 +190,7 @@ class DeviceSystem(object):
         return list(n_in), list(n_out)
 
     def alloc_outputs(self, n0, mode=_lib.MODE_PATH, with_valid_out=True, pitch=None, want_fields=False,
-                      packed_flags=False, placement="auto", extra_bytes=()):
+                      packed_flags=False, placement="auto", extra_bytes=(), want_nonconv=False):
         """Output buffers for trace_into.  All-isotropic tables get ROW-PITCHED arrays
         ((S,3,pitch) / (S,pitch), pitch = prt_recommended_pitch(n0) unless given: rows aligned
         to 128-B lines are worth ~35 % HBM write bandwidth); tables with anisotropic media get
@@ -240,6 +249,8 @@ class DeviceSystem(object):
                 valid_out=(torch.empty(nw, dtype=torch.uint8, device=dev) if with_valid_out else None),
                 extra=[], placement={"policy": "torch"})
         bufs.update(n_in=n_in, n_out=n_out, mode=mode, pitch=pitch, packed_flags=bool(packed_flags))
+        if want_nonconv and not packed_flags:      # packed flags carry the bit themselves (bit 2)
+            bufs["nonconv"] = torch.zeros(nv, dtype=torch.uint8, device=dev)
         if want_fields:
             if self.all_isotropic:
                 raise ValueError("E fields are produced at crystal interfaces only")
@@ -264,7 +275,8 @@ class DeviceSystem(object):
         _lib.check(self.lib.prt_trace(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
                                       _ptr(e0_im), _mode_word(bufs), bufs["pitch"], _ptr(bufs["x_hit"]),
                                       _ptr(bufs["k_out"]), _ptr(bufs["valid"]),
-                                      _ptr(bufs["valid_out"]), _stream_handle(self.device)))
+                                      _ptr(bufs["valid_out"]), _ptr(bufs.get("nonconv")),
+                                      _stream_handle(self.device)))
 
     def trace_moments_into(self, x0, k0, bufs, ws, slot=0, e0_re=None, e0_im=None, ref=None):
         """trace_into + the image-plane moments of the traced bundle from the same launch
@@ -313,8 +325,10 @@ class DeviceSystem(object):
         return ms.value
 
     def trace(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH, want_fields=False,
-              packed_flags=False):
-        """OpticalSystem.seqtrace on device tensors; returns a TraceResult of views."""
+              packed_flags=False, want_nonconv=False):
+        """OpticalSystem.seqtrace on device tensors; returns a TraceResult of views.
+        ``want_nonconv``: also fill ``TraceResult.nonconv`` (per surface, 1 where the Newton iteration of
+        an explicit shape ended at its cap; with ``packed_flags`` it is always there, bit 2 of the flags)."""
         n0 = x0.shape[1]
         pitches = set()
         for (t, name) in ((x0, "x0"), (k0, "k0"), (e0_re, "e0_re"), (e0_im, "e0_im")):
@@ -325,7 +339,8 @@ class DeviceSystem(object):
             (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
         with torch.cuda.device(self.device):
             bufs = self.alloc_outputs(n0, mode, want_fields=want_fields,
-                                      packed_flags=packed_flags and self.all_isotropic)
+                                      packed_flags=packed_flags and self.all_isotropic,
+                                      want_nonconv=want_nonconv and not want_fields)
             self.trace_into(x0, k0, bufs, e0_re, e0_im)
         return self.views(bufs)
 
@@ -335,19 +350,21 @@ class DeviceSystem(object):
 
     # -- per-surface plugin granularity -------------------------------------
     def propagate(self, surface, x, k, direction=None, e_re=None, e_im=None,
-                  default_e=True, valid_in=None):
-        """Material.propagate / Surface.intersect for one surface."""
+                  default_e=True, valid_in=None, want_nonconv=False):
+        """Material.propagate / Surface.intersect for one surface.  Returns (x_hit, valid), with
+        ``want_nonconv`` (x_hit, valid, nonconv)."""
         (x, k, direction, e_re, e_im) = [_rows_contiguous(t) for t in (x, k, direction, e_re, e_im)]
         _check_rays(x, "x")
         n = x.shape[1]
         with torch.cuda.device(self.device):
             x_hit = torch.empty((3, n), dtype=torch.float64, device=self.device)
             valid = torch.empty(n, dtype=torch.uint8, device=self.device)
+            nonconv = torch.empty(n, dtype=torch.uint8, device=self.device) if want_nonconv else None
             _lib.check(self.lib.prt_propagate(self._h, surface, n, _ptr(x), _ptr(k),
                                               _ptr(direction), _ptr(e_re), _ptr(e_im),
                                               1 if default_e else 0, _ptr(valid_in), _ptr(x_hit),
-                                              _ptr(valid), _stream_handle(self.device)))
-        return x_hit, valid
+                                              _ptr(valid), _ptr(nonconv), _stream_handle(self.device)))
+        return (x_hit, valid, nonconv) if want_nonconv else (x_hit, valid)
 
     def interact(self, surface, x_hit, k, valid_in=None, want_e=False):
         """Material.refract / reflect at one surface.  Returns
@@ -473,6 +490,67 @@ def collimated_bundle_device(nray, radius, start, kvec, evec, device, lo=0, hi=N
                                              _ptr(bufs[0]), _ptr(bufs[1]), _ptr(bufs[2]),
                                              _stream_handle(device)))
     return bufs[0][:, :n], bufs[1][:, :n], bufs[2][:, :n], total
+
+
+def _raster_struct(tables):
+    """prt_raster_t for one (xa, xb, ya, yb, clip) entry of ``raster.device_tables`` (keeps the arrays alive)"""
+    (xa, xb, ya, yb, clip) = tables
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (xa, xb, ya, yb)]
+    r = _lib.PrtRaster()
+    (r.nj, r.ni) = (arrs[0].shape[0], arrs[1].shape[0])
+    if arrs[2].shape[0] != r.nj or arrs[3].shape[0] != r.ni:
+        raise ValueError("raster tables: xa, ya need nj entries, xb, yb ni entries")
+    (r.xa, r.xb, r.ya, r.yb) = [a.ctypes.data for a in arrs]
+    r.clip = 1 if clip else 0
+    r._keepalive = arrs
+    return r
+
+
+def raster_bundle_device(tables_list, kind, device, radius=1.0, start=(0., 0., 0.), anglex=0.0, angley=0.0,
+                         index=1.0, kvec=None, evec=None, lo=0, hi=None, want_pupil=False):
+    """A bundle on a pupil raster given by its outer-product tables (``raster.device_tables(nray)``),
+    generated on the GPU (prt_raster_bundle): ``kind`` "collimated" (origin = radius * p + start, kvec /
+    evec constant) or "divergent" (origin = start, directions fanned out over the pupil angles, k = index *
+    unit vector).  Rays [lo, hi) of the concatenated sub-rasters.  Returns row-pitched (3, n) views
+    (x, k, e), the total number of points and -- with ``want_pupil`` -- the (2, n) pupil samples."""
+    lib = _lib.load()
+    rasters = [_raster_struct(t) for t in tables_list]
+    counts = []
+    with torch.cuda.device(device):
+        for r in rasters:
+            c = ctypes.c_int64()
+            _lib.check(lib.prt_raster_count(device.index, ctypes.byref(r), ctypes.byref(c), _stream_handle(device)))
+            counts.append(c.value)
+    total = sum(counts)
+    if hi is None:
+        hi = total
+    if not 0 <= lo <= hi <= total:
+        raise ValueError("ray range [%d, %d) outside the raster's %d points" % (lo, hi, total))
+    n = hi - lo
+    prm = _lib.PrtBundle()
+    prm.kind = {"collimated": 0, "divergent": 1}[kind]
+    (prm.radius, prm.anglex, prm.angley, prm.index) = (float(radius), float(anglex), float(angley), float(index))
+    for q in range(3):
+        prm.start[q] = float(start[q])
+        prm.k[q] = float(kvec[q]) if kvec is not None else 0.0
+        prm.e[q] = float(evec[q]) if evec is not None else 0.0
+    pitch = recommended_pitch(max(n, 1))
+    bufs = [torch.empty((3, pitch), dtype=torch.float64, device=device) for _ in range(3)]
+    pup = torch.empty((2, pitch), dtype=torch.float64, device=device) if want_pupil else None
+    with torch.cuda.device(device):
+        base = 0                   # global index of the current sub-raster's first point
+        for (r, c) in zip(rasters, counts):
+            (a, b) = (max(lo, base), min(hi, base + c))
+            if a < b:
+                off = (a - lo) * 8
+                _lib.check(lib.prt_raster_bundle(
+                    device.index, ctypes.byref(r), a - base, b - base, ctypes.byref(prm), pitch,
+                    ctypes.c_void_p(bufs[0].data_ptr() + off), ctypes.c_void_p(bufs[1].data_ptr() + off),
+                    ctypes.c_void_p(bufs[2].data_ptr() + off),
+                    None if pup is None else ctypes.c_void_p(pup.data_ptr() + off), _stream_handle(device)))
+            base += c
+    out = (bufs[0][:, :n], bufs[1][:, :n], bufs[2][:, :n], total)
+    return out + (pup[:, :n],) if want_pupil else out
 
 
 class MomentsWorkspace(object):

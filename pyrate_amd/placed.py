@@ -165,9 +165,10 @@ class PlacedArena(object):
 
     def stats(self):
         v = (ctypes.c_int64 * 12)()
-        r = (ctypes.c_double * 3)()
-        _lib.check(self.lib.prt_arena_stats(self._h, v, 12, r, 3))
+        r = (ctypes.c_double * 4)()
+        _lib.check(self.lib.prt_arena_stats(self._h, v, 12, r, 4))
         return {"kinds_seen": v[0], "probes": v[1], "slabs_created": v[2], "slabs_released": v[3],
                 "slabs_free": v[4], "slabs_in_use": v[5], "slabs_cached": v[6], "slab_bytes": v[7],
                 "slabs_per_kind": [v[8], v[9], v[10], v[11]], "probe_same_kind_GBps": r[0],
-                "probe_cross_kind_GBps": r[1], "probe_ms_total": r[2], "tensor_wrap": self._wrap}
+                "probe_cross_kind_GBps": r[1], "probe_ms_total": r[2], "address_space_reserved_GiB": r[3] / 2 ** 30,
+                "tensor_wrap": self._wrap}

@@ -67,30 +67,41 @@ class OpticalSystemAnalysis(object):
         return (origin, k, _perp_field(k))
 
     def aim(self, numrays, rays_dict, bundletype="collimated", wave=standard_wavelength):
-        """(:167-181).  A collimated bundle on the default RectGrid raster is generated
-        directly on the GPU (prt_collimated_bundle, bit-identical samples, no H2D copy)."""
+        """(:167-181).  For the deterministic rasters (RectGrid, HexGrid, the fans, CircularGrid -- those
+        with ``device_tables``) both bundle types are generated directly on the GPU (prt_raster_bundle:
+        the pupil samples are the reference's bit for bit, nothing is uploaded); random rasters and
+        hand-picked rays are sampled on the host."""
         rays_dict = rays_dict or {}
-        if bundletype == "collimated" and type(rays_dict.get("raster", RectGrid())) is RectGrid:
-            self.initial_bundles = [self._collimated_bundle_on_device(numrays, rays_dict, wave)]
+        if bundletype not in ("collimated", "divergent"):
+            raise KeyError(bundletype)
+        rasterobj = rays_dict.get("raster", RectGrid())
+        tables = rasterobj.device_tables(numrays) if hasattr(rasterobj, "device_tables") else None
+        if tables is not None:
+            self.initial_bundles = [self._bundle_on_device(tables, bundletype, rays_dict, wave)]
             return
         call = {"collimated": self.collimated_bundle, "divergent": self.divergent_bundle}
         (o, k, e) = call[bundletype](numrays, rays_dict, wave=wave)
         self.initial_bundles = [RayBundle(x0=o, k0=k, Efield0=e, wave=wave)]
 
-    def _collimated_bundle_on_device(self, nrays, pd, wave):
+    def _bundle_on_device(self, tables, bundletype, pd, wave):
         (angley, anglex) = (pd.get("angley", 0.0), pd.get("anglex", 0.0))
+        index = self._background_index(wave)
+        start = (pd.get("startx", 0.), pd.get("starty", 0.), pd.get("startz", 0.))
+        dev = default_device()
+        if bundletype == "divergent":
+            (x, k, e, _) = engine.raster_bundle_device(tables, "divergent", dev, radius=pd.get("radius", 45.0 * degree),
+                                                       start=start, anglex=anglex, angley=angley, index=index)
+            return RayBundle(x0=x, k0=k, Efield0=e, wave=wave, device=dev)
         unit = np.array([math.sin(angley) * math.cos(anglex), math.sin(anglex),
                          math.cos(angley) * math.cos(anglex)])
-        kvec = self._background_index(wave) * unit
+        kvec = index * unit
         # one unit vector perpendicular to k for the whole bundle (same rule as prt_efield_perp)
         axis = np.eye(3)[int(np.argmin(np.abs(kvec)))] if abs(kvec[1]) > min(abs(kvec[0]), abs(kvec[2])) \
             else np.array([0., 1., 0.])
         evec = np.cross(kvec, axis)
         evec = evec / np.linalg.norm(evec)
-        dev = default_device()
-        (x, k, e, _) = engine.collimated_bundle_device(
-            nrays, pd.get("radius", 1.0), (pd.get("startx", 0.), pd.get("starty", 0.), pd.get("startz", 0.)),
-            kvec, evec, dev)
+        (x, k, e, _) = engine.raster_bundle_device(tables, "collimated", dev, radius=pd.get("radius", 1.0),
+                                                   start=start, kvec=kvec, evec=evec)
         return RayBundle(x0=x, k0=k, Efield0=e, wave=wave, device=dev)
 
     def trace(self, **kwargs):

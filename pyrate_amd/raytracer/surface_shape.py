@@ -7,8 +7,11 @@ Surface shapes with the reference's interface (raytracer/surface_shape.py): ``Co
 
 Deliberate difference to the reference (SURVEY.md headline 4): the explicit shapes'
 ``intersect`` does per-ray Newton to machine precision instead of one N-dimensional
-``scipy.optimize.fsolve`` with xtol=1e-6; ``annotations["tol"]`` is kept but unused,
-``annotations["iterations"]`` caps the Newton iterations.
+``scipy.optimize.fsolve`` with xtol=1e-6; ``annotations["tol"]`` and ``annotations["iterations"]``
+are kept but unused (the reference does not hand ``iterations`` to its solver either,
+surface_shape.py:457).  The device iteration cap is 30; ``annotations["newton_maxit"]`` overrides it.
+Rays that end at the cap are reported in the ``nonconv`` mask of ``prt_trace`` / ``prt_propagate``
+(``DeviceSystem.trace(want_nonconv=True)``), their ``valid`` stays True like in the reference.
 """
 import numpy as np
 import torch

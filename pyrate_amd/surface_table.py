@@ -194,7 +194,13 @@ def describe_material(material, wave):
 def surface_record(surface, material, is_mirror, wave):
     """One table record: ``surface`` is hit, ``material`` is the medium the ray is in
     after the interaction (for a mirror: the medium it stays in)."""
+    # device-side Newton cap of explicit shapes: annotations["newton_maxit"] (0 / absent: the engine's
+    # default of 30).  The reference's annotations["iterations"] never reaches its solver either
+    # (surface_shape.py:457 passes only xtol) and is deliberately not used as the cap.
+    annotations = getattr(surface.shape, "annotations", None) or {}
+    cap = int(annotations.get("newton_maxit", 0) or 0)
     return {
+        **({"newton_maxit": cap} if cap > 0 else {}),
         "shape": describe_shape(surface.shape),
         "B_shape": _mat33(surface.shape.lc.localbasis),
         "g_shape": _vec3(surface.shape.lc.globalcoordinates),

@@ -360,3 +360,66 @@ def test_raytrace_prism_like_the_reference_demo(gpu_device, tag, wave):
     assert np.allclose(rp.raybundles[0].x[0], case.x0, rtol=0, atol=1e-14)
     assert np.allclose(np.real(rp.raybundles[0].k[0]), np.real(case.k0), rtol=0, atol=1e-15)
     assert_paths_match(rp, case.raw_bundles)
+
+
+def test_device_bundles_on_every_deterministic_raster_equal_the_reference(gpu_device):
+    """collimated AND divergent bundles generated on the GPU (prt_raster_bundle) on RectGrid,
+    HexGrid, Meridional / SagitalFan and CircularGrid, in air and in a dense background medium, against
+    the reference's own bundles (tests/golden/bundles.json, oracle/make_golden.py): pupil samples and
+    origins bit for bit, wave vectors to 2e-15 (device sin / cos vs libm: a few ulp; the reference itself
+    gets k from a per-ray eigenproblem), |k| = n, E a unit vector perpendicular to k; shards of the
+    raster equal slices of the whole"""
+    import json
+    import os
+    import torch
+    from pyrate_amd import engine
+    from pyrate_amd.sampling2d import raster
+    ref = json.load(open(os.path.join(_golden.GOLDEN_DIR, "bundles.json")))
+    objs = {"rect_60": raster.RectGrid(), "hex_45": raster.HexGrid(), "meridional_9": raster.MeridionalFan(),
+            "sagital_8": raster.SagitalFan(), "circular_49": raster.CircularGrid()}
+    for (key, case) in ref.items():
+        pd = case["props"]
+        tables = objs[case["raster"]].device_tables(case["nray"])
+        (gx, gy) = objs[case["raster"]].getGrid(case["nray"])
+        start = (pd["startx"], pd["starty"], pd["startz"])
+        kw = dict(radius=pd["radius"], start=start, anglex=pd["anglex"], angley=pd["angley"], index=case["index"])
+        if case["bundle"] == "collimated":
+            unit = np.array([math.sin(pd["angley"]) * math.cos(pd["anglex"]), math.sin(pd["anglex"]),
+                             math.cos(pd["angley"]) * math.cos(pd["anglex"])])
+            kw.update(kvec=case["index"] * unit, evec=np.array([1.0, 0.0, 0.0]))
+        (x, k, e, total, pup) = engine.raster_bundle_device(tables, case["bundle"], gpu_device, want_pupil=True, **kw)
+        (xr, kr) = (np.array(case["x"]), np.array(case["k"]))
+        assert total == xr.shape[1] == gx.shape[0], key
+        assert np.array_equal(pup.cpu().numpy(), np.vstack((gx, gy))), key
+        assert np.array_equal(x.cpu().numpy(), xr), key
+        kd = k.cpu().numpy()
+        assert np.abs(kd - kr).max() < 2e-15, (key, np.abs(kd - kr).max())
+        assert np.abs(np.sqrt((kd ** 2).sum(axis=0)) - case["index"]).max() < 4e-16, key
+        if case["bundle"] == "divergent":
+            ed = e.cpu().numpy()
+            assert np.abs((ed * kd).sum(axis=0)).max() < 1e-15 and np.abs((ed ** 2).sum(axis=0) - 1).max() < 1e-15
+        # a shard that straddles the two lattices of the hex raster / an arbitrary slice of the others
+        (lo, hi) = (total // 3, total // 3 + max(1, total // 2))
+        (xs, ks, es, _) = engine.raster_bundle_device(tables, case["bundle"], gpu_device, lo=lo, hi=hi, **kw)
+        assert torch.equal(xs, x[:, lo:hi]) and torch.equal(ks, k[:, lo:hi])
+
+
+def test_aim_generates_divergent_and_fan_bundles_on_the_device(gpu_device):
+    """OpticalSystemAnalysis.aim (optical_system_analysis.py:167-181) with a divergent bundle on a fan: the
+    initial bundle is device resident (nothing uploaded) and equals the host form of divergent_bundle;
+    tracing it gives the same path as tracing the host bundle"""
+    from pyrate_amd.raytracer.analysis.optical_system_analysis import OpticalSystemAnalysis
+    from pyrate_amd.sampling2d import raster
+    api = zoo.mirror_api()
+    (s, seq) = zoo.doublet(api)
+    osa = OpticalSystemAnalysis(s, seq)
+    props = {"startz": -40.0, "radius": 0.2, "raster": raster.MeridionalFan()}
+    osa.aim(15, props, bundletype="divergent", wave=zoo.DLINE)
+    ib = osa.initial_bundles[0]
+    (o, k, e) = osa.divergent_bundle(15, props, wave=zoo.DLINE)
+    assert np.array_equal(ib.x[0], o) and np.abs(np.real(ib.k[0]) - k).max() < 1e-15
+    paths_dev = osa.trace()[0]
+    from pyrate_amd.raytracer.ray import RayBundle
+    paths_host = s.seqtrace(RayBundle(x0=o, k0=k, Efield0=e, wave=zoo.DLINE), seq)
+    for (a, b) in zip(paths_dev[0].raybundles, paths_host[0].raybundles):
+        assert np.allclose(a.x, b.x, rtol=0, atol=1e-12) and np.array_equal(a.valid, b.valid)

@@ -606,3 +606,54 @@ def test_a_rays_result_does_not_depend_on_its_position_in_the_bundle(system, gpu
             assert torch.equal(a.x_hit[s][:, 1:].contiguous().view(torch.int64), b.x_hit[s].contiguous().view(torch.int64))
             assert torch.equal(a.k_out[s][:, 1:].contiguous().view(torch.int64), b.k_out[s].contiguous().view(torch.int64))
             assert torch.equal(a.valid_out[s][1:], b.valid_out[s])
+
+
+def test_nonconvergence_mask_flags_capped_newton_rays_and_leaves_valid_alone(gpu_device):
+    """ABI v4: the optional ``nonconv`` mask of prt_trace / prt_propagate.  The reference's
+    ExplicitShape.intersect reports valid = True for every ray, converged or not (surface_shape.py:462);
+    the engine keeps ``valid`` that way, poisons the hit point of a ray whose Newton iteration ended at
+    its cap with NaN and says so in ``nonconv`` -- so a caller can tell it from a ray that left the
+    domain of a conic (valid = 0, nonconv = 0)."""
+    from pyrate_amd import engine, systems, _lib
+    (o, k, e0) = systems.double_gauss_bundle(20000, rpup=9.0, z0=-5.0, field_deg=5.0)
+    (x0, k0, e0d) = [engine.to_device_rays(a, gpu_device) for a in (o, k, e0)]
+    n = o.shape[1]
+    recs = systems.asphere_records(coefficients=(1e-3, -1e-6, 1e-8), curv=-1. / 30., cc=-1.5)
+    # default cap (30 iterations): everything converges, nothing is flagged
+    full = engine.DeviceSystem(recs, 0).trace(x0, k0, e0d, want_nonconv=True)
+    assert all(int(full.nonconv[s].sum()) == 0 for s in range(4))
+    # a cap of 2 iterations at the asphere (surface 2): most rays end at the cap
+    capped_recs = [dict(r) for r in recs]
+    capped_recs[2]["newton_maxit"] = 2
+    sysc = engine.DeviceSystem(capped_recs, 0)
+    res = sysc.trace(x0, k0, e0d, want_nonconv=True)
+    nc = res.nonconv[2].bool()
+    assert 0.5 * n < int(nc.sum()) <= n
+    assert int(res.nonconv[0].sum()) == int(res.nonconv[1].sum()) == int(res.nonconv[3].sum()) == 0
+    # valid after the propagate stays reference-compatible (True); the hit point of a capped ray is NaN,
+    # the refraction that follows drops it; rays that did converge equal the uncapped trace bit for bit
+    assert torch.equal(res.valid[2], full.valid[2]) and bool(res.valid[2].bool().all())
+    assert bool(torch.isnan(res.x_hit[2][:, nc]).all()) and not bool(res.valid_out[2].bool()[nc].any())
+    assert torch.equal(res.x_hit[2][:, ~nc], full.x_hit[2][:, ~nc])
+    assert torch.equal(res.valid_out[2][~nc], full.valid_out[2][~nc])
+    # packed flags carry the same bit (bit 2), image mode reports the last surface only
+    packed = sysc.trace(x0, k0, e0d, packed_flags=True)
+    assert torch.equal(packed.nonconv[2], res.nonconv[2]) and torch.equal(packed.valid[2], res.valid[2])
+    assert torch.equal(packed.valid_out[2], res.valid_out[2])
+    assert torch.equal(packed.flags[2], res.valid[2] | (res.valid_out[2] << 1) | (res.nonconv[2] << 2))
+    img = sysc.trace(x0, k0, e0d, mode=_lib.MODE_IMAGE, want_nonconv=True)
+    assert int(img.nonconv[0].sum()) == 0
+    # the per-surface entry point reports the same rays
+    # (direction k/|k| like behind a refraction; with the default E = ey the first-segment rule would send
+    # these rays exactly along z, where g(t) is linear and Newton is done after one step)
+    (xh, v, pnc) = sysc.propagate(2, res.x_hit[1].contiguous(), res.k_out[1].contiguous(),
+                                  valid_in=res.valid_out[1], default_e=False, want_nonconv=True)
+    assert torch.equal(pnc, res.nonconv[2])
+    (_, _, pnc_z) = sysc.propagate(2, res.x_hit[1].contiguous(), res.k_out[1].contiguous(),
+                                   valid_in=res.valid_out[1], default_e=True, want_nonconv=True)
+    assert int(pnc_z.sum()) == 0
+    # a ray that misses a conic is invalid but NOT non-converged; an all-conic table zeroes the mask
+    dg = engine.DeviceSystem(systems.double_gauss_records(), 0)
+    (ow, kw, ew) = systems.double_gauss_bundle(5000, rpup=14.0, field_deg=12.0)
+    wide = dg.trace(*[engine.to_device_rays(a, gpu_device) for a in (ow, kw, ew)], want_nonconv=True)
+    assert int((~wide.valid[-1].bool()).sum()) > 0 and all(int(wide.nonconv[s].sum()) == 0 for s in range(12))
