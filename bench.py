@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--placement", choices=["arena", "torch"], default="arena",
                     help="where the path arrays come from: the engine's placement-aware arena (default; what "
                          "DeviceSystem.trace uses for arrays of this size) or the torch allocator")
+    ap.add_argument("--inputs", choices=["arena", "torch"], default="arena",
+                    help="where the input arrays x0, k0, E0 live: in a third kind of HBM from the arena (default: "
+                         "what engine.ray_rows / RayBundle do for bundles of this size) or in torch-allocated arrays")
     ap.add_argument("--two-mask-arrays", action="store_true",
                     help="write valid and valid_out as two byte arrays (50 B per record) instead of one "
                          "byte of packed flags (49 B, default)")
@@ -292,8 +295,21 @@ def main():
     placement = args.placement if (iso and mode == _lib.MODE_PATH) else "torch"
     # one row pitch on every rank: a gathered row is read n_pad elements deep (pdist.ImagePlaneGather)
     pitch = engine.recommended_pitch(pdist.shard_stride(n_total, n_gpus)) if iso else None
+    # The input arrays: big bundles are generated straight into arena memory of a kind the path arrays do
+    # not use (engine.ray_rows; loads that share a kind of HBM with the march's write streams cost it
+    # 5 %).  --inputs torch moves them into torch-allocated arrays instead (A/B).
+    if args.inputs == "torch" and iso:
+        moved = []
+        for t in (x0, k0, e0d):
+            buf = torch.empty((3, t.stride(0)), dtype=torch.float64, device=dev)[:, :n_local]
+            buf.copy_(t)
+            moved.append(buf)
+        (x0, k0, e0d) = moved
+        torch.cuda.synchronize()
     bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed, placement=placement, pitch=pitch)
             for _ in range(n_out_bufs)]
+    arena_obj = placed.PlacedArena.for_device(local_rank) if placement == "arena" else None
+    input_kind = arena_obj.kind_of(x0) if arena_obj is not None else None
     host_staged = (args.backend == "gloo")
     stats = [pdist.SpotStatistics(dev, n_rays=n_local) for _ in range(nbuf)] if do_stats else []
     gathers = ([pdist.ImagePlaneGather(n_total, dev, stage_on_host=host_staged)
@@ -448,7 +464,7 @@ def main():
             else:
                 roofline = dict(hbm, note="FP64-VALU bound kernel; no flop count on file for this size "
                                           "(profiles/fp64_flops.json), HBM fraction shown")
-        arena_stats = placed.PlacedArena.for_device(local_rank).stats() if placement == "arena" else None
+        arena_stats = arena_obj.stats() if arena_obj is not None else None
         out = {
             "metric": "ray_surface_ops_per_s", "value": value, "unit": "ray-surface-ops/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -463,6 +479,8 @@ def main():
                        "wavelengths": len(sysds), "prewarm_launches": PREWARM_LAUNCHES,
                        "output_placement": {"policy": bufs[0]["placement"]["policy"],
                                             "memory_kinds_of_x_hit_and_k_out": bufs[0]["placement"].get("kinds"),
+                                            "memory_kind_of_inputs": input_kind,
+                                            "inputs": "arena" if input_kind is not None else "torch allocator",
                                             "arena": arena_stats},
                        "image_plane_exchange": {
                            "per_step": {"gather": "spot moments from the trace kernel + one 7-double all-reduce, then "

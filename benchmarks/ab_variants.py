@@ -22,7 +22,16 @@ dev = torch.device("cuda", 0)
 sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
 (x0, k0, e0d, n) = systems.double_gauss_bundle_device(10000000, dev)
 placement = "torch" if len(sys.argv) > 1 and sys.argv[1] == "torch" else "arena"
-bufs = sysd.alloc_outputs(n, packed_flags=True, placement=placement)
+pitch_in = x0.stride(0)
+bufs = sysd.alloc_outputs(n, packed_flags=True, placement=placement,
+                          extra_bytes=([9 * pitch_in * 8] if placement == "arena" else ()))
+inputs = {"torch": (x0, k0, e0d)}
+if placement == "arena":
+    rows = bufs["extra"][0][:9 * pitch_in * 8].view(torch.float64).view(9, pitch_in)
+    placed_in = (rows[0:3, :n], rows[3:6, :n], rows[6:9, :n])
+    for (dst, src) in zip(placed_in, (x0, k0, e0d)):
+        dst.copy_(src)
+    inputs["arena"] = placed_in
 img = sysd.alloc_outputs(n, _lib.MODE_IMAGE, packed_flags=True)
 libs = {"in-tree": (sysd.lib, sysd._h)}
 for path in sorted(glob.glob(os.path.join(ROOT, "scratch", "variants", "libprt_*.so"))):
@@ -38,9 +47,10 @@ st = engine._stream_handle(dev)
 P = engine._ptr
 
 
-def timed(lib, h, b, iters):
+def timed(lib, h, b, iters, where="torch"):
+    (xi, ki, ei) = inputs[where]
     ms = ctypes.c_double()
-    rc = lib.prt_trace_timed(h, n, sysd._in_pitch(x0, k0, e0d, None), P(x0), P(k0), P(e0d), None,
+    rc = lib.prt_trace_timed(h, n, pitch_in, P(xi), P(ki), P(ei), None,
                              engine._mode_word(b), b["pitch"], P(b["x_hit"]), P(b["k_out"]), P(b["valid"]),
                              None, st, iters, ctypes.byref(ms))
     assert rc == 0, rc
@@ -48,10 +58,14 @@ def timed(lib, h, b, iters):
 
 
 timed(*libs["in-tree"], bufs, 40)
-out = {"placement": bufs["placement"], "path_ms": {k: [] for k in libs}, "image_ms": {k: [] for k in libs}}
+out = {"placement": bufs["placement"]}
+for where in inputs:
+    out["path_ms_inputs_" + where] = {k: [] for k in libs}
+    out["image_ms_inputs_" + where] = {k: [] for k in libs}
 for rep in range(4):
-    for (tag, b, it) in (("path_ms", bufs, 20), ("image_ms", img, 30)):
-        for (name, (lib, h)) in libs.items():
-            timed(lib, h, b, 2)
-            out[tag][name].append(round(timed(lib, h, b, it), 4))
+    for where in inputs:
+        for (tag, b, it) in (("path_ms", bufs, 20), ("image_ms", img, 30)):
+            for (name, (lib, h)) in libs.items():
+                timed(lib, h, b, 2, where)
+                out[tag + "_inputs_" + where][name].append(round(timed(lib, h, b, it, where), 4))
 print(json.dumps(out))

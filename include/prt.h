@@ -387,17 +387,24 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
  * representatives, at most PRT_ARENA_MAX_KINDS GiB, stay with the arena), and maps slabs of ONE kind
  * to contiguous virtual addresses for every buffer.
  *
- *   prt_arena_alloc   n_parts (<= 8) buffers of bytes[i] bytes (rounded up to whole slabs).  Parts 0
- *                     and 1 are placed in two DIFFERENT kinds (pass x_hit and k_out there); further
- *                     parts get a kind no other part of the call uses when slabs of one are at hand.
- *                     To find a second kind the arena may take up to max_hunt_slabs extra slabs
- *                     from the driver for the duration of the call (-1: default 128); if the device
- *                     has no second kind to offer the call still succeeds and kinds[] tells.
+ *   prt_arena_alloc   n_parts (<= 8) buffers of bytes[i] bytes (rounded up to whole slabs).  The first
+ *                     n_distinct parts (-1: 2) are placed in pairwise DIFFERENT kinds (pass x_hit
+ *                     and k_out there, and the input arrays as a third: reads that share a kind with
+ *                     the write streams cost 3 % of the march); further parts get a kind no other part
+ *                     of the call uses when slabs of one are at hand.  To find the kinds the arena
+ *                     may take up to max_hunt_slabs extra slabs from the driver for the duration
+ *                     of the call (-1: default 128); if the device cannot offer that many kinds
+ *                     the call still succeeds and kinds[] tells.  avoid_mask (bit q = kind q):
+ *                     kinds this request leaves to others if it can -- a caller that allocates its
+ *                     input arrays separately passes 3, which keeps them out of kinds 0 and 1, the
+ *                     ones a two-part output request takes first.
  *                     ptrs[i] are ordinary device pointers, 2-MiB aligned.  The probe runs on
  *                     `stream`; the call synchronises it.
- *   prt_arena_free    returns a buffer (pointer as given by prt_arena_alloc).  Waits for the device
- *                     to finish work that may still use it.  The buffer stays mapped and serves the
- *                     next request of the same size and kind without any driver call.
+ *   prt_arena_free    returns a buffer (pointer as given by prt_arena_alloc).  Does not block: an event
+ *                     recorded on `stream` -- the stream of the last work that uses the buffer --
+ *                     marks the release; the next prt_arena_alloc that hands the buffer out makes
+ *                     its stream wait for that event.  The buffer stays mapped and serves the next
+ *                     request of the same size and kind without any driver call.
  *   prt_arena_trim    hands all cached (unused) memory back to the driver.
  *   prt_arena_kind_of kind index of a pointer inside one of the arena's buffers.
  *   prt_arena_stats   out[0..12): kinds seen, probes run, slabs created, slabs released, free slabs,
@@ -414,8 +421,9 @@ typedef struct prt_arena prt_arena_t;
 int32_t prt_arena_create(int32_t device, prt_arena_t **out);
 int32_t prt_arena_destroy(prt_arena_t *arena);
 int32_t prt_arena_alloc(prt_arena_t *arena, int32_t n_parts, const int64_t *bytes, void **ptrs,
-                        int32_t *kinds, int32_t max_hunt_slabs, void *stream);
-int32_t prt_arena_free(prt_arena_t *arena, void *ptr);
+                        int32_t *kinds, int32_t n_distinct, int32_t avoid_mask, int32_t max_hunt_slabs,
+                        void *stream);
+int32_t prt_arena_free(prt_arena_t *arena, void *ptr, void *stream);
 int32_t prt_arena_trim(prt_arena_t *arena);
 int32_t prt_arena_kind_of(prt_arena_t *arena, const void *ptr, int32_t *kind);
 int32_t prt_arena_stats(prt_arena_t *arena, int64_t *out, int32_t n_out, double *rates, int32_t n_rates);

@@ -135,8 +135,8 @@ PROTOTYPES["prt_arena_create"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.POINTE
 PROTOTYPES["prt_arena_destroy"] = (ctypes.c_int32, [ctypes.c_void_p])
 PROTOTYPES["prt_arena_alloc"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64),
                                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int32),
-                                                 ctypes.c_int32, c_stream])
-PROTOTYPES["prt_arena_free"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p])
+                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_stream])
+PROTOTYPES["prt_arena_free"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, c_stream])
 PROTOTYPES["prt_arena_trim"] = (ctypes.c_int32, [ctypes.c_void_p])
 PROTOTYPES["prt_arena_kind_of"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)])
 PROTOTYPES["prt_arena_stats"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int32,

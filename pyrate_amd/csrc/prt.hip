@@ -482,11 +482,11 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
         int n_aniso = 0;
         for (int s = 0; s < sys->n_surfaces; ++s)
             if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC) ++n_aniso;
-        // The fused march re-traces shared prefixes (2^(A-1) passes per thread).  Measured at 1e6
-        // rays through the doublet of config 4 against the per-surface march: uniaxial 0.28 vs
-        // 0.41 ms, one biaxial crystal 0.32 vs 0.42 ms, two biaxial crystals 0.35 vs 0.43 ms; for
-        // many interfaces the recomputation grows like 2^(A-1) S and the per-surface march wins.
-        if (per_surface || n_aniso > 4)
+        // The fused march walks the tree of split rays depth first inside one launch (k_trace_general);
+        // the per-surface march (one launch pair per surface, intermediate arrays) remains for
+        // sequences with more crystal interfaces than the kernel has parking slots, and as the
+        // independent implementation PRT_GENERAL_PER_SURFACE=1 selects for cross-checks.
+        if (per_surface || n_aniso > PRT_FUSED_MAX_CRYSTALS)
             return trace_general(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, e_out, e_out_im, valid, valid_out,
                                  nonconv, st);
         const dim3 grid(nblocks(n0, PRT_BLOCK)), block(PRT_BLOCK);

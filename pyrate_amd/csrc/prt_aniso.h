@@ -310,22 +310,61 @@ PRT_DEV void interact_anisotropic(const prt_dev_surface *__restrict__ sf, const 
         }
     }
 
-    // eigenvectors, Poynting vectors and S.n
-    vec3 kk[4], ee_[4], ss[4];
+    // eigenvectors and S.n of the four solutions.  Only E (scaled) and S.n are kept per solution --
+    // k = kpa + xi n and S are a handful of operations to rebuild for the two solutions that leave,
+    // and holding all four (k, E, S) triples cost 24 more live doubles at the kernel's register peak
+    vec3 ee_[4];
     double sn[4];
+    const vec3 caxis = v3(sf->aniso_axis[0], sf->aniso_axis[1], sf->aniso_axis[2]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const vec3 kv = v3(kpa.x + xi[i] * n.x, kpa.y + xi[i] * n.y, kpa.z + xi[i] * n.z);
         const double k2 = dot(kv, kv);
-        const vec3 w0 = v3(eps[0] - k2 + kv.x * kv.x, eps[1] + kv.x * kv.y, eps[2] + kv.x * kv.z);
-        const vec3 w1 = v3(eps[3] + kv.y * kv.x, eps[4] - k2 + kv.y * kv.y, eps[5] + kv.y * kv.z);
-        const vec3 w2 = v3(eps[6] + kv.z * kv.x, eps[7] + kv.z * kv.y, eps[8] - k2 + kv.z * kv.z);
-        vec3 E = null_vector(w0, w1, w2, variant[i]);
+        // Closed-form eigenvectors where the class of eps has them (a third of the instructions of the
+        // generic null vector below, which stays for biaxial crystals and for the neighbourhood of the
+        // optic axis, where the two sheets touch and these forms lose their digits):
+        //   eps = e I:                       any two orthonormal vectors perpendicular to k
+        //   eps = eo I + (ee - eo) c c^T:    ordinary  E = k x c   (perpendicular to k and to the axis),
+        //                                    extraordinary  E = (k.c) k - eo c
+        //     (W E = [k^T eps k - eo ee] c = 0 on the extraordinary sheet; D = eps E is perpendicular to k)
+        vec3 E = v3(0.0, 0.0, 0.0);
+        bool closed = false;
+        if (cls == PRT_ANISO_ISOTROPIC) {
+            const double ax = fabs(kv.x), ay = fabs(kv.y), az = fabs(kv.z);
+            const vec3 a = (ax <= ay && ax <= az) ? v3(1, 0, 0) : ((ay <= az) ? v3(0, 1, 0) : v3(0, 0, 1));
+            vec3 v1 = cross(kv, a);
+            double inv = fast_rsqrt(dot(v1, v1));
+            v1 = v3(v1.x * inv, v1.y * inv, v1.z * inv);
+            if (variant[i] == 0) {
+                E = v1;
+            } else {
+                const vec3 v2 = cross(kv, v1);
+                inv = fast_rsqrt(dot(v2, v2));
+                E = v3(v2.x * inv, v2.y * inv, v2.z * inv);
+            }
+            closed = true;
+        } else if (cls == PRT_ANISO_UNIAXIAL) {
+            const vec3 kxc = cross(kv, caxis);
+            const double q = dot(kxc, kxc);
+            closed = q > 1e-8 * k2;  // sin^2 of the angle to the optic axis
+            const double kc = dot(kv, caxis);
+            const vec3 ex = v3(kc * kv.x - sf->aniso_eo * caxis.x, kc * kv.y - sf->aniso_eo * caxis.y,
+                               kc * kv.z - sf->aniso_eo * caxis.z);
+            const vec3 raw = (variant[i] == 0) ? kxc : ex;
+            const double inv = fast_rsqrt(dot(raw, raw));
+            E = v3(raw.x * inv, raw.y * inv, raw.z * inv);
+        }
+        if (!closed) {
+            const vec3 w0 = v3(eps[0] - k2 + kv.x * kv.x, eps[1] + kv.x * kv.y, eps[2] + kv.x * kv.z);
+            const vec3 w1 = v3(eps[3] + kv.y * kv.x, eps[4] - k2 + kv.y * kv.y, eps[5] + kv.y * kv.z);
+            const vec3 w2 = v3(eps[6] + kv.z * kv.x, eps[7] + kv.z * kv.y, eps[8] - k2 + kv.z * kv.z);
+            E = null_vector(w0, w1, w2, variant[i]);
+        }
         const double sc = fast_rsqrt(1.0 + xi[i] * xi[i]);  // LAPACK unit-norm [xi E; E]
         E = v3(E.x * sc, E.y * sc, E.z * sc);
         const double e2 = dot(E, E), ke = dot(kv, E);
         const vec3 S = v3(e2 * kv.x - ke * E.x, e2 * kv.y - ke * E.y, e2 * kv.z - ke * E.z);
-        kk[i] = kv; ee_[i] = E; ss[i] = S;
+        ee_[i] = E;
         sn[i] = dot(S, n);
     }
     // argsort ascending by S.n (material.py:147); NaNs last like numpy.  Compare-exchange
@@ -360,10 +399,14 @@ PRT_DEV void interact_anisotropic(const prt_dev_surface *__restrict__ sf, const 
     for (int b = 0; b < 2; ++b) {
         const int src = mirror ? idx[b] : idx[2 + b];
         // pick without dynamic register indexing
-        vec3 kv = kk[0], E = ee_[0], S = ss[0];
+        vec3 E = ee_[0];
+        double x = xi[0];
 #pragma unroll
         for (int q = 1; q < 4; ++q)
-            if (src == q) { kv = kk[q]; E = ee_[q]; S = ss[q]; }
+            if (src == q) { E = ee_[q]; x = xi[q]; }
+        vec3 kv = v3(kpa.x + x * n.x, kpa.y + x * n.y, kpa.z + x * n.z);
+        const double e2 = dot(E, E), ke = dot(kv, E);
+        vec3 S = v3(e2 * kv.x - ke * E.x, e2 * kv.y - ke * E.y, e2 * kv.z - ke * E.z);
         if (mirror) {  // material_anisotropic.py:136-137: k, E negated (S is even in E, odd in k)
             kv = v3(-kv.x, -kv.y, -kv.z);
             E = v3(-E.x, -E.y, -E.z);

@@ -38,9 +38,17 @@ struct rayio {
     static PRT_DEV void load(const double *__restrict__ a, int64_t pitch, int64_t i, bool second,
                              vec3 v[2]) {
         if (VEC) {
+            // non-temporal hint: every input is read once (+1.7 % on the path-mode march, +4 % in image
+            // mode, same arrays, benchmarks/ab_variants.py; PRT_PLAIN_LOADS builds the other variant)
+#ifndef PRT_PLAIN_LOADS
+            const prt_double2 x = __builtin_nontemporal_load(reinterpret_cast<const prt_double2 *>(a + i));
+            const prt_double2 y = __builtin_nontemporal_load(reinterpret_cast<const prt_double2 *>(a + pitch + i));
+            const prt_double2 z = __builtin_nontemporal_load(reinterpret_cast<const prt_double2 *>(a + 2 * pitch + i));
+#else
             const prt_double2 x = *reinterpret_cast<const prt_double2 *>(a + i);
             const prt_double2 y = *reinterpret_cast<const prt_double2 *>(a + pitch + i);
             const prt_double2 z = *reinterpret_cast<const prt_double2 *>(a + 2 * pitch + i);
+#endif
             v[0] = v3(x.x, y.x, z.x);
             v[1] = v3(x.y, y.y, z.y);
         } else {
@@ -51,7 +59,10 @@ struct rayio {
     static PRT_DEV void store(double *__restrict__ a, int64_t pitch, int64_t i, bool second,
                               const vec3 v[2]) {
         if (VEC) {
-#ifdef PRT_NT_STORES   // experiment (benchmarks/ab_variants.py): non-temporal hint on the path stores
+            // non-temporal hint: a path array is written once and not read by this kernel again; with
+            // x_hit and k_out in two kinds of HBM it is worth 2 % (1.016 vs 1.038 ms, same arrays,
+            // benchmarks/ab_variants.py; PRT_PLAIN_STORES builds the other variant)
+#ifndef PRT_PLAIN_STORES
             __builtin_nontemporal_store(prt_double2{v[0].x, v[1].x}, reinterpret_cast<prt_double2 *>(a + i));
             __builtin_nontemporal_store(prt_double2{v[0].y, v[1].y}, reinterpret_cast<prt_double2 *>(a + pitch + i));
             __builtin_nontemporal_store(prt_double2{v[0].z, v[1].z}, reinterpret_cast<prt_double2 *>(a + 2 * pitch + i));
@@ -264,22 +275,29 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE ==
 // fused march through tables that contain anisotropic media (ray doubling).  Thread i owns
 // input ray i and ALL its descendants: with A anisotropic interfaces there are 2^A leaves,
 // leaf L having bit j = which of the two transmitted solutions is followed at the j-th crystal
-// interface.  No per-ray stack: a pass follows ONE choice at each of the first A-1 crystal
-// interfaces (2^(A-1) passes, each traced from the start) and keeps BOTH solutions of the last
-// one, marching the two children side by side through the remaining (isotropic) surfaces.
-// Recomputation instead of 2^A live states: config 4 (A = 2) costs 4 interface solves + 14
-// surface steps per input ray (minimum 3 + 12; tracing every leaf from the start, the first
-// version of this kernel, cost 8 + 20 and 0.34 instead of 0.28 ms), in one launch, with no
-// intermediate arrays and no direction buffers.  A prefix shared by several leaves is WRITTEN
-// only by the pass whose remaining bits are zero.  Outputs use the concatenated layout of
-// include/prt.h (rays of a split bundle stacked [sol2, sol3] like np.hstack,
-// material_anisotropic.py:89): at a level with a doublings, leaf L sits at i + N (L mod 2^a).
+// interface.  The tree is walked depth first: at a crystal interface the thread writes both
+// children, parks child 1 (hit point, wave vector, direction, mask: 10 values in a per-thread slot
+// of its level -- at most one parked child per level, so A slots in private memory) and goes on
+// with child 0; at the end of the sequence it resumes the deepest parked child.  Every state of
+// the tree is computed exactly once: 2^A - 1 interface solves per input ray whatever A is (the
+// previous scheme re-traced shared prefixes -- 2^(A-1) passes from the start -- and was limited to
+// A <= 4), in one launch, with no intermediate arrays and no direction buffers.  The walk is the
+// same for every ray, so control flow (surface index, level, offsets) is wave-uniform.
+// Outputs use the concatenated layout of include/prt.h (rays of a split bundle stacked
+// [sol2, sol3] like np.hstack, material_anisotropic.py:89): at a level with a doublings, leaf L
+// sits at i + N (L mod 2^a).
 // ---------------------------------------------------------------------------
-// 3 waves/SIMD: the register allocator lands at 170 VGPRs on its own (2 waves); capping it at 168
-// costs three spilled dwords and gains 11 % (0.277 -> 0.246 ms); 4 waves (128 VGPRs, 160 B of
-// scratch) is slower than either (0.36 ms).
+#define PRT_FUSED_MAX_CRYSTALS 8
+#ifdef PRT_GENERAL_NT_STORES   // experiment (benchmarks/ab_crystal.py)
+#define PRT_GSTORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define PRT_GSTORE(ptr, val) (*(ptr) = (val))
+#endif
+#ifndef PRT_GENERAL_WAVES
+#define PRT_GENERAL_WAVES 4
+#endif
 template <int MODE, bool GENERAL = true>
-__global__ __launch_bounds__(PRT_BLOCK, 3) void k_trace_general(
+__global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
     const prt_dev_surface *__restrict__ tab, int32_t S, int32_t A, int64_t N,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, double *__restrict__ xh_out,
@@ -288,30 +306,27 @@ __global__ __launch_bounds__(PRT_BLOCK, 3) void k_trace_general(
     uint8_t *__restrict__ nonconv_out = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
     if (i >= N) return;
-    const vec3 xs = v3(x0[i], x0[N + i], x0[2 * N + i]);
-    const vec3 ks = v3(k0[i], k0[N + i], k0[2 * N + i]);
-    vec3 ds;
+    vec3 x = v3(x0[i], x0[N + i], x0[2 * N + i]);
+    vec3 k = v3(k0[i], k0[N + i], k0[2 * N + i]);
+    vec3 d;
     {
-        vec3 kk[2] = {ks, ks};
+        vec3 kk[2] = {k, k};
         vec3 dd[2];
         first_direction<false>(e_mode, e_re, e_im, N, i, false, kk, dd);
-        ds = dd[0];
+        d = dd[0];
     }
-    const int64_t passes = (int64_t)1 << (A - 1);
-    for (int64_t P = 0; P < passes; ++P) {
-        vec3 x[2], k[2], d[2];
-        bool valid[2] = {true, true};
-        x[0] = xs;
-        k[0] = ks;
-        d[0] = ds;
-        double d2 = 1.0;
-        int a = 0;         // doublings so far
-        int nstate = 1;    // 2 behind the last crystal interface
-        int64_t off_in = 0, off_out = 0;
-        for (int32_t s = 0; s < S; ++s) {
+    bool valid = true;
+    double d2 = 1.0;
+    double parked[PRT_FUSED_MAX_CRYSTALS][10];  // per level: child 1 of the crystal interface of that level
+    uint32_t pending = 0;                        // levels with a parked child (wave-uniform)
+    int64_t L = 0;                               // choices made so far: bit j = child taken at level j
+    int32_t s = 0;                               // next surface
+    int a = 0;                                   // doublings so far = level of the next crystal interface
+    int64_t off_in = 0, off_out = 0;             // ray offsets of surface s in the concatenated arrays
+    for (;;) {
+        for (; s < S; ++s) {
             const prt_dev_surface *__restrict__ sf = tab + s;
-            const bool last = (s == S - 1);
-            const bool store = (MODE == PRT_MODE_PATH || last);
+            const bool store = (MODE == PRT_MODE_PATH || s == S - 1);
             const bool crystal = sf->mat_type == PRT_MAT_ANISOTROPIC;
             const int64_t n_in = N << a;
             const int a_out = crystal ? a + 1 : a;
@@ -320,89 +335,96 @@ __global__ __launch_bounds__(PRT_BLOCK, 3) void k_trace_general(
             const int64_t base_out = (MODE == PRT_MODE_PATH) ? off_out : 0;
             double *xo = xh_out + 3 * base_in;
             double *ko = k_out + 3 * base_out;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (c >= nstate) continue;
-                // leaf index of this state: bits 0..A-2 = P, bit A-1 = c
-                const int64_t L = P + ((int64_t)c << (A - 1));
-                const int64_t idx_in = i + N * (L & (((int64_t)1 << a) - 1));
-                const bool alive = valid[c];
-                vec3 xh, p, g;
-                double g2;
-                bool ncv;
-                propagate_step(sf, x[c], d[c], d2, xh, p, g, g2, valid[c], ncv);
-                if ((L >> a) == 0 && store) {
-                    xo[idx_in] = xh.x;
-                    xo[n_in + idx_in] = xh.y;
-                    xo[2 * n_in + idx_in] = xh.z;
-                    valid_out_hit[base_in + idx_in] = valid[c] ? 1 : 0;
-                    if (nonconv_out) nonconv_out[base_in + idx_in] = ncv ? 1 : 0;
-                }
-                x[c] = xh;
-                if (crystal) {  // only reached with nstate == 1 (c == 0)
-                    aniso_solution sol[2];
-                    interact_anisotropic<GENERAL>(sf, p, k[0], sol);
-                    valid[0] = alive;  // no validity filtering at a crystal interface (ray.py:68)
-                    const bool keep_both = (a == A - 1);
-                    const int pick = (int)((P >> a) & 1);
+            const int64_t Lp = L & (((int64_t)1 << a) - 1);
+            const int64_t idx_in = i + N * Lp;
+            const bool alive = valid;
+            vec3 xh, p, g;
+            double g2;
+            bool ncv;
+            propagate_step(sf, x, d, d2, xh, p, g, g2, valid, ncv);
+            if (store) {
+                PRT_GSTORE(xo + idx_in, xh.x);
+                PRT_GSTORE(xo + n_in + idx_in, xh.y);
+                PRT_GSTORE(xo + 2 * n_in + idx_in, xh.z);
+#ifndef PRT_GENERAL_NO_MASKS
+                valid_out_hit[base_in + idx_in] = valid ? 1 : 0;
+#endif
+                if (nonconv_out) nonconv_out[base_in + idx_in] = ncv ? 1 : 0;
+            }
+            x = xh;
+            if (crystal) {
+                aniso_solution sol[2];
+                interact_anisotropic<GENERAL>(sf, p, k, sol);
+                valid = alive;  // no validity filtering at a crystal interface (ray.py:68)
+                if (store) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        // child b lives at leaf bits (..., bit a = b); written by the pass that owns it
-                        const int64_t Lb = (P & (((int64_t)1 << a) - 1)) + ((int64_t)b << a);
-                        const bool mine = keep_both ? true : (b == pick && (P >> a_out) == 0);
-                        if (mine && store) {
-                            const int64_t idx_out = i + N * Lb;
-                            ko[idx_out] = sol[b].k.x;
-                            ko[n_out + idx_out] = sol[b].k.y;
-                            ko[2 * n_out + idx_out] = sol[b].k.z;
-                            if (e_out) {
-                                double *eo = e_out + 3 * base_out;
-                                eo[idx_out] = sol[b].er.x;
-                                eo[n_out + idx_out] = sol[b].er.y;
-                                eo[2 * n_out + idx_out] = sol[b].er.z;
-                                if (e_out_im) {
-                                    double *ei = e_out_im + 3 * base_out;
-                                    ei[idx_out] = sol[b].ei.x;
-                                    ei[n_out + idx_out] = sol[b].ei.y;
-                                    ei[2 * n_out + idx_out] = sol[b].ei.z;
-                                }
+                        const int64_t idx_out = i + N * (Lp + ((int64_t)b << a));
+                        PRT_GSTORE(ko + idx_out, sol[b].k.x);
+                        PRT_GSTORE(ko + n_out + idx_out, sol[b].k.y);
+                        PRT_GSTORE(ko + 2 * n_out + idx_out, sol[b].k.z);
+                        if (e_out) {
+                            double *eo = e_out + 3 * base_out;
+                            eo[idx_out] = sol[b].er.x;
+                            eo[n_out + idx_out] = sol[b].er.y;
+                            eo[2 * n_out + idx_out] = sol[b].er.z;
+                            if (e_out_im) {
+                                double *ei = e_out_im + 3 * base_out;
+                                ei[idx_out] = sol[b].ei.x;
+                                ei[n_out + idx_out] = sol[b].ei.y;
+                                ei[2 * n_out + idx_out] = sol[b].ei.z;
                             }
-                            if (valid_out_refr) valid_out_refr[base_out + idx_out] = alive ? 1 : 0;
                         }
-                    }
-                    if (keep_both) {
-                        k[1] = sol[1].k;
-                        d[1] = sol[1].d;
-                        x[1] = xh;
-                        valid[1] = alive;
-                        k[0] = sol[0].k;
-                        d[0] = sol[0].d;
-                    } else {
-                        k[0] = pick ? sol[1].k : sol[0].k;
-                        d[0] = pick ? sol[1].d : sol[0].d;
-                    }
-                } else {
-                    const vec3 n = normal_from_grad(sf, g, g2);
-                    interact_isotropic(sf, n, k[c], valid[c]);
-                    d[c] = k[c];
-                    if ((L >> a_out) == 0 && store) {
-                        const int64_t idx_out = i + N * (L & (((int64_t)1 << a_out) - 1));
-                        ko[idx_out] = k[c].x;
-                        ko[n_out + idx_out] = k[c].y;
-                        ko[2 * n_out + idx_out] = k[c].z;
-                        if (valid_out_refr) valid_out_refr[base_out + idx_out] = valid[c] ? 1 : 0;
+                        if (valid_out_refr) valid_out_refr[base_out + idx_out] = alive ? 1 : 0;
                     }
                 }
-            }
-            if (crystal) {
+                double *slot = parked[a];
+                slot[0] = xh.x; slot[1] = xh.y; slot[2] = xh.z;
+                slot[3] = sol[1].k.x; slot[4] = sol[1].k.y; slot[5] = sol[1].k.z;
+                slot[6] = sol[1].d.x; slot[7] = sol[1].d.y; slot[8] = sol[1].d.z;
+                slot[9] = alive ? 1.0 : 0.0;
+                pending |= 1u << a;
+                k = sol[0].k;
+                d = sol[0].d;
                 d2 = 1.0;
-                if (a == A - 1) nstate = 2;
             } else {
+                const vec3 n = normal_from_grad(sf, g, g2);
+                interact_isotropic(sf, n, k, valid);
+                d = k;
                 d2 = sf->n_after * sf->n_after;
+                if (store) {
+                    PRT_GSTORE(ko + idx_in, k.x);
+                    PRT_GSTORE(ko + n_out + idx_in, k.y);
+                    PRT_GSTORE(ko + 2 * n_out + idx_in, k.z);
+#ifndef PRT_GENERAL_NO_MASKS
+                    if (valid_out_refr) valid_out_refr[base_out + idx_in] = valid ? 1 : 0;
+#endif
+                }
             }
             off_in += n_in;
             off_out += n_out;
             a = a_out;
+        }
+        if (pending == 0) break;
+        // resume the deepest parked child: level j, just behind the (j+1)-th crystal interface
+        const int j = 31 - __builtin_clz(pending);
+        pending &= ~(1u << j);
+        const double *slot = parked[j];
+        x = v3(slot[0], slot[1], slot[2]);
+        k = v3(slot[3], slot[4], slot[5]);
+        d = v3(slot[6], slot[7], slot[8]);
+        valid = slot[9] != 0.0;
+        d2 = 1.0;
+        L = (L & (((int64_t)1 << j) - 1)) | ((int64_t)1 << j);
+        // surface index and offsets behind that interface (wave-uniform scan of the table)
+        off_in = 0;
+        off_out = 0;
+        a = 0;
+        for (s = 0; a <= j; ++s) {
+            const bool cr = tab[s].mat_type == PRT_MAT_ANISOTROPIC;
+            off_in += N << a;
+            if (cr) ++a;
+            off_out += N << a;
         }
     }
 }

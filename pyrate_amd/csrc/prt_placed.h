@@ -58,6 +58,7 @@ struct prt_placed_buffer {
     size_t bytes = 0;              // mapped size (whole slabs)
     int32_t kind = -1;
     bool in_use = false;
+    hipEvent_t released = nullptr;  // recorded when the buffer was handed back: the last work that used it
     std::vector<prt_slab> slabs;
 };
 
@@ -199,6 +200,11 @@ static void arena_release_slab(prt_arena *a, const prt_slab &s) {
 }
 
 static void arena_unmap_buffer(prt_arena *a, prt_placed_buffer *b, bool keep_slabs) {
+    if (b->released) {
+        (void)hipEventSynchronize(b->released);
+        (void)hipEventDestroy(b->released);
+        b->released = nullptr;
+    }
     if (b->va) (void)hipMemUnmap(b->va, b->bytes);      // the addresses are retired, not handed back
     for (const prt_slab &s : b->slabs) {
         if (keep_slabs) a->free_slabs.push_back(s);
@@ -333,9 +339,11 @@ int32_t prt_arena_destroy(prt_arena_t *a) {
 }
 
 int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, void **ptrs, int32_t *kinds,
-                        int32_t max_hunt_slabs, void *stream) {
-    if (!a || n_parts <= 0 || n_parts > 8 || !bytes || !ptrs)
+                        int32_t n_distinct, int32_t avoid_mask, int32_t max_hunt_slabs, void *stream) {
+    if (!a || n_parts <= 0 || n_parts > 8 || !bytes || !ptrs || n_distinct > PRT_ARENA_MAX_KINDS || avoid_mask < 0)
         return fail(PRT_ERR_INVALID_ARG, "prt_arena_alloc: bad arguments");
+    if (n_distinct < 0) n_distinct = 2;
+    if (n_distinct > n_parts) n_distinct = n_parts;
     for (int i = 0; i < n_parts; ++i) {
         if (bytes[i] <= 0) return fail(PRT_ERR_INVALID_ARG, "prt_arena_alloc: part sizes must be positive");
         ptrs[i] = nullptr;
@@ -347,12 +355,14 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
     size_t need[8];
     for (int i = 0; i < n_parts; ++i) need[i] = ((size_t)bytes[i] + PRT_SLAB_BYTES - 1) / PRT_SLAB_BYTES;
 
-    // Assignment of kinds to parts: the first two parts (x_hit, k_out -- the two halves of the write
-    // streams) must differ; further parts take a kind nobody uses yet if one is at hand, otherwise
-    // whatever has room.  A part is served by a cached buffer of its size and kind, or by free slabs.
+    // Assignment of kinds to parts: the first n_distinct parts (x_hit, k_out -- the two halves of the
+    // write streams --, then the inputs) must differ pairwise; further parts take a kind nobody uses
+    // yet if one is at hand, otherwise whatever has room.  A part is served by a cached buffer of its size and kind, or by free slabs.
     // Greedy over the parts in order; returns false if a part cannot be served.
     int32_t chosen[8];
-    auto assign = [&](bool strict) {
+    // Kinds in avoid_mask (bit q = kind q) are left to other users -- the input arrays stay out of the
+    // kinds the write streams use -- unless `use_avoided` gives up on that.
+    auto assign = [&](int strict_parts, bool use_avoided) {
         int64_t slabs_taken[PRT_ARENA_MAX_KINDS] = {0, 0, 0, 0};
         bool from_cache[8];
         bool used[PRT_ARENA_MAX_KINDS] = {false, false, false, false};
@@ -360,9 +370,10 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
             int best = -1;
             bool best_cached = false;
             for (int pass = 0; pass < 2 && best < 0; ++pass) {     // pass 0: kinds no earlier part uses
-                if (pass == 1 && strict && i < 2) break;           // the first two parts must differ
+                if (pass == 1 && i < strict_parts) break;          // these parts must differ pairwise
                 for (int q = 0; q < a->n_kinds && best < 0; ++q) {
                     if (pass == 0 && used[q]) continue;
+                    if (!use_avoided && ((avoid_mask >> q) & 1)) continue;
                     int64_t cached_taken = 0;
                     for (int j = 0; j < i; ++j)
                         cached_taken += (chosen[j] == q && need[j] == need[i] && from_cache[j]);
@@ -384,11 +395,10 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
     };
 
     // hunt: take slabs from the driver until the strict assignment works (or the hunt budget is spent)
-    const bool want_two_kinds = n_parts >= 2;
     a->self_rate = 0.0;            // re-measured by the first slab this call takes from the driver
     int32_t hunted = 0;
     hipError_t hunt_err = hipSuccess;
-    while (!assign(want_two_kinds)) {
+    while (!assign(n_distinct, false)) {
         size_t total_need = 0;
         for (int i = 0; i < n_parts; ++i) total_need += need[i];
         if (hunted >= (int32_t)total_need + max_hunt_slabs) break;
@@ -399,8 +409,9 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
         if (!became_rep) a->free_slabs.push_back(s);
         ++hunted;
     }
-    bool ok = assign(want_two_kinds);
-    if (!ok) ok = assign(false);              // not enough memory of a second kind: one kind it is
+    bool ok = false;                          // not enough memory of that many kinds: fewer it is
+    for (int strict = n_distinct; strict >= 0 && !ok; --strict) ok = assign(strict, false);
+    for (int strict = n_distinct; strict >= 0 && !ok; --strict) ok = assign(strict, true);
     if (!ok) {
         if (hunt_err != hipSuccess && hunt_err != hipErrorOutOfMemory)
             return fail(PRT_ERR_DEVICE, "prt_arena_alloc: taking memory from the driver", hunt_err);
@@ -417,6 +428,7 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
                             "prt_arena_alloc: mapping a buffer", e);
             }
         }
+        if (b->released) HIP_TRY(hipStreamWaitEvent(st, b->released, 0));   // behind its previous user
         b->in_use = true;
         got[i] = b;
     }
@@ -444,14 +456,17 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
     return PRT_OK;
 }
 
-int32_t prt_arena_free(prt_arena_t *a, void *ptr) {
+int32_t prt_arena_free(prt_arena_t *a, void *ptr, void *stream) {
     if (!a || !ptr) return fail(PRT_ERR_INVALID_ARG, "prt_arena_free: null argument");
     PRT_ON_DEVICE(a->device);
     std::lock_guard<std::mutex> lock(a->mu);
     for (prt_placed_buffer *b : a->buffers)
         if (b->va == ptr && b->in_use) {
-            // work that still uses the buffer must be finished before somebody else gets it
-            HIP_TRY(hipDeviceSynchronize());
+            // No host wait: an event on the caller's stream marks the last work that may use the
+            // buffer; whoever gets the buffer next is ordered behind it (prt_arena_alloc), and it is
+            // waited for before the memory is unmapped.
+            if (!b->released) HIP_TRY(hipEventCreateWithFlags(&b->released, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(b->released, (hipStream_t)stream));
             b->in_use = false;        // stays mapped: the next request of this size and kind takes it as it is
             return PRT_OK;
         }

@@ -201,8 +201,9 @@ class DeviceSystem(object):
         of 5.6 TB/s); "torch": the torch allocator (whatever kind it happens to
         get); "auto" (default): the arena for path-mode outputs of all-isotropic tables from
         ``placed.PLACED_MIN_BYTES`` on, torch otherwise.  ``extra_bytes``: further buffers to take from
-        the arena in the same request (returned as uint8 tensors in ``bufs["extra"]``; they get a
-        third kind of memory when one is at hand) -- only with arena placement."""
+        the arena in the same request (returned as uint8 tensors in ``bufs["extra"]``); the first of
+        them is placed in a third kind of memory (the place for the input arrays: reads that share
+        a kind with the write streams cost ~3 % of the march) -- only with arena placement."""
         if packed_flags:
             if not self.all_isotropic:
                 raise ValueError("packed mask flags need an all-isotropic table")
@@ -232,7 +233,11 @@ class DeviceSystem(object):
                 return -(-v // 4096) * 4096
             (off_v, off_w) = (up(8 * nx), up(up(8 * nx) + nv))
             arena = placed.PlacedArena.for_device(dev.index)
-            (parts, kinds) = arena.alloc([off_w + nw, 8 * nk] + [int(b) for b in extra_bytes])
+            # (without extras: stay out of the kinds beyond the first two -- that is where big input
+            # bundles live, engine.ray_rows)
+            (parts, kinds) = arena.alloc([off_w + nw, 8 * nk] + [int(b) for b in extra_bytes],
+                                         n_distinct=3 if extra_bytes else 2,
+                                         avoid_mask=0 if extra_bytes else (0xF & ~placed.OUTPUT_KINDS_MASK))
             bufs = dict(
                 x_hit=parts[0][:8 * nx].view(torch.float64),
                 k_out=parts[1][:8 * nk].view(torch.float64),
@@ -485,7 +490,7 @@ def collimated_bundle_device(nray, radius, start, kvec, evec, device, lo=0, hi=N
         prm.e[q] = float(evec[q])
     pitch = recommended_pitch(n)
     with torch.cuda.device(device):
-        bufs = [torch.empty((3, max(pitch, 1)), dtype=torch.float64, device=device) for _ in range(3)]
+        bufs = [ray_rows(max(n, 1), device) for _ in range(3)]
         _lib.check(lib.prt_collimated_bundle(device.index, int(nray), lo, hi, ctypes.byref(prm), pitch,
                                              _ptr(bufs[0]), _ptr(bufs[1]), _ptr(bufs[2]),
                                              _stream_handle(device)))
@@ -535,7 +540,7 @@ def raster_bundle_device(tables_list, kind, device, radius=1.0, start=(0., 0., 0
         prm.k[q] = float(kvec[q]) if kvec is not None else 0.0
         prm.e[q] = float(evec[q]) if evec is not None else 0.0
     pitch = recommended_pitch(max(n, 1))
-    bufs = [torch.empty((3, pitch), dtype=torch.float64, device=device) for _ in range(3)]
+    bufs = [ray_rows(max(n, 1), device) for _ in range(3)]
     pup = torch.empty((2, pitch), dtype=torch.float64, device=device) if want_pupil else None
     with torch.cuda.device(device):
         base = 0                   # global index of the current sub-raster's first point
@@ -659,6 +664,18 @@ def stack_to_host(tensors):
     return out.numpy()
 
 
+def ray_rows(n, device):
+    """an uninitialised row-pitched (3, n) array for an input bundle (rows prt_recommended_pitch(n)
+    apart).  Big bundles get arena memory of a kind the path arrays do not use (``placed.InputRows``):
+    input loads that share a kind of HBM with the march's write streams cost it 5 %."""
+    pitch = recommended_pitch(n)
+    device = torch.device(device)
+    if device.type == "cuda" and 3 * pitch * 8 >= placed.PLACED_INPUT_MIN_BYTES:
+        with torch.cuda.device(device):
+            return placed.input_rows.take(device, pitch)[:, :n]
+    return torch.empty((3, pitch), dtype=torch.float64, device=device)[:, :n]
+
+
 def to_device_rays(a, device, pitched=True):
     """numpy (3, N) real or zero-imaginary complex -> float64 device tensor.  With
     ``pitched`` the rows live in a (3, prt_recommended_pitch(N)) allocation (the returned
@@ -671,7 +688,6 @@ def to_device_rays(a, device, pitched=True):
     n = t.shape[1]
     if not pitched or n == 0:
         return t.to(device)
-    buf = torch.empty((3, recommended_pitch(n)), dtype=torch.float64, device=device)
-    view = buf[:, :n]
+    view = ray_rows(n, device)
     view.copy_(t)
     return view

@@ -21,6 +21,32 @@ SLAB_BYTES = 1 << 30
 # below this many output bytes a trace keeps using the torch allocator: small path arrays live in the
 # L2 / Infinity Cache for most of the march, and a 1-GiB slab per array would be mostly padding
 PLACED_MIN_BYTES = int(os.environ.get("PRT_PLACED_MIN_BYTES", 768 << 20))
+# input bundles (x0, k0, E0) from this many bytes per (3, N) array on are uploaded into arena memory of
+# a kind the output arrays do not use (loads that share a kind with the write streams cost the march 5 %)
+PLACED_INPUT_MIN_BYTES = int(os.environ.get("PRT_PLACED_INPUT_MIN_BYTES", 96 << 20))
+OUTPUT_KINDS_MASK = 0b011       # a two-part output request takes kinds 0 and 1
+
+
+class InputRows(object):
+    """Row-pitched (3, pitch) blocks for big input bundles, nine rows (x0, k0, E0) per arena buffer."""
+
+    def __init__(self):
+        self._cur = {}            # device index -> [uint8 buffer, pitch, rows in the buffer, rows handed out]
+        self._lock = threading.Lock()
+
+    def take(self, device, pitch, nrows=3):
+        with self._lock:
+            ent = self._cur.get(device.index)
+            if ent is None or ent[1] != pitch or ent[3] + nrows > ent[2]:
+                (parts, _) = PlacedArena.for_device(device.index).alloc([9 * pitch * 8], n_distinct=1,
+                                                                         avoid_mask=OUTPUT_KINDS_MASK)
+                ent = self._cur[device.index] = [parts[0], pitch, 9, 0]
+            lo = ent[3] * pitch * 8
+            ent[3] += nrows
+            return ent[0][lo:lo + nrows * pitch * 8].view(torch.float64).view(nrows, pitch)
+
+
+input_rows = InputRows()
 
 
 class _Block(object):
@@ -122,8 +148,11 @@ class PlacedArena(object):
             return arena
 
     def _release(self, ptr):
+        # (on the current stream: the stream the buffer's last kernels were launched on in every use
+        # this package makes of it; prt_arena_free records an event there instead of waiting)
         if self._h:
-            self.lib.prt_arena_free(self._h, ctypes.c_void_p(ptr))
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)
+            self.lib.prt_arena_free(self._h, ctypes.c_void_p(ptr), stream)
 
     def _tensor(self, block):
         dev = torch.device("cuda", self.device_index)
@@ -139,15 +168,18 @@ class PlacedArena(object):
         self._wrap = "dlpack"
         return _dlpack_tensor(block, self.device_index)
 
-    def alloc(self, sizes, max_hunt_slabs=-1):
-        """Buffers of ``sizes`` bytes as uint8 tensors, plus their kind indices.  The first two land in
-        two different kinds of memory whenever the device has two to offer."""
+    def alloc(self, sizes, n_distinct=2, avoid_mask=0, max_hunt_slabs=-1):
+        """Buffers of ``sizes`` bytes as uint8 tensors, plus their kind indices.  The first ``n_distinct``
+        land in pairwise different kinds of memory whenever the device has that many to offer; kinds in
+        ``avoid_mask`` (bit q = kind q) are left to other requests if possible."""
         n = len(sizes)
         c_sizes = (ctypes.c_int64 * n)(*[int(s) for s in sizes])
         ptrs = (ctypes.c_void_p * n)()
         kinds = (ctypes.c_int32 * n)()
         stream = ctypes.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)
-        _lib.check(self.lib.prt_arena_alloc(self._h, n, c_sizes, ptrs, kinds, int(max_hunt_slabs), stream))
+        _lib.check(self.lib.prt_arena_alloc(self._h, n, c_sizes, ptrs, kinds, int(n_distinct), int(avoid_mask),
+                                            int(max_hunt_slabs),
+                                            stream))
         out = []
         for i in range(n):
             rounded = -(-int(sizes[i]) // SLAB_BYTES) * SLAB_BYTES
