@@ -138,7 +138,7 @@ def _lookup(fname, key):
         return None
 
 
-def cpu_baseline_numpy(records, o, k, e0, m):
+def cpu_baseline_numpy(records, o, k, e0, m, n_all):
     """configs the C port does not cover (explicit shapes, crystals): the NumPy oracle on the first m rays"""
     from oracle import seqtrace_np as oracle
     m = min(m, o.shape[1])
@@ -148,7 +148,7 @@ def cpu_baseline_numpy(records, o, k, e0, m):
     dt = time.perf_counter() - t0
     return {"value": m * len(records) / dt, "unit": "ray-surface-ops/s", "cores": 1, "kind": "port",
             "sample": "NumPy oracle (oracle/seqtrace_np.py), first %d of %d rays x %d surfaces, %.1f s"
-                      % (m, o.shape[1], len(records), dt),
+                      % (m, n_all, len(records), dt),
             "host_cpus": os.cpu_count()}
 
 
@@ -292,7 +292,7 @@ def main():
     n_out_bufs = 2 if (do_step_gather or (do_stats and not fused_stats)) else 1
     packed = iso and not args.two_mask_arrays
     record_bytes = 49 if packed else 50
-    placement = args.placement if (iso and mode == _lib.MODE_PATH) else "torch"
+    placement = args.placement if mode == _lib.MODE_PATH else "torch"
     # one row pitch on every rank: a gathered row is read n_pad elements deep (pdist.ImagePlaneGather)
     pitch = engine.recommended_pitch(pdist.shard_stride(n_total, n_gpus)) if iso else None
     # The input arrays: big bundles are generated straight into arena memory of a kind the path arrays do
@@ -460,7 +460,11 @@ def main():
                             "flops_source": "profiles/fp64_flops.json: SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 of an "
                                             "earlier PMC run of this workload (2 flop per FMA, 64 lanes per "
                                             "wave instruction), looked up -- NOT measured in this run",
-                            "kernel": "k_trace_general", "kernel_ms": kernel_ms, "secondary": hbm}
+                            "kernel": "k_trace_general", "kernel_ms": kernel_ms, "secondary": hbm,
+                            # all VALU wave instructions (selects, compares, address arithmetic included) at one
+                            # per 4 cycles and SIMD against the 1024 SIMDs at 2.4 GHz: what the kernel is bound by
+                            "valu_issue_frac": (fent["counters"]["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9)
+                                                / (kernel_ms * 1e-3)) if "counters" in fent else None}
             else:
                 roofline = dict(hbm, note="FP64-VALU bound kernel; no flop count on file for this size "
                                           "(profiles/fp64_flops.json), HBM fraction shown")
@@ -509,9 +513,9 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(records, x0[:, :m].cpu().numpy(), k0[:, :m].cpu().numpy(),
                                                    e0d[:, :m].cpu().numpy(), n_all=n_local)
             else:
-                m = 1_500_000 if args.config == "asphere" else 16_000
+                m = 10_000_000 if args.config == "asphere" else 64_000
                 out["cpu_baseline"] = cpu_baseline_numpy(records, x0[:, :m].cpu().numpy(), k0[:, :m].cpu().numpy(),
-                                                         e0d[:, :m].cpu().numpy(), m)
+                                                         e0d[:, :m].cpu().numpy(), m, n_local)
         else:
             out["cpu_baseline"] = None
     if use_dist:

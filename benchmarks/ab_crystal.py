@@ -32,27 +32,31 @@ paths = [None] + sorted(glob.glob(os.path.join(ROOT, "scratch", "variants", "lib
 out = {}
 for (tag, (e1, e2)) in cases.items():
     sysd = engine.DeviceSystem(systems.aniso_doublet_records(e1, e2), 0)
+    builds = []
+    for path in paths:
+        if path is None:
+            builds.append(("in-tree", sysd.lib, sysd._h))
+            continue
+        lib = ctypes.CDLL(os.path.abspath(path))
+        for fn in ("prt_system_create", "prt_trace_timed", "prt_system_destroy"):
+            (res, args) = _lib.PROTOTYPES[fn]
+            getattr(lib, fn).restype = res
+            getattr(lib, fn).argtypes = args
+        h = ctypes.c_void_p()
+        assert lib.prt_system_create(sysd._table, sysd.n_surfaces, 0, ctypes.byref(h)) == 0
+        builds.append((os.path.basename(path)[7:-3], lib, h))
     for (mname, mode) in (("path", _lib.MODE_PATH), ("image", _lib.MODE_IMAGE)):
         bufs = sysd.alloc_outputs(n, mode)
-        for path in paths:
-            if path is None:
-                (name, lib, h) = ("in-tree", sysd.lib, sysd._h)
-            else:
-                name = os.path.basename(path)[7:-3]
-                lib = ctypes.CDLL(os.path.abspath(path))
-                for fn in ("prt_system_create", "prt_trace_timed", "prt_system_destroy"):
-                    (res, args) = _lib.PROTOTYPES[fn]
-                    getattr(lib, fn).restype = res
-                    getattr(lib, fn).argtypes = args
-                h = ctypes.c_void_p()
-                assert lib.prt_system_create(sysd._table, sysd.n_surfaces, 0, ctypes.byref(h)) == 0
-            ts = []
-            for rep in range(4):
-                ms = ctypes.c_double()
-                rc = lib.prt_trace_timed(h, n, 0, P(x0), P(k0), P(e0d), None, mode, 0, P(bufs["x_hit"]),
-                                         P(bufs["k_out"]), P(bufs["valid"]), P(bufs["valid_out"]), st, 10,
-                                         ctypes.byref(ms))
-                assert rc == 0, rc
-                ts.append(round(ms.value, 4))
-            out["%s_%s_%s" % (tag, mname, name)] = ts
+
+        def timed(lib, h, iters):
+            ms = ctypes.c_double()
+            rc = lib.prt_trace_timed(h, n, 0, P(x0), P(k0), P(e0d), None, mode, 0, P(bufs["x_hit"]),
+                                     P(bufs["k_out"]), P(bufs["valid"]), P(bufs["valid_out"]), st, iters,
+                                     ctypes.byref(ms))
+            assert rc == 0, rc
+            return ms.value
+        timed(builds[0][1], builds[0][2], 100)          # clocks up before anything is compared
+        for rep in range(5):                            # builds interleaved: drifts hit all of them alike
+            for (name, lib, h) in builds:
+                out.setdefault("%s_%s_%s" % (tag, mname, name), []).append(round(timed(lib, h, 20), 4))
 print(json.dumps(out))

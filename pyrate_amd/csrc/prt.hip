@@ -496,10 +496,18 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
             if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC &&
                 sys->h_table[s].aniso_class == PRT_ANISO_GENERAL)
                 general_eps = true;
-#define PRT_LAUNCH_G(MODE_, GEN_)                                                                        \
-    hipLaunchKernelGGL((k_trace_general<MODE_, GEN_>), grid, block, 0, st, sys->d_table, sys->n_surfaces, \
-                       n_aniso, n0, x0, k0, e0_re, e0_im, e_mode_g, x_hit, k_out, e_out, e_out_im, valid, \
-                       valid_out, nonconv)
+        // few crystal interfaces: the parking slots of the depth-first walk fit into LDS
+        const bool park_lds = n_aniso <= PRT_PARK_LDS_LEVELS;
+        const size_t park_bytes = park_lds ? (size_t)n_aniso * PRT_BLOCK * (9 * sizeof(double) + 1) : 0;
+#define PRT_LAUNCH_GP(MODE_, GEN_, LDS_)                                                                      \
+    hipLaunchKernelGGL((k_trace_general<MODE_, GEN_, LDS_>), grid, block, park_bytes, st, sys->d_table,       \
+                       sys->n_surfaces, n_aniso, n0, x0, k0, e0_re, e0_im, e_mode_g, x_hit, k_out, e_out,     \
+                       e_out_im, valid, valid_out, nonconv)
+#define PRT_LAUNCH_G(MODE_, GEN_)                        \
+    do {                                                 \
+        if (park_lds) PRT_LAUNCH_GP(MODE_, GEN_, true);  \
+        else PRT_LAUNCH_GP(MODE_, GEN_, false);          \
+    } while (0)
         if (mode == PRT_MODE_PATH) {
             if (general_eps) PRT_LAUNCH_G(PRT_MODE_PATH, true);
             else PRT_LAUNCH_G(PRT_MODE_PATH, false);
@@ -507,6 +515,7 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
             if (general_eps) PRT_LAUNCH_G(PRT_MODE_IMAGE, true);
             else PRT_LAUNCH_G(PRT_MODE_IMAGE, false);
         }
+#undef PRT_LAUNCH_GP
 #undef PRT_LAUNCH_G
         HIP_TRY(hipGetLastError());
         return PRT_OK;
@@ -616,21 +625,24 @@ int32_t prt_trace_moments(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
         HIP_TRY(hipGetLastError());
         return PRT_OK;
     }
-    // unaligned / odd-pitch buffers: the plain trace followed by the two-kernel reduction
-    if (packed_flags)
-        return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: PRT_MODE_FLAGS needs aligned, even-pitch buffers");
-    int32_t rc = prt_trace(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode_in, out_pitch, x_hit, k_out, valid,
-                           valid_out, (uint8_t *)nullptr, stream);
-    if (rc != PRT_OK) return rc;
+    // empty, unaligned or odd-pitch buffers: the plain trace followed by the two-kernel reduction (with
+    // packed flags the selecting mask is bit 1 of the flags byte)
+    if (n0 > 0) {
+        int32_t rc = prt_trace(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode_in, out_pitch, x_hit, k_out, valid,
+                               valid_out, (uint8_t *)nullptr, stream);
+        if (rc != PRT_OK) return rc;
+    }
     const int64_t row = (mode == PRT_MODE_PATH) ? (int64_t)(sys->n_surfaces - 1) : 0;
-    const uint8_t *mask = valid_out ? valid_out + row * out_pitch : nullptr;
-    if (!mask) return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: valid_out is required for unaligned buffers");
+    const uint8_t *mask = packed_flags ? (valid ? valid + row * out_pitch : nullptr)
+                                       : (valid_out ? valid_out + row * out_pitch : nullptr);
+    if (n0 > 0 && !mask)
+        return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: valid_out is required for unaligned buffers");
     int nbk = (int)((n0 + PRT_BLOCK * 8 - 1) / (PRT_BLOCK * 8));
     if (nbk > 2048) nbk = 2048;
     if (nbk < 1) nbk = 1;
     hipLaunchKernelGGL(k_moments_partial, dim3(nbk), dim3(PRT_BLOCK), 0, st, n0, out_pitch,
                        x_hit + row * 3 * out_pitch, mask, 0, rx, ry, rz, (const double *)nullptr, 0,
-                       scratch_dev);
+                       scratch_dev, packed_flags ? 2 : 0xff);
     hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, nbk, scratch_dev, out7_dev);
     HIP_TRY(hipGetLastError());
     return PRT_OK;

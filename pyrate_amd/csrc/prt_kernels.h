@@ -288,7 +288,10 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE ==
 // sits at i + N (L mod 2^a).
 // ---------------------------------------------------------------------------
 #define PRT_FUSED_MAX_CRYSTALS 8
-#ifdef PRT_GENERAL_NT_STORES   // experiment (benchmarks/ab_crystal.py)
+// non-temporal hint on the path stores of the crystal march (written once, never read back by the
+// kernel): 0.213 instead of 0.254 ms on BASELINE configs[3] (benchmarks/ab_crystal.py; PRT_GENERAL_PLAIN_STORES
+// builds the other variant)
+#ifndef PRT_GENERAL_PLAIN_STORES
 #define PRT_GSTORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #else
 #define PRT_GSTORE(ptr, val) (*(ptr) = (val))
@@ -296,7 +299,15 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE ==
 #ifndef PRT_GENERAL_WAVES
 #define PRT_GENERAL_WAVES 4
 #endif
-template <int MODE, bool GENERAL = true>
+// PARK_LDS: the parking slots live in LDS ([level][value][thread]: conflict-free, 9 doubles + 1 byte per
+// level and thread) instead of private memory.  For up to PRT_PARK_LDS_LEVELS crystal interfaces the block's
+// slots (37 KB) leave room for four blocks per CU.  Private-memory slots are real HBM / L2 traffic: PMC
+// 1.20 GB per launch instead of 0.82 GB on BASELINE configs[3] (0.75 GB algorithmic), and 0.193 instead of
+// 0.162 ms in path mode, 0.139 instead of 0.125 ms in image mode (same arrays, benchmarks/ab_crystal.py).
+#ifndef PRT_PARK_LDS_LEVELS
+#define PRT_PARK_LDS_LEVELS 2
+#endif
+template <int MODE, bool GENERAL = true, bool PARK_LDS = false>
 __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
     const prt_dev_surface *__restrict__ tab, int32_t S, int32_t A, int64_t N,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
@@ -317,7 +328,10 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
     }
     bool valid = true;
     double d2 = 1.0;
-    double parked[PRT_FUSED_MAX_CRYSTALS][10];  // per level: child 1 of the crystal interface of that level
+    // per level: child 1 of the crystal interface of that level (hit point, k, d, alive)
+    extern __shared__ double park_lds[];
+    double parked[PARK_LDS ? 1 : PRT_FUSED_MAX_CRYSTALS][10];
+    uint8_t *park_lds_alive = reinterpret_cast<uint8_t *>(park_lds + (size_t)A * 9 * PRT_BLOCK);
     uint32_t pending = 0;                        // levels with a parked child (wave-uniform)
     int64_t L = 0;                               // choices made so far: bit j = child taken at level j
     int32_t s = 0;                               // next surface
@@ -346,9 +360,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
                 PRT_GSTORE(xo + idx_in, xh.x);
                 PRT_GSTORE(xo + n_in + idx_in, xh.y);
                 PRT_GSTORE(xo + 2 * n_in + idx_in, xh.z);
-#ifndef PRT_GENERAL_NO_MASKS
-                valid_out_hit[base_in + idx_in] = valid ? 1 : 0;
-#endif
+                PRT_GSTORE(valid_out_hit + base_in + idx_in, (uint8_t)(valid ? 1 : 0));
                 if (nonconv_out) nonconv_out[base_in + idx_in] = ncv ? 1 : 0;
             }
             x = xh;
@@ -375,14 +387,22 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
                                 ei[2 * n_out + idx_out] = sol[b].ei.z;
                             }
                         }
-                        if (valid_out_refr) valid_out_refr[base_out + idx_out] = alive ? 1 : 0;
+                        if (valid_out_refr) PRT_GSTORE(valid_out_refr + base_out + idx_out, (uint8_t)(alive ? 1 : 0));
                     }
                 }
-                double *slot = parked[a];
-                slot[0] = xh.x; slot[1] = xh.y; slot[2] = xh.z;
-                slot[3] = sol[1].k.x; slot[4] = sol[1].k.y; slot[5] = sol[1].k.z;
-                slot[6] = sol[1].d.x; slot[7] = sol[1].d.y; slot[8] = sol[1].d.z;
-                slot[9] = alive ? 1.0 : 0.0;
+                if (PARK_LDS) {
+                    double *slot = park_lds + (size_t)a * 9 * PRT_BLOCK + threadIdx.x;
+                    slot[0 * PRT_BLOCK] = xh.x; slot[1 * PRT_BLOCK] = xh.y; slot[2 * PRT_BLOCK] = xh.z;
+                    slot[3 * PRT_BLOCK] = sol[1].k.x; slot[4 * PRT_BLOCK] = sol[1].k.y; slot[5 * PRT_BLOCK] = sol[1].k.z;
+                    slot[6 * PRT_BLOCK] = sol[1].d.x; slot[7 * PRT_BLOCK] = sol[1].d.y; slot[8 * PRT_BLOCK] = sol[1].d.z;
+                    park_lds_alive[a * PRT_BLOCK + threadIdx.x] = alive ? 1 : 0;
+                } else {
+                    double *slot = parked[a];
+                    slot[0] = xh.x; slot[1] = xh.y; slot[2] = xh.z;
+                    slot[3] = sol[1].k.x; slot[4] = sol[1].k.y; slot[5] = sol[1].k.z;
+                    slot[6] = sol[1].d.x; slot[7] = sol[1].d.y; slot[8] = sol[1].d.z;
+                    slot[9] = alive ? 1.0 : 0.0;
+                }
                 pending |= 1u << a;
                 k = sol[0].k;
                 d = sol[0].d;
@@ -396,9 +416,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
                     PRT_GSTORE(ko + idx_in, k.x);
                     PRT_GSTORE(ko + n_out + idx_in, k.y);
                     PRT_GSTORE(ko + 2 * n_out + idx_in, k.z);
-#ifndef PRT_GENERAL_NO_MASKS
-                    if (valid_out_refr) valid_out_refr[base_out + idx_in] = valid ? 1 : 0;
-#endif
+                    if (valid_out_refr) PRT_GSTORE(valid_out_refr + base_out + idx_in, (uint8_t)(valid ? 1 : 0));
                 }
             }
             off_in += n_in;
@@ -409,11 +427,19 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
         // resume the deepest parked child: level j, just behind the (j+1)-th crystal interface
         const int j = 31 - __builtin_clz(pending);
         pending &= ~(1u << j);
-        const double *slot = parked[j];
-        x = v3(slot[0], slot[1], slot[2]);
-        k = v3(slot[3], slot[4], slot[5]);
-        d = v3(slot[6], slot[7], slot[8]);
-        valid = slot[9] != 0.0;
+        if (PARK_LDS) {
+            const double *slot = park_lds + (size_t)j * 9 * PRT_BLOCK + threadIdx.x;
+            x = v3(slot[0 * PRT_BLOCK], slot[1 * PRT_BLOCK], slot[2 * PRT_BLOCK]);
+            k = v3(slot[3 * PRT_BLOCK], slot[4 * PRT_BLOCK], slot[5 * PRT_BLOCK]);
+            d = v3(slot[6 * PRT_BLOCK], slot[7 * PRT_BLOCK], slot[8 * PRT_BLOCK]);
+            valid = park_lds_alive[j * PRT_BLOCK + threadIdx.x] != 0;
+        } else {
+            const double *slot = parked[j];
+            x = v3(slot[0], slot[1], slot[2]);
+            k = v3(slot[3], slot[4], slot[5]);
+            d = v3(slot[6], slot[7], slot[8]);
+            valid = slot[9] != 0.0;
+        }
         d2 = 1.0;
         L = (L & (((int64_t)1 << j) - 1)) | ((int64_t)1 << j);
         // surface index and offsets behind that interface (wave-uniform scan of the table)
@@ -633,7 +659,9 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_moments_partial(int64_t N, int64_
                                                                double rz,
                                                                const double *__restrict__ ref_dev,
                                                                int32_t ref_kind,
-                                                               double *__restrict__ partials) {
+                                                               double *__restrict__ partials,
+                                                               int32_t mask_bits = 0xff) {
+    // mask_bits: which bits of a mask byte select a ray (0xff: any; 2: the valid_out bit of packed flags)
     // ref_kind 1: ref_dev holds the reference point (3 doubles); 2: ref_dev holds a moments
     // vector {count, sum x, ...} (e.g. all-reduced over the ranks) -> reference = centroid
     if (ref_kind == 1) {
@@ -649,7 +677,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_moments_partial(int64_t N, int64_
     double acc[MOM_VALUES] = {0, 0, 0, 0, 0, 0, 0};
     for (int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x; i < N;
          i += (int64_t)gridDim.x * PRT_BLOCK) {
-        if (mask && !mask[i]) continue;
+        if (mask && !(mask[i] & mask_bits)) continue;
         double dx = x[i], dy = x[pitch + i], dz = x[2 * pitch + i];
         if (mode == 0) {  // points relative to ref
             dx -= rx;

@@ -199,8 +199,8 @@ class DeviceSystem(object):
         ``placement``: where the memory comes from.  "arena": x_hit and k_out are built from physical
         HBM slabs of two DIFFERENT kinds (``pyrate_amd.placed``; the march then writes at 7.0 instead
         of 5.6 TB/s); "torch": the torch allocator (whatever kind it happens to
-        get); "auto" (default): the arena for path-mode outputs of all-isotropic tables from
-        ``placed.PLACED_MIN_BYTES`` on, torch otherwise.  ``extra_bytes``: further buffers to take from
+        get); "auto" (default): the arena for path-mode outputs from ``placed.PLACED_MIN_BYTES`` on,
+        torch otherwise.  ``extra_bytes``: further buffers to take from
         the arena in the same request (returned as uint8 tensors in ``bufs["extra"]``); the first of
         them is placed in a third kind of memory (the place for the input arrays: reads that share
         a kind with the write streams cost ~3 % of the march) -- only with arena placement."""
@@ -224,7 +224,7 @@ class DeviceSystem(object):
             nw = 0
         if placement == "auto":
             big = 8 * (nx + nk) + nv + nw >= placed.PLACED_MIN_BYTES
-            placement = "arena" if (self.all_isotropic and mode == _lib.MODE_PATH and big) else "torch"
+            placement = "arena" if (mode == _lib.MODE_PATH and big and not want_fields) else "torch"
         if placement not in ("arena", "torch"):
             raise ValueError("placement must be 'auto', 'arena' or 'torch'")
         if placement == "arena":
@@ -432,11 +432,17 @@ def compact(mask, arrays, ids=None, flags=None):
                                    _ptr(flags), _ptr(flt), _ptr(scratch), ctypes.byref(kept),
                                    _stream_handle(dev)))
     m = kept.value
+    if 2 * m < n and nrow:
+        # heavily vignetted bundle: a right-sized copy instead of views that pin rows * N * 8 bytes
+        # for as long as the compacted bundle lives
+        small = torch.empty((nrow, recommended_pitch(max(m, 1))), dtype=torch.float64, device=dev)
+        small[:, :m].copy_(tmp[:, :m])
+        tmp = small
     out = []
     r0 = 0
     for a in arrays:
         rr = a.shape[0]
-        out.append(tmp[r0:r0 + rr, :m])        # row-pitched view (pitch n), no second copy
+        out.append(tmp[r0:r0 + rr, :m])        # row-pitched view, no second copy when most rays survive
         r0 += rr
     idc = idt[:m].contiguous() if ids is not None else None
     flc = flt[:m].contiguous() if flags is not None else None

@@ -20,7 +20,7 @@ from . import _lib
 SLAB_BYTES = 1 << 30
 # below this many output bytes a trace keeps using the torch allocator: small path arrays live in the
 # L2 / Infinity Cache for most of the march, and a 1-GiB slab per array would be mostly padding
-PLACED_MIN_BYTES = int(os.environ.get("PRT_PLACED_MIN_BYTES", 768 << 20))
+PLACED_MIN_BYTES = int(os.environ.get("PRT_PLACED_MIN_BYTES", 512 << 20))
 # input bundles (x0, k0, E0) from this many bytes per (3, N) array on are uploaded into arena memory of
 # a kind the output arrays do not use (loads that share a kind with the write streams cost the march 5 %)
 PLACED_INPUT_MIN_BYTES = int(os.environ.get("PRT_PLACED_INPUT_MIN_BYTES", 96 << 20))

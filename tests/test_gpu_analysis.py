@@ -250,6 +250,14 @@ def test_trace_moments_equals_two_pass_statistics(gpu_device):
     x = v.x_hit[-1].cpu().numpy()[:, valid]
     (cnt, cen, rms) = engine.spot_from_moments(m, sysd.moments_reference())
     assert cnt == valid.sum() and np.allclose(cen, x.mean(axis=1), rtol=0, atol=1e-10)
+    # the same with packed mask flags (what OpticalSystem.image_moments allocates): the fallback selects by
+    # bit 1 of the flags byte; and an empty bundle gives zero moments instead of an error
+    pb = sysd.alloc_outputs(n_odd, _lib.MODE_IMAGE, pitch=n_odd, packed_flags=True)
+    mp = sysd.trace_moments_into(xo, ko, pb, ws, slot=1, e0_re=eo).cpu().numpy()
+    assert np.array_equal(mp, m)
+    empty = sysd.alloc_outputs(0, _lib.MODE_IMAGE, packed_flags=True)
+    z = torch.zeros((3, 0), dtype=torch.float64, device=gpu_device)
+    assert np.array_equal(sysd.trace_moments_into(z, z, empty, ws, slot=1).cpu().numpy(), np.zeros(7))
     # crystals: not offered
     sysa = engine.DeviceSystem(systems.aniso_doublet_records(), 0)
     with pytest.raises(_lib.PrtError):
