@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PRT_LIBRARY") or os.path.join(_HERE, "csrc", "libprt.so")
 
 PRT_OK = 0
+ERR_NOMEM = -5         # PRT_ERR_NOMEM
 MODE_PATH = 0
 MODE_IMAGE = 1
 MODE_FLAGS = 2          # OR-ed in: both masks of a record in one byte (include/prt.h)

@@ -222,11 +222,13 @@ class DeviceSystem(object):
             (nx, nk, nv, nw) = (3 * sum(n_in), 3 * sum(n_out), sum(n_in), sum(n_out))
         if not with_valid_out:
             nw = 0
+        auto_placement = placement == "auto"
         if placement == "auto":
             big = 8 * (nx + nk) + nv + nw >= placed.PLACED_MIN_BYTES
             placement = "arena" if (mode == _lib.MODE_PATH and big and not want_fields) else "torch"
         if placement not in ("arena", "torch"):
             raise ValueError("placement must be 'auto', 'arena' or 'torch'")
+        parts = None
         if placement == "arena":
             # part 0: x_hit, then the mask bytes (each on a 4-KiB boundary); part 1: k_out
             def up(v):
@@ -235,9 +237,17 @@ class DeviceSystem(object):
             arena = placed.PlacedArena.for_device(dev.index)
             # (without extras: stay out of the kinds beyond the first two -- that is where big input
             # bundles live, engine.ray_rows)
-            (parts, kinds) = arena.alloc([off_w + nw, 8 * nk] + [int(b) for b in extra_bytes],
-                                         n_distinct=3 if extra_bytes else 2,
-                                         avoid_mask=0 if extra_bytes else (0xF & ~placed.OUTPUT_KINDS_MASK))
+            try:
+                (parts, kinds) = arena.alloc([off_w + nw, 8 * nk] + [int(b) for b in extra_bytes],
+                                             n_distinct=3 if extra_bytes else 2,
+                                             avoid_mask=0 if extra_bytes else (0xF & ~placed.OUTPUT_KINDS_MASK))
+            except _lib.PrtError as exc:
+                # no whole free slabs left on the device (somebody else holds the memory): the arrays
+                # come from the torch allocator like small ones do -- slower placement, same results
+                if exc.code != _lib.ERR_NOMEM or extra_bytes or auto_placement is False:
+                    raise
+                placement = "torch"
+        if parts is not None:
             bufs = dict(
                 x_hit=parts[0][:8 * nx].view(torch.float64),
                 k_out=parts[1][:8 * nk].view(torch.float64),
@@ -677,8 +687,12 @@ def ray_rows(n, device):
     pitch = recommended_pitch(n)
     device = torch.device(device)
     if device.type == "cuda" and 3 * pitch * 8 >= placed.PLACED_INPUT_MIN_BYTES:
-        with torch.cuda.device(device):
-            return placed.input_rows.take(device, pitch)[:, :n]
+        try:
+            with torch.cuda.device(device):
+                return placed.input_rows.take(device, pitch)[:, :n]
+        except _lib.PrtError as exc:
+            if exc.code != _lib.ERR_NOMEM:      # no whole free slabs left: torch memory, slower placement
+                raise
     return torch.empty((3, pitch), dtype=torch.float64, device=device)[:, :n]
 
 

@@ -698,3 +698,40 @@ def test_asphere_march_at_full_size(gpu_device):
         assert np.array_equal(res.valid_out[s][idx].cpu().numpy().astype(bool), v)
         assert np.abs(res.x_hit[s][:, idx].cpu().numpy()[:, v] - out[s]["x_hit"][:, v]).max() < 1e-10
         assert np.abs(res.k_out[s][:, idx].cpu().numpy()[:, v] - out[s]["k_out"][:, v]).max() < 1e-12
+
+
+def test_arena_buffers_keep_their_data_through_allocation_churn(gpu_device):
+    """the arena maps every virtual address once (ROCm keeps translating a re-used range to the old pages):
+    buffers of changing sizes are taken, filled with a pattern, released, trimmed and taken again while
+    other buffers stay alive -- every live buffer still holds exactly what was written to it, and no two
+    live buffers overlap"""
+    from pyrate_amd import placed
+    arena = placed.PlacedArena.for_device(0)
+    rng = np.random.RandomState(5)
+    live = []
+    for step in range(24):
+        sizes = [int(rng.randint(1, 3) * (1 << 30) - rng.randint(0, 1 << 20)) for _ in range(int(rng.randint(1, 4)))]
+        (parts, kinds) = arena.alloc(sizes, n_distinct=min(2, len(sizes)))
+        if len(sizes) >= 2:
+            assert kinds[0] != kinds[1]
+        for (t, sz) in zip(parts, sizes):
+            tag = int(rng.randint(1, 250))
+            words = t[:sz // 8 * 8].view(torch.int64)
+            words.fill_(tag)
+            words[::4097] += torch.arange(words[::4097].shape[0], device=gpu_device)      # position-dependent part
+            live.append((t, sz, tag))
+        # release a random subset, sometimes hand the cached memory back to the driver
+        rng.shuffle(live)
+        keep = int(rng.randint(0, 5))
+        del live[keep:]
+        if step % 5 == 4:
+            arena.trim()
+        spans = sorted((t.data_ptr(), t.data_ptr() + t.numel()) for (t, _, _) in live)
+        assert all(a[1] <= b[0] for (a, b) in zip(spans[:-1], spans[1:]))
+        for (t, sz, tag) in live:
+            words = t[:sz // 8 * 8].view(torch.int64)
+            expect = torch.full_like(words[::4097], tag) + torch.arange(words[::4097].shape[0], device=gpu_device)
+            assert torch.equal(words[::4097], expect)
+            assert int(words[1]) == tag and int(words[-1]) in (tag, tag + (words.shape[0] - 1) // 4097)
+    del live
+    arena.trim()
