@@ -3,7 +3,8 @@
 extra -D flags), path mode and image mode of the double Gauss march.  The path arrays come from the
 placement-aware arena (x_hit and k_out in two different kinds of HBM): the regime the product runs in.
 
-    python benchmarks/ab_variants.py [torch]      # "torch": arrays from the torch allocator instead
+    python benchmarks/ab_variants.py [torch] [asphere]     # "torch": arrays from the torch allocator instead;
+                                                           # "asphere": BASELINE configs[2] instead of the double Gauss
 """
 import ctypes
 import glob
@@ -19,9 +20,13 @@ import torch
 from pyrate_amd import engine, systems, _lib
 
 dev = torch.device("cuda", 0)
-sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
-(x0, k0, e0d, n) = systems.double_gauss_bundle_device(10000000, dev)
-placement = "torch" if len(sys.argv) > 1 and sys.argv[1] == "torch" else "arena"
+if "asphere" in sys.argv[1:]:
+    sysd = engine.DeviceSystem(systems.asphere_records(coefficients=(1e-3, -1e-6, 1e-8), curv=-1. / 30., cc=-1.5), 0)
+    (x0, k0, e0d, n) = systems.double_gauss_bundle_device(10000000, dev, rpup=9.0, z0=-5.0, field_deg=5.0)
+else:
+    sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
+    (x0, k0, e0d, n) = systems.double_gauss_bundle_device(10000000, dev)
+placement = "torch" if "torch" in sys.argv[1:] else "arena"
 pitch_in = x0.stride(0)
 bufs = sysd.alloc_outputs(n, packed_flags=True, placement=placement,
                           extra_bytes=([9 * pitch_in * 8] if placement == "arena" else ()))

@@ -21,6 +21,7 @@ struct prt_system {
     int32_t n_surfaces;
     int32_t all_isotropic;
     int32_t all_conic;
+    int32_t shape_level;       // PRT_SHAPES_*: the least kernel instantiation that covers the table's shapes
     prt_dev_surface *d_table;  // device records (prt_device.h: the caller's records repacked, 504 B each)
     prt_surface_t *h_table;    // host copy of the caller's records (dispatch decisions)
     void *d_side;              // one device array: the coefficients / term powers / spline data in use
@@ -123,14 +124,16 @@ static void launch_trace_iso(const prt_system_t *sys, int64_t n0, int64_t in_pit
                        packed_flags, nonconv)
 #define PRT_LAUNCH(VI, VO)                 \
     do {                                   \
-        if (sys->all_conic)                \
-            PRT_LAUNCH_E(VI, VO, false);   \
-        else                               \
-            PRT_LAUNCH_E(VI, VO, true);    \
+        if (sys->shape_level == PRT_SHAPES_CONIC)          \
+            PRT_LAUNCH_E(VI, VO, PRT_SHAPES_CONIC);        \
+        else if (sys->shape_level == PRT_SHAPES_ASPHERE)   \
+            PRT_LAUNCH_E(VI, VO, PRT_SHAPES_ASPHERE);      \
+        else                                               \
+            PRT_LAUNCH_E(VI, VO, PRT_SHAPES_ALL);          \
     } while (0)
     static const bool lds_table = getenv("PRT_LDS_TABLE") != nullptr;
     if (vec_in && vec_out && lds_table && sys->all_conic && sys->n_surfaces <= PRT_LDS_TAB_MAX)
-        hipLaunchKernelGGL((k_trace_iso<MODE, true, true, false, true>), grid, block, 0, st, sys->d_table,
+        hipLaunchKernelGGL((k_trace_iso<MODE, true, true, PRT_SHAPES_CONIC, true>), grid, block, 0, st, sys->d_table,
                            sys->n_surfaces, n0, in_pitch, x0, k0, e_re, e_im, e_mode, out_pitch, x_hit,
                            k_out, valid, valid_out, 0.0, 0.0, 0.0, (double *)nullptr, packed_flags);
     else if (vec_in && vec_out)
@@ -235,6 +238,7 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     memcpy(sys->h_table, table, sizeof(prt_surface_t) * n_surfaces);
     sys->all_isotropic = 1;
     sys->all_conic = 1;
+    sys->shape_level = PRT_SHAPES_CONIC;
     // side array: per surface its doubles (coefficients, or the grid-sag spline) then, 8-byte
     // aligned, its (x power, y power) pairs
     auto n_doubles = [](const prt_surface_t &r) -> size_t {
@@ -267,6 +271,8 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
         prt_dev_surface &d = recs[s];
         if (r.mat_type != PRT_MAT_ISOTROPIC) sys->all_isotropic = 0;
         if (r.shape_type != PRT_SHAPE_CONIC) sys->all_conic = 0;
+        if (r.shape_type == PRT_SHAPE_ASPHERE && sys->shape_level < PRT_SHAPES_ASPHERE) sys->shape_level = PRT_SHAPES_ASPHERE;
+        if (r.shape_type != PRT_SHAPE_CONIC && r.shape_type != PRT_SHAPE_ASPHERE) sys->shape_level = PRT_SHAPES_ALL;
         memset(&d, 0, sizeof d);
         d.shape_type = r.shape_type;
         d.n_coeffs = r.n_coeffs;
@@ -611,11 +617,13 @@ int32_t prt_trace_moments(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
                        sys->n_surfaces, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch, x_hit,     \
                        k_out, valid, valid_out, rx, ry, rz, scratch_dev, packed_flags)
         if (mode == PRT_MODE_PATH) {
-            if (sys->all_conic) PRT_LAUNCH_M(PRT_MODE_PATH, false);
-            else PRT_LAUNCH_M(PRT_MODE_PATH, true);
+            if (sys->shape_level == PRT_SHAPES_CONIC) PRT_LAUNCH_M(PRT_MODE_PATH, PRT_SHAPES_CONIC);
+            else if (sys->shape_level == PRT_SHAPES_ASPHERE) PRT_LAUNCH_M(PRT_MODE_PATH, PRT_SHAPES_ASPHERE);
+            else PRT_LAUNCH_M(PRT_MODE_PATH, PRT_SHAPES_ALL);
         } else {
-            if (sys->all_conic) PRT_LAUNCH_M(PRT_MODE_IMAGE, false);
-            else PRT_LAUNCH_M(PRT_MODE_IMAGE, true);
+            if (sys->shape_level == PRT_SHAPES_CONIC) PRT_LAUNCH_M(PRT_MODE_IMAGE, PRT_SHAPES_CONIC);
+            else if (sys->shape_level == PRT_SHAPES_ASPHERE) PRT_LAUNCH_M(PRT_MODE_IMAGE, PRT_SHAPES_ASPHERE);
+            else PRT_LAUNCH_M(PRT_MODE_IMAGE, PRT_SHAPES_ALL);
         }
 #undef PRT_LAUNCH_M
         const unsigned ng = (nb + PRT_BLOCK - 1) / PRT_BLOCK;

@@ -346,10 +346,17 @@ PRT_DEV void gridsag_eval(const prt_dev_surface *__restrict__ sf, double x, doub
     }
 }
 
+// Which shape code a kernel instantiation carries (the host picks the level from the table's content):
+// 0: conics only; 1: conics and even aspheres; 2: every shape.  Fewer shapes = fewer VGPRs = more waves.
+#define PRT_SHAPES_CONIC 0
+#define PRT_SHAPES_ASPHERE 1
+#define PRT_SHAPES_ALL 2
+
 // explicit z = F(x,y) shapes: value and in-plane derivatives
+template <int SHAPES = PRT_SHAPES_ALL>
 PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, double x, double y, double &F,
                            double &Fx, double &Fy) {
-    if (sf->shape_type == PRT_SHAPE_ASPHERE) {
+    if (SHAPES == PRT_SHAPES_ASPHERE || sf->shape_type == PRT_SHAPE_ASPHERE) {
         double m;
         asphere_eval(sf, sf->n_coeffs, x, y, F, m);
         Fx = x * m;
@@ -383,6 +390,7 @@ PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, double x, dou
 // iteration was <= 1e-15, so they are the derivatives at the root to rounding and the
 // normal does not need another evaluation of the shape.
 // The convergence scale is in units of |d| (d may be k, |k| = n ~ 1..2).
+template <int SHAPES = PRT_SHAPES_ALL>
 PRT_DEV double explicit_t(const prt_dev_surface *__restrict__ sf, const vec3 &r0, const vec3 &d,
                           bool &nonconv, double &gx, double &gy) {
     double t = 0.0;
@@ -393,7 +401,7 @@ PRT_DEV double explicit_t(const prt_dev_surface *__restrict__ sf, const vec3 &r0
     for (int it = 0; it < maxit; ++it) {
         double F, Fx, Fy;
         const double px = r0.x + t * d.x, py = r0.y + t * d.y;
-        explicit_eval(sf, px, py, F, Fx, Fy);
+        explicit_eval<SHAPES>(sf, px, py, F, Fx, Fy);
         const double g = r0.z + t * d.z - F;
         const double gp = d.z - Fx * d.x - Fy * d.y;
         const double dt = g * fast_rcp(gp);
@@ -448,7 +456,7 @@ PRT_DEV bool aperture_ok(const prt_dev_surface *__restrict__ sf, double x, doubl
 // ---------------------------------------------------------------------------
 //        g (unnormalised surface gradient at p, shape frame) and g2 = |g|^2 as by-products
 //   d may be any positive multiple of the unit direction, d2 = d.d
-template <bool EXPLICIT = true>
+template <int SHAPES = PRT_SHAPES_ALL>
 PRT_DEV void propagate_step(const prt_dev_surface *__restrict__ sf, const vec3 &x, const vec3 &d,
                             double d2, vec3 &xh, vec3 &p, vec3 &g, double &g2, bool &valid, bool &nonconv) {
     nonconv = false;
@@ -460,7 +468,7 @@ PRT_DEV void propagate_step(const prt_dev_surface *__restrict__ sf, const vec3 &
         dl = matT_vec(sf->B_shape, d);
     }
     double t;
-    if (!EXPLICIT || sf->shape_type == PRT_SHAPE_CONIC) {
+    if (SHAPES == PRT_SHAPES_CONIC || sf->shape_type == PRT_SHAPE_CONIC) {
         bool ok;
         t = conic_t(sf->curv, sf->cc, r0, dl, d2, ok);
         valid = valid && ok;
@@ -468,7 +476,7 @@ PRT_DEV void propagate_step(const prt_dev_surface *__restrict__ sf, const vec3 &
         g = conic_grad_on_surface(sf->curv, sf->cc, p, g2);
     } else {
         double fx, fy;
-        t = explicit_t(sf, r0, dl, nonconv, fx, fy);  // reference: valid all True (surface_shape.py:462)
+        t = explicit_t<SHAPES>(sf, r0, dl, nonconv, fx, fy);  // reference: valid all True (surface_shape.py:462)
         // A ray whose Newton iteration hit the cap has no trustworthy hit point.  The mask after
         // propagate stays reference-compatible (True); the NaN hit point makes the normal NaN, so
         // the ray is dropped by the finite-normal test of the following refraction.  `nonconv` is
@@ -508,10 +516,10 @@ PRT_DEV vec3 to_shape_frame(const prt_dev_surface *__restrict__ sf, const vec3 &
 // unit normal in the frame of the medium from the shape-frame gradient g (|g|^2 = g2):
 // Shape.getNormal (surface_shape.py:100-112) + RayBundle.getLocalSurfaceNormal (ray.py:156-161).
 // Spheres have |g| = 1 identically (conic_grad_on_surface): no normalisation.
-template <bool EXPLICIT = true>
+template <int SHAPES = PRT_SHAPES_ALL>
 PRT_DEV vec3 normal_from_grad(const prt_dev_surface *__restrict__ sf, const vec3 &g, double g2) {
     vec3 n = g;
-    if (!((!EXPLICIT || sf->shape_type == PRT_SHAPE_CONIC) && sf->cc == 0.0)) {
+    if (!((SHAPES == PRT_SHAPES_CONIC || sf->shape_type == PRT_SHAPE_CONIC) && sf->cc == 0.0)) {
         const double r = fast_rsqrt(g2);
         n = v3(g.x * r, g.y * r, g.z * r);
     }

@@ -1,6 +1,6 @@
 // prt_kernels.h -- the __global__ kernels of libprt.so (launched from prt.hip).
 //
-//   k_trace_iso<MODE,VEC_IN,VEC_OUT,EXPLICIT,LDS_TAB>  whole isotropic sequence in one launch
+//   k_trace_iso<MODE,VEC_IN,VEC_OUT,SHAPES,LDS_TAB>    whole isotropic sequence in one launch
 //   k_trace_general<MODE>                              whole sequence through crystals (leaf re-tracing)
 //   k_propagate / k_interact_iso / k_interact_aniso    one plugin-granular step
 //   k_shape_eval, k_efield_perp, k_poynting_dir, k_path_sums
@@ -138,9 +138,9 @@ PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
 // into VGPRs) instead of through the scalar cache (s_load into SGPRs).  Kept only for that A/B
 // (PRT_LDS_TABLE=1); it is slower and uses more VGPRs.
 #define PRT_LDS_TAB_MAX 16
-// EXPLICIT = false: the host guarantees that every shape of the table is a Conic, and the
-// Newton / polynomial code of the explicit shapes is compiled out (fewer VGPRs: one more wave
-// per SIMD for the all-conic systems such as the double Gauss).
+// SHAPES (prt_device.h): the shape code compiled into the instantiation.  The host guarantees that the
+// table holds nothing else: conics only -> no Newton / polynomial code at all (68 VGPRs, 7 waves per SIMD:
+// the double Gauss); conics + even aspheres (BASELINE configs[2]); every shape (116 VGPRs, 4 waves).
 // MOMENTS = true additionally reduces the image-plane spot moments of the bundle inside the same
 // launch: every block writes {count, sum v, sum v*v} (v = last hit point - mref, rays still valid
 // after the last interaction) of its 512 rays to moment_partials[blockIdx.x*7..]; k_moments_final
@@ -149,7 +149,7 @@ PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
 #define MOM_VALUES 7
 // Image mode of the all-conic march is FP64-VALU bound: 8 waves/SIMD (63 VGPRs, no spills) instead
 // of the allocator's 7 is worth 5 % there (0.47 -> 0.446 ms); path mode is HBM bound and unaffected.
-template <int MODE, bool VEC_IN, bool VEC_OUT, bool EXPLICIT = true, bool LDS_TAB = false,
+template <int MODE, bool VEC_IN, bool VEC_OUT, int SHAPES = PRT_SHAPES_ALL, bool LDS_TAB = false,
           bool MOMENTS = false>
 #ifndef PRT_PATH_WAVES
 #define PRT_PATH_WAVES 1
@@ -164,7 +164,12 @@ template <int MODE, bool VEC_IN, bool VEC_OUT, bool EXPLICIT = true, bool LDS_TA
 #ifdef PRT_PATH_WAVES_MAX   // experiment: cap the occupancy of every march instantiation
 __attribute__((amdgpu_waves_per_eu(1, PRT_PATH_WAVES_MAX)))
 #endif
-__global__ __launch_bounds__(PRT_MARCH_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE == PRT_MODE_IMAGE ? 8 : PRT_PATH_WAVES) : 1) void k_trace_iso(
+// asphere level: 82 VGPRs on its own = 5 waves; forcing 6 (80 VGPRs, 2-14 spilled dwords) is no faster in
+// path mode and 6 % slower in image mode (benchmarks/ab_variants.py asphere)
+#ifndef PRT_ASPHERE_WAVES
+#define PRT_ASPHERE_WAVES 5
+#endif
+__global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LDS_TAB) ? (MODE == PRT_MODE_IMAGE ? 8 : PRT_PATH_WAVES) : (SHAPES == PRT_SHAPES_ASPHERE ? PRT_ASPHERE_WAVES : 1)) void k_trace_iso(
     const prt_dev_surface *__restrict__ tab_g, int32_t S, int64_t N, int64_t in_pitch,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, int64_t out_pitch,
@@ -203,9 +208,9 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE ==
         for (int r = 0; r < 2; ++r) {
             vec3 xh, p, g;
             double g2;
-            propagate_step<EXPLICIT>(sf, x[r], d[r], d2, xh, p, g, g2, valid[r], ncv[r]);
+            propagate_step<SHAPES>(sf, x[r], d[r], d2, xh, p, g, g2, valid[r], ncv[r]);
             vhit[r] = valid[r];
-            nrm[r] = normal_from_grad<EXPLICIT>(sf, g, g2);
+            nrm[r] = normal_from_grad<SHAPES>(sf, g, g2);
             x[r] = xh;
         }
         // the hit points go out before the interaction is computed: spreading a surface's stores
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (!EXPLICIT && !LDS_TAB) ? (MODE ==
                 if (valid_out_refr)
                     rayio<VEC_OUT>::store_mask(valid_out_refr + so * out_pitch, i, second, valid);
             }
-            if (EXPLICIT && nonconv_out)
+            if (SHAPES != PRT_SHAPES_CONIC && nonconv_out)
                 rayio<VEC_OUT>::store_mask(nonconv_out + so * out_pitch, i, second, ncv);
         }
     }
