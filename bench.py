@@ -513,7 +513,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(records, x0[:, :m].cpu().numpy(), k0[:, :m].cpu().numpy(),
                                                    e0d[:, :m].cpu().numpy(), n_all=n_local)
             else:
-                m = 10_000_000 if args.config == "asphere" else 64_000
+                m = 4_000_000 if args.config == "asphere" else 64_000
                 out["cpu_baseline"] = cpu_baseline_numpy(records, x0[:, :m].cpu().numpy(), k0[:, :m].cpu().numpy(),
                                                          e0d[:, :m].cpu().numpy(), m, n_local)
         else:

@@ -129,7 +129,12 @@ def seqtrace_fused(ib, records, lengths):
     k0 = ib._k[-1]
     (e_re, e_im) = _initial_fields(ib, k0)
     res = sysd.trace(x0, k0, e_re, e_im, mode=_lib.MODE_PATH, packed_flags=True)
-    ids0 = ib.ray_ids_dev()
+    ids_cache = []            # rayIDs on the device: built when the first bundle is touched, not per trace
+
+    def ids0():
+        if not ids_cache:
+            ids_cache.append(ib.ray_ids_dev())
+        return ids_cache[0]
     wave = ib.wave
     kc = ib._k_complex
 
@@ -145,7 +150,7 @@ def seqtrace_fused(ib, records, lengths):
             if j < S:
                 arrays.append(res.x_hit[j])
                 flags = res.valid[j]
-            out = engine.compact(mask, arrays, ids0, flags)
+            out = engine.compact(mask, arrays, ids0(), flags)
             (cx, ck) = (out[0][0], out[0][1])
             m = cx.shape[1]
             ones = torch.ones(m, dtype=torch.uint8, device=dev)
