@@ -405,6 +405,26 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
         prt_slab s;
         bool became_rep = false;
         hunt_err = arena_new_slab(a, st, &s, &became_rep);
+        if (hunt_err == hipErrorOutOfMemory) {
+            // The driver has nothing left.  Buffers of other sizes that sit in the cache hold slabs this
+            // request can use: take them apart (their addresses are retired, the slabs classified already).
+            bool recycled = false;
+            for (size_t i = 0; i < a->buffers.size();) {
+                prt_placed_buffer *b = a->buffers[i];
+                if (!b->in_use) {
+                    arena_unmap_buffer(a, b, true);
+                    delete b;
+                    a->buffers.erase(a->buffers.begin() + i);
+                    recycled = true;
+                } else {
+                    ++i;
+                }
+            }
+            if (recycled) {
+                hunt_err = hipSuccess;
+                continue;
+            }
+        }
         if (hunt_err != hipSuccess) break;
         if (!became_rep) a->free_slabs.push_back(s);
         ++hunted;

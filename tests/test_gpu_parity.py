@@ -735,3 +735,29 @@ def test_arena_buffers_keep_their_data_through_allocation_churn(gpu_device):
             assert int(words[1]) == tag and int(words[-1]) in (tag, tag + (words.shape[0] - 1) // 4097)
     del live
     arena.trim()
+
+
+def test_arena_recycles_cached_buffers_when_the_device_is_full(gpu_device):
+    """buffers of other sizes that sit in the arena's cache must not starve a new request: with the free
+    memory squeezed to ~40 GiB, requests of growing size succeed by taking the cached buffers apart"""
+    from pyrate_amd import placed
+    arena = placed.PlacedArena.for_device(0)
+    arena.trim()
+    (free_b, _) = torch.cuda.mem_get_info(gpu_device)
+    hog = torch.empty(max(0, free_b - (40 << 30)), dtype=torch.uint8, device=gpu_device)   # untouched
+    try:
+        created_before = arena.stats()["slabs_created"]
+        for gib in (7, 8, 9, 10):
+            (parts, kinds) = arena.alloc([gib << 30, gib << 30])
+            parts[0][:16].fill_(gib)
+            parts[1][-16:].fill_(gib)
+            assert int(parts[0][0]) == gib and int(parts[1][-1]) == gib
+            del parts                       # back to the cache: 2 * gib GiB stay mapped
+        st = arena.stats()
+        # 2 * (7 + 8 + 9 + 10) = 68 GiB were requested in total, more than the device had to give:
+        # slabs were recycled from the cache instead of taken from the driver
+        assert st["slabs_created"] - created_before < 60, st
+    finally:
+        del hog
+        arena.trim()
+        torch.cuda.empty_cache()
