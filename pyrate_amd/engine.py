@@ -225,7 +225,8 @@ class DeviceSystem(object):
         auto_placement = placement == "auto"
         if placement == "auto":
             big = 8 * (nx + nk) + nv + nw >= placed.PLACED_MIN_BYTES
-            placement = "arena" if (mode == _lib.MODE_PATH and big and not want_fields) else "torch"
+            placement = "arena" if (mode == _lib.MODE_PATH and big and not want_fields
+                                    and placed.DISABLED is None) else "torch"
         if placement not in ("arena", "torch"):
             raise ValueError("placement must be 'auto', 'arena' or 'torch'")
         parts = None
@@ -234,18 +235,22 @@ class DeviceSystem(object):
             def up(v):
                 return -(-v // 4096) * 4096
             (off_v, off_w) = (up(8 * nx), up(up(8 * nx) + nv))
-            arena = placed.PlacedArena.for_device(dev.index)
             # (without extras: stay out of the kinds beyond the first two -- that is where big input
             # bundles live, engine.ray_rows)
             try:
+                arena = placed.PlacedArena.for_device(dev.index)
                 (parts, kinds) = arena.alloc([off_w + nw, 8 * nk] + [int(b) for b in extra_bytes],
                                              n_distinct=3 if extra_bytes else 2,
                                              avoid_mask=0 if extra_bytes else (0xF & ~placed.OUTPUT_KINDS_MASK))
             except _lib.PrtError as exc:
-                # no whole free slabs left on the device (somebody else holds the memory): the arrays
-                # come from the torch allocator like small ones do -- slower placement, same results
-                if exc.code != _lib.ERR_NOMEM or extra_bytes or auto_placement is False:
+                # "auto" never fails because of the arena: no whole free slabs left on the device
+                # (somebody else holds the memory), or a driver without the virtual-memory API -- the
+                # arrays then come from the torch allocator like small ones do (slower placement, same
+                # results).  An explicit placement="arena" raises.
+                if extra_bytes or not auto_placement:
                     raise
+                if exc.code != _lib.ERR_NOMEM:
+                    placed.disable("prt_arena_alloc failed: %s" % exc)
                 placement = "torch"
         if parts is not None:
             bufs = dict(
@@ -686,13 +691,14 @@ def ray_rows(n, device):
     input loads that share a kind of HBM with the march's write streams cost it 5 %."""
     pitch = recommended_pitch(n)
     device = torch.device(device)
-    if device.type == "cuda" and 3 * pitch * 8 >= placed.PLACED_INPUT_MIN_BYTES:
+    if device.type == "cuda" and 3 * pitch * 8 >= placed.PLACED_INPUT_MIN_BYTES and placed.DISABLED is None:
         try:
             with torch.cuda.device(device):
                 return placed.input_rows.take(device, pitch)[:, :n]
         except _lib.PrtError as exc:
-            if exc.code != _lib.ERR_NOMEM:      # no whole free slabs left: torch memory, slower placement
-                raise
+            # no whole free slabs left / no virtual-memory API: torch memory, slower placement
+            if exc.code != _lib.ERR_NOMEM:
+                placed.disable("prt_arena_alloc failed: %s" % exc)
     return torch.empty((3, pitch), dtype=torch.float64, device=device)[:, :n]
 
 

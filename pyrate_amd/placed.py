@@ -27,6 +27,20 @@ PLACED_INPUT_MIN_BYTES = int(os.environ.get("PRT_PLACED_INPUT_MIN_BYTES", 96 << 
 OUTPUT_KINDS_MASK = 0b011       # a two-part output request takes kinds 0 and 1
 
 
+# set (with the reason) when the arena turned out to be unusable on this machine -- e.g. a driver without
+# the HIP virtual-memory API; automatic placement then stays with the torch allocator for the process
+DISABLED = None
+
+
+def disable(reason):
+    global DISABLED
+    if DISABLED is None:
+        DISABLED = str(reason)
+        import warnings
+        warnings.warn("pyrate_amd: placement-aware memory switched off, path arrays come from the torch "
+                      "allocator (%s)" % reason, RuntimeWarning)
+
+
 class InputRows(object):
     """Row-pitched (3, pitch) blocks for big input bundles, nine rows (x0, k0, E0) per arena buffer."""
 
