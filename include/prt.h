@@ -18,7 +18,7 @@
  * reference checkout, package pyrateoptics 0.4.0):
  *
  *   prt_trace            OpticalSystem.seqtrace      raytracer/optical_system.py:73-94
- *                        OpticalElement.seqtrace     raytracer/optical_element.py:324-379
+ *   prt_trace_seq        OpticalElement.seqtrace     raytracer/optical_element.py:324-379
  *   prt_propagate        Material.propagate          raytracer/material/material_isotropic.py:238-247
  *                        Surface.intersect           raytracer/surface.py:116-135
  *                        Conic.intersect             raytracer/surface_shape.py:289-325
@@ -189,6 +189,24 @@ int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const d
                   const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
                   int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
                   uint8_t *valid_out, uint8_t *nonconv, void *stream);
+
+/*
+ * The same in one call, without a handle (the form SURVEY.md section 8b proposes): the table is uploaded
+ * on first use and kept by content (the last 8 tables of the process).
+ *   x0, k0        (3,n) tight arrays on the device
+ *   d0            (3,n) unit directions of the first segment (RayBundle.returnKtoD of the initial
+ *                 bundle, ray.py:136-152) or NULL: d = k/|k| (E perpendicular to k)
+ *   ray_id        accepted for the caller's bookkeeping and ignored: outputs are dense, column i
+ *                 belongs to input ray i
+ *   mode          PRT_MODE_PATH: x_hit, k_out (S,3,n), valid (S,n) tight -- tables with crystals: the
+ *                 concatenated layout of prt_trace; PRT_MODE_IMAGE: the last surface only
+ *   valid         cumulative mask after intersect + aperture (the reference's RayBundle.valid);
+ *   nonconv       optional, as in prt_trace
+ * Asynchronous on `stream` (tables with grid-sag surfaces are not cached and synchronise it).
+ */
+int32_t prt_trace_seq(const prt_surface_t *table, int32_t n_surfaces, int64_t n, const double *x0,
+                      const double *k0, const double *d0, const int64_t *ray_id, int32_t mode, double *x_hit,
+                      double *k_out, uint8_t *valid, uint8_t *nonconv, int32_t device, void *stream);
 
 /*
  * prt_trace for all-isotropic tables that also reduces the image-plane moments of the traced

@@ -121,6 +121,9 @@ PROTOTYPES["prt_bundle_moments_async"] = (ctypes.c_int32, [ctypes.c_int32, ctype
                                                           c_double_p, c_u8_p, ctypes.c_int32, c_double_p,
                                                           ctypes.c_int32, c_double_p, c_double_p, c_stream])
 
+PROTOTYPES["prt_trace_seq"] = (ctypes.c_int32, [ctypes.POINTER(PrtSurface), ctypes.c_int32, ctypes.c_int64, c_double_p,
+                                               c_double_p, c_double_p, ctypes.c_void_p, ctypes.c_int32, c_double_p,
+                                               c_double_p, c_u8_p, c_u8_p, ctypes.c_int32, c_stream])
 PROTOTYPES["prt_trace_fields"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, c_double_p, c_double_p,
                                                   c_double_p, c_double_p, ctypes.c_int32, c_double_p,
                                                   c_double_p, c_double_p, c_double_p, c_u8_p, c_u8_p,

@@ -10,6 +10,7 @@
 #include <math.h>
 #include <string.h>
 #include <new>
+#include <mutex>
 #include "prt_kernels.h"
 
 
@@ -357,7 +358,7 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
                              const double *k0, const double *e_re, const double *e_im,
                              int32_t mode, double *x_hit, double *k_out, double *e_out,
                              double *e_out_im, uint8_t *valid, uint8_t *valid_out, uint8_t *nonconv,
-                             hipStream_t st) {
+                             int32_t e_mode_first, hipStream_t st) {
     const int S = sys->n_surfaces;
     // scratch: directions after anisotropic interfaces, plus ping-pong state in IMAGE mode
     int64_t n_final = n0;
@@ -396,7 +397,12 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
     int64_t n_src = n0;  // number of distinct points in cur_x
     int64_t n = n0;
     int64_t off_in = 0, off_out = 0;  // element offsets into the concatenated outputs
-    int e_mode = e_mode_of(e_re, 1);
+    int e_mode = e_mode_first;
+    if (e_mode == 3) {  // the caller's unit directions for the first segment
+        cur_dir = e_re;
+        e_re = nullptr;
+        e_mode = 0;
+    }
     for (int s = 0; s < S; ++s) {
         const prt_surface_t *rec = sys->h_table + s;
         const bool last = (s == S - 1);
@@ -464,8 +470,10 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
                           const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
                           int64_t out_pitch, double *x_hit, double *k_out, double *e_out,
                           double *e_out_im, uint8_t *valid, uint8_t *valid_out, uint8_t *nonconv,
-                          void *stream) {
+                          void *stream, int32_t first_dir_mode = -1) {
+    // first_dir_mode: -1 = from E0 (e0_re NULL: E = ey), 0 = d = k/|k|, 3 = e0_re holds the unit directions
     if (!sys || n0 < 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace: null system / negative count");
+    const int32_t e_mode_first = first_dir_mode >= 0 ? first_dir_mode : e_mode_of(e0_re, 1);
     const int32_t packed_flags = (mode & PRT_MODE_FLAGS) ? 1 : 0;
     if (mode >= 0) mode &= ~PRT_MODE_FLAGS;
     if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE)
@@ -494,9 +502,9 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
         // independent implementation PRT_GENERAL_PER_SURFACE=1 selects for cross-checks.
         if (per_surface || n_aniso > PRT_FUSED_MAX_CRYSTALS)
             return trace_general(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, e_out, e_out_im, valid, valid_out,
-                                 nonconv, st);
+                                 nonconv, e_mode_first, st);
         const dim3 grid(nblocks(n0, PRT_BLOCK)), block(PRT_BLOCK);
-        const int32_t e_mode_g = e_mode_of(e0_re, 1);
+        const int32_t e_mode_g = e_mode_first;
         bool general_eps = false;
         for (int s = 0; s < sys->n_surfaces; ++s)
             if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC &&
@@ -527,7 +535,7 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
         return PRT_OK;
     }
     if (out_pitch == 0) out_pitch = n0;
-    const int32_t e_mode = e_mode_of(e0_re, 1);
+    const int32_t e_mode = e_mode_first;
     const bool vec_in = (in_pitch % 2 == 0) && aligned16(x0) && aligned16(k0) &&
                         (!e0_re || aligned16(e0_re)) && (!e0_im || aligned16(e0_im));
     if (packed_flags) valid_out = nullptr;
@@ -554,6 +562,88 @@ int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const d
                   uint8_t *valid_out, uint8_t *nonconv, void *stream) {
     return trace_core(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out,
                       (double *)nullptr, (double *)nullptr, valid, valid_out, nonconv, stream);
+}
+
+// ---- one-call form: no handle for the caller to keep -----------------------
+// Tables are uploaded once and kept by content (the last PRT_SEQ_CACHE of them per process): an optimiser
+// loop that re-traces a changing prescription pays one table upload per distinct table.
+#define PRT_SEQ_CACHE 8
+struct seq_cache_entry {
+    int32_t device, n_surfaces;
+    prt_surface_t *table;  // host copy, the key
+    prt_system *sys;
+    uint64_t stamp;
+};
+static std::mutex g_seq_mu;
+static seq_cache_entry g_seq_cache[PRT_SEQ_CACHE];
+static uint64_t g_seq_clock = 0;
+
+static int32_t seq_system(const prt_surface_t *table, int32_t S, int32_t device, prt_system **out, bool *owned) {
+    *owned = false;
+    bool cacheable = true;  // records that point to host data (grid-sag splines) are not compared by content
+    for (int s = 0; s < S; ++s)
+        if (table[s].aux) cacheable = false;
+    if (!cacheable) {
+        *owned = true;
+        return prt_system_create(table, S, device, out);
+    }
+    std::lock_guard<std::mutex> lock(g_seq_mu);
+    int victim = 0;
+    for (int i = 0; i < PRT_SEQ_CACHE; ++i) {
+        seq_cache_entry &e = g_seq_cache[i];
+        if (e.sys && e.device == device && e.n_surfaces == S &&
+            memcmp(e.table, table, sizeof(prt_surface_t) * (size_t)S) == 0) {
+            e.stamp = ++g_seq_clock;
+            *out = e.sys;
+            return PRT_OK;
+        }
+        if (g_seq_cache[i].stamp < g_seq_cache[victim].stamp) victim = i;
+    }
+    prt_system *sys = nullptr;
+    int32_t rc = prt_system_create(table, S, device, &sys);
+    if (rc != PRT_OK) return rc;
+    prt_surface_t *copy = new (std::nothrow) prt_surface_t[S];
+    if (!copy) {
+        *owned = true;  // no room to remember it: the caller's call owns it
+        *out = sys;
+        return PRT_OK;
+    }
+    memcpy(copy, table, sizeof(prt_surface_t) * (size_t)S);
+    seq_cache_entry &v = g_seq_cache[victim];
+    if (v.sys) {
+        // work of earlier calls may still use the evicted table
+        device_guard guard_(v.device);
+        (void)hipDeviceSynchronize();
+        free_system(v.sys);
+        delete[] v.table;
+    }
+    v.device = device;
+    v.n_surfaces = S;
+    v.table = copy;
+    v.sys = sys;
+    v.stamp = ++g_seq_clock;
+    *out = sys;
+    return PRT_OK;
+}
+
+int32_t prt_trace_seq(const prt_surface_t *table, int32_t n_surfaces, int64_t n, const double *x0,
+                      const double *k0, const double *d0, const int64_t *ray_id, int32_t mode, double *x_hit,
+                      double *k_out, uint8_t *valid, uint8_t *nonconv, int32_t device, void *stream) {
+    (void)ray_id;  // outputs are dense: column i belongs to input ray i, whatever the caller calls it
+    if (!table || n_surfaces <= 0 || n < 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace_seq: bad table / count");
+    if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE) return fail(PRT_ERR_INVALID_ARG, "prt_trace_seq: bad mode");
+    prt_system *sys = nullptr;
+    bool owned = false;
+    int32_t rc = seq_system(table, n_surfaces, device, &sys, &owned);
+    if (rc != PRT_OK) return rc;
+    rc = trace_core(sys, n, 0, x0, k0, d0, nullptr, mode, 0, x_hit, k_out, (double *)nullptr, (double *)nullptr,
+                    valid, (uint8_t *)nullptr, nonconv, stream, d0 ? 3 : 0);
+    if (owned) {
+        device_guard guard_(device);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        free_system(sys);
+    }
+    return rc;
 }
 
 int32_t prt_trace_fields(const prt_system_t *sys, int64_t n0, const double *x0, const double *k0,

@@ -106,6 +106,7 @@ struct rayio {
 
 // first-segment direction selector
 //   e_mode 0: d = k/|k|        1: E = (0,1,0) (ray.py:71-73)     2: E given (re [, im])
+//          3: e_re holds the unit directions themselves (prt_trace_seq's d0)
 template <bool VEC>
 PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
                              const double *__restrict__ e_im, int64_t pitch, int64_t i, bool second,
@@ -116,6 +117,8 @@ PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
     } else if (e_mode == 1) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) d[r] = poynting_dir(k[r], v3(0, 1, 0), v3(0, 0, 0));
+    } else if (e_mode == 3) {
+        rayio<VEC>::load(e_re, pitch, i, second, d);
     } else {
         vec3 er[2], ei[2];
         rayio<VEC>::load(e_re, pitch, i, second, er);

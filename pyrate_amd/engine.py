@@ -419,6 +419,37 @@ class DeviceSystem(object):
         return sag, grad
 
 
+def trace_seq(records, x0, k0, d0=None, mode=_lib.MODE_PATH, want_nonconv=False, device=None):
+    """The one-call form of the boundary (prt_trace_seq): surface records + tight (3, n)
+    device arrays in, dense tight outputs back -- no DeviceSystem to keep; the library caches the uploaded
+    table by content.  ``d0``: unit directions of the first segment, None = k/|k|.  Returns a TraceResult
+    (x_hit, k_out, valid [, nonconv]; valid_out is not part of this entry point)."""
+    lib = _lib.load()
+    (x0, k0, d0) = [_rows_contiguous(t) for t in (x0, k0, d0)]
+    _check_rays(x0, "x0")
+    n = x0.shape[1]
+    dev = x0.device if device is None else device
+    table = pack_table(list(records))
+    S = len(table)
+    counts_in = [n]
+    for r in list(records)[:-1]:
+        counts_in.append(counts_in[-1] * (2 if r["material"]["type"] == "anisotropic" else 1))
+    counts_out = [c * (2 if r["material"]["type"] == "anisotropic" else 1) for (c, r) in zip(counts_in, records)]
+    if mode == _lib.MODE_IMAGE:
+        (counts_in, counts_out) = (counts_in[-1:], counts_out[-1:])
+    with torch.cuda.device(dev):
+        bufs = dict(x_hit=torch.empty(3 * sum(counts_in), dtype=torch.float64, device=dev),
+                    k_out=torch.empty(3 * sum(counts_out), dtype=torch.float64, device=dev),
+                    valid=torch.empty(sum(counts_in), dtype=torch.uint8, device=dev), valid_out=None,
+                    n_in=counts_in, n_out=counts_out, mode=mode, pitch=0, packed_flags=False)
+        if want_nonconv:
+            bufs["nonconv"] = torch.zeros(sum(counts_in), dtype=torch.uint8, device=dev)
+        _lib.check(lib.prt_trace_seq(table, S, n, _ptr(x0), _ptr(k0), _ptr(d0), None, mode, _ptr(bufs["x_hit"]),
+                                     _ptr(bufs["k_out"]), _ptr(bufs["valid"]), _ptr(bufs.get("nonconv")),
+                                     dev.index, _stream_handle(dev)))
+    return TraceResult.from_buffers(bufs)
+
+
 def compact(mask, arrays, ids=None, flags=None):
     """Order-preserving ``[:, mask]`` on the device (material_isotropic.py:194-199).
     arrays: list of (R_i, N) float64 tensors; ids: optional (N,) int64; flags: optional

@@ -761,3 +761,41 @@ def test_arena_recycles_cached_buffers_when_the_device_is_full(gpu_device):
         del hog
         arena.trim()
         torch.cuda.empty_cache()
+
+
+def test_one_call_trace_seq_equals_the_handle_based_trace(gpu_device):
+    """prt_trace_seq (the one-call form of SURVEY.md 8b: table + arrays in, no handle; explicit first-segment
+    directions d0): with d0 = the Poynting directions of (k0, E0) it reproduces prt_trace bit for bit, path and
+    image mode, isotropic and crystal tables; d0 = NULL means k/|k|; the table cache survives more distinct
+    tables than it holds"""
+    from pyrate_amd import engine, systems, _lib
+    (o, k, e0) = systems.double_gauss_bundle(3001, field_deg=3.0)
+    (x0, k0, e0d) = [engine.to_device_rays(a, gpu_device, pitched=False) for a in (o, k, e0)]
+    d0 = engine.poynting_dir(k0, e0d)
+    c = systems.CALCITE_TILTED
+    tables = [systems.double_gauss_records(), systems.asphere_records(),
+              systems.aniso_doublet_records(systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"]))]
+    for recs in tables:
+        sysd = engine.DeviceSystem(recs, 0)
+        for mode in (_lib.MODE_PATH, _lib.MODE_IMAGE):
+            ref = sysd.trace(x0, k0, e0d, mode=mode, want_nonconv=True)
+            one = engine.trace_seq(recs, x0, k0, d0, mode=mode, want_nonconv=True)
+            for s in range(len(ref.x_hit)):
+                assert torch.equal(one.x_hit[s].contiguous().view(torch.int64), ref.x_hit[s].contiguous().view(torch.int64))
+                assert torch.equal(one.k_out[s].contiguous().view(torch.int64), ref.k_out[s].contiguous().view(torch.int64))
+                assert torch.equal(one.valid[s], ref.valid[s]) and torch.equal(one.nonconv[s], ref.nonconv[s])
+    # d0 = NULL: d = k/|k|, which is what an E field perpendicular to k gives (to rounding)
+    recs = tables[0]
+    a = engine.trace_seq(recs, x0, k0, None)
+    b = engine.DeviceSystem(recs, 0).trace(x0, k0, engine.efield_perp(k0))
+    m = b.valid[-1].bool()
+    assert torch.equal(a.valid[-1], b.valid[-1]) and float((a.x_hit[-1] - b.x_hit[-1])[:, m].abs().max()) < 1e-12
+    # more distinct tables than the cache holds, then the first one again
+    first = engine.trace_seq(systems.double_gauss_records(), x0, k0, d0).x_hit[-1].clone()
+    for q in range(10):
+        engine.trace_seq(systems.double_gauss_records(0.45e-3 + 0.03e-3 * q), x0, k0, d0)
+    again = engine.trace_seq(systems.double_gauss_records(), x0, k0, d0).x_hit[-1]
+    assert torch.equal(first.view(torch.int64), again.contiguous().view(torch.int64))
+    # structural misuse is an error code, not a crash
+    lib = _lib.load()
+    assert lib.prt_trace_seq(None, 0, 0, None, None, None, None, 0, None, None, None, None, 0, None) == -1

@@ -162,6 +162,7 @@ def test_c_abi_exports_every_declared_symbol():
     # argument validation happens before any device work
     assert lib.prt_system_create(None, 0, 0, None) == -1
     assert lib.prt_trace(None, 0, 0, None, None, None, None, 0, 0, None, None, None, None, None, None) == -1
+    assert lib.prt_trace_seq(None, 0, 0, None, None, None, None, 0, None, None, None, None, 0, None) == -1
     assert lib.prt_recommended_pitch(9994476) == 9994752 and lib.prt_recommended_pitch(512) == 512
     assert lib.prt_compact_scratch_bytes(0) > 0
     assert lib.prt_arena_alloc(None, 0, None, None, None, -1, 0, -1, None) == -1 and lib.prt_arena_free(None, None, None) == -1
