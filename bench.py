@@ -156,8 +156,10 @@ def main():
     _stdout_of_other_ranks_to_stderr()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    # (200 steps = 0.2 s of device time at N = 1: a single scheduling hiccup of the host -- one was seen to cost
+    # 10 ms of a 50-ms timed region -- no longer moves the rate by more than a few per cent)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=["doublegauss", "asphere", "aniso"], default="doublegauss",
                     help="BASELINE.json configs[1] (default, the headline), configs[2], configs[3]")
     ap.add_argument("--rays", type=int, default=None,

@@ -411,7 +411,8 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
  *                     the write streams cost 3 % of the march); further parts get a kind no other part
  *                     of the call uses when slabs of one are at hand.  To find the kinds the arena
  *                     may take up to max_hunt_slabs extra slabs from the driver for the duration
- *                     of the call (-1: default 128); if the device cannot offer that many kinds
+ *                     of the call (-1: default 256 -- a kind is 96 GiB, so the third can be 192 slabs away; about 2.5 ms per
+ *                     slab, once); if the device cannot offer that many kinds
  *                     the call still succeeds and kinds[] tells.  avoid_mask (bit q = kind q):
  *                     kinds this request leaves to others if it can -- a caller that allocates its
  *                     input arrays separately passes 3, which keeps them out of kinds 0 and 1, the

@@ -348,7 +348,7 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
         if (bytes[i] <= 0) return fail(PRT_ERR_INVALID_ARG, "prt_arena_alloc: part sizes must be positive");
         ptrs[i] = nullptr;
     }
-    if (max_hunt_slabs < 0) max_hunt_slabs = 128;
+    if (max_hunt_slabs < 0) max_hunt_slabs = 256;   // a kind is 96 GiB: 192 slabs of the other two at worst
     PRT_ON_DEVICE(a->device);
     std::lock_guard<std::mutex> lock(a->mu);
     hipStream_t st = (hipStream_t)stream;
