@@ -451,3 +451,19 @@ def test_host_bundles_equal_reference_bundles(api):
         assert gx.shape[0] == np.array(case["x"]).shape[1], key
     assert objs["rect_60"].device_tables(60) is not None and raster.RandomGrid().device_tables(60) is None
     assert raster.ChiefAndComa().device_tables(6) is None and raster.Single().device_tables(1) is None
+
+
+def test_newton_cap_annotation_reaches_the_table(api):
+    """``shape.annotations["newton_maxit"]`` is the device-side Newton cap of an explicit shape (the reference's
+    ``iterations`` annotation never reaches its solver, surface_shape.py:457, and is not used as the cap);
+    absent / 0 leaves the record -- and with it the table flattened from unmodified reference objects -- as it was"""
+    (s, seq) = api.build_simple_optical_system(systems.asphere_builduplist())
+    (recs, _) = _flatten(s, seq, zoo.DLINE)
+    assert all("newton_maxit" not in r for r in recs)
+    elem = next(iter(s.elements.values()))
+    elem.surfaces["back"].shape.annotations["newton_maxit"] = 7
+    elem.surfaces["back"].shape.annotations["iterations"] = 3
+    (recs, _) = _flatten(s, seq, zoo.DLINE)
+    assert [r.get("newton_maxit", 0) for r in recs] == [0, 0, 7, 0]
+    table = st.pack_table(recs)
+    assert [table[i].newton_maxit for i in range(4)] == [0, 0, 7, 0]
