@@ -1,0 +1,105 @@
+#!/usr/bin/env python
+"""A/B of libprt builds (scratch/variants/libprt_<name>.so) on the Newton-intersected shapes: the 4-surface
+system of BASELINE configs[2] with its third surface replaced by an even asphere with 3 / 10 coefficients, an
+XY polynomial (12 terms up to degree 4), a Zernike-like polynomial (42 monomials up to degree 8) and a biconic
+with two (a, b) pairs; 1e7 rays at 5 degrees, path mode and image mode, same arrays for every build.
+
+    python benchmarks/ab_shapes.py [nrays]
+"""
+import ctypes
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch
+
+from pyrate_amd import engine, systems, _lib
+
+
+def system_with(surface):
+    return systems.simple_system_records([
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
+        ({"shape": "Conic"}, {"decz": 5.0}, 1.5168, "front", {}),
+        (surface, {"decz": 20.0}, None, "back", {}),
+        ({"shape": "Conic"}, {"decz": 100.0}, None, "image", {}),
+    ])
+
+
+def polynomial(degree, scale):
+    """paraboloid -r^2/60 plus small terms of every order up to `degree`, sorted by (i, j)"""
+    terms = []
+    for i in range(degree + 1):
+        for j in range(degree + 1 - i):
+            if i + j < 2:
+                continue
+            c = scale * (-1.0) ** (i + j) / (10.0 ** (i + j))
+            if (i, j) in ((2, 0), (0, 2)):
+                c += -1.0 / 60.0
+            terms.append((i, j, c))
+    return terms
+
+
+CASES = {
+    "asphere_3": {"shape": "Asphere", "curv": -1. / 30., "cc": -1.5, "coefficients": [1e-3, -1e-6, 1e-8]},
+    "asphere_10": {"shape": "Asphere", "curv": -1. / 30., "cc": -1.5,
+                   "coefficients": [1e-3, -1e-6, 1e-8, -1e-11, 1e-14, -1e-17, 1e-20, -1e-23, 1e-26, -1e-29]},
+    "xypoly_deg4": {"shape": "XYPolynomials", "normradius": 1.0, "coefficients": polynomial(4, 1e-3)},
+    "xypoly_deg8": {"shape": "XYPolynomials", "normradius": 1.0, "coefficients": polynomial(8, 1e-3)},
+    "biconic_2": {"shape": "Biconic", "curvx": -1. / 30., "curvy": -1. / 35., "ccx": -1.5, "ccy": -0.5,
+                  "coefficients": [(1e-6, 0.1), (-1e-9, -0.2)]},
+}
+
+dev = torch.device("cuda", 0)
+nrays = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10000000
+(x0, k0, e0d, n) = systems.double_gauss_bundle_device(nrays, dev, rpup=9.0, z0=-5.0, field_deg=5.0)
+pitch_in = x0.stride(0)
+st = engine._stream_handle(dev)
+P = engine._ptr
+paths = sorted(glob.glob(os.path.join(ROOT, "scratch", "variants", "libprt_*.so")))
+out = {"rays": n, "terms": {k: len(v["coefficients"]) for (k, v) in CASES.items()}}
+for (case, surface) in CASES.items():
+    sysd = engine.DeviceSystem(system_with(surface), 0)
+    libs = {"in-tree": (sysd.lib, sysd._h)}
+    for path in paths:
+        lib = ctypes.CDLL(os.path.abspath(path))
+        for name in ("prt_system_create", "prt_trace_timed", "prt_system_destroy"):
+            (res, args) = _lib.PROTOTYPES[name]
+            getattr(lib, name).restype = res
+            getattr(lib, name).argtypes = args
+        h = ctypes.c_void_p()
+        assert lib.prt_system_create(sysd._table, sysd.n_surfaces, 0, ctypes.byref(h)) == 0
+        libs[os.path.basename(path)[7:-3]] = (lib, h)
+    for (mname, mode) in (("path", _lib.MODE_PATH), ("image", _lib.MODE_IMAGE)):
+        bufs = sysd.alloc_outputs(n, mode, packed_flags=True)
+
+        def timed(lib, h, iters):
+            ms = ctypes.c_double()
+            rc = lib.prt_trace_timed(h, n, pitch_in, P(x0), P(k0), P(e0d), None, engine._mode_word(bufs),
+                                     bufs["pitch"], P(bufs["x_hit"]), P(bufs["k_out"]), P(bufs["valid"]), None, st,
+                                     iters, ctypes.byref(ms))
+            assert rc == 0, rc
+            return ms.value
+        timed(*libs["in-tree"], 10)
+        for rep in range(3):
+            for (name, (lib, h)) in libs.items():
+                timed(lib, h, 2)
+                out.setdefault("%s_%s_ms" % (case, mname), {}).setdefault(name, []).append(round(timed(lib, h, 10), 4))
+        # the builds must agree on the result (the last one timed wrote the arrays; compare against in-tree)
+        ref = None
+        for (name, (lib, h)) in libs.items():
+            timed(lib, h, 1)
+            torch.cuda.synchronize()
+            flat = bufs["x_hit"]
+            rows = flat.numel() // (3 * bufs["pitch"])
+            cur = flat[(rows - 1) * 3 * bufs["pitch"]:rows * 3 * bufs["pitch"]].view(3, bufs["pitch"])[:, :n].clone()
+            if ref is None:
+                ref = cur
+            else:
+                same = bool(torch.equal(torch.nan_to_num(cur), torch.nan_to_num(ref)))
+                out.setdefault("%s_%s_last_hit_identical_to_in_tree" % (case, mname), {})[name] = same
+        del bufs
+print(json.dumps(out))

@@ -242,24 +242,36 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     sys->shape_level = PRT_SHAPES_CONIC;
     // side array: per surface its doubles (coefficients, or the grid-sag spline) then, 8-byte
     // aligned, its (x power, y power) pairs
-    auto n_doubles = [](const prt_surface_t &r) -> size_t {
+    // coefficients of the even-asphere part of a surface: its products (n+1) a_n follow the doubles of the
+    // host table in the side array (asphere_prefetch)
+    auto n_asphere_part = [](const prt_surface_t &r) -> size_t {
+        if (r.shape_type == PRT_SHAPE_ASPHERE) return (size_t)r.n_coeffs;
+        if (r.shape_type == PRT_SHAPE_COMBO) return (size_t)r.n_asphere;
+        return 0;
+    };
+    auto n_doubles = [n_asphere_part](const prt_surface_t &r) -> size_t {
         if (r.shape_type == PRT_SHAPE_GRIDSAG)
             return (size_t)r.grid_nx + (size_t)r.grid_ny + (size_t)(r.grid_nx - 4) * (size_t)(r.grid_ny - 4);
-        return (size_t)r.n_coeffs * (r.shape_type == PRT_SHAPE_BICONIC ? 2 : 1);
+        if (r.shape_type == PRT_SHAPE_BICONIC) return 2 * (size_t)r.n_coeffs;
+        return (size_t)r.n_coeffs + n_asphere_part(r);
     };
     auto n_pows = [](const prt_surface_t &r) -> size_t {
         return (r.shape_type == PRT_SHAPE_XYPOLY || r.shape_type == PRT_SHAPE_COMBO) ? 2 * (size_t)r.n_coeffs : 0;
     };
+    // slack behind the last entry: asphere_prefetch reads PRT_ASPHERE_PREFETCH doubles from the start of a
+    // surface's coefficients whatever their number
+    const size_t PRT_SIDE_SLACK = 8 + 8 * PRT_ASPHERE_PREFETCH;
     size_t side_bytes = 0;
     for (int s = 0; s < n_surfaces; ++s)
         side_bytes += 8 * n_doubles(table[s]) + 8 * ((n_pows(table[s]) + 1) / 2);
-    char *h_side = new (std::nothrow) char[side_bytes + 8];
+    char *h_side = new (std::nothrow) char[side_bytes + PRT_SIDE_SLACK];
     if (!h_side) {
         delete[] recs;
         free_system(sys);
         return fail(PRT_ERR_NOMEM, "host alloc");
     }
-    e = hipMalloc(&sys->d_side, side_bytes + 8);
+    memset(h_side, 0, side_bytes + PRT_SIDE_SLACK);
+    e = hipMalloc(&sys->d_side, side_bytes + PRT_SIDE_SLACK);
     if (e != hipSuccess) {
         delete[] recs;
         delete[] h_side;
@@ -305,7 +317,10 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
         d.asphere_scale = r.asphere_scale;
         const size_t nd = n_doubles(r), np = n_pows(r);
         d.coeffs = (const double *)((char *)sys->d_side + off);
-        memcpy(h_side + off, r.shape_type == PRT_SHAPE_GRIDSAG ? (const void *)r.aux : (const void *)r.coeffs, 8 * nd);
+        const size_t na = n_asphere_part(r);
+        memcpy(h_side + off, r.shape_type == PRT_SHAPE_GRIDSAG ? (const void *)r.aux : (const void *)r.coeffs,
+               8 * (nd - na));
+        for (size_t n = 0; n < na; ++n) ((double *)(h_side + off))[nd - na + n] = (double)(n + 1) * r.coeffs[n];
         off += 8 * nd;
         d.pows = (const int32_t *)((char *)sys->d_side + off);
         for (size_t t = 0; t < np / 2; ++t) {
@@ -314,7 +329,7 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
         }
         off += 8 * ((np + 1) / 2);
     }
-    e = hipMemcpy(sys->d_side, h_side, side_bytes + 8, hipMemcpyHostToDevice);
+    e = hipMemcpy(sys->d_side, h_side, side_bytes + PRT_SIDE_SLACK, hipMemcpyHostToDevice);
     delete[] h_side;
     if (e == hipSuccess) e = hipMalloc((void **)&sys->d_table, sizeof(prt_dev_surface) * n_surfaces);
     if (e == hipSuccess)

@@ -212,7 +212,62 @@ PRT_DEV vec3 null_vector(const vec3 &r0, const vec3 &r1, const vec3 &r2, int var
     return v3(v2.x * inv, v2.y * inv, v2.z * inv);
 }
 
-// The four (xi, E, S.n) solutions for one ray, then the reference's ordering.
+// Eigenvector E (scaled like LAPACK's unit-norm [xi E; E]) and S.n of ONE solution xi of the
+// dispersion relation.  Closed forms where the class of eps has them (a third of the instructions of
+// the generic null vector, which stays for biaxial crystals and for the neighbourhood of the optic
+// axis, where the two sheets touch and these forms lose their digits):
+//   eps = e I:                       any two orthonormal vectors perpendicular to k
+//   eps = eo I + (ee - eo) c c^T:    ordinary  E = k x c   (perpendicular to k and to the axis),
+//                                    extraordinary  E = (k.c) k - eo c
+//     (W E = [k^T eps k - eo ee] c = 0 on the extraordinary sheet; D = eps E is perpendicular to k)
+PRT_DEV void eigen_solution(const prt_dev_surface *__restrict__ sf, int cls, const vec3 &kpa, const vec3 &n,
+                            double x, int variant, vec3 &E_out, double &sn_out) {
+    const double *__restrict__ eps = sf->eps_re;
+    const vec3 kv = v3(kpa.x + x * n.x, kpa.y + x * n.y, kpa.z + x * n.z);
+    const double k2 = dot(kv, kv);
+    vec3 E = v3(0.0, 0.0, 0.0);
+    bool closed = false;
+    if (cls == PRT_ANISO_ISOTROPIC) {
+        const double ax = fabs(kv.x), ay = fabs(kv.y), az = fabs(kv.z);
+        const vec3 a = (ax <= ay && ax <= az) ? v3(1, 0, 0) : ((ay <= az) ? v3(0, 1, 0) : v3(0, 0, 1));
+        vec3 v1 = cross(kv, a);
+        double inv = fast_rsqrt(dot(v1, v1));
+        v1 = v3(v1.x * inv, v1.y * inv, v1.z * inv);
+        if (variant == 0) {
+            E = v1;
+        } else {
+            const vec3 v2 = cross(kv, v1);
+            inv = fast_rsqrt(dot(v2, v2));
+            E = v3(v2.x * inv, v2.y * inv, v2.z * inv);
+        }
+        closed = true;
+    } else if (cls == PRT_ANISO_UNIAXIAL) {
+        const vec3 caxis = v3(sf->aniso_axis[0], sf->aniso_axis[1], sf->aniso_axis[2]);
+        const vec3 kxc = cross(kv, caxis);
+        const double q = dot(kxc, kxc);
+        closed = q > 1e-8 * k2;  // sin^2 of the angle to the optic axis
+        const double kc = dot(kv, caxis);
+        const vec3 ex = v3(kc * kv.x - sf->aniso_eo * caxis.x, kc * kv.y - sf->aniso_eo * caxis.y,
+                           kc * kv.z - sf->aniso_eo * caxis.z);
+        const vec3 raw = (variant == 0) ? kxc : ex;
+        const double inv = fast_rsqrt(dot(raw, raw));
+        E = v3(raw.x * inv, raw.y * inv, raw.z * inv);
+    }
+    if (!closed) {
+        const vec3 w0 = v3(eps[0] - k2 + kv.x * kv.x, eps[1] + kv.x * kv.y, eps[2] + kv.x * kv.z);
+        const vec3 w1 = v3(eps[3] + kv.y * kv.x, eps[4] - k2 + kv.y * kv.y, eps[5] + kv.y * kv.z);
+        const vec3 w2 = v3(eps[6] + kv.z * kv.x, eps[7] + kv.z * kv.y, eps[8] - k2 + kv.z * kv.z);
+        E = null_vector(w0, w1, w2, variant);
+    }
+    const double sc = fast_rsqrt(1.0 + x * x);  // LAPACK unit-norm [xi E; E]
+    E = v3(E.x * sc, E.y * sc, E.z * sc);
+    const double e2 = dot(E, E), ke = dot(kv, E);
+    const vec3 S = v3(e2 * kv.x - ke * E.x, e2 * kv.y - ke * E.y, e2 * kv.z - ke * E.z);
+    E_out = E;
+    sn_out = dot(S, n);
+}
+
+// The solutions (xi, E, S.n) of the dispersion relation for one ray, then the reference's ordering.
 // p: hit point in the shape frame; k: incoming wave vector (global).
 // out[0], out[1]: refract -> sorted solutions 2, 3; mirror -> -(0), -(1).
 // GENERAL = false: the host guarantees that no crystal of the table needs the quartic solver (all
@@ -227,36 +282,62 @@ PRT_DEV void interact_anisotropic(const prt_dev_surface *__restrict__ sf, const 
     const vec3 kpa = v3(k1.x - kn * n.x, k1.y - kn * n.y, k1.z - kn * n.z);
     const double *__restrict__ eps = sf->eps_re;
     const double kap2 = dot(kpa, kpa);
-
-    double xi[4];
-    int variant[4];
     const int cls = sf->aniso_class;
-    if (cls == PRT_ANISO_ISOTROPIC) {
-        const double e = sf->aniso_eo;
-        const double r = fast_sqrt(e - kap2);  // NaN if evanescent
-        xi[0] = -r; xi[1] = -r; xi[2] = r; xi[3] = r;
-        variant[0] = 0; variant[1] = 1; variant[2] = 0; variant[3] = 1;
-    } else if (cls == PRT_ANISO_UNIAXIAL) {
-        const double eo = sf->aniso_eo, ee = sf->aniso_ee;
-        const vec3 c = v3(sf->aniso_axis[0], sf->aniso_axis[1], sf->aniso_axis[2]);
-        const double ro = fast_sqrt(eo - kap2);
-        const double nc = dot(n, c), kc = dot(kpa, c);
-        const double A = eo + (ee - eo) * nc * nc;
-        const double Bh = (ee - eo) * kc * nc;  // B/2
-        const double C = eo * kap2 + (ee - eo) * kc * kc - eo * ee;
-        const double disc = fast_sqrt(Bh * Bh - A * C);  // NaN if evanescent
-        // stable quadratic roots
-        const double q = -(Bh + copysign(disc, Bh));
-        double x1 = q / A, x2 = (q != 0.0) ? C / q : -x1;
-        if (Bh == 0.0) { x1 = -disc / A; x2 = disc / A; }
-        xi[0] = -ro; xi[2] = ro;
-        xi[1] = fmin(x1, x2); xi[3] = fmax(x1, x2);
-        if (!isfinite(disc)) { xi[1] = xi[3] = __builtin_nan(""); }
-        variant[0] = 0; variant[2] = 0; variant[1] = 1; variant[3] = 1;
+    const bool mirror = sf->interaction == PRT_MIRROR;
+
+    // the two solutions that leave, in the reference's order
+    vec3 e_out[2];
+    double x_out[2];
+
+    if (cls == PRT_ANISO_ISOTROPIC || cls == PRT_ANISO_UNIAXIAL) {
+        // The four roots come as an ordinary pair -ro < +ro and an extraordinary pair x1 < x2 of a
+        // quadratic A x^2 + 2 Bh x + C with A > 0.  S.n has the sign of the derivative of the dispersion
+        // polynomial at the root: negative at -ro and x1, positive at +ro and x2.  The reference sorts
+        // all four by S.n (material_anisotropic.py:147) and refracts into the sorted solutions 2, 3,
+        // reflects into -(0), -(1): the forward pair {+ro, x2} resp. the backward pair {-ro, x1},
+        // ordered among themselves by S.n.  Only that pair is computed here -- half the eigenvector
+        // work of the generic path below, and no four-element sort.
+        // An evanescent mode (complex xi, NaN here) carries no energy flux through the interface: the
+        // reference computes S.n ~ 0 for it, which places it BETWEEN the backward (S.n < 0) and the
+        // forward (S.n > 0) propagating modes, i.e. before a propagating forward partner and after a
+        // propagating backward one.  Its key is 0 here for the same order ([NaN, real] for one
+        // transmitted mode totally reflected).
+        double x_o, x_e;
+        if (cls == PRT_ANISO_ISOTROPIC) {
+            const double r = fast_sqrt(sf->aniso_eo - kap2);  // NaN if evanescent
+            x_o = x_e = mirror ? -r : r;
+        } else {
+            const double eo = sf->aniso_eo, ee = sf->aniso_ee;
+            const vec3 c = v3(sf->aniso_axis[0], sf->aniso_axis[1], sf->aniso_axis[2]);
+            const double ro = fast_sqrt(eo - kap2);
+            const double nc = dot(n, c), kc = dot(kpa, c);
+            const double A = eo + (ee - eo) * nc * nc;
+            const double Bh = (ee - eo) * kc * nc;  // B/2
+            const double C = eo * kap2 + (ee - eo) * kc * kc - eo * ee;
+            const double disc = fast_sqrt(Bh * Bh - A * C);  // NaN if evanescent
+            // stable quadratic roots
+            const double q = -(Bh + copysign(disc, Bh));
+            double x1 = q / A, x2 = (q != 0.0) ? C / q : -x1;
+            if (Bh == 0.0) { x1 = -disc / A; x2 = disc / A; }
+            x_o = mirror ? -ro : ro;
+            x_e = mirror ? fmin(x1, x2) : fmax(x1, x2);
+            if (!isfinite(disc)) x_e = __builtin_nan("");
+        }
+        vec3 E_o, E_e;
+        double s_o, s_e;
+        eigen_solution(sf, cls, kpa, n, x_o, 0, E_o, s_o);
+        eigen_solution(sf, cls, kpa, n, x_e, 1, E_e, s_e);
+        const double key_o = isnan(s_o) ? 0.0 : s_o, key_e = isnan(s_e) ? 0.0 : s_e;
+        const bool sw = key_e < key_o;  // stable: the ordinary solution first on a tie
+        x_out[0] = sw ? x_e : x_o;
+        x_out[1] = sw ? x_o : x_e;
+        e_out[0] = v3(sw ? E_e.x : E_o.x, sw ? E_e.y : E_o.y, sw ? E_e.z : E_o.z);
+        e_out[1] = v3(sw ? E_o.x : E_e.x, sw ? E_o.y : E_e.y, sw ? E_o.z : E_e.z);
     } else if (!GENERAL) {
-        xi[0] = xi[1] = xi[2] = xi[3] = __builtin_nan("");
-        variant[0] = variant[1] = variant[2] = variant[3] = 0;
+        x_out[0] = x_out[1] = __builtin_nan("");
+        e_out[0] = e_out[1] = v3(0.0, 0.0, 0.0);
     } else {
+        double xi[4];
         double pc[5];
         xi_polynomial(eps, n, kpa, pc);
         // forward / backward pairs by Bairstow from the mean-index guess; the complex Aberth
@@ -306,77 +387,21 @@ PRT_DEV void interact_anisotropic(const prt_dev_surface *__restrict__ sf, const 
                 if (isfinite(dx) && fabs(dx) < 1e-6 * fmax(1.0, fabs(x))) x -= dx;
             }
             xi[i] = x;
-            variant[i] = i & 1;
         }
-    }
 
-    // eigenvectors and S.n of the four solutions.  Only E (scaled) and S.n are kept per solution --
-    // k = kpa + xi n and S are a handful of operations to rebuild for the two solutions that leave,
-    // and holding all four (k, E, S) triples cost 24 more live doubles at the kernel's register peak
-    vec3 ee_[4];
-    double sn[4];
-    const vec3 caxis = v3(sf->aniso_axis[0], sf->aniso_axis[1], sf->aniso_axis[2]);
+        // eigenvectors and S.n of the four solutions.  Only E (scaled) and S.n are kept per solution --
+        // k = kpa + xi n and S are a handful of operations to rebuild for the two solutions that leave,
+        // and holding all four (k, E, S) triples cost 24 more live doubles at the kernel's register peak
+        vec3 ee_[4];
+        double sn[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const vec3 kv = v3(kpa.x + xi[i] * n.x, kpa.y + xi[i] * n.y, kpa.z + xi[i] * n.z);
-        const double k2 = dot(kv, kv);
-        // Closed-form eigenvectors where the class of eps has them (a third of the instructions of the
-        // generic null vector below, which stays for biaxial crystals and for the neighbourhood of the
-        // optic axis, where the two sheets touch and these forms lose their digits):
-        //   eps = e I:                       any two orthonormal vectors perpendicular to k
-        //   eps = eo I + (ee - eo) c c^T:    ordinary  E = k x c   (perpendicular to k and to the axis),
-        //                                    extraordinary  E = (k.c) k - eo c
-        //     (W E = [k^T eps k - eo ee] c = 0 on the extraordinary sheet; D = eps E is perpendicular to k)
-        vec3 E = v3(0.0, 0.0, 0.0);
-        bool closed = false;
-        if (cls == PRT_ANISO_ISOTROPIC) {
-            const double ax = fabs(kv.x), ay = fabs(kv.y), az = fabs(kv.z);
-            const vec3 a = (ax <= ay && ax <= az) ? v3(1, 0, 0) : ((ay <= az) ? v3(0, 1, 0) : v3(0, 0, 1));
-            vec3 v1 = cross(kv, a);
-            double inv = fast_rsqrt(dot(v1, v1));
-            v1 = v3(v1.x * inv, v1.y * inv, v1.z * inv);
-            if (variant[i] == 0) {
-                E = v1;
-            } else {
-                const vec3 v2 = cross(kv, v1);
-                inv = fast_rsqrt(dot(v2, v2));
-                E = v3(v2.x * inv, v2.y * inv, v2.z * inv);
-            }
-            closed = true;
-        } else if (cls == PRT_ANISO_UNIAXIAL) {
-            const vec3 kxc = cross(kv, caxis);
-            const double q = dot(kxc, kxc);
-            closed = q > 1e-8 * k2;  // sin^2 of the angle to the optic axis
-            const double kc = dot(kv, caxis);
-            const vec3 ex = v3(kc * kv.x - sf->aniso_eo * caxis.x, kc * kv.y - sf->aniso_eo * caxis.y,
-                               kc * kv.z - sf->aniso_eo * caxis.z);
-            const vec3 raw = (variant[i] == 0) ? kxc : ex;
-            const double inv = fast_rsqrt(dot(raw, raw));
-            E = v3(raw.x * inv, raw.y * inv, raw.z * inv);
-        }
-        if (!closed) {
-            const vec3 w0 = v3(eps[0] - k2 + kv.x * kv.x, eps[1] + kv.x * kv.y, eps[2] + kv.x * kv.z);
-            const vec3 w1 = v3(eps[3] + kv.y * kv.x, eps[4] - k2 + kv.y * kv.y, eps[5] + kv.y * kv.z);
-            const vec3 w2 = v3(eps[6] + kv.z * kv.x, eps[7] + kv.z * kv.y, eps[8] - k2 + kv.z * kv.z);
-            E = null_vector(w0, w1, w2, variant[i]);
-        }
-        const double sc = fast_rsqrt(1.0 + xi[i] * xi[i]);  // LAPACK unit-norm [xi E; E]
-        E = v3(E.x * sc, E.y * sc, E.z * sc);
-        const double e2 = dot(E, E), ke = dot(kv, E);
-        const vec3 S = v3(e2 * kv.x - ke * E.x, e2 * kv.y - ke * E.y, e2 * kv.z - ke * E.z);
-        ee_[i] = E;
-        sn[i] = dot(S, n);
-    }
-    // argsort ascending by S.n (material.py:147); NaNs last like numpy.  Compare-exchange
-    // network on (key, id) pairs held in registers (indexing sn[] by a sorted index would put
-    // the arrays in scratch memory).
-    // An evanescent mode (complex xi, NaN here) carries no energy flux through the interface: the
-    // reference computes S.n ~ 0 for it, which places it BETWEEN the backward (S.n < 0) and the
-    // forward (S.n > 0) propagating modes.  Sorting its key as 0 keeps a propagating partner in
-    // the slot the reference puts it in (e.g. one transmitted mode totally reflected: [NaN, real]).
-    int id0 = 0, id1 = 1, id2 = 2, id3 = 3;
-    double s0 = isnan(sn[0]) ? 0.0 : sn[0], s1 = isnan(sn[1]) ? 0.0 : sn[1];
-    double s2 = isnan(sn[2]) ? 0.0 : sn[2], s3 = isnan(sn[3]) ? 0.0 : sn[3];
+        for (int i = 0; i < 4; ++i) eigen_solution(sf, cls, kpa, n, xi[i], i & 1, ee_[i], sn[i]);
+        // argsort ascending by S.n (material.py:147); NaNs last like numpy.  Compare-exchange
+        // network on (key, id) pairs held in registers (indexing sn[] by a sorted index would put
+        // the arrays in scratch memory).  Evanescent modes: key 0, see above.
+        int id0 = 0, id1 = 1, id2 = 2, id3 = 3;
+        double s0 = isnan(sn[0]) ? 0.0 : sn[0], s1 = isnan(sn[1]) ? 0.0 : sn[1];
+        double s2 = isnan(sn[2]) ? 0.0 : sn[2], s3 = isnan(sn[3]) ? 0.0 : sn[3];
 #define PRT_CSWAP(ka, kb, ia, ib)                                   \
     {                                                               \
         const bool sw = (kb < ka) || (isnan(ka) && !isnan(kb));     \
@@ -387,23 +412,31 @@ PRT_DEV void interact_anisotropic(const prt_dev_surface *__restrict__ sf, const 
         ib = sw ? ia : ib;                                          \
         ia = ti;                                                    \
     }
-    PRT_CSWAP(s0, s1, id0, id1)
-    PRT_CSWAP(s2, s3, id2, id3)
-    PRT_CSWAP(s0, s2, id0, id2)
-    PRT_CSWAP(s1, s3, id1, id3)
-    PRT_CSWAP(s1, s2, id1, id2)
+        PRT_CSWAP(s0, s1, id0, id1)
+        PRT_CSWAP(s2, s3, id2, id3)
+        PRT_CSWAP(s0, s2, id0, id2)
+        PRT_CSWAP(s1, s3, id1, id3)
+        PRT_CSWAP(s1, s2, id1, id2)
 #undef PRT_CSWAP
-    const int idx[4] = {id0, id1, id2, id3};
-    const bool mirror = sf->interaction == PRT_MIRROR;
+        const int idx[4] = {id0, id1, id2, id3};
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int src = mirror ? idx[b] : idx[2 + b];
+            // pick without dynamic register indexing
+            vec3 E = ee_[0];
+            double x = xi[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (src == q) { E = ee_[q]; x = xi[q]; }
+            e_out[b] = E;
+            x_out[b] = x;
+        }
+    }
+
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int src = mirror ? idx[b] : idx[2 + b];
-        // pick without dynamic register indexing
-        vec3 E = ee_[0];
-        double x = xi[0];
-#pragma unroll
-        for (int q = 1; q < 4; ++q)
-            if (src == q) { E = ee_[q]; x = xi[q]; }
+        vec3 E = e_out[b];
+        const double x = x_out[b];
         vec3 kv = v3(kpa.x + x * n.x, kpa.y + x * n.y, kpa.z + x * n.z);
         const double e2 = dot(E, E), ke = dot(kv, E);
         vec3 S = v3(e2 * kv.x - ke * E.x, e2 * kv.y - ke * E.y, e2 * kv.z - ke * E.z);

@@ -179,20 +179,67 @@ PRT_DEV double conic_sag(double c, double cc, double r2) {
     return c * r2 / (1.0 + sqrt(st));
 }
 
+// The side array (coefficients, term powers, spline knots) is written by the host before the launch and only
+// read by the kernels.  Read through the CONSTANT address space, an access whose index every lane of the wave
+// shares becomes a scalar load (s_load into SGPRs through the scalar cache).  Read through the generic pointer
+// stored in the record it was a flat_load per lane + s_waitcnt vmcnt(0) per coefficient and Newton step -- a
+// vector-memory round trip each, and on gfx950 vmcnt counts the wave's outstanding path stores too, so each of
+// those waits also drained the stores.
+#define PRT_CONST_AS __attribute__((address_space(4)))
+#define PRT_GLOBAL_AS __attribute__((address_space(1)))
+typedef const PRT_CONST_AS double *prt_cdoubles;
+typedef const PRT_CONST_AS int32_t *prt_cints;
+PRT_DEV prt_cdoubles side_doubles(const prt_dev_surface *__restrict__ sf) {
+    return (prt_cdoubles)(uint64_t)sf->coeffs;
+}
+PRT_DEV prt_cints side_ints(const prt_dev_surface *__restrict__ sf) { return (prt_cints)(uint64_t)sf->pows; }
+
+// The first PRT_ASPHERE_PREFETCH even-asphere coefficients a_n and the products b_n = (n+1) a_n of one surface,
+// fetched ONCE per surface (two s_load_dwordx16) and held in scalar registers across the Newton iteration.
+// Side-array layout of a surface with an asphere part (prt_system_create): the coefficients as the host
+// table has them (n_coeffs doubles: a_0.., for a combination followed by its polynomial terms), then the
+// b_n of the asphere part.  The array is padded, so both 8-slot reads are always in bounds; slots >= nc are
+// forced to zero, which makes the fixed-length Horner below exact for any nc <= 8.
+#define PRT_ASPHERE_PREFETCH 8
+struct asphere_coeffs {
+    double a[PRT_ASPHERE_PREFETCH], b[PRT_ASPHERE_PREFETCH];
+};
+PRT_DEV void asphere_prefetch(const prt_dev_surface *__restrict__ sf, int nc, asphere_coeffs &ac) {
+    prt_cdoubles cf = side_doubles(sf);
+    prt_cdoubles cb = cf + sf->n_coeffs;
+#pragma unroll
+    for (int n = 0; n < PRT_ASPHERE_PREFETCH; ++n) {
+        const double va = cf[n], vb = cb[n];
+        ac.a[n] = (n < nc) ? va : 0.0;
+        ac.b[n] = (n < nc) ? vb : 0.0;
+    }
+}
+
 // Asphere.F and Asphere.gradF, surface_shape.py:529-555, in one pass:
 //   F  = c r2/(1+sq) + sum_n a_n r2^(n+1)
 //   Fx = x (c/sq + sum_n 2(n+1) a_n r2^n),   gradient of z-F = (-Fx, -Fy, 1)
 // Horner in r2 (the reference sums the powers; same polynomial).
-PRT_DEV void asphere_eval(const prt_dev_surface *__restrict__ sf, int nc, double x, double y, double &F,
-                          double &dFdr2x2 /* Fx = x * this */) {
+// PRE: the first 8 coefficient pairs come from `ac` (scalar registers, the asphere-only kernels); otherwise
+// every pair is a scalar load inside the loop (the all-shapes kernels have no registers to spare for `ac`).
+template <bool PRE>
+PRT_DEV void asphere_eval(const prt_dev_surface *__restrict__ sf, int nc, const asphere_coeffs &ac, double x,
+                          double y, double &F, double &dFdr2x2 /* Fx = x * this */) {
     const double c = sf->curv, cc = sf->cc;
     const double r2 = x * x + y * y;
     const double sq = fast_sqrt(1.0 - c * c * (1.0 + cc) * r2);
     double p = 0.0, dp = 0.0;  // p = sum a_n r2^n ; dp = sum (n+1) a_n r2^n
-    for (int n = nc - 1; n >= 0; --n) {
-        const double a = sf->coeffs[n];
-        p = p * r2 + a;
-        dp = dp * r2 + (double)(n + 1) * a;
+    prt_cdoubles cf = side_doubles(sf);
+    prt_cdoubles cb = cf + sf->n_coeffs;
+    for (int n = nc - 1; n >= (PRE ? PRT_ASPHERE_PREFETCH : 0); --n) {
+        p = p * r2 + cf[n];
+        dp = dp * r2 + cb[n];
+    }
+    if (PRE) {
+#pragma unroll
+        for (int n = PRT_ASPHERE_PREFETCH - 1; n >= 0; --n) {  // a_n = b_n = 0 for n >= nc: p, dp stay 0 until n < nc
+            p = p * r2 + ac.a[n];
+            dp = dp * r2 + ac.b[n];
+        }
     }
     F = c * r2 * fast_rcp(1.0 + sq) + p * r2;
     dFdr2x2 = c * fast_rcp(sq) + 2.0 * dp;
@@ -213,9 +260,11 @@ PRT_DEV void xypoly_eval(const prt_dev_surface *__restrict__ sf, int t0, int nt,
     int ip = 0, jp = 0;
     double xp = 1.0, xpm1 = 0.0;  // x^ip, x^(ip-1) (0 for ip = 0: d/dx of a constant)
     double yp = 1.0, ypm1 = 0.0;
+    prt_cdoubles cf = side_doubles(sf);
+    prt_cints pw = side_ints(sf);
     for (int t = t0; t < nt; ++t) {
-        const int i = sf->pows[2 * t], j = sf->pows[2 * t + 1];
-        const double c = sf->coeffs[t];
+        const int i = pw[2 * t], j = pw[2 * t + 1];
+        const double c = cf[t];
         if (i != ip) {
             if (i < ip) {
                 ip = 0;
@@ -265,8 +314,9 @@ PRT_DEV void biconic_eval(const prt_dev_surface *__restrict__ sf, double x, doub
     Fx = cx * x * (cx * (ccx + 1.0) * u + two_den_sq) * common;
     Fy = cy * y * (cy * (ccy + 1.0) * u + two_den_sq) * common;
     const int np = sf->n_coeffs;
+    prt_cdoubles cf = side_doubles(sf);
     for (int n = 0; n < np; ++n) {
-        const double a = sf->coeffs[2 * n], b = sf->coeffs[2 * n + 1];
+        const double a = cf[2 * n], b = cf[2 * n + 1];
         const double w = x2 * (1.0 - b) + y2 * (1.0 + b);
         double wn = 1.0;  // w^n
         for (int q = 0; q < n; ++q) wn *= w;
@@ -281,7 +331,8 @@ PRT_DEV void biconic_eval(const prt_dev_surface *__restrict__ sf, double x, doub
 // FITPACK bispev / parder on the (tx, ty, c) form.  Arguments outside the knot range are clamped to
 // it (bispev); the knot interval is located by bisection; the four non-zero cubic basis functions
 // and their derivatives come from the Cox-de Boor recurrence (FITPACK fpbspl).
-PRT_DEV int bspline_interval(const double *__restrict__ t, int n, double x) {
+typedef const PRT_GLOBAL_AS double *prt_gdoubles;
+PRT_DEV int bspline_interval(prt_gdoubles t, int n, double x) {
     int lo = 3, hi = n - 5;  // t[lo] <= x < t[lo+1], lo in [3, n-5]
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -290,7 +341,7 @@ PRT_DEV int bspline_interval(const double *__restrict__ t, int n, double x) {
     return lo;
 }
 
-PRT_DEV void bspline_basis3(const double *__restrict__ t, int l, double x, double b[4], double db[4]) {
+PRT_DEV void bspline_basis3(prt_gdoubles t, int l, double x, double b[4], double db[4]) {
     // degree 1
     const double t0 = t[l], t1 = t[l + 1];
     const double i1 = fast_rcp(t1 - t0);
@@ -317,11 +368,14 @@ PRT_DEV void bspline_basis3(const double *__restrict__ t, int l, double x, doubl
 PRT_DEV void gridsag_eval(const prt_dev_surface *__restrict__ sf, double x, double y, double &F,
                           double &Fx, double &Fy) {
     const int nx = sf->grid_nx, ny = sf->grid_ny;
-    const double *__restrict__ tx = sf->coeffs;
-    const double *__restrict__ ty = tx + nx;
-    const double *__restrict__ c = ty + ny;
-    const double xc = fmin(fmax(x, tx[3]), tx[nx - 4]);
-    const double yc = fmin(fmax(y, ty[3]), ty[ny - 4]);
+    // knots and coefficients are indexed per ray: vector loads, through the GLOBAL address space (the generic
+    // pointer of the record would make them flat loads); the four range limits are wave-uniform: scalar loads
+    prt_gdoubles tx = (prt_gdoubles)(uint64_t)sf->coeffs;
+    prt_gdoubles ty = tx + nx;
+    prt_gdoubles c = ty + ny;
+    prt_cdoubles ux = side_doubles(sf);
+    const double xc = fmin(fmax(x, ux[3]), ux[nx - 4]);
+    const double yc = fmin(fmax(y, ux[nx + 3]), ux[nx + ny - 4]);
     const int lx = bspline_interval(tx, nx, xc), ly = bspline_interval(ty, ny, yc);
     double bx[4], dbx[4], by[4], dby[4];
     bspline_basis3(tx, lx, xc, bx, dbx);
@@ -332,7 +386,7 @@ PRT_DEV void gridsag_eval(const prt_dev_surface *__restrict__ sf, double x, doub
     Fy = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const double *__restrict__ row = c + (int64_t)(lx - 3 + i) * ncy + (ly - 3);
+        prt_gdoubles row = c + (int64_t)(lx - 3 + i) * ncy + (ly - 3);
         double s = 0.0, sy = 0.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -354,11 +408,11 @@ PRT_DEV void gridsag_eval(const prt_dev_surface *__restrict__ sf, double x, doub
 
 // explicit z = F(x,y) shapes: value and in-plane derivatives
 template <int SHAPES = PRT_SHAPES_ALL>
-PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, double x, double y, double &F,
-                           double &Fx, double &Fy) {
+PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, const asphere_coeffs &ac, double x, double y,
+                           double &F, double &Fx, double &Fy) {
     if (SHAPES == PRT_SHAPES_ASPHERE || sf->shape_type == PRT_SHAPE_ASPHERE) {
         double m;
-        asphere_eval(sf, sf->n_coeffs, x, y, F, m);
+        asphere_eval<SHAPES == PRT_SHAPES_ASPHERE>(sf, sf->n_coeffs, ac, x, y, F, m);
         Fx = x * m;
         Fy = y * m;
     } else if (sf->shape_type == PRT_SHAPE_BICONIC) {
@@ -369,7 +423,7 @@ PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, double x, dou
         // LinearCombination.F / gradF (surface_shape.py:713-748) of one conic / asphere part and
         // polynomial parts, merged by the host: scale * asphere + sum c_ij x^i y^j
         double Fa, m;
-        asphere_eval(sf, sf->n_asphere, x, y, Fa, m);
+        asphere_eval<false>(sf, sf->n_asphere, ac, x, y, Fa, m);
         xypoly_eval(sf, sf->n_asphere, sf->n_coeffs, x, y, F, Fx, Fy);
         const double sc = sf->asphere_scale;
         F += sc * Fa;
@@ -378,6 +432,12 @@ PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, double x, dou
     } else {
         xypoly_eval(sf, 0, sf->n_coeffs, x, y, F, Fx, Fy);
     }
+}
+
+// what explicit_eval wants fetched once per surface (the asphere-only kernels; nothing otherwise)
+template <int SHAPES = PRT_SHAPES_ALL>
+PRT_DEV void explicit_prefetch(const prt_dev_surface *__restrict__ sf, asphere_coeffs &ac) {
+    if (SHAPES == PRT_SHAPES_ASPHERE) asphere_prefetch(sf, sf->n_coeffs, ac);
 }
 
 // ExplicitShape.intersect, surface_shape.py:448-465: root of
@@ -398,10 +458,12 @@ PRT_DEV double explicit_t(const prt_dev_surface *__restrict__ sf, const vec3 &r0
     gx = 0.0;
     gy = 0.0;
     const int maxit = sf->newton_maxit > 0 ? sf->newton_maxit : 30;
+    asphere_coeffs ac;
+    explicit_prefetch<SHAPES>(sf, ac);
     for (int it = 0; it < maxit; ++it) {
         double F, Fx, Fy;
         const double px = r0.x + t * d.x, py = r0.y + t * d.y;
-        explicit_eval<SHAPES>(sf, px, py, F, Fx, Fy);
+        explicit_eval<SHAPES>(sf, ac, px, py, F, Fx, Fy);
         const double g = r0.z + t * d.z - F;
         const double gp = d.z - Fx * d.x - Fy * d.y;
         const double dt = g * fast_rcp(gp);
@@ -423,14 +485,18 @@ PRT_DEV double explicit_t(const prt_dev_surface *__restrict__ sf, const vec3 &r0
 PRT_DEV vec3 shape_grad(const prt_dev_surface *__restrict__ sf, double x, double y) {
     if (sf->shape_type == PRT_SHAPE_CONIC) return conic_grad(sf->curv, sf->cc, x, y);
     double F, Fx, Fy;
-    explicit_eval(sf, x, y, F, Fx, Fy);
+    asphere_coeffs ac;
+    explicit_prefetch(sf, ac);
+    explicit_eval(sf, ac, x, y, F, Fx, Fy);
     return v3(-Fx, -Fy, 1.0);
 }
 
 PRT_DEV double shape_sag(const prt_dev_surface *__restrict__ sf, double x, double y) {
     if (sf->shape_type == PRT_SHAPE_CONIC) return conic_sag(sf->curv, sf->cc, x * x + y * y);
     double F, Fx, Fy;
-    explicit_eval(sf, x, y, F, Fx, Fy);
+    asphere_coeffs ac;
+    explicit_prefetch(sf, ac);
+    explicit_eval(sf, ac, x, y, F, Fx, Fy);
     return F;
 }
 

@@ -153,6 +153,19 @@ PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
 // sums the blocks in a fixed order.  This is RayBundleAnalysis' centroid / RMS spot input
 // (analysis/ray_analysis.py:44-86) without a second pass over the image-plane arrays.
 #define MOM_VALUES 7
+// Loads and stores share one in-order counter on gfx950 (vmcnt).  If an input load can still be pending when
+// a loop over surfaces is entered -- on ANY path, e.g. x0 / k0 when the first direction is given -- the compiler
+// guards the later uses and overwrites of those registers inside the loop with s_waitcnt vmcnt(n), and from
+// the second surface on such a wait is a wait for the wave's own path STORES to be acknowledged by HBM
+// (asphere march: a vmcnt(3) after the stores of every surface; crystal march: three full drains per ray
+// at the un-park steps).  One explicit wait in front of the loop removes all of them.
+// s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt = imm[3:0] | imm[15:14], expcnt = imm[6:4] = 7 and lgkmcnt = imm[11:8] = 15
+// left alone)
+#ifndef PRT_NO_LOAD_FENCE
+#define PRT_WAIT_VMEM_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
+#else
+#define PRT_WAIT_VMEM_LOADS() ((void)0)
+#endif
 // Image mode of the all-conic march is FP64-VALU bound: 8 waves/SIMD (63 VGPRs, no spills) instead
 // of the allocator's 7 is worth 5 % there (0.47 -> 0.446 ms); path mode is HBM bound and unaffected.
 template <int MODE, bool VEC_IN, bool VEC_OUT, int SHAPES = PRT_SHAPES_ALL, bool LDS_TAB = false,
@@ -204,6 +217,8 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
     rayio<VEC_IN>::load(k0, in_pitch, i, second, k);
     first_direction<VEC_IN>(e_mode, e_re, e_im, in_pitch, i, second, k, d);
     double d2 = 1.0;  // |d|^2: unit Poynting direction on the first segment
+    // no input load may still be in flight when the march starts: see PRT_WAIT_VMEM_LOADS
+    PRT_WAIT_VMEM_LOADS();
 
     for (int32_t s = 0; s < S; ++s) {
         const prt_dev_surface *__restrict__ sf = tab + s;
@@ -307,8 +322,25 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
 #else
 #define PRT_GSTORE(ptr, val) (*(ptr) = (val))
 #endif
+// ... but NOT on the byte masks: a wave's 64 mask bytes are half a cache line, and with the hint each of them
+// goes to memory on its own -- 0.164 ms with the hint, 0.149 without, 0.149 with no mask stores at all
+// (profiles/r02zc_ab_crystal_store_variants.json; PRT_GENERAL_NT_MASKS / PRT_DIAG_NO_MASKS build those)
+#if defined(PRT_DIAG_NO_MASKS)
+#define PRT_GSTORE_MASK(ptr, val) ((void)0)
+#elif defined(PRT_GENERAL_NT_MASKS)
+#define PRT_GSTORE_MASK(ptr, val) PRT_GSTORE(ptr, val)
+#else
+#define PRT_GSTORE_MASK(ptr, val) (*(ptr) = (val))
+#endif
 #ifndef PRT_GENERAL_WAVES
 #define PRT_GENERAL_WAVES 4
+#endif
+// diagnostic builds only (benchmarks/ab_crystal.py): every store of the march lands in a 16k-ray window that
+// stays in L2 -- what the march costs when HBM takes no part
+#ifdef PRT_DIAG_L2_STORES
+#define PRT_DIAG_STORE_INDEX(i) ((i) & 16383)
+#else
+#define PRT_DIAG_STORE_INDEX(i) (i)
 #endif
 // PARK_LDS: the parking slots live in LDS ([level][value][thread]: conflict-free, 9 doubles + 1 byte per
 // level and thread) instead of private memory.  For up to PRT_PARK_LDS_LEVELS crystal interfaces the block's
@@ -318,6 +350,19 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
 #ifndef PRT_PARK_LDS_LEVELS
 #define PRT_PARK_LDS_LEVELS 2
 #endif
+// A pointer every lane of the wave agrees on, pinned to scalar registers: "p + threadIdx" then compiles to
+// the scalar-base form of global_load / global_store (64-bit base in SGPRs + 32-bit lane offset) instead of
+// a 64-bit vector add per access -- and the optimiser cannot fold the lane index back into the base.
+// (the integer round trip loses the address space; the result is declared global again, or the stores would
+// be flat_store)
+template <typename T>
+PRT_DEV PRT_GLOBAL_AS T *uniform_ptr(T *p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (PRT_GLOBAL_AS T *)(((uint64_t)hi << 32) | lo);
+}
+
 template <int MODE, bool GENERAL = true, bool PARK_LDS = false>
 __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
     const prt_dev_surface *__restrict__ tab, int32_t S, int32_t A, int64_t N,
@@ -326,7 +371,9 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
     double *__restrict__ k_out, double *__restrict__ e_out, double *__restrict__ e_out_im,
     uint8_t *__restrict__ valid_out_hit, uint8_t *__restrict__ valid_out_refr,
     uint8_t *__restrict__ nonconv_out = nullptr) {
-    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const int64_t blk = (int64_t)blockIdx.x * PRT_BLOCK;
+    const int64_t i = blk + tid;
     if (i >= N) return;
     vec3 x = v3(x0[i], x0[N + i], x0[2 * N + i]);
     vec3 k = v3(k0[i], k0[N + i], k0[2 * N + i]);
@@ -337,6 +384,8 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
         first_direction<false>(e_mode, e_re, e_im, N, i, false, kk, dd);
         d = dd[0];
     }
+    // all input loads land here, so that no wait inside the walk ever counts stores (PRT_WAIT_VMEM_LOADS)
+    PRT_WAIT_VMEM_LOADS();
     bool valid = true;
     double d2 = 1.0;
     // per level: child 1 of the crystal interface of that level (hit point, k, d, alive)
@@ -361,18 +410,21 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
             double *xo = xh_out + 3 * base_in;
             double *ko = k_out + 3 * base_out;
             const int64_t Lp = L & (((int64_t)1 << a) - 1);
-            const int64_t idx_in = i + N * Lp;
+            // store addresses = wave-uniform row base (scalar registers) + the thread's 32-bit offset: the
+            // form global_store takes with a scalar base, no 64-bit vector arithmetic per store
+            const int64_t idx_in = PRT_DIAG_STORE_INDEX(blk) + N * Lp;
             const bool alive = valid;
             vec3 xh, p, g;
             double g2;
             bool ncv;
             propagate_step(sf, x, d, d2, xh, p, g, g2, valid, ncv);
             if (store) {
-                PRT_GSTORE(xo + idx_in, xh.x);
-                PRT_GSTORE(xo + n_in + idx_in, xh.y);
-                PRT_GSTORE(xo + 2 * n_in + idx_in, xh.z);
-                PRT_GSTORE(valid_out_hit + base_in + idx_in, (uint8_t)(valid ? 1 : 0));
-                if (nonconv_out) nonconv_out[base_in + idx_in] = ncv ? 1 : 0;
+                PRT_GLOBAL_AS double *xrow = uniform_ptr(xo + idx_in);
+                PRT_GSTORE(xrow + tid, xh.x);
+                PRT_GSTORE(xrow + n_in + tid, xh.y);
+                PRT_GSTORE(xrow + 2 * n_in + tid, xh.z);
+                PRT_GSTORE_MASK(uniform_ptr(valid_out_hit + base_in + idx_in) + tid, (uint8_t)(valid ? 1 : 0));
+                if (nonconv_out) uniform_ptr(nonconv_out + base_in + idx_in)[tid] = ncv ? 1 : 0;
             }
             x = xh;
             if (crystal) {
@@ -382,23 +434,24 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
                 if (store) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        const int64_t idx_out = i + N * (Lp + ((int64_t)b << a));
-                        PRT_GSTORE(ko + idx_out, sol[b].k.x);
-                        PRT_GSTORE(ko + n_out + idx_out, sol[b].k.y);
-                        PRT_GSTORE(ko + 2 * n_out + idx_out, sol[b].k.z);
+                        const int64_t idx_out = PRT_DIAG_STORE_INDEX(blk) + N * (Lp + ((int64_t)b << a));
+                        PRT_GLOBAL_AS double *krow = uniform_ptr(ko + idx_out);
+                        PRT_GSTORE(krow + tid, sol[b].k.x);
+                        PRT_GSTORE(krow + n_out + tid, sol[b].k.y);
+                        PRT_GSTORE(krow + 2 * n_out + tid, sol[b].k.z);
                         if (e_out) {
-                            double *eo = e_out + 3 * base_out;
-                            eo[idx_out] = sol[b].er.x;
-                            eo[n_out + idx_out] = sol[b].er.y;
-                            eo[2 * n_out + idx_out] = sol[b].er.z;
+                            PRT_GLOBAL_AS double *eo = uniform_ptr(e_out + 3 * base_out + idx_out);
+                            eo[tid] = sol[b].er.x;
+                            (eo + n_out)[tid] = sol[b].er.y;
+                            (eo + 2 * n_out)[tid] = sol[b].er.z;
                             if (e_out_im) {
-                                double *ei = e_out_im + 3 * base_out;
-                                ei[idx_out] = sol[b].ei.x;
-                                ei[n_out + idx_out] = sol[b].ei.y;
-                                ei[2 * n_out + idx_out] = sol[b].ei.z;
+                                PRT_GLOBAL_AS double *ei = uniform_ptr(e_out_im + 3 * base_out + idx_out);
+                                ei[tid] = sol[b].ei.x;
+                                (ei + n_out)[tid] = sol[b].ei.y;
+                                (ei + 2 * n_out)[tid] = sol[b].ei.z;
                             }
                         }
-                        if (valid_out_refr) PRT_GSTORE(valid_out_refr + base_out + idx_out, (uint8_t)(alive ? 1 : 0));
+                        if (valid_out_refr) PRT_GSTORE_MASK(uniform_ptr(valid_out_refr + base_out + idx_out) + tid, (uint8_t)(alive ? 1 : 0));
                     }
                 }
                 if (PARK_LDS) {
@@ -424,10 +477,11 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
                 d = k;
                 d2 = sf->n_after * sf->n_after;
                 if (store) {
-                    PRT_GSTORE(ko + idx_in, k.x);
-                    PRT_GSTORE(ko + n_out + idx_in, k.y);
-                    PRT_GSTORE(ko + 2 * n_out + idx_in, k.z);
-                    if (valid_out_refr) PRT_GSTORE(valid_out_refr + base_out + idx_in, (uint8_t)(valid ? 1 : 0));
+                    PRT_GLOBAL_AS double *krow = uniform_ptr(ko + idx_in);
+                    PRT_GSTORE(krow + tid, k.x);
+                    PRT_GSTORE(krow + n_out + tid, k.y);
+                    PRT_GSTORE(krow + 2 * n_out + tid, k.z);
+                    if (valid_out_refr) PRT_GSTORE_MASK(uniform_ptr(valid_out_refr + base_out + idx_in) + tid, (uint8_t)(valid ? 1 : 0));
                 }
             }
             off_in += n_in;
