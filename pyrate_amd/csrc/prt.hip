@@ -255,15 +255,19 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
         if (r.shape_type == PRT_SHAPE_BICONIC) return 2 * (size_t)r.n_coeffs;
         return (size_t)r.n_coeffs + n_asphere_part(r);
     };
-    auto n_pows = [](const prt_surface_t &r) -> size_t {
-        return (r.shape_type == PRT_SHAPE_XYPOLY || r.shape_type == PRT_SHAPE_COMBO) ? 2 * (size_t)r.n_coeffs : 0;
+    // polynomial terms of a surface (xypoly: all coefficients; combination: those behind the asphere part),
+    // one poly_term each behind the doubles
+    auto n_terms = [](const prt_surface_t &r) -> size_t {
+        if (r.shape_type == PRT_SHAPE_XYPOLY) return (size_t)r.n_coeffs;
+        if (r.shape_type == PRT_SHAPE_COMBO) return (size_t)(r.n_coeffs - r.n_asphere);
+        return 0;
     };
     // slack behind the last entry: asphere_prefetch reads PRT_ASPHERE_PREFETCH doubles from the start of a
-    // surface's coefficients whatever their number
+    // surface's coefficients whatever their number, xypoly_eval one poly_term beyond the last
     const size_t PRT_SIDE_SLACK = 8 + 8 * PRT_ASPHERE_PREFETCH;
     size_t side_bytes = 0;
     for (int s = 0; s < n_surfaces; ++s)
-        side_bytes += 8 * n_doubles(table[s]) + 8 * ((n_pows(table[s]) + 1) / 2);
+        side_bytes += 8 * n_doubles(table[s]) + sizeof(poly_term) * n_terms(table[s]);
     char *h_side = new (std::nothrow) char[side_bytes + PRT_SIDE_SLACK];
     if (!h_side) {
         delete[] recs;
@@ -315,19 +319,24 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
         d.curv_y = r.curv_y;
         d.cc_y = r.cc_y;
         d.asphere_scale = r.asphere_scale;
-        const size_t nd = n_doubles(r), np = n_pows(r);
+        const size_t nd = n_doubles(r), ntm = n_terms(r);
         d.coeffs = (const double *)((char *)sys->d_side + off);
         const size_t na = n_asphere_part(r);
         memcpy(h_side + off, r.shape_type == PRT_SHAPE_GRIDSAG ? (const void *)r.aux : (const void *)r.coeffs,
                8 * (nd - na));
         for (size_t n = 0; n < na; ++n) ((double *)(h_side + off))[nd - na + n] = (double)(n + 1) * r.coeffs[n];
         off += 8 * nd;
-        d.pows = (const int32_t *)((char *)sys->d_side + off);
-        for (size_t t = 0; t < np / 2; ++t) {
-            ((int32_t *)(h_side + off))[2 * t] = r.xpow[t];
-            ((int32_t *)(h_side + off))[2 * t + 1] = r.ypow[t];
+        d.pows = (const void *)((char *)sys->d_side + off);
+        for (size_t t = 0; t < ntm; ++t) {
+            const size_t src = (size_t)r.n_coeffs - ntm + t;
+            poly_term &pt = ((poly_term *)(h_side + off))[t];
+            pt.c = r.coeffs[src];
+            pt.ci = r.coeffs[src] * (double)r.xpow[src];
+            pt.cj = r.coeffs[src] * (double)r.ypow[src];
+            pt.i = r.xpow[src];
+            pt.j = r.ypow[src];
         }
-        off += 8 * ((np + 1) / 2);
+        off += sizeof(poly_term) * ntm;
     }
     e = hipMemcpy(sys->d_side, h_side, side_bytes + PRT_SIDE_SLACK, hipMemcpyHostToDevice);
     delete[] h_side;

@@ -31,7 +31,7 @@ struct prt_dev_surface {
     int32_t n_asphere, grid_nx, grid_ny, pad_;
     double curv, cc;
     const double *coeffs;  // n_coeffs doubles (biconic: 2 n_coeffs); GRIDSAG: knots tx, ty, coefficients
-    const int32_t *pows;   // xypoly / combo terms: x power of term t at [2t], y power at [2t + 1]
+    const void *pows;      // xypoly / combo: the polynomial terms, one poly_term {c, c*i, c*j, i, j} each
     double B_shape[9], g_shape[3];
     double B_ap[9], g_ap[3];
     double ap_p0, ap_p1;
@@ -188,11 +188,9 @@ PRT_DEV double conic_sag(double c, double cc, double r2) {
 #define PRT_CONST_AS __attribute__((address_space(4)))
 #define PRT_GLOBAL_AS __attribute__((address_space(1)))
 typedef const PRT_CONST_AS double *prt_cdoubles;
-typedef const PRT_CONST_AS int32_t *prt_cints;
 PRT_DEV prt_cdoubles side_doubles(const prt_dev_surface *__restrict__ sf) {
     return (prt_cdoubles)(uint64_t)sf->coeffs;
 }
-PRT_DEV prt_cints side_ints(const prt_dev_surface *__restrict__ sf) { return (prt_cints)(uint64_t)sf->pows; }
 
 // The first PRT_ASPHERE_PREFETCH even-asphere coefficients a_n and the products b_n = (n+1) a_n of one surface,
 // fetched ONCE per surface (two s_load_dwordx16) and held in scalar registers across the Newton iteration.
@@ -245,11 +243,26 @@ PRT_DEV void asphere_eval(const prt_dev_surface *__restrict__ sf, int nc, const 
     dFdr2x2 = c * fast_rcp(sq) + 2.0 * dp;
 }
 
-// XYPolynomials.F / gradF, surface_shape.py:785-807.  coeffs[] already hold
-// c / normradius^(i+j) (host side).  Powers by repeated multiplication with
-// wave-uniform trip counts.
-PRT_DEV void xypoly_eval(const prt_dev_surface *__restrict__ sf, int t0, int nt, double x, double y,
-                         double &F, double &Fx, double &Fy) {
+// XYPolynomials.F / gradF, surface_shape.py:785-807.  One 32-byte entry per term in the side array (built by
+// prt_system_create): c (already divided by normradius^(i+j) on the host), c*i, c*j and the powers i, j --
+// ONE scalar load per term, issued one term ahead, and no integer -> double conversion or c*i product per
+// evaluation.  Powers by repeated multiplication with wave-uniform trip counts.
+struct poly_term {
+    double c, ci, cj;
+    int32_t i, j;
+};
+typedef const PRT_CONST_AS poly_term *prt_cterms;
+PRT_DEV poly_term load_term(prt_cterms tp, int t) {  // (member by member: no struct copy out of an address space)
+    poly_term r;
+    r.c = tp[t].c;
+    r.ci = tp[t].ci;
+    r.cj = tp[t].cj;
+    r.i = tp[t].i;
+    r.j = tp[t].j;
+    return r;
+}
+PRT_DEV void xypoly_eval(const prt_dev_surface *__restrict__ sf, int nt, double x, double y, double &F,
+                         double &Fx, double &Fy) {
     // The host stores the terms sorted by (i, j), so the powers are built incrementally: x^i advances
     // when i does, y^j restarts with every new i -- about (#terms + degree^2 / 2) multiplications per
     // evaluation instead of sum (i + j) (a 25-term Zernike series: 45 monomials up to degree 8).
@@ -260,11 +273,11 @@ PRT_DEV void xypoly_eval(const prt_dev_surface *__restrict__ sf, int t0, int nt,
     int ip = 0, jp = 0;
     double xp = 1.0, xpm1 = 0.0;  // x^ip, x^(ip-1) (0 for ip = 0: d/dx of a constant)
     double yp = 1.0, ypm1 = 0.0;
-    prt_cdoubles cf = side_doubles(sf);
-    prt_cints pw = side_ints(sf);
-    for (int t = t0; t < nt; ++t) {
-        const int i = pw[2 * t], j = pw[2 * t + 1];
-        const double c = cf[t];
+    prt_cterms tp = (prt_cterms)(uint64_t)sf->pows;
+    poly_term cur = load_term(tp, 0);  // (the side array is padded: entry nt exists, its content is never used)
+    for (int t = 0; t < nt; ++t) {
+        const poly_term nxt = load_term(tp, t + 1);
+        const int i = cur.i, j = cur.j;
         if (i != ip) {
             if (i < ip) {
                 ip = 0;
@@ -290,9 +303,10 @@ PRT_DEV void xypoly_eval(const prt_dev_surface *__restrict__ sf, int t0, int nt,
             yp *= y;
             ++jp;
         }
-        F += c * xp * yp;
-        Fx += c * (double)i * xpm1 * yp;
-        Fy += c * (double)j * xp * ypm1;
+        F += cur.c * xp * yp;
+        Fx += cur.ci * xpm1 * yp;
+        Fy += cur.cj * xp * ypm1;
+        cur = nxt;
     }
 }
 
@@ -424,13 +438,13 @@ PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, const asphere
         // polynomial parts, merged by the host: scale * asphere + sum c_ij x^i y^j
         double Fa, m;
         asphere_eval<false>(sf, sf->n_asphere, ac, x, y, Fa, m);
-        xypoly_eval(sf, sf->n_asphere, sf->n_coeffs, x, y, F, Fx, Fy);
+        xypoly_eval(sf, sf->n_coeffs - sf->n_asphere, x, y, F, Fx, Fy);
         const double sc = sf->asphere_scale;
         F += sc * Fa;
         Fx += sc * x * m;
         Fy += sc * y * m;
     } else {
-        xypoly_eval(sf, 0, sf->n_coeffs, x, y, F, Fx, Fy);
+        xypoly_eval(sf, sf->n_coeffs, x, y, F, Fx, Fy);
     }
 }
 
