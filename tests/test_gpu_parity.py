@@ -700,6 +700,65 @@ def test_asphere_march_at_full_size(gpu_device):
         assert np.abs(res.k_out[s][:, idx].cpu().numpy()[:, v] - out[s]["k_out"][:, v]).max() < 1e-12
 
 
+@pytest.mark.parametrize("surface", [
+    {"shape": "Asphere", "curv": -1. / 30., "cc": -1.5,     # more coefficients than the 8 the kernel holds in registers
+     "coefficients": [1e-3, -1e-6, 1e-8, -1e-11, 1e-14, -1e-17, 1e-20, -1e-23, 1e-26, -1e-29]},
+    {"shape": "Asphere", "curv": 1. / 45., "cc": 0.3, "coefficients": [2e-4]},
+    {"shape": "Asphere", "curv": -1. / 30., "cc": -1.5, "coefficients": []},
+    {"shape": "XYPolynomials", "normradius": 2.0,           # odd number of terms, not sorted by powers
+     "coefficients": [(0, 2, -0.06), (2, 0, -0.07), (1, 1, 1e-3), (3, 0, -2e-4), (0, 4, 3e-5), (2, 1, 1e-4),
+                      (0, 0, 1e-2)]},
+    {"shape": "XYPolynomials", "normradius": 1.0, "coefficients": [(2, 0, -1. / 60.)]},
+    {"shape": "Biconic", "curvx": -1. / 30., "curvy": -1. / 35., "ccx": -1.5, "ccy": -0.5,
+     "coefficients": [(1e-6, 0.1), (-1e-9, -0.2), (1e-12, 0.3)]},
+], ids=["asphere10", "asphere1", "asphere0", "xypoly7_unsorted", "xypoly1", "biconic3"])
+def test_side_array_layouts_of_the_explicit_shapes(surface, gpu_device):
+    """coefficient / term tables as the kernels read them (scalar loads from the side array: asphere pairs
+    (a_n, (n+1) a_n) with 8 held in registers, 32-byte polynomial terms fetched one ahead, biconic pairs)
+    against the oracle, path mode and image mode, with the asphere-only and the all-shapes instantiation"""
+    from pyrate_amd import engine, systems, _lib
+    recs = systems.simple_system_records([
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
+        ({"shape": "Conic", "curv": 1. / 80.}, {"decz": 5.0}, 1.5168, "front", {}),
+        (surface, {"decz": 20.0}, None, "back", {}),
+        ({"shape": "Conic"}, {"decz": 100.0}, None, "image", {}),
+    ])
+    (o, k, e0) = systems.double_gauss_bundle(20000, rpup=9.0, z0=-5.0, field_deg=5.0)
+    with np.errstate(all="ignore"):
+        out = oracle.trace(recs, o, k, e0)
+    sysd = engine.DeviceSystem(recs, 0)
+    (x0, k0, e0d) = [engine.to_device_rays(a, gpu_device) for a in (o, k, e0)]
+    res = sysd.trace(x0, k0, e0d)
+    img = sysd.trace(x0, k0, e0d, mode=_lib.MODE_IMAGE)
+    torch.cuda.synchronize()
+    for s in range(4):
+        v = out[s]["valid_out"]
+        assert v.sum() > 0.9 * o.shape[1]
+        assert np.array_equal(res.valid_out[s].cpu().numpy().astype(bool), v)
+        assert np.abs(res.x_hit[s].cpu().numpy()[:, v] - out[s]["x_hit"][:, v]).max() < 1e-10
+        assert np.abs(res.k_out[s].cpu().numpy()[:, v] - out[s]["k_out"][:, v]).max() < 1e-12
+    assert torch.equal(torch.nan_to_num(img.x_hit[-1]), torch.nan_to_num(res.x_hit[-1]))
+    # the same surface behind a second explicit surface of another kind: the all-shapes instantiation
+    other = ({"shape": "Biconic", "curvx": 1. / 70., "curvy": 1. / 75., "ccx": 0.1, "ccy": -0.1, "coefficients": []}
+             if surface["shape"] != "Biconic" else
+             {"shape": "XYPolynomials", "normradius": 1.0, "coefficients": [(2, 0, 1. / 150.), (0, 2, 1. / 150.)]})
+    recs2 = systems.simple_system_records([
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
+        (other, {"decz": 5.0}, 1.5168, "front", {}),
+        (surface, {"decz": 20.0}, None, "back", {}),
+        ({"shape": "Conic"}, {"decz": 100.0}, None, "image", {}),
+    ])
+    with np.errstate(all="ignore"):
+        out2 = oracle.trace(recs2, o, k, e0)
+    res2 = engine.DeviceSystem(recs2, 0).trace(x0, k0, e0d)
+    torch.cuda.synchronize()
+    for s in range(4):
+        v = out2[s]["valid_out"]
+        assert np.array_equal(res2.valid_out[s].cpu().numpy().astype(bool), v)
+        assert np.abs(res2.x_hit[s].cpu().numpy()[:, v] - out2[s]["x_hit"][:, v]).max() < 1e-10
+        assert np.abs(res2.k_out[s].cpu().numpy()[:, v] - out2[s]["k_out"][:, v]).max() < 1e-12
+
+
 def test_arena_buffers_keep_their_data_through_allocation_churn(gpu_device):
     """the arena maps every virtual address once (ROCm keeps translating a re-used range to the old pages):
     buffers of changing sizes are taken, filled with a pattern, released, trimmed and taken again while
