@@ -22,12 +22,15 @@ for cfg in doublegauss asphere aniso; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/${cfg}_pmc/write -- $B --config $cfg > /dev/null 2> $O/${cfg}_write.err
   if [ $cfg = aniso ]; then
     rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/${cfg}_pmc/f64 -- $B --config $cfg > /dev/null 2> $O/${cfg}_f64.err
+    rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/${cfg}_pmc/sq1 -- $B --config $cfg > /dev/null 2> $O/${cfg}_sq1.err
+    rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU --output-format csv -d $O/${cfg}_pmc/sq2 -- $B --config $cfg > /dev/null 2> $O/${cfg}_sq2.err
   fi
   python benchmarks/pmc_summary.py $O/${cfg}_pmc $kernel > $O/${cfg}_pmc_counters.json 2>> $O/${cfg}_fetch.err
 done
 python bench.py --force-multi --steps 20 --warmup 5 > $O/bench_force_multi.json 2> $O/bench_force_multi.err
 python benchmarks/ab_variants.py > $O/ab_variants.json 2> $O/ab_variants.err
 python benchmarks/ab_crystal.py > $O/ab_crystal.json 2> $O/ab_crystal.err
+python benchmarks/ab_shapes.py > $O/ab_shapes.json 2> $O/ab_shapes.err
 python benchmarks/dropin_call_time.py > $O/dropin.json 2> $O/dropin.err
 python tests/parity_report.py > $O/parity_report.txt 2> $O/parity_report.err
 # keep only the summaries (the raw traces are large)
