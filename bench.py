@@ -221,24 +221,18 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    json_fd = 1
     if use_dist:
-        # RCCL prints a version banner to STDOUT when its first communicator comes up; the contract is ONE
-        # JSON line on stdout, so file descriptor 1 points at stderr until the communicator exists
+        # RCCL prints a version banner to STDOUT whenever a communicator comes up (first collective of every
+        # process group); the contract is ONE JSON line on stdout.  So file descriptor 1 points at stderr for
+        # the whole run and the line goes to a duplicate of the original stdout at the end.
         sys.stdout.flush()
-        saved_stdout = os.dup(1)
+        json_fd = os.dup(1)
         os.dup2(2, 1)
-        try:
-            if args.backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            else:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-            warm = torch.zeros(1, device=dev)
-            dist.all_reduce(warm)
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     n_gpus = world
 
     from pyrate_amd import build as prt_build, engine, placed, systems, _lib
@@ -540,7 +534,8 @@ def main():
         # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio
         # (block-buffered on a pipe, so it would otherwise surface at exit, after the line)
         _flush_c_stdio()
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
         sys.stdout.flush()
 
 

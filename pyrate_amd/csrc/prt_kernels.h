@@ -61,7 +61,9 @@ struct rayio {
         if (VEC) {
             // non-temporal hint: a path array is written once and not read by this kernel again; with
             // x_hit and k_out in two kinds of HBM it is worth 2 % (1.016 vs 1.038 ms, same arrays,
-            // benchmarks/ab_variants.py; PRT_PLAIN_STORES builds the other variant)
+            // benchmarks/ab_variants.py; PRT_PLAIN_STORES builds the other variant).  Of the cache-policy bits a
+            // gfx950 store can carry, "nt" alone is the best: nt 0.975 ms, sc0 nt 0.976, sc1 nt / sc0 sc1 nt 0.979,
+            // none / sc0 sc1 0.996-0.999 (inline-asm stores, profiles/r02zd_ab_store_cache_policy_bits.json)
 #ifndef PRT_PLAIN_STORES
             __builtin_nontemporal_store(prt_double2{v[0].x, v[1].x}, reinterpret_cast<prt_double2 *>(a + i));
             __builtin_nontemporal_store(prt_double2{v[0].y, v[1].y}, reinterpret_cast<prt_double2 *>(a + pitch + i));
