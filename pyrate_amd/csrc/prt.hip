@@ -11,6 +11,7 @@
 #include <string.h>
 #include <new>
 #include <mutex>
+#include <vector>
 #include "prt_kernels.h"
 
 
@@ -175,6 +176,39 @@ const char *prt_strerror(int32_t code) {
 
 const char *prt_last_error(void) { return g_err; }
 
+// The polynomial part of a surface (xypoly: all terms; combination: those behind the asphere part) as the
+// dense Horner rows xypoly_eval reads: header ints, then 32-byte chunks (layout: prt_device.h).
+#define PRT_MAX_POLY_POWER 64
+static std::vector<char> poly_rows(const prt_surface_t &r) {
+    std::vector<char> blob;
+    int t0 = 0;
+    if (r.shape_type == PRT_SHAPE_COMBO) t0 = r.n_asphere;
+    else if (r.shape_type != PRT_SHAPE_XYPOLY) return blob;
+    int D = -1;
+    for (int t = t0; t < r.n_coeffs; ++t) D = r.xpow[t] > D ? r.xpow[t] : D;
+    const int nrows = D + 1;
+    std::vector<std::vector<double>> row(nrows);  // row[i][j] = c_ij (terms with equal powers add up)
+    for (int t = t0; t < r.n_coeffs; ++t) {
+        std::vector<double> &w = row[r.xpow[t]];
+        if ((int)w.size() <= r.ypow[t]) w.resize(r.ypow[t] + 1, 0.0);
+        w[r.ypow[t]] += r.coeffs[t];
+    }
+    std::vector<int32_t> head(2 + nrows + ((2 + nrows) & 1), 0);
+    std::vector<double> data;
+    for (int i = D; i >= 0; --i) {
+        const int len = (int)row[i].size(), nch = (len + 3) / 4;
+        head[2 + (D - i)] = nch;
+        for (int q = 0; q < 4 * nch - len; ++q) data.push_back(0.0);  // leading zeros: p, dp stay 0
+        for (int j = len - 1; j >= 0; --j) data.push_back(row[i][j]);
+    }
+    head[0] = nrows;
+    head[1] = (int32_t)(data.size() / 4);
+    blob.resize(4 * head.size() + 8 * data.size());
+    memcpy(blob.data(), head.data(), 4 * head.size());
+    if (!data.empty()) memcpy(blob.data() + 4 * head.size(), data.data(), 8 * data.size());
+    return blob;
+}
+
 static int32_t check_record(const prt_surface_t *r, int idx) {
     char msg[128];
     if (r->shape_type < PRT_SHAPE_CONIC || r->shape_type > PRT_SHAPE_GRIDSAG) {
@@ -193,6 +227,14 @@ static int32_t check_record(const prt_surface_t *r, int idx) {
     if (r->shape_type == PRT_SHAPE_COMBO && (r->n_asphere < 0 || r->n_asphere > r->n_coeffs)) {
         snprintf(msg, sizeof msg, "surface %d: n_asphere %d out of range", idx, r->n_asphere);
         return fail(PRT_ERR_INVALID_ARG, msg);
+    }
+    if (r->shape_type == PRT_SHAPE_XYPOLY || r->shape_type == PRT_SHAPE_COMBO) {
+        for (int t = (r->shape_type == PRT_SHAPE_COMBO ? r->n_asphere : 0); t < r->n_coeffs; ++t)
+            if (r->xpow[t] < 0 || r->ypow[t] < 0 || r->xpow[t] > PRT_MAX_POLY_POWER || r->ypow[t] > PRT_MAX_POLY_POWER) {
+                snprintf(msg, sizeof msg, "surface %d: polynomial term %d has powers (%d, %d) outside 0..%d", idx, t,
+                         r->xpow[t], r->ypow[t], PRT_MAX_POLY_POWER);
+                return fail(PRT_ERR_INVALID_ARG, msg);
+            }
     }
     if (r->ap_type < PRT_AP_NONE || r->ap_type > PRT_AP_RECTANGULAR ||
         r->interaction < PRT_REFRACT || r->interaction > PRT_MIRROR ||
@@ -255,19 +297,22 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
         if (r.shape_type == PRT_SHAPE_BICONIC) return 2 * (size_t)r.n_coeffs;
         return (size_t)r.n_coeffs + n_asphere_part(r);
     };
-    // polynomial terms of a surface (xypoly: all coefficients; combination: those behind the asphere part),
-    // one poly_term each behind the doubles
-    auto n_terms = [](const prt_surface_t &r) -> size_t {
-        if (r.shape_type == PRT_SHAPE_XYPOLY) return (size_t)r.n_coeffs;
-        if (r.shape_type == PRT_SHAPE_COMBO) return (size_t)(r.n_coeffs - r.n_asphere);
-        return 0;
-    };
     // slack behind the last entry: asphere_prefetch reads PRT_ASPHERE_PREFETCH doubles from the start of a
-    // surface's coefficients whatever their number, xypoly_eval one poly_term beyond the last
+    // surface's coefficients whatever their number, xypoly_eval one 32-byte chunk beyond the last
     const size_t PRT_SIDE_SLACK = 8 + 8 * PRT_ASPHERE_PREFETCH;
     size_t side_bytes = 0;
-    for (int s = 0; s < n_surfaces; ++s)
-        side_bytes += 8 * n_doubles(table[s]) + sizeof(poly_term) * n_terms(table[s]);
+    std::vector<std::vector<char>> poly;
+    try {
+        poly.resize(n_surfaces);
+        for (int s = 0; s < n_surfaces; ++s) {
+            poly[s] = poly_rows(table[s]);
+            side_bytes += 8 * n_doubles(table[s]) + poly[s].size();
+        }
+    } catch (...) {  // std::bad_alloc: the ABI never throws
+        delete[] recs;
+        free_system(sys);
+        return fail(PRT_ERR_NOMEM, "host alloc");
+    }
     char *h_side = new (std::nothrow) char[side_bytes + PRT_SIDE_SLACK];
     if (!h_side) {
         delete[] recs;
@@ -319,7 +364,7 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
         d.curv_y = r.curv_y;
         d.cc_y = r.cc_y;
         d.asphere_scale = r.asphere_scale;
-        const size_t nd = n_doubles(r), ntm = n_terms(r);
+        const size_t nd = n_doubles(r);
         d.coeffs = (const double *)((char *)sys->d_side + off);
         const size_t na = n_asphere_part(r);
         memcpy(h_side + off, r.shape_type == PRT_SHAPE_GRIDSAG ? (const void *)r.aux : (const void *)r.coeffs,
@@ -327,16 +372,8 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
         for (size_t n = 0; n < na; ++n) ((double *)(h_side + off))[nd - na + n] = (double)(n + 1) * r.coeffs[n];
         off += 8 * nd;
         d.pows = (const void *)((char *)sys->d_side + off);
-        for (size_t t = 0; t < ntm; ++t) {
-            const size_t src = (size_t)r.n_coeffs - ntm + t;
-            poly_term &pt = ((poly_term *)(h_side + off))[t];
-            pt.c = r.coeffs[src];
-            pt.ci = r.coeffs[src] * (double)r.xpow[src];
-            pt.cj = r.coeffs[src] * (double)r.ypow[src];
-            pt.i = r.xpow[src];
-            pt.j = r.ypow[src];
-        }
-        off += sizeof(poly_term) * ntm;
+        if (!poly[s].empty()) memcpy(h_side + off, poly[s].data(), poly[s].size());
+        off += poly[s].size();
     }
     e = hipMemcpy(sys->d_side, h_side, side_bytes + PRT_SIDE_SLACK, hipMemcpyHostToDevice);
     delete[] h_side;

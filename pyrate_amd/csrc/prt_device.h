@@ -31,7 +31,7 @@ struct prt_dev_surface {
     int32_t n_asphere, grid_nx, grid_ny, pad_;
     double curv, cc;
     const double *coeffs;  // n_coeffs doubles (biconic: 2 n_coeffs); GRIDSAG: knots tx, ty, coefficients
-    const void *pows;      // xypoly / combo: the polynomial terms, one poly_term {c, c*i, c*j, i, j} each
+    const void *pows;      // xypoly / combo: the polynomial part as dense Horner rows (xypoly_eval)
     double B_shape[9], g_shape[3];
     double B_ap[9], g_ap[3];
     double ap_p0, ap_p1;
@@ -243,70 +243,51 @@ PRT_DEV void asphere_eval(const prt_dev_surface *__restrict__ sf, int nc, const 
     dFdr2x2 = c * fast_rcp(sq) + 2.0 * dp;
 }
 
-// XYPolynomials.F / gradF, surface_shape.py:785-807.  One 32-byte entry per term in the side array (built by
-// prt_system_create): c (already divided by normradius^(i+j) on the host), c*i, c*j and the powers i, j --
-// ONE scalar load per term, issued one term ahead, and no integer -> double conversion or c*i product per
-// evaluation.  Powers by repeated multiplication with wave-uniform trip counts.
-struct poly_term {
-    double c, ci, cj;
-    int32_t i, j;
-};
-typedef const PRT_CONST_AS poly_term *prt_cterms;
-PRT_DEV poly_term load_term(prt_cterms tp, int t) {  // (member by member: no struct copy out of an address space)
-    poly_term r;
-    r.c = tp[t].c;
-    r.ci = tp[t].ci;
-    r.cj = tp[t].cj;
-    r.i = tp[t].i;
-    r.j = tp[t].j;
-    return r;
-}
-PRT_DEV void xypoly_eval(const prt_dev_surface *__restrict__ sf, int nt, double x, double y, double &F,
-                         double &Fx, double &Fy) {
-    // The host stores the terms sorted by (i, j), so the powers are built incrementally: x^i advances
-    // when i does, y^j restarts with every new i -- about (#terms + degree^2 / 2) multiplications per
-    // evaluation instead of sum (i + j) (a 25-term Zernike series: 45 monomials up to degree 8).
-    // Any other order still evaluates correctly (the running powers restart when an index drops).
+// XYPolynomials.F / gradF, surface_shape.py:785-807: F = sum c_ij x^i y^j (c_ij already divided by
+// normradius^(i+j) on the host), as a nested Horner scheme over the DENSE rows of the coefficient triangle:
+//   F = sum_i x^i P_i(y),   P_i(y) = sum_j c_ij y^j
+//   rows i = D .. 0:   (P_i, P_i') by Horner in y with derivative;   Fx <- Fx x + F;  F <- F x + P_i;  Fy <- Fy x + P_i'
+// Two FMAs per coefficient and three per row, no data-dependent control flow, no powers to keep -- the
+// monomial-by-monomial sum it replaces took six VALU operations per term plus the running powers
+// (42 monomials up to degree 8: 1.13 -> 0.6x ms at 1e7 rays; |difference| of the two evaluations on the
+// golden Zernike / polynomial cases: 3e-17).  Side-array layout (prt_system_create, poly_rows):
+//   int32 n_rows, int32 n_chunks, int32 chunks_of_row[n_rows] (row D first), padded to 8 bytes;
+//   then 32-byte chunks of four coefficients in Horner order (highest power of y first, a row's first
+//   chunk padded with leading zeros).  One s_load_dwordx8 per chunk, issued one chunk ahead.
+typedef const PRT_CONST_AS int32_t *prt_cints;
+PRT_DEV void xypoly_eval(const prt_dev_surface *__restrict__ sf, double x, double y, double &F, double &Fx,
+                         double &Fy) {
+    prt_cints hd = (prt_cints)(uint64_t)sf->pows;
+    const int nrows = hd[0];
+    prt_cdoubles cd = (prt_cdoubles)((uint64_t)sf->pows + 8 * (uint64_t)((nrows + 3) >> 1));
     F = 0.0;
     Fx = 0.0;
     Fy = 0.0;
-    int ip = 0, jp = 0;
-    double xp = 1.0, xpm1 = 0.0;  // x^ip, x^(ip-1) (0 for ip = 0: d/dx of a constant)
-    double yp = 1.0, ypm1 = 0.0;
-    prt_cterms tp = (prt_cterms)(uint64_t)sf->pows;
-    poly_term cur = load_term(tp, 0);  // (the side array is padded: entry nt exists, its content is never used)
-    for (int t = 0; t < nt; ++t) {
-        const poly_term nxt = load_term(tp, t + 1);
-        const int i = cur.i, j = cur.j;
-        if (i != ip) {
-            if (i < ip) {
-                ip = 0;
-                xp = 1.0;
-                xpm1 = 0.0;
-            }
-            while (ip < i) {
-                xpm1 = xp;
-                xp *= x;
-                ++ip;
-            }
-            jp = 0;
-            yp = 1.0;
-            ypm1 = 0.0;
+    // (the side array is padded: the chunk behind the last one exists, its content is never used)
+    double c0 = cd[0], c1 = cd[1], c2 = cd[2], c3 = cd[3];
+    int ch = 0;
+    for (int r = 0; r < nrows; ++r) {
+        const int nch = hd[2 + r];
+        double p = 0.0, dp = 0.0;
+        for (int q = 0; q < nch; ++q) {
+            ++ch;
+            const double n0 = cd[4 * ch], n1 = cd[4 * ch + 1], n2 = cd[4 * ch + 2], n3 = cd[4 * ch + 3];
+            dp = dp * y + p;
+            p = p * y + c0;
+            dp = dp * y + p;
+            p = p * y + c1;
+            dp = dp * y + p;
+            p = p * y + c2;
+            dp = dp * y + p;
+            p = p * y + c3;
+            c0 = n0;
+            c1 = n1;
+            c2 = n2;
+            c3 = n3;
         }
-        if (j < jp) {
-            jp = 0;
-            yp = 1.0;
-            ypm1 = 0.0;
-        }
-        while (jp < j) {
-            ypm1 = yp;
-            yp *= y;
-            ++jp;
-        }
-        F += cur.c * xp * yp;
-        Fx += cur.ci * xpm1 * yp;
-        Fy += cur.cj * xp * ypm1;
-        cur = nxt;
+        Fx = Fx * x + F;
+        F = F * x + p;
+        Fy = Fy * x + dp;
     }
 }
 
@@ -438,13 +419,13 @@ PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, const asphere
         // polynomial parts, merged by the host: scale * asphere + sum c_ij x^i y^j
         double Fa, m;
         asphere_eval<false>(sf, sf->n_asphere, ac, x, y, Fa, m);
-        xypoly_eval(sf, sf->n_coeffs - sf->n_asphere, x, y, F, Fx, Fy);
+        xypoly_eval(sf, x, y, F, Fx, Fy);
         const double sc = sf->asphere_scale;
         F += sc * Fa;
         Fx += sc * x * m;
         Fy += sc * y * m;
     } else {
-        xypoly_eval(sf, sf->n_coeffs, x, y, F, Fx, Fy);
+        xypoly_eval(sf, x, y, F, Fx, Fy);
     }
 }
 
