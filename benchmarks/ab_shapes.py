@@ -2,7 +2,8 @@
 """A/B of libprt builds (scratch/variants/libprt_<name>.so) on the Newton-intersected shapes: the 4-surface
 system of BASELINE configs[2] with its third surface replaced by an even asphere with 3 / 10 coefficients, an
 XY polynomial (12 terms up to degree 4), a Zernike-like polynomial (42 monomials up to degree 8) and a biconic
-with two (a, b) pairs; 1e7 rays at 5 degrees, path mode and image mode, same arrays for every build.
+with two (a, b) pairs; 1e7 rays at 5 degrees; plus the sag-grid system of the golden case gridsag_field2 (3
+surfaces); path mode and image mode, same arrays for every build.
 
     python benchmarks/ab_shapes.py [nrays]
 """
@@ -53,6 +54,15 @@ CASES = {
                   "coefficients": [(1e-6, 0.1), (-1e-9, -0.2)]},
 }
 
+
+def gridsag_case():
+    """the sag-grid system of the golden case gridsag_field2 (25 x 21 cubic B-spline coefficients) with a 1e7-ray
+    bundle of the same aperture and field"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _golden
+    return _golden.load_case("gridsag_field2").table
+
+
 dev = torch.device("cuda", 0)
 nrays = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10000000
 (x0, k0, e0d, n) = systems.double_gauss_bundle_device(nrays, dev, rpup=9.0, z0=-5.0, field_deg=5.0)
@@ -60,9 +70,14 @@ pitch_in = x0.stride(0)
 st = engine._stream_handle(dev)
 P = engine._ptr
 paths = sorted(glob.glob(os.path.join(ROOT, "scratch", "variants", "libprt_*.so")))
-out = {"rays": n, "terms": {k: len(v["coefficients"]) for (k, v) in CASES.items()}}
+out = {"rays": n, "terms": {k: len(v["coefficients"]) for (k, v) in CASES.items() if v is not None}}
+bundles = {"default": (x0, k0, e0d, n, pitch_in)}
+CASES["gridsag_25x21"] = None
+(gx0, gk0, ge0, gn) = systems.double_gauss_bundle_device(nrays, dev, rpup=6.8, z0=-3.0, field_deg=2.0)
+bundles["gridsag_25x21"] = (gx0, gk0, ge0, gn, gx0.stride(0))
 for (case, surface) in CASES.items():
-    sysd = engine.DeviceSystem(system_with(surface), 0)
+    sysd = engine.DeviceSystem(system_with(surface) if surface is not None else gridsag_case(), 0)
+    (x0, k0, e0d, n, pitch_in) = bundles.get(case, bundles["default"])
     libs = {"in-tree": (sysd.lib, sysd._h)}
     for path in paths:
         lib = ctypes.CDLL(os.path.abspath(path))
