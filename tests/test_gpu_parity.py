@@ -700,6 +700,58 @@ def test_asphere_march_at_full_size(gpu_device):
         assert np.abs(res.k_out[s][:, idx].cpu().numpy()[:, v] - out[s]["k_out"][:, v]).max() < 1e-12
 
 
+def test_biconic_mirror_system_at_full_size(gpu_device):
+    """reflection at scale: the two tilted biconic mirrors of the golden case hud_biconic_mirrors
+    with 1e7 rays -- every hit point lies on its biconic to 1e-12 mm, reflection keeps |k| to 1e-14 and obeys
+    the reference's mirror rule against the surface normal grad(z - F) on every ray; masks
+    and a 1e4-ray sub-sample equal the oracle's; nothing ends at the Newton iteration cap"""
+    from pyrate_amd import engine, systems
+    recs = _golden.load_case("hud_biconic_mirrors").table
+    sysd = engine.DeviceSystem(recs, 0)
+    (x0, k0, e0d, n) = systems.double_gauss_bundle_device(10000000, gpu_device, rpup=8.8, z0=-5.0, field_deg=1.0)
+    res = sysd.trace(x0, k0, e0d, packed_flags=True)
+    assert all(int(res.nonconv[s].sum()) == 0 for s in range(4))
+    assert int(res.valid_out[-1].sum()) == n
+    k_in = res.k_out[0]
+    for s in (1, 2):
+        sh = recs[s]["shape"]
+        B = torch.tensor(recs[s]["B_shape"], dtype=torch.float64, device=gpu_device)
+        g = torch.tensor(recs[s]["g_shape"], dtype=torch.float64, device=gpu_device)
+        p = B.T @ (res.x_hit[s] - g[:, None])                       # hit points in the shape frame
+        (cx, cy, ccx, ccy) = (sh["curvx"], sh["curvy"], sh["ccx"], sh["ccy"])
+        (x, y) = (p[0], p[1])
+        (x2, y2) = (x * x, y * y)
+        u = cx * x2 + cy * y2
+        sq = torch.sqrt(1 - cx * cx * (1 + ccx) * x2 - cy * cy * (1 + ccy) * y2)
+        F = u / (1 + sq)
+        Fx = cx * x * (cx * (ccx + 1) * u + 2 * (1 + sq) * sq) / ((1 + sq) ** 2 * sq)
+        Fy = cy * y * (cy * (ccy + 1) * u + 2 * (1 + sq) * sq) / ((1 + sq) ** 2 * sq)
+        for (q, (a, b)) in enumerate(sh["coeffs"]):
+            w = x2 * (1 - b) + y2 * (1 + b)
+            F = F + a * w ** (q + 1)
+            Fx = Fx + 2 * a * (q + 1) * w ** q * x * (1 - b)
+            Fy = Fy + 2 * a * (q + 1) * w ** q * y * (1 + b)
+        assert float((p[2] - F).abs().max()) < 1e-12
+        k_out = res.k_out[s]
+        assert float(((k_out ** 2).sum(dim=0).sqrt() - 1.0).abs().max()) < 1e-14
+        nrm = B @ torch.stack((-Fx, -Fy, torch.ones_like(Fx)))      # global, not normalised
+        nrm = nrm / (nrm ** 2).sum(dim=0).sqrt()
+        # the reference's mirror (material_isotropic.py:215-224): k2 = -k_inplane + xi * normal -- the in-plane
+        # part changes sign, the normal component is kept: k_out + k_in is parallel to the normal
+        assert float(torch.linalg.cross(k_out + k_in, nrm, dim=0).abs().max()) < 1e-13
+        assert float(((k_out * nrm).sum(dim=0) - (k_in * nrm).sum(dim=0)).abs().max()) < 1e-13
+        k_in = k_out
+    idx = torch.arange(0, n, 1000, device=gpu_device)
+    (o_s, k_s, e_s) = [t[:, idx].cpu().numpy() for t in (x0, k0, e0d)]
+    with np.errstate(all="ignore"):
+        out = oracle.trace(recs, o_s, k_s, e_s)
+    for s in range(4):
+        v = out[s]["valid_out"]
+        assert np.array_equal(res.valid_out[s][idx].cpu().numpy().astype(bool), v)
+        assert np.abs(res.x_hit[s][:, idx].cpu().numpy()[:, v] - out[s]["x_hit"][:, v]).max() < 1e-10
+        assert np.abs(res.k_out[s][:, idx].cpu().numpy()[:, v] - np.real(out[s]["k_out"])[:, v]).max() < 1e-12
+
+
 @pytest.mark.parametrize("surface", [
     {"shape": "Asphere", "curv": -1. / 30., "cc": -1.5,     # more coefficients than the 8 the kernel holds in registers
      "coefficients": [1e-3, -1e-6, 1e-8, -1e-11, 1e-14, -1e-17, 1e-20, -1e-23, 1e-26, -1e-29]},
