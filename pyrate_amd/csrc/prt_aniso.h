@@ -39,7 +39,7 @@ PRT_DEV cplx cmul(cplx a, cplx b) { return cplx{a.re * b.re - a.im * b.im, a.re 
 PRT_DEV cplx cadd(cplx a, cplx b) { return cplx{a.re + b.re, a.im + b.im}; }
 PRT_DEV cplx csub(cplx a, cplx b) { return cplx{a.re - b.re, a.im - b.im}; }
 PRT_DEV cplx cdiv(cplx a, cplx b) {
-    const double den = 1.0 / (b.re * b.re + b.im * b.im);
+    const double den = fast_rcp(b.re * b.re + b.im * b.im);
     return cplx{(a.re * b.re + a.im * b.im) * den, (a.im * b.re - a.re * b.im) * den};
 }
 PRT_DEV double cabs2(cplx a) { return a.re * a.re + a.im * a.im; }
@@ -85,7 +85,7 @@ PRT_DEV void xi_polynomial(const double *__restrict__ eps, const vec3 &n, const 
 
 // Aberth-Ehrlich on p4 z^4 + ... + p0 (complex roots), then two Newton steps each.
 PRT_DEV void quartic_roots(const double p[5], cplx z[4]) {
-    const double ip4 = 1.0 / p[4];
+    const double ip4 = fast_rcp(p[4]);
     const double a3 = p[3] * ip4, a2 = p[2] * ip4, a1 = p[1] * ip4, a0 = p[0] * ip4;
     // Cauchy bound for the start radius
     const double rad = 1.0 + fmax(fmax(fabs(a3), fabs(a2)), fmax(fabs(a1), fabs(a0)));
@@ -119,7 +119,7 @@ PRT_DEV void quartic_roots(const double p[5], cplx z[4]) {
             const cplx den = csub(cplx{1.0, 0.0}, cmul(newton, sum));
             w[i] = cdiv(newton, den);
             if (!(cabs2(fp) > 0.0) || !isfinite(w[i].re) || !isfinite(w[i].im)) w[i] = cplx{0.0, 0.0};
-            worst = fmax(worst, cabs2(w[i]) / fmax(cabs2(zi), 1e-300));
+            worst = fmax(worst, cabs2(w[i]) * fast_rcp(fmax(cabs2(zi), 1e-300)));
         }
         if (!done) {
 #pragma unroll
@@ -220,28 +220,23 @@ PRT_DEV vec3 null_vector(const vec3 &r0, const vec3 &r1, const vec3 &r2, int var
 //   eps = eo I + (ee - eo) c c^T:    ordinary  E = k x c   (perpendicular to k and to the axis),
 //                                    extraordinary  E = (k.c) k - eo c
 //     (W E = [k^T eps k - eo ee] c = 0 on the extraordinary sheet; D = eps E is perpendicular to k)
-PRT_DEV void eigen_solution(const prt_dev_surface *__restrict__ sf, int cls, const vec3 &kpa, const vec3 &n,
-                            double x, int variant, vec3 &E_out, double &sn_out) {
-    const double *__restrict__ eps = sf->eps_re;
-    const vec3 kv = v3(kpa.x + x * n.x, kpa.y + x * n.y, kpa.z + x * n.z);
-    const double k2 = dot(kv, kv);
-    vec3 E = v3(0.0, 0.0, 0.0);
-    bool closed = false;
+// In three pieces, so that the caller can run the straight-line parts of two solutions side by side (two
+// independent dependency chains in one basic block) and keep the rare fallback in one branch:
+PRT_DEV vec3 closed_form_e(const prt_dev_surface *__restrict__ sf, int cls, const vec3 &kv, double k2, int variant,
+                           bool &closed) {
     if (cls == PRT_ANISO_ISOTROPIC) {
         const double ax = fabs(kv.x), ay = fabs(kv.y), az = fabs(kv.z);
         const vec3 a = (ax <= ay && ax <= az) ? v3(1, 0, 0) : ((ay <= az) ? v3(0, 1, 0) : v3(0, 0, 1));
         vec3 v1 = cross(kv, a);
         double inv = fast_rsqrt(dot(v1, v1));
         v1 = v3(v1.x * inv, v1.y * inv, v1.z * inv);
-        if (variant == 0) {
-            E = v1;
-        } else {
-            const vec3 v2 = cross(kv, v1);
-            inv = fast_rsqrt(dot(v2, v2));
-            E = v3(v2.x * inv, v2.y * inv, v2.z * inv);
-        }
         closed = true;
-    } else if (cls == PRT_ANISO_UNIAXIAL) {
+        if (variant == 0) return v1;
+        const vec3 v2 = cross(kv, v1);
+        inv = fast_rsqrt(dot(v2, v2));
+        return v3(v2.x * inv, v2.y * inv, v2.z * inv);
+    }
+    if (cls == PRT_ANISO_UNIAXIAL) {
         const vec3 caxis = v3(sf->aniso_axis[0], sf->aniso_axis[1], sf->aniso_axis[2]);
         const vec3 kxc = cross(kv, caxis);
         const double q = dot(kxc, kxc);
@@ -251,20 +246,37 @@ PRT_DEV void eigen_solution(const prt_dev_surface *__restrict__ sf, int cls, con
                            kc * kv.z - sf->aniso_eo * caxis.z);
         const vec3 raw = (variant == 0) ? kxc : ex;
         const double inv = fast_rsqrt(dot(raw, raw));
-        E = v3(raw.x * inv, raw.y * inv, raw.z * inv);
+        return v3(raw.x * inv, raw.y * inv, raw.z * inv);
     }
-    if (!closed) {
-        const vec3 w0 = v3(eps[0] - k2 + kv.x * kv.x, eps[1] + kv.x * kv.y, eps[2] + kv.x * kv.z);
-        const vec3 w1 = v3(eps[3] + kv.y * kv.x, eps[4] - k2 + kv.y * kv.y, eps[5] + kv.y * kv.z);
-        const vec3 w2 = v3(eps[6] + kv.z * kv.x, eps[7] + kv.z * kv.y, eps[8] - k2 + kv.z * kv.z);
-        E = null_vector(w0, w1, w2, variant);
-    }
+    closed = false;
+    return v3(0.0, 0.0, 0.0);
+}
+
+PRT_DEV vec3 generic_e(const prt_dev_surface *__restrict__ sf, const vec3 &kv, double k2, int variant) {
+    const double *__restrict__ eps = sf->eps_re;
+    const vec3 w0 = v3(eps[0] - k2 + kv.x * kv.x, eps[1] + kv.x * kv.y, eps[2] + kv.x * kv.z);
+    const vec3 w1 = v3(eps[3] + kv.y * kv.x, eps[4] - k2 + kv.y * kv.y, eps[5] + kv.y * kv.z);
+    const vec3 w2 = v3(eps[6] + kv.z * kv.x, eps[7] + kv.z * kv.y, eps[8] - k2 + kv.z * kv.z);
+    return null_vector(w0, w1, w2, variant);
+}
+
+PRT_DEV void scaled_e_and_flux(const vec3 &E0, const vec3 &kv, const vec3 &n, double x, vec3 &E_out, double &sn_out) {
     const double sc = fast_rsqrt(1.0 + x * x);  // LAPACK unit-norm [xi E; E]
-    E = v3(E.x * sc, E.y * sc, E.z * sc);
+    const vec3 E = v3(E0.x * sc, E0.y * sc, E0.z * sc);
     const double e2 = dot(E, E), ke = dot(kv, E);
     const vec3 S = v3(e2 * kv.x - ke * E.x, e2 * kv.y - ke * E.y, e2 * kv.z - ke * E.z);
     E_out = E;
     sn_out = dot(S, n);
+}
+
+PRT_DEV void eigen_solution(const prt_dev_surface *__restrict__ sf, int cls, const vec3 &kpa, const vec3 &n,
+                            double x, int variant, vec3 &E_out, double &sn_out) {
+    const vec3 kv = v3(kpa.x + x * n.x, kpa.y + x * n.y, kpa.z + x * n.z);
+    const double k2 = dot(kv, kv);
+    bool closed;
+    vec3 E = closed_form_e(sf, cls, kv, k2, variant, closed);
+    if (!closed) E = generic_e(sf, kv, k2, variant);
+    scaled_e_and_flux(E, kv, n, x, E_out, sn_out);
 }
 
 // The solutions (xi, E, S.n) of the dispersion relation for one ray, then the reference's ordering.
@@ -317,16 +329,29 @@ PRT_DEV void interact_anisotropic(const prt_dev_surface *__restrict__ sf, const 
             const double disc = fast_sqrt(Bh * Bh - A * C);  // NaN if evanescent
             // stable quadratic roots
             const double q = -(Bh + copysign(disc, Bh));
-            double x1 = q / A, x2 = (q != 0.0) ? C / q : -x1;
-            if (Bh == 0.0) { x1 = -disc / A; x2 = disc / A; }
+            // (fast_rcp: ~1 ulp; the IEEE division sequences of these four quotients were a sixth of the
+            // solver's instructions)
+            const double iA = fast_rcp(A);
+            double x1 = q * iA, x2 = (q != 0.0) ? C * fast_rcp(q) : -x1;
+            if (Bh == 0.0) { x1 = -disc * iA; x2 = disc * iA; }
             x_o = mirror ? -ro : ro;
             x_e = mirror ? fmin(x1, x2) : fmax(x1, x2);
             if (!isfinite(disc)) x_e = __builtin_nan("");
         }
-        vec3 E_o, E_e;
+        // both solutions side by side; the generic null vector (near the optic axis) in ONE rarely taken branch
+        const vec3 kv_o = v3(kpa.x + x_o * n.x, kpa.y + x_o * n.y, kpa.z + x_o * n.z);
+        const vec3 kv_e = v3(kpa.x + x_e * n.x, kpa.y + x_e * n.y, kpa.z + x_e * n.z);
+        const double k2_o = dot(kv_o, kv_o), k2_e = dot(kv_e, kv_e);
+        bool closed_o, closed_e;
+        vec3 E_o = closed_form_e(sf, cls, kv_o, k2_o, 0, closed_o);
+        vec3 E_e = closed_form_e(sf, cls, kv_e, k2_e, 1, closed_e);
+        if (!(closed_o && closed_e)) {
+            if (!closed_o) E_o = generic_e(sf, kv_o, k2_o, 0);
+            if (!closed_e) E_e = generic_e(sf, kv_e, k2_e, 1);
+        }
         double s_o, s_e;
-        eigen_solution(sf, cls, kpa, n, x_o, 0, E_o, s_o);
-        eigen_solution(sf, cls, kpa, n, x_e, 1, E_e, s_e);
+        scaled_e_and_flux(E_o, kv_o, n, x_o, E_o, s_o);
+        scaled_e_and_flux(E_e, kv_e, n, x_e, E_e, s_e);
         const double key_o = isnan(s_o) ? 0.0 : s_o, key_e = isnan(s_e) ? 0.0 : s_e;
         const bool sw = key_e < key_o;  // stable: the ordinary solution first on a tie
         x_out[0] = sw ? x_e : x_o;
@@ -383,7 +408,7 @@ PRT_DEV void interact_anisotropic(const prt_dev_surface *__restrict__ sf, const 
             for (int it = 0; it < 2; ++it) {
                 const double f = (((pc[4] * x + pc[3]) * x + pc[2]) * x + pc[1]) * x + pc[0];
                 const double fp = ((4.0 * pc[4] * x + 3.0 * pc[3]) * x + 2.0 * pc[2]) * x + pc[1];
-                const double dx = f / fp;
+                const double dx = f * fast_rcp(fp);
                 if (isfinite(dx) && fabs(dx) < 1e-6 * fmax(1.0, fabs(x))) x -= dx;
             }
             xi[i] = x;
