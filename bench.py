@@ -221,6 +221,10 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if os.environ.get("PRT_BENCH_WATCHDOG"):
+        # debugging aid: dump every thread's stack to stderr and exit if the run takes longer than this
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PRT_BENCH_WATCHDOG"]), exit=True)
     json_fd = 1
     if use_dist:
         # RCCL prints a version banner to STDOUT whenever a communicator comes up (first collective of every
