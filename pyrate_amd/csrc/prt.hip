@@ -282,8 +282,8 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     sys->all_isotropic = 1;
     sys->all_conic = 1;
     sys->shape_level = PRT_SHAPES_CONIC;
-    // side array: per surface its doubles (coefficients, or the grid-sag spline) then, 8-byte
-    // aligned, its (x power, y power) pairs
+    // side array: per surface its doubles (coefficients -- for an asphere part followed by the products
+    // (n+1) a_n --, or the grid-sag spline), then the polynomial part as dense Horner rows (poly_rows)
     // coefficients of the even-asphere part of a surface: its products (n+1) a_n follow the doubles of the
     // host table in the side array (asphere_prefetch)
     auto n_asphere_part = [](const prt_surface_t &r) -> size_t {
