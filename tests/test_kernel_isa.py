@@ -1,0 +1,57 @@
+"""
+What the compiler made of the march kernels (hipcc cross-compiles gfx950 without a GPU; skipped where there
+is no hipcc): the properties DESIGN.md 4 relies on, read from the assembly by benchmarks/isa_report.py.
+
+  * no flat_load / flat_store in any march kernel: every table access is a scalar load (constant address
+    space) or a global access (a generic pointer costs a vector-memory round trip per coefficient and a
+    vmcnt(0) that also drains the path stores -- found in round 2 on the asphere and polynomial shapes)
+  * no s_waitcnt vmcnt inside the surface loop of the kernels that only store there (conic and asphere
+    marches): gfx950 counts loads and stores in one counter
+  * registers / occupancy of the instantiations the BASELINE configs run
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "benchmarks"))
+
+
+@pytest.fixture(scope="module")
+def isa():
+    from pyrate_amd import build
+    if build.find_hipcc() is None:
+        pytest.skip("no hipcc on this box")
+    import isa_report
+    rep = isa_report.report()
+    return {k["kernel"]: k for k in rep["kernels"]}
+
+
+def test_no_flat_memory_operations_in_the_march_kernels(isa):
+    assert len(isa) >= 30
+    for (name, k) in isa.items():
+        assert k["flat_memory_ops"] == 0, name
+
+
+def test_store_only_loops_never_wait_on_the_memory_counter(isa):
+    """conic (SHAPES = 0) and asphere (SHAPES = 1) instantiations without the LDS-table / moments variants:
+    their surface loop contains stores and scalar loads only, so no vmcnt wait may appear in it"""
+    for (name, k) in isa.items():
+        if name.startswith("k_trace_iso<") and name.split(",")[3] in ("0", "1") and name.endswith(",0,0>"):
+            assert k["vmcnt_waits_in_loops"] == 0, name
+
+
+def test_registers_and_occupancy_of_the_baseline_instantiations(isa):
+    head = isa["k_trace_iso<0,1,1,0,0,0>"]        # BASELINE configs[1]: path mode, 2 rays per lane, conics only
+    assert head["scratch_bytes_per_lane"] == 0 and head["waves_per_simd"] >= 7 and head["vgprs"] <= 72
+    asph = isa["k_trace_iso<0,1,1,1,0,0>"]        # configs[2]: conics + even aspheres
+    assert asph["scratch_bytes_per_lane"] == 0 and asph["waves_per_simd"] >= 5
+    image = isa["k_trace_iso<1,1,1,0,0,0>"]       # image mode of the conic march: capped at 64 VGPRs for 8 waves
+    assert image["waves_per_simd"] == 8
+    crystal = isa["k_trace_general<0,0,1>"]       # configs[3]: uniaxial crystals, parking slots in LDS
+    assert crystal["scratch_bytes_per_lane"] == 0 and crystal["waves_per_simd"] >= 4
+    # path rows through a scalar base + lane offset; only the byte masks keep 64-bit lane addresses
+    assert crystal["scalar_base_stores"] >= 20 and crystal["vector_address_stores"] <= 6
+    allshapes = isa["k_trace_iso<0,1,1,2,0,0>"]   # every explicit shape compiled in
+    assert allshapes["scratch_bytes_per_lane"] == 0 and allshapes["waves_per_simd"] >= 4
