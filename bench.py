@@ -517,7 +517,7 @@ def main():
                            "backend": ("rccl" if args.backend == "nccl" else "gloo dry run (host staged)")
                            if multi else "none"},
                        "image_plane_spot": spot,
-                       "build": prt_build.build_info()},
+                       "build": prt_build.build_info(_lib.LIB_PATH)},
             "roofline": roofline,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -69,21 +69,26 @@ def hipcc_version(hipcc=None):
     return out.splitlines()[0].strip() if out else None
 
 
-def library_hash():
-    """first 16 hex digits of the SHA-256 of libprt.so (None if it is not built)"""
-    if not os.path.exists(OUT):
+def library_hash(path=None):
+    """first 16 hex digits of the SHA-256 of libprt.so (None if it is not built); ``path``: another build
+    of the library"""
+    path = path or OUT
+    if not os.path.exists(path):
         return None
     h = hashlib.sha256()
-    with open(OUT, "rb") as f:
+    with open(path, "rb") as f:
         for block in iter(lambda: f.read(1 << 20), b""):
             h.update(block)
     return h.hexdigest()[:16]
 
 
-def build_info():
-    """what bench.py puts into its JSON line: hash of the library that is loaded, and the compiler
-    that produced it (from the side file the build writes; None if the library came from elsewhere)"""
-    info = {"libprt_sha256_16": library_hash(), "hipcc": None}
+def build_info(loaded_path=None):
+    """what bench.py puts into its JSON line: hash of the library that is loaded (``loaded_path``: the file
+    the process really mapped, if it is not the in-tree one -- PRT_LIBRARY), and the compiler that produced
+    it (from the side file the build writes; None if the library came from elsewhere)"""
+    info = {"libprt_sha256_16": library_hash(loaded_path), "hipcc": None}
+    if loaded_path and os.path.abspath(loaded_path) != os.path.abspath(OUT):
+        info["library"] = os.path.relpath(loaded_path, os.path.dirname(HERE))
     try:
         with open(INFO) as f:
             rec = json.load(f)
