@@ -22,6 +22,15 @@ def _free_port():
 
 
 def _rank(rank, world, port, nrays, q):
+    """one rank; whatever happens, exactly one (rank, ok, message) goes into the queue"""
+    try:
+        q.put((rank, bool(_rank_body(rank, world, port, nrays)), ""))
+    except BaseException as exc:      # the parent must hear about it instead of waiting for its timeout
+        import traceback
+        q.put((rank, False, "%r\n%s" % (exc, traceback.format_exc())))
+
+
+def _rank_body(rank, world, port, nrays):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     from pyrate_amd import distributed as pdist, engine, systems, _lib
@@ -56,7 +65,7 @@ def _rank(rank, world, port, nrays, q):
         rms_ref = float(torch.sqrt(((xs - xs.mean(dim=1, keepdim=True)) ** 2).sum() / (int(m.sum()) - 1)))
         ok = ok and cnt == int(m.sum()) and bool(np.allclose(cen, cen_ref, rtol=0, atol=1e-10)) \
             and abs(rms - rms_ref) < 1e-10
-        q.put((rank, bool(ok)))
+        return ok
     finally:
         dist.destroy_process_group()
 
@@ -65,15 +74,41 @@ def test_sharded_trace_with_rccl_gather_equals_the_unsharded_trace():
     world = min(torch.cuda.device_count(), 8)
     if world < 2:
         pytest.skip("needs at least 2 GPUs (RCCL, one process per GPU)")
+    _run_ranks(world, 2000003, 420)
+
+
+def _run_ranks(world, nrays, timeout):
+    import queue
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, world, port, 2000003, q)) for r in range(world)]
+    # daemon processes, terminated in any case: a rank stuck in a collective must not keep the test run alive
+    procs = [ctx.Process(target=_rank, args=(r, world, port, nrays, q), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    assert sorted(results) == [(r, True) for r in range(world)]
+    results = []
+    try:
+        for _ in procs:
+            try:
+                results.append(q.get(timeout=timeout))
+            except queue.Empty:
+                break
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+    assert len(results) == world, "ranks that did not answer within the timeout: %s" % (
+        sorted(set(range(world)) - {r[0] for r in results}),)
+    assert all(ok for (_, ok, _) in results), [r for r in results if not r[1]]
+
+
+def test_the_rank_program_with_a_single_rccl_rank():
+    """the very program every rank of the multi-GPU test runs, as a world of one (RCCL communicator, sharding,
+    fused statistics + all-reduce, all-gather into the final layout, comparison with the unsharded trace): what
+    a 1-GPU box can check of it"""
+    if torch.cuda.device_count() < 1:
+        pytest.skip("needs a GPU")
+    _run_ranks(1, 500003, 300)
