@@ -319,8 +319,20 @@ def main():
             moved.append(buf)
         (x0, k0, e0d) = moved
         torch.cuda.synchronize()
-    bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed, placement=placement, pitch=pitch)
-            for _ in range(n_out_bufs)]
+    placement_note = None
+    try:
+        bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed, placement=placement, pitch=pitch)
+                for _ in range(n_out_bufs)]
+    except RuntimeError as exc:
+        if placement != "arena":
+            raise
+        # no placement control on this device / driver: the run still measures the march, on arrays from the
+        # torch allocator, and says so
+        placement_note = "arena unavailable (%s): path arrays from the torch allocator" % exc
+        print("bench.py: " + placement_note, file=sys.stderr)
+        placement = "torch"
+        bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed, placement=placement, pitch=pitch)
+                for _ in range(n_out_bufs)]
     arena_obj = placed.PlacedArena.for_device(local_rank) if placement == "arena" else None
     input_kind = arena_obj.kind_of(x0) if arena_obj is not None else None
     host_staged = (args.backend == "gloo")
@@ -494,7 +506,7 @@ def main():
                        "masks": ("valid | valid_out << 1 in one byte" if packed else "two byte arrays"),
                        "sharding": "rays" if n_gpus > 1 else "none",
                        "wavelengths": len(sysds), "prewarm_launches": PREWARM_LAUNCHES,
-                       "output_placement": {"policy": bufs[0]["placement"]["policy"],
+                       "output_placement": {"policy": bufs[0]["placement"]["policy"], "note": placement_note,
                                             "memory_kinds_of_x_hit_and_k_out": bufs[0]["placement"].get("kinds"),
                                             "memory_kind_of_inputs": input_kind,
                                             "inputs": "arena" if input_kind is not None else "torch allocator",
