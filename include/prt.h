@@ -425,6 +425,10 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
  *                     its stream wait for that event.  The buffer stays mapped and serves the next
  *                     request of the same size and kind without any driver call.
  *   prt_arena_trim    hands all cached (unused) memory back to the driver.
+ *   prt_arena_set_budget  caps the physical memory the arena may hold at any time, in 1-GiB slabs (in use +
+ *                     cached + free + the representatives; negative = no cap, the default).  At the cap a
+ *                     request behaves as if the driver had nothing left: cached buffers of other sizes are
+ *                     taken apart, fewer kinds are accepted, or PRT_ERR_NOMEM.
  *   prt_arena_kind_of kind index of a pointer inside one of the arena's buffers.
  *   prt_arena_stats   out[0..12): kinds seen, probes run, slabs created, slabs released, free slabs,
  *                     slabs in use, slabs cached, slab size in bytes, slabs per kind (4 entries);
@@ -444,6 +448,7 @@ int32_t prt_arena_alloc(prt_arena_t *arena, int32_t n_parts, const int64_t *byte
                         void *stream);
 int32_t prt_arena_free(prt_arena_t *arena, void *ptr, void *stream);
 int32_t prt_arena_trim(prt_arena_t *arena);
+int32_t prt_arena_set_budget(prt_arena_t *arena, int64_t max_live_slabs);
 int32_t prt_arena_kind_of(prt_arena_t *arena, const void *ptr, int32_t *kind);
 int32_t prt_arena_stats(prt_arena_t *arena, int64_t *out, int32_t n_out, double *rates, int32_t n_rates);
 

@@ -142,6 +142,7 @@ PROTOTYPES["prt_arena_alloc"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int3
                                                  ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_stream])
 PROTOTYPES["prt_arena_free"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, c_stream])
 PROTOTYPES["prt_arena_trim"] = (ctypes.c_int32, [ctypes.c_void_p])
+PROTOTYPES["prt_arena_set_budget"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64])
 PROTOTYPES["prt_arena_kind_of"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)])
 PROTOTYPES["prt_arena_stats"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int32,
                                                  ctypes.POINTER(ctypes.c_double), ctypes.c_int32])

@@ -72,6 +72,7 @@ struct prt_arena {
     int32_t last_kind = 0;         // kind of the previous slab: slabs come in long runs of one kind
     double self_rate = 0.0;        // yardstick of the current hunt: a slab against itself, GB/s
     int64_t va_reserved = 0;       // bytes of address space taken so far (never returned, see above)
+    int64_t slab_budget = -1;      // cap on the slabs held at any time (created - released); < 0: none
     std::vector<prt_slab> free_slabs;
     std::vector<prt_placed_buffer *> buffers;      // in use and cached
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -163,6 +164,7 @@ static hipError_t arena_new_slab(prt_arena *a, hipStream_t st, prt_slab *out, bo
     hipError_t e = hipMemGetInfo(&free_b, &total_b);
     if (e != hipSuccess) return e;
     if (free_b < 3 * PRT_SLAB_BYTES) return hipErrorOutOfMemory;      // leave the last GiBs to others
+    if (a->slab_budget >= 0 && a->n_created - a->n_released >= a->slab_budget) return hipErrorOutOfMemory;
     prt_slab s;
     s.kind = -1;
     if ((e = hipMemCreate(&s.handle, PRT_SLAB_BYTES, &a->prop, 0)) != hipSuccess) return e;
@@ -313,6 +315,13 @@ int32_t prt_arena_trim(prt_arena_t *a) {
     }
     for (const prt_slab &s : a->free_slabs) arena_release_slab(a, s);
     a->free_slabs.clear();
+    return PRT_OK;
+}
+
+int32_t prt_arena_set_budget(prt_arena_t *a, int64_t max_live_slabs) {
+    if (!a) return fail(PRT_ERR_INVALID_ARG, "prt_arena_set_budget: null arena");
+    std::lock_guard<std::mutex> lock(a->mu);
+    a->slab_budget = max_live_slabs;
     return PRT_OK;
 }
 

@@ -209,6 +209,10 @@ class PlacedArena(object):
     def trim(self):
         _lib.check(self.lib.prt_arena_trim(self._h))
 
+    def set_budget(self, max_live_slabs):
+        """cap on the 1-GiB slabs the arena holds at any time (None / negative: no cap)"""
+        _lib.check(self.lib.prt_arena_set_budget(self._h, -1 if max_live_slabs is None else int(max_live_slabs)))
+
     def stats(self):
         v = (ctypes.c_int64 * 12)()
         r = (ctypes.c_double * 4)()
