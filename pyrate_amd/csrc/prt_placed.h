@@ -163,7 +163,10 @@ static hipError_t arena_new_slab(prt_arena *a, hipStream_t st, prt_slab *out, bo
     size_t free_b = 0, total_b = 0;
     hipError_t e = hipMemGetInfo(&free_b, &total_b);
     if (e != hipSuccess) return e;
-    if (free_b < 3 * PRT_SLAB_BYTES) return hipErrorOutOfMemory;      // leave the last GiBs to others
+    // Leave the last GiBs alone: a hunt for a far-away kind holds everything it has walked through, and a
+    // device with (almost) nothing free is where the runtime's own allocations start to fail -- once, with
+    // ~3 GiB left, a HIP call aborted the process instead of returning an error.
+    if (free_b < 12 * PRT_SLAB_BYTES) return hipErrorOutOfMemory;
     if (a->slab_budget >= 0 && a->n_created - a->n_released >= a->slab_budget) return hipErrorOutOfMemory;
     prt_slab s;
     s.kind = -1;
