@@ -494,6 +494,13 @@ def main():
                 roofline = dict(hbm, note="FP64-VALU bound kernel; no flop count on file for this size "
                                           "(profiles/fp64_flops.json), HBM fraction shown")
         arena_stats = arena_obj.stats() if arena_obj is not None else None
+        kinds_out = bufs[0]["placement"].get("kinds")
+        if placement_note is None and kinds_out and len(set(kinds_out[:2])) < 2:
+            placement_note = ("x_hit and k_out share a kind of HBM (the arena found no second kind within its "
+                              "hunt): expect the 5.6 TB/s regime of same-kind write streams")
+        elif placement_note is None and arena_obj is not None and iso and input_kind is not None \
+                and kinds_out and input_kind in kinds_out[:2]:
+            placement_note = "the inputs share a kind of HBM with a path array (no third kind found): about 5 % slower"
         out = {
             "metric": "ray_surface_ops_per_s", "value": value, "unit": "ray-surface-ops/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
