@@ -221,6 +221,11 @@ def main():
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    try:        # no core file of a process with hundreds of GiB of device memory mapped
+        import resource
+        resource.setrlimit(resource.RLIMIT_CORE, (0, resource.getrlimit(resource.RLIMIT_CORE)[1]))
+    except (ImportError, ValueError, OSError):
+        pass
     if os.environ.get("PRT_BENCH_WATCHDOG"):
         # debugging aid: dump every thread's stack to stderr and exit if the run takes longer than this
         import faulthandler

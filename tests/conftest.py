@@ -11,6 +11,13 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A process that has hundreds of GiB of device memory mapped must not write a core file if it ever dies:
+    # once a crash inside the HIP runtime filled the box's disk that way and took the following run with it.
+    try:
+        import resource
+        resource.setrlimit(resource.RLIMIT_CORE, (0, resource.getrlimit(resource.RLIMIT_CORE)[1]))
+    except (ImportError, ValueError, OSError):
+        pass
 
 
 @pytest.fixture(scope="session")
