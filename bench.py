@@ -5,16 +5,28 @@ bench.py -- ray-surface-ops/s of the sequential-raytrace hot path on MI355X.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of OpticalSystem.seqtrace over one bundle.  Default workload:
+One "step" = one pass of OpticalSystem.seqtrace over one bundle.  Headline workload:
 BASELINE.json configs[1], the 12-surface Rudolph double Gauss (12 spherical Conic
 surfaces, ConstantIndexGlass d-line indices), ~1e7 rays PER GPU (RectGrid disk
 raster, collimated on-axis), float64, full path materialised (hit point, outgoing
 wave vector and validity at every surface written to HBM).  Inputs are resident in
-HBM before the timed region.  ``--config asphere`` / ``--config aniso`` run
-configs[2] (even asphere, Newton intersection, 1e7 rays) and configs[3]
-(anisotropic doublet, 1e6 -> 4e6 rays) under the same contract.  The path arrays
-come from the engine's placement-aware arena (x_hit and k_out in two different
-kinds of HBM) -- the allocation the product path uses, no scan.
+HBM before the timed region.  BASELINE's bundles are collimated: k0 and E0 are one
+vector for the whole bundle and travel as such (prt_trace_ex, uniform first
+segment: the march reads only x0; ``--first-segment arrays`` feeds per-ray arrays).
+The path arrays come from the engine's placement-aware arena (x_hit and k_out in
+two different kinds of HBM) -- the allocation the product path
+uses, no scan.
+
+At N = 1 the default run then measures the other single-GPU configurations under
+the same contract (``configs`` on the same JSON line, each with its own roofline
+and cpu_baseline): configs[2] (even asphere, Newton intersection, 1e7 rays),
+configs[3] (anisotropic doublet, 1e6 -> 4e6 rays) and an XY-polynomial system
+(demo_asphere geometry, 12-term XYPolynomials, 1e7 rays).  ``--config X`` makes X
+the headline and measures X alone.  HBM traffic (roofline.traffic) is measured in
+the same run: the script re-runs the marches under ``rocprofv3 --kernel-trace
+--pmc`` (FETCH_SIZE, WRITE_SIZE and the FP64 instruction counters in separate
+passes) and falls back to the figures on file (profiles/*.json) when rocprofv3 is
+not available.
 
 For N > 1 (configs[4]) the bundle of N x 1.25e7 rays is sharded by rays (weak
 scaling, no collective in the trace) and the five prescription wavelengths are
@@ -23,6 +35,8 @@ cycled over the steps; every step ends with that wavelength's spot statistics (o
 on a side stream so that they overlap the next wavelength's trace (two sets of
 path arrays); the timed region ends when everything has completed.  The rate of
 the same steps without the gather is measured right after and reported beside it.
+A watchdog (N > 1: on by default) prints a JSON line with an ``error`` field
+instead of hanging.
 
 metric: ray-surface-ops/s = rays x surfaces / seconds (the reference's own
 definition, demos/demo_benchmark.py:82-85).
@@ -30,10 +44,17 @@ definition, demos/demo_benchmark.py:82-85).
 Prints ONE JSON line (rank 0).
 """
 import argparse
+import csv
 import ctypes
+import glob
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -45,70 +66,175 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz (SURVEY.md 8d)
 PREWARM_LAUNCHES = 30
+SINGLE_GPU_CONFIGS = ("doublegauss", "asphere", "aniso", "xypoly")
+T_START = time.perf_counter()
 
 
-def algorithmic_bytes(n_rays, n_surfaces, with_e0=True, record_bytes=49):
-    """HBM bytes the fused path-mode march must move per launch:
-    read x0, k0 (+E0) once: 48 (+24) B/ray; write per surface x_hit 24 + k_out 24 + one byte holding
-    both masks (valid | valid_out << 1) = 49 B/ray -- SURVEY 8d's ray-surface record -- or 50 B with
-    the masks in two separate arrays."""
-    return n_rays * ((72 if with_e0 else 48) + record_bytes * n_surfaces)
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def make_workload(config, rays, dev, n_gpus=1, rank=0, multi=False, first_segment="uniform"):
+    """records + the device-resident input bundle of one BASELINE configuration.  Every bundle is the
+    RectGrid disk raster of the reference, collimated, generated on the device (bit-identical to the host
+    raster); rank r owns a contiguous, equal-stride slice of it (pdist.shard_range)."""
+    from pyrate_amd import engine, systems
+    from pyrate_amd import distributed as pdist
+    record_sets = None
+    if config == "doublegauss":
+        # N = 1: BASELINE configs[1] (d line).  N > 1: configs[4] -- the same lens at the five
+        # wavelengths of the prescription (spd:5), per-wavelength indices from the Conrady fit
+        # through the (d, F, C) indices; step i traces wavelength i % 5.
+        records = systems.double_gauss_records()
+        if multi:
+            record_sets = [systems.double_gauss_records(w) for w in systems.DOUBLE_GAUSS_WAVES_MM]
+        bundle = dict()
+        workload = (("demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 double Gauss, "
+                     "ConstantIndexGlass d-line), RectGrid disk bundle, BASELINE configs[1]") if not multi else
+                    ("demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 double Gauss), 5 wavelengths "
+                     "cycled (Conrady indices), RectGrid disk bundle ray-sharded over the GPUs (1.25e7 rays per "
+                     "GPU: the 1e8-ray bundle at 8 GPUs), BASELINE configs[4]"))
+    elif config == "asphere":
+        # configs[2]: demo_asphere.py geometry (stop, plane front, even asphere back, image) with the
+        # test-suite coefficient set (tests/test_surf_shape.py:115-127) scaled to stay in-domain, bundle
+        # radius 9, 5 degree field: the Newton iteration count varies over the wavefront
+        records = systems.asphere_records(coefficients=(1e-3, -1e-6, 1e-8), curv=-1. / 30., cc=-1.5)
+        bundle = dict(rpup=9.0, z0=-5.0, field_deg=5.0)
+        workload = ("demo_asphere: stop, plane, even asphere (curv -1/30, cc -1.5, A2..A6 = 1e-3, -1e-6, 1e-8; "
+                    "Newton intersection), image; RectGrid disk bundle r = 9 mm at 5 deg, BASELINE configs[2]")
+    elif config == "xypoly":
+        # the XYPolynomials shape of BASELINE's north_star on the geometry of configs[2]
+        records = systems.xypoly_records()
+        bundle = dict(rpup=9.0, z0=-5.0, field_deg=5.0)
+        workload = ("demo_asphere geometry with an XYPolynomials back surface (12 terms up to degree 4: paraboloid "
+                    "-r^2/60 + small terms of every order; Newton intersection); RectGrid disk bundle r = 9 mm at "
+                    "5 deg -- the XY-polynomial companion of BASELINE configs[2]")
+    elif config == "aniso":
+        c = systems.CALCITE_TILTED
+        records = systems.aniso_doublet_records(
+            systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"]),
+            systems.uniaxial_eps(1.6727, 1.60, (np.sin(0.2), 0.0, np.cos(0.2))))
+        bundle = dict(rpup=11.43, z0=-5.0)
+        workload = ("demo_anisotropic_doublet: cemented doublet of two uniaxial crystals (calcite-like, tilted "
+                    "axes), k-vector solve + ray doubling at two interfaces (1 -> 2 -> 4 rays), RectGrid disk "
+                    "bundle r = 11.43 mm, BASELINE configs[3]")
+    else:
+        raise ValueError(config)
+    (_, n_total) = engine.rect_grid_count(rays * n_gpus, dev)
+    (lo, hi) = pdist.shard_range(n_total, rank, n_gpus)
+    uniform = first_segment == "uniform"
+    (x0, k0, e0, _) = systems.double_gauss_bundle_device(rays * n_gpus, dev, lo=lo, hi=hi, uniform=uniform, **bundle)
+    uni = None
+    if uniform:
+        (uni, k0, e0) = (k0, None, None)
+    if config == "aniso":            # the crystal march takes tight arrays
+        (x0, k0, e0) = [None if t is None else t.contiguous() for t in (x0, k0, e0)]
+    return dict(config=config, records=records, record_sets=record_sets or [records], x0=x0, k0=k0, e0=e0,
+                uniform=uni, n_total=n_total, n_local=hi - lo, lo=lo, hi=hi, S=len(records), workload=workload,
+                bundle=bundle, first_segment=first_segment)
 
 
-def cpu_baseline(records, o, k, e0, n_all=None, chunk=100_000):
+def host_bundle(wl, m):
+    """the first m rays of a workload's bundle as host arrays (x0, k0, E0) for the CPU baselines"""
+    m = min(m, wl["n_local"])
+    x = wl["x0"][:, :m].cpu().numpy()
+    if wl["uniform"] is not None:
+        k = np.repeat(np.array(wl["uniform"].k)[:, None], m, axis=1)
+        e = np.repeat(np.array(wl["uniform"].e_re)[:, None], m, axis=1)
+    else:
+        (k, e) = (wl["k0"][:, :m].cpu().numpy(), wl["e0"][:, :m].cpu().numpy())
+    return np.ascontiguousarray(x), np.ascontiguousarray(k), np.ascontiguousarray(e)
+
+
+def input_bytes_per_ray(wl):
+    """x0 24 B (+ k0 24 B + E0 24 B when the first segment travels as arrays)"""
+    return 24 if wl["uniform"] is not None else 72
+
+
+def algorithmic_bytes(wl, sysd, mode, record_bytes):
+    """HBM bytes one launch of the fused march must move: the inputs once; per surface
+    x_hit 24 B + k_out 24 B + one byte holding both masks (SURVEY 8d's 49-B ray-surface record; 50 B with the
+    masks in two arrays).  Tables with crystals (concatenated layout, real k): per surface x_hit 24 B + mask
+    1 B per entering ray and k_out 24 B + mask 1 B per leaving ray (crystal interfaces double the rays)."""
+    n = wl["n_local"]
+    read = input_bytes_per_ray(wl) * n
+    if not sysd.all_isotropic:
+        (n_in, n_out) = sysd.ray_counts(n)
+        return read + (25 * (sum(n_in) + sum(n_out)) if mode == "path" else 25 * (n_in[-1] + n_out[-1]))
+    return read + n * record_bytes * (wl["S"] if mode == "path" else 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (test oracles timed on the GPU box's host cores; reported, not the target)
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(wl, budget_s=4.0, with_numpy=True):
     """CPU restatements of the reference algorithm (test oracles, geometry only -- i.e. WITHOUT
     the reference's SVD E-field step that is 91% of its time) on a bounded sample of the same
     workload, timed on this box's host cores:
-      value: C / OpenMP port (oracle/seqtrace_c.c) on all host threads
+      value: C / OpenMP port (oracle/seqtrace_c.c) on the best of a few thread counts
       numpy_single_core: the NumPy port (oracle/seqtrace_np.py), one process
-      with_svd_efield: NumPy port incl. the SVD E-field step, the reference's true cost profile"""
+      with_svd_efield: NumPy port incl. the SVD E-field step, the reference's true cost profile (headline only)"""
     from oracle import seqtrace_np as oracle
     from oracle import seqtrace_c
-    S = len(records)
+    records = wl["records"]
+    S = wl["S"]
+    out = {"unit": "ray-surface-ops/s", "host_cpus": os.cpu_count()}
+    m_c = {"doublegauss": 4_000_000, "asphere": 4_000_000, "xypoly": 4_000_000, "aniso": 500_000}[wl["config"]]
+    (o, k, e0) = host_bundle(wl, m_c)
     n = o.shape[1]
-    ws = seqtrace_c.Workspace(S, n)                   # outputs allocated and touched once
-    seqtrace_c.trace_arrays(records, o, k, e0, workspace=ws)                            # warm-up
-    # the port is memory bound on the host; pick the best of a few thread counts, then time it
-    nmax = seqtrace_c.load().seqtrace_c_threads()
-    best = (None, 0.0)
-    for nt in sorted(set(max(1, nmax // q) for q in (1, 2, 4, 8))):
+    if seqtrace_c.supports(records):
+        ws = seqtrace_c.Workspace(records, n)               # outputs allocated and touched once
+        seqtrace_c.trace_arrays(records, o, k, e0, workspace=ws)                            # warm-up
+        # the port is memory bound on the host; pick the best of a few thread counts, then time it
+        nmax = seqtrace_c.load().seqtrace_c_threads()
+        best = (None, 0.0)
+        for nt in sorted(set(max(1, nmax // q) for q in (1, 2, 4, 8))):
+            t0 = time.perf_counter()
+            seqtrace_c.trace_arrays(records, o, k, e0, nthreads=nt, workspace=ws)
+            rate = n * S / (time.perf_counter() - t0)
+            if rate > best[1]:
+                best = (nt, rate)
+        reps = 0
         t0 = time.perf_counter()
-        seqtrace_c.trace_arrays(records, o, k, e0, nthreads=nt, workspace=ws)
-        rate = n * S / (time.perf_counter() - t0)
-        if rate > best[1]:
-            best = (nt, rate)
-    reps = 0
-    t0 = time.perf_counter()
-    while True:
-        (_, _, _, _, used) = seqtrace_c.trace_arrays(records, o, k, e0, nthreads=best[0], workspace=ws)
-        reps += 1
-        dt_c = time.perf_counter() - t0
-        if dt_c > 5.0 or reps >= 30:
-            break
-    m_np = min(n, 1_000_000)
-    t1 = time.perf_counter()
-    done = 0
-    with np.errstate(all="ignore"):
-        while done < m_np:
-            hi = min(done + chunk, m_np)
-            oracle.trace(records, o[:, done:hi], k[:, done:hi], e0[:, done:hi])
-            done = hi
-    dt_np = time.perf_counter() - t1
-    m_e = min(n, 50_000)
-    t2 = time.perf_counter()
-    with np.errstate(all="ignore"):
-        oracle.trace(records, o[:, :m_e], k[:, :m_e], e0[:, :m_e], with_efield=True)
-    dt_e = time.perf_counter() - t2
-    return {"value": reps * n * S / dt_c, "unit": "ray-surface-ops/s", "cores": used, "kind": "port",
-            "sample": "C/OpenMP oracle: %d x (first %d of the %d rays x %d surfaces, path written to "
-                      "host RAM), %.1f s" % (reps, n, n_all or n, S, dt_c),
-            "numpy_single_core": {"value": m_np * S / dt_np, "sample": "%d rays in chunks of %d, %.1f s"
-                                  % (m_np, chunk, dt_np)},
-            "with_svd_efield": {"value": m_e * S / dt_e, "sample": "%d rays, %.1f s" % (m_e, dt_e)},
-            "host_cpus": os.cpu_count()}
+        while True:
+            used = seqtrace_c.trace_arrays(records, o, k, e0, nthreads=best[0], workspace=ws)[-1]
+            reps += 1
+            dt_c = time.perf_counter() - t0
+            if dt_c > budget_s or reps >= 30:
+                break
+        out.update({"value": reps * n * S / dt_c, "cores": used, "kind": "port",
+                    "sample": "C/OpenMP oracle (oracle/seqtrace_c.c): %d x (first %d of the %d rays x %d surfaces, "
+                              "path written to host RAM), %.1f s" % (reps, n, wl["n_local"], S, dt_c)})
+    if with_numpy or "value" not in out:
+        m_np = min(n, {"aniso": 20_000}.get(wl["config"], 500_000))
+        t1 = time.perf_counter()
+        done = 0
+        with np.errstate(all="ignore"):
+            while done < m_np:
+                hi = min(done + 100_000, m_np)
+                oracle.trace(records, o[:, done:hi], k[:, done:hi], e0[:, done:hi])
+                done = hi
+        dt_np = time.perf_counter() - t1
+        npy = {"value": m_np * S / dt_np, "sample": "NumPy oracle (oracle/seqtrace_np.py), first %d rays in chunks "
+                                                    "of 100000, one process, %.1f s" % (m_np, dt_np)}
+        if "value" in out:
+            out["numpy_single_core"] = npy
+        else:
+            out.update(npy, cores=1, kind="port")
+    if wl["config"] == "doublegauss" and with_numpy:
+        m_e = min(n, 50_000)
+        t2 = time.perf_counter()
+        with np.errstate(all="ignore"):
+            oracle.trace(records, o[:, :m_e], k[:, :m_e], e0[:, :m_e], with_efield=True)
+        dt_e = time.perf_counter() - t2
+        out["with_svd_efield"] = {"value": m_e * S / dt_e, "sample": "%d rays, %.1f s" % (m_e, dt_e)}
+    return out
 
 
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
 def _flush_c_stdio():
     try:
         ctypes.CDLL(None).fflush(None)
@@ -124,12 +250,9 @@ def _stdout_of_other_ranks_to_stderr():
         os.dup2(2, 1)
 
 
-FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz (SURVEY.md 8d)
-
-
 def _lookup(fname, key):
     """a per-launch figure measured by rocprofv3 PMC passes of an EARLIER run of the same workload
-    (benchmarks/hbm_traffic.py, benchmarks/valu_profile.py) -- looked up, not measured in this run"""
+    (benchmarks/collect_profiles.sh) -- looked up, not measured in this run"""
     path = os.path.join(ROOT, "profiles", fname)
     try:
         with open(path) as f:
@@ -138,20 +261,301 @@ def _lookup(fname, key):
         return None
 
 
-def cpu_baseline_numpy(records, o, k, e0, m, n_all):
-    """configs the C port does not cover (explicit shapes, crystals): the NumPy oracle on the first m rays"""
-    from oracle import seqtrace_np as oracle
-    m = min(m, o.shape[1])
+def alloc_outputs_or_torch(sysd, n_local, mode, packed, placement, pitch, count=1):
+    """the path arrays of a run: from the arena (the product path's allocation for arrays of this size) or,
+    where the device / driver offers no placement control, from the torch allocator -- and says so"""
+    note = None
+    try:
+        bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed, placement=placement, pitch=pitch)
+                for _ in range(count)]
+    except RuntimeError as exc:
+        if placement != "arena":
+            raise
+        note = "arena unavailable (%s): path arrays from the torch allocator" % exc
+        print("bench.py: " + note, file=sys.stderr)
+        placement = "torch"
+        bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed, placement=placement, pitch=pitch)
+                for _ in range(count)]
+    return bufs, placement, note
+
+
+def kernel_label(config):
+    return "k_trace_general" if config == "aniso" else "k_trace_iso"
+
+
+# ------------------------------------------------------------------------------------------------
+# one single-GPU configuration: K timed steps + kernel time + roofline (+ CPU baseline)
+# ------------------------------------------------------------------------------------------------
+def measure_single(config, args, dev, rays, with_cpu):
+    from pyrate_amd import engine, placed, _lib
+    wl = make_workload(config, rays, dev, first_segment=args.first_segment)
+    sysd = engine.DeviceSystem(wl["records"], dev.index)
+    iso = sysd.all_isotropic
+    mode = _lib.MODE_PATH if args.mode == "path" else _lib.MODE_IMAGE
+    packed = iso and not args.two_mask_arrays
+    record_bytes = 49 if packed else 50
+    placement = args.placement if mode == _lib.MODE_PATH else "torch"
+    (x0, k0, e0, uni, n_local) = (wl["x0"], wl["k0"], wl["e0"], wl["uniform"], wl["n_local"])
+    if args.inputs == "torch" and iso:
+        # A/B: the inputs in torch-allocated arrays instead of arena memory of a third kind
+        moved = []
+        for t in (x0, k0, e0):
+            if t is None:
+                moved.append(None)
+                continue
+            buf = torch.empty((3, t.stride(0)), dtype=torch.float64, device=dev)[:, :n_local]
+            buf.copy_(t)
+            moved.append(buf)
+        (x0, k0, e0) = moved
+        torch.cuda.synchronize()
+    pitch = engine.recommended_pitch(n_local) if iso else None
+    (bufs, placement, placement_note) = alloc_outputs_or_torch(sysd, n_local, mode, packed, placement, pitch)
+    ob = bufs[0]
+    arena_obj = placed.PlacedArena.for_device(dev.index) if placement == "arena" else None
+    input_kind = arena_obj.kind_of(x0) if arena_obj is not None else None
+
+    def launch():
+        sysd.trace_into(x0, k0, ob, e0, uniform=uni)
+
+    # device wake-up (not one of the W warm-up steps): after idle the first ~25 ms of launches run at ramping
+    # clocks; 30 plain launches of the same kernel bring the chip to its steady state before anything is counted
+    for _ in range(PREWARM_LAUNCHES):
+        launch()
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        launch()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    with np.errstate(all="ignore"):
-        oracle.trace(records, o[:, :m], k[:, :m], e0[:, :m])
-    dt = time.perf_counter() - t0
-    return {"value": m * len(records) / dt, "unit": "ray-surface-ops/s", "cores": 1, "kind": "port",
-            "sample": "NumPy oracle (oracle/seqtrace_np.py), first %d of %d rays x %d surfaces, %.1f s"
-                      % (m, n_all, len(records), dt),
-            "host_cpus": os.cpu_count()}
+    for _ in range(args.steps):
+        launch()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # dominant kernel: average launch duration from HIP events on the launch stream
+    kernel_ms = sysd.trace_timed(x0, k0, ob, max(args.steps, 5), e0, uniform=uni)
+    torch.cuda.synchronize()
+
+    S = wl["S"]
+    alg = algorithmic_bytes(wl, sysd, args.mode, record_bytes)
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": None, "traffic_source": None, "kernel": kernel_label(config), "kernel_ms": kernel_ms,
+           "algorithmic_bytes_per_launch": alg, "bytes_per_ray_surface_op": alg / (n_local * S)}
+    if config == "doublegauss" and args.mode == "path":
+        hbm["frac_at_98B_per_op_convention"] = (n_local * S * 98 / (kernel_ms * 1e-3) / 1e9) / HBM_PEAK_GBS
+    kinds_out = ob["placement"].get("kinds")
+    if placement_note is None and kinds_out and len(set(kinds_out[:2])) < 2:
+        placement_note = ("x_hit and k_out share a kind of HBM (the arena found no second kind within its "
+                          "hunt): expect the 5.6 TB/s regime of same-kind write streams")
+    elif placement_note is None and arena_obj is not None and iso and input_kind is not None \
+            and kinds_out and input_kind in kinds_out[:2]:
+        placement_note = "the inputs share a kind of HBM with a path array (no third kind found): about 5 % slower"
+    (n_in, n_out) = sysd.ray_counts(n_local)
+    rec = {"name": config, "workload": wl["workload"], "value": n_local * S * args.steps / elapsed,
+           "unit": "ray-surface-ops/s", "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "dtype": "f64",
+           "rays": n_local, "surfaces": S, "mode": args.mode,
+           "rays_per_surface": None if iso else {"entering": n_in, "leaving": n_out},
+           "first_segment": ("uniform k0 / E0 (collimated bundle: one vector each, 24 B/ray of loads)"
+                             if uni is not None else "arrays x0, k0, E0 (72 B/ray of loads)"),
+           "record_bytes": record_bytes if iso else 25,
+           "masks": ("valid | valid_out << 1 in one byte" if packed else "two byte arrays"),
+           "output_placement": {"policy": ob["placement"]["policy"], "note": placement_note,
+                                "memory_kinds_of_x_hit_and_k_out": kinds_out,
+                                "memory_kind_of_inputs": input_kind,
+                                "inputs": "arena" if input_kind is not None else "torch allocator"},
+           "roofline": hbm, "cpu_baseline": None, "_iso": iso, "_alg": alg, "_n_local": n_local}
+    if with_cpu:
+        rec["cpu_baseline"] = cpu_baseline(wl, budget_s=args.cpu_budget, with_numpy=(config == args.config))
+    del bufs, ob, x0, k0, e0
+    return rec
 
 
+def finish_roofline(rec, traffic, flops, lookup=True):
+    """fill roofline.traffic (+ the FP64 roof of the crystal march) from the live PMC passes or the files"""
+    hbm = rec["roofline"]
+    live = (traffic or {}).get(rec["name"])
+    if live and live.get("bytes_per_launch"):
+        hbm["traffic"] = live["bytes_per_launch"]
+        hbm["traffic_ratio_to_algorithmic"] = live["bytes_per_launch"] / rec["_alg"]
+        hbm["traffic_source"] = live["source"]
+    elif lookup:
+        fkey = ("%s_%d_uniform" if rec["first_segment"].startswith("uniform") else "%s_%d") \
+            % (rec["mode"], rec["_n_local"])
+        if rec["name"] != "doublegauss":
+            fkey = rec["name"] + "_" + fkey
+        tent = _lookup("hbm_traffic.json", fkey)
+        if tent:
+            hbm["traffic"] = tent["bytes_per_launch"]
+            hbm["traffic_source"] = ("profiles/hbm_traffic.json[%s]: rocprofv3 PMC passes of an earlier run of this "
+                                     "workload, looked up by ray count -- NOT measured in this run%s"
+                                     % (fkey, "" if not traffic else " (" + str(traffic.get("error")) + ")"))
+    if not rec["_iso"]:
+        # crystal march: FP64-VALU bound (SURVEY.md 8d) -- flops per launch from SQ instruction counters,
+        # HBM as the secondary roof
+        fl = (flops or {}).get(rec["name"])
+        src = None
+        if fl and fl.get("flops_per_launch"):
+            (fpl, valu, src) = (fl["flops_per_launch"], fl.get("valu_wave_instructions"), fl["source"])
+        else:
+            fent = _lookup("fp64_flops.json", "%s_%s_%d" % (rec["name"], rec["mode"], rec["_n_local"]))
+            (fpl, valu) = (None, None)
+            if fent:
+                fpl = fent["flops_per_launch"]
+                valu = fent.get("counters", {}).get("SQ_INSTS_VALU")
+                src = ("profiles/fp64_flops.json: SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 of an earlier PMC run of "
+                       "this workload (2 flop per FMA, 64 lanes per wave instruction), looked up -- NOT measured "
+                       "in this run")
+        if fpl:
+            ms = hbm["kernel_ms"]
+            tf = fpl / (ms * 1e-3) / 1e12
+            rec["roofline"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": hbm["traffic"],
+                               "flops_per_launch": fpl, "flops_source": src, "kernel": hbm["kernel"],
+                               "kernel_ms": ms, "secondary": hbm,
+                               # all VALU wave instructions (selects, compares, address arithmetic included) at one
+                               # per 4 cycles and SIMD against the 1024 SIMDs at 2.4 GHz: what the kernel is bound by
+                               "valu_issue_frac": (valu * 4.0 / (1024 * 2.4e9) / (ms * 1e-3)) if valu else None}
+        else:
+            hbm["note"] = "FP64-VALU bound kernel; no flop count available, HBM fraction shown"
+    for k in [k for k in rec if k.startswith("_")]:
+        del rec[k]
+    return rec
+
+
+# ------------------------------------------------------------------------------------------------
+# live PMC: the marches re-run under rocprofv3 (separate --pmc passes, kernel trace only)
+# ------------------------------------------------------------------------------------------------
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64",
+               "SQ_INSTS_VALU"))
+PMC_LAUNCHES = 6
+
+
+def pmc_inner(args, dev):
+    """what runs under rocprofv3: every requested config's march, a few launches each, nothing else timed"""
+    from pyrate_amd import engine, _lib
+    for config in args.pmc_inner.split(","):
+        wl = make_workload(config, args.rays_of[config], dev, first_segment=args.first_segment)
+        sysd = engine.DeviceSystem(wl["records"], dev.index)
+        iso = sysd.all_isotropic
+        packed = iso and not args.two_mask_arrays
+        mode = _lib.MODE_PATH if args.mode == "path" else _lib.MODE_IMAGE
+        # (placement does not change the bytes a launch moves: plain torch arrays, no arena hunt under the profiler)
+        ob = sysd.alloc_outputs(wl["n_local"], mode, packed_flags=packed, placement="torch",
+                                pitch=engine.recommended_pitch(wl["n_local"]) if iso else None)
+        for _ in range(PMC_LAUNCHES):
+            sysd.trace_into(wl["x0"], wl["k0"], ob, wl["e0"], uniform=wl["uniform"])
+        torch.cuda.synchronize()
+        del ob, wl, sysd
+        torch.cuda.empty_cache()
+
+
+def _pmc_config_of(kernel_name):
+    """which bench config a march launch belongs to, from its instantiation: k_trace_general -> aniso;
+    k_trace_iso<MODE, VEC_IN, VEC_OUT, SHAPES, ...> with SHAPES 0 / 1 / 2 -> doublegauss / asphere / xypoly"""
+    if "k_trace_general<" in kernel_name:
+        return "aniso"
+    m = re.search(r"k_trace_iso<\s*\d+\s*,\s*\w+\s*,\s*\w+\s*,\s*(\d+)", kernel_name)
+    if m:
+        return {0: "doublegauss", 1: "asphere", 2: "xypoly"}.get(int(m.group(1)))
+    return None
+
+
+def measure_pmc_live(configs, args, rays_of, timeout_s):
+    """(traffic, flops): per config the HBM bytes and FP64 flops of one launch, from rocprofv3 PMC passes over
+    this script's --pmc-inner mode, collected and corrected as MI355X_MICROARCH.md 'HBM' prescribes (separate
+    passes; counters in KiB; FETCH_SIZE doubled on gfx950 for 16 B/lane coalesced reads; WRITE_SIZE as reported)."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {"error": "rocprofv3 not found"}, {}
+    tmp = tempfile.mkdtemp(prefix="prt_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    sums = {}
+    t_end = time.perf_counter() + timeout_s
+    try:
+        for (p, counters) in enumerate(PMC_PASSES):
+            left = t_end - time.perf_counter()
+            if left < 10:
+                return {"error": "PMC passes ran out of their time budget (%d s)" % timeout_s}, {}
+            out_dir = os.path.join(tmp, "pass%d" % p)
+            cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out_dir, "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-inner", ",".join(configs),
+                   "--rays-of", json.dumps(rays_of), "--first-segment", args.first_segment, "--mode", args.mode] + \
+                  (["--two-mask-arrays"] if args.two_mask_arrays else [])
+            res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left)
+            if res.returncode != 0:
+                return {"error": "rocprofv3 pass %s failed (rc %d): %s"
+                                 % ("+".join(counters), res.returncode, res.stderr.decode(errors="replace")[-300:])}, {}
+            for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                with open(path, newline="") as fh:
+                    for row in csv.DictReader(fh):
+                        cfg = _pmc_config_of(row.get("Kernel_Name", ""))
+                        if cfg in configs:
+                            sums.setdefault((cfg, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+    except (subprocess.TimeoutExpired, OSError) as exc:
+        return {"error": "rocprofv3 PMC passes: %s" % exc}, {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic, flops = {}, {}
+    for cfg in configs:
+        def avg(name):
+            v = sums.get((cfg, name))
+            return (sum(v) / len(v), len(v)) if v else (None, 0)
+        (f, nf) = avg("FETCH_SIZE")
+        (w, nw) = avg("WRITE_SIZE")
+        if f is not None and w is not None:
+            traffic[cfg] = {"bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0, "fetch_bytes": 2.0 * f * 1024.0,
+                            "write_bytes": w * 1024.0, "launches": [nf, nw],
+                            "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc "
+                                      "WRITE_SIZE (separate passes, %d launches each) over `bench.py --pmc-inner`; "
+                                      "2 x FETCH_SIZE (gfx950 counts the 128-B requests of 16 B/lane coalesced "
+                                      "reads at 64 B) + WRITE_SIZE, in KiB" % nf}
+        c = {n: avg(n)[0] for n in PMC_PASSES[2]}
+        if all(v is not None for v in c.values()):
+            flops[cfg] = {"flops_per_launch": 64.0 * (2.0 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_ADD_F64"]
+                                                      + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]),
+                          "valu_wave_instructions": c["SQ_INSTS_VALU"],
+                          "source": "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 "
+                                    "SQ_INSTS_VALU over `bench.py --pmc-inner` (2 flop per FMA, 64 lanes per wave "
+                                    "instruction)"}
+    if not traffic:
+        return {"error": "no march launches found in the rocprofv3 counter files"}, flops
+    return traffic, flops
+
+
+# ------------------------------------------------------------------------------------------------
+# watchdog: a JSON line with an error field instead of a hang
+# ------------------------------------------------------------------------------------------------
+class Watchdog(object):
+    def __init__(self, seconds, rank, json_fd_ref, base):
+        self.seconds = seconds
+        self.stage = "start"
+        self._done = threading.Event()
+        if seconds > 0:
+            t = threading.Thread(target=self._run, args=(rank, json_fd_ref, base), daemon=True)
+            t.start()
+
+    def _run(self, rank, json_fd_ref, base):
+        if self._done.wait(self.seconds):
+            return
+        msg = "watchdog: no result after %.0f s (stage: %s)" % (self.seconds, self.stage)
+        try:
+            import faulthandler
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        except Exception:
+            pass
+        if rank == 0:
+            line = dict(base, value=None, ms_per_step=None, error=msg)
+            os.write(json_fd_ref[0], (json.dumps(line) + "\n").encode())
+        os._exit(3)
+
+    def done(self):
+        self._done.set()
+
+
+# ------------------------------------------------------------------------------------------------
 def main():
     _stdout_of_other_ranks_to_stderr()
     ap = argparse.ArgumentParser()
@@ -160,11 +564,17 @@ def main():
     # 10 ms of a 50-ms timed region -- no longer moves the rate by more than a few per cent)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", choices=["doublegauss", "asphere", "aniso"], default="doublegauss",
-                    help="BASELINE.json configs[1] (default, the headline), configs[2], configs[3]")
+    ap.add_argument("--config", choices=list(SINGLE_GPU_CONFIGS), default=None,
+                    help="measure this configuration alone, as the headline: BASELINE.json configs[1] (doublegauss), "
+                         "configs[2] (asphere), configs[3] (aniso), the XY-polynomial system (xypoly).  Default: "
+                         "doublegauss as the headline, and at N = 1 the other three beside it (`configs`)")
+    ap.add_argument("--headline-only", action="store_true", help="N = 1: do not measure the other configurations")
     ap.add_argument("--rays", type=int, default=None,
                     help="requested rays per GPU (default: 1e7 at N = 1 = BASELINE configs[1]/[2]; 1e6 for "
-                         "--config aniso; 1.25e7 at N > 1, so that 8 GPUs trace the 1e8-ray bundle of configs[4])")
+                         "aniso; 1.25e7 at N > 1, so that 8 GPUs trace the 1e8-ray bundle of configs[4])")
+    ap.add_argument("--first-segment", choices=["uniform", "arrays"], default="uniform",
+                    help="how the collimated bundle's k0 / E0 reach the march: as one vector each (default; "
+                         "prt_trace_ex, only x0 is loaded: 24 B/ray) or as per-ray arrays (72 B/ray)")
     ap.add_argument("--exchange", choices=["gather", "stats", "final-gather", "none"], default="gather",
                     help="N>1, what every step ends with: gather = spot-statistics all-reduce + the image-plane "
                          "all-gather (49 B/ray), overlapped with the next trace (default); stats = the "
@@ -177,12 +587,17 @@ def main():
                     help="where the path arrays come from: the engine's placement-aware arena (default; what "
                          "DeviceSystem.trace uses for arrays of this size) or the torch allocator")
     ap.add_argument("--inputs", choices=["arena", "torch"], default="arena",
-                    help="where the input arrays x0, k0, E0 live: in a third kind of HBM from the arena (default: "
+                    help="where the input arrays live: in a third kind of HBM from the arena (default: "
                          "what engine.ray_rows / RayBundle do for bundles of this size) or in torch-allocated arrays")
     ap.add_argument("--two-mask-arrays", action="store_true",
                     help="write valid and valid_out as two byte arrays (50 B per record) instead of one "
                          "byte of packed flags (49 B, default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=4.0, help="seconds of C-port timing per configuration")
+    ap.add_argument("--traffic", choices=["auto", "live", "lookup", "none"], default="auto",
+                    help="roofline.traffic: live = rocprofv3 PMC passes over the marches in this run (auto: when "
+                         "rocprofv3 is there, N = 1); lookup = the figures on file (profiles/hbm_traffic.json)")
+    ap.add_argument("--traffic-timeout", type=float, default=150.0)
     ap.add_argument("--mode", choices=["path", "image"], default="path")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: dry run of the multi-rank path on ONE GPU (all ranks share cuda:0, "
@@ -190,6 +605,11 @@ def main():
     ap.add_argument("--force-multi", action="store_true",
                     help="run the N>1 code path (5 wavelengths, side-stream all-reduce and all-gather) "
                          "with whatever world size there is, also 1: RCCL smoke test on a 1-GPU box")
+    ap.add_argument("--watchdog", type=float, default=None,
+                    help="seconds after which a JSON line with an `error` field is printed and the process exits "
+                         "(default: 900 for N > 1, off at N = 1; PRT_BENCH_WATCHDOG overrides)")
+    ap.add_argument("--pmc-inner", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--rays-of", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.force_multi:
         os.environ["PRT_FORCE_COLLECTIVES"] = "1"
@@ -205,11 +625,9 @@ def main():
                                   os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = world > 1 or args.force_multi
-    if args.config == "aniso" and use_dist:
-        raise SystemExit("--config aniso is BASELINE configs[3], a 1-GPU workload")
-    if args.rays is None:
-        args.rays = (1_000_000 if args.config == "aniso" else
-                     10_000_000 if not use_dist else 12_500_000)
+    if use_dist and args.config not in (None, "doublegauss"):
+        raise SystemExit("--config %s is a 1-GPU workload (BASELINE configs[4] is the double Gauss)" % args.config)
+    headline = args.config or "doublegauss"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if use_dist:
@@ -226,79 +644,108 @@ def main():
         resource.setrlimit(resource.RLIMIT_CORE, (0, resource.getrlimit(resource.RLIMIT_CORE)[1]))
     except (ImportError, ValueError, OSError):
         pass
+
+    def default_rays(config):
+        return args.rays if args.rays is not None else (1_000_000 if config == "aniso" else 10_000_000)
+
+    if args.pmc_inner:
+        args.rays_of = json.loads(args.rays_of)
+        pmc_inner(args, dev)
+        return
+
+    json_fd = [1]
+    base_line = {"metric": "ray_surface_ops_per_s", "unit": "ray-surface-ops/s", "n_gpus": world, "steps": args.steps,
+                 "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                 "dtype": "f64", "data": "synthetic"}
+    wd_s = args.watchdog if args.watchdog is not None else (900.0 if use_dist else 0.0)
     if os.environ.get("PRT_BENCH_WATCHDOG"):
-        # debugging aid: dump every thread's stack to stderr and exit if the run takes longer than this
-        import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["PRT_BENCH_WATCHDOG"]), exit=True)
-    json_fd = 1
+        wd_s = float(os.environ["PRT_BENCH_WATCHDOG"])
+    watchdog = Watchdog(wd_s, rank, json_fd, base_line)
     if use_dist:
         # RCCL prints a version banner to STDOUT whenever a communicator comes up (first collective of every
         # process group); the contract is ONE JSON line on stdout.  So file descriptor 1 points at stderr for
         # the whole run and the line goes to a duplicate of the original stdout at the end.
         sys.stdout.flush()
-        json_fd = os.dup(1)
+        json_fd[0] = os.dup(1)
         os.dup2(2, 1)
+        watchdog.stage = "init_process_group"
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    n_gpus = world
 
-    from pyrate_amd import build as prt_build, engine, placed, systems, _lib
+    from pyrate_amd import build as prt_build, _lib
+    if use_dist:
+        out = run_multi(args, dev, world, rank, local_rank, watchdog)
+    else:
+        configs = [headline]
+        if args.config is None and not args.headline_only and args.mode == "path":
+            configs += [c for c in SINGLE_GPU_CONFIGS if c != headline]
+        rays_of = {c: default_rays(c) for c in configs}
+        recs = []
+        for c in configs:
+            watchdog.stage = "measure " + c
+            recs.append(measure_single(c, args, dev, rays_of[c], with_cpu=not args.no_cpu_baseline))
+        traffic, flops = None, None
+        want_live = args.traffic == "live" or (args.traffic == "auto" and shutil.which("rocprofv3") is not None)
+        if want_live:
+            watchdog.stage = "PMC passes"
+            (traffic, flops) = measure_pmc_live(configs, args, rays_of, args.traffic_timeout)
+            if "error" in traffic:
+                print("bench.py: live HBM traffic unavailable: %s" % traffic["error"], file=sys.stderr)
+        arena_stats = None
+        if args.placement == "arena":
+            from pyrate_amd import placed
+            try:
+                arena_stats = placed.PlacedArena.for_device(dev.index).stats()
+            except Exception:
+                arena_stats = None
+        recs = [finish_roofline(r, traffic, flops, lookup=args.traffic != "none") for r in recs]
+        head = recs[0]
+        out = dict(base_line)
+        out.update({"value": head["value"], "ms_per_step": head["ms_per_step"],
+                    "config": {"workload": head["workload"], "rays_per_gpu": head["rays"], "rays_total": head["rays"],
+                               "surfaces": head["surfaces"], "rays_per_surface": head["rays_per_surface"],
+                               "mode": head["mode"], "first_segment": head["first_segment"],
+                               "record_bytes": head["record_bytes"], "masks": head["masks"], "sharding": "none",
+                               "wavelengths": 1, "prewarm_launches": PREWARM_LAUNCHES,
+                               "output_placement": dict(head["output_placement"], arena=arena_stats),
+                               "build": prt_build.build_info(_lib.LIB_PATH),
+                               "wall_s": None},
+                    "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"],
+                    # every single-GPU configuration of BASELINE.json measured by this run, headline first
+                    "configs": recs})
+        out["config"]["wall_s"] = time.perf_counter() - T_START
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    watchdog.done()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio
+        # (block-buffered on a pipe, so it would otherwise surface at exit, after the line)
+        _flush_c_stdio()
+        sys.stdout.flush()
+        os.write(json_fd[0], (json.dumps(out) + "\n").encode())
+        sys.stdout.flush()
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 (and --force-multi): BASELINE configs[4]
+# ------------------------------------------------------------------------------------------------
+def run_multi(args, dev, world, rank, local_rank, watchdog):
+    from pyrate_amd import build as prt_build, engine, placed, _lib
     from pyrate_amd import distributed as pdist
-
-    # ---- workload ---------------------------------------------------------------------------
-    # rank r owns a contiguous, equal-stride slice of the global bundle (pdist.shard_range)
-    multi = use_dist
-    if args.config == "doublegauss":
-        # N = 1: BASELINE configs[1] (d line).  N > 1: configs[4] -- the same lens at the five
-        # wavelengths of the prescription (spd:5), per-wavelength indices from the Conrady fit
-        # through the (d, F, C) indices; step i traces wavelength i % 5.
-        records = systems.double_gauss_records()
-        record_sets = ([systems.double_gauss_records(w) for w in systems.DOUBLE_GAUSS_WAVES_MM]
-                       if multi else [records])
-        bundle_args = dict()
-        workload = (("demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 double Gauss, "
-                     "ConstantIndexGlass d-line), RectGrid disk bundle, BASELINE configs[1]") if n_gpus == 1 else
-                    ("demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 double Gauss), 5 wavelengths "
-                     "cycled (Conrady indices), RectGrid disk bundle ray-sharded over the GPUs (1.25e7 rays per "
-                     "GPU: the 1e8-ray bundle at 8 GPUs), BASELINE configs[4]"))
-    elif args.config == "asphere":
-        # configs[2]: demo_asphere.py geometry (stop, plane front, even asphere back, image) with the
-        # test-suite coefficient set (tests/test_surf_shape.py:115-127) scaled to stay in-domain, bundle
-        # radius 9, 5 degree field: the Newton iteration count varies over the wavefront
-        records = systems.asphere_records(coefficients=(1e-3, -1e-6, 1e-8), curv=-1. / 30., cc=-1.5)
-        record_sets = [records]
-        bundle_args = dict(rpup=9.0, z0=-5.0, field_deg=5.0)
-        workload = ("demo_asphere: stop, plane, even asphere (curv -1/30, cc -1.5, A2..A6 = 1e-3, -1e-6, 1e-8; "
-                    "Newton intersection), image; RectGrid disk bundle r = 9 mm at 5 deg, BASELINE configs[2]")
-    else:
-        c = systems.CALCITE_TILTED
-        records = systems.aniso_doublet_records(
-            systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"]),
-            systems.uniaxial_eps(1.6727, 1.60, (np.sin(0.2), 0.0, np.cos(0.2))))
-        record_sets = [records]
-        workload = ("demo_anisotropic_doublet: cemented doublet of two uniaxial crystals (calcite-like, tilted "
-                    "axes), k-vector solve + ray doubling at two interfaces (1 -> 2 -> 4 rays), RectGrid disk "
-                    "bundle r = 11.43 mm, BASELINE configs[3]")
-    S = len(records)
-    if args.config == "aniso":
-        (o_h, k_h) = systems.collimated_bundle(args.rays, 11.43, -5.0)
-        e_h = np.ascontiguousarray(np.cross(k_h, np.array([1., 0., 0.]), axisa=0, axisb=0).T)
-        (x0, k0, e0d) = [engine.to_device_rays(a, dev, pitched=False) for a in (o_h, k_h, e_h)]
-        n_total = n_local = o_h.shape[1]
-        (lo, hi) = (0, n_total)
-    else:
-        (_, n_total) = engine.rect_grid_count(args.rays * n_gpus, dev)
-        (lo, hi) = pdist.shard_range(n_total, rank, n_gpus)
-        n_local = hi - lo
-        (x0, k0, e0d, _) = systems.double_gauss_bundle_device(args.rays * n_gpus, dev, lo=lo, hi=hi, **bundle_args)
-
-    sysds = [engine.DeviceSystem(r, local_rank) for r in record_sets]
+    n_gpus = world
+    rays = args.rays if args.rays is not None else 12_500_000
+    watchdog.stage = "bundle generation"
+    wl = make_workload("doublegauss", rays, dev, n_gpus=n_gpus, rank=rank, multi=True,
+                       first_segment=args.first_segment)
+    (x0, k0, e0d, uni) = (wl["x0"], wl["k0"], wl["e0"], wl["uniform"])
+    (n_total, n_local, S) = (wl["n_total"], wl["n_local"], wl["S"])
+    sysds = [engine.DeviceSystem(r, local_rank) for r in wl["record_sets"]]
     sysd = sysds[0]
-    iso = sysd.all_isotropic
     mode = _lib.MODE_PATH if args.mode == "path" else _lib.MODE_IMAGE
-    exchange = args.exchange if multi else "none"
+    exchange = args.exchange
     do_stats = exchange in ("gather", "stats", "final-gather")
     do_step_gather = exchange == "gather"
     do_final_gather = exchange == "final-gather"
@@ -308,43 +755,32 @@ def main():
     # arrays, so with it the path arrays are double-buffered.
     nbuf = 2 if (do_stats or do_step_gather) else 1
     n_out_bufs = 2 if (do_step_gather or (do_stats and not fused_stats)) else 1
-    packed = iso and not args.two_mask_arrays
+    packed = not args.two_mask_arrays
     record_bytes = 49 if packed else 50
     placement = args.placement if mode == _lib.MODE_PATH else "torch"
     # one row pitch on every rank: a gathered row is read n_pad elements deep (pdist.ImagePlaneGather)
-    pitch = engine.recommended_pitch(pdist.shard_stride(n_total, n_gpus)) if iso else None
-    # The input arrays: big bundles are generated straight into arena memory of a kind the path arrays do
-    # not use (engine.ray_rows; loads that share a kind of HBM with the march's write streams cost it
-    # 5 %).  --inputs torch moves them into torch-allocated arrays instead (A/B).
-    if args.inputs == "torch" and iso:
+    pitch = engine.recommended_pitch(pdist.shard_stride(n_total, n_gpus))
+    if args.inputs == "torch":
         moved = []
         for t in (x0, k0, e0d):
+            if t is None:
+                moved.append(None)
+                continue
             buf = torch.empty((3, t.stride(0)), dtype=torch.float64, device=dev)[:, :n_local]
             buf.copy_(t)
             moved.append(buf)
         (x0, k0, e0d) = moved
         torch.cuda.synchronize()
-    placement_note = None
-    try:
-        bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed, placement=placement, pitch=pitch)
-                for _ in range(n_out_bufs)]
-    except RuntimeError as exc:
-        if placement != "arena":
-            raise
-        # no placement control on this device / driver: the run still measures the march, on arrays from the
-        # torch allocator, and says so
-        placement_note = "arena unavailable (%s): path arrays from the torch allocator" % exc
-        print("bench.py: " + placement_note, file=sys.stderr)
-        placement = "torch"
-        bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed, placement=placement, pitch=pitch)
-                for _ in range(n_out_bufs)]
+    watchdog.stage = "output allocation (arena)"
+    (bufs, placement, placement_note) = alloc_outputs_or_torch(sysd, n_local, mode, packed, placement, pitch,
+                                                                count=n_out_bufs)
     arena_obj = placed.PlacedArena.for_device(local_rank) if placement == "arena" else None
     input_kind = arena_obj.kind_of(x0) if arena_obj is not None else None
     host_staged = (args.backend == "gloo")
     stats = [pdist.SpotStatistics(dev, n_rays=n_local) for _ in range(nbuf)] if do_stats else []
     gathers = ([pdist.ImagePlaneGather(n_total, dev, stage_on_host=host_staged)
                 for _ in range(nbuf if do_step_gather else 1)] if (do_step_gather or do_final_gather) else [])
-    comm_stream = torch.cuda.Stream(device=dev) if multi else None
+    comm_stream = torch.cuda.Stream(device=dev)
     main_stream = torch.cuda.current_stream(dev)
     side_done = [None] * nbuf          # event: side-stream work of slot b has finished
 
@@ -359,9 +795,9 @@ def main():
             main_stream.wait_event(side_done[b])      # slot b (and its path arrays) are free again
         ob = bufs[b % n_out_bufs]
         if fused_stats:
-            stats[b].trace_and_start(sysds[i % len(sysds)], x0, k0, ob, e0d)
+            stats[b].trace_and_start(sysds[i % len(sysds)], x0, k0, ob, e0d, uniform=uni)
         else:
-            sysds[i % len(sysds)].trace_into(x0, k0, ob, e0d)
+            sysds[i % len(sysds)].trace_into(x0, k0, ob, e0d, uniform=uni)
         if do_stats or do_step_gather:
             ev = torch.cuda.Event()
             ev.record(main_stream)
@@ -392,179 +828,117 @@ def main():
 
     def finish():
         """every step's work (trace + per-step exchange) has completed"""
-        if comm_stream is not None:
-            comm_stream.synchronize()
+        comm_stream.synchronize()
         torch.cuda.synchronize()
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-
     def timed_region(n_steps, **kw):
-        barrier()
+        dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n_steps):
             step(i, **kw)
         finish()
-        barrier()
+        dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=(dev if args.backend == "nccl" else "cpu"))
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        t = torch.tensor([dt], dtype=torch.float64, device=(dev if args.backend == "nccl" else "cpu"))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    # device wake-up (not one of the W warm-up steps): after idle the first ~25 ms of launches run
-    # at ramping clocks (per-launch trace in DESIGN.md section 5); 30 plain launches of the same
-    # kernel bring the chip to its steady state before anything is counted
+    watchdog.stage = "warm-up"
     for _ in range(PREWARM_LAUNCHES):
-        sysd.trace_into(x0, k0, bufs[0], e0d)
+        sysd.trace_into(x0, k0, bufs[0], e0d, uniform=uni)
     torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     finish()
     if do_final_gather and args.warmup > 0:
         final_gather(args.warmup - 1)          # warms the all-gather path too
+    watchdog.stage = "timed region"
     elapsed = timed_region(args.steps)
-    # N > 1: the same steps without the image-plane all-gather, measured right after (reported beside)
+    # the same steps without the image-plane all-gather, measured right after (reported beside)
+    watchdog.stage = "timed region without gather"
     elapsed_without_gather = timed_region(args.steps, with_gather=False) if do_step_gather else None
     # the final image-plane gather of --exchange final-gather is not one of the K steps: timed on its own
     final_gather_ms = None
     if do_final_gather:
-        barrier()
+        dist.barrier()
         torch.cuda.synchronize()
         tg = time.perf_counter()
         final_gather(args.steps - 1)
-        barrier()
+        dist.barrier()
         final_gather_ms = (time.perf_counter() - tg) * 1e3
     spot = None
     if do_stats:
         (cnt, cen, rms) = stats[(args.steps - 1) % nbuf].result()
         spot = {"rays": float(cnt), "centroid_mm": [float(c) for c in cen], "rms_spot_mm": rms}
-
-    # dominant kernel: average launch duration from HIP events on the launch stream
-    kernel_ms = sysd.trace_timed(x0, k0, bufs[0], max(args.steps, 5), e0d)
+    watchdog.stage = "kernel timing"
+    kernel_ms = sysd.trace_timed(x0, k0, bufs[0], max(args.steps, 5), e0d, uniform=uni)
     torch.cuda.synchronize()
-
     ops_total = n_total * S * args.steps
-    value = ops_total / elapsed
-    if rank == 0:
-        (n_in, n_out) = sysd.ray_counts(n_local)
-        if not iso:
-            # concatenated layout (real k): read x0, k0, E0; per surface write x_hit 24 B + mask 1 B per
-            # entering ray and k_out 24 B + mask 1 B per leaving ray (crystal interfaces double the rays)
-            alg = 72 * n_local + 25 * (sum(n_in) + sum(n_out)) if args.mode == "path" \
-                else 72 * n_local + 25 * (n_in[-1] + n_out[-1])
-        elif args.mode == "path":
-            alg = algorithmic_bytes(n_local, S, record_bytes=record_bytes)
-        else:
-            alg = n_local * (72 + record_bytes)
-        achieved = alg / (kernel_ms * 1e-3) / 1e9
-        tkey = "%s_%d%s" % (args.mode, n_local, "" if packed else "_two_masks")
-        if args.config != "doublegauss":
-            tkey = args.config + "_" + tkey
-        tent = _lookup("hbm_traffic.json", tkey)
-        hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": achieved / HBM_PEAK_GBS,
-               "traffic": tent["bytes_per_launch"] if tent else None,
-               "traffic_source": ("profiles/hbm_traffic.json[%s]: rocprofv3 PMC passes of an earlier run of this "
-                                  "workload, looked up by ray count -- NOT measured in this run" % tkey)
-               if tent else None,
-               "kernel": "k_trace_iso" if iso else "k_trace_general", "kernel_ms": kernel_ms,
-               "algorithmic_bytes_per_launch": alg,
-               "bytes_per_ray_surface_op": alg / (n_local * S)}
-        if args.config == "doublegauss":
-            hbm["frac_at_98B_per_op_convention"] = (n_local * S * 98 / (kernel_ms * 1e-3) / 1e9) / HBM_PEAK_GBS
-        roofline = hbm
-        if not iso:
-            # crystal march: FP64-VALU bound (SURVEY.md 8d) -- flops per launch from SQ instruction
-            # counters (benchmarks/valu_profile.py pass c), HBM as the secondary roof
-            fent = _lookup("fp64_flops.json", "%s_%s_%d" % (args.config, args.mode, n_local))
-            if fent:
-                tf = fent["flops_per_launch"] / (kernel_ms * 1e-3) / 1e12
-                roofline = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS,
-                            "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": hbm["traffic"],
-                            "flops_per_launch": fent["flops_per_launch"],
-                            "flops_source": "profiles/fp64_flops.json: SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 of an "
-                                            "earlier PMC run of this workload (2 flop per FMA, 64 lanes per "
-                                            "wave instruction), looked up -- NOT measured in this run",
-                            "kernel": "k_trace_general", "kernel_ms": kernel_ms, "secondary": hbm,
-                            # all VALU wave instructions (selects, compares, address arithmetic included) at one
-                            # per 4 cycles and SIMD against the 1024 SIMDs at 2.4 GHz: what the kernel is bound by
-                            "valu_issue_frac": (fent["counters"]["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9)
-                                                / (kernel_ms * 1e-3)) if "counters" in fent else None}
-            else:
-                roofline = dict(hbm, note="FP64-VALU bound kernel; no flop count on file for this size "
-                                          "(profiles/fp64_flops.json), HBM fraction shown")
-        arena_stats = arena_obj.stats() if arena_obj is not None else None
-        kinds_out = bufs[0]["placement"].get("kinds")
-        if placement_note is None and kinds_out and len(set(kinds_out[:2])) < 2:
-            placement_note = ("x_hit and k_out share a kind of HBM (the arena found no second kind within its "
-                              "hunt): expect the 5.6 TB/s regime of same-kind write streams")
-        elif placement_note is None and arena_obj is not None and iso and input_kind is not None \
-                and kinds_out and input_kind in kinds_out[:2]:
-            placement_note = "the inputs share a kind of HBM with a path array (no third kind found): about 5 % slower"
-        out = {
-            "metric": "ray_surface_ops_per_s", "value": value, "unit": "ray-surface-ops/s",
-            "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload,
-                       "rays_per_gpu": n_local, "rays_total": n_total, "surfaces": S,
-                       "rays_per_surface": None if iso else {"entering": n_in, "leaving": n_out},
-                       "mode": args.mode, "record_bytes": record_bytes if iso else 25,
-                       "masks": ("valid | valid_out << 1 in one byte" if packed else "two byte arrays"),
-                       "sharding": "rays" if n_gpus > 1 else "none",
-                       "wavelengths": len(sysds), "prewarm_launches": PREWARM_LAUNCHES,
-                       "output_placement": {"policy": bufs[0]["placement"]["policy"], "note": placement_note,
-                                            "memory_kinds_of_x_hit_and_k_out": bufs[0]["placement"].get("kinds"),
-                                            "memory_kind_of_inputs": input_kind,
-                                            "inputs": "arena" if input_kind is not None else "torch allocator",
-                                            "arena": arena_stats},
-                       "image_plane_exchange": {
-                           "per_step": {"gather": "spot moments from the trace kernel + one 7-double all-reduce, then "
-                                                  "image-plane all-gather 49 B/ray (7 row collectives straight into "
-                                                  "the [row][global ray] layout), side stream, overlaps the next trace",
-                                        "stats": "spot moments from the trace kernel + one 7-double all-reduce (side stream)",
-                                        "final-gather": "spot moments + one 7-double all-reduce (side stream)",
-                                        "none": "none"}[exchange]
-                                       + ("" if fused_stats or not do_stats else " [two-pass statistics]"),
-                           "final": ("image-plane all-gather 49 B/ray, once after the K timed steps"
-                                     if do_final_gather else "none"),
-                           "final_gather_ms": final_gather_ms,
-                           "ms_per_step_without_gather": (elapsed_without_gather / args.steps * 1e3
-                                                          if elapsed_without_gather else None),
-                           "value_without_gather": (ops_total / elapsed_without_gather
-                                                    if elapsed_without_gather else None),
-                           "backend": ("rccl" if args.backend == "nccl" else "gloo dry run (host staged)")
-                           if multi else "none"},
-                       "image_plane_spot": spot,
-                       "build": prt_build.build_info(_lib.LIB_PATH)},
-            "roofline": roofline,
-        }
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            if args.config == "doublegauss":
-                m = min(n_local, 4_000_000)
-                out["cpu_baseline"] = cpu_baseline(records, x0[:, :m].cpu().numpy(), k0[:, :m].cpu().numpy(),
-                                                   e0d[:, :m].cpu().numpy(), n_all=n_local)
-            else:
-                m = 4_000_000 if args.config == "asphere" else 64_000
-                out["cpu_baseline"] = cpu_baseline_numpy(records, x0[:, :m].cpu().numpy(), k0[:, :m].cpu().numpy(),
-                                                         e0d[:, :m].cpu().numpy(), m, n_local)
-        else:
-            out["cpu_baseline"] = None
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio
-        # (block-buffered on a pipe, so it would otherwise surface at exit, after the line)
-        _flush_c_stdio()
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-        sys.stdout.flush()
+    if rank != 0:
+        return None
+    alg = algorithmic_bytes(wl, sysd, args.mode, record_bytes)
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    fkey = ("%s_%d_uniform" if uni is not None else "%s_%d") % (args.mode, n_local)
+    tent = _lookup("hbm_traffic.json", fkey)
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": tent["bytes_per_launch"] if tent else None,
+                "traffic_source": ("profiles/hbm_traffic.json[%s]: looked up, NOT measured in this run" % fkey)
+                if tent else None,
+                "kernel": "k_trace_iso", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg,
+                "bytes_per_ray_surface_op": alg / (n_local * S),
+                "note": "per rank (rank 0's march); every rank runs the same launch on its shard"}
+    kinds_out = bufs[0]["placement"].get("kinds")
+    # what DESIGN.md section 6 expects for this run (so that a measured curve can be read against it): the trace of
+    # one shard takes what the 1-GPU march takes at this size (kernel_ms); the per-step all-gather moves
+    # 49 B x n_pad to each of the N-1 peers over one xGMI link each (point-to-point, ~153 GB/s per link and
+    # direction, 0.65-0.8 of it reached) and overlaps the next trace -> a step costs max(trace, gather)
+    n_pad = pdist.shard_stride(n_total, n_gpus)
+    gather_ms = [49.0 * n_pad / (f * 153e9) * 1e3 for f in (0.8, 0.65)] if n_gpus > 1 else [0.0, 0.0]
+    expected = {"trace_ms_per_step": kernel_ms,
+                "gather_ms_per_step_at_0.8_and_0.65_of_the_link_rate": gather_ms,
+                "ms_per_step_with_gather": [max(kernel_ms, g) for g in gather_ms],
+                "value_with_gather": [n_total * S / (max(kernel_ms, g) * 1e-3) for g in gather_ms],
+                "value_without_gather": n_total * S / (kernel_ms * 1e-3),
+                "basis": "DESIGN.md section 6: step = max(this rank's march, image-plane all-gather of 49 B x %d rays "
+                         "per peer over one xGMI link each at 0.65-0.8 x 153 GB/s); weak scaling, so without the "
+                         "gather the value grows with N" % n_pad}
+    return dict({"metric": "ray_surface_ops_per_s", "value": ops_total / elapsed, "unit": "ray-surface-ops/s",
+                 "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                 "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"},
+                config={"workload": wl["workload"], "rays_per_gpu": n_local, "rays_total": n_total, "surfaces": S,
+                        "rays_per_surface": None, "mode": args.mode,
+                        "first_segment": "uniform k0 / E0" if uni is not None else "arrays x0, k0, E0",
+                        "record_bytes": record_bytes,
+                        "masks": ("valid | valid_out << 1 in one byte" if packed else "two byte arrays"),
+                        "sharding": "rays", "wavelengths": len(sysds), "prewarm_launches": PREWARM_LAUNCHES,
+                        "output_placement": {"policy": bufs[0]["placement"]["policy"], "note": placement_note,
+                                             "memory_kinds_of_x_hit_and_k_out": kinds_out,
+                                             "memory_kind_of_inputs": input_kind,
+                                             "inputs": "arena" if input_kind is not None else "torch allocator",
+                                             "arena": arena_obj.stats() if arena_obj is not None else None},
+                        "image_plane_exchange": {
+                            "per_step": {"gather": "spot moments from the trace kernel + one 7-double all-reduce, then "
+                                                   "image-plane all-gather 49 B/ray (7 row collectives straight into "
+                                                   "the [row][global ray] layout), side stream, overlaps the next trace",
+                                         "stats": "spot moments from the trace kernel + one 7-double all-reduce (side stream)",
+                                         "final-gather": "spot moments + one 7-double all-reduce (side stream)",
+                                         "none": "none"}[exchange]
+                                        + ("" if fused_stats or not do_stats else " [two-pass statistics]"),
+                            "final": ("image-plane all-gather 49 B/ray, once after the K timed steps"
+                                      if do_final_gather else "none"),
+                            "final_gather_ms": final_gather_ms,
+                            "ms_per_step_without_gather": (elapsed_without_gather / args.steps * 1e3
+                                                           if elapsed_without_gather else None),
+                            "value_without_gather": (ops_total / elapsed_without_gather
+                                                     if elapsed_without_gather else None),
+                            "backend": "rccl" if args.backend == "nccl" else "gloo dry run (host staged)"},
+                        "expected": expected,
+                        "image_plane_spot": spot,
+                        "build": prt_build.build_info(_lib.LIB_PATH)},
+                roofline=roofline, cpu_baseline=None)
 
 
 if __name__ == "__main__":

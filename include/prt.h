@@ -18,6 +18,10 @@
  * reference checkout, package pyrateoptics 0.4.0):
  *
  *   prt_trace            OpticalSystem.seqtrace      raytracer/optical_system.py:73-94
+ *   prt_trace_ex         the same, every option in one struct; adds the UNIFORM first segment of the
+ *                        collimated bundles (OpticalSystemAnalysis.collimated_bundle,
+ *                        raytracer/analysis/optical_system_analysis.py:83-122: k and E are one vector
+ *                        for the whole bundle)
  *   prt_trace_seq        OpticalElement.seqtrace     raytracer/optical_element.py:324-379
  *   prt_propagate        Material.propagate          raytracer/material/material_isotropic.py:238-247
  *                        Surface.intersect           raytracer/surface.py:116-135
@@ -46,7 +50,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 4
+#define PRT_ABI_VERSION 5
 #define PRT_MAX_COEFFS 128 /* asphere A2.. coefficients and / or XY-polynomial terms */
 
 /* ---- error codes ---------------------------------------------------- */
@@ -191,6 +195,64 @@ int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const d
                   uint8_t *valid_out, uint8_t *nonconv, void *stream);
 
 /*
+ * ---- the general form: every option of the whole-sequence trace in one struct -------------------
+ * prt_trace, prt_trace_seq, prt_trace_fields, prt_trace_moments and prt_trace_timed are thin wrappers
+ * that fill this struct; prt_trace_ex additionally offers
+ *
+ *   the UNIFORM first segment (ABI v5).  The bundles of the reference's analysis layer are collimated
+ *   (OpticalSystemAnalysis.collimated_bundle, analysis/optical_system_analysis.py:83-122): k0 and E0 are
+ *   ONE vector for all rays, yet as arrays they cost 48 B/ray of loads (72 of the 268 B/ray of BASELINE
+ *   configs[2]).  With k0 == NULL every ray has k_uniform, the first segment's direction comes from the
+ *   uniform E (or is k/|k|, or is given), only x0 is read -- and the results are bit-identical to the
+ *   array form (same per-ray arithmetic on the same values).
+ *
+ * first_dir: where the unit direction d of the first segment comes from (RayBundle.returnKtoD,
+ * ray.py:136-152: the Poynting direction of (k, E))
+ *   PRT_FIRST_E          from k and E: e0_re / e0_im arrays, e0_re == NULL means E = (0,1,0)
+ *                        (ray.py:71-73); needs k0 when arrays are given
+ *   PRT_FIRST_K          d = k/|k| (E perpendicular to k: any bundle that left an isotropic interface)
+ *   PRT_FIRST_DIR        e0_re holds the unit directions themselves, (3,n0) (prt_trace_seq's d0)
+ *   PRT_FIRST_E_UNIFORM  from k and the uniform E = e_uniform_re + i e_uniform_im
+ *   PRT_FIRST_DIR_UNIFORM  d = e_uniform_re for every ray
+ * k0 == NULL (uniform k) goes with PRT_FIRST_E (E = ey only), PRT_FIRST_K, PRT_FIRST_E_UNIFORM and
+ * PRT_FIRST_DIR_UNIFORM; the uniform E / direction kinds go with k0 == NULL only.
+ *
+ * Outputs and modes exactly as described at prt_trace (e_out_*: prt_trace_fields; moments_*:
+ * prt_trace_moments; timed_iters > 0: prt_trace_timed, *ms_avg receives the average milliseconds per
+ * launch -- of the march kernel only when moments are requested too).  struct_bytes must be
+ * sizeof(prt_trace_args_t): a caller built against another layout is refused (PRT_ERR_INVALID_ARG).
+ */
+enum { PRT_FIRST_E = 0, PRT_FIRST_K = 1, PRT_FIRST_DIR = 2, PRT_FIRST_E_UNIFORM = 3, PRT_FIRST_DIR_UNIFORM = 4 };
+typedef struct prt_trace_args {
+    int32_t struct_bytes; /* sizeof(prt_trace_args_t)                                     */
+    int32_t mode;         /* PRT_MODE_PATH / PRT_MODE_IMAGE, optionally | PRT_MODE_FLAGS   */
+    int64_t n0;           /* rays entering the first surface                              */
+    /* first segment */
+    int64_t in_pitch;     /* row pitch of x0 / k0 / e0 in elements, 0 = n0               */
+    const double *x0;     /* (3,n0) device                                                */
+    const double *k0;     /* (3,n0) device, or NULL: every ray has k_uniform              */
+    const double *e0_re, *e0_im; /* (3,n0) device or NULL (see first_dir)                 */
+    int32_t first_dir;    /* PRT_FIRST_*                                                  */
+    int32_t pad0_;
+    double k_uniform[3];
+    double e_uniform_re[3], e_uniform_im[3];
+    /* outputs (layouts: prt_trace) */
+    int64_t out_pitch;
+    double *x_hit, *k_out;
+    uint8_t *valid, *valid_out, *nonconv;
+    double *e_out_re, *e_out_im;  /* E behind crystal interfaces (prt_trace_fields) or NULL */
+    /* fused image-plane moments (prt_trace_moments): requested by moments_out7_dev != NULL */
+    const double *moments_ref3;   /* HOST, 3 doubles, or NULL: vertex of the last surface   */
+    double *moments_out7_dev, *moments_scratch_dev;
+    /* timing (prt_trace_timed): timed_iters > 0 */
+    int32_t timed_iters, pad1_;
+    double *ms_avg;               /* HOST                                                  */
+    void *stream;                 /* hipStream_t, NULL = default stream                    */
+} prt_trace_args_t;
+int32_t prt_sizeof_trace_args(void);
+int32_t prt_trace_ex(const prt_system_t *sys, const prt_trace_args_t *args);
+
+/*
  * The same in one call, without a handle (the form SURVEY.md section 8b proposes): the table is uploaded
  * on first use and kept by content (the last 8 tables of the process).
  *   x0, k0        (3,n) tight arrays on the device
@@ -280,7 +342,9 @@ int32_t prt_efield_perp(int32_t device, int64_t n, const double *k, double *e_ou
  *   prt_rect_grid_count: number of samples per dimension and inside the disk for a requested
  *                        ray count (the raster returns "approximately nray" points).
  *   prt_collimated_bundle: writes rays [lo, hi) of that raster (a rank's shard, or 0..n_in_disk)
- *                        into (3, pitch) arrays x_out, k_out and (optionally) e_out.
+ *                        into (3, pitch) arrays x_out and (optionally) k_out, e_out.  k and E are one
+ *                        vector for the whole bundle: a caller that traces with the uniform first
+ *                        segment of prt_trace_ex passes k_out = e_out = NULL and stores nothing per ray.
  */
 typedef struct prt_collimated {
     double radius, startx, starty, startz;
@@ -309,7 +373,8 @@ int32_t prt_collimated_bundle(int32_t device, int64_t nray, int64_t lo, int64_t 
  *   kind 1, divergent:  origin = start; unit vector (sin(angley + radius*px) cos(anglex + radius*py),
  *           sin(anglex + radius*py), cos(angley + radius*px) cos(anglex + radius*py)), k = index * unit,
  *           E = the unit vector perpendicular to k that prt_efield_perp picks
- *   p_out (optional, (2, pitch)): the pupil samples themselves.
+ *   p_out (optional, (2, pitch)): the pupil samples themselves.  k_out may be NULL for kind 0 (see
+ *   prt_collimated_bundle).
  */
 typedef struct prt_raster {
     int64_t ni, nj;

@@ -26,7 +26,7 @@ c_double_p = ctypes.c_void_p      # device pointers travel as raw addresses
 c_u8_p = ctypes.c_void_p
 c_stream = ctypes.c_void_p
 
-ABI_VERSION = 4          # PRT_ABI_VERSION of include/prt.h
+ABI_VERSION = 5          # PRT_ABI_VERSION of include/prt.h
 
 # name -> (restype, argtypes); must list every symbol declared in include/prt.h
 PROTOTYPES = {
@@ -135,6 +135,34 @@ PROTOTYPES["prt_trace_moments"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_in
                                                    ctypes.c_int64, c_double_p, c_double_p, c_u8_p, c_u8_p,
                                                    c_double_p, c_double_p, c_double_p, c_stream])
 
+# first_dir of prt_trace_args_t (include/prt.h PRT_FIRST_*)
+FIRST_E = 0
+FIRST_K = 1
+FIRST_DIR = 2
+FIRST_E_UNIFORM = 3
+FIRST_DIR_UNIFORM = 4
+
+
+class PrtTraceArgs(ctypes.Structure):
+    """ctypes mirror of prt_trace_args_t (include/prt.h)"""
+    _fields_ = [("struct_bytes", ctypes.c_int32), ("mode", ctypes.c_int32), ("n0", ctypes.c_int64),
+                ("in_pitch", ctypes.c_int64), ("x0", ctypes.c_void_p), ("k0", ctypes.c_void_p),
+                ("e0_re", ctypes.c_void_p), ("e0_im", ctypes.c_void_p),
+                ("first_dir", ctypes.c_int32), ("pad0_", ctypes.c_int32),
+                ("k_uniform", ctypes.c_double * 3), ("e_uniform_re", ctypes.c_double * 3),
+                ("e_uniform_im", ctypes.c_double * 3),
+                ("out_pitch", ctypes.c_int64), ("x_hit", ctypes.c_void_p), ("k_out", ctypes.c_void_p),
+                ("valid", ctypes.c_void_p), ("valid_out", ctypes.c_void_p), ("nonconv", ctypes.c_void_p),
+                ("e_out_re", ctypes.c_void_p), ("e_out_im", ctypes.c_void_p),
+                ("moments_ref3", ctypes.POINTER(ctypes.c_double)), ("moments_out7_dev", ctypes.c_void_p),
+                ("moments_scratch_dev", ctypes.c_void_p),
+                ("timed_iters", ctypes.c_int32), ("pad1_", ctypes.c_int32),
+                ("ms_avg", ctypes.POINTER(ctypes.c_double)), ("stream", ctypes.c_void_p)]
+
+
+PROTOTYPES["prt_sizeof_trace_args"] = (ctypes.c_int32, [])
+PROTOTYPES["prt_trace_ex"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(PrtTraceArgs)])
+
 PROTOTYPES["prt_arena_create"] = (ctypes.c_int32, [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)])
 PROTOTYPES["prt_arena_destroy"] = (ctypes.c_int32, [ctypes.c_void_p])
 PROTOTYPES["prt_arena_alloc"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64),
@@ -190,6 +218,9 @@ def load():
     if lib.prt_sizeof_surface() != ctypes.sizeof(PrtSurface):
         raise ImportError("pyrate_amd: prt_surface_t layout mismatch: C %d bytes, ctypes %d"
                           % (lib.prt_sizeof_surface(), ctypes.sizeof(PrtSurface)))
+    if lib.prt_sizeof_trace_args() != ctypes.sizeof(PrtTraceArgs):
+        raise ImportError("pyrate_amd: prt_trace_args_t layout mismatch: C %d bytes, ctypes %d"
+                          % (lib.prt_sizeof_trace_args(), ctypes.sizeof(PrtTraceArgs)))
     _lib = lib
     return lib
 

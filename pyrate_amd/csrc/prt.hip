@@ -112,42 +112,65 @@ static int32_t e_mode_of(const double *e_re, int32_t use_default_e) {
     return use_default_e ? 1 : 0;
 }
 
-template <int MODE>
-static void launch_trace_iso(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
-                             const double *k0, const double *e_re, const double *e_im,
-                             int32_t e_mode, int64_t out_pitch, double *x_hit, double *k_out,
-                             uint8_t *valid, uint8_t *valid_out, bool vec_in, bool vec_out,
-                             int32_t packed_flags, uint8_t *nonconv, hipStream_t st) {
-    const dim3 grid(nblocks(n0, PRT_MARCH_BLOCK * 2)), block(PRT_MARCH_BLOCK);
-#define PRT_LAUNCH_E(VI, VO, EX)                                                                 \
-    hipLaunchKernelGGL((k_trace_iso<MODE, VI, VO, EX>), grid, block, 0, st, sys->d_table,        \
-                       sys->n_surfaces, n0, in_pitch, x0, k0, e_re, e_im, e_mode, out_pitch,     \
-                       x_hit, k_out, valid, valid_out, 0.0, 0.0, 0.0, (double *)nullptr,         \
-                       packed_flags, nonconv)
-#define PRT_LAUNCH(VI, VO)                 \
-    do {                                   \
-        if (sys->shape_level == PRT_SHAPES_CONIC)          \
-            PRT_LAUNCH_E(VI, VO, PRT_SHAPES_CONIC);        \
-        else if (sys->shape_level == PRT_SHAPES_ASPHERE)   \
-            PRT_LAUNCH_E(VI, VO, PRT_SHAPES_ASPHERE);      \
-        else                                               \
-            PRT_LAUNCH_E(VI, VO, PRT_SHAPES_ALL);          \
-    } while (0)
+// ---- launch of the fused isotropic march: picks the instantiation ---------------------------------
+struct iso_launch {
+    const prt_system_t *sys;
+    int64_t n0, in_pitch;
+    const double *x0, *k0, *e_re, *e_im;
+    int32_t e_mode;
+    int64_t out_pitch;
+    double *x_hit, *k_out;
+    uint8_t *valid, *valid_out;
+    int32_t packed_flags;
+    uint8_t *nonconv;
+    bool uni;          // uniform first segment (k0 == NULL): fu holds k and E / the direction
+    first_uniform fu;
+    bool moments;      // also reduce the image-plane moments (partials: one row of 7 per block)
+    double rx, ry, rz;
+    double *partials;
+    hipStream_t st;
+};
+
+template <int MODE, bool VI, bool VO, int SH, bool LDS, bool MOM, bool UNI>
+static void launch_iso_inst(const iso_launch &a) {
+    const dim3 grid(nblocks(a.n0, PRT_MARCH_BLOCK * 2)), block(PRT_MARCH_BLOCK);
+    hipLaunchKernelGGL((k_trace_iso<MODE, VI, VO, SH, LDS, MOM, UNI>), grid, block, 0, a.st, a.sys->d_table,
+                       a.sys->n_surfaces, a.n0, a.in_pitch, a.x0, a.k0, a.e_re, a.e_im, a.e_mode, a.out_pitch,
+                       a.x_hit, a.k_out, a.valid, a.valid_out, a.rx, a.ry, a.rz, a.partials, a.packed_flags,
+                       a.nonconv, a.fu, (int32_t)(a.uni ? 1 : 0));
+}
+
+// The aligned case (16-B rows in and out: what prt_recommended_pitch gives) has compile-time variants for the
+// uniform first segment and the fused moments; unaligned buffers run the general instantiations, which take
+// the uniform first segment as a run-time flag (moments: two-kernel reduction behind the trace, see trace_launch).
+template <int MODE, int SH>
+static void launch_iso_shape(const iso_launch &a, bool vi, bool vo) {
     static const bool lds_table = getenv("PRT_LDS_TABLE") != nullptr;
-    if (vec_in && vec_out && lds_table && sys->all_conic && sys->n_surfaces <= PRT_LDS_TAB_MAX)
-        hipLaunchKernelGGL((k_trace_iso<MODE, true, true, PRT_SHAPES_CONIC, true>), grid, block, 0, st, sys->d_table,
-                           sys->n_surfaces, n0, in_pitch, x0, k0, e_re, e_im, e_mode, out_pitch, x_hit,
-                           k_out, valid, valid_out, 0.0, 0.0, 0.0, (double *)nullptr, packed_flags);
-    else if (vec_in && vec_out)
-        PRT_LAUNCH(true, true);
-    else if (vec_in)
-        PRT_LAUNCH(true, false);
-    else if (vec_out)
-        PRT_LAUNCH(false, true);
-    else
-        PRT_LAUNCH(false, false);
-#undef PRT_LAUNCH
-#undef PRT_LAUNCH_E
+    if (a.moments) {
+        if (a.uni) launch_iso_inst<MODE, true, true, SH, false, true, true>(a);
+        else launch_iso_inst<MODE, true, true, SH, false, true, false>(a);
+    } else if (vi && vo) {
+        if (SH == PRT_SHAPES_CONIC && lds_table && !a.uni && a.sys->n_surfaces <= PRT_LDS_TAB_MAX)
+            launch_iso_inst<MODE, true, true, PRT_SHAPES_CONIC, true, false, false>(a);
+        else if (a.uni) launch_iso_inst<MODE, true, true, SH, false, false, true>(a);
+        else launch_iso_inst<MODE, true, true, SH, false, false, false>(a);
+    } else if (vi) {
+        launch_iso_inst<MODE, true, false, SH, false, false, false>(a);
+    } else if (vo) {
+        launch_iso_inst<MODE, false, true, SH, false, false, false>(a);
+    } else {
+        launch_iso_inst<MODE, false, false, SH, false, false, false>(a);
+    }
+}
+
+template <int MODE>
+static void launch_trace_iso(const iso_launch &a, bool vi, bool vo) {
+    switch (a.sys->shape_level) {
+        case PRT_SHAPES_CONIC: launch_iso_shape<MODE, PRT_SHAPES_CONIC>(a, vi, vo); break;
+        case PRT_SHAPES_ASPHERE: launch_iso_shape<MODE, PRT_SHAPES_ASPHERE>(a, vi, vo); break;
+        case PRT_SHAPES_POLY: launch_iso_shape<MODE, PRT_SHAPES_POLY>(a, vi, vo); break;
+        default: launch_iso_shape<MODE, PRT_SHAPES_ALL>(a, vi, vo); break;
+    }
 }
 
 extern "C" {
@@ -334,7 +357,9 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
         if (r.mat_type != PRT_MAT_ISOTROPIC) sys->all_isotropic = 0;
         if (r.shape_type != PRT_SHAPE_CONIC) sys->all_conic = 0;
         if (r.shape_type == PRT_SHAPE_ASPHERE && sys->shape_level < PRT_SHAPES_ASPHERE) sys->shape_level = PRT_SHAPES_ASPHERE;
-        if (r.shape_type != PRT_SHAPE_CONIC && r.shape_type != PRT_SHAPE_ASPHERE) sys->shape_level = PRT_SHAPES_ALL;
+        if ((r.shape_type == PRT_SHAPE_XYPOLY || r.shape_type == PRT_SHAPE_BICONIC) && sys->shape_level < PRT_SHAPES_POLY)
+            sys->shape_level = PRT_SHAPES_POLY;
+        if (r.shape_type == PRT_SHAPE_COMBO || r.shape_type == PRT_SHAPE_GRIDSAG) sys->shape_level = PRT_SHAPES_ALL;
         memset(&d, 0, sizeof d);
         d.shape_type = r.shape_type;
         d.n_coeffs = r.n_coeffs;
@@ -527,28 +552,83 @@ int64_t prt_recommended_pitch(int64_t n) {
     return (n + 511) / 512 * 512;  // 4 KiB of doubles: every row starts on a 128-B line
 }
 
-static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
-                          const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
-                          int64_t out_pitch, double *x_hit, double *k_out, double *e_out,
-                          double *e_out_im, uint8_t *valid, uint8_t *valid_out, uint8_t *nonconv,
-                          void *stream, int32_t first_dir_mode = -1) {
-    // first_dir_mode: -1 = from E0 (e0_re NULL: E = ey), 0 = d = k/|k|, 3 = e0_re holds the unit directions
-    if (!sys || n0 < 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace: null system / negative count");
-    const int32_t e_mode_first = first_dir_mode >= 0 ? first_dir_mode : e_mode_of(e0_re, 1);
-    const int32_t packed_flags = (mode & PRT_MODE_FLAGS) ? 1 : 0;
+// a uniform first segment for the code paths that read per-ray arrays (the per-surface march): broadcast
+__global__ __launch_bounds__(PRT_BLOCK) void k_broadcast_rows(int64_t n, double v0, double v1, double v2,
+                                                              double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    out[i] = v0;
+    out[n + i] = v1;
+    out[2 * n + i] = v2;
+}
+
+static prt_trace_args_t blank_args() {
+    prt_trace_args_t a;
+    memset(&a, 0, sizeof a);
+    a.struct_bytes = (int32_t)sizeof a;
+    return a;
+}
+
+// One trace call with every option (include/prt.h, prt_trace_args_t); no timing loop here.
+static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) {
+    if (!sys || a.n0 < 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace: null system / negative count");
+    const int64_t n0 = a.n0;
+    int32_t mode = a.mode;
+    const int32_t packed_flags = (mode >= 0 && (mode & PRT_MODE_FLAGS)) ? 1 : 0;
     if (mode >= 0) mode &= ~PRT_MODE_FLAGS;
-    if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE)
-        return fail(PRT_ERR_INVALID_ARG, "prt_trace: bad mode");
+    if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE) return fail(PRT_ERR_INVALID_ARG, "prt_trace: bad mode");
     if (packed_flags && !sys->all_isotropic)
         return fail(PRT_ERR_UNSUPPORTED, "prt_trace: PRT_MODE_FLAGS needs an all-isotropic table");
-    if (n0 == 0) return PRT_OK;  // empty bundle: nothing to do (buffers may be NULL)
-    if (!x0 || !k0 || !x_hit || !k_out || !valid)
-        return fail(PRT_ERR_INVALID_ARG, "prt_trace: null pointer");
+    const bool moments = a.moments_out7_dev != nullptr;
+    if (moments && !a.moments_scratch_dev) return fail(PRT_ERR_INVALID_ARG, "prt_trace: moments need their scratch array");
+    if (moments && !sys->all_isotropic)
+        return fail(PRT_ERR_UNSUPPORTED, "prt_trace_moments: isotropic tables only (use prt_trace + prt_bundle_moments)");
+    // ---- the first segment ----
+    const bool uni = (a.k0 == nullptr);
+    int32_t e_mode;
+    const double *e_re = a.e0_re, *e_im = a.e0_im;
+    first_uniform fu;
+    memset(&fu, 0, sizeof fu);
+    for (int q = 0; q < 3; ++q) fu.k[q] = a.k_uniform[q];
+    switch (a.first_dir) {
+        case PRT_FIRST_E:
+            if (uni && e_re) return fail(PRT_ERR_INVALID_ARG, "prt_trace: E arrays need k arrays (k0 is NULL)");
+            e_mode = e_re ? 2 : 1;
+            break;
+        case PRT_FIRST_K:
+            e_mode = 0;
+            e_re = e_im = nullptr;
+            break;
+        case PRT_FIRST_DIR:
+            if (uni || !e_re) return fail(PRT_ERR_INVALID_ARG, "prt_trace: PRT_FIRST_DIR needs k0 and the directions in e0_re");
+            e_mode = 3;
+            e_im = nullptr;
+            break;
+        case PRT_FIRST_E_UNIFORM:
+        case PRT_FIRST_DIR_UNIFORM:
+            if (!uni) return fail(PRT_ERR_INVALID_ARG, "prt_trace: a uniform E / direction goes with a uniform k (k0 = NULL)");
+            e_mode = (a.first_dir == PRT_FIRST_E_UNIFORM) ? 2 : 3;
+            e_re = e_im = nullptr;
+            for (int q = 0; q < 3; ++q) {
+                fu.er[q] = a.e_uniform_re[q];
+                fu.ei[q] = (a.first_dir == PRT_FIRST_E_UNIFORM) ? a.e_uniform_im[q] : 0.0;
+            }
+            break;
+        default:
+            return fail(PRT_ERR_INVALID_ARG, "prt_trace: bad first_dir");
+    }
+    PRT_ON_DEVICE(sys->device);
+    hipStream_t st = (hipStream_t)a.stream;
+    if (n0 == 0) {  // empty bundle: nothing to trace (buffers may be NULL); the moments are zero
+        if (moments) HIP_TRY(hipMemsetAsync(a.moments_out7_dev, 0, sizeof(double) * MOM_VALUES, st));
+        return PRT_OK;
+    }
+    if (!a.x0 || !a.x_hit || !a.k_out || !a.valid) return fail(PRT_ERR_INVALID_ARG, "prt_trace: null pointer");
+    int64_t in_pitch = a.in_pitch, out_pitch = a.out_pitch;
     if (in_pitch == 0) in_pitch = n0;
     if (in_pitch < n0 || (out_pitch != 0 && out_pitch < n0))
         return fail(PRT_ERR_INVALID_ARG, "prt_trace: pitch smaller than the ray count");
-    PRT_ON_DEVICE(sys->device);
-    hipStream_t st = (hipStream_t)stream;
+    uint8_t *valid_out = a.valid_out;
     if (!sys->all_isotropic) {
         if (out_pitch != 0 || in_pitch != n0)
             return fail(PRT_ERR_INVALID_ARG,
@@ -561,11 +641,32 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
         // the per-surface march (one launch pair per surface, intermediate arrays) remains for
         // sequences with more crystal interfaces than the kernel has parking slots, and as the
         // independent implementation PRT_GENERAL_PER_SURFACE=1 selects for cross-checks.
-        if (per_surface || n_aniso > PRT_FUSED_MAX_CRYSTALS)
-            return trace_general(sys, n0, x0, k0, e0_re, e0_im, mode, x_hit, k_out, e_out, e_out_im, valid, valid_out,
-                                 nonconv, e_mode_first, st);
+        if (per_surface || n_aniso > PRT_FUSED_MAX_CRYSTALS) {
+            stream_scratch rows(st);
+            const double *k0 = a.k0;
+            if (uni) {  // the per-surface kernels read arrays: broadcast the uniform vectors once
+                double *kb = nullptr, *eb = nullptr, *ib = nullptr;
+                HIP_TRY(rows.get(&kb, sizeof(double) * 3 * n0));
+                hipLaunchKernelGGL(k_broadcast_rows, dim3(nblocks(n0, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st, n0, fu.k[0],
+                                   fu.k[1], fu.k[2], kb);
+                k0 = kb;
+                if (e_mode >= 2) {
+                    HIP_TRY(rows.get(&eb, sizeof(double) * 3 * n0));
+                    hipLaunchKernelGGL(k_broadcast_rows, dim3(nblocks(n0, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st, n0,
+                                       fu.er[0], fu.er[1], fu.er[2], eb);
+                    e_re = eb;
+                    if (e_mode == 2 && (fu.ei[0] != 0.0 || fu.ei[1] != 0.0 || fu.ei[2] != 0.0)) {
+                        HIP_TRY(rows.get(&ib, sizeof(double) * 3 * n0));
+                        hipLaunchKernelGGL(k_broadcast_rows, dim3(nblocks(n0, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st, n0,
+                                           fu.ei[0], fu.ei[1], fu.ei[2], ib);
+                        e_im = ib;
+                    }
+                }
+            }
+            return trace_general(sys, n0, a.x0, k0, e_re, e_im, mode, a.x_hit, a.k_out, a.e_out_re, a.e_out_im,
+                                 a.valid, valid_out, a.nonconv, e_mode, st);
+        }
         const dim3 grid(nblocks(n0, PRT_BLOCK)), block(PRT_BLOCK);
-        const int32_t e_mode_g = e_mode_first;
         bool general_eps = false;
         for (int s = 0; s < sys->n_surfaces; ++s)
             if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC &&
@@ -574,10 +675,15 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
         // few crystal interfaces: the parking slots of the depth-first walk fit into LDS
         const bool park_lds = n_aniso <= PRT_PARK_LDS_LEVELS;
         const size_t park_bytes = park_lds ? (size_t)n_aniso * PRT_BLOCK * (9 * sizeof(double) + 1) : 0;
-#define PRT_LAUNCH_GP(MODE_, GEN_, LDS_)                                                                      \
-    hipLaunchKernelGGL((k_trace_general<MODE_, GEN_, LDS_>), grid, block, park_bytes, st, sys->d_table,       \
-                       sys->n_surfaces, n_aniso, n0, x0, k0, e0_re, e0_im, e_mode_g, x_hit, k_out, e_out,     \
-                       e_out_im, valid, valid_out, nonconv)
+#define PRT_LAUNCH_GU(MODE_, GEN_, LDS_, UNI_)                                                                \
+    hipLaunchKernelGGL((k_trace_general<MODE_, GEN_, LDS_, UNI_>), grid, block, park_bytes, st, sys->d_table, \
+                       sys->n_surfaces, n_aniso, n0, a.x0, a.k0, e_re, e_im, e_mode, a.x_hit, a.k_out,        \
+                       a.e_out_re, a.e_out_im, a.valid, valid_out, a.nonconv, fu)
+#define PRT_LAUNCH_GP(MODE_, GEN_, LDS_)                   \
+    do {                                                   \
+        if (uni) PRT_LAUNCH_GU(MODE_, GEN_, LDS_, true);   \
+        else PRT_LAUNCH_GU(MODE_, GEN_, LDS_, false);      \
+    } while (0)
 #define PRT_LAUNCH_G(MODE_, GEN_)                        \
     do {                                                 \
         if (park_lds) PRT_LAUNCH_GP(MODE_, GEN_, true);  \
@@ -590,39 +696,141 @@ static int32_t trace_core(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
             if (general_eps) PRT_LAUNCH_G(PRT_MODE_IMAGE, true);
             else PRT_LAUNCH_G(PRT_MODE_IMAGE, false);
         }
+#undef PRT_LAUNCH_GU
 #undef PRT_LAUNCH_GP
 #undef PRT_LAUNCH_G
         HIP_TRY(hipGetLastError());
         return PRT_OK;
     }
+    // ---- all-isotropic table: the fused march ----
     if (out_pitch == 0) out_pitch = n0;
-    const int32_t e_mode = e_mode_first;
-    const bool vec_in = (in_pitch % 2 == 0) && aligned16(x0) && aligned16(k0) &&
-                        (!e0_re || aligned16(e0_re)) && (!e0_im || aligned16(e0_im));
+    const bool vec_in = (in_pitch % 2 == 0) && aligned16(a.x0) && (uni || aligned16(a.k0)) &&
+                        (!e_re || aligned16(e_re)) && (!e_im || aligned16(e_im));
     if (packed_flags) valid_out = nullptr;
-    const bool vec_out = (out_pitch % 2 == 0) && aligned16(x_hit) && aligned16(k_out) &&
-                         ((((uintptr_t)valid) & 1u) == 0) &&
+    uint8_t *nonconv = a.nonconv;
+    const bool vec_out = (out_pitch % 2 == 0) && aligned16(a.x_hit) && aligned16(a.k_out) &&
+                         ((((uintptr_t)a.valid) & 1u) == 0) &&
                          (!valid_out || (((uintptr_t)valid_out) & 1u) == 0) &&
                          (n0 % 2 == 0 || out_pitch > n0);  // odd N: the tail lane's 2nd ray lands in the padding
     if (nonconv && sys->all_conic)  // closed-form intersections only: nothing can hit an iteration cap
         HIP_TRY(hipMemsetAsync(nonconv, 0, (size_t)(mode == PRT_MODE_PATH ? sys->n_surfaces : 1) * (size_t)out_pitch, st));
     const bool vec_nc = !nonconv || (((uintptr_t)nonconv) & 1u) == 0;
-    if (mode == PRT_MODE_PATH)
-        launch_trace_iso<PRT_MODE_PATH>(sys, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch, x_hit, k_out,
-                                        valid, valid_out, vec_in, vec_out && vec_nc, packed_flags, nonconv, st);
-    else
-        launch_trace_iso<PRT_MODE_IMAGE>(sys, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch, x_hit, k_out,
-                                         valid, valid_out, vec_in, vec_out && vec_nc, packed_flags, nonconv, st);
+    const bool vec_all = vec_in && vec_out && vec_nc;
+    iso_launch L;
+    L.sys = sys;
+    L.n0 = n0;
+    L.in_pitch = in_pitch;
+    L.x0 = a.x0;
+    L.k0 = a.k0;
+    L.e_re = e_re;
+    L.e_im = e_im;
+    L.e_mode = e_mode;
+    L.out_pitch = out_pitch;
+    L.x_hit = a.x_hit;
+    L.k_out = a.k_out;
+    L.valid = a.valid;
+    L.valid_out = valid_out;
+    L.packed_flags = packed_flags;
+    L.nonconv = nonconv;
+    L.uni = uni;
+    L.fu = fu;
+    L.moments = moments && vec_all && !nonconv;
+    L.rx = L.ry = L.rz = 0.0;
+    L.partials = nullptr;
+    L.st = st;
+    if (moments) {
+        // reference point of the sums: the vertex of the last surface unless the caller names one
+        const prt_surface_t *last = sys->h_table + (sys->n_surfaces - 1);
+        L.rx = a.moments_ref3 ? a.moments_ref3[0] : last->g_shape[0];
+        L.ry = a.moments_ref3 ? a.moments_ref3[1] : last->g_shape[1];
+        L.rz = a.moments_ref3 ? a.moments_ref3[2] : last->g_shape[2];
+        L.partials = a.moments_scratch_dev;
+    }
+    if (mode == PRT_MODE_PATH) launch_trace_iso<PRT_MODE_PATH>(L, vec_in, vec_out && vec_nc);
+    else launch_trace_iso<PRT_MODE_IMAGE>(L, vec_in, vec_out && vec_nc);
+    if (L.moments) {
+        const unsigned nb = (unsigned)nblocks(n0, PRT_MARCH_BLOCK * 2);
+        const unsigned ng = (nb + PRT_BLOCK - 1) / PRT_BLOCK;
+        double *stage = a.moments_scratch_dev + (int64_t)MOM_VALUES * nb;
+        hipLaunchKernelGGL(k_moments_stage, dim3(ng), dim3(PRT_BLOCK), 0, st, (int)nb, a.moments_scratch_dev, stage);
+        hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, (int)ng, stage, a.moments_out7_dev);
+    } else if (moments) {
+        // unaligned or odd-pitch buffers: the plain trace above followed by the two-kernel reduction (with
+        // packed flags the selecting mask is bit 1 of the flags byte)
+        const int64_t row = (mode == PRT_MODE_PATH) ? (int64_t)(sys->n_surfaces - 1) : 0;
+        const uint8_t *mask = packed_flags ? a.valid + row * out_pitch : (valid_out ? valid_out + row * out_pitch : nullptr);
+        if (!mask) return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: valid_out is required for unaligned buffers");
+        int nbk = (int)((n0 + PRT_BLOCK * 8 - 1) / (PRT_BLOCK * 8));
+        if (nbk > 2048) nbk = 2048;
+        if (nbk < 1) nbk = 1;
+        hipLaunchKernelGGL(k_moments_partial, dim3(nbk), dim3(PRT_BLOCK), 0, st, n0, out_pitch,
+                           a.x_hit + row * 3 * out_pitch, mask, 0, L.rx, L.ry, L.rz, (const double *)nullptr, 0,
+                           a.moments_scratch_dev, packed_flags ? 2 : 0xff);
+        hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, nbk, a.moments_scratch_dev,
+                           a.moments_out7_dev);
+    }
     HIP_TRY(hipGetLastError());
     return PRT_OK;
+}
+
+int32_t prt_sizeof_trace_args(void) { return (int32_t)sizeof(prt_trace_args_t); }
+
+int32_t prt_trace_ex(const prt_system_t *sys, const prt_trace_args_t *args) {
+    if (!args) return fail(PRT_ERR_INVALID_ARG, "prt_trace_ex: null argument struct");
+    if (args->struct_bytes != (int32_t)sizeof(prt_trace_args_t))
+        return fail(PRT_ERR_INVALID_ARG, "prt_trace_ex: struct_bytes is not sizeof(prt_trace_args_t) of this library");
+    if (args->timed_iters <= 0) return trace_launch(sys, *args);
+    if (!args->ms_avg) return fail(PRT_ERR_INVALID_ARG, "prt_trace_ex: timed_iters without ms_avg");
+    if (!sys) return fail(PRT_ERR_INVALID_ARG, "null system");
+    PRT_ON_DEVICE(sys->device);
+    hipStream_t st = (hipStream_t)args->stream;
+    event_pair ev;
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+    HIP_TRY(hipEventRecord(ev.a, st));
+    for (int it = 0; it < args->timed_iters; ++it) {
+        int32_t rc = trace_launch(sys, *args);
+        if (rc != PRT_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(ev.b, st));
+    HIP_TRY(hipEventSynchronize(ev.b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+    *args->ms_avg = (double)ms / args->timed_iters;
+    return PRT_OK;
+}
+
+static prt_trace_args_t legacy_args(int64_t n0, int64_t in_pitch, const double *x0, const double *k0,
+                                    const double *e0_re, const double *e0_im, int32_t mode, int64_t out_pitch,
+                                    double *x_hit, double *k_out, uint8_t *valid, uint8_t *valid_out,
+                                    uint8_t *nonconv, void *stream) {
+    prt_trace_args_t a = blank_args();
+    a.mode = mode;
+    a.n0 = n0;
+    a.in_pitch = in_pitch;
+    a.x0 = x0;
+    a.k0 = k0;
+    a.e0_re = e0_re;
+    a.e0_im = e0_im;
+    a.first_dir = PRT_FIRST_E;
+    a.out_pitch = out_pitch;
+    a.x_hit = x_hit;
+    a.k_out = k_out;
+    a.valid = valid;
+    a.valid_out = valid_out;
+    a.nonconv = nonconv;
+    a.stream = stream;
+    return a;
 }
 
 int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
                   const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
                   int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
                   uint8_t *valid_out, uint8_t *nonconv, void *stream) {
-    return trace_core(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out,
-                      (double *)nullptr, (double *)nullptr, valid, valid_out, nonconv, stream);
+    if (n0 > 0 && !k0) return fail(PRT_ERR_INVALID_ARG, "prt_trace: null pointer (a uniform k0 is prt_trace_ex's)");
+    const prt_trace_args_t a = legacy_args(n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out, valid,
+                                           valid_out, nonconv, stream);
+    return trace_launch(sys, a);
 }
 
 // ---- one-call form: no handle for the caller to keep -----------------------
@@ -639,16 +847,10 @@ static std::mutex g_seq_mu;
 static seq_cache_entry g_seq_cache[PRT_SEQ_CACHE];
 static uint64_t g_seq_clock = 0;
 
-static int32_t seq_system(const prt_surface_t *table, int32_t S, int32_t device, prt_system **out, bool *owned) {
+// caller holds g_seq_mu (cacheable tables) -- the lock is kept until the launch is enqueued, so an entry cannot be
+// evicted between the lookup and the launch that uses its device table
+static int32_t seq_system_locked(const prt_surface_t *table, int32_t S, int32_t device, prt_system **out, bool *owned) {
     *owned = false;
-    bool cacheable = true;  // records that point to host data (grid-sag splines) are not compared by content
-    for (int s = 0; s < S; ++s)
-        if (table[s].aux) cacheable = false;
-    if (!cacheable) {
-        *owned = true;
-        return prt_system_create(table, S, device, out);
-    }
-    std::lock_guard<std::mutex> lock(g_seq_mu);
     int victim = 0;
     for (int i = 0; i < PRT_SEQ_CACHE; ++i) {
         seq_cache_entry &e = g_seq_cache[i];
@@ -672,7 +874,7 @@ static int32_t seq_system(const prt_surface_t *table, int32_t S, int32_t device,
     memcpy(copy, table, sizeof(prt_surface_t) * (size_t)S);
     seq_cache_entry &v = g_seq_cache[victim];
     if (v.sys) {
-        // work of earlier calls may still use the evicted table
+        // work of earlier calls may still use the evicted table (enqueued under this lock, so it is visible)
         device_guard guard_(v.device);
         (void)hipDeviceSynchronize();
         free_system(v.sys);
@@ -693,13 +895,30 @@ int32_t prt_trace_seq(const prt_surface_t *table, int32_t n_surfaces, int64_t n,
     (void)ray_id;  // outputs are dense: column i belongs to input ray i, whatever the caller calls it
     if (!table || n_surfaces <= 0 || n < 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace_seq: bad table / count");
     if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE) return fail(PRT_ERR_INVALID_ARG, "prt_trace_seq: bad mode");
+    if (n > 0 && !k0) return fail(PRT_ERR_INVALID_ARG, "prt_trace_seq: null pointer");
+    prt_trace_args_t a = legacy_args(n, 0, x0, k0, d0, nullptr, mode, 0, x_hit, k_out, valid, nullptr, nonconv, stream);
+    a.first_dir = d0 ? PRT_FIRST_DIR : PRT_FIRST_K;
+    bool cacheable = true;  // records that point to host data (grid-sag splines) are not compared by content
+    for (int s = 0; s < n_surfaces; ++s)
+        if (table[s].aux) cacheable = false;
     prt_system *sys = nullptr;
-    bool owned = false;
-    int32_t rc = seq_system(table, n_surfaces, device, &sys, &owned);
+    if (cacheable) {
+        std::lock_guard<std::mutex> lock(g_seq_mu);
+        bool owned = false;
+        int32_t rc = seq_system_locked(table, n_surfaces, device, &sys, &owned);
+        if (rc != PRT_OK) return rc;
+        rc = trace_launch(sys, a);
+        if (owned) {
+            device_guard guard_(device);
+            (void)hipStreamSynchronize((hipStream_t)stream);
+            free_system(sys);
+        }
+        return rc;
+    }
+    int32_t rc = prt_system_create(table, n_surfaces, device, &sys);
     if (rc != PRT_OK) return rc;
-    rc = trace_core(sys, n, 0, x0, k0, d0, nullptr, mode, 0, x_hit, k_out, (double *)nullptr, (double *)nullptr,
-                    valid, (uint8_t *)nullptr, nonconv, stream, d0 ? 3 : 0);
-    if (owned) {
+    rc = trace_launch(sys, a);
+    {
         device_guard guard_(device);
         (void)hipStreamSynchronize((hipStream_t)stream);
         free_system(sys);
@@ -712,8 +931,11 @@ int32_t prt_trace_fields(const prt_system_t *sys, int64_t n0, const double *x0, 
                          double *k_out, double *e_out_re, double *e_out_im, uint8_t *valid,
                          uint8_t *valid_out, void *stream) {
     if (!e_out_re) return fail(PRT_ERR_INVALID_ARG, "prt_trace_fields: e_out_re is NULL");
-    return trace_core(sys, n0, 0, x0, k0, e0_re, e0_im, mode, 0, x_hit, k_out, e_out_re, e_out_im, valid,
-                      valid_out, (uint8_t *)nullptr, stream);
+    if (n0 > 0 && !k0) return fail(PRT_ERR_INVALID_ARG, "prt_trace_fields: null pointer");
+    prt_trace_args_t a = legacy_args(n0, 0, x0, k0, e0_re, e0_im, mode, 0, x_hit, k_out, valid, valid_out, nullptr, stream);
+    a.e_out_re = e_out_re;
+    a.e_out_im = e_out_im;
+    return trace_launch(sys, a);
 }
 
 int64_t prt_trace_moments_scratch_doubles(int64_t n0) {
@@ -732,79 +954,13 @@ int32_t prt_trace_moments(const prt_system_t *sys, int64_t n0, int64_t in_pitch,
                           double *scratch_dev, void *stream) {
     if (!sys || n0 < 0 || !out7_dev || !scratch_dev)
         return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: bad argument");
-    if (!sys->all_isotropic)
-        return fail(PRT_ERR_UNSUPPORTED, "prt_trace_moments: isotropic tables only (use prt_trace + prt_bundle_moments)");
-    const int32_t mode_in = mode;
-    const int32_t packed_flags = (mode & PRT_MODE_FLAGS) ? 1 : 0;
-    if (mode >= 0) mode &= ~PRT_MODE_FLAGS;
-    if (packed_flags) valid_out = nullptr;
-    if (mode != PRT_MODE_PATH && mode != PRT_MODE_IMAGE)
-        return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: bad mode");
-    if (n0 > 0 && (!x0 || !k0 || !x_hit || !k_out || !valid))
-        return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: null pointer");
-    if (in_pitch == 0) in_pitch = n0;
-    if (out_pitch == 0) out_pitch = n0;
-    if (in_pitch < n0 || out_pitch < n0)
-        return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: pitch smaller than the ray count");
-    PRT_ON_DEVICE(sys->device);
-    hipStream_t st = (hipStream_t)stream;
-    const prt_surface_t *last = sys->h_table + (sys->n_surfaces - 1);
-    // reference point of the sums: the vertex of the last surface unless the caller names one
-    const double rx = ref3 ? ref3[0] : last->g_shape[0];
-    const double ry = ref3 ? ref3[1] : last->g_shape[1];
-    const double rz = ref3 ? ref3[2] : last->g_shape[2];
-    const bool vec_in = (in_pitch % 2 == 0) && aligned16(x0) && aligned16(k0) &&
-                        (!e0_re || aligned16(e0_re)) && (!e0_im || aligned16(e0_im));
-    const bool vec_out = (out_pitch % 2 == 0) && aligned16(x_hit) && aligned16(k_out) &&
-                         ((((uintptr_t)valid) & 1u) == 0) &&
-                         (!valid_out || (((uintptr_t)valid_out) & 1u) == 0) &&
-                         (n0 % 2 == 0 || out_pitch > n0);
-    if (n0 > 0 && vec_in && vec_out) {
-        const unsigned nb = (unsigned)nblocks(n0, PRT_MARCH_BLOCK * 2);
-        const dim3 grid(nb), block(PRT_MARCH_BLOCK);
-        const int32_t e_mode = e_mode_of(e0_re, 1);
-#define PRT_LAUNCH_M(MODE_, EX)                                                                           \
-    hipLaunchKernelGGL((k_trace_iso<MODE_, true, true, EX, false, true>), grid, block, 0, st, sys->d_table, \
-                       sys->n_surfaces, n0, in_pitch, x0, k0, e0_re, e0_im, e_mode, out_pitch, x_hit,     \
-                       k_out, valid, valid_out, rx, ry, rz, scratch_dev, packed_flags)
-        if (mode == PRT_MODE_PATH) {
-            if (sys->shape_level == PRT_SHAPES_CONIC) PRT_LAUNCH_M(PRT_MODE_PATH, PRT_SHAPES_CONIC);
-            else if (sys->shape_level == PRT_SHAPES_ASPHERE) PRT_LAUNCH_M(PRT_MODE_PATH, PRT_SHAPES_ASPHERE);
-            else PRT_LAUNCH_M(PRT_MODE_PATH, PRT_SHAPES_ALL);
-        } else {
-            if (sys->shape_level == PRT_SHAPES_CONIC) PRT_LAUNCH_M(PRT_MODE_IMAGE, PRT_SHAPES_CONIC);
-            else if (sys->shape_level == PRT_SHAPES_ASPHERE) PRT_LAUNCH_M(PRT_MODE_IMAGE, PRT_SHAPES_ASPHERE);
-            else PRT_LAUNCH_M(PRT_MODE_IMAGE, PRT_SHAPES_ALL);
-        }
-#undef PRT_LAUNCH_M
-        const unsigned ng = (nb + PRT_BLOCK - 1) / PRT_BLOCK;
-        double *stage = scratch_dev + (int64_t)MOM_VALUES * nb;
-        hipLaunchKernelGGL(k_moments_stage, dim3(ng), dim3(PRT_BLOCK), 0, st, (int)nb, scratch_dev, stage);
-        hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, (int)ng, stage, out7_dev);
-        HIP_TRY(hipGetLastError());
-        return PRT_OK;
-    }
-    // empty, unaligned or odd-pitch buffers: the plain trace followed by the two-kernel reduction (with
-    // packed flags the selecting mask is bit 1 of the flags byte)
-    if (n0 > 0) {
-        int32_t rc = prt_trace(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode_in, out_pitch, x_hit, k_out, valid,
-                               valid_out, (uint8_t *)nullptr, stream);
-        if (rc != PRT_OK) return rc;
-    }
-    const int64_t row = (mode == PRT_MODE_PATH) ? (int64_t)(sys->n_surfaces - 1) : 0;
-    const uint8_t *mask = packed_flags ? (valid ? valid + row * out_pitch : nullptr)
-                                       : (valid_out ? valid_out + row * out_pitch : nullptr);
-    if (n0 > 0 && !mask)
-        return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: valid_out is required for unaligned buffers");
-    int nbk = (int)((n0 + PRT_BLOCK * 8 - 1) / (PRT_BLOCK * 8));
-    if (nbk > 2048) nbk = 2048;
-    if (nbk < 1) nbk = 1;
-    hipLaunchKernelGGL(k_moments_partial, dim3(nbk), dim3(PRT_BLOCK), 0, st, n0, out_pitch,
-                       x_hit + row * 3 * out_pitch, mask, 0, rx, ry, rz, (const double *)nullptr, 0,
-                       scratch_dev, packed_flags ? 2 : 0xff);
-    hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, nbk, scratch_dev, out7_dev);
-    HIP_TRY(hipGetLastError());
-    return PRT_OK;
+    if (n0 > 0 && !k0) return fail(PRT_ERR_INVALID_ARG, "prt_trace_moments: null pointer");
+    prt_trace_args_t a = legacy_args(n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out, valid,
+                                     valid_out, nullptr, stream);
+    a.moments_ref3 = ref3;
+    a.moments_out7_dev = out7_dev;
+    a.moments_scratch_dev = scratch_dev;
+    return trace_launch(sys, a);
 }
 
 int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
@@ -812,24 +968,12 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
                         int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,
                         uint8_t *valid_out, void *stream, int32_t iters, double *ms_avg) {
     if (!ms_avg || iters <= 0) return fail(PRT_ERR_INVALID_ARG, "prt_trace_timed");
-    if (!sys) return fail(PRT_ERR_INVALID_ARG, "null system");
-    PRT_ON_DEVICE(sys->device);
-    hipStream_t st = (hipStream_t)stream;
-    event_pair ev;
-    HIP_TRY(hipEventCreate(&ev.a));
-    HIP_TRY(hipEventCreate(&ev.b));
-    HIP_TRY(hipEventRecord(ev.a, st));
-    for (int it = 0; it < iters; ++it) {
-        int32_t rc = prt_trace(sys, n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out,
-                               valid, valid_out, (uint8_t *)nullptr, stream);
-        if (rc != PRT_OK) return rc;
-    }
-    HIP_TRY(hipEventRecord(ev.b, st));
-    HIP_TRY(hipEventSynchronize(ev.b));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
-    *ms_avg = (double)ms / iters;
-    return PRT_OK;
+    if (n0 > 0 && !k0) return fail(PRT_ERR_INVALID_ARG, "prt_trace_timed: null pointer");
+    prt_trace_args_t a = legacy_args(n0, in_pitch, x0, k0, e0_re, e0_im, mode, out_pitch, x_hit, k_out, valid,
+                                     valid_out, nullptr, stream);
+    a.timed_iters = iters;
+    a.ms_avg = ms_avg;
+    return prt_trace_ex(sys, &a);
 }
 
 int32_t prt_propagate(const prt_system_t *sys, int32_t surface, int64_t n, const double *x,
@@ -949,7 +1093,7 @@ int32_t prt_collimated_bundle(int32_t device, int64_t nray, int64_t lo, int64_t 
                               double *k_out, double *e_out, void *stream) {
     if (nray < 1 || !prm || lo < 0 || hi < lo) return fail(PRT_ERR_INVALID_ARG, "prt_collimated_bundle");
     if (hi == lo) return PRT_OK;
-    if (!x_out || !k_out) return fail(PRT_ERR_INVALID_ARG, "prt_collimated_bundle: null pointer");
+    if (!x_out) return fail(PRT_ERR_INVALID_ARG, "prt_collimated_bundle: null pointer");
     if (pitch == 0) pitch = hi - lo;
     if (pitch < hi - lo) return fail(PRT_ERR_INVALID_ARG, "prt_collimated_bundle: pitch < hi - lo");
     PRT_ON_DEVICE(device);
@@ -1039,7 +1183,7 @@ int32_t prt_raster_bundle(int32_t device, const prt_raster_t *raster, int64_t lo
     if (!prm || lo < 0 || hi < lo || prm->kind < 0 || prm->kind > 1)
         return fail(PRT_ERR_INVALID_ARG, "prt_raster_bundle: bad argument");
     if (hi == lo) return PRT_OK;
-    if (!x_out || !k_out) return fail(PRT_ERR_INVALID_ARG, "prt_raster_bundle: null pointer");
+    if (!x_out || (!k_out && prm->kind != 0)) return fail(PRT_ERR_INVALID_ARG, "prt_raster_bundle: null pointer");
     if (pitch == 0) pitch = hi - lo;
     if (pitch < hi - lo) return fail(PRT_ERR_INVALID_ARG, "prt_raster_bundle: pitch < hi - lo");
     PRT_ON_DEVICE(device);

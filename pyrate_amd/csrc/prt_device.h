@@ -396,10 +396,15 @@ PRT_DEV void gridsag_eval(const prt_dev_surface *__restrict__ sf, double x, doub
 }
 
 // Which shape code a kernel instantiation carries (the host picks the level from the table's content):
-// 0: conics only; 1: conics and even aspheres; 2: every shape.  Fewer shapes = fewer VGPRs = more waves.
+// 0: conics only; 1: conics and even aspheres; 2: conics, even aspheres, XY polynomials (also the monomial
+// expansions of Zernike surfaces) and biconics -- the explicit shapes BASELINE's north_star names plus SURVEY
+// 8 f3 --, all of them fed by scalar loads only; 3: every shape (adds the sag grid, whose spline data is
+// indexed per ray = vector loads inside the Newton loop, and the asphere + polynomial combination).
+// Fewer shapes = fewer VGPRs = more waves.
 #define PRT_SHAPES_CONIC 0
 #define PRT_SHAPES_ASPHERE 1
-#define PRT_SHAPES_ALL 2
+#define PRT_SHAPES_POLY 2
+#define PRT_SHAPES_ALL 3
 
 // explicit z = F(x,y) shapes: value and in-plane derivatives
 template <int SHAPES = PRT_SHAPES_ALL>
@@ -412,9 +417,9 @@ PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, const asphere
         Fy = y * m;
     } else if (sf->shape_type == PRT_SHAPE_BICONIC) {
         biconic_eval(sf, x, y, F, Fx, Fy);
-    } else if (sf->shape_type == PRT_SHAPE_GRIDSAG) {
+    } else if (SHAPES == PRT_SHAPES_ALL && sf->shape_type == PRT_SHAPE_GRIDSAG) {
         gridsag_eval(sf, x, y, F, Fx, Fy);
-    } else if (sf->shape_type == PRT_SHAPE_COMBO) {
+    } else if (SHAPES == PRT_SHAPES_ALL && sf->shape_type == PRT_SHAPE_COMBO) {
         // LinearCombination.F / gradF (surface_shape.py:713-748) of one conic / asphere part and
         // polynomial parts, merged by the host: scale * asphere + sum c_ij x^i y^j
         double Fa, m;

@@ -138,6 +138,21 @@ PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
     }
 }
 
+// The UNIFORM first segment (prt_trace_ex, k0 == NULL): the bundles of the reference's analysis layer are
+// collimated (analysis/optical_system_analysis.py:83-122) -- one wave vector and one E field for all rays.  The
+// values travel as kernel arguments (scalar registers); every lane runs the per-ray arithmetic of
+// first_direction on them, so the results equal the array form bit for bit, and only x0 is loaded.
+struct first_uniform {
+    double k[3], er[3], ei[3];
+};
+PRT_DEV vec3 uniform_first_direction(int e_mode, const first_uniform &fu, const vec3 &k) {
+    const vec3 er = v3(fu.er[0], fu.er[1], fu.er[2]);
+    if (e_mode == 0) return normalized(k);
+    if (e_mode == 1) return poynting_dir(k, v3(0, 1, 0), v3(0, 0, 0));
+    if (e_mode == 3) return er;
+    return poynting_dir(k, er, v3(fu.ei[0], fu.ei[1], fu.ei[2]));
+}
+
 // ---------------------------------------------------------------------------
 // fused isotropic march: OpticalElement.seqtrace's loop (optical_element.py:336-375)
 // ---------------------------------------------------------------------------
@@ -170,8 +185,10 @@ PRT_DEV void first_direction(int e_mode, const double *__restrict__ e_re,
 #endif
 // Image mode of the all-conic march is FP64-VALU bound: 8 waves/SIMD (63 VGPRs, no spills) instead
 // of the allocator's 7 is worth 5 % there (0.47 -> 0.446 ms); path mode is HBM bound and unaffected.
+// UNI = true: the uniform first segment, decided at compile time (the aligned instantiations); the unaligned
+// fall-back instantiations (VEC_IN / VEC_OUT false) decide at run time (uni_rt) instead of doubling their number.
 template <int MODE, bool VEC_IN, bool VEC_OUT, int SHAPES = PRT_SHAPES_ALL, bool LDS_TAB = false,
-          bool MOMENTS = false>
+          bool MOMENTS = false, bool UNI = false>
 #ifndef PRT_PATH_WAVES
 #define PRT_PATH_WAVES 1
 #endif
@@ -190,14 +207,17 @@ __attribute__((amdgpu_waves_per_eu(1, PRT_PATH_WAVES_MAX)))
 #ifndef PRT_ASPHERE_WAVES
 #define PRT_ASPHERE_WAVES 5
 #endif
-__global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LDS_TAB) ? (MODE == PRT_MODE_IMAGE ? 8 : PRT_PATH_WAVES) : (SHAPES == PRT_SHAPES_ASPHERE ? PRT_ASPHERE_WAVES : 1)) void k_trace_iso(
+#ifndef PRT_POLY_WAVES
+#define PRT_POLY_WAVES 5
+#endif
+__global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LDS_TAB) ? (MODE == PRT_MODE_IMAGE ? 8 : PRT_PATH_WAVES) : (SHAPES == PRT_SHAPES_ASPHERE ? PRT_ASPHERE_WAVES : (SHAPES == PRT_SHAPES_POLY ? PRT_POLY_WAVES : 1))) void k_trace_iso(
     const prt_dev_surface *__restrict__ tab_g, int32_t S, int64_t N, int64_t in_pitch,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, int64_t out_pitch,
     double *__restrict__ xh_out, double *__restrict__ k_out, uint8_t *__restrict__ valid_out_hit,
     uint8_t *__restrict__ valid_out_refr, double mref_x = 0.0, double mref_y = 0.0,
     double mref_z = 0.0, double *__restrict__ moment_partials = nullptr, int32_t packed_flags = 0,
-    uint8_t *__restrict__ nonconv_out = nullptr) {
+    uint8_t *__restrict__ nonconv_out = nullptr, first_uniform fu = first_uniform(), int32_t uni_rt = 0) {
     const prt_dev_surface *__restrict__ tab = tab_g;
     if (LDS_TAB) {
         __shared__ prt_dev_surface lds_tab[PRT_LDS_TAB_MAX];
@@ -216,8 +236,13 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
     bool valid[2] = {true, true};
     if (i < N) {  // (always true without MOMENTS; with MOMENTS the tail threads join the reduction)
     rayio<VEC_IN>::load(x0, in_pitch, i, second, x);
-    rayio<VEC_IN>::load(k0, in_pitch, i, second, k);
-    first_direction<VEC_IN>(e_mode, e_re, e_im, in_pitch, i, second, k, d);
+    if (UNI || (!(VEC_IN && VEC_OUT) && uni_rt)) {
+        k[0] = k[1] = v3(fu.k[0], fu.k[1], fu.k[2]);
+        d[0] = d[1] = uniform_first_direction(e_mode, fu, k[0]);
+    } else {
+        rayio<VEC_IN>::load(k0, in_pitch, i, second, k);
+        first_direction<VEC_IN>(e_mode, e_re, e_im, in_pitch, i, second, k, d);
+    }
     double d2 = 1.0;  // |d|^2: unit Poynting direction on the first segment
     // no input load may still be in flight when the march starts: see PRT_WAIT_VMEM_LOADS
     PRT_WAIT_VMEM_LOADS();
@@ -365,22 +390,25 @@ PRT_DEV PRT_GLOBAL_AS T *uniform_ptr(T *p) {
     return (PRT_GLOBAL_AS T *)(((uint64_t)hi << 32) | lo);
 }
 
-template <int MODE, bool GENERAL = true, bool PARK_LDS = false>
+template <int MODE, bool GENERAL = true, bool PARK_LDS = false, bool UNI = false>
 __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
     const prt_dev_surface *__restrict__ tab, int32_t S, int32_t A, int64_t N,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, double *__restrict__ xh_out,
     double *__restrict__ k_out, double *__restrict__ e_out, double *__restrict__ e_out_im,
     uint8_t *__restrict__ valid_out_hit, uint8_t *__restrict__ valid_out_refr,
-    uint8_t *__restrict__ nonconv_out = nullptr) {
+    uint8_t *__restrict__ nonconv_out = nullptr, first_uniform fu = first_uniform()) {
     const uint32_t tid = threadIdx.x;
     const int64_t blk = (int64_t)blockIdx.x * PRT_BLOCK;
     const int64_t i = blk + tid;
     if (i >= N) return;
     vec3 x = v3(x0[i], x0[N + i], x0[2 * N + i]);
-    vec3 k = v3(k0[i], k0[N + i], k0[2 * N + i]);
-    vec3 d;
-    {
+    vec3 k, d;
+    if (UNI) {  // uniform first segment: only x0 is read
+        k = v3(fu.k[0], fu.k[1], fu.k[2]);
+        d = uniform_first_direction(e_mode, fu, k);
+    } else {
+        k = v3(k0[i], k0[N + i], k0[2 * N + i]);
         vec3 kk[2] = {k, k};
         vec3 dd[2];
         first_direction<false>(e_mode, e_re, e_im, N, i, false, kk, dd);
@@ -999,9 +1027,11 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_rectgrid_scatter(
         x_out[o] = add_rn(mul_rn(prm.radius, px), prm.startx);
         x_out[pitch + o] = add_rn(mul_rn(prm.radius, py), prm.starty);
         x_out[2 * pitch + o] = prm.startz;
-        k_out[o] = prm.k[0];
-        k_out[pitch + o] = prm.k[1];
-        k_out[2 * pitch + o] = prm.k[2];
+        if (k_out) {  // NULL: the caller keeps the bundle's k and E as one vector each (uniform first segment)
+            k_out[o] = prm.k[0];
+            k_out[pitch + o] = prm.k[1];
+            k_out[2 * pitch + o] = prm.k[2];
+        }
         if (e_out) {
             e_out[o] = prm.e[0];
             e_out[pitch + o] = prm.e[1];
@@ -1097,9 +1127,11 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_raster_bundle(
             const vec3 a = (fy <= fx && fy <= fz) ? v3(0, 1, 0) : ((fx <= fz) ? v3(1, 0, 0) : v3(0, 0, 1));
             e = normalized(cross(k, a));
         }
-        k_out[o] = k.x;
-        k_out[pitch + o] = k.y;
-        k_out[2 * pitch + o] = k.z;
+        if (k_out) {
+            k_out[o] = k.x;
+            k_out[pitch + o] = k.y;
+            k_out[2 * pitch + o] = k.z;
+        }
         if (e_out) {
             e_out[o] = e.x;
             e_out[pitch + o] = e.y;

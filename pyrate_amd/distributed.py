@@ -29,9 +29,12 @@ def shard_stride(n_total, world):
 
 def shard_range(n_total, rank, world):
     """Contiguous, ordered slices of EQUAL STRIDE: rank r owns [r*n_pad, min((r+1)*n_pad, N)) with
-    n_pad = ceil(N / world) -- only the last rank is short (by less than ``world`` rays).  With one
-    common stride, ray i of rank r is global ray r*n_pad + i, so an all-gather of one row lands in
-    global ray order as it is (ImagePlaneGather needs no repacking)."""
+    n_pad = ceil(N / world).  All ranks together are short by world*n_pad - N < world rays; for N >> world
+    that is the last rank alone, for tiny bundles several trailing ranks can be short or EMPTY (N = 9,
+    world = 8: ranks 0..3 own 2 rays, rank 4 one, ranks 5..7 none) -- callers must cope with zero-size
+    shards (the trace, the gather and the statistics do).  With one common stride, ray i of rank r is
+    global ray r*n_pad + i, so an all-gather of one row lands in global ray order as it is
+    (ImagePlaneGather needs no repacking)."""
     n_pad = shard_stride(n_total, world)
     lo = min(rank * n_pad, n_total)
     return lo, min(lo + n_pad, n_total)
@@ -46,7 +49,7 @@ def _row_of(t2d, row, start, n, n_pad):
     whatever follows them in memory up to the common stride (padding of a pitched row, the next
     branch, the next row -- never looked at by anybody).  None if the storage ends before that."""
     if n_pad == n:
-        return t2d[row, start:start + n]
+        return t2d[row, start:start + n] if (n == 0 or t2d.stride(1) == 1) else None   # collectives need contiguous rows
     off = t2d.storage_offset() + row * t2d.stride(0) + start * t2d.stride(1)
     room = t2d.untyped_storage().nbytes() // t2d.element_size() - off
     if t2d.stride(1) != 1 or room < n_pad:
@@ -229,12 +232,13 @@ class SpotStatistics(object):
         if self.multi:
             dist.all_reduce(m2, op=dist.ReduceOp.SUM, group=self.group)
 
-    def trace_and_start(self, sysd, x0, k0, bufs, e0_re=None, e0_im=None):
+    def trace_and_start(self, sysd, x0, k0, bufs, e0_re=None, e0_im=None, uniform=None):
         """Fused form: the trace kernel itself reduces the shard's moments about the vertex of the
         last surface (prt_trace_moments); ONE 7-double all-reduce combines the shards.  Call on the
-        stream the trace should run on; ``reduce()`` may be issued on another stream afterwards."""
+        stream the trace should run on; ``reduce()`` may be issued on another stream afterwards.
+        ``uniform``: the bundle's uniform first segment instead of k0 / e0 (engine.UniformFirst)."""
         self._fused_ref = sysd.moments_reference()
-        return sysd.trace_moments_into(x0, k0, bufs, self.ws, slot=0, e0_re=e0_re, e0_im=e0_im)
+        return sysd.trace_moments_into(x0, k0, bufs, self.ws, slot=0, e0_re=e0_re, e0_im=e0_im, uniform=uniform)
 
     def reduce(self):
         """the all-reduce of the fused form (current stream)"""

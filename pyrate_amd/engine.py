@@ -50,6 +50,52 @@ def recommended_pitch(n):
     return int(_lib.load().prt_recommended_pitch(n))
 
 
+class UniformFirst(object):
+    """The first segment of a collimated bundle (OpticalSystemAnalysis.collimated_bundle,
+    analysis/optical_system_analysis.py:83-122): ONE wave vector -- and one E field or direction -- for all
+    rays.  Passed as ``uniform=`` to the whole-sequence traces instead of (3, N) arrays k0 / E0: the march then
+    loads only x0 (prt_trace_ex, k0 = NULL) and produces bit-identical results.
+
+    ``kind``: "e" -- direction = Poynting direction of (k, e); e None means E = (0,1,0) like a RayBundle
+    created without a field (ray.py:71-73); "k" -- direction = k/|k|; "dir" -- ``e`` is the unit direction."""
+
+    def __init__(self, k, e=None, kind="e"):
+        if kind not in ("e", "k", "dir"):
+            raise ValueError("kind must be 'e', 'k' or 'dir'")
+        if kind == "dir" and e is None:
+            raise ValueError("kind 'dir' needs the direction")
+        self.k = tuple(float(np.real(v)) for v in k)
+        e = None if e is None else np.asarray(e, dtype=complex).reshape(3)
+        self.e_re = None if e is None else tuple(float(v) for v in e.real)
+        self.e_im = None if e is None else tuple(float(v) for v in e.imag)
+        self.kind = kind
+
+    def _first_dir(self):
+        if self.kind == "k":
+            return _lib.FIRST_K
+        if self.kind == "dir":
+            return _lib.FIRST_DIR_UNIFORM
+        return _lib.FIRST_E if self.e_re is None else _lib.FIRST_E_UNIFORM
+
+    def fill(self, args):
+        args.k0 = None
+        args.e0_re = None
+        args.e0_im = None
+        args.first_dir = self._first_dir()
+        for q in range(3):
+            args.k_uniform[q] = self.k[q]
+            args.e_uniform_re[q] = self.e_re[q] if self.e_re is not None else 0.0
+            args.e_uniform_im[q] = self.e_im[q] if self.e_im is not None else 0.0
+
+    def rows(self, n, device, what="k"):
+        """the (3, n) array this stands for, as an expanded (stride-0) view of three numbers on the device:
+        what a consumer of RayBundle.k / .Efield sees; ``.contiguous()`` materialises it"""
+        v = {"k": self.k, "e_re": self.e_re, "e_im": self.e_im}[what]
+        if v is None:
+            return None
+        return torch.tensor(v, dtype=torch.float64, device=device).view(3, 1).expand(3, n)
+
+
 class _LazyViews(object):
     """list-like: per-surface tensor views created on first access (a 12-surface path has 48
     of them; an optimiser loop that only looks at the image plane should not pay for all)"""
@@ -279,26 +325,48 @@ class DeviceSystem(object):
         return bufs
 
     # -- whole sequence ----------------------------------------------------
-    def trace_into(self, x0, k0, bufs, e0_re=None, e0_im=None):
-        """Asynchronous launch into preallocated buffers (see alloc_outputs)."""
+    def _trace_args(self, x0, k0, bufs, e0_re=None, e0_im=None, uniform=None, first_dir=None):
+        """prt_trace_args_t for one trace into ``bufs``.  ``uniform`` (a UniformFirst) replaces k0 / E0."""
         n0 = x0.shape[1]
-        if not self.all_isotropic:      # per-surface march: tight arrays
+        if uniform is None and k0 is None:
+            raise ValueError("k0 is required (or a uniform first segment)")
+        if uniform is not None:
+            (k0, e0_re, e0_im) = (None, None, None)
+        if not self.all_isotropic:      # crystal march: tight arrays
             (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
+        a = _lib.PrtTraceArgs()
+        a.struct_bytes = ctypes.sizeof(_lib.PrtTraceArgs)
+        a.mode = _mode_word(bufs)
+        a.n0 = n0
+        a.in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
+        a.x0 = x0.data_ptr() if n0 else None
+        if uniform is not None:
+            uniform.fill(a)
+        else:
+            a.k0 = k0.data_ptr() if n0 else None
+            a.e0_re = None if e0_re is None else e0_re.data_ptr()
+            a.e0_im = None if e0_im is None else e0_im.data_ptr()
+            a.first_dir = _lib.FIRST_E if first_dir is None else first_dir
+        a.out_pitch = bufs["pitch"]
+        for name in ("x_hit", "k_out", "valid", "valid_out", "nonconv"):
+            t = bufs.get(name)
+            setattr(a, name, None if t is None else t.data_ptr())
         if bufs.get("e_re") is not None:
-            _lib.check(self.lib.prt_trace_fields(self._h, n0, _ptr(x0), _ptr(k0), _ptr(e0_re), _ptr(e0_im),
-                                                 bufs["mode"], _ptr(bufs["x_hit"]), _ptr(bufs["k_out"]),
-                                                 _ptr(bufs["e_re"]), _ptr(bufs["e_im"]),
-                                                 _ptr(bufs["valid"]), _ptr(bufs["valid_out"]),
-                                                 _stream_handle(self.device)))
-            return
-        in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
-        _lib.check(self.lib.prt_trace(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
-                                      _ptr(e0_im), _mode_word(bufs), bufs["pitch"], _ptr(bufs["x_hit"]),
-                                      _ptr(bufs["k_out"]), _ptr(bufs["valid"]),
-                                      _ptr(bufs["valid_out"]), _ptr(bufs.get("nonconv")),
-                                      _stream_handle(self.device)))
+            a.e_out_re = bufs["e_re"].data_ptr()
+            a.e_out_im = bufs["e_im"].data_ptr()
+        a.stream = torch.cuda.current_stream(self.device).cuda_stream
+        a._keep = (x0, k0, e0_re, e0_im)       # tight copies must outlive the launch call
+        return a
 
-    def trace_moments_into(self, x0, k0, bufs, ws, slot=0, e0_re=None, e0_im=None, ref=None):
+    def trace_into(self, x0, k0, bufs, e0_re=None, e0_im=None, uniform=None, first_dir=None):
+        """Asynchronous launch into preallocated buffers (see alloc_outputs).  ``uniform``: a UniformFirst
+        instead of the arrays k0 / e0 (collimated bundles); ``first_dir``: _lib.FIRST_K / FIRST_DIR for
+        bundles whose first direction is k/|k| / given in e0_re."""
+        a = self._trace_args(x0, k0, bufs, e0_re, e0_im, uniform, first_dir)
+        _lib.check(self.lib.prt_trace_ex(self._h, ctypes.byref(a)))
+
+    def trace_moments_into(self, x0, k0, bufs, ws, slot=0, e0_re=None, e0_im=None, ref=None, uniform=None,
+                           first_dir=None):
         """trace_into + the image-plane moments of the traced bundle from the same launch
         (prt_trace_moments): ws.out[slot] = {count, sum v, sum v*v}, v = x_img - ref (default: vertex
         of the last surface), over the rays valid after the last surface.  See ``spot_from_moments``."""
@@ -306,13 +374,13 @@ class DeviceSystem(object):
         need = self.lib.prt_trace_moments_scratch_doubles(n0)
         if ws.scratch.numel() < need:
             raise ValueError("MomentsWorkspace too small: construct it with n_rays >= %d" % n0)
-        in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
+        a = self._trace_args(x0, k0, bufs, e0_re, e0_im, uniform, first_dir)
         ref3 = None if ref is None else (ctypes.c_double * 3)(*[float(v) for v in ref])
-        _lib.check(self.lib.prt_trace_moments(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
-                                              _ptr(e0_im), _mode_word(bufs), bufs["pitch"], _ptr(bufs["x_hit"]),
-                                              _ptr(bufs["k_out"]), _ptr(bufs["valid"]),
-                                              _ptr(bufs["valid_out"]), ref3, _ptr(ws.out[slot]),
-                                              _ptr(ws.scratch), _stream_handle(self.device)))
+        if ref3 is not None:
+            a.moments_ref3 = ctypes.cast(ref3, ctypes.POINTER(ctypes.c_double))
+        a.moments_out7_dev = ws.out[slot].data_ptr()
+        a.moments_scratch_dev = ws.scratch.data_ptr()
+        _lib.check(self.lib.prt_trace_ex(self._h, ctypes.byref(a)))
         return ws.out[slot]
 
     def moments_reference(self):
@@ -329,27 +397,24 @@ class DeviceSystem(object):
                 raise ValueError("x0, k0 and E0 must share one row pitch")
         return pitch
 
-    def trace_timed(self, x0, k0, bufs, iters, e0_re=None, e0_im=None):
-        """Average device milliseconds per prt_trace launch (HIP events on the launch
-        stream, inside libprt)."""
+    def trace_timed(self, x0, k0, bufs, iters, e0_re=None, e0_im=None, uniform=None):
+        """Average device milliseconds per trace launch (HIP events on the launch stream, inside libprt)."""
         ms = ctypes.c_double()
-        n0 = x0.shape[1]
-        if not self.all_isotropic:
-            (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
-        in_pitch = self._in_pitch(x0, k0, e0_re, e0_im)
-        _lib.check(self.lib.prt_trace_timed(self._h, n0, in_pitch, _ptr(x0), _ptr(k0), _ptr(e0_re),
-                                            _ptr(e0_im), _mode_word(bufs), bufs["pitch"],
-                                            _ptr(bufs["x_hit"]), _ptr(bufs["k_out"]),
-                                            _ptr(bufs["valid"]), _ptr(bufs["valid_out"]),
-                                            _stream_handle(self.device), iters, ctypes.byref(ms)))
+        a = self._trace_args(x0, k0, bufs, e0_re, e0_im, uniform)
+        a.timed_iters = iters
+        a.ms_avg = ctypes.pointer(ms)
+        _lib.check(self.lib.prt_trace_ex(self._h, ctypes.byref(a)))
         return ms.value
 
     def trace(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH, want_fields=False,
-              packed_flags=False, want_nonconv=False):
+              packed_flags=False, want_nonconv=False, uniform=None, first_dir=None):
         """OpticalSystem.seqtrace on device tensors; returns a TraceResult of views.
+        ``uniform``: a UniformFirst instead of k0 / e0 (collimated bundle: k0 may be None).
         ``want_nonconv``: also fill ``TraceResult.nonconv`` (per surface, 1 where the Newton iteration of
         an explicit shape ended at its cap; with ``packed_flags`` it is always there, bit 2 of the flags)."""
         n0 = x0.shape[1]
+        if uniform is not None:
+            (k0, e0_re, e0_im) = (None, None, None)
         pitches = set()
         for (t, name) in ((x0, "x0"), (k0, "k0"), (e0_re, "e0_re"), (e0_im, "e0_im")):
             if t is not None:
@@ -361,7 +426,7 @@ class DeviceSystem(object):
             bufs = self.alloc_outputs(n0, mode, want_fields=want_fields,
                                       packed_flags=packed_flags and self.all_isotropic,
                                       want_nonconv=want_nonconv and not want_fields)
-            self.trace_into(x0, k0, bufs, e0_re, e0_im)
+            self.trace_into(x0, k0, bufs, e0_re, e0_im, uniform=uniform, first_dir=first_dir)
         return self.views(bufs)
 
     @staticmethod
@@ -526,9 +591,10 @@ def rect_grid_count(nray, device):
     return n_per_dim.value, n_disk.value
 
 
-def collimated_bundle_device(nray, radius, start, kvec, evec, device, lo=0, hi=None):
+def collimated_bundle_device(nray, radius, start, kvec, evec, device, lo=0, hi=None, uniform=False):
     """RectGrid raster + collimated bundle generated on the GPU (prt_collimated_bundle).
-    Returns row-pitched (3, hi-lo) views x, k, e and the total number of rays in the raster."""
+    Returns row-pitched (3, hi-lo) views x, k, e and the total number of rays in the raster; with
+    ``uniform`` only x is generated and (x, UniformFirst(kvec, evec), None, total) is returned."""
     lib = _lib.load()
     (_, total) = rect_grid_count(nray, device)
     if hi is None:
@@ -542,10 +608,12 @@ def collimated_bundle_device(nray, radius, start, kvec, evec, device, lo=0, hi=N
         prm.e[q] = float(evec[q])
     pitch = recommended_pitch(n)
     with torch.cuda.device(device):
-        bufs = [ray_rows(max(n, 1), device) for _ in range(3)]
+        bufs = [ray_rows(max(n, 1), device) for _ in range(1 if uniform else 3)] + [None, None]
         _lib.check(lib.prt_collimated_bundle(device.index, int(nray), lo, hi, ctypes.byref(prm), pitch,
                                              _ptr(bufs[0]), _ptr(bufs[1]), _ptr(bufs[2]),
                                              _stream_handle(device)))
+    if uniform:
+        return bufs[0][:, :n], UniformFirst(kvec, evec, "e"), None, total
     return bufs[0][:, :n], bufs[1][:, :n], bufs[2][:, :n], total
 
 
@@ -564,12 +632,13 @@ def _raster_struct(tables):
 
 
 def raster_bundle_device(tables_list, kind, device, radius=1.0, start=(0., 0., 0.), anglex=0.0, angley=0.0,
-                         index=1.0, kvec=None, evec=None, lo=0, hi=None, want_pupil=False):
+                         index=1.0, kvec=None, evec=None, lo=0, hi=None, want_pupil=False, uniform=False):
     """A bundle on a pupil raster given by its outer-product tables (``raster.device_tables(nray)``),
     generated on the GPU (prt_raster_bundle): ``kind`` "collimated" (origin = radius * p + start, kvec /
     evec constant) or "divergent" (origin = start, directions fanned out over the pupil angles, k = index *
     unit vector).  Rays [lo, hi) of the concatenated sub-rasters.  Returns row-pitched (3, n) views
-    (x, k, e), the total number of points and -- with ``want_pupil`` -- the (2, n) pupil samples."""
+    (x, k, e), the total number of points and -- with ``want_pupil`` -- the (2, n) pupil samples.  With
+    ``uniform`` (collimated only) k and e are not generated: (x, UniformFirst(kvec, evec), None, total ...)."""
     lib = _lib.load()
     rasters = [_raster_struct(t) for t in tables_list]
     counts = []
@@ -592,7 +661,9 @@ def raster_bundle_device(tables_list, kind, device, radius=1.0, start=(0., 0., 0
         prm.k[q] = float(kvec[q]) if kvec is not None else 0.0
         prm.e[q] = float(evec[q]) if evec is not None else 0.0
     pitch = recommended_pitch(max(n, 1))
-    bufs = [ray_rows(max(n, 1), device) for _ in range(3)]
+    if uniform and kind != "collimated":
+        raise ValueError("only collimated bundles have a uniform first segment")
+    bufs = [ray_rows(max(n, 1), device) for _ in range(1 if uniform else 3)]
     pup = torch.empty((2, pitch), dtype=torch.float64, device=device) if want_pupil else None
     with torch.cuda.device(device):
         base = 0                   # global index of the current sub-raster's first point
@@ -602,11 +673,15 @@ def raster_bundle_device(tables_list, kind, device, radius=1.0, start=(0., 0., 0
                 off = (a - lo) * 8
                 _lib.check(lib.prt_raster_bundle(
                     device.index, ctypes.byref(r), a - base, b - base, ctypes.byref(prm), pitch,
-                    ctypes.c_void_p(bufs[0].data_ptr() + off), ctypes.c_void_p(bufs[1].data_ptr() + off),
-                    ctypes.c_void_p(bufs[2].data_ptr() + off),
+                    ctypes.c_void_p(bufs[0].data_ptr() + off),
+                    None if uniform else ctypes.c_void_p(bufs[1].data_ptr() + off),
+                    None if uniform else ctypes.c_void_p(bufs[2].data_ptr() + off),
                     None if pup is None else ctypes.c_void_p(pup.data_ptr() + off), _stream_handle(device)))
             base += c
-    out = (bufs[0][:, :n], bufs[1][:, :n], bufs[2][:, :n], total)
+    if uniform:
+        out = (bufs[0][:, :n], UniformFirst(kvec, evec, "e"), None, total)
+    else:
+        out = (bufs[0][:, :n], bufs[1][:, :n], bufs[2][:, :n], total)
     return out + (pup[:, :n],) if want_pupil else out
 
 

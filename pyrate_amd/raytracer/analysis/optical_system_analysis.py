@@ -100,9 +100,12 @@ class OpticalSystemAnalysis(object):
             else np.array([0., 1., 0.])
         evec = np.cross(kvec, axis)
         evec = evec / np.linalg.norm(evec)
-        (x, k, e, _) = engine.raster_bundle_device(tables, "collimated", dev, radius=pd.get("radius", 1.0),
-                                                   start=start, kvec=kvec, evec=evec)
-        return RayBundle(x0=x, k0=k, Efield0=e, wave=wave, device=dev)
+        # k and E are one vector each for the whole bundle: nothing is stored per ray and the fused trace
+        # loads only the origins (prt_trace_ex, uniform first segment); RayBundle.k / .Efield still return
+        # the reference's (P,3,N) arrays
+        (x, uni, _, _) = engine.raster_bundle_device(tables, "collimated", dev, radius=pd.get("radius", 1.0),
+                                                     start=start, kvec=kvec, evec=evec, uniform=True)
+        return RayBundle(x0=x, k0=None, Efield0=None, wave=wave, device=dev, uniform=uni)
 
     def trace(self, **kwargs):
         return [self.opticalsystem.seqtrace(ib, self.sequence, **kwargs) for ib in self.initial_bundles]

@@ -77,8 +77,7 @@ class OpticalSystem(LocalCoordinatesTreeBase):
         dev = initialbundle.device
         sysd = _dispatch.system_for(records, dev)
         x0 = initialbundle._x[-1]
-        k0 = initialbundle._k[-1]
-        (e_re, e_im) = _initial_fields(initialbundle, k0)
+        first = _first_segment(initialbundle)
         n = x0.shape[1]
         key = (dev.index, n)
         cache = OpticalSystem._moment_buffers
@@ -88,7 +87,7 @@ class OpticalSystem(LocalCoordinatesTreeBase):
             cache[key] = (sysd.alloc_outputs(n, _lib.MODE_IMAGE, packed_flags=True),
                           engine.MomentsWorkspace(dev, n_results=1, n_rays=n))
         (bufs, ws) = cache[key]
-        m = sysd.trace_moments_into(x0, k0, bufs, ws, slot=0, e0_re=e_re, e0_im=e_im)
+        m = sysd.trace_moments_into(x0, first.pop("k0"), bufs, ws, slot=0, **first)
         return (m.cpu().numpy(), sysd.moments_reference())
 
     _moment_buffers = {}
@@ -126,9 +125,7 @@ def seqtrace_fused(ib, records, lengths):
     sysd = _dispatch.system_for(records, dev)
     S = len(records)
     x0 = ib._x[-1]
-    k0 = ib._k[-1]
-    (e_re, e_im) = _initial_fields(ib, k0)
-    res = sysd.trace(x0, k0, e_re, e_im, mode=_lib.MODE_PATH, packed_flags=True)
+    res = sysd.trace(x0, mode=_lib.MODE_PATH, packed_flags=True, **_first_segment(ib))
     ids_cache = []            # rayIDs on the device: built when the first bundle is touched, not per trace
 
     def ids0():
@@ -184,12 +181,17 @@ def _assemble_path(bundles, lengths, res):
     return path
 
 
-def _initial_fields(ib, k0):
-    if ib._dir_from_k:
-        return engine.efield_perp(k0), None    # E perpendicular to k: Poynting direction = k/|k|
+def _first_segment(ib):
+    """keyword arguments of DeviceSystem.trace / trace_moments_into that describe the first segment of a
+    bundle: a uniform (k, E) for collimated bundles -- only x0 is read --, else the arrays"""
+    if getattr(ib, "_uniform", None) is not None:
+        return dict(k0=None, uniform=ib._uniform)
+    k0 = ib._k[-1]
+    if ib._dir_from_k:            # E perpendicular to k: Poynting direction = k/|k|
+        return dict(k0=k0, first_dir=_lib.FIRST_K)
     if ib._e[-1] is not None:
-        return ib._e[-1]
-    return None, None
+        return dict(k0=k0, e0_re=ib._e[-1][0], e0_im=ib._e[-1][1])
+    return dict(k0=k0)
 
 
 def _seqtrace_fused_crystal(ib, records, lengths):
@@ -205,9 +207,7 @@ def _seqtrace_fused_crystal(ib, records, lengths):
     sysd = _dispatch.system_for(records, dev)
     S = len(records)
     x0 = ib._x[-1]
-    k0 = ib._k[-1]
-    (e_re, e_im) = _initial_fields(ib, k0)
-    res = sysd.trace(x0, k0, e_re, e_im, mode=_lib.MODE_PATH, want_fields=True)
+    res = sysd.trace(x0, mode=_lib.MODE_PATH, want_fields=True, **_first_segment(ib))
     n = x0.shape[1]
     wave = ib.wave
     crystal = [r["material"]["type"] == "anisotropic" for r in records]

@@ -54,15 +54,35 @@ def _to_dev(a, device):
     return engine.to_device_rays(a, device), None, False
 
 
+UNIFORM_DETECT_MIN_RAYS = 4096
+
+
+def _uniform_columns(a):
+    """the common column of a host (3, N) array whose columns are all equal (a collimated bundle's k or E:
+    analysis/optical_system_analysis.py:110-118), else None.  One pass over host memory -- cheaper than the
+    upload it saves."""
+    if not isinstance(a, np.ndarray) or a.ndim != 2 or a.shape[0] != 3 or a.shape[1] < UNIFORM_DETECT_MIN_RAYS:
+        return None
+    c = a[:, :1]
+    if not np.all(np.isfinite(c)) or not bool(np.all(a == c)):
+        return None
+    return c[:, 0]
+
+
 class RayBundle(object):
     def __init__(self, x0, k0, Efield0, rayID=None, wave=standard_wavelength, splitted=False,
-                 device=None):
+                 device=None, uniform=None):
         """
         :param x0: (3, N) start points, global coordinates (numpy or device tensor)
         :param k0: (3, N) wave vectors, global coordinates, |k| = refractive index
         :param Efield0: (3, N) polarisation (may be complex) or None -> E = ey (ray.py:71-73)
         :param rayID: (N,) ints or None -> arange
         :param wave: wavelength [mm]
+        :param uniform: extension -- an ``engine.UniformFirst`` instead of k0 / Efield0 (both None): a
+            collimated bundle, one wave vector and one E field for all rays.  Nothing is stored per ray, and
+            the fused trace reads only x0.  Host arrays k0 / Efield0 whose columns are all equal (what the
+            reference's ``collimated_bundle`` returns) are recognised and treated the same way; ``k`` /
+            ``Efield`` still come back as full (P,3,N) arrays.
         """
         self.splitted = splitted
         self.wave = wave
@@ -74,13 +94,43 @@ class RayBundle(object):
         (xr, xi, _) = _to_dev(x0, dev)
         if xi is not None:
             raise ValueError("complex ray positions are not supported")
+        if xr.dim() != 2 or xr.shape[0] != 3:
+            raise ValueError("x0 and k0 must both be (3, N)")
+        numray = xr.shape[1]
+        kcomplex = False
+        if uniform is None and (Efield0 is None or len(Efield0) == 0 or isinstance(Efield0, np.ndarray)):
+            kc = _uniform_columns(k0) if isinstance(k0, np.ndarray) and k0.shape == tuple(xr.shape) else None
+            if kc is not None and not np.any(np.imag(kc) != 0):
+                ec = None
+                no_field = Efield0 is None or len(Efield0) == 0
+                if not no_field:
+                    ec = _uniform_columns(Efield0) if Efield0.shape == tuple(xr.shape) else None
+                if no_field or ec is not None:
+                    uniform = engine.UniformFirst(np.real(kc), ec, "e")
+                    kcomplex = np.iscomplexobj(k0)
+        self._uniform = uniform
+        if uniform is not None:
+            self._k_complex = kcomplex
+            self._x = [xr]
+            self._k = [uniform.rows(numray, dev, "k")]
+            self._valid = [torch.ones(numray, dtype=torch.uint8, device=dev)]
+            if uniform.kind == "e" and uniform.e_re is None:
+                self._e = [None]
+                self._e_default = True
+            elif uniform.kind == "e":
+                im = uniform.rows(numray, dev, "e_im") if any(uniform.e_im) else None
+                self._e = [(uniform.rows(numray, dev, "e_re"), im)]
+                self._e_default = False
+            else:
+                raise ValueError("a RayBundle's uniform first segment carries an E field (kind 'e')")
+            self._finish_init(rayID, numray)
+            return
         (kr, ki, kcomplex) = _to_dev(k0, dev)
         if ki is not None:
             raise NotImplementedError("complex wave vectors (absorbing media) are out of scope")
-        if xr.dim() != 2 or xr.shape[0] != 3 or kr.shape != xr.shape:
+        if kr.shape != xr.shape:
             raise ValueError("x0 and k0 must both be (3, N)")
         self._k_complex = kcomplex           # round-trip the caller's dtype
-        numray = xr.shape[1]
         self._x = [xr]
         self._k = [kr]
         self._valid = [torch.ones(numray, dtype=torch.uint8, device=dev)]
@@ -91,6 +141,9 @@ class RayBundle(object):
             (er, ei, _) = _to_dev(Efield0, dev)
             self._e = [(er, ei)]
             self._e_default = False
+        self._finish_init(rayID, numray)
+
+    def _finish_init(self, rayID, numray):
         self._dir = None                      # explicit unit directions for the next propagate
         self._dir_from_k = False              # bundle left an isotropic interface: d = k/|k|
         if rayID is None or len(rayID) == 0:
@@ -115,6 +168,7 @@ class RayBundle(object):
         self.wave = wave
         self.device = device
         self._thunk = thunk
+        self._uniform = None
         self._cache = {}
         self._k_complex = False
         self._e_default = False
@@ -130,6 +184,7 @@ class RayBundle(object):
         self.wave = wave
         self.device = device
         self._thunk = None
+        self._uniform = None
         self._cache = {}
         self._x = list(x_list)
         self._k = list(k_list)
@@ -252,6 +307,8 @@ class RayBundle(object):
             v = Validnew.to(device=dev, dtype=torch.uint8)
         else:
             v = torch.from_numpy(np.asarray(Validnew).astype(np.uint8)).to(dev)
+        if knew is not None or Enew is not None:
+            self._uniform = None              # the last point no longer carries the bundle's uniform (k, E)
         self._x.append(xr)
         self._k.append(kr)
         self._valid.append(self._valid[-1] * v)

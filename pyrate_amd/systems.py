@@ -174,15 +174,16 @@ def double_gauss_bundle(nrays, rpup=5.0, z0=-10.0, field_deg=0.0):
     return (o, k, np.ascontiguousarray(e0))
 
 
-def double_gauss_bundle_device(nrays, device, rpup=5.0, z0=-10.0, field_deg=0.0, lo=0, hi=None):
+def double_gauss_bundle_device(nrays, device, rpup=5.0, z0=-10.0, field_deg=0.0, lo=0, hi=None, uniform=False):
     """the same bundle generated on the GPU (bit-identical to double_gauss_bundle; rays
-    [lo, hi) of the raster only -- a rank's shard).  Returns (x0, k0, e0, n_total)."""
+    [lo, hi) of the raster only -- a rank's shard).  Returns (x0, k0, e0, n_total); with ``uniform``
+    (x0, engine.UniformFirst(k, E), None, n_total): the collimated bundle's k and E as one vector each."""
     from . import engine
     field = field_deg * math.pi / 180.
     k = (0.0, math.sin(field), math.cos(field))
     e = (0.0, k[2], -k[1])                        # k x ex
     return engine.collimated_bundle_device(nrays, rpup, (0.0, z0 * math.tan(field), z0), k, e, device,
-                                           lo=lo, hi=hi)
+                                           lo=lo, hi=hi, uniform=uniform)
 
 
 # ---- config 1: cemented doublet (demos/demo_doublet.py:48-101) --------------------
@@ -226,6 +227,34 @@ def asphere_builduplist(coefficients=(0.0, 1e-7, -1e-10), curv=-1. / 50., cc=-1.
 
 def asphere_records(**kw):
     return simple_system_records(asphere_builduplist(**kw))
+
+
+# ---- the XY-polynomial companion of config 3: demo_asphere.py's geometry with a freeform back surface -------
+def xypoly_terms(degree=4, scale=1e-3):
+    """XYPolynomials coefficients (surface_shape.py:780-858) [(i, j, c_ij), ...]: the paraboloid -r^2/60 plus small
+    terms of every order 2 .. ``degree`` (12 terms for degree 4), sorted by (i, j)"""
+    terms = []
+    for i in range(degree + 1):
+        for j in range(degree + 1 - i):
+            if i + j < 2:
+                continue
+            c = scale * (-1.0) ** (i + j) / (10.0 ** (i + j))
+            if (i, j) in ((2, 0), (0, 2)):
+                c += -1.0 / 60.0
+            terms.append((i, j, c))
+    return terms
+
+
+def xypoly_records(degree=4, scale=1e-3):
+    """stop, plane front (n = 1.5168), XY-polynomial back surface, image: demo_asphere.py:47-57 with the asphere
+    replaced by a 12-term polynomial freeform"""
+    return simple_system_records([
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
+        ({"shape": "Conic"}, {"decz": 5.0}, 1.5168, "front", {}),
+        ({"shape": "XYPolynomials", "normradius": 1.0, "coefficients": xypoly_terms(degree, scale)},
+         {"decz": 20.0}, None, "back", {}),
+        ({"shape": "Conic"}, {"decz": 100.0}, None, "image", {}),
+    ])
 
 
 # ---- config 4: anisotropic doublet (demos/demo_anisotropic_doublet.py:55-121) ------

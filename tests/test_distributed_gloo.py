@@ -26,6 +26,20 @@ def test_shard_ranges_partition_the_bundle():
             assert all(lo == min(r * n_pad, n) for (r, (lo, _)) in enumerate(spans))
             assert sizes == [max(0, min(n_pad, n - r * n_pad)) for r in range(world)]
             assert sizes == pdist.shard_sizes(n, world)
+    # tiny bundles: several trailing ranks can be short or empty (zero-size shards are legal)
+    assert pdist.shard_sizes(9, 8) == [2, 2, 2, 2, 1, 0, 0, 0]
+    assert pdist.shard_sizes(1, 2) == [1, 0]
+
+
+def test_gather_rows_must_be_contiguous():
+    """a collective needs a contiguous input row: a view with a stride along the rays goes through staging"""
+    t = torch.arange(24, dtype=torch.float64).reshape(3, 8)
+    assert pdist._row_of(t, 1, 2, 4, 4).tolist() == [10., 11., 12., 13.]
+    assert pdist._row_of(t[:, ::2], 1, 0, 4, 4) is None
+    g = pdist.ImagePlaneGather(4, torch.device("cpu"), world=1, rank=0)
+    g.deposit(0, t[:, ::2], t[:, 1::2], torch.ones(4, dtype=torch.uint8))
+    (x, k, v) = g.finish()
+    assert torch.equal(x, t[:, ::2]) and torch.equal(k, t[:, 1::2]) and int(v.sum()) == 4
 
 
 def _free_port():
@@ -68,6 +82,9 @@ def _worker(rank, world, port, n_total, q):
         (cnt, cen, rms) = pdist.global_spot_statistics(torch.from_numpy(x[:, lo:hi].copy()),
                                                        torch.from_numpy(v[lo:hi].copy()), moments_fn=np_moments)
         m = v.astype(bool)
+        if m.sum() < 2:                  # (the one-ray bundle of the empty-shard case: no spread to compare)
+            q.put((rank, ok and cnt == m.sum()))
+            return
         cen_ref = x[:, m].sum(axis=1) / m.sum()
         rms_ref = np.sqrt(((x[:, m] - cen_ref[:, None]) ** 2).sum() / (m.sum() - 1))
         ok = ok and cnt == m.sum() and bool(np.allclose(cen, cen_ref, rtol=1e-13)) and abs(rms - rms_ref) < 1e-13
@@ -109,8 +126,9 @@ def _worker(rank, world, port, n_total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [1000, 1001])
+@pytest.mark.parametrize("n_total", [1000, 1001, 1])
 def test_image_plane_gather_world2_gloo(n_total):
+    """n_total = 1: rank 1 owns an empty shard"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -156,13 +156,20 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(_lib.PROTOTYPES.keys())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.prt_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.prt_abi_version() == _lib.ABI_VERSION == 5
     assert lib.prt_sizeof_surface() == ctypes.sizeof(st.PrtSurface)
     assert lib.prt_strerror(-2) == b"unsupported shape/material"
     # argument validation happens before any device work
     assert lib.prt_system_create(None, 0, 0, None) == -1
     assert lib.prt_trace(None, 0, 0, None, None, None, None, 0, 0, None, None, None, None, None, None) == -1
     assert lib.prt_trace_seq(None, 0, 0, None, None, None, None, 0, None, None, None, None, 0, None) == -1
+    # prt_trace_ex: the struct must carry this library's sizeof (a caller built against another layout is refused)
+    assert lib.prt_sizeof_trace_args() == ctypes.sizeof(_lib.PrtTraceArgs)
+    args = _lib.PrtTraceArgs()
+    assert lib.prt_trace_ex(None, None) == -1 and lib.prt_trace_ex(None, ctypes.byref(args)) == -1
+    assert b"struct_bytes" in lib.prt_last_error()
+    args.struct_bytes = ctypes.sizeof(_lib.PrtTraceArgs)
+    assert lib.prt_trace_ex(None, ctypes.byref(args)) == -1 and b"null system" in lib.prt_last_error()
     assert lib.prt_recommended_pitch(9994476) == 9994752 and lib.prt_recommended_pitch(512) == 512
     assert lib.prt_compact_scratch_bytes(0) > 0
     assert lib.prt_arena_alloc(None, 0, None, None, None, -1, 0, -1, None) == -1 and lib.prt_arena_free(None, None, None) == -1

@@ -5,6 +5,11 @@ import pytest
 
 import _golden
 from oracle import seqtrace_c, seqtrace_np
+from test_oracle_golden import explicit_tolerance
+
+# explicit shapes the C oracle covers (Asphere, XYPolynomials, Biconic)
+C_EXPLICIT_CASES = [c for c in _golden.EXPLICIT_CASES
+                    if seqtrace_c.supports(_golden.load_case(c).table)]
 
 
 @pytest.mark.parametrize("name", _golden.ISO_CASES)
@@ -13,6 +18,74 @@ def test_c_oracle_vs_reference(name):
     out = seqtrace_c.trace(case.table, case.x0, case.k0, case.E0)
     res = _golden.compare_dense_to_reference(case, _golden.dense_from_oracle(out), rtol_x=1e-12, atol_k=1e-12)
     assert res["n_compared"] > 0
+
+
+def test_the_c_oracle_covers_the_explicit_shapes_of_the_hot_path():
+    assert set(C_EXPLICIT_CASES) >= {"asphere_mild_axis", "asphere_mild_field5", "asphere_strong_axis",
+                                     "asphere_strong_field5", "xypoly_axis", "xypoly_field5", "biconic_axis",
+                                     "biconic_field5", "hud_biconic_mirrors"}
+
+
+@pytest.mark.parametrize("name", C_EXPLICIT_CASES)
+def test_c_oracle_vs_reference_explicit_shapes(name):
+    """Asphere / XYPolynomials / Biconic by per-ray Newton: against the reference's fsolve result with the
+    residual-aware tolerance of SURVEY headline 4, and the C oracle's own residual on the surface < 1e-13"""
+    case = _golden.load_case(name)
+    out = seqtrace_c.trace(case.table, case.x0, case.k0, case.E0)
+    dense = _golden.dense_from_oracle(out)
+    _golden.compare_dense_to_reference(case, dense, rtol_x=1e-10, atol_k=1e-10, explicit_tol=explicit_tolerance)
+    for (s, rec) in enumerate(case.table):
+        if rec["shape"]["type"] == "conic":
+            continue
+        p = seqtrace_np.g2l_points(np.asarray(rec["B_shape"]), np.asarray(rec["g_shape"]), dense[s]["x_hit"])
+        resid = np.abs(p[2] - seqtrace_np.shape_sag(rec["shape"], p[0], p[1]))
+        assert np.nanmax(resid) < 1e-13
+    # and against the NumPy oracle (same algorithm, written twice): masks equal, values to rounding
+    ref = seqtrace_np.trace(case.table, case.x0, case.k0, case.E0)
+    for s in range(case.n_surfaces):
+        assert np.array_equal(out[s]["valid"], ref[s]["valid"]) and np.array_equal(out[s]["valid_out"], ref[s]["valid_out"])
+        v = ref[s]["valid_out"]
+        assert np.max(np.abs(out[s]["x_hit"][:, v] - ref[s]["x_hit"][:, v]), initial=0.0) < 1e-11
+        assert np.max(np.abs(out[s]["k_out"][:, v] - ref[s]["k_out"][:, v]), initial=0.0) < 1e-12
+
+
+@pytest.mark.parametrize("name", _golden.ANISO_CASES + ["aniso_partial_evanescent"])
+def test_c_oracle_vs_reference_crystals(name):
+    """anisotropic media through LAPACK's zggev (SciPy's, the routine behind the reference's scipy.linalg.eig):
+    hit points and wave vectors of the doubled rays against the reference's bundles, order of the two solutions
+    included; complex k of evanescent modes like the NumPy oracle's"""
+    if not seqtrace_c.load().seqtrace_c_has_zggev():
+        pytest.skip("this SciPy does not export zggev")
+    case = _golden.load_case(name)
+    assert seqtrace_c.supports(case.table)
+    out = seqtrace_c.trace(case.table, case.x0, case.k0, case.E0)
+    if name == "aniso_partial_evanescent":
+        # the reference's own bundle behind the crystal interface: which slots are real, and their values
+        kref = case.raw_bundles[3]["k"][0]
+        real_ref = np.all(np.abs(np.imag(kref)) < 1e-12, axis=0)
+        ko = out[1]["k_out"]
+        assert np.array_equal(np.all(np.abs(np.imag(ko)) < 1e-12, axis=0), real_ref) and (~real_ref).sum() > 5
+        assert np.abs(ko[:, real_ref] - kref[:, real_ref]).max() < 1e-13
+        # evanescent modes: complex k like the reference's (the pair xi, conj(xi) may come in either order)
+        assert np.abs(np.real(ko[:, ~real_ref]) - np.real(kref[:, ~real_ref])).max() < 1e-12
+        assert np.abs(np.abs(np.imag(ko[:, ~real_ref])) - np.abs(np.imag(kref[:, ~real_ref]))).max() < 1e-12
+    else:
+        res = _golden.compare_dense_to_reference(case, _golden.dense_from_oracle(out), rtol_x=1e-10, atol_k=1e-10)
+        assert res["n_compared"] > 0
+    ref = seqtrace_np.trace(case.table, case.x0, case.k0, case.E0)
+    for s in range(case.n_surfaces):
+        assert out[s]["x_hit"].shape == ref[s]["x_hit"].shape and out[s]["k_out"].shape == ref[s]["k_out"].shape
+        assert np.array_equal(out[s]["valid"], ref[s]["valid"]) and np.array_equal(out[s]["valid_out"], ref[s]["valid_out"])
+        assert np.array_equal(out[s]["ray_id"], ref[s]["ray_id"])
+        fin = np.all(np.isfinite(ref[s]["k_out"]), axis=0)
+        assert np.array_equal(fin, np.all(np.isfinite(out[s]["k_out"]), axis=0))
+        # (an evanescent pair xi, conj(xi) has S.n = 0 twice: which of the two comes first is the sort's choice)
+        (ko, kr) = (out[s]["k_out"][:, fin], ref[s]["k_out"][:, fin])
+        assert np.max(np.abs(np.real(ko) - np.real(kr)), initial=0.0) < 1e-11
+        assert np.max(np.abs(np.abs(np.imag(ko)) - np.abs(np.imag(kr))), initial=0.0) < 1e-11
+        # (rays behind an evanescent mode travel along the interface: hit points at 1e17 mm, not compared)
+        vx = np.all(np.isfinite(ref[s]["x_hit"]), axis=0) & np.all(np.abs(ref[s]["x_hit"]) < 1e6, axis=0)
+        assert np.max(np.abs(out[s]["x_hit"][:, vx] - ref[s]["x_hit"][:, vx]), initial=0.0) < 1e-10
 
 
 def test_c_oracle_matches_numpy_oracle_dense_and_threads():
@@ -31,5 +104,7 @@ def test_c_oracle_matches_numpy_oracle_dense_and_threads():
 
 
 def test_c_oracle_rejects_out_of_scope_tables():
+    table = _golden.load_case("gridsag_field2").table
+    assert not seqtrace_c.supports(table)
     with pytest.raises(ValueError):
-        seqtrace_c.flat_table(_golden.load_case("asphere_mild_axis").table)
+        seqtrace_c.flat_table(table)
