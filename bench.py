@@ -314,8 +314,7 @@ def measure_single(config, args, dev, rays, with_cpu):
     arena_obj = placed.PlacedArena.for_device(dev.index) if placement == "arena" else None
     input_kind = arena_obj.kind_of(x0) if arena_obj is not None else None
 
-    def launch():
-        sysd.trace_into(x0, k0, ob, e0, uniform=uni)
+    launch = sysd.launcher(x0, k0, ob, e0, uniform=uni)     # the argument struct is built once
 
     # device wake-up (not one of the W warm-up steps): after idle the first ~25 ms of launches run at ramping
     # clocks; 30 plain launches of the same kernel bring the chip to its steady state before anything is counted

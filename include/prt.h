@@ -171,9 +171,17 @@ int32_t prt_system_ray_counts(const prt_system_t *sys, int64_t n0, int64_t *n_in
  *                 x_hit, k_out  (S,3,out_pitch) doubles;  valid, valid_out (S,out_pitch) bytes;
  *                 out_pitch 0 = n0 (tight).  Use prt_recommended_pitch(): rows that do not start
  *                 on a 128-B line cost ~35 % of the HBM write bandwidth.
- *   mode PATH, table with anisotropic media (out_pitch and in_pitch must be 0): concatenated
+ *   mode PATH, table with anisotropic media: concatenated
  *                 x_hit = concat_s (3,n_in[s]),  valid = concat_s (n_in[s]),
- *                 k_out = concat_s (3,n_out[s]), valid_out = concat_s (n_out[s]).
+ *                 k_out = concat_s (3,n_out[s]), valid_out = concat_s (n_out[s]),
+ *                 n_in / n_out = prt_system_ray_counts(sys, P): the layout of a bundle of P = out_pitch rays
+ *                 (0 = n0, tight) of which only the first n0 of every branch exist -- ray i of branch b of surface s
+ *                 at b*P + i of its row; the engine writes nothing into the P - n0 padding slots of a branch
+ *                 (masks there stay what the caller put: zero them once).  With P a multiple of 16 every row starts
+ *                 on a 128-B line: 0.124 instead of 0.151 ms on BASELINE configs[3] (998012 rays), so a caller that
+ *                 allocates the arrays itself should pass P = n0 rounded up to 128 (prt_crystal_pitch).
+ *                 in_pitch: row pitch of the inputs as for isotropic tables.  More than 8 crystal interfaces (the
+ *                 per-surface march): tight arrays only.
  *   mode IMAGE:   the same four arrays for the last surface only.
  *   valid_out may be NULL.
  *   nonconv (may be NULL; layout of valid): 1 where the Newton iteration of an explicit shape
@@ -189,6 +197,7 @@ int32_t prt_system_ray_counts(const prt_system_t *sys, int64_t n0, int64_t *n_in
  *   stream: hipStream_t (NULL = default stream).  Asynchronous.
  */
 int64_t prt_recommended_pitch(int64_t n); /* n rounded up to 512 elements (4 KiB of doubles) */
+int64_t prt_crystal_pitch(int64_t n);     /* n rounded up to 128: ray pitch of the concatenated layout */
 int32_t prt_trace(const prt_system_t *sys, int64_t n0, int64_t in_pitch, const double *x0,
                   const double *k0, const double *e0_re, const double *e0_im, int32_t mode,
                   int64_t out_pitch, double *x_hit, double *k_out, uint8_t *valid,

@@ -43,6 +43,7 @@ PROTOTYPES = {
                                                ctypes.POINTER(ctypes.c_int64),
                                                ctypes.POINTER(ctypes.c_int64)]),
     "prt_recommended_pitch": (ctypes.c_int64, [ctypes.c_int64]),
+    "prt_crystal_pitch": (ctypes.c_int64, [ctypes.c_int64]),
     "prt_trace": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, c_double_p,
                                    c_double_p, c_double_p, c_double_p, ctypes.c_int32,
                                    ctypes.c_int64, c_double_p, c_double_p, c_u8_p, c_u8_p, c_u8_p,

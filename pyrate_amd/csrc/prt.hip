@@ -202,8 +202,9 @@ const char *prt_last_error(void) { return g_err; }
 // The polynomial part of a surface (xypoly: all terms; combination: those behind the asphere part) as the
 // dense Horner rows xypoly_eval reads: header ints, then 32-byte chunks (layout: prt_device.h).
 #define PRT_MAX_POLY_POWER 64
-static std::vector<char> poly_rows(const prt_surface_t &r) {
+static std::vector<char> poly_rows(const prt_surface_t &r, bool *dense_out) {
     std::vector<char> blob;
+    *dense_out = false;
     int t0 = 0;
     if (r.shape_type == PRT_SHAPE_COMBO) t0 = r.n_asphere;
     else if (r.shape_type != PRT_SHAPE_XYPOLY) return blob;
@@ -226,9 +227,23 @@ static std::vector<char> poly_rows(const prt_surface_t &r) {
     }
     head[0] = nrows;
     head[1] = (int32_t)(data.size() / 4);
-    blob.resize(4 * head.size() + 8 * data.size());
-    memcpy(blob.data(), head.data(), 4 * head.size());
-    if (!data.empty()) memcpy(blob.data() + 4 * head.size(), data.data(), 8 * data.size());
+    // the dense triangle of total degree <= PRT_POLY_DENSE_DEG in front (dense_poly_eval); zeros if it does not fit
+    double dense[PRT_POLY_DENSE_SLOTS] = {0};
+    bool fits = true;
+    for (int i = 0; i <= D; ++i)
+        for (size_t j = 0; j < row[i].size(); ++j)
+            if (row[i][j] != 0.0 && i + (int)j > PRT_POLY_DENSE_DEG) fits = false;
+    if (fits) {
+        int q = 0;
+        for (int i = PRT_POLY_DENSE_DEG; i >= 0; --i)
+            for (int j = PRT_POLY_DENSE_DEG - i; j >= 0; --j, ++q)
+                dense[q] = (i <= D && j < (int)row[i].size()) ? row[i][j] : 0.0;
+    }
+    *dense_out = fits;
+    blob.resize(sizeof dense + 4 * head.size() + 8 * data.size());
+    memcpy(blob.data(), dense, sizeof dense);
+    memcpy(blob.data() + sizeof dense, head.data(), 4 * head.size());
+    if (!data.empty()) memcpy(blob.data() + sizeof dense + 4 * head.size(), data.data(), 8 * data.size());
     return blob;
 }
 
@@ -325,10 +340,14 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     const size_t PRT_SIDE_SLACK = 8 + 8 * PRT_ASPHERE_PREFETCH;
     size_t side_bytes = 0;
     std::vector<std::vector<char>> poly;
+    std::vector<char> poly_dense;
     try {
         poly.resize(n_surfaces);
+        poly_dense.resize(n_surfaces, 0);
         for (int s = 0; s < n_surfaces; ++s) {
-            poly[s] = poly_rows(table[s]);
+            bool dense = false;
+            poly[s] = poly_rows(table[s], &dense);
+            poly_dense[s] = (dense && table[s].shape_type == PRT_SHAPE_XYPOLY) ? 1 : 0;
             side_bytes += 8 * n_doubles(table[s]) + poly[s].size();
         }
     } catch (...) {  // std::bad_alloc: the ABI never throws
@@ -372,6 +391,7 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
         d.n_asphere = r.n_asphere;
         d.grid_nx = r.grid_nx;
         d.grid_ny = r.grid_ny;
+        d.poly_dense = poly_dense[s];
         d.curv = r.curv;
         d.cc = r.cc;
         memcpy(d.B_shape, r.B_shape, sizeof d.B_shape);
@@ -552,6 +572,11 @@ int64_t prt_recommended_pitch(int64_t n) {
     return (n + 511) / 512 * 512;  // 4 KiB of doubles: every row starts on a 128-B line
 }
 
+int64_t prt_crystal_pitch(int64_t n) {
+    if (n <= 0) return 0;
+    return (n + 127) / 128 * 128;  // rows of doubles AND rows of mask bytes start on 128-B lines at every level
+}
+
 // a uniform first segment for the code paths that read per-ray arrays (the per-surface march): broadcast
 __global__ __launch_bounds__(PRT_BLOCK) void k_broadcast_rows(int64_t n, double v0, double v1, double v2,
                                                               double *__restrict__ out) {
@@ -630,9 +655,8 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
         return fail(PRT_ERR_INVALID_ARG, "prt_trace: pitch smaller than the ray count");
     uint8_t *valid_out = a.valid_out;
     if (!sys->all_isotropic) {
-        if (out_pitch != 0 || in_pitch != n0)
-            return fail(PRT_ERR_INVALID_ARG,
-                        "prt_trace: tables with anisotropic media use the concatenated layout (pitch 0)");
+        // concatenated layout with ray pitch out_pitch (0 = n0, tight)
+        if (out_pitch == 0) out_pitch = n0;
         static const bool per_surface = getenv("PRT_GENERAL_PER_SURFACE") != nullptr;
         int n_aniso = 0;
         for (int s = 0; s < sys->n_surfaces; ++s)
@@ -642,6 +666,9 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
         // sequences with more crystal interfaces than the kernel has parking slots, and as the
         // independent implementation PRT_GENERAL_PER_SURFACE=1 selects for cross-checks.
         if (per_surface || n_aniso > PRT_FUSED_MAX_CRYSTALS) {
+            if (out_pitch != n0 || in_pitch != n0)
+                return fail(PRT_ERR_UNSUPPORTED, "prt_trace: the per-surface march through crystals (more than 8 crystal "
+                                                 "interfaces) takes tight arrays (pitch 0)");
             stream_scratch rows(st);
             const double *k0 = a.k0;
             if (uni) {  // the per-surface kernels read arrays: broadcast the uniform vectors once
@@ -666,7 +693,7 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
             return trace_general(sys, n0, a.x0, k0, e_re, e_im, mode, a.x_hit, a.k_out, a.e_out_re, a.e_out_im,
                                  a.valid, valid_out, a.nonconv, e_mode, st);
         }
-        const dim3 grid(nblocks(n0, PRT_BLOCK)), block(PRT_BLOCK);
+        const dim3 grid(nblocks(n0, PRT_GENERAL_BLOCK)), block(PRT_GENERAL_BLOCK);
         bool general_eps = false;
         for (int s = 0; s < sys->n_surfaces; ++s)
             if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC &&
@@ -674,11 +701,18 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
                 general_eps = true;
         // few crystal interfaces: the parking slots of the depth-first walk fit into LDS
         const bool park_lds = n_aniso <= PRT_PARK_LDS_LEVELS;
-        const size_t park_bytes = park_lds ? (size_t)n_aniso * PRT_BLOCK * (9 * sizeof(double) + 1) : 0;
-#define PRT_LAUNCH_GU(MODE_, GEN_, LDS_, UNI_)                                                                \
-    hipLaunchKernelGGL((k_trace_general<MODE_, GEN_, LDS_, UNI_>), grid, block, park_bytes, st, sys->d_table, \
-                       sys->n_surfaces, n_aniso, n0, a.x0, a.k0, e_re, e_im, e_mode, a.x_hit, a.k_out,        \
+        const size_t park_bytes = park_lds ? (size_t)n_aniso * PRT_GENERAL_BLOCK * (9 * sizeof(double) + 1) : 0;
+        const bool conics = sys->all_conic != 0;
+#define PRT_LAUNCH_GS(MODE_, GEN_, LDS_, UNI_, SH_)                                                                 \
+    hipLaunchKernelGGL((k_trace_general<MODE_, GEN_, LDS_, UNI_, SH_>), grid, block, park_bytes, st, sys->d_table, \
+                       sys->n_surfaces, n_aniso, n0, in_pitch, out_pitch, a.x0, a.k0, e_re, e_im, e_mode, a.x_hit, \
+                       a.k_out,                                                                                    \
                        a.e_out_re, a.e_out_im, a.valid, valid_out, a.nonconv, fu)
+#define PRT_LAUNCH_GU(MODE_, GEN_, LDS_, UNI_)                                   \
+    do {                                                                         \
+        if (conics) PRT_LAUNCH_GS(MODE_, GEN_, LDS_, UNI_, PRT_SHAPES_CONIC);    \
+        else PRT_LAUNCH_GS(MODE_, GEN_, LDS_, UNI_, PRT_SHAPES_ALL);             \
+    } while (0)
 #define PRT_LAUNCH_GP(MODE_, GEN_, LDS_)                   \
     do {                                                   \
         if (uni) PRT_LAUNCH_GU(MODE_, GEN_, LDS_, true);   \
@@ -696,6 +730,7 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
             if (general_eps) PRT_LAUNCH_G(PRT_MODE_IMAGE, true);
             else PRT_LAUNCH_G(PRT_MODE_IMAGE, false);
         }
+#undef PRT_LAUNCH_GS
 #undef PRT_LAUNCH_GU
 #undef PRT_LAUNCH_GP
 #undef PRT_LAUNCH_G

@@ -284,10 +284,21 @@ PRT_DEV void eigen_solution(const prt_dev_surface *__restrict__ sf, int cls, con
 // out[0], out[1]: refract -> sorted solutions 2, 3; mirror -> -(0), -(1).
 // GENERAL = false: the host guarantees that no crystal of the table needs the quartic solver (all
 // epsilon tensors isotropic or uniaxial) and that code is compiled out.
+// n: unit surface normal in the frame of the medium (the fused march has it from the intersection it just did:
+// normal_from_grad; the per-surface entry point evaluates the shape at the caller's point)
 template <bool GENERAL = true>
+PRT_DEV void interact_anisotropic_n(const prt_dev_surface *__restrict__ sf, const vec3 &n,
+                                    const vec3 &k_glob, aniso_solution out[2]);
+
+template <bool GENERAL = true, int SHAPES = PRT_SHAPES_ALL>
 PRT_DEV void interact_anisotropic(const prt_dev_surface *__restrict__ sf, const vec3 &p,
                                   const vec3 &k_glob, aniso_solution out[2]) {
-    const vec3 n = normal_in_material_frame(sf, p);
+    interact_anisotropic_n<GENERAL>(sf, normal_in_material_frame<SHAPES>(sf, p), k_glob, out);
+}
+
+template <bool GENERAL>
+PRT_DEV void interact_anisotropic_n(const prt_dev_surface *__restrict__ sf, const vec3 &n,
+                                    const vec3 &k_glob, aniso_solution out[2]) {
     const bool mat_id = sf->frame_flags & PRT_FRAME_MAT_IDENTITY;
     const vec3 k1 = mat_id ? k_glob : matT_vec(sf->B_mat, k_glob);
     const double kn = dot(k1, n);

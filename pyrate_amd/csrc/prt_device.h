@@ -28,7 +28,8 @@
 // 12-surface table is 6 KB and stays in the scalar cache whatever else runs.
 struct prt_dev_surface {
     int32_t shape_type, n_coeffs, ap_type, interaction, mat_type, frame_flags, newton_maxit, aniso_class;
-    int32_t n_asphere, grid_nx, grid_ny, pad_;
+    int32_t n_asphere, grid_nx, grid_ny;
+    int32_t poly_dense;  // xypoly: 1 if the polynomial fits the dense triangle of total degree <= PRT_POLY_DENSE_DEG (dense_poly_eval)
     double curv, cc;
     const double *coeffs;  // n_coeffs doubles (biconic: 2 n_coeffs); GRIDSAG: knots tx, ty, coefficients
     const void *pows;      // xypoly / combo: the polynomial part as dense Horner rows (xypoly_eval)
@@ -254,12 +255,18 @@ PRT_DEV void asphere_eval(const prt_dev_surface *__restrict__ sf, int nc, const 
 //   int32 n_rows, int32 n_chunks, int32 chunks_of_row[n_rows] (row D first), padded to 8 bytes;
 //   then 32-byte chunks of four coefficients in Horner order (highest power of y first, a row's first
 //   chunk padded with leading zeros).  One s_load_dwordx8 per chunk, issued one chunk ahead.
+//   In front of all that: the DENSE TRIANGLE of total degree <= PRT_POLY_DENSE_DEG, PRT_POLY_DENSE_SLOTS doubles
+//   (rows i = D .. 0, row i holding c_i,D-i .. c_i,0 -- Horner order --, absent terms zero; all zero and unused
+//   when the polynomial does not fit): what dense_poly_eval keeps in scalar registers.
+#define PRT_POLY_DENSE_DEG 4
+#define PRT_POLY_DENSE_COEFFS ((PRT_POLY_DENSE_DEG + 1) * (PRT_POLY_DENSE_DEG + 2) / 2)
+#define PRT_POLY_DENSE_SLOTS 16
 typedef const PRT_CONST_AS int32_t *prt_cints;
 PRT_DEV void xypoly_eval(const prt_dev_surface *__restrict__ sf, double x, double y, double &F, double &Fx,
                          double &Fy) {
-    prt_cints hd = (prt_cints)(uint64_t)sf->pows;
+    prt_cints hd = (prt_cints)((uint64_t)sf->pows + 8 * PRT_POLY_DENSE_SLOTS);
     const int nrows = hd[0];
-    prt_cdoubles cd = (prt_cdoubles)((uint64_t)sf->pows + 8 * (uint64_t)((nrows + 3) >> 1));
+    prt_cdoubles cd = (prt_cdoubles)((uint64_t)sf->pows + 8 * PRT_POLY_DENSE_SLOTS + 8 * (uint64_t)((nrows + 3) >> 1));
     F = 0.0;
     Fx = 0.0;
     Fy = 0.0;
@@ -284,6 +291,38 @@ PRT_DEV void xypoly_eval(const prt_dev_surface *__restrict__ sf, double x, doubl
             c1 = n1;
             c2 = n2;
             c3 = n3;
+        }
+        Fx = Fx * x + F;
+        F = F * x + p;
+        Fy = Fy * x + dp;
+    }
+}
+
+// The same polynomial when it fits the dense triangle of total degree <= PRT_POLY_DENSE_DEG (12-term freeforms,
+// low-order Zernike expansions): all coefficients fetched ONCE per surface (two s_load_dwordx16) and held in
+// scalar registers across the Newton iteration, like the first asphere coefficients; the loops have
+// compile-time bounds, so nothing but FMAs remains per evaluation -- no scalar-load round trip per chunk.  Same
+// Horner order as xypoly_eval (whose padding zeros leave p and dp untouched): bit-identical results.
+struct poly_coeffs {
+    double c[PRT_POLY_DENSE_COEFFS];
+};
+PRT_DEV void dense_poly_prefetch(const prt_dev_surface *__restrict__ sf, poly_coeffs &pc) {
+    prt_cdoubles cd = (prt_cdoubles)(uint64_t)sf->pows;
+#pragma unroll
+    for (int q = 0; q < PRT_POLY_DENSE_COEFFS; ++q) pc.c[q] = cd[q];
+}
+PRT_DEV void dense_poly_eval(const poly_coeffs &pc, double x, double y, double &F, double &Fx, double &Fy) {
+    F = 0.0;
+    Fx = 0.0;
+    Fy = 0.0;
+    int q = 0;
+#pragma unroll
+    for (int i = PRT_POLY_DENSE_DEG; i >= 0; --i) {
+        double p = 0.0, dp = 0.0;
+#pragma unroll
+        for (int j = PRT_POLY_DENSE_DEG - i; j >= 0; --j) {
+            dp = dp * y + p;
+            p = p * y + pc.c[q++];
         }
         Fx = Fx * x + F;
         F = F * x + p;
@@ -407,9 +446,17 @@ PRT_DEV void gridsag_eval(const prt_dev_surface *__restrict__ sf, double x, doub
 #define PRT_SHAPES_ALL 3
 
 // explicit z = F(x,y) shapes: value and in-plane derivatives
+// what explicit_eval wants fetched once per surface: the first asphere coefficient pairs (asphere-only kernels),
+// a dense polynomial (the "conics + aspheres + polynomials + biconics" kernels); nothing otherwise
+struct explicit_prefetched {
+    asphere_coeffs ac;
+    poly_coeffs pc;
+    bool dense_poly;
+};
 template <int SHAPES = PRT_SHAPES_ALL>
-PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, const asphere_coeffs &ac, double x, double y,
+PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, const explicit_prefetched &pre, double x, double y,
                            double &F, double &Fx, double &Fy) {
+    const asphere_coeffs &ac = pre.ac;
     if (SHAPES == PRT_SHAPES_ASPHERE || sf->shape_type == PRT_SHAPE_ASPHERE) {
         double m;
         asphere_eval<SHAPES == PRT_SHAPES_ASPHERE>(sf, sf->n_coeffs, ac, x, y, F, m);
@@ -429,15 +476,21 @@ PRT_DEV void explicit_eval(const prt_dev_surface *__restrict__ sf, const asphere
         F += sc * Fa;
         Fx += sc * x * m;
         Fy += sc * y * m;
+    } else if (SHAPES == PRT_SHAPES_POLY && pre.dense_poly) {
+        dense_poly_eval(pre.pc, x, y, F, Fx, Fy);
     } else {
         xypoly_eval(sf, x, y, F, Fx, Fy);
     }
 }
 
-// what explicit_eval wants fetched once per surface (the asphere-only kernels; nothing otherwise)
 template <int SHAPES = PRT_SHAPES_ALL>
-PRT_DEV void explicit_prefetch(const prt_dev_surface *__restrict__ sf, asphere_coeffs &ac) {
-    if (SHAPES == PRT_SHAPES_ASPHERE) asphere_prefetch(sf, sf->n_coeffs, ac);
+PRT_DEV void explicit_prefetch(const prt_dev_surface *__restrict__ sf, explicit_prefetched &pre) {
+    pre.dense_poly = false;
+    if (SHAPES == PRT_SHAPES_ASPHERE) asphere_prefetch(sf, sf->n_coeffs, pre.ac);
+    if (SHAPES == PRT_SHAPES_POLY && sf->shape_type == PRT_SHAPE_XYPOLY && sf->poly_dense) {
+        dense_poly_prefetch(sf, pre.pc);
+        pre.dense_poly = true;
+    }
 }
 
 // ExplicitShape.intersect, surface_shape.py:448-465: root of
@@ -458,12 +511,12 @@ PRT_DEV double explicit_t(const prt_dev_surface *__restrict__ sf, const vec3 &r0
     gx = 0.0;
     gy = 0.0;
     const int maxit = sf->newton_maxit > 0 ? sf->newton_maxit : 30;
-    asphere_coeffs ac;
-    explicit_prefetch<SHAPES>(sf, ac);
+    explicit_prefetched pre;
+    explicit_prefetch<SHAPES>(sf, pre);
     for (int it = 0; it < maxit; ++it) {
         double F, Fx, Fy;
         const double px = r0.x + t * d.x, py = r0.y + t * d.y;
-        explicit_eval<SHAPES>(sf, ac, px, py, F, Fx, Fy);
+        explicit_eval<SHAPES>(sf, pre, px, py, F, Fx, Fy);
         const double g = r0.z + t * d.z - F;
         const double gp = d.z - Fx * d.x - Fy * d.y;
         const double dt = g * fast_rcp(gp);
@@ -485,18 +538,18 @@ PRT_DEV double explicit_t(const prt_dev_surface *__restrict__ sf, const vec3 &r0
 PRT_DEV vec3 shape_grad(const prt_dev_surface *__restrict__ sf, double x, double y) {
     if (sf->shape_type == PRT_SHAPE_CONIC) return conic_grad(sf->curv, sf->cc, x, y);
     double F, Fx, Fy;
-    asphere_coeffs ac;
-    explicit_prefetch(sf, ac);
-    explicit_eval(sf, ac, x, y, F, Fx, Fy);
+    explicit_prefetched pre;
+    explicit_prefetch(sf, pre);
+    explicit_eval(sf, pre, x, y, F, Fx, Fy);
     return v3(-Fx, -Fy, 1.0);
 }
 
 PRT_DEV double shape_sag(const prt_dev_surface *__restrict__ sf, double x, double y) {
     if (sf->shape_type == PRT_SHAPE_CONIC) return conic_sag(sf->curv, sf->cc, x * x + y * y);
     double F, Fx, Fy;
-    asphere_coeffs ac;
-    explicit_prefetch(sf, ac);
-    explicit_eval(sf, ac, x, y, F, Fx, Fy);
+    explicit_prefetched pre;
+    explicit_prefetch(sf, pre);
+    explicit_eval(sf, pre, x, y, F, Fx, Fy);
     return F;
 }
 
@@ -597,8 +650,9 @@ PRT_DEV vec3 normal_from_grad(const prt_dev_surface *__restrict__ sf, const vec3
 
 // the same for an arbitrary point of the shape frame (per-surface API: the caller's points
 // need not lie on the surface, so the sag is evaluated like the reference does)
+template <int SHAPES = PRT_SHAPES_ALL>
 PRT_DEV vec3 normal_in_material_frame(const prt_dev_surface *__restrict__ sf, const vec3 &p) {
-    vec3 g = shape_grad(sf, p.x, p.y);
+    vec3 g = (SHAPES == PRT_SHAPES_CONIC) ? conic_grad(sf->curv, sf->cc, p.x, p.y) : shape_grad(sf, p.x, p.y);
     const double inv = 1.0 / sqrt(dot(g, g));
     vec3 n = v3(g.x * inv, g.y * inv, g.z * inv);
     const int ff = sf->frame_flags;

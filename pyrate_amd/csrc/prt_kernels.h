@@ -337,8 +337,8 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
 // A <= 4), in one launch, with no intermediate arrays and no direction buffers.  The walk is the
 // same for every ray, so control flow (surface index, level, offsets) is wave-uniform.
 // Outputs use the concatenated layout of include/prt.h (rays of a split bundle stacked
-// [sol2, sol3] like np.hstack, material_anisotropic.py:89): at a level with a doublings, leaf L
-// sits at i + N (L mod 2^a).
+// [sol2, sol3] like np.hstack, material_anisotropic.py:89) with ray pitch P >= N: at a level with a
+// doublings, leaf L sits at i + P (L mod 2^a).
 // ---------------------------------------------------------------------------
 #define PRT_FUSED_MAX_CRYSTALS 8
 // non-temporal hint on the path stores of the crystal march (written once, never read back by the
@@ -390,28 +390,38 @@ PRT_DEV PRT_GLOBAL_AS T *uniform_ptr(T *p) {
     return (PRT_GLOBAL_AS T *)(((uint64_t)hi << 32) | lo);
 }
 
-template <int MODE, bool GENERAL = true, bool PARK_LDS = false, bool UNI = false>
-__global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
-    const prt_dev_surface *__restrict__ tab, int32_t S, int32_t A, int64_t N,
+// Block size of the crystal march alone (the walk is the same for every ray, so blocks share nothing but
+// the LDS parking slots): PRT_GENERAL_BLOCK threads.
+#ifndef PRT_GENERAL_BLOCK
+#define PRT_GENERAL_BLOCK 256
+#endif
+// SHAPES: the shape code compiled in (as in k_trace_iso): tables whose surfaces are all conics get an
+// instantiation without any Newton / polynomial / spline code.
+template <int MODE, bool GENERAL = true, bool PARK_LDS = false, bool UNI = false, int SHAPES = PRT_SHAPES_ALL>
+__global__ __launch_bounds__(PRT_GENERAL_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
+    const prt_dev_surface *__restrict__ tab, int32_t S, int32_t A, int64_t N, int64_t in_pitch, int64_t P,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, double *__restrict__ xh_out,
     double *__restrict__ k_out, double *__restrict__ e_out, double *__restrict__ e_out_im,
     uint8_t *__restrict__ valid_out_hit, uint8_t *__restrict__ valid_out_refr,
     uint8_t *__restrict__ nonconv_out = nullptr, first_uniform fu = first_uniform()) {
     const uint32_t tid = threadIdx.x;
-    const int64_t blk = (int64_t)blockIdx.x * PRT_BLOCK;
+    const int64_t blk = (int64_t)blockIdx.x * PRT_GENERAL_BLOCK;
     const int64_t i = blk + tid;
     if (i >= N) return;
-    vec3 x = v3(x0[i], x0[N + i], x0[2 * N + i]);
+    // N rays; P >= N is the ray pitch of the concatenated output layout (a bundle of P rays of which the last P - N
+    // do not exist): with P a multiple of 16 every row of every level starts on a 128-B line -- 0.124 instead of
+    // 0.151 ms on BASELINE configs[3], whose 998012 rays put every row at an odd multiple of 32 B
+    vec3 x = v3(x0[i], x0[in_pitch + i], x0[2 * in_pitch + i]);
     vec3 k, d;
     if (UNI) {  // uniform first segment: only x0 is read
         k = v3(fu.k[0], fu.k[1], fu.k[2]);
         d = uniform_first_direction(e_mode, fu, k);
     } else {
-        k = v3(k0[i], k0[N + i], k0[2 * N + i]);
+        k = v3(k0[i], k0[in_pitch + i], k0[2 * in_pitch + i]);
         vec3 kk[2] = {k, k};
         vec3 dd[2];
-        first_direction<false>(e_mode, e_re, e_im, N, i, false, kk, dd);
+        first_direction<false>(e_mode, e_re, e_im, in_pitch, i, false, kk, dd);
         d = dd[0];
     }
     // all input loads land here, so that no wait inside the walk ever counts stores (PRT_WAIT_VMEM_LOADS)
@@ -421,7 +431,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
     // per level: child 1 of the crystal interface of that level (hit point, k, d, alive)
     extern __shared__ double park_lds[];
     double parked[PARK_LDS ? 1 : PRT_FUSED_MAX_CRYSTALS][10];
-    uint8_t *park_lds_alive = reinterpret_cast<uint8_t *>(park_lds + (size_t)A * 9 * PRT_BLOCK);
+    uint8_t *park_lds_alive = reinterpret_cast<uint8_t *>(park_lds + (size_t)A * 9 * PRT_GENERAL_BLOCK);
     uint32_t pending = 0;                        // levels with a parked child (wave-uniform)
     int64_t L = 0;                               // choices made so far: bit j = child taken at level j
     int32_t s = 0;                               // next surface
@@ -432,9 +442,9 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
             const prt_dev_surface *__restrict__ sf = tab + s;
             const bool store = (MODE == PRT_MODE_PATH || s == S - 1);
             const bool crystal = sf->mat_type == PRT_MAT_ANISOTROPIC;
-            const int64_t n_in = N << a;
+            const int64_t n_in = P << a;
             const int a_out = crystal ? a + 1 : a;
-            const int64_t n_out = N << a_out;
+            const int64_t n_out = P << a_out;
             const int64_t base_in = (MODE == PRT_MODE_PATH) ? off_in : 0;
             const int64_t base_out = (MODE == PRT_MODE_PATH) ? off_out : 0;
             double *xo = xh_out + 3 * base_in;
@@ -442,12 +452,12 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
             const int64_t Lp = L & (((int64_t)1 << a) - 1);
             // store addresses = wave-uniform row base (scalar registers) + the thread's 32-bit offset: the
             // form global_store takes with a scalar base, no 64-bit vector arithmetic per store
-            const int64_t idx_in = PRT_DIAG_STORE_INDEX(blk) + N * Lp;
+            const int64_t idx_in = PRT_DIAG_STORE_INDEX(blk) + P * Lp;
             const bool alive = valid;
             vec3 xh, p, g;
             double g2;
             bool ncv;
-            propagate_step(sf, x, d, d2, xh, p, g, g2, valid, ncv);
+            propagate_step<SHAPES>(sf, x, d, d2, xh, p, g, g2, valid, ncv);
             if (store) {
                 PRT_GLOBAL_AS double *xrow = uniform_ptr(xo + idx_in);
                 PRT_GSTORE(xrow + tid, xh.x);
@@ -459,12 +469,15 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
             x = xh;
             if (crystal) {
                 aniso_solution sol[2];
-                interact_anisotropic<GENERAL>(sf, p, k, sol);
+                // (the normal is evaluated from the hit point like the per-surface entry point does -- not taken from
+                // the intersection's gradient: for eps = e I the eigenvectors are an arbitrary basis picked by
+                // comparisons of k's components, and the two paths must pick the same one)
+                interact_anisotropic<GENERAL, SHAPES>(sf, p, k, sol);
                 valid = alive;  // no validity filtering at a crystal interface (ray.py:68)
                 if (store) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        const int64_t idx_out = PRT_DIAG_STORE_INDEX(blk) + N * (Lp + ((int64_t)b << a));
+                        const int64_t idx_out = PRT_DIAG_STORE_INDEX(blk) + P * (Lp + ((int64_t)b << a));
                         PRT_GLOBAL_AS double *krow = uniform_ptr(ko + idx_out);
                         PRT_GSTORE(krow + tid, sol[b].k.x);
                         PRT_GSTORE(krow + n_out + tid, sol[b].k.y);
@@ -485,11 +498,11 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
                     }
                 }
                 if (PARK_LDS) {
-                    double *slot = park_lds + (size_t)a * 9 * PRT_BLOCK + threadIdx.x;
-                    slot[0 * PRT_BLOCK] = xh.x; slot[1 * PRT_BLOCK] = xh.y; slot[2 * PRT_BLOCK] = xh.z;
-                    slot[3 * PRT_BLOCK] = sol[1].k.x; slot[4 * PRT_BLOCK] = sol[1].k.y; slot[5 * PRT_BLOCK] = sol[1].k.z;
-                    slot[6 * PRT_BLOCK] = sol[1].d.x; slot[7 * PRT_BLOCK] = sol[1].d.y; slot[8 * PRT_BLOCK] = sol[1].d.z;
-                    park_lds_alive[a * PRT_BLOCK + threadIdx.x] = alive ? 1 : 0;
+                    double *slot = park_lds + (size_t)a * 9 * PRT_GENERAL_BLOCK + threadIdx.x;
+                    slot[0 * PRT_GENERAL_BLOCK] = xh.x; slot[1 * PRT_GENERAL_BLOCK] = xh.y; slot[2 * PRT_GENERAL_BLOCK] = xh.z;
+                    slot[3 * PRT_GENERAL_BLOCK] = sol[1].k.x; slot[4 * PRT_GENERAL_BLOCK] = sol[1].k.y; slot[5 * PRT_GENERAL_BLOCK] = sol[1].k.z;
+                    slot[6 * PRT_GENERAL_BLOCK] = sol[1].d.x; slot[7 * PRT_GENERAL_BLOCK] = sol[1].d.y; slot[8 * PRT_GENERAL_BLOCK] = sol[1].d.z;
+                    park_lds_alive[a * PRT_GENERAL_BLOCK + threadIdx.x] = alive ? 1 : 0;
                 } else {
                     double *slot = parked[a];
                     slot[0] = xh.x; slot[1] = xh.y; slot[2] = xh.z;
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
                 d = sol[0].d;
                 d2 = 1.0;
             } else {
-                const vec3 n = normal_from_grad(sf, g, g2);
+                const vec3 n = normal_from_grad<SHAPES>(sf, g, g2);
                 interact_isotropic(sf, n, k, valid);
                 d = k;
                 d2 = sf->n_after * sf->n_after;
@@ -523,11 +536,11 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
         const int j = 31 - __builtin_clz(pending);
         pending &= ~(1u << j);
         if (PARK_LDS) {
-            const double *slot = park_lds + (size_t)j * 9 * PRT_BLOCK + threadIdx.x;
-            x = v3(slot[0 * PRT_BLOCK], slot[1 * PRT_BLOCK], slot[2 * PRT_BLOCK]);
-            k = v3(slot[3 * PRT_BLOCK], slot[4 * PRT_BLOCK], slot[5 * PRT_BLOCK]);
-            d = v3(slot[6 * PRT_BLOCK], slot[7 * PRT_BLOCK], slot[8 * PRT_BLOCK]);
-            valid = park_lds_alive[j * PRT_BLOCK + threadIdx.x] != 0;
+            const double *slot = park_lds + (size_t)j * 9 * PRT_GENERAL_BLOCK + threadIdx.x;
+            x = v3(slot[0 * PRT_GENERAL_BLOCK], slot[1 * PRT_GENERAL_BLOCK], slot[2 * PRT_GENERAL_BLOCK]);
+            k = v3(slot[3 * PRT_GENERAL_BLOCK], slot[4 * PRT_GENERAL_BLOCK], slot[5 * PRT_GENERAL_BLOCK]);
+            d = v3(slot[6 * PRT_GENERAL_BLOCK], slot[7 * PRT_GENERAL_BLOCK], slot[8 * PRT_GENERAL_BLOCK]);
+            valid = park_lds_alive[j * PRT_GENERAL_BLOCK + threadIdx.x] != 0;
         } else {
             const double *slot = parked[j];
             x = v3(slot[0], slot[1], slot[2]);
@@ -543,9 +556,9 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
         a = 0;
         for (s = 0; a <= j; ++s) {
             const bool cr = tab[s].mat_type == PRT_MAT_ANISOTROPIC;
-            off_in += N << a;
+            off_in += P << a;
             if (cr) ++a;
-            off_out += N << a;
+            off_out += P << a;
         }
     }
 }

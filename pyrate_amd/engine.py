@@ -5,6 +5,7 @@ on device-resident (3, N) float64 tensors.  torch is used only as the device
 allocator and stream provider; every number is produced by ``libprt.so``.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -12,6 +13,9 @@ import torch
 from . import _lib
 from . import placed
 from .surface_table import pack_table
+
+
+FUSED_MAX_CRYSTALS = 8       # PRT_FUSED_MAX_CRYSTALS: crystal interfaces the fused walk parks (csrc/prt_kernels.h)
 
 
 def _mode_word(bufs):
@@ -138,6 +142,8 @@ class TraceResult(object):
         self.e_out = e_out            # per surface (re, im) behind crystal interfaces (trace(want_fields))
         self.flags = None             # per surface packed mask bytes (alloc_outputs(packed_flags=True))
         self.nonconv = None           # per surface: Newton ended at its iteration cap (want_nonconv / packed flags)
+        self.padded = None            # crystal tables: the same lists over the raw arrays with ray pitch ``ray_pitch``
+        self.ray_pitch = None
         self.x_hit = x_hit
         self.k_out = k_out
         self.valid = valid
@@ -152,7 +158,7 @@ class TraceResult(object):
         rows = len(n_in)
         pitch = bufs.get("pitch", 0)
         (bx, bk, bv, bw) = (bufs["x_hit"], bufs["k_out"], bufs["valid"], bufs["valid_out"])
-        if pitch:
+        if pitch and not bufs.get("concatenated"):
             n = n_in[0]
 
             def rays(buf):
@@ -176,26 +182,56 @@ class TraceResult(object):
             if bufs.get("nonconv") is not None:
                 res.nonconv = _LazyViews(rows, mask(bufs["nonconv"]))
             return res
-        # concatenated layout (tables with anisotropic media)
+        # concatenated layout (tables with anisotropic media), ray pitch P >= n0: surface s holds B = n_in[s] / n0
+        # branches of P slots each, the first n0 of them rays (include/prt.h).  The per-surface entries are the
+        # TIGHT (3, B * n0) arrays of the reference's stacking: views when P == n0 or B == 1, otherwise gathered
+        # on first access; ``padded`` gives the raw (3, B * P) arrays (what the drop-in layer compacts from).
+        n0 = bufs.get("n0", n_in[0] if n_in else 0)
+        P = bufs.get("pitch") or n0
+        br_in = [(c // n0 if n0 else 1) for c in n_in]
+        br_out = [(c // n0 if n0 else 1) for c in n_out]
         off_in = [0]
         off_out = [0]
-        for (ni, no) in zip(n_in, n_out):
-            off_in.append(off_in[-1] + ni)
-            off_out.append(off_out[-1] + no)
-        e_views = None
-        if bufs.get("e_re") is not None:
-            (er, ei) = (bufs["e_re"], bufs["e_im"])
-            e_views = _LazyViews(rows, lambda s: (er[3 * off_out[s]:3 * off_out[s + 1]].view(3, n_out[s]),
-                                                  ei[3 * off_out[s]:3 * off_out[s + 1]].view(3, n_out[s])))
-        res = cls(
-            _LazyViews(rows, lambda s: bx[3 * off_in[s]:3 * off_in[s + 1]].view(3, n_in[s])),
-            _LazyViews(rows, lambda s: bk[3 * off_out[s]:3 * off_out[s + 1]].view(3, n_out[s])),
-            _LazyViews(rows, lambda s: bv[off_in[s]:off_in[s + 1]]),
-            _LazyViews(rows, (lambda s: bw[off_out[s]:off_out[s + 1]]) if bw is not None else (lambda s: None)),
-            n_in, n_out, bufs["mode"], e_out=e_views)
-        if bufs.get("nonconv") is not None:
-            bn = bufs["nonconv"]
-            res.nonconv = _LazyViews(rows, lambda s: bn[off_in[s]:off_in[s + 1]])
+        for (bi, bo) in zip(br_in, br_out):
+            off_in.append(off_in[-1] + bi * P)
+            off_out.append(off_out[-1] + bo * P)
+
+        def rows3(buf, off, B, padded=False):
+            v = buf[3 * off:3 * (off + B * P)]
+            if padded:
+                return v.view(3, B * P)
+            if P == n0:
+                return v.view(3, B * n0)
+            v = v.view(3, B, P)[:, :, :n0]
+            return v[:, 0, :] if B == 1 else v.reshape(3, B * n0)
+
+        def row1(buf, off, B, padded=False):
+            v = buf[off:off + B * P]
+            if padded or P == n0:
+                return v
+            v = v.view(B, P)[:, :n0]
+            return v[0] if B == 1 else v.reshape(B * n0)
+
+        def views(padded):
+            e_views = None
+            if bufs.get("e_re") is not None:
+                (er, ei) = (bufs["e_re"], bufs["e_im"])
+                e_views = _LazyViews(rows, lambda s: (rows3(er, off_out[s], br_out[s], padded),
+                                                      rows3(ei, off_out[s], br_out[s], padded)))
+            res = cls(
+                _LazyViews(rows, lambda s: rows3(bx, off_in[s], br_in[s], padded)),
+                _LazyViews(rows, lambda s: rows3(bk, off_out[s], br_out[s], padded)),
+                _LazyViews(rows, lambda s: row1(bv, off_in[s], br_in[s], padded)),
+                _LazyViews(rows, (lambda s: row1(bw, off_out[s], br_out[s], padded)) if bw is not None
+                           else (lambda s: None)),
+                n_in, n_out, bufs["mode"], e_out=e_views)
+            if bufs.get("nonconv") is not None:
+                bn = bufs["nonconv"]
+                res.nonconv = _LazyViews(rows, lambda s: row1(bn, off_in[s], br_in[s], padded))
+            return res
+        res = views(False)
+        res.padded = views(True)
+        res.ray_pitch = P
         return res
 
 
@@ -264,8 +300,17 @@ class DeviceSystem(object):
             rows = len(n_in)
             (nx, nk, nv, nw) = (3 * rows * pitch, 3 * rows * pitch, rows * pitch, rows * pitch)
         else:
-            pitch = 0
-            (nx, nk, nv, nw) = (3 * sum(n_in), 3 * sum(n_out), sum(n_in), sum(n_out))
+            # concatenated layout with ray pitch (include/prt.h): n0 rounded up to 128 puts every row of every
+            # level on a 128-B line (0.124 instead of 0.151 ms on BASELINE configs[3]); tight (pitch 0) for the
+            # per-surface march (more crystal interfaces than the fused walk parks)
+            crystals = sum(r["material"]["type"] == "anisotropic" for r in self.records)
+            if pitch is None:
+                pitch = int(self.lib.prt_crystal_pitch(n0))
+            if crystals > FUSED_MAX_CRYSTALS or os.environ.get("PRT_GENERAL_PER_SURFACE") or pitch < n0:
+                pitch = 0
+            P = pitch or n0
+            (pin, pout) = ([c // n0 * P if n0 else 0 for c in n_in], [c // n0 * P if n0 else 0 for c in n_out])
+            (nx, nk, nv, nw) = (3 * sum(pin), 3 * sum(pout), sum(pin), sum(pout))
         if not with_valid_out:
             nw = 0
         auto_placement = placement == "auto"
@@ -314,7 +359,13 @@ class DeviceSystem(object):
                 valid=torch.empty(nv, dtype=torch.uint8, device=dev),
                 valid_out=(torch.empty(nw, dtype=torch.uint8, device=dev) if with_valid_out else None),
                 extra=[], placement={"policy": "torch"})
-        bufs.update(n_in=n_in, n_out=n_out, mode=mode, pitch=pitch, packed_flags=bool(packed_flags))
+        bufs.update(n_in=n_in, n_out=n_out, mode=mode, pitch=pitch, packed_flags=bool(packed_flags), n0=n0,
+                    concatenated=not self.all_isotropic)
+        if not self.all_isotropic and pitch and pitch != n0:
+            # the padding slots of a branch are never written by the engine: their masks say "no ray"
+            bufs["valid"].zero_()
+            if bufs["valid_out"] is not None:
+                bufs["valid_out"].zero_()
         if want_nonconv and not packed_flags:      # packed flags carry the bit themselves (bit 2)
             bufs["nonconv"] = torch.zeros(nv, dtype=torch.uint8, device=dev)
         if want_fields:
@@ -332,8 +383,13 @@ class DeviceSystem(object):
             raise ValueError("k0 is required (or a uniform first segment)")
         if uniform is not None:
             (k0, e0_re, e0_im) = (None, None, None)
-        if not self.all_isotropic:      # crystal march: tight arrays
-            (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
+        if not self.all_isotropic:
+            # the fused crystal march takes row-pitched inputs; the per-surface march (more crystal interfaces than
+            # the walk parks) and mixed pitches need tight arrays
+            strides = set(t.stride(0) for t in (x0, k0, e0_re, e0_im) if t is not None and t.shape[1] > 0)
+            if len(strides) > 1 or not bufs.get("pitch") or any(t is not None and t.shape[1] > 0 and t.stride(1) != 1
+                                                                 for t in (x0, k0, e0_re, e0_im)):
+                (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
         a = _lib.PrtTraceArgs()
         a.struct_bytes = ctypes.sizeof(_lib.PrtTraceArgs)
         a.mode = _mode_word(bufs)
@@ -364,6 +420,21 @@ class DeviceSystem(object):
         bundles whose first direction is k/|k| / given in e0_re."""
         a = self._trace_args(x0, k0, bufs, e0_re, e0_im, uniform, first_dir)
         _lib.check(self.lib.prt_trace_ex(self._h, ctypes.byref(a)))
+
+    def launcher(self, x0, k0, bufs, e0_re=None, e0_im=None, uniform=None, first_dir=None):
+        """a callable that enqueues this trace on the current stream: the argument struct is built once, a call
+        costs one ctypes call (repeated traces into the same arrays: timing loops, wavelength sweeps; the
+        march of a small crystal bundle takes 0.12 ms, building the struct in Python about as long)"""
+        a = self._trace_args(x0, k0, bufs, e0_re, e0_im, uniform, first_dir)
+        (fn, h, ref, dev) = (self.lib.prt_trace_ex, self._h, ctypes.byref(a), self.device)
+
+        def launch():
+            a.stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = fn(h, ref)
+            if rc < 0:
+                _lib.check(rc)
+        launch.args = a
+        return launch
 
     def trace_moments_into(self, x0, k0, bufs, ws, slot=0, e0_re=None, e0_im=None, ref=None, uniform=None,
                            first_dir=None):
@@ -419,8 +490,8 @@ class DeviceSystem(object):
         for (t, name) in ((x0, "x0"), (k0, "k0"), (e0_re, "e0_re"), (e0_im, "e0_im")):
             if t is not None:
                 pitches.add(_check_rays(t, name, n0, allow_pitch=True))
-        if len(pitches) > 1 or not self.all_isotropic:
-            # mixed pitches, or the per-surface march (tight arrays): tight copies
+        if len(pitches) > 1:
+            # mixed pitches: tight copies (the per-surface march through many crystals gets them in _trace_args)
             (x0, k0, e0_re, e0_im) = [_rows_contiguous(t) for t in (x0, k0, e0_re, e0_im)]
         with torch.cuda.device(self.device):
             bufs = self.alloc_outputs(n0, mode, want_fields=want_fields,
@@ -506,7 +577,8 @@ def trace_seq(records, x0, k0, d0=None, mode=_lib.MODE_PATH, want_nonconv=False,
         bufs = dict(x_hit=torch.empty(3 * sum(counts_in), dtype=torch.float64, device=dev),
                     k_out=torch.empty(3 * sum(counts_out), dtype=torch.float64, device=dev),
                     valid=torch.empty(sum(counts_in), dtype=torch.uint8, device=dev), valid_out=None,
-                    n_in=counts_in, n_out=counts_out, mode=mode, pitch=0, packed_flags=False)
+                    n_in=counts_in, n_out=counts_out, mode=mode, pitch=0, packed_flags=False, n0=n,
+                    concatenated=True)
         if want_nonconv:
             bufs["nonconv"] = torch.zeros(sum(counts_in), dtype=torch.uint8, device=dev)
         _lib.check(lib.prt_trace_seq(table, S, n, _ptr(x0), _ptr(k0), _ptr(d0), None, mode, _ptr(bufs["x_hit"]),

@@ -212,7 +212,15 @@ def _seqtrace_fused_crystal(ib, records, lengths):
     wave = ib.wave
     crystal = [r["material"]["type"] == "anisotropic" for r in records]
     first_crystal = crystal.index(True)
-    ids_cache = {0: ib.ray_ids_dev()}
+    # The dense arrays have a ray pitch P >= n (rows of every level on 128-B lines, engine.alloc_outputs): a branch
+    # is P slots of which the first n are rays and the rest carry mask 0 -- so the compaction by ``valid_out`` that
+    # carves a bundle out of them drops the padding by itself, and nothing has to be gathered beforehand.
+    dense = res.padded
+    P = res.ray_pitch
+    ids0 = ib.ray_ids_dev()
+    if P != n:
+        ids0 = torch.cat((ids0, torch.zeros(P - n, dtype=ids0.dtype, device=dev)))
+    ids_cache = {0: ids0}
 
     def dense_ids(level):
         # ids of the dense slots after ``level`` doublings: [ids, ids] per crystal interface
@@ -229,17 +237,17 @@ def _seqtrace_fused_crystal(ib, records, lengths):
         level = sum(crystal[:s + 1])
 
         def thunk(b):
-            mask = res.valid_out[s]
-            xs = res.x_hit[s]
+            mask = dense.valid_out[s]
+            xs = dense.x_hit[s]
             if crystal[s]:
                 xs = torch.cat((xs, xs), dim=1)
-            arrays = [xs, res.k_out[s]]
+            arrays = [xs, dense.k_out[s]]
             if crystal[s]:
-                arrays += list(res.e_out[s])
+                arrays += list(dense.e_out[s])
             flags = None
             if j < S:
-                arrays.append(res.x_hit[j])
-                flags = res.valid[j]
+                arrays.append(dense.x_hit[j])
+                flags = dense.valid[j]
             out = engine.compact(mask, arrays, dense_ids(level), flags)
             arr = out[0]
             (cx, ck) = (arr[0], arr[1])

@@ -301,9 +301,9 @@ def test_error_codes_and_unsupported_tables(gpu_device):
     rec_a = systems.aniso_doublet_records()
     sysa = engine.DeviceSystem(rec_a, 0)
     bufa = sysa.alloc_outputs(8, 0)
-    bufa["pitch"] = 512
+    bufa["pitch"] = 4
     with pytest.raises(_lib.PrtError):
-        sysa.trace_into(x, x, bufa)                        # crystals use the concatenated layout
+        sysa.trace_into(x, x, bufa)                        # a ray pitch smaller than the ray count
 
 
 @pytest.mark.parametrize("name", ["double_gauss_wide", "tilted_frames", "asphere_strong_field5"])

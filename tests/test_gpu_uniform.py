@@ -215,7 +215,7 @@ def test_wrappers_equal_prt_trace_ex(gpu_device):
     sysc = engine.DeviceSystem(recs, 0)
     (xt, kt, et) = [engine.to_device_rays(a, gpu_device, pitched=False) for a in (o, k, e)]
     refc = sysc.trace(xt, kt, et, want_fields=True)
-    b = sysc.alloc_outputs(n, want_fields=True)
+    b = sysc.alloc_outputs(n, want_fields=True, pitch=0)        # the wrapper's layout is the tight one
     _lib.check(lib.prt_trace_fields(sysc._h, n, P(xt), P(kt), P(et), None, 0, P(b["x_hit"]), P(b["k_out"]),
                                     P(b["e_re"]), P(b["e_im"]), P(b["valid"]), P(b["valid_out"]), st))
     got = sysc.views(b)
@@ -309,3 +309,73 @@ def test_xypoly_march_at_full_size(gpu_device):
         assert np.array_equal(res.valid_out[s][idx].cpu().numpy().astype(bool), v)
         assert np.abs(res.x_hit[s][:, idx].cpu().numpy()[:, v] - out[s]["x_hit"][:, v]).max() < 1e-10
         assert np.abs(res.k_out[s][:, idx].cpu().numpy()[:, v] - out[s]["k_out"][:, v]).max() < 1e-12
+
+
+def test_dense_polynomial_in_scalar_registers_equals_the_streamed_evaluation(gpu_device):
+    """XY polynomials of total degree <= 4 are evaluated from scalar registers (dense_poly_eval, coefficients
+    fetched once per surface); anything bigger streams its Horner rows (xypoly_eval).  Same Horner order: a
+    degree-5 term too small to matter (1e-300) sends the same surface down the streaming path -- bit-identical
+    path arrays, tilted field, 1e6 rays; and a sparse polynomial (missing rows / columns) against the oracle"""
+    from pyrate_amd import engine, systems
+    (x0, uni, _, n) = systems.double_gauss_bundle_device(1000000, gpu_device, rpup=9.0, z0=-5.0, field_deg=5.0,
+                                                         uniform=True)
+    recs = systems.xypoly_records()
+    streamed = systems.xypoly_records()
+    streamed[2]["shape"]["terms"] = list(streamed[2]["shape"]["terms"]) + [[5, 0, 1e-300], [0, 5, 1e-300]]
+    a = engine.DeviceSystem(recs, 0).trace(x0, None, packed_flags=True, uniform=uni)
+    b = engine.DeviceSystem(streamed, 0).trace(x0, None, packed_flags=True, uniform=uni)
+    _same(a, b)
+    assert int(a.valid_out[-1].sum()) == n
+    sparse = systems.xypoly_records()
+    sparse[2]["shape"]["terms"] = [[2, 0, -1. / 55.], [0, 2, -1. / 65.], [0, 3, 2e-5], [4, 0, -1e-6], [1, 1, 1e-4],
+                                   [0, 0, 0.01], [1, 0, 1e-3]]
+    res = engine.DeviceSystem(sparse, 0).trace(x0, None, packed_flags=True, uniform=uni)
+    idx = torch.arange(0, n, 500, device=gpu_device)
+    o_s = x0[:, idx].cpu().numpy()
+    k_s = np.repeat(np.array(uni.k)[:, None], o_s.shape[1], axis=1)
+    e_s = np.repeat(np.array(uni.e_re)[:, None], o_s.shape[1], axis=1)
+    out = oracle.trace(sparse, o_s, k_s, e_s)
+    for s in range(4):
+        v = out[s]["valid_out"]
+        assert v.all() and np.array_equal(res.valid_out[s][idx].cpu().numpy().astype(bool), v)
+        assert np.abs(res.x_hit[s][:, idx].cpu().numpy() - out[s]["x_hit"]).max() < 1e-11
+        assert np.abs(res.k_out[s][:, idx].cpu().numpy() - out[s]["k_out"]).max() < 1e-13
+
+
+@pytest.mark.parametrize("n_req", [1000000, 777, 130])
+def test_crystal_layout_with_a_ray_pitch_equals_the_tight_layout(n_req, gpu_device):
+    """tables with crystals: the concatenated layout with ray pitch P = n rounded up to 128 (rows of every level on
+    128-B lines, what alloc_outputs picks) holds the same numbers as the tight layout, bit for bit -- path and
+    image mode, E fields included; the padding slots of a branch carry mask 0 and are never written"""
+    from pyrate_amd import engine, systems, _lib
+    (recs, bargs, _) = _configs()["aniso"]
+    sysd = engine.DeviceSystem(recs, 0)
+    (x0, uni, _, n) = systems.double_gauss_bundle_device(n_req, gpu_device, uniform=True, **bargs)
+    P = int(_lib.load().prt_crystal_pitch(n))
+    assert P % 128 == 0 and 0 <= P - n < 128
+    for mode in (_lib.MODE_PATH, _lib.MODE_IMAGE):
+        for fields in (False, True):
+            tight = sysd.alloc_outputs(n, mode, pitch=0, want_fields=fields)
+            pitched = sysd.alloc_outputs(n, mode, want_fields=fields)
+            assert tight["pitch"] == 0 and pitched["pitch"] == P
+            for b in (tight, pitched):
+                b["x_hit"].fill_(-7.0)
+                b["k_out"].fill_(-7.0)
+                sysd.trace_into(x0, None, b, uniform=uni)
+            (rt, rp) = (sysd.views(tight), sysd.views(pitched))
+            _same(rp, rt)
+            if fields:
+                for s in range(len(rt.x_hit)):
+                    if rt.e_out[s] is not None and recs[s if mode == _lib.MODE_PATH else -1]["material"]["type"] == "anisotropic":
+                        assert torch.equal(_bits(rp.e_out[s][0]), _bits(rt.e_out[s][0]))
+            if P != n:
+                for s in range(len(rt.x_hit)):
+                    B = rp.padded.valid_out[s].numel() // P
+                    assert int(rp.padded.valid_out[s].view(B, P)[:, n:].sum()) == 0
+                    assert int(rp.padded.valid[s].view(-1, P)[:, n:].sum()) == 0
+                    assert float(rp.padded.k_out[s].view(3, B, P)[:, :, n:].min()) == -7.0        # untouched
+                    assert float(rp.padded.k_out[s].view(3, B, P)[:, :, n:].max()) == -7.0
+    # pitched inputs are taken as they are (no tight copy), and give the same bits
+    (xa, ka, ea, _) = systems.double_gauss_bundle_device(n_req, gpu_device, **bargs)
+    assert n < 512 or xa.stride(0) != n
+    _same(sysd.trace(xa, ka, ea), sysd.trace(xa.contiguous(), ka.contiguous(), ea.contiguous()))
