@@ -1,15 +1,40 @@
-"""drop-in OpticalSystem.seqtrace at 1e7 rays vs the bench kernel (round 2 verdict item 1): one call at a
-time (host work + kernel, synchronised) and back to back (the host work of call i+1 overlaps the kernel of
-call i: what an optimiser loop or a wavelength sweep sees)"""
+"""drop-in OpticalSystem.seqtrace at 1e7 rays vs the bench kernel: the COLD START (first call of a fresh process:
+library load, table upload, the arena's hunt for three kinds of HBM, first launch -- everything a user's first
+seqtrace pays), then one call at a time (host work + kernel, synchronised) and back to back (the host work of
+call i+1 overlaps the kernel of call i: what an optimiser loop or a wavelength sweep sees).
+
+    python benchmarks/dropin_call_time.py > profiles/<tag>_dropin_call_time.json
+"""
 import json, os, sys, time
+T0 = time.perf_counter()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pyrate_amd import engine, systems, placed
 from pyrate_amd.builders import build_rotationally_symmetric_optical_system
 from pyrate_amd.raytracer.ray import RayBundle
+t_import = time.perf_counter() - T0
 (s, seq) = build_rotationally_symmetric_optical_system(systems.double_gauss_tuples())
 (o, k, e0) = systems.double_gauss_bundle(10000000)
-ib = RayBundle(o, k, e0, wave=systems.DLINE)
+torch.cuda.init()
+torch.zeros(1, device="cuda").item()                 # HIP context up: not the engine's cost
+t0 = time.perf_counter()
+ib = RayBundle(o, k, e0, wave=systems.DLINE)          # host arrays of a collimated bundle: recognised as uniform
+torch.cuda.synchronize()
+t_bundle = time.perf_counter() - t0
+t0 = time.perf_counter()
+rp = s.seqtrace(ib, seq)                              # FIRST call: table upload + arena hunt + launch
+torch.cuda.synchronize()
+t_first = time.perf_counter() - t0
+arena_cold = placed.PlacedArena.for_device(0).stats()
+t0 = time.perf_counter()
+x_img = rp.raybundles[-1].x                           # first look at a result: compaction + D2H of the image plane
+t_first_result = time.perf_counter() - t0
+del rp, x_img
+t0 = time.perf_counter()
+rp = s.seqtrace(ib, seq)
+torch.cuda.synchronize()
+t_second = time.perf_counter() - t0
+del rp
 for _ in range(5):
     rp = s.seqtrace(ib, seq); del rp
 torch.cuda.synchronize()
@@ -28,10 +53,15 @@ torch.cuda.synchronize()
 back_to_back = (time.perf_counter() - t0) * 1e3 / 20
 # the kernel alone into the same kind of arrays
 sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
-(x0, k0, e0d) = [engine.to_device_rays(a, torch.device("cuda", 0)) for a in (o, k, e0)]
+x0 = ib._x[-1]
 bufs = sysd.alloc_outputs(o.shape[1], packed_flags=True)
-sysd.trace_timed(x0, k0, bufs, 10, e0d)
-kernel_ms = sysd.trace_timed(x0, k0, bufs, 30, e0d)
-print(json.dumps({"dropin_seqtrace_call_ms_synchronised": [round(t, 4) for t in ts],
+sysd.trace_timed(x0, None, bufs, 10, uniform=ib._uniform)
+kernel_ms = sysd.trace_timed(x0, None, bufs, 30, uniform=ib._uniform)
+print(json.dumps({"cold_start": {"import_s": t_import, "bundle_upload_ms": t_bundle * 1e3,
+                                 "first_seqtrace_ms": t_first * 1e3, "second_seqtrace_ms": t_second * 1e3,
+                                 "first_look_at_the_image_plane_ms": t_first_result * 1e3,
+                                 "arena_after_first_call": arena_cold,
+                                 "uniform_bundle": ib._uniform is not None},
+                  "dropin_seqtrace_call_ms_synchronised": [round(t, 4) for t in ts],
                   "dropin_seqtrace_ms_back_to_back": back_to_back, "kernel_ms": kernel_ms, "rays": o.shape[1],
                   "arena": placed.PlacedArena.for_device(0).stats()}))

@@ -485,8 +485,9 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
  *                     the write streams cost 3 % of the march); further parts get a kind no other part
  *                     of the call uses when slabs of one are at hand.  To find the kinds the arena
  *                     may take up to max_hunt_slabs extra slabs from the driver for the duration
- *                     of the call (-1: default 256 -- a kind is 96 GiB, so the third can be 192 slabs away; about 2.5 ms per
- *                     slab, once); if the device cannot offer that many kinds
+ *                     of the call (-1: default = half of the memory that is free at the time of the call, at most
+ *                     256 -- a kind is 96 GiB, so the third can be 192 slabs away; about 2.5 ms per slab, once; a
+ *                     hunt also stops after 2 s of probing, PRT_ARENA_HUNT_MS); if the device cannot offer that many kinds
  *                     the call still succeeds and kinds[] tells.  avoid_mask (bit q = kind q):
  *                     kinds this request leaves to others if it can -- a caller that allocates its
  *                     input arrays separately passes 3, which keeps them out of kinds 0 and 1, the
@@ -500,7 +501,9 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
  *                     request of the same size and kind without any driver call.
  *   prt_arena_trim    hands all cached (unused) memory back to the driver.
  *   prt_arena_set_budget  caps the physical memory the arena may hold at any time, in 1-GiB slabs (in use +
- *                     cached + free + the representatives; negative = no cap, the default).  At the cap a
+ *                     cached + free + the representatives; negative = no cap; default: three quarters of the
+ *                     device's memory, PRT_ARENA_BUDGET_GIB).  Independently, cached (unused) buffers beyond
+ *                     64 GiB (PRT_ARENA_CACHE_GIB) are handed back to the driver when a buffer is freed.  At the cap a
  *                     request behaves as if the driver had nothing left: cached buffers of other sizes are
  *                     taken apart, fewer kinds are accepted, or PRT_ERR_NOMEM.
  *   prt_arena_kind_of kind index of a pointer inside one of the arena's buffers.

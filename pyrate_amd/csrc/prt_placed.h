@@ -73,6 +73,8 @@ struct prt_arena {
     double self_rate = 0.0;        // yardstick of the current hunt: a slab against itself, GB/s
     int64_t va_reserved = 0;       // bytes of address space taken so far (never returned, see above)
     int64_t slab_budget = -1;      // cap on the slabs held at any time (created - released); < 0: none
+    int64_t cache_cap = 64;        // cap on the slabs of cached (unused, still mapped) buffers + free slabs
+    double hunt_ms_cap = 2000.0;   // a hunt for kinds stops taking slabs after this long (it then settles for fewer)
     std::vector<prt_slab> free_slabs;
     std::vector<prt_placed_buffer *> buffers;      // in use and cached
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -197,6 +199,7 @@ static hipError_t arena_new_slab(prt_arena *a, hipStream_t st, prt_slab *out, bo
     void *va = nullptr;
     if ((e = arena_fresh_va(a, &va, PRT_SLAB_BYTES)) != hipSuccess || (e = arena_map(a, va, s)) != hipSuccess) {
         (void)hipMemRelease(s.handle);
+        a->n_released += 1;      // (keeps created - released = slabs held: what the budget counts)
         return e;
     }
     int32_t kind = -1;
@@ -204,6 +207,7 @@ static hipError_t arena_new_slab(prt_arena *a, hipStream_t st, prt_slab *out, bo
     if (e != hipSuccess) {
         (void)hipMemUnmap(va, PRT_SLAB_BYTES);
         (void)hipMemRelease(s.handle);
+        a->n_released += 1;
         return e;
     }
     if (kind == a->n_kinds && a->n_kinds < PRT_ARENA_MAX_KINDS) {
@@ -319,8 +323,41 @@ int32_t prt_arena_create(int32_t device, prt_arena_t **out) {
         delete a;
         return fail(PRT_ERR_DEVICE, "prt_arena_create", e);
     }
+    // Defaults that keep the arena a good neighbour of the torch allocator and of other processes on the device
+    // (ADVICE round 2): never more than three quarters of the device's memory, at most 64 GiB of cached (unused)
+    // memory, a hunt bounded in time.  PRT_ARENA_BUDGET_GIB / PRT_ARENA_CACHE_GIB / PRT_ARENA_HUNT_MS override.
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0)
+        a->slab_budget = (int64_t)(total_b / PRT_SLAB_BYTES) * 3 / 4;
+    if (const char *v = getenv("PRT_ARENA_BUDGET_GIB")) a->slab_budget = atoll(v);
+    if (const char *v = getenv("PRT_ARENA_CACHE_GIB")) a->cache_cap = atoll(v);
+    if (const char *v = getenv("PRT_ARENA_HUNT_MS")) a->hunt_ms_cap = atof(v);
     *out = a;
     return PRT_OK;
+}
+
+// cached (unused) buffers beyond the cache cap go back to the driver, oldest first (caller holds the lock)
+static void arena_shrink_cache(prt_arena *a) {
+    if (a->cache_cap < 0) return;
+    int64_t cached = (int64_t)a->free_slabs.size();
+    for (const prt_placed_buffer *b : a->buffers)
+        if (!b->in_use) cached += (int64_t)b->slabs.size();
+    for (size_t i = 0; i < a->buffers.size() && cached > a->cache_cap;) {
+        prt_placed_buffer *b = a->buffers[i];
+        if (!b->in_use) {
+            cached -= (int64_t)b->slabs.size();
+            arena_unmap_buffer(a, b, false);     // waits for the buffer's last user (its release event)
+            delete b;
+            a->buffers.erase(a->buffers.begin() + i);
+        } else {
+            ++i;
+        }
+    }
+    while (cached > a->cache_cap && !a->free_slabs.empty()) {
+        arena_release_slab(a, a->free_slabs.back());
+        a->free_slabs.pop_back();
+        --cached;
+    }
 }
 
 int32_t prt_arena_trim(prt_arena_t *a) {
@@ -382,9 +419,16 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
         if (bytes[i] <= 0) return fail(PRT_ERR_INVALID_ARG, "prt_arena_alloc: part sizes must be positive");
         ptrs[i] = nullptr;
     }
-    if (max_hunt_slabs < 0) max_hunt_slabs = 256;   // a kind is 96 GiB: 192 slabs of the other two at worst
     PRT_ON_DEVICE(a->device);
     std::lock_guard<std::mutex> lock(a->mu);
+    if (max_hunt_slabs < 0) {
+        // a kind is 96 GiB, so the third one can be 192 slabs of the other two away -- but a hunt holds what it walks
+        // through: by default it may take at most half of what is free right now (and never more than 256 slabs)
+        size_t free_b = 0, total_b = 0;
+        max_hunt_slabs = 256;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            max_hunt_slabs = (int32_t)std::min<size_t>(256, free_b / PRT_SLAB_BYTES / 2);
+    }
     hipStream_t st = (hipStream_t)stream;
     size_t need[8];
     for (int i = 0; i < n_parts; ++i) need[i] = ((size_t)bytes[i] + PRT_SLAB_BYTES - 1) / PRT_SLAB_BYTES;
@@ -432,10 +476,14 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
     a->self_rate = 0.0;            // re-measured by the first slab this call takes from the driver
     int32_t hunted = 0;
     hipError_t hunt_err = hipSuccess;
+    const double probe_ms_start = a->probe_ms_total;
     while (!assign(n_distinct, false)) {
         size_t total_need = 0;
         for (int i = 0; i < n_parts; ++i) total_need += need[i];
         if (hunted >= (int32_t)total_need + max_hunt_slabs) break;
+        // bounded in time as well: once the request could be served with fewer kinds, a hunt that has probed for
+        // hunt_ms_cap stops and settles for them (kinds[] tells the caller)
+        if (a->hunt_ms_cap >= 0 && a->probe_ms_total - probe_ms_start > a->hunt_ms_cap && assign(0, true)) break;
         prt_slab s;
         bool became_rep = false;
         hunt_err = arena_new_slab(a, st, &s, &became_rep);
@@ -522,6 +570,7 @@ int32_t prt_arena_free(prt_arena_t *a, void *ptr, void *stream) {
             if (!b->released) HIP_TRY(hipEventCreateWithFlags(&b->released, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(b->released, (hipStream_t)stream));
             b->in_use = false;        // stays mapped: the next request of this size and kind takes it as it is
+            arena_shrink_cache(a);     // ... unless the cache is over its cap
             return PRT_OK;
         }
     return fail(PRT_ERR_INVALID_ARG, "prt_arena_free: not a buffer of this arena");

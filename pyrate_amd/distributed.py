@@ -139,6 +139,12 @@ class ImagePlaneGather(object):
             self._work = []
             return
         srcs = self._sources(x_img, k_img, valid, e_re, e_im, n)
+        if x_img.is_cuda:
+            # the collectives read the trace's own output arrays on THIS stream: if they live in the placement arena,
+            # their release must wait for it (placed.record_stream; no-op for torch-allocated arrays)
+            from . import placed
+            for t in (x_img, k_img, valid):
+                placed.record_stream(t)
         if self.stage_on_host and x_img.is_cuda:
             torch.cuda.current_stream(x_img.device).synchronize()     # D2H staging complete
         self._work = [dist.all_gather_into_tensor(self._dest(row, b), src, group=self.group, async_op=True)

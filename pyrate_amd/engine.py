@@ -18,6 +18,17 @@ from .surface_table import pack_table
 FUSED_MAX_CRYSTALS = 8       # PRT_FUSED_MAX_CRYSTALS: crystal interfaces the fused walk parks (csrc/prt_kernels.h)
 
 
+def _torch_alloc(make):
+    """a torch allocation that, out of memory, first makes the arena hand its cached buffers back to the driver
+    (torch's caching allocator cannot reclaim those) and tries once more"""
+    try:
+        return make()
+    except torch.cuda.OutOfMemoryError:
+        placed.trim_all()
+        torch.cuda.empty_cache()
+        return make()
+
+
 def _mode_word(bufs):
     return bufs["mode"] | (_lib.MODE_FLAGS if bufs.get("packed_flags") else 0)
 
@@ -321,6 +332,8 @@ class DeviceSystem(object):
         if placement not in ("arena", "torch"):
             raise ValueError("placement must be 'auto', 'arena' or 'torch'")
         parts = None
+        if placement == "arena" and placed.DISABLED is not None:
+            raise RuntimeError("placement='arena' but the arena is switched off: %s" % placed.DISABLED)
         if placement == "arena":
             # part 0: x_hit, then the mask bytes (each on a 4-KiB boundary); part 1: k_out
             def up(v):
@@ -353,12 +366,12 @@ class DeviceSystem(object):
         else:
             if extra_bytes:
                 raise ValueError("extra_bytes needs arena placement")
-            bufs = dict(
+            bufs = _torch_alloc(lambda: dict(
                 x_hit=torch.empty(nx, dtype=torch.float64, device=dev),
                 k_out=torch.empty(nk, dtype=torch.float64, device=dev),
                 valid=torch.empty(nv, dtype=torch.uint8, device=dev),
                 valid_out=(torch.empty(nw, dtype=torch.uint8, device=dev) if with_valid_out else None),
-                extra=[], placement={"policy": "torch"})
+                extra=[], placement={"policy": "torch"}))
         bufs.update(n_in=n_in, n_out=n_out, mode=mode, pitch=pitch, packed_flags=bool(packed_flags), n0=n0,
                     concatenated=not self.all_isotropic)
         if not self.all_isotropic and pitch and pitch != n0:
@@ -604,7 +617,7 @@ def compact(mask, arrays, ids=None, flags=None):
     if nrow > 16:
         raise ValueError("compact: at most 16 rows per call")
     with torch.cuda.device(dev):
-        tmp = torch.empty((max(nrow, 1), n), dtype=torch.float64, device=dev)
+        tmp = _torch_alloc(lambda: torch.empty((max(nrow, 1), n), dtype=torch.float64, device=dev))
         idt = torch.empty(n, dtype=torch.int64, device=dev) if ids is not None else None
         flt = torch.empty(n, dtype=torch.uint8, device=dev) if flags is not None else None
         scratch = torch.empty(lib.prt_compact_scratch_bytes(n), dtype=torch.uint8, device=dev)
@@ -877,7 +890,7 @@ def ray_rows(n, device):
             # no whole free slabs left / no virtual-memory API: torch memory, slower placement
             if exc.code != _lib.ERR_NOMEM:
                 placed.disable("prt_arena_alloc failed: %s" % exc)
-    return torch.empty((3, pitch), dtype=torch.float64, device=device)[:, :n]
+    return _torch_alloc(lambda: torch.empty((3, pitch), dtype=torch.float64, device=device))[:, :n]
 
 
 def to_device_rays(a, device, pitched=True):

@@ -12,6 +12,7 @@ last view dies the buffer goes back to the arena, which keeps it mapped for the 
 import ctypes
 import os
 import threading
+import weakref
 
 import torch
 
@@ -28,8 +29,10 @@ OUTPUT_KINDS_MASK = 0b011       # a two-part output request takes kinds 0 and 1
 
 
 # set (with the reason) when the arena turned out to be unusable on this machine -- e.g. a driver without
-# the HIP virtual-memory API; automatic placement then stays with the torch allocator for the process
-DISABLED = None
+# the HIP virtual-memory API; automatic placement then stays with the torch allocator for the process.
+# PRT_ARENA=off switches the arena off from the start (every array from the torch allocator).
+DISABLED = "PRT_ARENA=%s" % os.environ["PRT_ARENA"] if os.environ.get("PRT_ARENA", "").lower() in ("off", "0", "no") \
+    else None
 
 
 def disable(reason):
@@ -39,6 +42,24 @@ def disable(reason):
         import warnings
         warnings.warn("pyrate_amd: placement-aware memory switched off, path arrays come from the torch "
                       "allocator (%s)" % reason, RuntimeWarning)
+
+
+def record_stream(tensor, stream=None):
+    """``PlacedArena.record_stream`` for whatever device the tensor lives on (no-op outside the arena)"""
+    if DISABLED is not None or not tensor.is_cuda:
+        return False
+    arena = PlacedArena._instances.get(tensor.device.index)
+    return arena.record_stream(tensor, stream) if arena is not None else False
+
+
+def trim_all():
+    """hand every arena's cached (unused) memory back to the driver -- what the engine does when a torch
+    allocation runs out of memory (the caching allocator cannot reclaim what the arena holds)"""
+    for arena in list(PlacedArena._instances.values()):
+        try:
+            arena.trim()
+        except Exception:
+            pass
 
 
 class InputRows(object):
@@ -72,6 +93,7 @@ class _Block(object):
         self.ptr = ptr
         self.nbytes = nbytes
         self.kind = kind
+        self.streams = set()          # streams other than the allocating one that used the memory (record_stream)
 
     @property
     def __cuda_array_interface__(self):
@@ -80,7 +102,7 @@ class _Block(object):
 
     def __del__(self):
         try:
-            self.arena._release(self.ptr)
+            self.arena._release(self.ptr, self.streams)
         except Exception:           # interpreter shutdown: the process takes the memory with it
             pass
 
@@ -109,7 +131,7 @@ _DLManagedTensor._fields_ = [("dl_tensor", _DLTensor), ("manager_ctx", ctypes.c_
                              ("deleter", _DLDeleter)]
 _KDLROCM = 10
 _dl_alive = {}            # address of the managed tensor -> (managed tensor, shape array, block)
-_dl_lock = threading.Lock()
+_dl_lock = threading.RLock()    # re-entrant: a garbage collection inside _dlpack_tensor may run _dl_delete
 
 
 @_DLDeleter
@@ -152,6 +174,7 @@ class PlacedArena(object):
         _lib.check(self.lib.prt_arena_create(self.device_index, ctypes.byref(handle)))
         self._h = handle
         self._wrap = os.environ.get("PRT_PLACED_WRAP", "")       # "", "cai" or "dlpack"
+        self._blocks = {}                                        # base pointer -> weak reference to its _Block
 
     @classmethod
     def for_device(cls, device_index):
@@ -161,12 +184,18 @@ class PlacedArena(object):
                 arena = cls._instances[device_index] = cls(device_index)
             return arena
 
-    def _release(self, ptr):
-        # (on the current stream: the stream the buffer's last kernels were launched on in every use
-        # this package makes of it; prt_arena_free records an event there instead of waiting)
+    def _release(self, ptr, streams=()):
+        # prt_arena_free records an event on ONE stream instead of waiting; the next user of the memory is ordered
+        # behind it.  That stream is the current one at the time the last tensor dies -- made to wait first for
+        # every other stream the memory was used on (record_stream: a gather on a side stream, ...), so that
+        # the release is behind all of its users whatever stream the garbage collector happens to run under.
+        self._blocks.pop(ptr, None)
         if self._h:
-            stream = ctypes.c_void_p(torch.cuda.current_stream(self.device_index).cuda_stream)
-            self.lib.prt_arena_free(self._h, ctypes.c_void_p(ptr), stream)
+            cur = torch.cuda.current_stream(self.device_index)
+            for s in streams:
+                if s != cur:
+                    cur.wait_stream(s)
+            self.lib.prt_arena_free(self._h, ctypes.c_void_p(ptr), ctypes.c_void_p(cur.cuda_stream))
 
     def _tensor(self, block):
         dev = torch.device("cuda", self.device_index)
@@ -198,8 +227,24 @@ class PlacedArena(object):
         for i in range(n):
             rounded = -(-int(sizes[i]) // SLAB_BYTES) * SLAB_BYTES
             block = _Block(self, ptrs[i], rounded, int(kinds[i]))
+            self._blocks[ptrs[i]] = weakref.ref(block)
             out.append(self._tensor(block))
         return out, [int(k) for k in kinds]
+
+    def record_stream(self, tensor, stream=None):
+        """tell the arena that ``tensor`` (a view into one of its buffers) is used on ``stream`` (default: the
+        current one) -- like torch.Tensor.record_stream for the caching allocator: the buffer is not handed to
+        its next user before the work queued on that stream so far ... at release time has finished.  No-op for
+        tensors that do not live in the arena."""
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device_index)
+        p = tensor.data_ptr()
+        for (base, ref) in list(self._blocks.items()):
+            blk = ref()
+            if blk is not None and base <= p < base + blk.nbytes:
+                blk.streams.add(stream)
+                return True
+        return False
 
     def kind_of(self, tensor):
         kind = ctypes.c_int32(-1)

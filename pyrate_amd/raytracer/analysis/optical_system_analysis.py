@@ -8,7 +8,7 @@ import math
 import numpy as np
 
 from ... import engine
-from ...sampling2d.raster import RectGrid
+from ...sampling2d.raster import RectGrid, device_tables_of
 from ..globalconstants import degree, standard_wavelength
 from ..ray import RayBundle, default_device
 
@@ -75,7 +75,7 @@ class OpticalSystemAnalysis(object):
         if bundletype not in ("collimated", "divergent"):
             raise KeyError(bundletype)
         rasterobj = rays_dict.get("raster", RectGrid())
-        tables = rasterobj.device_tables(numrays) if hasattr(rasterobj, "device_tables") else None
+        tables = device_tables_of(rasterobj, numrays)
         if tables is not None:
             self.initial_bundles = [self._bundle_on_device(tables, bundletype, rays_dict, wave)]
             return

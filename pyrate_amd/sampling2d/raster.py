@@ -9,6 +9,25 @@ import math
 import numpy as np
 
 
+def device_tables_of(rasterobj, nray):
+    """``rasterobj.device_tables(nray)`` if those tables describe the samples ``rasterobj.getGrid`` returns, else
+    None (host sampling, like the reference, which always calls getGrid: analysis/optical_system_analysis.py:
+    99-100).  The tables belong to the class that defines them: a subclass that overrides ``getGrid`` WITHOUT
+    overriding ``device_tables`` has its own samples and inherits somebody else's tables -- not used."""
+    if not hasattr(rasterobj, "device_tables"):
+        return None
+    mro = type(rasterobj).__mro__
+
+    def owner(name):
+        for (depth, k) in enumerate(mro):
+            if name in k.__dict__:
+                return depth
+        return len(mro)
+    if owner("device_tables") > owner("getGrid"):      # getGrid was overridden further down than the tables
+        return None
+    return rasterobj.device_tables(nray)
+
+
 def _inside_unit_disk(x, y):
     keep = (x ** 2 + y ** 2) <= 1
     return (x[keep], y[keep])
@@ -19,8 +38,6 @@ class RectGrid(object):
         """[(xa, xb, ya, yb, clip), ...]: the raster as outer products x = xa[j] * xb[i],
         y = ya[j] * yb[i] (i slow, j fast), one entry per sub-raster in output order; None for
         rasters that are not of this form (random ones, hand-picked rays)"""
-        if type(self).getGrid is not RectGrid.getGrid:
-            return None                     # a subclass with its own samples and no tables
         x1d = self._samples_1d(nray)
         one = np.ones_like(x1d)
         return [(x1d, one, one, x1d, True)]

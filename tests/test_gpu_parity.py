@@ -439,46 +439,6 @@ def test_arena_outputs_are_ordinary_buffers_in_two_kinds_of_memory(gpu_device):
     assert arena.stats()["slabs_cached"] == 0 and arena.stats()["slabs_in_use"] == in_use_before
 
 
-def test_arena_placement_makes_the_full_size_march_fast_and_repeatable(gpu_device):
-    """the claim behind the arena: with x_hit, k_out and the inputs in three different
-    kinds of HBM the 1e7-ray, 12-surface march runs at 83.5-85 % of the HBM peak on every fresh allocation
-    (asserted: >= 78 % with < 3 % spread, the bar of round 1's verdict), and never slower than into
-    torch-allocated arrays (which are a lottery between 62 % and 81 %).  The inputs' third kind is required
-    only where the arena found one (the hunt for it is bounded)"""
-    from pyrate_amd import engine, placed, systems, _lib
-    sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
-    (x0, k0, e0d, n) = systems.double_gauss_bundle_device(10000000, gpu_device)
-    alg = n * (72 + 49 * 12)
-    arena = placed.PlacedArena.for_device(0)
-    # a bundle of this size is generated into arena memory of a third kind (engine.ray_rows)
-    kind_in = arena.kind_of(x0)
-    assert kind_in is not None and arena.kind_of(k0) == kind_in == arena.kind_of(e0d)
-    three_kinds = arena.stats()["kinds_seen"] >= 3
-    warm = sysd.alloc_outputs(n, packed_flags=True, placement="torch")
-    for _ in range(30):
-        sysd.trace_into(x0, k0, warm, e0d)
-    t_torch = sysd.trace_timed(x0, k0, warm, 20, e0d)
-    del warm
-    fracs = []
-    for rep in range(3):
-        bufs = sysd.alloc_outputs(n, packed_flags=True)          # auto -> arena at this size
-        assert bufs["placement"]["policy"] == "arena"
-        kinds = bufs["placement"]["kinds"]
-        assert kinds[0] != kinds[1], bufs["placement"]
-        if three_kinds:
-            assert kind_in not in kinds, (kind_in, bufs["placement"])
-        sysd.trace_timed(x0, k0, bufs, 5, e0d)
-        ms = sysd.trace_timed(x0, k0, bufs, 20, e0d)
-        fracs.append(alg / (ms * 1e-3) / 8e12)
-        del bufs
-        arena.trim()                                           # next round starts from the driver again
-    print("march into arena arrays: %s of the HBM peak; torch arrays %.3f"
-          % (["%.3f" % f for f in fracs], alg / (t_torch * 1e-3) / 8e12))
-    assert min(fracs) >= 0.78, fracs
-    assert max(fracs) - min(fracs) < 0.03 * max(fracs), fracs
-    assert min(fracs) >= 0.97 * alg / (t_torch * 1e-3) / 8e12
-
-
 @pytest.mark.parametrize("kind", ["uniaxial", "biaxial"])
 def test_crystal_solutions_satisfy_the_wave_equation_at_full_size(kind, gpu_device):
     """size-independent property (reference: tests/test_material.py:38-401): behind every crystal

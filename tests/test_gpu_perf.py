@@ -1,0 +1,128 @@
+"""
+Performance observations on the GPU (run with -m gpu): they REPORT what they measure (pytest -s / the captured
+output of a failure) and assert only a soft bar, so that a busy box cannot turn the parity suite red.  The numbers
+that count are bench.py's (BENCH_rNN.json) and the profiles/ summaries.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_arena_placement_of_the_full_size_march_is_reported(gpu_device):
+    """the claim behind the arena: with x_hit, k_out and the inputs in three different
+    kinds of HBM the 1e7-ray, 12-surface march runs at 83-85 % of the HBM peak on every fresh allocation, and never
+    slower than into torch-allocated arrays (which are a lottery between 62 % and 81 %).  Reported; asserted only:
+    the placement itself (two kinds for the path arrays, a third for the inputs where the arena found one), a soft
+    floor of 60 %, and "not slower than torch arrays" with a 10 % margin"""
+    from pyrate_amd import engine, placed, systems
+    sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
+    (x0, uni, _, n) = systems.double_gauss_bundle_device(10000000, gpu_device, uniform=True)
+    alg = n * (24 + 49 * 12)
+    arena = placed.PlacedArena.for_device(0)
+    kind_in = arena.kind_of(x0)            # a bundle of this size is generated into arena memory (engine.ray_rows)
+    assert kind_in is not None
+    three_kinds = arena.stats()["kinds_seen"] >= 3
+    warm = sysd.alloc_outputs(n, packed_flags=True, placement="torch")
+    for _ in range(30):
+        sysd.trace_into(x0, None, warm, uniform=uni)
+    t_torch = sysd.trace_timed(x0, None, warm, 20, uniform=uni)
+    del warm
+    fracs = []
+    for rep in range(3):
+        bufs = sysd.alloc_outputs(n, packed_flags=True)          # auto -> arena at this size
+        assert bufs["placement"]["policy"] == "arena"
+        kinds = bufs["placement"]["kinds"]
+        assert kinds[0] != kinds[1], bufs["placement"]
+        if three_kinds:
+            assert kind_in not in kinds, (kind_in, bufs["placement"])
+        sysd.trace_timed(x0, None, bufs, 5, uniform=uni)
+        ms = sysd.trace_timed(x0, None, bufs, 20, uniform=uni)
+        fracs.append(alg / (ms * 1e-3) / 8e12)
+        del bufs
+        arena.trim()                                           # next round starts from the driver again
+    f_torch = alg / (t_torch * 1e-3) / 8e12
+    print("march into arena arrays: %s of the HBM peak; torch arrays %.3f" % (["%.3f" % f for f in fracs], f_torch))
+    assert min(fracs) >= 0.60, fracs
+    assert min(fracs) >= 0.90 * f_torch, (fracs, f_torch)
+
+
+def test_arena_address_space_stops_growing_once_buffers_are_cached(gpu_device):
+    """the arena never hands an address range back (ROCm keeps translating a re-used range to the old pages), so
+    address space is its one leak -- it must stop once the working set is cached: repeated traces of one size
+    re-use the mapped buffers (no new reservations, no new slabs, no probes), and a release is an event, not a
+    device synchronisation"""
+    import gc
+    from pyrate_amd import engine, placed, systems
+    sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
+    (x0, uni, _, n) = systems.double_gauss_bundle_device(10000000, gpu_device, uniform=True)
+    arena = placed.PlacedArena.for_device(0)
+    for rep in range(3):                                  # working set: two result sets alive at a time
+        res = [sysd.trace(x0, None, packed_flags=True, uniform=uni) for _ in range(2)]
+        del res
+    gc.collect()
+    st0 = arena.stats()
+    for rep in range(40):
+        res = [sysd.trace(x0, None, packed_flags=True, uniform=uni) for _ in range(2)]
+        del res
+    gc.collect()
+    torch.cuda.synchronize()
+    st1 = arena.stats()
+    print("arena after 40 more rounds of two live traces:", st1)
+    assert st1["address_space_reserved_GiB"] == st0["address_space_reserved_GiB"]
+    assert st1["slabs_created"] == st0["slabs_created"] and st1["probes"] == st0["probes"]
+
+
+def test_arena_cache_cap_and_default_budget(gpu_device):
+    """good-neighbour defaults: the arena holds at most three quarters of the device, and cached
+    (unused) buffers beyond 64 GiB go back to the driver when a buffer is freed"""
+    import gc
+    from pyrate_amd import placed
+    arena = placed.PlacedArena.for_device(0)
+    gc.collect()
+    arena.trim()
+    held0 = arena.stats()["slabs_created"] - arena.stats()["slabs_released"]
+    for gib in (20, 21, 22, 23):                          # 172 GiB pass through the cache
+        (parts, _) = arena.alloc([gib << 30, gib << 30])
+        parts[0][:8].fill_(1)
+        del parts
+        gc.collect()
+        st = arena.stats()
+        assert st["slabs_cached"] + st["slabs_free"] <= 64 + 2 * gib, st
+    st = arena.stats()
+    print("arena after 172 GiB of released buffers:", st)
+    assert st["slabs_cached"] + st["slabs_free"] <= 64
+    assert st["slabs_created"] - st["slabs_released"] <= held0 + 64 + 8
+    free_b, total_b = torch.cuda.mem_get_info(0)
+    assert free_b > 0.5 * total_b
+    arena.trim()
+
+
+def test_release_waits_for_side_streams_that_used_the_memory(gpu_device):
+    """placed.record_stream: a buffer read on a side stream is not handed to its next user before that stream's
+    work is done, whatever stream is current when the last tensor dies"""
+    import gc
+    from pyrate_amd import placed
+    arena = placed.PlacedArena.for_device(0)
+    side = torch.cuda.Stream(device=gpu_device)
+    (parts, _) = arena.alloc([1 << 30], n_distinct=1)
+    buf = parts[0]
+    ptr = buf.data_ptr()
+    buf.fill_(7)
+    out = torch.empty(1 << 28, dtype=torch.uint8, device=gpu_device)
+    side.wait_stream(torch.cuda.current_stream(gpu_device))
+    with torch.cuda.stream(side):
+        for _ in range(50):                               # a long reader on the side stream
+            out.copy_(buf[:1 << 28])
+        assert placed.record_stream(buf)
+        total = out.to(torch.int64).sum()
+    del buf, parts
+    gc.collect()
+    (parts2, _) = arena.alloc([1 << 30], n_distinct=1)    # same size: the cached buffer comes back
+    if parts2[0].data_ptr() == ptr:
+        parts2[0].fill_(9)                                # must be ordered behind the side stream's reads
+    torch.cuda.synchronize()
+    assert int(total) == 7 * (1 << 28)
+    assert not placed.record_stream(torch.zeros(4, device=gpu_device))
+    del parts2
+    arena.trim()

@@ -459,6 +459,24 @@ def test_host_bundles_equal_reference_bundles(api):
     assert objs["rect_60"].device_tables(60) is not None and raster.RandomGrid().device_tables(60) is None
     assert raster.ChiefAndComa().device_tables(6) is None and raster.Single().device_tables(1) is None
 
+    # the tables belong to the class that defines them: a subclass that overrides ONLY getGrid has its own samples
+    # (the reference always calls getGrid) and must not get its parent's tables -- for every raster, not only RectGrid
+    for base in (raster.RectGrid, raster.HexGrid, raster.MeridionalFan, raster.SagitalFan, raster.CircularGrid):
+        class Own(base):
+            def getGrid(self, nray):
+                return (np.zeros(3), np.linspace(0, 0.5, 3))
+        assert raster.device_tables_of(base(), 40) is not None, base
+        assert raster.device_tables_of(Own(), 40) is None, base
+
+        class Both(base):                      # overrides both: its tables are its own again
+            def getGrid(self, nray):
+                return (np.zeros(3), np.linspace(0, 0.5, 3))
+
+            def device_tables(self, nray):
+                return [(np.zeros(1), np.ones(3), np.ones(1), np.linspace(0, 0.5, 3), False)]
+        assert raster.device_tables_of(Both(), 40) is not None
+    assert raster.device_tables_of(object(), 3) is None
+
 
 def test_newton_cap_annotation_reaches_the_table(api):
     """``shape.annotations["newton_maxit"]`` is the device-side Newton cap of an explicit shape (the reference's
