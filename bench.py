@@ -75,7 +75,7 @@ T_START = time.perf_counter()
 # ------------------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------------------
-def make_workload(config, rays, dev, n_gpus=1, rank=0, multi=False, first_segment="uniform"):
+def make_workload(config, rays, dev, n_gpus=1, rank=0, multi=False, first_segment="uniform", align=1):
     """records + the device-resident input bundle of one BASELINE configuration.  Every bundle is the
     RectGrid disk raster of the reference, collimated, generated on the device (bit-identical to the host
     raster); rank r owns a contiguous, equal-stride slice of it (pdist.shard_range)."""
@@ -122,7 +122,7 @@ def make_workload(config, rays, dev, n_gpus=1, rank=0, multi=False, first_segmen
     else:
         raise ValueError(config)
     (_, n_total) = engine.rect_grid_count(rays * n_gpus, dev)
-    (lo, hi) = pdist.shard_range(n_total, rank, n_gpus)
+    (lo, hi) = pdist.shard_range(n_total, rank, n_gpus, align)
     uniform = first_segment == "uniform"
     (x0, k0, e0, _) = systems.double_gauss_bundle_device(rays * n_gpus, dev, lo=lo, hi=hi, uniform=uniform, **bundle)
     uni = None
@@ -579,6 +579,10 @@ def main():
                          "all-gather (49 B/ray), overlapped with the next trace (default); stats = the "
                          "all-reduce only; final-gather = all-reduce per step, ONE all-gather after the K "
                          "steps (outside the timed region); none = the bare sharded trace")
+    ap.add_argument("--gather-mode", choices=["inplace", "copy"], default="inplace",
+                    help="N>1, --exchange gather: inplace = the trace writes its image plane straight into its slot of "
+                         "the all-gather's receive buffer and the collectives run in place (default, RCCL); copy = "
+                         "the collectives read the image-plane rows of the path arrays (one more copy of the shard)")
     ap.add_argument("--two-pass-stats", action="store_true",
                     help="N>1: per-step spot statistics from two extra passes over the image plane and two "
                          "all-reduces (default: moments reduced inside the trace kernel, one all-reduce)")
@@ -737,8 +741,11 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
     n_gpus = world
     rays = args.rays if args.rays is not None else 12_500_000
     watchdog.stage = "bundle generation"
+    # shards of one common stride that is a multiple of 512 rays: rank r's slot of a gathered row starts on a 4-KiB
+    # boundary, so the march can write its image plane straight into it (ImagePlaneGather.own_rows)
+    align = 512
     wl = make_workload("doublegauss", rays, dev, n_gpus=n_gpus, rank=rank, multi=True,
-                       first_segment=args.first_segment)
+                       first_segment=args.first_segment, align=align)
     (x0, k0, e0d, uni) = (wl["x0"], wl["k0"], wl["e0"], wl["uniform"])
     (n_total, n_local, S) = (wl["n_total"], wl["n_local"], wl["S"])
     sysds = [engine.DeviceSystem(r, local_rank) for r in wl["record_sets"]]
@@ -758,7 +765,7 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
     record_bytes = 49 if packed else 50
     placement = args.placement if mode == _lib.MODE_PATH else "torch"
     # one row pitch on every rank: a gathered row is read n_pad elements deep (pdist.ImagePlaneGather)
-    pitch = engine.recommended_pitch(pdist.shard_stride(n_total, n_gpus))
+    pitch = engine.recommended_pitch(pdist.shard_stride(n_total, n_gpus, align))
     if args.inputs == "torch":
         moved = []
         for t in (x0, k0, e0d):
@@ -777,8 +784,13 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
     input_kind = arena_obj.kind_of(x0) if arena_obj is not None else None
     host_staged = (args.backend == "gloo")
     stats = [pdist.SpotStatistics(dev, n_rays=n_local) for _ in range(nbuf)] if do_stats else []
-    gathers = ([pdist.ImagePlaneGather(n_total, dev, stage_on_host=host_staged)
+    gathers = ([pdist.ImagePlaneGather(n_total, dev, stage_on_host=host_staged, align=align)
                 for _ in range(nbuf if do_step_gather else 1)] if (do_step_gather or do_final_gather) else [])
+    # in place: the march of slot b deposits its image plane in gathers[b]'s receive buffer (prt_trace_ex redirect)
+    inplace = do_step_gather and args.gather_mode == "inplace" and not host_staged and mode == _lib.MODE_PATH
+    if inplace:
+        for b in range(nbuf):
+            bufs[b % n_out_bufs] = dict(bufs[b % n_out_bufs], image_rows=gathers[b].own_rows())
     comm_stream = torch.cuda.Stream(device=dev)
     main_stream = torch.cuda.current_stream(dev)
     side_done = [None] * nbuf          # event: side-stream work of slot b has finished
@@ -808,7 +820,10 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
                 elif do_stats:
                     stats[b].start(xi, sysd.views(ob).valid_out[-1])
                 if do_step_gather and with_gather:
-                    gathers[b].start(xi, ki, vi)
+                    if inplace:
+                        gathers[b].start_in_place()
+                    else:
+                        gathers[b].start(xi, ki, vi)
                     gathers[b].wait()
                 done = torch.cuda.Event()
                 done.record(comm_stream)
@@ -893,7 +908,7 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
     # one shard takes what the 1-GPU march takes at this size (kernel_ms); the per-step all-gather moves
     # 49 B x n_pad to each of the N-1 peers over one xGMI link each (point-to-point, ~153 GB/s per link and
     # direction, 0.65-0.8 of it reached) and overlaps the next trace -> a step costs max(trace, gather)
-    n_pad = pdist.shard_stride(n_total, n_gpus)
+    n_pad = pdist.shard_stride(n_total, n_gpus, align)
     gather_ms = [49.0 * n_pad / (f * 153e9) * 1e3 for f in (0.8, 0.65)] if n_gpus > 1 else [0.0, 0.0]
     expected = {"trace_ms_per_step": kernel_ms,
                 "gather_ms_per_step_at_0.8_and_0.65_of_the_link_rate": gather_ms,
@@ -921,7 +936,9 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
                         "image_plane_exchange": {
                             "per_step": {"gather": "spot moments from the trace kernel + one 7-double all-reduce, then "
                                                    "image-plane all-gather 49 B/ray (7 row collectives straight into "
-                                                   "the [row][global ray] layout), side stream, overlaps the next trace",
+                                                   "the [row][global ray] layout%s), side stream, overlaps the next trace"
+                                                   % (", IN PLACE: the march wrote the shard's rows into its slot of the "
+                                                      "receive buffer" if inplace else ""),
                                          "stats": "spot moments from the trace kernel + one 7-double all-reduce (side stream)",
                                          "final-gather": "spot moments + one 7-double all-reduce (side stream)",
                                          "none": "none"}[exchange]

@@ -27,7 +27,7 @@ torch.cuda.synchronize()
 t_first = time.perf_counter() - t0
 arena_cold = placed.PlacedArena.for_device(0).stats()
 t0 = time.perf_counter()
-x_img = rp.raybundles[-1].x                           # first look at a result: compaction + D2H of the image plane
+x_img = rp[0].raybundles[-1].x                           # first look at a result: compaction + D2H of the image plane
 t_first_result = time.perf_counter() - t0
 del rp, x_img
 t0 = time.perf_counter()

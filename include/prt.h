@@ -250,6 +250,15 @@ typedef struct prt_trace_args {
     double *x_hit, *k_out;
     uint8_t *valid, *valid_out, *nonconv;
     double *e_out_re, *e_out_im;  /* E behind crystal interfaces (prt_trace_fields) or NULL */
+    /* image-plane redirect (all-isotropic tables, PRT_MODE_PATH, 16-B aligned rows): when x_img != NULL the record
+     * of the LAST surface goes to x_img, k_img (3 rows of img_pitch elements each) and valid_img (the mask byte
+     * row: `valid`, or the flags byte with PRT_MODE_FLAGS; valid_out_img: the second mask row without
+     * PRT_MODE_FLAGS, may be NULL) instead of to its rows of x_hit / k_out / valid / valid_out -- which are then
+     * not written.  This is how a ray-sharded trace deposits its image plane straight into its slot of the
+     * all-gather's receive buffer (the collective then runs in place, no copy of the shard's own rows). */
+    double *x_img, *k_img;
+    uint8_t *valid_img, *valid_out_img;
+    int64_t img_pitch;
     /* fused image-plane moments (prt_trace_moments): requested by moments_out7_dev != NULL */
     const double *moments_ref3;   /* HOST, 3 doubles, or NULL: vertex of the last surface   */
     double *moments_out7_dev, *moments_scratch_dev;

@@ -128,16 +128,18 @@ struct iso_launch {
     bool moments;      // also reduce the image-plane moments (partials: one row of 7 per block)
     double rx, ry, rz;
     double *partials;
+    bool redirect;     // the last surface's record goes to img (path mode, aligned rows)
+    img_redirect img;
     hipStream_t st;
 };
 
-template <int MODE, bool VI, bool VO, int SH, bool LDS, bool MOM, bool UNI>
+template <int MODE, bool VI, bool VO, int SH, bool LDS, bool MOM, bool UNI, bool IMG = false>
 static void launch_iso_inst(const iso_launch &a) {
     const dim3 grid(nblocks(a.n0, PRT_MARCH_BLOCK * 2)), block(PRT_MARCH_BLOCK);
-    hipLaunchKernelGGL((k_trace_iso<MODE, VI, VO, SH, LDS, MOM, UNI>), grid, block, 0, a.st, a.sys->d_table,
+    hipLaunchKernelGGL((k_trace_iso<MODE, VI, VO, SH, LDS, MOM, UNI, IMG>), grid, block, 0, a.st, a.sys->d_table,
                        a.sys->n_surfaces, a.n0, a.in_pitch, a.x0, a.k0, a.e_re, a.e_im, a.e_mode, a.out_pitch,
                        a.x_hit, a.k_out, a.valid, a.valid_out, a.rx, a.ry, a.rz, a.partials, a.packed_flags,
-                       a.nonconv, a.fu, (int32_t)(a.uni ? 1 : 0));
+                       a.nonconv, a.fu, (int32_t)(a.uni ? 1 : 0), a.img);
 }
 
 // The aligned case (16-B rows in and out: what prt_recommended_pitch gives) has compile-time variants for the
@@ -146,7 +148,14 @@ static void launch_iso_inst(const iso_launch &a) {
 template <int MODE, int SH>
 static void launch_iso_shape(const iso_launch &a, bool vi, bool vo) {
     static const bool lds_table = getenv("PRT_LDS_TABLE") != nullptr;
-    if (a.moments) {
+    if (a.redirect) {  // (path mode, aligned rows: checked by the caller)
+        if (MODE == PRT_MODE_PATH) {
+            if (a.moments && a.uni) launch_iso_inst<PRT_MODE_PATH, true, true, SH, false, true, true, true>(a);
+            else if (a.moments) launch_iso_inst<PRT_MODE_PATH, true, true, SH, false, true, false, true>(a);
+            else if (a.uni) launch_iso_inst<PRT_MODE_PATH, true, true, SH, false, false, true, true>(a);
+            else launch_iso_inst<PRT_MODE_PATH, true, true, SH, false, false, false, true>(a);
+        }
+    } else if (a.moments) {
         if (a.uni) launch_iso_inst<MODE, true, true, SH, false, true, true>(a);
         else launch_iso_inst<MODE, true, true, SH, false, true, false>(a);
     } else if (vi && vo) {
@@ -654,6 +663,8 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
     if (in_pitch < n0 || (out_pitch != 0 && out_pitch < n0))
         return fail(PRT_ERR_INVALID_ARG, "prt_trace: pitch smaller than the ray count");
     uint8_t *valid_out = a.valid_out;
+    if (!sys->all_isotropic && a.x_img)
+        return fail(PRT_ERR_UNSUPPORTED, "prt_trace: the image-plane redirect is for all-isotropic tables");
     if (!sys->all_isotropic) {
         // concatenated layout with ray pitch out_pitch (0 = n0, tight)
         if (out_pitch == 0) out_pitch = n0;
@@ -773,6 +784,21 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
     L.rx = L.ry = L.rz = 0.0;
     L.partials = nullptr;
     L.st = st;
+    L.redirect = a.x_img != nullptr;
+    memset(&L.img, 0, sizeof L.img);
+    if (L.redirect) {
+        const bool img_ok = a.k_img && a.valid_img && a.img_pitch >= n0 && (a.img_pitch % 2 == 0) && aligned16(a.x_img) &&
+                            aligned16(a.k_img) && ((((uintptr_t)a.valid_img) & 1u) == 0) &&
+                            (!a.valid_out_img || (((uintptr_t)a.valid_out_img) & 1u) == 0);
+        if (mode != PRT_MODE_PATH || !vec_all || nonconv || !img_ok)
+            return fail(PRT_ERR_INVALID_ARG, "prt_trace: the image-plane redirect needs PRT_MODE_PATH, 16-B aligned rows "
+                                             "everywhere (even pitches) and no nonconv array");
+        L.img.x = a.x_img;
+        L.img.k = a.k_img;
+        L.img.valid = a.valid_img;
+        L.img.valid_out = packed_flags ? nullptr : a.valid_out_img;
+        L.img.pitch = a.img_pitch;
+    }
     if (moments) {
         // reference point of the sums: the vertex of the last surface unless the caller names one
         const prt_surface_t *last = sys->h_table + (sys->n_surfaces - 1);

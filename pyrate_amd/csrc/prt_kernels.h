@@ -187,8 +187,16 @@ PRT_DEV vec3 uniform_first_direction(int e_mode, const first_uniform &fu, const 
 // of the allocator's 7 is worth 5 % there (0.47 -> 0.446 ms); path mode is HBM bound and unaffected.
 // UNI = true: the uniform first segment, decided at compile time (the aligned instantiations); the unaligned
 // fall-back instantiations (VEC_IN / VEC_OUT false) decide at run time (uni_rt) instead of doubling their number.
+// IMG = true (path mode): the record of the LAST surface goes to separate rows (img_redirect) instead of its
+// rows of the path arrays -- a ray-sharded trace deposits its image plane straight into its slot of the
+// all-gather's receive buffer.
+struct img_redirect {
+    double *x, *k;
+    uint8_t *valid, *valid_out;
+    int64_t pitch;
+};
 template <int MODE, bool VEC_IN, bool VEC_OUT, int SHAPES = PRT_SHAPES_ALL, bool LDS_TAB = false,
-          bool MOMENTS = false, bool UNI = false>
+          bool MOMENTS = false, bool UNI = false, bool IMG = false>
 #ifndef PRT_PATH_WAVES
 #define PRT_PATH_WAVES 1
 #endif
@@ -217,7 +225,8 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
     double *__restrict__ xh_out, double *__restrict__ k_out, uint8_t *__restrict__ valid_out_hit,
     uint8_t *__restrict__ valid_out_refr, double mref_x = 0.0, double mref_y = 0.0,
     double mref_z = 0.0, double *__restrict__ moment_partials = nullptr, int32_t packed_flags = 0,
-    uint8_t *__restrict__ nonconv_out = nullptr, first_uniform fu = first_uniform(), int32_t uni_rt = 0) {
+    uint8_t *__restrict__ nonconv_out = nullptr, first_uniform fu = first_uniform(), int32_t uni_rt = 0,
+    img_redirect img = img_redirect()) {
     const prt_dev_surface *__restrict__ tab = tab_g;
     if (LDS_TAB) {
         __shared__ prt_dev_surface lds_tab[PRT_LDS_TAB_MAX];
@@ -264,9 +273,12 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
         // the hit points go out before the interaction is computed: spreading a surface's stores
         // over the iteration is worth 2 % on the write-bound march (1.031 vs 1.052 ms, same arrays,
         // scratch/ab_same_buffers.py)
+        // (IMG: the last surface's rows are somewhere else -- wave-uniform pointer / pitch selects, one store sequence)
+        const bool redirected = IMG && s == S - 1;
+        const int64_t row_pitch = redirected ? img.pitch : out_pitch;
         if (MODE == PRT_MODE_PATH || s == S - 1) {
             const int64_t so = (MODE == PRT_MODE_PATH) ? (int64_t)s : 0;
-            rayio<VEC_OUT>::store(xh_out + so * 3 * out_pitch, out_pitch, i, second, x);
+            rayio<VEC_OUT>::store(redirected ? img.x : xh_out + so * 3 * out_pitch, row_pitch, i, second, x);
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -280,13 +292,14 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
 
         if (MODE == PRT_MODE_PATH || s == S - 1) {
             const int64_t so = (MODE == PRT_MODE_PATH) ? (int64_t)s : 0;
-            rayio<VEC_OUT>::store(k_out + so * 3 * out_pitch, out_pitch, i, second, k);
+            rayio<VEC_OUT>::store(redirected ? img.k : k_out + so * 3 * out_pitch, row_pitch, i, second, k);
+            uint8_t *__restrict__ m_hit = redirected ? img.valid : valid_out_hit + so * out_pitch;
+            uint8_t *__restrict__ m_refr = redirected ? img.valid_out : (valid_out_refr ? valid_out_refr + so * out_pitch : nullptr);
             if (packed_flags) {
-                rayio<VEC_OUT>::store_flags(valid_out_hit + so * out_pitch, i, second, vhit, valid, ncv);
+                rayio<VEC_OUT>::store_flags(m_hit, i, second, vhit, valid, ncv);
             } else {
-                rayio<VEC_OUT>::store_mask(valid_out_hit + so * out_pitch, i, second, vhit);
-                if (valid_out_refr)
-                    rayio<VEC_OUT>::store_mask(valid_out_refr + so * out_pitch, i, second, valid);
+                rayio<VEC_OUT>::store_mask(m_hit, i, second, vhit);
+                if (m_refr) rayio<VEC_OUT>::store_mask(m_refr, i, second, valid);
             }
             if (SHAPES != PRT_SHAPES_CONIC && nonconv_out)
                 rayio<VEC_OUT>::store_mask(nonconv_out + so * out_pitch, i, second, ncv);

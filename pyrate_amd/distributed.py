@@ -22,12 +22,17 @@ def _collectives_needed(group=None):
     return dist.get_world_size(group) > 1 or os.environ.get("PRT_FORCE_COLLECTIVES", "0") == "1"
 
 
-def shard_stride(n_total, world):
-    """rays per rank: every rank but the last owns exactly this many"""
-    return -(-n_total // world) if world > 0 else 0
+def shard_stride(n_total, world, align=1):
+    """rays per rank: every rank but the trailing one(s) owns exactly this many.  ``align``: round the stride up to
+    a multiple (512 = one row pitch unit: rank r's slot of a gathered row then starts on a 4-KiB boundary, which
+    lets the trace write its image plane straight into that slot, ImagePlaneGather.own_rows)"""
+    if world <= 0:
+        return 0
+    stride = -(-n_total // world)
+    return -(-stride // align) * align if align > 1 else stride
 
 
-def shard_range(n_total, rank, world):
+def shard_range(n_total, rank, world, align=1):
     """Contiguous, ordered slices of EQUAL STRIDE: rank r owns [r*n_pad, min((r+1)*n_pad, N)) with
     n_pad = ceil(N / world).  All ranks together are short by world*n_pad - N < world rays; for N >> world
     that is the last rank alone, for tiny bundles several trailing ranks can be short or EMPTY (N = 9,
@@ -35,13 +40,13 @@ def shard_range(n_total, rank, world):
     shards (the trace, the gather and the statistics do).  With one common stride, ray i of rank r is
     global ray r*n_pad + i, so an all-gather of one row lands in global ray order as it is
     (ImagePlaneGather needs no repacking)."""
-    n_pad = shard_stride(n_total, world)
+    n_pad = shard_stride(n_total, world, align)
     lo = min(rank * n_pad, n_total)
     return lo, min(lo + n_pad, n_total)
 
 
-def shard_sizes(n_total, world):
-    return [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+def shard_sizes(n_total, world, align=1):
+    return [shard_range(n_total, r, world, align)[1] - shard_range(n_total, r, world, align)[0] for r in range(world)]
 
 
 def _row_of(t2d, row, start, n, n_pad):
@@ -80,7 +85,7 @@ class ImagePlaneGather(object):
     """
 
     def __init__(self, n_total, device, group=None, stage_on_host=False, branches=1,
-                 with_fields=False, world=None, rank=None):
+                 with_fields=False, world=None, rank=None, align=1):
         """stage_on_host: exchange through host buffers (for the ``gloo`` backend, which cannot
         all-gather device tensors; used by the single-GPU dry run of the multi-rank bench path --
         the production path is RCCL on device buffers).  ``world`` / ``rank``: override the process
@@ -92,8 +97,9 @@ class ImagePlaneGather(object):
         self.n_total = n_total
         self.branches = int(branches)
         self.rows = 12 if with_fields else 6
-        self.sizes = shard_sizes(n_total, self.world)
-        self.n_pad = shard_stride(n_total, self.world)
+        self.align = align
+        self.sizes = shard_sizes(n_total, self.world, align)
+        self.n_pad = shard_stride(n_total, self.world, align)
         self.device = device
         self.bdev = torch.device("cpu") if stage_on_host else device
         (m, r) = (self.branches, self.rows)
@@ -124,6 +130,31 @@ class ImagePlaneGather(object):
 
     def _dest(self, row, b):
         return self.recv_v[b] if row == self.rows else self.recv_f[row, b]
+
+    def own_rows(self):
+        """(x (3, n), k (3, n), mask (n,)): this rank's slot of the receive buffers as row-pitched views (row pitch
+        world * n_pad).  A trace that writes its image plane THERE (``bufs["image_rows"]``, prt_trace_ex's redirect)
+        needs no copy of its own rows: ``start_in_place()`` then runs the collectives in place (NCCL / RCCL: send
+        buffer = the rank's slot of the receive buffer).  Isotropic bundles (one branch) on device buffers; the
+        stride must make the slot 16-B aligned and even (``align`` = 512 does)."""
+        if self.branches != 1 or self.stage_on_host:
+            raise ValueError("own_rows: one branch, device buffers")
+        if (self.rank * self.n_pad) % 2 or (self.world * self.n_pad) % 2:
+            raise ValueError("own_rows needs an even stride (construct the gather and the shards with align=512)")
+        (lo, n) = (self.rank * self.n_pad, self.sizes[self.rank])
+        return self.recv_f[0:3, 0, lo:lo + n], self.recv_f[3:6, 0, lo:lo + n], self.recv_v[0, lo:lo + n]
+
+    def start_in_place(self):
+        """the all-gather of rows that already sit in this rank's slot (own_rows): in place, nothing is staged or
+        copied locally; with a single rank there is nothing to do at all"""
+        self._work = []
+        if not _collectives_needed(self.group):
+            return
+        lo = self.rank * self.n_pad
+        for row in range(self.rows + 1):
+            dst = self._dest(row, 0)
+            self._work.append(dist.all_gather_into_tensor(dst, dst[lo:lo + self.n_pad], group=self.group,
+                                                          async_op=True))
 
     def deposit(self, rank, x_img, k_img, valid, e_re=None, e_im=None):
         """what the collectives do with rank ``rank``'s contribution, as local copies: the

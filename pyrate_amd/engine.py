@@ -171,27 +171,39 @@ class TraceResult(object):
         (bx, bk, bv, bw) = (bufs["x_hit"], bufs["k_out"], bufs["valid"], bufs["valid_out"])
         if pitch and not bufs.get("concatenated"):
             n = n_in[0]
+            # the last surface's record may live in redirect rows (e.g. a gather's receive buffer, _trace_args)
+            img = bufs.get("image_rows") if bufs["mode"] == _lib.MODE_PATH else None
+            last = rows - 1
 
-            def rays(buf):
-                return lambda s: buf[3 * s * pitch:3 * (s + 1) * pitch].view(3, pitch)[:, :n]
+            def rays(buf, which):
+                def make(s):
+                    if img is not None and s == last:
+                        return img[which][:, :n]
+                    return buf[3 * s * pitch:3 * (s + 1) * pitch].view(3, pitch)[:, :n]
+                return make
 
-            def mask(buf):
-                return lambda s: buf[s * pitch:s * pitch + n]
+            def mask(buf, which):
+                def make(s):
+                    if img is not None and s == last:
+                        return img[which][:n] if len(img) > which and img[which] is not None else None
+                    return buf[s * pitch:s * pitch + n]
+                return make
             if bufs.get("packed_flags"):
                 # one byte per record: bit 0 = valid, bit 1 = valid_out; the 0/1 masks are derived
                 # on first access (and cached by _LazyViews)
-                flags = mask(bv)
-                res = cls(_LazyViews(rows, rays(bx)), _LazyViews(rows, rays(bk)),
+                flags = mask(bv, 2)
+                res = cls(_LazyViews(rows, rays(bx, 0)), _LazyViews(rows, rays(bk, 1)),
                           _LazyViews(rows, lambda s: flags(s) & 1), _LazyViews(rows, lambda s: (flags(s) >> 1) & 1),
                           n_in, n_out, bufs["mode"])
                 res.flags = _LazyViews(rows, flags)
                 res.nonconv = _LazyViews(rows, lambda s: (flags(s) >> 2) & 1)
                 return res
-            res = cls(_LazyViews(rows, rays(bx)), _LazyViews(rows, rays(bk)), _LazyViews(rows, mask(bv)),
-                      _LazyViews(rows, (mask(bw) if bw is not None else (lambda s: None))),
+            res = cls(_LazyViews(rows, rays(bx, 0)), _LazyViews(rows, rays(bk, 1)), _LazyViews(rows, mask(bv, 2)),
+                      _LazyViews(rows, (mask(bw, 3) if bw is not None else (lambda s: None))),
                       n_in, n_out, bufs["mode"])
             if bufs.get("nonconv") is not None:
-                res.nonconv = _LazyViews(rows, mask(bufs["nonconv"]))
+                bn = bufs["nonconv"]
+                res.nonconv = _LazyViews(rows, lambda s: bn[s * pitch:s * pitch + n])
             return res
         # concatenated layout (tables with anisotropic media), ray pitch P >= n0: surface s holds B = n_in[s] / n0
         # branches of P slots each, the first n0 of them rays (include/prt.h).  The per-surface entries are the
@@ -390,7 +402,9 @@ class DeviceSystem(object):
 
     # -- whole sequence ----------------------------------------------------
     def _trace_args(self, x0, k0, bufs, e0_re=None, e0_im=None, uniform=None, first_dir=None):
-        """prt_trace_args_t for one trace into ``bufs``.  ``uniform`` (a UniformFirst) replaces k0 / E0."""
+        """prt_trace_args_t for one trace into ``bufs``.  ``uniform`` (a UniformFirst) replaces k0 / E0.
+        ``bufs["image_rows"]`` = (x_img, k_img, mask_img) -- (3, n) / (n,) views with unit stride along the rays,
+        e.g. ``ImagePlaneGather.own_rows()`` -- redirects the last surface's record there (path mode)."""
         n0 = x0.shape[1]
         if uniform is None and k0 is None:
             raise ValueError("k0 is required (or a uniform first segment)")
@@ -423,6 +437,16 @@ class DeviceSystem(object):
         if bufs.get("e_re") is not None:
             a.e_out_re = bufs["e_re"].data_ptr()
             a.e_out_im = bufs["e_im"].data_ptr()
+        img = bufs.get("image_rows")
+        if img is not None:
+            (xi, ki, vi) = img[:3]
+            if xi.stride(0) != ki.stride(0) or (n0 and (xi.stride(1) != 1 or ki.stride(1) != 1 or vi.stride(0) != 1)):
+                raise ValueError("image rows: x and k must share one row pitch and have unit stride along the rays")
+            a.x_img = xi.data_ptr()
+            a.k_img = ki.data_ptr()
+            a.valid_img = vi.data_ptr()
+            a.valid_out_img = img[3].data_ptr() if len(img) > 3 and img[3] is not None else None
+            a.img_pitch = xi.stride(0)
         a.stream = torch.cuda.current_stream(self.device).cuda_stream
         a._keep = (x0, k0, e0_re, e0_im)       # tight copies must outlive the launch call
         return a

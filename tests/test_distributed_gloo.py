@@ -26,6 +26,11 @@ def test_shard_ranges_partition_the_bundle():
             assert all(lo == min(r * n_pad, n) for (r, (lo, _)) in enumerate(spans))
             assert sizes == [max(0, min(n_pad, n - r * n_pad)) for r in range(world)]
             assert sizes == pdist.shard_sizes(n, world)
+            # an aligned common stride: still a partition, every slot starts on a multiple of the alignment
+            spans_a = [pdist.shard_range(n, r, world, align=512) for r in range(world)]
+            assert spans_a[0][0] == 0 and spans_a[-1][1] == n and all(a[1] == b[0] for (a, b) in zip(spans_a[:-1], spans_a[1:]))
+            assert pdist.shard_stride(n, world, 512) % 512 == 0 and pdist.shard_stride(n, world, 512) >= n_pad
+            assert all(lo == min(r * pdist.shard_stride(n, world, 512), n) for (r, (lo, _)) in enumerate(spans_a))
     # tiny bundles: several trailing ranks can be short or empty (zero-size shards are legal)
     assert pdist.shard_sizes(9, 8) == [2, 2, 2, 2, 1, 0, 0, 0]
     assert pdist.shard_sizes(1, 2) == [1, 0]
@@ -71,6 +76,19 @@ def _worker(rank, world, port, n_total, q):
                 torch.from_numpy(v[lo:hi].copy()))
         (gx, _, _) = g.finish()
         ok = ok and bool(np.array_equal(gx.numpy(), 2 * x))
+        # in place: shards of an aligned common stride write their rows straight into their slot of the receive
+        # buffer (what the march's image-plane redirect does on the GPU), the collectives run in place
+        (lo_a, hi_a) = pdist.shard_range(n_total, rank, world, align=512)
+        ga = pdist.ImagePlaneGather(n_total, torch.device("cpu"), align=512)
+        (ox, ok_, ov) = ga.own_rows()
+        assert ox.shape == (3, hi_a - lo_a) and ga.n_pad % 512 == 0
+        ox.copy_(torch.from_numpy(x[:, lo_a:hi_a].copy()))
+        ok_.copy_(torch.from_numpy(k[:, lo_a:hi_a].copy()))
+        ov.copy_(torch.from_numpy(v[lo_a:hi_a].copy()))
+        ga.start_in_place()
+        (gx, gk, gv) = ga.finish()
+        ok = ok and bool(np.array_equal(gx.numpy(), x) and np.array_equal(gk.numpy(), k)
+                         and np.array_equal(gv.numpy(), v))
         # sharded spot statistics == statistics of the whole bundle (NumPy stand-in for the
         # device reduction: this test runs without a GPU; the all-reduce plumbing is what it checks)
         def np_moments(xs, mask=None, ref=None):

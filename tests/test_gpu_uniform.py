@@ -379,3 +379,52 @@ def test_crystal_layout_with_a_ray_pitch_equals_the_tight_layout(n_req, gpu_devi
     (xa, ka, ea, _) = systems.double_gauss_bundle_device(n_req, gpu_device, **bargs)
     assert n < 512 or xa.stride(0) != n
     _same(sysd.trace(xa, ka, ea), sysd.trace(xa.contiguous(), ka.contiguous(), ea.contiguous()))
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_image_plane_redirect_into_the_gathers_receive_buffer(packed, gpu_device):
+    """prt_trace_ex's image-plane redirect: the march writes the LAST surface's record into this rank's slot of an
+    ImagePlaneGather's receive buffer (own_rows) instead of into its rows of the path arrays -- same bits as the
+    plain trace, the skipped rows of the path arrays untouched, the fused moments unchanged; the in-place all-gather
+    (a single rank here) then holds the image plane in global ray order"""
+    from pyrate_amd import engine, systems, _lib
+    from pyrate_amd import distributed as pdist
+    sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
+    (x0, uni, _, n) = systems.double_gauss_bundle_device(300000, gpu_device, field_deg=9.0, uniform=True)   # some rays vignette
+    S = sysd.n_surfaces
+    ref = sysd.trace(x0, None, packed_flags=packed, uniform=uni)
+    g = pdist.ImagePlaneGather(n, gpu_device, world=1, rank=0, align=512)
+    rows = g.own_rows()
+    if not packed:
+        rows = rows + (torch.zeros(n, dtype=torch.uint8, device=gpu_device),)
+    bufs = sysd.alloc_outputs(n, packed_flags=packed)
+    bufs["x_hit"].fill_(-3.0)
+    bufs["k_out"].fill_(-3.0)
+    bufs["image_rows"] = rows
+    ws = engine.MomentsWorkspace(gpu_device, n_results=2, n_rays=n)
+    m_red = sysd.trace_moments_into(x0, None, bufs, ws, 0, uniform=uni).clone()
+    got = sysd.views(bufs)
+    _same(got, ref)
+    plain = sysd.alloc_outputs(n, packed_flags=packed)
+    m_plain = sysd.trace_moments_into(x0, None, plain, ws, 1, uniform=uni)
+    assert torch.equal(_bits(m_red), _bits(m_plain)) and 0 < float(m_red[0]) < n
+    # the last surface's rows of the path arrays were not written
+    pitch = bufs["pitch"]
+    assert float(bufs["x_hit"][3 * (S - 1) * pitch:].max()) == -3.0 and float(bufs["k_out"][3 * (S - 1) * pitch:].min()) == -3.0
+    # without moments, and through the launcher
+    bufs2 = sysd.alloc_outputs(n, packed_flags=packed)
+    bufs2["image_rows"] = rows
+    for r in rows[:2]:
+        r.fill_(0.0)
+    sysd.launcher(x0, None, bufs2, uniform=uni)()
+    _same(sysd.views(bufs2), ref)
+    # the gather: in place, one rank -> nothing to move; finish() = the image plane
+    g.start_in_place()
+    (gx, gk, gv) = g.finish()
+    assert torch.equal(_bits(gx), _bits(ref.x_hit[-1])) and torch.equal(_bits(gk), _bits(ref.k_out[-1]))
+    assert torch.equal(gv, ref.flags[-1] if packed else ref.valid[-1])
+    # structural misuse: image mode, or odd pitch
+    bad = sysd.alloc_outputs(n, _lib.MODE_IMAGE, packed_flags=packed)
+    bad["image_rows"] = rows
+    with pytest.raises(_lib.PrtError):
+        sysd.trace_into(x0, None, bad, uniform=uni)

@@ -35,7 +35,7 @@ def test_no_flat_memory_operations_in_the_march_kernels(isa):
 
 
 def _iso_args(name):
-    """k_trace_iso<MODE,VEC_IN,VEC_OUT,SHAPES,LDS_TAB,MOMENTS,UNI> -> the seven template arguments"""
+    """k_trace_iso<MODE,VEC_IN,VEC_OUT,SHAPES,LDS_TAB,MOMENTS,UNI,IMG> -> the eight template arguments"""
     return [int(v) for v in name[len("k_trace_iso<"):-1].split(",")]
 
 
@@ -47,7 +47,7 @@ def test_store_only_loops_never_wait_on_the_memory_counter(isa):
     for (name, k) in isa.items():
         if not name.startswith("k_trace_iso<"):
             continue
-        (mode, _vi, _vo, shapes, lds, _mom, _uni) = _iso_args(name)
+        (mode, _vi, _vo, shapes, lds, _mom, _uni, _img) = _iso_args(name)
         if mode == 0 and shapes in (0, 1, 2) and not lds:
             assert k["vmcnt_waits_in_loops"] == 0, name
             seen += 1
@@ -56,14 +56,14 @@ def test_store_only_loops_never_wait_on_the_memory_counter(isa):
 
 def test_registers_and_occupancy_of_the_baseline_instantiations(isa):
     for uni in (0, 1):                            # arrays k0 / E0, and the uniform first segment of collimated bundles
-        head = isa["k_trace_iso<0,1,1,0,0,0,%d>" % uni]   # BASELINE configs[1]: path mode, 2 rays per lane, conics only
+        head = isa["k_trace_iso<0,1,1,0,0,0,%d,0>" % uni]   # BASELINE configs[1]: path mode, 2 rays per lane, conics only
         assert head["scratch_bytes_per_lane"] == 0 and head["waves_per_simd"] >= 7 and head["vgprs"] <= 72
-        asph = isa["k_trace_iso<0,1,1,1,0,0,%d>" % uni]   # configs[2]: conics + even aspheres
+        asph = isa["k_trace_iso<0,1,1,1,0,0,%d,0>" % uni]   # configs[2]: conics + even aspheres
         assert asph["scratch_bytes_per_lane"] == 0 and asph["waves_per_simd"] >= 5
         # conics + aspheres + XY polynomials + biconics (north_star's shapes + SURVEY 8 f3): <= 96 VGPRs = 5 waves
-        poly = isa["k_trace_iso<0,1,1,2,0,0,%d>" % uni]
+        poly = isa["k_trace_iso<0,1,1,2,0,0,%d,0>" % uni]
         assert poly["scratch_bytes_per_lane"] == 0 and poly["waves_per_simd"] >= 5 and poly["vgprs"] <= 96
-        image = isa["k_trace_iso<1,1,1,0,0,0,%d>" % uni]  # image mode of the conic march: capped at 64 VGPRs for 8 waves
+        image = isa["k_trace_iso<1,1,1,0,0,0,%d,0>" % uni]  # image mode of the conic march: capped at 64 VGPRs for 8 waves
         assert image["waves_per_simd"] == 8
         # configs[3]: uniaxial crystals, parking slots in LDS, conic shapes only (k_trace_general<MODE, GENERAL,
         # PARK_LDS, UNI, SHAPES>): no scratch, and NO vmcnt wait inside the walk (the waits that isa_report found
@@ -73,5 +73,5 @@ def test_registers_and_occupancy_of_the_baseline_instantiations(isa):
         assert crystal["vmcnt_waits_in_loops"] == 0 and crystal["vgprs"] <= 112
         # path rows through a scalar base + lane offset; only the byte masks keep 64-bit lane addresses
         assert crystal["scalar_base_stores"] >= 20 and crystal["vector_address_stores"] <= 6
-    allshapes = isa["k_trace_iso<0,1,1,3,0,0,0>"]   # every explicit shape compiled in (sag grids, combinations)
+    allshapes = isa["k_trace_iso<0,1,1,3,0,0,0,0>"]   # every explicit shape compiled in (sag grids, combinations)
     assert allshapes["scratch_bytes_per_lane"] == 0 and allshapes["waves_per_simd"] >= 4
