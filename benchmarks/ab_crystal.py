@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B of libprt builds (scratch/variants/libprt_<name>.so) on the crystal march of BASELINE configs[3]:
 anisotropic doublet, 1e6 rays -> 4e6 at the image, uniaxial and biaxial crystals, path and image mode;
-same arrays for every build."""
+same arrays for every build (concatenated layout with the engine's ray pitch, inputs as arrays)."""
 import ctypes
 import glob
 import json
@@ -50,7 +50,7 @@ for (tag, (e1, e2)) in cases.items():
 
         def timed(lib, h, iters):
             ms = ctypes.c_double()
-            rc = lib.prt_trace_timed(h, n, 0, P(x0), P(k0), P(e0d), None, mode, 0, P(bufs["x_hit"]),
+            rc = lib.prt_trace_timed(h, n, 0, P(x0), P(k0), P(e0d), None, mode, bufs["pitch"], P(bufs["x_hit"]),
                                      P(bufs["k_out"]), P(bufs["valid"]), P(bufs["valid_out"]), st, iters,
                                      ctypes.byref(ms))
             assert rc == 0, rc

@@ -62,6 +62,26 @@ def _row_of(t2d, row, start, n, n_pad):
     return t2d.as_strided((n_pad,), (1,), off)
 
 
+def _all_gather_rows(pairs, group, device):
+    """one all_gather_into_tensor per (destination row, source) pair, asynchronous; returns the work handles.
+    With RCCL the rows of a bundle go out as ONE group (ncclGroupStart / End through torch's coalescing manager:
+    one launch instead of seven -- the per-collective launch cost is what a step of the single-rank smoke run saw)"""
+    backend = dist.get_backend(group)
+    if backend == "nccl" and hasattr(dist, "_coalescing_manager") and os.environ.get("PRT_GATHER_COALESCE", "1") != "0":
+        try:
+            work = []
+            for dtype in sorted(set(dst.dtype for (dst, _) in pairs), key=str):      # one group per element type
+                with dist._coalescing_manager(group=group, async_ops=True) as cm:
+                    for (dst, src) in pairs:
+                        if dst.dtype == dtype:
+                            dist.all_gather_into_tensor(dst, src, group=group)
+                work.append(cm)
+            return work
+        except (TypeError, RuntimeError, AttributeError, ValueError):
+            pass                      # this torch's manager does not take these collectives: one by one
+    return [dist.all_gather_into_tensor(dst, src, group=group, async_op=True) for (dst, src) in pairs]
+
+
 class ImagePlaneGather(object):
     """All-gather of the image-plane arrays of a ray-sharded trace, straight into the final layout.
 
@@ -151,10 +171,8 @@ class ImagePlaneGather(object):
         if not _collectives_needed(self.group):
             return
         lo = self.rank * self.n_pad
-        for row in range(self.rows + 1):
-            dst = self._dest(row, 0)
-            self._work.append(dist.all_gather_into_tensor(dst, dst[lo:lo + self.n_pad], group=self.group,
-                                                          async_op=True))
+        pairs = [(self._dest(row, 0), self._dest(row, 0)[lo:lo + self.n_pad]) for row in range(self.rows + 1)]
+        self._work = _all_gather_rows(pairs, self.group, self.device)
 
     def deposit(self, rank, x_img, k_img, valid, e_re=None, e_im=None):
         """what the collectives do with rank ``rank``'s contribution, as local copies: the
@@ -178,8 +196,8 @@ class ImagePlaneGather(object):
                 placed.record_stream(t)
         if self.stage_on_host and x_img.is_cuda:
             torch.cuda.current_stream(x_img.device).synchronize()     # D2H staging complete
-        self._work = [dist.all_gather_into_tensor(self._dest(row, b), src, group=self.group, async_op=True)
-                      for (row, b, src) in srcs]
+        self._work = _all_gather_rows([(self._dest(row, b), src) for (row, b, src) in srcs], self.group,
+                                      self.bdev)
 
     def wait(self):
         for w in self._work:
