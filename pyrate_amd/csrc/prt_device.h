@@ -225,7 +225,12 @@ PRT_DEV void asphere_eval(const prt_dev_surface *__restrict__ sf, int nc, const 
                           double y, double &F, double &dFdr2x2 /* Fx = x * this */) {
     const double c = sf->curv, cc = sf->cc;
     const double r2 = x * x + y * y;
-    const double sq = fast_sqrt(1.0 - c * c * (1.0 + cc) * r2);
+    // sq and 1/sq from ONE reciprocal square root (v_rsq_f64 + two Newton steps) instead of a square root and a
+    // reciprocal sequence: image mode of BASELINE configs[2] 0.266 -> 0.251 ms (benchmarks/ab_builds.py,
+    // profiles/r03b_ab_asphere_eval.json; hit points move by at most 4e-14 mm)
+    const double st = 1.0 - c * c * (1.0 + cc) * r2;
+    const double isq = fast_rsqrt(st);
+    const double sq = st * isq;
     double p = 0.0, dp = 0.0;  // p = sum a_n r2^n ; dp = sum (n+1) a_n r2^n
     prt_cdoubles cf = side_doubles(sf);
     prt_cdoubles cb = cf + sf->n_coeffs;
@@ -234,14 +239,24 @@ PRT_DEV void asphere_eval(const prt_dev_surface *__restrict__ sf, int nc, const 
         dp = dp * r2 + cb[n];
     }
     if (PRE) {
+        // (a_n = b_n = 0 for n >= nc: the upper half of the fixed-length Horner does nothing for the usual 2..4
+        // coefficients -- a wave-uniform branch skips it: 0.266 -> 0.258 ms in image mode, both changes 0.241;
+        // path mode 0.358 -> 0.348 ms)
+        if (nc > PRT_ASPHERE_PREFETCH / 2) {
 #pragma unroll
-        for (int n = PRT_ASPHERE_PREFETCH - 1; n >= 0; --n) {  // a_n = b_n = 0 for n >= nc: p, dp stay 0 until n < nc
+            for (int n = PRT_ASPHERE_PREFETCH - 1; n >= PRT_ASPHERE_PREFETCH / 2; --n) {
+                p = p * r2 + ac.a[n];
+                dp = dp * r2 + ac.b[n];
+            }
+        }
+#pragma unroll
+        for (int n = PRT_ASPHERE_PREFETCH / 2 - 1; n >= 0; --n) {
             p = p * r2 + ac.a[n];
             dp = dp * r2 + ac.b[n];
         }
     }
     F = c * r2 * fast_rcp(1.0 + sq) + p * r2;
-    dFdr2x2 = c * fast_rcp(sq) + 2.0 * dp;
+    dFdr2x2 = c * isq + 2.0 * dp;
 }
 
 // XYPolynomials.F / gradF, surface_shape.py:785-807: F = sum c_ij x^i y^j (c_ij already divided by
@@ -339,11 +354,13 @@ PRT_DEV void biconic_eval(const prt_dev_surface *__restrict__ sf, double x, doub
     const double cx = sf->curv, ccx = sf->cc, cy = sf->curv_y, ccy = sf->cc_y;
     const double x2 = x * x, y2 = y * y;
     const double u = cx * x2 + cy * y2;
-    const double sq = fast_sqrt(1.0 - cx * cx * (1.0 + ccx) * x2 - cy * cy * (1.0 + ccy) * y2);
+    const double st = 1.0 - cx * cx * (1.0 + ccx) * x2 - cy * cy * (1.0 + ccy) * y2;
+    const double isq = fast_rsqrt(st);  // sq and 1/sq from one reciprocal square root (as in asphere_eval)
+    const double sq = st * isq;
     const double den = 1.0 + sq;
     const double iden = fast_rcp(den);
     F = u * iden;
-    const double common = iden * iden * fast_rcp(sq);
+    const double common = iden * iden * isq;
     const double two_den_sq = 2.0 * den * sq;
     Fx = cx * x * (cx * (ccx + 1.0) * u + two_den_sq) * common;
     Fy = cy * y * (cy * (ccy + 1.0) * u + two_den_sq) * common;
