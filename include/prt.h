@@ -51,6 +51,7 @@ extern "C" {
 #endif
 
 #define PRT_ABI_VERSION 5
+#define PRT_COMPACT_MAX_ROWS 24 /* rows prt_compact moves per call */
 #define PRT_MAX_COEFFS 128 /* asphere A2.. coefficients and / or XY-polynomial terms */
 
 /* ---- error codes ---------------------------------------------------- */
@@ -250,6 +251,12 @@ typedef struct prt_trace_args {
     double *x_hit, *k_out;
     uint8_t *valid, *valid_out, *nonconv;
     double *e_out_re, *e_out_im;  /* E behind crystal interfaces (prt_trace_fields) or NULL */
+    /* Evanescent modes at crystal interfaces (PRT_MODE_PATH, fused march): the reference carries them as COMPLEX
+     * wave vectors (material/material.py:407-454); the engine does not trace them (their slot of k_out is NaN and
+     * everything behind it invalid).  With k_out_im != NULL (layout of k_out) such a slot receives the complex k
+     * instead -- real part in k_out, imaginary part here, 0 for propagating modes -- from a post-pass over the
+     * crystal surfaces (of a conjugate pair the root with Im(xi) > 0; the reference's pick is its sort's). */
+    double *k_out_im;
     /* image-plane redirect (all-isotropic tables, PRT_MODE_PATH, 16-B aligned rows): when x_img != NULL the record
      * of the LAST surface goes to x_img, k_img (3 rows of img_pitch elements each) and valid_img (the mask byte
      * row: `valid`, or the flags byte with PRT_MODE_FLAGS; valid_out_img: the second mask row without
@@ -450,7 +457,7 @@ int32_t prt_bundle_moments_async(int32_t device, int64_t n, int64_t pitch, const
 
 /*
  * Order-preserving compaction by mask (the reference's [:, valid] indexing):
- * n_arrays (<= 16) row pointers of n doubles each (src[r] -> dst[r]; the pointer
+ * n_arrays (<= PRT_COMPACT_MAX_ROWS) row pointers of n doubles each (src[r] -> dst[r]; the pointer
  * tables themselves are HOST arrays of device pointers), plus an optional int64
  * id row and an optional uint8 row.  *n_kept (host) receives the survivor count.  Synchronises the
  * stream (the count is returned to the host).  scratch: device buffer of at

@@ -154,7 +154,7 @@ class PrtTraceArgs(ctypes.Structure):
                 ("e_uniform_im", ctypes.c_double * 3),
                 ("out_pitch", ctypes.c_int64), ("x_hit", ctypes.c_void_p), ("k_out", ctypes.c_void_p),
                 ("valid", ctypes.c_void_p), ("valid_out", ctypes.c_void_p), ("nonconv", ctypes.c_void_p),
-                ("e_out_re", ctypes.c_void_p), ("e_out_im", ctypes.c_void_p),
+                ("e_out_re", ctypes.c_void_p), ("e_out_im", ctypes.c_void_p), ("k_out_im", ctypes.c_void_p),
                 ("x_img", ctypes.c_void_p), ("k_img", ctypes.c_void_p), ("valid_img", ctypes.c_void_p),
                 ("valid_out_img", ctypes.c_void_p), ("img_pitch", ctypes.c_int64),
                 ("moments_ref3", ctypes.POINTER(ctypes.c_double)), ("moments_out7_dev", ctypes.c_void_p),

@@ -680,6 +680,9 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
             if (out_pitch != n0 || in_pitch != n0)
                 return fail(PRT_ERR_UNSUPPORTED, "prt_trace: the per-surface march through crystals (more than 8 crystal "
                                                  "interfaces) takes tight arrays (pitch 0)");
+            if (a.k_out_im)
+                return fail(PRT_ERR_UNSUPPORTED, "prt_trace: k_out_im (complex k of evanescent modes) comes from the fused "
+                                                 "crystal march (at most 8 crystal interfaces)");
             stream_scratch rows(st);
             const double *k0 = a.k0;
             if (uni) {  // the per-surface kernels read arrays: broadcast the uniform vectors once
@@ -745,6 +748,33 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
 #undef PRT_LAUNCH_GU
 #undef PRT_LAUNCH_GP
 #undef PRT_LAUNCH_G
+        if (a.k_out_im) {
+            // complex wave vectors of the evanescent modes: post-pass over the crystal surfaces (k_evanescent_fill)
+            if (mode != PRT_MODE_PATH)
+                return fail(PRT_ERR_INVALID_ARG, "prt_trace: k_out_im needs PRT_MODE_PATH (the post-pass reads the path)");
+            int64_t tot_out = 0, br = 1;
+            for (int s = 0; s < sys->n_surfaces; ++s) {
+                if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC) br *= 2;
+                tot_out += br * out_pitch;
+            }
+            HIP_TRY(hipMemsetAsync(a.k_out_im, 0, sizeof(double) * 3 * (size_t)tot_out, st));
+            int64_t off_in = 0, off_out = 0;
+            br = 1;
+            for (int s = 0; s < sys->n_surfaces; ++s) {
+                const bool cr = sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC;
+                const int64_t bp = br * out_pitch;
+                if (cr) {
+                    const double *k_par = (s == 0) ? a.k0 : a.k_out + 3 * (off_out - bp);
+                    const int64_t par_pitch = (s == 0) ? in_pitch : bp;
+                    hipLaunchKernelGGL(k_evanescent_fill, dim3(nblocks(bp, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st,
+                                       sys->d_table + s, n0, out_pitch, bp, a.x_hit + 3 * off_in, k_par, par_pitch, fu,
+                                       a.k_out + 3 * off_out, a.k_out_im + 3 * off_out);
+                    br *= 2;
+                }
+                off_in += bp;
+                off_out += br * out_pitch;
+            }
+        }
         HIP_TRY(hipGetLastError());
         return PRT_OK;
     }
@@ -1366,15 +1396,15 @@ int32_t prt_bundle_moments_async(int32_t device, int64_t n, int64_t pitch, const
 int64_t prt_compact_scratch_bytes(int64_t n) {
     if (n < 0) return 0;
     const int64_t nb = (n + CMP_TILE - 1) / CMP_TILE;
-    // block sums (+1 total) and the two pointer tables (up to 16 arrays each)
-    return (nb + 1) * (int64_t)sizeof(int64_t) + 2 * 16 * (int64_t)sizeof(void *) + 64;
+    // block sums (+1 total) and the two pointer tables (up to PRT_COMPACT_MAX_ROWS arrays each)
+    return (nb + 1) * (int64_t)sizeof(int64_t) + 2 * PRT_COMPACT_MAX_ROWS * (int64_t)sizeof(void *) + 64;
 }
 
 int32_t prt_compact(int64_t n, const uint8_t *mask, int32_t n_arrays, const double *const *src,
                     double *const *dst, const int64_t *id_src, int64_t *id_dst,
                     const uint8_t *u8_src, uint8_t *u8_dst, void *scratch, int64_t *n_kept,
                     void *stream) {
-    if (n < 0 || (n > 0 && !mask) || n_arrays < 0 || n_arrays > 16 || (n_arrays && (!src || !dst)) ||
+    if (n < 0 || (n > 0 && !mask) || n_arrays < 0 || n_arrays > PRT_COMPACT_MAX_ROWS || (n_arrays && (!src || !dst)) ||
         (n > 0 && !scratch) || !n_kept || (id_src && !id_dst) || (u8_src && !u8_dst))
         return fail(PRT_ERR_INVALID_ARG, "prt_compact: bad argument");
     *n_kept = 0;
@@ -1391,7 +1421,7 @@ int32_t prt_compact(int64_t n, const uint8_t *mask, int32_t n_arrays, const doub
     int64_t *sums = (int64_t *)scratch;
     uintptr_t pbase = ((uintptr_t)(sums + nb + 1) + 15u) & ~(uintptr_t)15u;
     const double **d_src = (const double **)pbase;
-    double **d_dst = (double **)(pbase + 16 * sizeof(void *));
+    double **d_dst = (double **)(pbase + PRT_COMPACT_MAX_ROWS * sizeof(void *));
     if (n_arrays) {
         HIP_TRY(hipMemcpyAsync((void *)d_src, src, sizeof(void *) * n_arrays, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync((void *)d_dst, dst, sizeof(void *) * n_arrays, hipMemcpyHostToDevice, st));

@@ -577,6 +577,98 @@ __global__ __launch_bounds__(PRT_GENERAL_BLOCK, PRT_GENERAL_WAVES) void k_trace_
 }
 
 // ---------------------------------------------------------------------------
+// Evanescent modes at a crystal interface: the reference carries them as COMPLEX wave vectors (complex xi from
+// LAPACK, material.py:407-454; k = kpa + xi n, material_anisotropic.py:87-100); the march computes in real
+// arithmetic and leaves NaN in such a slot (the mode carries no energy through the interface and is not traced
+// further).  This post-pass over one crystal surface of a finished PATH-mode trace fills those slots: real part
+// into k_re, imaginary part into k_im (0 everywhere else).  Which root lands in which slot follows the order the
+// march (and the reference's S.n sort, where an evanescent mode has S.n = 0) gives the two leaving solutions:
+// uniaxial / isotropic eps -- closed forms, ordinary before extraordinary; general eps -- the complex roots of the
+// quartic (Aberth) with positive imaginary part, by ascending real part.  Of a conjugate pair xi, conj(xi) the one
+// with Im > 0 is reported (the reference's pick is whatever its sort leaves first).
+//   x_hit_s (3, BP) hit points of the surface; k_par: wave vectors of the entering rays, rows par_pitch apart,
+//   indexed by slot (NULL: every ray has fu.k); k_re / k_im (3, 2 BP): the surface's block of k_out / k_out_im;
+//   BP = branches * P slots, ray i of a branch exists for i < N.
+__global__ __launch_bounds__(PRT_BLOCK) void k_evanescent_fill(
+    const prt_dev_surface *__restrict__ sf, int64_t N, int64_t P, int64_t BP, const double *__restrict__ x_hit_s,
+    const double *__restrict__ k_par, int64_t par_pitch, first_uniform fu, double *__restrict__ k_re,
+    double *__restrict__ k_im) {
+    const int64_t j = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    bool live = j < BP && (j % P) < N;
+    const int64_t jj = live ? j : 0;
+    const int64_t M = 2 * BP;
+    const bool nan0 = live && isnan(k_re[jj]), nan1 = live && isnan(k_re[jj + BP]);
+    live = live && (nan0 || nan1);
+    // (no early return: quartic_roots votes across the wave)
+    const vec3 xh = v3(x_hit_s[jj], x_hit_s[BP + jj], x_hit_s[2 * BP + jj]);
+    const vec3 kg = k_par ? v3(k_par[jj], k_par[par_pitch + jj], k_par[2 * par_pitch + jj]) : v3(fu.k[0], fu.k[1], fu.k[2]);
+    const vec3 n = normal_in_material_frame(sf, to_shape_frame(sf, xh));
+    const bool mat_id = sf->frame_flags & PRT_FRAME_MAT_IDENTITY;
+    const vec3 k1 = mat_id ? kg : matT_vec(sf->B_mat, kg);
+    const double kn = dot(k1, n);
+    const vec3 kpa = v3(k1.x - kn * n.x, k1.y - kn * n.y, k1.z - kn * n.z);
+    const double kap2 = dot(kpa, kpa);
+    live = live && isfinite(kap2) && isfinite(n.x) && isfinite(n.y) && isfinite(n.z);
+    cplx cand[2] = {cplx{0.0, 0.0}, cplx{0.0, 0.0}};
+    int nc = 0;
+    const int cls = sf->aniso_class;
+    if (cls == PRT_ANISO_ISOTROPIC) {
+        const double q = sf->aniso_eo - kap2;
+        if (q < 0.0) {
+            cand[0] = cand[1] = cplx{0.0, sqrt(-q)};
+            nc = 2;
+        }
+    } else if (cls == PRT_ANISO_UNIAXIAL) {
+        const double eo = sf->aniso_eo, ee = sf->aniso_ee;
+        const vec3 c = v3(sf->aniso_axis[0], sf->aniso_axis[1], sf->aniso_axis[2]);
+        const double q = eo - kap2;
+        if (q < 0.0) cand[nc++] = cplx{0.0, sqrt(-q)};
+        const double ncx = dot(n, c), kc = dot(kpa, c);
+        const double A = eo + (ee - eo) * ncx * ncx;
+        const double Bh = (ee - eo) * kc * ncx;
+        const double C = eo * kap2 + (ee - eo) * kc * kc - eo * ee;
+        const double disc = Bh * Bh - A * C;
+        if (disc < 0.0) cand[nc++] = cplx{-Bh / A, sqrt(-disc) / fabs(A)};
+    } else {
+        double pc[5];
+        cplx z[4];
+        xi_polynomial(sf->eps_re, n, kpa, pc);
+        if (!live) {  // keep the iteration of dead lanes harmless
+            pc[0] = -1.0; pc[1] = 0.0; pc[2] = 0.0; pc[3] = 0.0; pc[4] = 1.0;
+        }
+        quartic_roots(pc, z);
+        // the complex roots with positive imaginary part, by ascending real part
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool cx = z[i].im > 1e-9 * fmax(1.0, fabs(z[i].re));
+            if (cx && nc < 2) cand[nc++] = z[i];
+        }
+        if (nc == 2 && cand[1].re < cand[0].re) {
+            const cplx t = cand[0];
+            cand[0] = cand[1];
+            cand[1] = t;
+        }
+    }
+    if (!live) return;
+    const double sg = (sf->interaction == PRT_MIRROR) ? -1.0 : 1.0;  // reflect: -(k), material_anisotropic.py:136
+    int used = 0;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        if (!(b == 0 ? nan0 : nan1) || used >= nc) continue;
+        const cplx xi = cand[used++];
+        vec3 kr = v3(sg * (kpa.x + xi.re * n.x), sg * (kpa.y + xi.re * n.y), sg * (kpa.z + xi.re * n.z));
+        vec3 ki = v3(sg * xi.im * n.x, sg * xi.im * n.y, sg * xi.im * n.z);
+        if (!mat_id) {
+            kr = mat_vec(sf->B_mat, kr);
+            ki = mat_vec(sf->B_mat, ki);
+        }
+        const int64_t o = jj + b * BP;
+        k_re[o] = kr.x; k_re[M + o] = kr.y; k_re[2 * M + o] = kr.z;
+        k_im[o] = ki.x; k_im[M + o] = ki.y; k_im[2 * M + o] = ki.z;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // per-surface kernels (the plugin-granular API, and the march through
 // anisotropic systems).  x is read modulo n_src so that the two children of a
 // split ray share their parent's hit point without a copy.

@@ -15,6 +15,7 @@ from . import placed
 from .surface_table import pack_table
 
 
+COMPACT_MAX_ROWS = 24         # PRT_COMPACT_MAX_ROWS (include/prt.h)
 FUSED_MAX_CRYSTALS = 8       # PRT_FUSED_MAX_CRYSTALS: crystal interfaces the fused walk parks (csrc/prt_kernels.h)
 
 
@@ -153,6 +154,7 @@ class TraceResult(object):
         self.e_out = e_out            # per surface (re, im) behind crystal interfaces (trace(want_fields))
         self.flags = None             # per surface packed mask bytes (alloc_outputs(packed_flags=True))
         self.nonconv = None           # per surface: Newton ended at its iteration cap (want_nonconv / packed flags)
+        self.k_out_im = None          # crystal tables traced with want_fields: Im(k), non-zero for evanescent modes
         self.padded = None            # crystal tables: the same lists over the raw arrays with ray pitch ``ray_pitch``
         self.ray_pitch = None
         self.x_hit = x_hit
@@ -251,6 +253,9 @@ class TraceResult(object):
             if bufs.get("nonconv") is not None:
                 bn = bufs["nonconv"]
                 res.nonconv = _LazyViews(rows, lambda s: row1(bn, off_in[s], br_in[s], padded))
+            if bufs.get("k_im") is not None:
+                bki = bufs["k_im"]
+                res.k_out_im = _LazyViews(rows, lambda s: rows3(bki, off_out[s], br_out[s], padded))
             return res
         res = views(False)
         res.padded = views(True)
@@ -398,6 +403,9 @@ class DeviceSystem(object):
                 raise ValueError("E fields are produced at crystal interfaces only")
             bufs["e_re"] = torch.zeros(nk, dtype=torch.float64, device=dev)
             bufs["e_im"] = torch.zeros(nk, dtype=torch.float64, device=dev)
+            if mode == _lib.MODE_PATH and pitch:      # (the fused march; the per-surface march has no such report)
+                # imaginary parts of the wave vectors: non-zero in the slots of evanescent modes (prt.h k_out_im)
+                bufs["k_im"] = torch.zeros(nk, dtype=torch.float64, device=dev)
         return bufs
 
     # -- whole sequence ----------------------------------------------------
@@ -437,6 +445,8 @@ class DeviceSystem(object):
         if bufs.get("e_re") is not None:
             a.e_out_re = bufs["e_re"].data_ptr()
             a.e_out_im = bufs["e_im"].data_ptr()
+        if bufs.get("k_im") is not None:
+            a.k_out_im = bufs["k_im"].data_ptr()
         img = bufs.get("image_rows")
         if img is not None:
             (xi, ki, vi) = img[:3]
@@ -638,8 +648,8 @@ def compact(mask, arrays, ids=None, flags=None):
             raise ValueError("compact: arrays must be float64 (R, N) with unit stride along N")
         rows_src += [a[r] for r in range(a.shape[0])]
     nrow = len(rows_src)
-    if nrow > 16:
-        raise ValueError("compact: at most 16 rows per call")
+    if nrow > COMPACT_MAX_ROWS:
+        raise ValueError("compact: at most %d rows per call" % COMPACT_MAX_ROWS)
     with torch.cuda.device(dev):
         tmp = _torch_alloc(lambda: torch.empty((max(nrow, 1), n), dtype=torch.float64, device=dev))
         idt = torch.empty(n, dtype=torch.int64, device=dev) if ids is not None else None

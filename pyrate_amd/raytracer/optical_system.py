@@ -242,8 +242,11 @@ def _seqtrace_fused_crystal(ib, records, lengths):
             if crystal[s]:
                 xs = torch.cat((xs, xs), dim=1)
             arrays = [xs, dense.k_out[s]]
+            with_kim = crystal[s] and dense.k_out_im is not None
             if crystal[s]:
                 arrays += list(dense.e_out[s])
+            if with_kim:
+                arrays.append(dense.k_out_im[s])        # Im(k): evanescent modes (complex k like the reference's)
             flags = None
             if j < S:
                 arrays.append(dense.x_hit[j])
@@ -252,6 +255,7 @@ def _seqtrace_fused_crystal(ib, records, lengths):
             arr = out[0]
             (cx, ck) = (arr[0], arr[1])
             e = (arr[2], arr[3]) if crystal[s] else None
+            b._k_im = [arr[4]] if with_kim else None
             m = cx.shape[1]
             b._x = [cx]
             b._k = [ck]
@@ -262,6 +266,8 @@ def _seqtrace_fused_crystal(ib, records, lengths):
                 b._k.append(ck)
                 b._valid.append(out[2])
                 b._e.append(e)
+                if b._k_im is not None:
+                    b._k_im.append(b._k_im[0])
             b._ray_id = out[1]
             b._n = m
             b._k_complex = True if s >= first_crystal else ib._k_complex

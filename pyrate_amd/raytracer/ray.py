@@ -215,7 +215,11 @@ class RayBundle(object):
         k = self._stack("k", self._k)
         if self._k_complex:
             if "kc" not in self._cache:
-                self._cache["kc"] = k.astype(complex)
+                kc = k.astype(complex)
+                k_im = getattr(self, "_k_im", None)
+                if k_im is not None:          # evanescent modes behind a crystal interface: complex k (prt.h k_out_im)
+                    kc = kc + 1j * engine.stack_to_host(k_im)
+                self._cache["kc"] = kc
             return self._cache["kc"]
         return k
 
@@ -317,6 +321,8 @@ class RayBundle(object):
         else:
             (er, ei, _) = _to_dev(Enew, dev)
             self._e.append((er, ei))
+        if getattr(self, "_k_im", None) is not None:
+            self._k_im.append(self._k_im[-1] if knew is None else torch.zeros_like(kr))
         self._cache = {}
 
     def _append_device(self, x_hit, valid_cumulative):
@@ -325,6 +331,8 @@ class RayBundle(object):
         self._k.append(self._k[-1])
         self._valid.append(valid_cumulative)
         self._e.append(self._e[-1])
+        if getattr(self, "_k_im", None) is not None:
+            self._k_im.append(self._k_im[-1])
         self._cache = {}
 
     def clone(self):
@@ -336,6 +344,8 @@ class RayBundle(object):
         other._k = list(self._k)
         other._valid = list(self._valid)
         other._e = list(self._e)
+        if getattr(self, "_k_im", None) is not None:
+            other._k_im = list(self._k_im)
         other._cache = {}
         return other
 
