@@ -690,7 +690,11 @@ def main():
             watchdog.stage = "measure " + c
             recs.append(measure_single(c, args, dev, rays_of[c], with_cpu=not args.no_cpu_baseline))
         traffic, flops = None, None
-        want_live = args.traffic == "live" or (args.traffic == "auto" and shutil.which("rocprofv3") is not None)
+        # (a run that is itself being profiled -- rocprofv3 -- python bench.py -- does not start a profiler of its own)
+        profiled = any("rocprof" in os.environ.get(v, "").lower() for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES",
+                                                                            "HSA_TOOLS_LIB", "ROCPROFILER_LIBRARY_PATH"))
+        want_live = args.traffic == "live" or (args.traffic == "auto" and shutil.which("rocprofv3") is not None
+                                               and not profiled)
         if want_live:
             watchdog.stage = "PMC passes"
             (traffic, flops) = measure_pmc_live(configs, args, rays_of, args.traffic_timeout)
