@@ -68,6 +68,7 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz
 PREWARM_LAUNCHES = 30
+PREWARM_MS = 50.0            # ... and at least this much device time of them (short kernels)
 SINGLE_GPU_CONFIGS = ("doublegauss", "asphere", "aniso", "xypoly")
 T_START = time.perf_counter()
 
@@ -317,9 +318,16 @@ def measure_single(config, args, dev, rays, with_cpu):
     launch = sysd.launcher(x0, k0, ob, e0, uniform=uni)     # the argument struct is built once
 
     # device wake-up (not one of the W warm-up steps): after idle the first ~25 ms of launches run at ramping
-    # clocks; 30 plain launches of the same kernel bring the chip to its steady state before anything is counted
+    # clocks; 30 plain launches of the same kernel -- and, for kernels as short as the crystal march (0.12 ms), as many
+    # more as it takes to fill 50 ms -- bring the chip to its steady state before anything is counted
     for _ in range(PREWARM_LAUNCHES):
         launch()
+    torch.cuda.synchronize()
+    est_ms = sysd.trace_timed(x0, k0, ob, 10, e0, uniform=uni)
+    prewarm = PREWARM_LAUNCHES + 10
+    while prewarm * est_ms < PREWARM_MS:
+        launch()
+        prewarm += 1
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         launch()
@@ -351,7 +359,7 @@ def measure_single(config, args, dev, rays, with_cpu):
     (n_in, n_out) = sysd.ray_counts(n_local)
     rec = {"name": config, "workload": wl["workload"], "value": n_local * S * args.steps / elapsed,
            "unit": "ray-surface-ops/s", "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": elapsed / args.steps * 1e3, "dtype": "f64",
+           "ms_per_step": elapsed / args.steps * 1e3, "dtype": "f64", "prewarm_launches": prewarm,
            "rays": n_local, "surfaces": S, "mode": args.mode,
            "rays_per_surface": None if iso else {"entering": n_in, "leaving": n_out},
            "first_segment": ("uniform k0 / E0 (collimated bundle: one vector each, 24 B/ray of loads)"
@@ -715,7 +723,7 @@ def main():
                                "surfaces": head["surfaces"], "rays_per_surface": head["rays_per_surface"],
                                "mode": head["mode"], "first_segment": head["first_segment"],
                                "record_bytes": head["record_bytes"], "masks": head["masks"], "sharding": "none",
-                               "wavelengths": 1, "prewarm_launches": PREWARM_LAUNCHES,
+                               "wavelengths": 1, "prewarm_launches": head["prewarm_launches"],
                                "output_placement": dict(head["output_placement"], arena=arena_stats),
                                "build": prt_build.build_info(_lib.LIB_PATH),
                                "wall_s": None},
