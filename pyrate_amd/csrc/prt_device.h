@@ -155,7 +155,9 @@ PRT_DEV double conic_t(double c, double cc, const vec3 &r0, const vec3 &d, doubl
 PRT_DEV vec3 conic_grad(double c, double cc, double x, double y) {
     const double r2 = x * x + y * y;
     const double st = 1.0 - (1.0 + cc) * c * c * r2;
-    const double sq = (st > 0.0) ? sqrt(st) : __builtin_nan("");
+    // (fast_sqrt: ~1 ulp without the IEEE sequence's scaling steps; this gradient feeds the surface normal of the
+    // interactions that evaluate the shape at a given point -- crystal interfaces, the per-surface entry points)
+    const double sq = (st > 0.0) ? fast_sqrt(st) : __builtin_nan("");
     return v3(-c * x, -c * y, sq);
 }
 
@@ -670,7 +672,7 @@ PRT_DEV vec3 normal_from_grad(const prt_dev_surface *__restrict__ sf, const vec3
 template <int SHAPES = PRT_SHAPES_ALL>
 PRT_DEV vec3 normal_in_material_frame(const prt_dev_surface *__restrict__ sf, const vec3 &p) {
     vec3 g = (SHAPES == PRT_SHAPES_CONIC) ? conic_grad(sf->curv, sf->cc, p.x, p.y) : shape_grad(sf, p.x, p.y);
-    const double inv = 1.0 / sqrt(dot(g, g));
+    const double inv = fast_rsqrt(dot(g, g));
     vec3 n = v3(g.x * inv, g.y * inv, g.z * inv);
     const int ff = sf->frame_flags;
     if (!(ff & PRT_FRAME_SHAPE_IDENTITY)) n = mat_vec(sf->B_shape, n);
