@@ -149,6 +149,9 @@ def case_xypoly():
     (s, seq) = build_simple_optical_system(zoo.xypoly_builduplist())
     dump_case("xypoly_axis", s, seq, disk_bundle(96, 8.0, -5.0))
     dump_case("xypoly_field5", s, seq, disk_bundle(96, 8.0, -5.0, field_deg=5.0))
+    # the XY-polynomial system bench.py times (`configs`: xypoly), with its bundle geometry
+    (s, seq) = build_simple_optical_system(systems.xypoly_builduplist())
+    dump_case("xypoly_bench_field5", s, seq, disk_bundle(96, 9.0, -5.0, field_deg=5.0))
 
 
 def case_biconic():

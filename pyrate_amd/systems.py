@@ -245,16 +245,20 @@ def xypoly_terms(degree=4, scale=1e-3):
     return terms
 
 
-def xypoly_records(degree=4, scale=1e-3):
+def xypoly_builduplist(degree=4, scale=1e-3):
     """stop, plane front (n = 1.5168), XY-polynomial back surface, image: demo_asphere.py:47-57 with the asphere
-    replaced by a 12-term polynomial freeform"""
-    return simple_system_records([
+    replaced by a 12-term polynomial freeform (build_simple_optical_system form)"""
+    return [
         ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
         ({"shape": "Conic"}, {"decz": 5.0}, 1.5168, "front", {}),
         ({"shape": "XYPolynomials", "normradius": 1.0, "coefficients": xypoly_terms(degree, scale)},
          {"decz": 20.0}, None, "back", {}),
         ({"shape": "Conic"}, {"decz": 100.0}, None, "image", {}),
-    ])
+    ]
+
+
+def xypoly_records(degree=4, scale=1e-3):
+    return simple_system_records(xypoly_builduplist(degree, scale))
 
 
 # ---- config 4: anisotropic doublet (demos/demo_anisotropic_doublet.py:55-121) ------

@@ -22,7 +22,7 @@ ISO_CASES = ["doublet", "doublet_clipped", "double_gauss_axis", "double_gauss_fi
              "tilted_frames", "mirrors", "two_elements", "catalog_doublet",
              "spd_double_gauss_Fline", "prism_red", "prism_blue"]
 EXPLICIT_CASES = ["asphere_mild_axis", "asphere_mild_field5", "asphere_strong_axis",
-                  "asphere_strong_field5", "xypoly_axis", "xypoly_field5", "biconic_axis",
+                  "asphere_strong_field5", "xypoly_axis", "xypoly_field5", "xypoly_bench_field5", "biconic_axis",
                   "biconic_field5", "hud_biconic_mirrors", "zmx_lenssystem",
                   "zernike_fringe_field3", "zernike_ansi_field2", "zernike_combination_mirror",
                   "gridsag_field2"]
