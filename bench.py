@@ -372,7 +372,7 @@ def measure_single(config, args, dev, rays, with_cpu):
                                 "inputs": "arena" if input_kind is not None else "torch allocator"},
            "roofline": hbm, "cpu_baseline": None, "_iso": iso, "_alg": alg, "_n_local": n_local}
     if with_cpu:
-        rec["cpu_baseline"] = cpu_baseline(wl, budget_s=args.cpu_budget, with_numpy=(config == args.config))
+        rec["cpu_baseline"] = cpu_baseline(wl, budget_s=args.cpu_budget, with_numpy=(config == (args.config or "doublegauss")))
     del bufs, ob, x0, k0, e0
     return rec
 
@@ -547,7 +547,7 @@ class Watchdog(object):
     def _run(self, rank, json_fd_ref, base):
         if self._done.wait(self.seconds):
             return
-        msg = "watchdog: no result after %.0f s (stage: %s)" % (self.seconds, self.stage)
+        msg = "watchdog: no result after %g s (stage: %s)" % (self.seconds, self.stage)
         try:
             import faulthandler
             faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
@@ -616,6 +616,10 @@ def main():
     ap.add_argument("--force-multi", action="store_true",
                     help="run the N>1 code path (5 wavelengths, side-stream all-reduce and all-gather) "
                          "with whatever world size there is, also 1: RCCL smoke test on a 1-GPU box")
+    ap.add_argument("--trace-stream", choices=["default", "new", "high"], default="new",
+                    help="N > 1: stream of the march -- a new one (default: on the default stream the barrier packets "
+                         "of RCCL's stream and of the side stream can share the march's hardware queue: +4 %% per step), "
+                         "the default stream, or a new high-priority one")
     ap.add_argument("--watchdog", type=float, default=None,
                     help="seconds after which a JSON line with an `error` field is printed and the process exits "
                          "(default: 900 for N > 1, off at N = 1; PRT_BENCH_WATCHDOG overrides)")
@@ -804,8 +808,15 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
         for b in range(nbuf):
             bufs[b % n_out_bufs] = dict(bufs[b % n_out_bufs], image_rows=gathers[b].own_rows())
     comm_stream = torch.cuda.Stream(device=dev)
+    if args.trace_stream != "default":
+        # the march on a stream of its own (high priority: a hardware queue that RCCL's stream and the side stream
+        # do not share -- their barrier packets otherwise sit between two marches in the same queue)
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1 if args.trace_stream == "high" else 0))
     main_stream = torch.cuda.current_stream(dev)
     side_done = [None] * nbuf          # event: side-stream work of slot b has finished
+    traced = [torch.cuda.Event() for _ in range(nbuf)]          # events are made once and re-recorded every step
+    side_events = [torch.cuda.Event() for _ in range(nbuf)]
 
     def image_rows(ob):
         """image-plane rows of a buffer set: (x, k, mask byte row) -- views, nothing is copied"""
@@ -822,22 +833,24 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
         else:
             sysds[i % len(sysds)].trace_into(x0, k0, ob, e0d, uniform=uni)
         if do_stats or do_step_gather:
-            ev = torch.cuda.Event()
+            ev = traced[b]
             ev.record(main_stream)
-            (xi, ki, vi) = image_rows(ob)
+            gather_now = do_step_gather and with_gather
+            if (gather_now and not inplace) or (do_stats and not fused_stats):
+                (xi, ki, vi) = image_rows(ob)
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
                 if fused_stats:
                     stats[b].reduce()
                 elif do_stats:
                     stats[b].start(xi, sysd.views(ob).valid_out[-1])
-                if do_step_gather and with_gather:
+                if gather_now:
                     if inplace:
                         gathers[b].start_in_place()
                     else:
                         gathers[b].start(xi, ki, vi)
                     gathers[b].wait()
-                done = torch.cuda.Event()
+                done = side_events[b]
                 done.record(comm_stream)
                 side_done[b] = done
 
@@ -857,12 +870,15 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
         comm_stream.synchronize()
         torch.cuda.synchronize()
 
+    issue_s = [0.0]
+
     def timed_region(n_steps, **kw):
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n_steps):
             step(i, **kw)
+        issue_s[0] = time.perf_counter() - t0          # the host is done issuing; the device may still be busy
         finish()
         dist.barrier()
         torch.cuda.synchronize()
@@ -880,8 +896,18 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
     finish()
     if do_final_gather and args.warmup > 0:
         final_gather(args.warmup - 1)          # warms the all-gather path too
+    if os.environ.get("PRT_BENCH_HOST_PROFILE"):       # where the host's time per step goes (stderr)
+        import cProfile, pstats
+        prof = cProfile.Profile()
+        prof.enable()
+        for i in range(200):
+            step(i)
+        prof.disable()
+        finish()
+        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
     watchdog.stage = "timed region"
     elapsed = timed_region(args.steps)
+    host_issue_ms = issue_s[0] / args.steps * 1e3
     # the same steps without the image-plane all-gather, measured right after (reported beside)
     watchdog.stage = "timed region without gather"
     elapsed_without_gather = timed_region(args.steps, with_gather=False) if do_step_gather else None
@@ -964,6 +990,7 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
                                                      if elapsed_without_gather else None),
                             "backend": "rccl" if args.backend == "nccl" else "gloo dry run (host staged)"},
                         "expected": expected,
+                        "host_issue_ms_per_step": host_issue_ms, "trace_stream": args.trace_stream,
                         "image_plane_spot": spot,
                         "build": prt_build.build_info(_lib.LIB_PATH)},
                 roofline=roofline, cpu_baseline=None)

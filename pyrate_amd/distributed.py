@@ -170,8 +170,15 @@ class ImagePlaneGather(object):
         self._work = []
         if not _collectives_needed(self.group):
             return
-        lo = self.rank * self.n_pad
-        pairs = [(self._dest(row, 0), self._dest(row, 0)[lo:lo + self.n_pad]) for row in range(self.rows + 1)]
+        (lo, n_pad) = (self.rank * self.n_pad, self.n_pad)
+        pairs = [(self.recv_f[row, 0], self.recv_f[row, 0, lo:lo + n_pad]) for row in range(self.rows)]
+        mask = self.recv_v[0]
+        if n_pad % 8 == 0 and mask.data_ptr() % 8 == 0:
+            # the mask row travels as n_pad / 8 doubles: all rows are of ONE element type and go out as one group
+            m8 = mask.view(torch.float64)
+            pairs.append((m8, m8[lo // 8:(lo + n_pad) // 8]))
+        else:
+            pairs.append((mask, mask[lo:lo + n_pad]))
         self._work = _all_gather_rows(pairs, self.group, self.device)
 
     def deposit(self, rank, x_img, k_img, valid, e_re=None, e_im=None):

@@ -126,3 +126,25 @@ def test_release_waits_for_side_streams_that_used_the_memory(gpu_device):
     assert not placed.record_stream(torch.zeros(4, device=gpu_device))
     del parts2
     arena.trim()
+
+
+def test_bench_multi_rank_path_with_a_watchdog_shorter_than_the_run(gpu_device):
+    """``bench.py --force-multi`` (RCCL, world 1) with a watchdog that fires before the run can finish: one JSON
+    line with ``error`` on stdout, exit code 3, no hang; and the same command with the default watchdog gives
+    the normal line with ``config.expected``"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PRT_BENCH_WATCHDOG="0.2")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-multi", "--steps", "5", "--warmup", "2",
+           "--rays", "1000000"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 3 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["error"].startswith("watchdog") and "stage" in line["error"]
+    env.pop("PRT_BENCH_WATCHDOG")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    line = json.loads(lines[0])
+    assert line["value"] > 0 and "expected" in line["config"] and "error" not in line

@@ -492,3 +492,34 @@ def test_newton_cap_annotation_reaches_the_table(api):
     assert [r.get("newton_maxit", 0) for r in recs] == [0, 0, 7, 0]
     table = st.pack_table(recs)
     assert [table[i].newton_maxit for i in range(4)] == [0, 0, 7, 0]
+
+
+def test_bench_watchdog_prints_one_json_error_line_and_exits_3():
+    """bench.py's watchdog: a process that makes no progress ends with ONE JSON line that has
+    an ``error`` field and the stage it was in, on the saved stdout, and exit code 3 -- instead of a hang"""
+    import json, os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import importlib.util, sys, threading, time
+        sys.argv = ["bench.py"]
+        spec = importlib.util.spec_from_file_location("bench", %r)
+        b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+        w = b.Watchdog(0.3, int(sys.stdin.readline()), [1], {"metric": "ray_surface_ops_per_s", "n_gpus": 2})
+        w.stage = "timed region"
+        threading.Event().wait(30)          # a collective that never returns
+        print("not reached")
+    """ % os.path.join(root, "bench.py"))
+    for (rank, n_lines) in ((0, 1), (1, 0)):
+        r = subprocess.run([sys.executable, "-c", code], input="%d\n" % rank, capture_output=True, text=True,
+                           timeout=120)
+        assert r.returncode == 3
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == n_lines and "not reached" not in r.stdout
+        if rank == 0:
+            line = json.loads(lines[0])
+            assert line["value"] is None and "timed region" in line["error"] and line["n_gpus"] == 2
+        assert "threading.py" in r.stderr or "Thread" in r.stderr       # the stack dump for the post-mortem
+    # and a run that finishes first is left alone
+    code_ok = code.replace("threading.Event().wait(30)", "w.done()").replace("not reached", "finished")
+    r = subprocess.run([sys.executable, "-c", code_ok], input="0\n", capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "finished"
