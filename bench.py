@@ -582,9 +582,11 @@ def main():
     ap.add_argument("--first-segment", choices=["uniform", "arrays"], default="uniform",
                     help="how the collimated bundle's k0 / E0 reach the march: as one vector each (default; "
                          "prt_trace_ex, only x0 is loaded: 24 B/ray) or as per-ray arrays (72 B/ray)")
-    ap.add_argument("--exchange", choices=["gather", "stats", "final-gather", "none"], default="gather",
+    ap.add_argument("--exchange", choices=["gather", "gather-direct", "stats", "final-gather", "none"], default="gather",
                     help="N>1, what every step ends with: gather = spot-statistics all-reduce + the image-plane "
-                         "all-gather (49 B/ray), overlapped with the next trace (default); stats = the "
+                         "all-gather (49 B/ray), overlapped with the next trace (default); gather-direct = the same "
+                         "exchange as peer writes into IPC-mapped receive buffers (one copy per row and peer, all "
+                         "xGMI links at once, no ring; the all-reduce closes it), RCCL backend only; stats = the "
                          "all-reduce only; final-gather = all-reduce per step, ONE all-gather after the K "
                          "steps (outside the timed region); none = the bare sharded trace")
     ap.add_argument("--gather-mode", choices=["inplace", "copy"], default="inplace",
@@ -768,8 +770,11 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
     sysd = sysds[0]
     mode = _lib.MODE_PATH if args.mode == "path" else _lib.MODE_IMAGE
     exchange = args.exchange
-    do_stats = exchange in ("gather", "stats", "final-gather")
-    do_step_gather = exchange == "gather"
+    direct = exchange == "gather-direct"
+    if direct and (args.backend != "nccl" or args.mode != "path" or args.two_pass_stats):
+        raise SystemExit("--exchange gather-direct: RCCL backend, path mode, fused statistics")
+    do_stats = exchange in ("gather", "gather-direct", "stats", "final-gather")
+    do_step_gather = exchange in ("gather", "gather-direct")
     do_final_gather = exchange == "final-gather"
     fused_stats = do_stats and not args.two_pass_stats
     # side-stream jobs in flight: the job of step i overlaps the trace of step i+1.  The fused
@@ -800,10 +805,13 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
     input_kind = arena_obj.kind_of(x0) if arena_obj is not None else None
     host_staged = (args.backend == "gloo")
     stats = [pdist.SpotStatistics(dev, n_rays=n_local) for _ in range(nbuf)] if do_stats else []
-    gathers = ([pdist.ImagePlaneGather(n_total, dev, stage_on_host=host_staged, align=align)
-                for _ in range(nbuf if do_step_gather else 1)] if (do_step_gather or do_final_gather) else [])
+    if direct:
+        gathers = [pdist.DirectImagePlaneGather(n_total, dev, align=align) for _ in range(nbuf)]
+    else:
+        gathers = ([pdist.ImagePlaneGather(n_total, dev, stage_on_host=host_staged, align=align)
+                    for _ in range(nbuf if do_step_gather else 1)] if (do_step_gather or do_final_gather) else [])
     # in place: the march of slot b deposits its image plane in gathers[b]'s receive buffer (prt_trace_ex redirect)
-    inplace = do_step_gather and args.gather_mode == "inplace" and not host_staged and mode == _lib.MODE_PATH
+    inplace = do_step_gather and (args.gather_mode == "inplace" or direct) and not host_staged and mode == _lib.MODE_PATH
     if inplace:
         for b in range(nbuf):
             bufs[b % n_out_bufs] = dict(bufs[b % n_out_bufs], image_rows=gathers[b].own_rows())
@@ -840,11 +848,13 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
                 (xi, ki, vi) = image_rows(ob)
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
+                if direct and gather_now:
+                    gathers[b].start_in_place()      # peer writes; the all-reduce below is their fence
                 if fused_stats:
                     stats[b].reduce()
                 elif do_stats:
                     stats[b].start(xi, sysd.views(ob).valid_out[-1])
-                if gather_now:
+                if gather_now and not direct:
                     if inplace:
                         gathers[b].start_in_place()
                     else:
@@ -977,6 +987,12 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
                                                    "the [row][global ray] layout%s), side stream, overlaps the next trace"
                                                    % (", IN PLACE: the march wrote the shard's rows into its slot of the "
                                                       "receive buffer" if inplace else ""),
+                                         "gather-direct": "spot moments from the trace kernel; the march writes the "
+                                                          "shard's image plane into its slot of the rank's receive "
+                                                          "buffer, then one device-to-device copy per row and peer into "
+                                                          "the peers' IPC-mapped receive buffers (49 B/ray to each of the "
+                                                          "N-1 peers, one stream per peer), closed by the 7-double "
+                                                          "all-reduce; side stream, overlaps the next trace",
                                          "stats": "spot moments from the trace kernel + one 7-double all-reduce (side stream)",
                                          "final-gather": "spot moments + one 7-double all-reduce (side stream)",
                                          "none": "none"}[exchange]

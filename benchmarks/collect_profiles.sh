@@ -42,6 +42,7 @@ python bench.py --rays 100000000 --steps 3 --warmup 1 --headline-only --no-cpu-b
 for gm in inplace copy; do python bench.py --force-multi --steps 50 --warmup 10 --gather-mode $gm > $O/bench_force_multi_$gm.json 2> $O/bench_force_multi_$gm.err; done
 python bench.py --force-multi --steps 50 --warmup 10 --exchange stats > $O/bench_force_multi_stats.json 2> /dev/null
 python bench.py --force-multi --steps 50 --warmup 10 --trace-stream default > $O/bench_force_multi_inplace_default_stream.json 2> /dev/null
+python bench.py --force-multi --steps 50 --warmup 10 --exchange gather-direct > $O/bench_force_multi_direct.json 2> /dev/null
 python benchmarks/ab_crystal.py > $O/ab_crystal.json 2> $O/ab_crystal.err
 python benchmarks/ab_shapes.py > $O/ab_shapes.json 2> $O/ab_shapes.err
 python benchmarks/dropin_call_time.py > $O/dropin_call_time.json 2> $O/dropin.err

@@ -239,6 +239,79 @@ class ImagePlaneGather(object):
         return torch.arange(self.branches, dtype=torch.int64).repeat_interleave(self.n_total)
 
 
+class DirectImagePlaneGather(ImagePlaneGather):
+    """The image-plane exchange as direct peer writes (one node, one process per GPU): every rank maps the receive
+    buffers of all its peers (IPC handles, exchanged once through the process group) and ``start_in_place()`` copies
+    the rank's own slot -- which the march filled through ``own_rows()`` -- into the same slot of every peer's buffer:
+    one contiguous device-to-device copy per row and peer, the peers served in parallel on one stream each, rank r
+    starting with peer r + 1.  xGMI is point to point (one link per pair of GPUs), so the seven copies of a row use
+    seven different links at once; there is no ring, no intermediate hop and no collective kernel on the compute
+    units -- the copies are the runtime's (copy engines).  SURVEY.md 8(e) "prefer the direct / one-shot algorithm".
+
+    Completion: the copies of THIS rank are done when the streams have run (``start_in_place`` joins them into the
+    current stream); that all PEERS have finished writing into this rank's buffer is known after any collective that
+    every rank issues behind its copies on the same stream -- the fused statistics' all-reduce
+    (``SpotStatistics.reduce()`` after ``start_in_place()``), or ``fence()``.  A buffer must not be filled again
+    before the local consumer is done with it AND a fence has passed in between (two gathers used alternately, each
+    step fenced, satisfy this by construction).
+
+    Isotropic bundles, device buffers, ``align`` = 512 (as for ``own_rows``)."""
+
+    def __init__(self, n_total, device, group=None, align=512):
+        super().__init__(n_total, device, group=group, align=align)
+        if not dist.is_initialized():
+            raise ValueError("DirectImagePlaneGather needs an initialised process group")
+        from torch.multiprocessing.reductions import reduce_tensor
+        mine = (reduce_tensor(self.recv_f), reduce_tensor(self.recv_v))
+        handles = [None] * self.world
+        dist.all_gather_object(handles, mine, group=group)
+        self.peer_f, self.peer_v, self._streams = {}, {}, {}
+        for (r, (hf, hv)) in enumerate(handles):
+            if r == self.rank:
+                continue
+            # tensors in THIS process whose storage is rank r's buffer (on rank r's GPU; written over xGMI)
+            self.peer_f[r] = hf[0](*hf[1])
+            self.peer_v[r] = hv[0](*hv[1])
+            self._streams[r] = torch.cuda.Stream(device=device)
+        self._ready = torch.cuda.Event()
+        self._done = {r: torch.cuda.Event() for r in self.peer_f}
+        self._token = torch.zeros(1, dtype=torch.float32, device=device)
+        dist.barrier(group=group)          # every rank has opened every buffer before anybody writes
+
+    def start_in_place(self):
+        """copies of this rank's slot into every peer's buffer; enqueued behind the work of the current stream,
+        which afterwards waits for them"""
+        self._work = []
+        (lo, n_pad) = (self.rank * self.n_pad, self.n_pad)
+        cur = torch.cuda.current_stream(self.device)
+        self._ready.record(cur)
+        for step in range(1, self.world):
+            r = (self.rank + step) % self.world
+            (st, pf, pv) = (self._streams[r], self.peer_f[r], self.peer_v[r])
+            with torch.cuda.stream(st):
+                st.wait_event(self._ready)
+                for row in range(self.rows):
+                    pf[row, 0, lo:lo + n_pad].copy_(self.recv_f[row, 0, lo:lo + n_pad], non_blocking=True)
+                pv[0, lo:lo + n_pad].copy_(self.recv_v[0, lo:lo + n_pad], non_blocking=True)
+                self._done[r].record(st)
+        for r in self._done:
+            cur.wait_event(self._done[r])
+
+    def start(self, x_img, k_img, valid, e_re=None, e_im=None):
+        """for arrays that are not in the receive buffer yet: one local copy into the own slot, then as above"""
+        self.deposit(self.rank, x_img, k_img, valid, e_re, e_im)
+        self.start_in_place()
+
+    def fence(self):
+        """after this (stream-ordered with RCCL; host-synchronising with gloo) every rank's copies issued before
+        its own fence() have arrived"""
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(self._token, group=self.group)
+        else:
+            torch.cuda.current_stream(self.device).synchronize()
+            dist.barrier(group=self.group)
+
+
 def global_spot_statistics(x_img, valid=None, group=None, moments_fn=None):
     """Centroid and RMS spot radius (about the centroid) of a ray-sharded image plane without
     gathering it: every rank reduces its shard on the device (prt_bundle_moments), then two

@@ -112,3 +112,116 @@ def test_the_rank_program_with_a_single_rccl_rank():
     if torch.cuda.device_count() < 1:
         pytest.skip("needs a GPU")
     _run_ranks(1, 500003, 300)
+
+
+def _direct_rank(rank, world, port, nrays, q):
+    try:
+        q.put((rank, bool(_direct_rank_body(rank, world, port, nrays)), ""))
+    except BaseException as exc:
+        import traceback
+        q.put((rank, False, "%r\n%s" % (exc, traceback.format_exc())))
+
+
+def _direct_rank_body(rank, world, port, nrays):
+    """one rank of the direct (peer-write) exchange; the ranks share GPU 0 when the box has fewer GPUs than ranks --
+    the IPC mapping, the slot arithmetic and the fence are the same, only the link is missing"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                      PRT_ARENA="off")
+    import torch.distributed as dist
+    from pyrate_amd import distributed as pdist, engine, systems
+    ndev = torch.cuda.device_count()
+    d = rank if ndev >= world else 0
+    torch.cuda.set_device(d)
+    dev = torch.device("cuda", d)
+    one_per_gpu = ndev >= world
+    if one_per_gpu:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        align = 512
+        sysd = engine.DeviceSystem(systems.double_gauss_records(), d)
+        (_, n_total) = engine.rect_grid_count(nrays, dev)
+        (lo, hi) = pdist.shard_range(n_total, rank, world, align)
+        (x0, k0, e0d, _) = systems.double_gauss_bundle_device(nrays, dev, field_deg=2.0, lo=lo, hi=hi)
+        (xa, ka, ea, _) = systems.double_gauss_bundle_device(nrays, dev, field_deg=2.0)
+        whole = sysd.trace(xa, ka, ea, packed_flags=True)
+        pitch = engine.recommended_pitch(pdist.shard_stride(n_total, world, align))
+        gathers = [pdist.DirectImagePlaneGather(n_total, dev, align=align) for _ in range(2)]
+        ok = True
+        for step in range(4):           # the two buffers alternately, twice each: re-use behind a fence
+            g = gathers[step % 2]
+            bufs = sysd.alloc_outputs(hi - lo, packed_flags=True, pitch=pitch)
+            bufs["image_rows"] = g.own_rows()
+            sysd.trace_into(x0, k0, bufs, e0d)
+            g.start_in_place()
+            g.fence()
+            (gx, gk, gf) = g.finish()
+            torch.cuda.synchronize()
+
+            def same(a, b):
+                return torch.equal(a.contiguous().view(torch.int64), b.contiguous().view(torch.int64))
+            ok = ok and same(gx, whole.x_hit[-1]) and same(gk, whole.k_out[-1]) and torch.equal(gf, whole.flags[-1])
+            # nobody overwrites a buffer a peer is still comparing: the ranks meet before the next round
+            dist.barrier()
+            if step < 2:                # poison the buffer: the second use must rewrite every slot
+                g.recv_f.fill_(float("nan"))
+                g.recv_v.fill_(255)
+                torch.cuda.synchronize()
+                dist.barrier()
+        # the variant that takes arrays (own slot filled by a local copy)
+        res = sysd.trace(x0, k0, e0d, packed_flags=True)
+        g = gathers[0]
+        g.start(res.x_hit[-1], res.k_out[-1], res.flags[-1])
+        g.fence()
+        (gx, gk, gf) = g.finish()
+        torch.cuda.synchronize()
+        ok = ok and torch.equal(gx, whole.x_hit[-1]) and torch.equal(gf, whole.flags[-1])
+        dist.barrier()
+        del gathers, g
+        return ok
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_direct(world, nrays, timeout):
+    import queue
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_direct_rank, args=(r, world, port, nrays, q), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = []
+    try:
+        for _ in procs:
+            try:
+                results.append(q.get(timeout=timeout))
+            except queue.Empty:
+                break
+    finally:
+        for p in procs:
+            p.join(timeout=20)
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
+    assert len(results) == world, "ranks that did not answer within the timeout: %s" % (
+        sorted(set(range(world)) - {r[0] for r in results}),)
+    assert all(ok for (_, ok, _) in results), [r for r in results if not r[1]]
+
+
+def test_direct_peer_write_exchange_between_two_ranks():
+    """DirectImagePlaneGather: every rank writes its slot of the image plane straight into the receive buffers of
+    its peers (IPC-mapped), the march having deposited it in the rank's own buffer.  One process per GPU over RCCL
+    where the box has the GPUs; two ranks sharing GPU 0 (gloo for the rendezvous) otherwise."""
+    if torch.cuda.device_count() < 1:
+        pytest.skip("needs a GPU")
+    _run_direct(2, 300007, 300)
+
+
+def test_direct_peer_write_exchange_on_every_gpu_of_the_node():
+    world = min(torch.cuda.device_count(), 8)
+    if world < 3:
+        pytest.skip("needs at least 3 GPUs")
+    _run_direct(world, 2000003, 420)
