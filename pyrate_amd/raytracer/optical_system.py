@@ -135,9 +135,7 @@ def seqtrace_fused(ib, records, lengths):
     wave = ib.wave
     kc = ib._k_complex
 
-    # bundle 0: copy of the initial bundle + the first hit point
-    b0 = ib.clone()
-    b0._append_device(res.x_hit[0], res.valid[0] * ib._valid[-1])
+    b0 = _first_bundle(ib, res)
 
     def make_thunk(j):
         def thunk(b):
@@ -167,6 +165,18 @@ def seqtrace_fused(ib, records, lengths):
 
     bundles = [b0] + [RayBundle._lazy(make_thunk(j), wave, dev) for j in range(1, S + 1)]
     return _assemble_path(bundles, lengths, res)
+
+
+def _first_bundle(ib, res):
+    """bundle 0 of a traced path: copy of the initial bundle + the first hit point.  The copy is taken now (the
+    caller may go on using ``ib``); the mask arithmetic of the appended point (two small kernels) waits until
+    somebody looks at the bundle, like the compaction of the later bundles"""
+    c0 = ib.clone()
+
+    def thunk(b):
+        c0._append_device(res.x_hit[0], res.valid[0] * c0._valid[-1])
+        b.__dict__.update(c0.__dict__)
+    return RayBundle._lazy(thunk, ib.wave, ib.device, splitted=ib.splitted)
 
 
 def _assemble_path(bundles, lengths, res):
@@ -229,8 +239,7 @@ def _seqtrace_fused_crystal(ib, records, lengths):
             ids_cache[level] = torch.cat((prev, prev))
         return ids_cache[level]
 
-    b0 = ib.clone()
-    b0._append_device(res.x_hit[0], res.valid[0] * ib._valid[-1])
+    b0 = _first_bundle(ib, res)
 
     def make_thunk(j):
         s = j - 1
