@@ -148,3 +148,28 @@ def test_bench_multi_rank_path_with_a_watchdog_shorter_than_the_run(gpu_device):
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-500:])
     line = json.loads(lines[0])
     assert line["value"] > 0 and "expected" in line["config"] and "error" not in line
+
+
+def test_bench_with_eight_ranks_on_this_gpu_gloo_dry_run(gpu_device):
+    """the N = 8 launch of the contract (`python bench.py --gpus 8` -> torch.distributed.run, one process per rank)
+    with all ranks on this box's GPU and gloo as the backend: rendezvous, equal-stride shards of a bundle that does
+    not divide evenly, per-step exchange (host staged), max-over-ranks timing, ONE JSON line from rank 0.  Plumbing
+    only -- the rate means nothing."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PRT_ARENA_BUDGET_GIB="12", PRT_BENCH_WATCHDOG="240", MASTER_PORT="29641")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo",
+                        "--rays", "1000000", "--steps", "3", "--warmup", "1"], env=env, capture_output=True,
+                       text=True, timeout=600, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.returncode, r.stdout[-800:], r.stderr[-800:])
+    line = json.loads(lines[0])
+    if "error" in line:
+        pytest.skip("the dry run ended in its watchdog: " + line["error"])
+    assert r.returncode == 0 and line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["rays_per_gpu"] % 512 == 0 and 7 * cfg["rays_per_gpu"] < cfg["rays_total"] <= 8 * cfg["rays_per_gpu"]
+    assert abs(cfg["image_plane_spot"]["rays"] - cfg["rays_total"]) < 1e-6 * cfg["rays_total"]   # no vignetting at 0 deg
+    assert len(cfg["expected"]["ms_per_step_with_gather"]) == 2
