@@ -357,6 +357,25 @@ def case_aniso_mirror():
     dump_case("aniso_mirror_biaxial", s, seq, disk_bundle(60, 4.0, -5.0, field_deg=-2.0))
 
 
+def absorbing_eps():
+    """complex (absorbing) epsilon tensors: tilted calcite with an anisotropic loss, a lossy biaxial crystal"""
+    c = systems.CALCITE_TILTED
+    e1 = systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"]) + 1j * np.diag([0.02, 0.05, 0.03])
+    e2 = biaxial_eps() + 1j * np.array([[0.04, 0.01, 0.0], [0.01, 0.02, 0.0], [0.0, 0.0, 0.06]])
+    return (e1, e2)
+
+
+def case_aniso_absorbing():
+    """complex eps (material_anisotropic.py:52-56 accepts it) for sequences that stay inside crystals: complex wave
+    vectors everywhere behind the first interface, doubling at every interface (reflection inside the crystal /
+    refraction into a second absorbing crystal, end plane inside)"""
+    (e1, e2) = absorbing_eps()
+    (s, seq) = zoo.crystal_inside(REFAPI, e1, mirror=True)
+    dump_case("aniso_absorbing_mirror", s, seq, disk_bundle(24, 4.0, -5.0, field_deg=3.0))
+    (s, seq) = zoo.crystal_inside(REFAPI, e1, mirror=False, eps2=e2)
+    dump_case("aniso_absorbing_two_crystals", s, seq, disk_bundle(24, 4.0, -5.0, field_deg=-2.0))
+
+
 def case_zmx():
     """tests/lenssystem.ZMX of the reference (a data file its smoke test holds, smoke_test.py:105)
     through the reference's ZMXParser: 13 even aspheres / planes, two coordinate breaks, BK7 given
@@ -511,6 +530,7 @@ def main():
     case_two_elements()
     case_aniso()
     case_aniso_mirror()
+    case_aniso_absorbing()
     case_evanescent()
     case_zmx()
     case_spd()

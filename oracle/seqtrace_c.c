@@ -292,13 +292,15 @@ int seqtrace_c(const double *tab, const double *cf, int S, int64_t N, const doub
 /* ---- anisotropic interface for one ray ----------------------------------------------------------------
  * n: unit normal, k1: incoming wave vector (real part), both in the material frame; eps (row major, complex).
  * out: the two leaving solutions (k, E complex, material frame) in the reference's order. */
-static void aniso_solutions(const double *n, const double *k1, const zc *eps, int mirror, zc kout[2][3], zc eout[2][3]) {
-    double kpa[3];
-    const double kn = k1[0] * n[0] + k1[1] * n[1] + k1[2] * n[2];
+static void aniso_solutions(const double *n, const zc *k1, const zc *eps, int mirror, zc kout[2][3], zc eout[2][3]) {
+    /* k1 is complex behind an absorbing crystal / an evanescent mode; bilinear products, no conjugate
+     * (material_anisotropic.py:72-79) */
+    zc kpa[3];
+    const zc kn = k1[0] * n[0] + k1[1] * n[1] + k1[2] * n[2];
     for (int q = 0; q < 3; ++q) kpa[q] = k1[q] - kn * n[q];
     int finite = 1;
     for (int q = 0; q < 3; ++q)
-        if (!isfinite(n[q]) || !isfinite(kpa[q])) finite = 0;
+        if (!isfinite(n[q]) || !isfinite(creal(kpa[q])) || !isfinite(cimag(kpa[q]))) finite = 0;
     if (!finite || !g_zggev) {
         for (int b = 0; b < 2; ++b)
             for (int q = 0; q < 3; ++q) kout[b][q] = eout[b][q] = NAN + NAN * I;
@@ -306,7 +308,7 @@ static void aniso_solutions(const double *n, const double *k1, const zc *eps, in
     }
     /* calcXiQEVMatricesNorm, material.py:353-403 */
     zc M[3][3], C[3][3], K[3][3];
-    const double kk = kpa[0] * kpa[0] + kpa[1] * kpa[1] + kpa[2] * kpa[2];
+    const zc kk = kpa[0] * kpa[0] + kpa[1] * kpa[1] + kpa[2] * kpa[2];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) {
             M[i][j] = (i == j ? -1.0 : 0.0) + n[i] * n[j];
@@ -411,11 +413,11 @@ int seqtrace_c_general(const double *tab, const double *cf, int S, int64_t N, co
     int64_t n_final = N;
     for (int s = 0; s < S; ++s)
         if ((int)tab[(int64_t)s * PRT_C_REC + 43] == 1) n_final *= 2;
-    /* state of the current bundle: x, k (real part), d, alive -- ping-pong */
+    /* state of the current bundle: x, Re k, d, Im k, alive -- ping-pong */
     double *st[2];
     uint8_t *al[2];
     for (int b = 0; b < 2; ++b) {
-        st[b] = (double *)malloc(sizeof(double) * 9 * (size_t)(n_final > 0 ? n_final : 1));
+        st[b] = (double *)malloc(sizeof(double) * 12 * (size_t)(n_final > 0 ? n_final : 1));
         al[b] = (uint8_t *)malloc((size_t)(n_final > 0 ? n_final : 1));
         if (!st[b] || !al[b]) return -1;
     }
@@ -426,6 +428,7 @@ int seqtrace_c_general(const double *tab, const double *cf, int S, int64_t N, co
             st[0][(0 + q) * n_final + i] = x0[q * N + i];
             st[0][(3 + q) * n_final + i] = k0[q * N + i];
             st[0][(6 + q) * n_final + i] = d0[q * N + i];
+            st[0][(9 + q) * n_final + i] = 0.0;
         }
         al[0][i] = 1;
     }
@@ -449,11 +452,12 @@ int seqtrace_c_general(const double *tab, const double *cf, int S, int64_t N, co
         const int mirror = r[29] != 0.0;
 #pragma omp parallel for schedule(dynamic, 256)
         for (int64_t i = 0; i < n; ++i) {
-            double x[3], k[3], d[3], xh[3], nrm[3];
+            double x[3], k[3], d[3], xh[3], nrm[3], kim[3];
             for (int q = 0; q < 3; ++q) {
                 x[q] = si[(0 + q) * n_final + i];
                 k[q] = si[(3 + q) * n_final + i];
                 d[q] = si[(6 + q) * n_final + i];
+                kim[q] = si[(9 + q) * n_final + i];
             }
             const int alive = ai[i];
             int ok = alive;
@@ -468,15 +472,18 @@ int seqtrace_c_general(const double *tab, const double *cf, int S, int64_t N, co
                     so[(0 + q) * n_final + i] = xh[q];
                     so[(3 + q) * n_final + i] = k[q];
                     so[(6 + q) * n_final + i] = d[q];
+                    so[(9 + q) * n_final + i] = 0.0;   /* (an isotropic medium: real wave vectors) */
                 }
                 wr[i] = (uint8_t)ok;
                 ao[i] = (uint8_t)ok;
             } else {
                 /* no validity filtering at a crystal interface: every ray still in the bundle gets two
                  * children in a fresh all-valid bundle (material_anisotropic.py:87-100, ray.py:68) */
-                double k1[3];
-                zc ko[2][3], eo[2][3];
-                matT_vec(Bm, k, k1);
+                double k1r[3], k1i[3];
+                zc k1[3], ko[2][3], eo[2][3];
+                matT_vec(Bm, k, k1r);
+                matT_vec(Bm, kim, k1i);
+                for (int q = 0; q < 3; ++q) k1[q] = k1r[q] + k1i[q] * I;
                 aniso_solutions(nrm, k1, eps, mirror, ko, eo);
                 for (int b = 0; b < 2; ++b) {
                     const int64_t o = i + b * n;
@@ -505,6 +512,7 @@ int seqtrace_c_general(const double *tab, const double *cf, int S, int64_t N, co
                         so[(0 + q) * n_final + o] = xh[q];
                         so[(3 + q) * n_final + o] = creal(kg[q]);
                         so[(6 + q) * n_final + o] = sv[q] / sl;
+                        so[(9 + q) * n_final + o] = cimag(kg[q]);
                     }
                     wr[o] = (uint8_t)alive;
                     ao[o] = (uint8_t)alive;

@@ -17,6 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PRT_LIBRARY") or os.path.join(_HERE, "csrc", "libprt.so")
 
 PRT_OK = 0
+ERR_INVALID_ARG = -1   # PRT_ERR_INVALID_ARG
+ERR_UNSUPPORTED = -2   # PRT_ERR_UNSUPPORTED
 ERR_NOMEM = -5         # PRT_ERR_NOMEM
 MODE_PATH = 0
 MODE_IMAGE = 1

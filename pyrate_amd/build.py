@@ -9,7 +9,7 @@ import time
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["prt.hip"]
-HEADERS = ["prt_kernels.h", "prt_device.h", "prt_aniso.h", "prt_placed.h", os.path.join("..", "..", "include", "prt.h")]
+HEADERS = ["prt_kernels.h", "prt_device.h", "prt_aniso.h", "prt_aniso_cplx.h", "prt_placed.h", os.path.join("..", "..", "include", "prt.h")]
 OUT = os.path.join(CSRC, "libprt.so")
 INFO = os.path.join(CSRC, "libprt.build.json")     # written by the build, travels with the .so
 # -ffp-contract=on: FMA contraction decided per source expression (the device default, "fast", lets the

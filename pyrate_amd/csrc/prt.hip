@@ -27,11 +27,14 @@ struct prt_system {
     prt_dev_surface *d_table;  // device records (prt_device.h: the caller's records repacked, 504 B each)
     prt_surface_t *h_table;    // host copy of the caller's records (dispatch decisions)
     void *d_side;              // one device array: the coefficients / term powers / spline data in use
+    int32_t complex_eps;       // some crystal of the table has a complex (absorbing) epsilon tensor
+    double *d_eps_im;          // (n_surfaces, 9): imaginary parts of the epsilon tensors, only if complex_eps
 };
 
 static void free_system(prt_system *sys) {
     if (!sys) return;
     if (sys->d_side) (void)hipFree(sys->d_side);
+    if (sys->d_eps_im) (void)hipFree(sys->d_eps_im);
     if (sys->d_table) (void)hipFree(sys->d_table);
     delete[] sys->h_table;
     delete sys;
@@ -289,13 +292,6 @@ static int32_t check_record(const prt_surface_t *r, int idx) {
         snprintf(msg, sizeof msg, "surface %d: bad aperture/interaction/material enum", idx);
         return fail(PRT_ERR_INVALID_ARG, msg);
     }
-    if (r->mat_type == PRT_MAT_ANISOTROPIC) {
-        for (int q = 0; q < 9; ++q)
-            if (r->eps_im[q] != 0.0) {
-                snprintf(msg, sizeof msg, "surface %d: complex epsilon tensor not supported", idx);
-                return fail(PRT_ERR_UNSUPPORTED, msg);
-            }
-    }
     return PRT_OK;
 }
 
@@ -318,6 +314,8 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     sys->n_surfaces = n_surfaces;
     sys->d_table = nullptr;
     sys->d_side = nullptr;
+    sys->complex_eps = 0;
+    sys->d_eps_im = nullptr;
     sys->h_table = new (std::nothrow) prt_surface_t[n_surfaces];
     prt_dev_surface *recs = new (std::nothrow) prt_dev_surface[n_surfaces];
     if (!sys->h_table || !recs) {
@@ -329,6 +327,30 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     sys->all_isotropic = 1;
     sys->all_conic = 1;
     sys->shape_level = PRT_SHAPES_CONIC;
+    // Complex (absorbing) epsilon tensors (material_anisotropic.py:52-56): supported for sequences that STAY inside
+    // crystals once they have entered an absorbing one.  Behind an isotropic interface the reference takes E from an
+    // SVD whose null space is two-dimensional for a complex k (material_isotropic.py:72-128): the Poynting direction,
+    // and with it every later hit point, is LAPACK's arbitrary pick -- there is nothing to be compatible with.
+    {
+        int first_complex = -1;
+        for (int s = 0; s < n_surfaces && first_complex < 0; ++s)
+            if (table[s].mat_type == PRT_MAT_ANISOTROPIC)
+                for (int q = 0; q < 9; ++q)
+                    if (table[s].eps_im[q] != 0.0) first_complex = s;
+        if (first_complex >= 0) {
+            for (int s = first_complex; s < n_surfaces; ++s)
+                if (table[s].mat_type != PRT_MAT_ANISOTROPIC) {
+                    delete[] recs;
+                    free_system(sys);
+                    char msg[200];
+                    snprintf(msg, sizeof msg, "surface %d: an isotropic medium behind the absorbing crystal of surface %d "
+                                              "(complex epsilon) -- only sequences that stay inside crystals are defined",
+                             s, first_complex);
+                    return fail(PRT_ERR_UNSUPPORTED, msg);
+                }
+            sys->complex_eps = 1;
+        }
+    }
     // side array: per surface its doubles (coefficients -- for an asphere part followed by the products
     // (n+1) a_n --, or the grid-sag spline), then the polynomial part as dense Horner rows (poly_rows)
     // coefficients of the even-asphere part of a surface: its products (n+1) a_n follow the doubles of the
@@ -431,6 +453,14 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     }
     e = hipMemcpy(sys->d_side, h_side, side_bytes + PRT_SIDE_SLACK, hipMemcpyHostToDevice);
     delete[] h_side;
+    if (e == hipSuccess && sys->complex_eps) {
+        std::vector<double> im((size_t)n_surfaces * 9, 0.0);
+        for (int s = 0; s < n_surfaces; ++s)
+            if (table[s].mat_type == PRT_MAT_ANISOTROPIC)
+                for (int q = 0; q < 9; ++q) im[(size_t)s * 9 + q] = table[s].eps_im[q];
+        e = hipMalloc((void **)&sys->d_eps_im, sizeof(double) * im.size());
+        if (e == hipSuccess) e = hipMemcpy(sys->d_eps_im, im.data(), sizeof(double) * im.size(), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&sys->d_table, sizeof(prt_dev_surface) * n_surfaces);
     if (e == hipSuccess)
         e = hipMemcpy(sys->d_table, recs, sizeof(prt_dev_surface) * n_surfaces, hipMemcpyHostToDevice);
@@ -473,14 +503,14 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
                              const double *k0, const double *e_re, const double *e_im,
                              int32_t mode, double *x_hit, double *k_out, double *e_out,
                              double *e_out_im, uint8_t *valid, uint8_t *valid_out, uint8_t *nonconv,
-                             int32_t e_mode_first, hipStream_t st) {
+                             int32_t e_mode_first, hipStream_t st, double *k_out_im = nullptr) {
     const int S = sys->n_surfaces;
     // scratch: directions after anisotropic interfaces, plus ping-pong state in IMAGE mode
     int64_t n_final = n0;
     for (int s = 0; s < S; ++s)
         if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC) n_final *= 2;
     double *dirbuf[2] = {nullptr, nullptr};
-    double *xbuf[2] = {nullptr, nullptr}, *kbuf[2] = {nullptr, nullptr};
+    double *xbuf[2] = {nullptr, nullptr}, *kbuf[2] = {nullptr, nullptr}, *kimbuf[2] = {nullptr, nullptr};
     uint8_t *vbuf[2] = {nullptr, nullptr}, *wbuf[2] = {nullptr, nullptr};
     stream_scratch scratch(st);
     HIP_TRY(scratch.get(&dirbuf[0], sizeof(double) * 3 * n_final));
@@ -489,6 +519,7 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
         for (int b = 0; b < 2; ++b) {
             HIP_TRY(scratch.get(&xbuf[b], sizeof(double) * 3 * n_final));
             HIP_TRY(scratch.get(&kbuf[b], sizeof(double) * 3 * n_final));
+            if (sys->complex_eps) HIP_TRY(scratch.get(&kimbuf[b], sizeof(double) * 3 * n_final));
             HIP_TRY(scratch.get(&vbuf[b], n_final));
             HIP_TRY(scratch.get(&wbuf[b], n_final));
         }
@@ -508,6 +539,7 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
     }
 
     const double *cur_x = x0, *cur_k = k0, *cur_dir = nullptr;
+    const double *cur_k_im = nullptr;  // imaginary part of the wave vectors (tables with a complex epsilon)
     const uint8_t *cur_valid = nullptr;
     int64_t n_src = n0;  // number of distinct points in cur_x
     int64_t n = n0;
@@ -548,7 +580,22 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
                            !nonconv ? (uint8_t *)nullptr
                                     : (mode == PRT_MODE_PATH ? nonconv + off_in : (last ? nonconv : (uint8_t *)nullptr)));
         double *dir_dst = dirbuf[s & 1];
-        if (aniso) {
+        double *kim_dst = nullptr;
+        if (sys->complex_eps && k_out_im)
+            kim_dst = (mode == PRT_MODE_PATH) ? k_out_im + 3 * off_out : (last ? k_out_im : kimbuf[s & 1]);
+        if (aniso && sys->complex_eps) {
+            hipLaunchKernelGGL(k_interact_aniso_cplx, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st,
+                               sys->d_table + s, sys->d_eps_im + (size_t)s * 9, n, xh_dst, cur_k, cur_k_im, cur_valid,
+                               k_dst, kim_dst, dir_dst,
+                               (e_out && mode == PRT_MODE_PATH) ? e_out + 3 * off_out
+                                                               : ((e_out && last) ? e_out : (double *)nullptr),
+                               (e_out_im && mode == PRT_MODE_PATH)
+                                   ? e_out_im + 3 * off_out
+                                   : ((e_out_im && last) ? e_out_im : (double *)nullptr),
+                               vo_dst);
+            cur_dir = dir_dst;
+            cur_k_im = kim_dst;
+        } else if (aniso) {
             hipLaunchKernelGGL(k_interact_aniso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                                st, sys->d_table + s, n, xh_dst, cur_k, cur_valid, k_dst, dir_dst,
                                (e_out && mode == PRT_MODE_PATH) ? e_out + 3 * off_out
@@ -676,13 +723,25 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
         // the per-surface march (one launch pair per surface, intermediate arrays) remains for
         // sequences with more crystal interfaces than the kernel has parking slots, and as the
         // independent implementation PRT_GENERAL_PER_SURFACE=1 selects for cross-checks.
-        if (per_surface || n_aniso > PRT_FUSED_MAX_CRYSTALS) {
+        if (per_surface || n_aniso > PRT_FUSED_MAX_CRYSTALS || sys->complex_eps) {
             if (out_pitch != n0 || in_pitch != n0)
                 return fail(PRT_ERR_UNSUPPORTED, "prt_trace: the per-surface march through crystals (more than 8 crystal "
                                                  "interfaces) takes tight arrays (pitch 0)");
-            if (a.k_out_im)
+            if (a.k_out_im && !sys->complex_eps)
                 return fail(PRT_ERR_UNSUPPORTED, "prt_trace: k_out_im (complex k of evanescent modes) comes from the fused "
                                                  "crystal march (at most 8 crystal interfaces)");
+            if (sys->complex_eps) {
+                // absorbing crystals: every wave vector behind the first interface is complex
+                if (!a.k_out_im)
+                    return fail(PRT_ERR_INVALID_ARG, "prt_trace: a table with a complex epsilon tensor needs k_out_im "
+                                                     "(the wave vectors are complex)");
+                int64_t cnt = 0, nn = n0;
+                for (int s = 0; s < sys->n_surfaces; ++s) {
+                    if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC) nn *= 2;
+                    cnt += nn;
+                }
+                HIP_TRY(hipMemsetAsync(a.k_out_im, 0, sizeof(double) * 3 * (size_t)(mode == PRT_MODE_PATH ? cnt : nn), st));
+            }
             stream_scratch rows(st);
             const double *k0 = a.k0;
             if (uni) {  // the per-surface kernels read arrays: broadcast the uniform vectors once
@@ -705,7 +764,7 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
                 }
             }
             return trace_general(sys, n0, a.x0, k0, e_re, e_im, mode, a.x_hit, a.k_out, a.e_out_re, a.e_out_im,
-                                 a.valid, valid_out, a.nonconv, e_mode, st);
+                                 a.valid, valid_out, a.nonconv, e_mode, st, a.k_out_im);
         }
         const dim3 grid(nblocks(n0, PRT_GENERAL_BLOCK)), block(PRT_GENERAL_BLOCK);
         bool general_eps = false;
@@ -1095,6 +1154,9 @@ int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const 
     const prt_surface_t *rec = sys->h_table + surface;
     if (rec->mat_type == PRT_MAT_ANISOTROPIC) {
         if (!dir_out) return fail(PRT_ERR_INVALID_ARG, "prt_interact: anisotropic needs dir_out");
+        if (sys->complex_eps)
+            return fail(PRT_ERR_UNSUPPORTED, "prt_interact: a table with a complex epsilon tensor is traced as a whole "
+                                             "(prt_trace_ex with k_out_im; the wave vectors are complex)");
         hipLaunchKernelGGL(k_interact_aniso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                            (hipStream_t)stream, sys->d_table + surface, n, x_hit, k,
                            (const uint8_t *)nullptr, k_out, dir_out, e_out_re, e_out_im, valid_out);

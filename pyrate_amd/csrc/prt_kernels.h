@@ -11,6 +11,7 @@
 #pragma once
 #include "prt_device.h"
 #include "prt_aniso.h"
+#include "prt_aniso_cplx.h"
 
 #ifndef PRT_BLOCK
 #define PRT_BLOCK 256
@@ -764,6 +765,50 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_interact_aniso(
             e_im_out[o] = sol[b].ei.x;
             e_im_out[M + o] = sol[b].ei.y;
             e_im_out[2 * M + o] = sol[b].ei.z;
+        }
+        if (valid_out) valid_out[o] = alive;
+    }
+}
+
+// The same interface for tables with a complex (absorbing) epsilon tensor: complex wave vectors in and out
+// (k_im_in may be NULL: the ray comes from a lossless medium), prt_aniso_cplx.h.  eps_im: the imaginary part of
+// this surface's tensor (9 doubles, device memory; not part of the march's record).
+__global__ __launch_bounds__(PRT_BLOCK) void k_interact_aniso_cplx(
+    const prt_dev_surface *__restrict__ sf, const double *__restrict__ eps_im, int64_t N,
+    const double *__restrict__ xh_in, const double *__restrict__ k_in, const double *__restrict__ k_im_in,
+    const uint8_t *__restrict__ alive_in, double *__restrict__ k_out, double *__restrict__ k_im_out,
+    double *__restrict__ dir_out, double *__restrict__ e_re_out, double *__restrict__ e_im_out,
+    uint8_t *__restrict__ valid_out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const vec3 xh = v3(xh_in[i], xh_in[N + i], xh_in[2 * N + i]);
+    const vec3 kr = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
+    const vec3 ki = k_im_in ? v3(k_im_in[i], k_im_in[N + i], k_im_in[2 * N + i]) : v3(0.0, 0.0, 0.0);
+    const vec3 p = to_shape_frame(sf, xh);
+    const uint8_t alive = alive_in ? alive_in[i] : (uint8_t)1;
+    aniso_solution_cplx sol[2];
+    interact_anisotropic_cplx(sf, eps_im, normal_in_material_frame(sf, p), kr, ki, sol);
+    const int64_t M = 2 * N;
+    for (int b = 0; b < 2; ++b) {
+        const int64_t o = i + b * N;
+        k_out[o] = sol[b].k_re.x;
+        k_out[M + o] = sol[b].k_re.y;
+        k_out[2 * M + o] = sol[b].k_re.z;
+        k_im_out[o] = sol[b].k_im.x;
+        k_im_out[M + o] = sol[b].k_im.y;
+        k_im_out[2 * M + o] = sol[b].k_im.z;
+        dir_out[o] = sol[b].d.x;
+        dir_out[M + o] = sol[b].d.y;
+        dir_out[2 * M + o] = sol[b].d.z;
+        if (e_re_out) {
+            e_re_out[o] = sol[b].e_re.x;
+            e_re_out[M + o] = sol[b].e_re.y;
+            e_re_out[2 * M + o] = sol[b].e_re.z;
+        }
+        if (e_im_out) {
+            e_im_out[o] = sol[b].e_im.x;
+            e_im_out[M + o] = sol[b].e_im.y;
+            e_im_out[2 * M + o] = sol[b].e_im.z;
         }
         if (valid_out) valid_out[o] = alive;
     }

@@ -12,6 +12,7 @@ import torch
 
 from . import _lib
 from . import placed
+from . import surface_table
 from .surface_table import pack_table
 
 
@@ -275,6 +276,8 @@ class DeviceSystem(object):
         self.n_surfaces = len(self.records)
         self._table = pack_table(self.records)
         self.all_isotropic = all(r["material"]["type"] == "isotropic" for r in self.records)
+        # absorbing crystals (complex eps): complex wave vectors, per-surface march, TraceResult.k_out_im always there
+        self.complex_eps = surface_table.has_complex_eps(self.records)
         handle = ctypes.c_void_p()
         torch.cuda.init()
         _lib.check(self.lib.prt_system_create(self._table, self.n_surfaces,
@@ -334,7 +337,8 @@ class DeviceSystem(object):
             crystals = sum(r["material"]["type"] == "anisotropic" for r in self.records)
             if pitch is None:
                 pitch = int(self.lib.prt_crystal_pitch(n0))
-            if crystals > FUSED_MAX_CRYSTALS or os.environ.get("PRT_GENERAL_PER_SURFACE") or pitch < n0:
+            if (crystals > FUSED_MAX_CRYSTALS or os.environ.get("PRT_GENERAL_PER_SURFACE") or pitch < n0
+                    or self.complex_eps):
                 pitch = 0
             P = pitch or n0
             (pin, pout) = ([c // n0 * P if n0 else 0 for c in n_in], [c // n0 * P if n0 else 0 for c in n_out])
@@ -406,6 +410,9 @@ class DeviceSystem(object):
             if mode == _lib.MODE_PATH and pitch:      # (the fused march; the per-surface march has no such report)
                 # imaginary parts of the wave vectors: non-zero in the slots of evanescent modes (prt.h k_out_im)
                 bufs["k_im"] = torch.zeros(nk, dtype=torch.float64, device=dev)
+        if self.complex_eps:
+            # absorbing crystals: the wave vectors ARE complex (prt.h: k_out_im is required for such tables)
+            bufs["k_im"] = torch.zeros(nk, dtype=torch.float64, device=dev)
         return bufs
 
     # -- whole sequence ----------------------------------------------------

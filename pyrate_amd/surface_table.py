@@ -252,7 +252,8 @@ def classify_eps(eps_re, eps_im, rtol=1e-12):
     er = np.asarray(eps_re, dtype=float).reshape(3, 3)
     ei = np.asarray(eps_im, dtype=float).reshape(3, 3)
     if np.any(ei != 0.0):
-        raise UnsupportedError("complex epsilon tensor is out of scope")
+        # absorbing crystal: the complex solver (csrc/prt_aniso_cplx.h) has no classes
+        return (ANISO_GENERAL, 0.0, 0.0, [0.0, 0.0, 1.0])
     scale = np.max(np.abs(er))
     if scale == 0.0 or not np.allclose(er, er.T, rtol=0, atol=rtol * scale):
         return (ANISO_GENERAL, 0.0, 0.0, [0.0, 0.0, 1.0])
@@ -416,8 +417,31 @@ _PACKED = {}            # JSON of a record -> bytes of its prt_surface_t (an opt
 _PACKED_MAX = 256       # surface per evaluation; the others are reused)
 
 
+def has_complex_eps(records):
+    """does some crystal of the table have a complex (absorbing) epsilon tensor?"""
+    return any(r["material"]["type"] == "anisotropic" and np.any(np.asarray(r["material"]["eps_im"], dtype=float) != 0.0)
+               for r in records)
+
+
+def check_complex_eps(records):
+    """Complex epsilon tensors (material_anisotropic.py:52-56) are supported for sequences that STAY inside crystals
+    once they have entered an absorbing one: behind an isotropic interface the reference takes E -- and with it the
+    direction of the ray -- from an SVD whose null space is two-dimensional for a complex wave vector
+    (material_isotropic.py:72-128); every later hit point is LAPACK's arbitrary pick and nothing can be compatible
+    with it.  libprt enforces the same (prt_system_create)."""
+    first = None
+    for (s, r) in enumerate(records):
+        m = r["material"]
+        if first is None and m["type"] == "anisotropic" and np.any(np.asarray(m["eps_im"], dtype=float) != 0.0):
+            first = s
+        if first is not None and m["type"] != "anisotropic":
+            raise UnsupportedError("surface %d: an isotropic medium behind the absorbing crystal of surface %d (complex "
+                                   "epsilon tensor) -- only sequences that stay inside crystals are defined" % (s, first))
+
+
 def pack_table(records):
     import json
+    check_complex_eps(records)
     blobs = []
     keep = []
     for rec in records:

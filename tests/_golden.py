@@ -30,6 +30,8 @@ ANISO_CASES = ["aniso_doublet_isoeps", "aniso_doublet_uniaxial", "aniso_doublet_
                "aniso_doublet_uniaxial_clipped", "aniso_doublet_uniaxial_stopped",
                "aniso_mirror_uniaxial", "aniso_mirror_biaxial"]
 ALL_CASES = ISO_CASES + EXPLICIT_CASES + ANISO_CASES
+# complex (absorbing) epsilon tensors, sequences that stay inside crystals: complex wave vectors, compared as such
+ABSORBING_CASES = ["aniso_absorbing_mirror", "aniso_absorbing_two_crystals"]
 
 # The reference's Zernike gradient (surface_shape.py:1073-1084) is not the derivative of its own sag
 # for terms with m != 0 (angular part divided by rho instead of rho**2; pinned by
@@ -206,9 +208,12 @@ def compare_dense_to_reference(case, dense, rtol_x=1e-10, atol_k=1e-10, explicit
                 extra_k = extra_k[sub]
         n_before = n_next
         kr = Bn["k"][0]
-        assert np.max(np.abs(np.imag(kr))) < 1e-9 if np.iscomplexobj(kr) else True
-        kr = np.real(kr)
         kd = d["k_out"][:, new_pos]
+        if np.iscomplexobj(kd):
+            kr = np.asarray(kr, dtype=complex)       # absorbing crystals: the wave vectors ARE complex, compared as such
+        else:
+            assert np.max(np.abs(np.imag(kr))) < 1e-9 if np.iscomplexobj(kr) else True
+            kr = np.real(kr)
         fin = np.all(np.isfinite(kr), axis=0)
         if np.any(fin):
             errk = np.abs(kd[:, fin] - kr[:, fin])
@@ -240,15 +245,19 @@ def surface_curvature(rec, x_glob, h=1e-4):
         return np.sqrt(hxx ** 2 + hxy ** 2 + hyx ** 2 + hyy ** 2)
 
 
-def dense_from_oracle(out):
-    return [dict(x_hit=o["x_hit"], valid=o["valid"], k_out=np.real(o["k_out"]),
+def dense_from_oracle(out, complex_k=False):
+    return [dict(x_hit=o["x_hit"], valid=o["valid"], k_out=(np.asarray(o["k_out"], dtype=complex) if complex_k
+                                                             else np.real(o["k_out"])),
                  valid_out=o["valid_out"]) for o in out]
 
 
-def dense_from_engine(res):
+def dense_from_engine(res, complex_k=False):
     """TraceResult (device tensors) -> list of numpy dicts."""
     dense = []
     for s in range(len(res.x_hit)):
+        k = res.k_out[s].cpu().numpy()
+        if complex_k:
+            k = k + 1j * res.k_out_im[s].cpu().numpy()
         dense.append(dict(x_hit=res.x_hit[s].cpu().numpy(), valid=res.valid[s].cpu().numpy(),
-                          k_out=res.k_out[s].cpu().numpy(), valid_out=res.valid_out[s].cpu().numpy()))
+                          k_out=k, valid_out=res.valid_out[s].cpu().numpy()))
     return dense

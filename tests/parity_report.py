@@ -21,19 +21,23 @@ from pyrate_amd import engine
 def main():
     dev = torch.device("cuda", 0)
     print("%-34s %5s %7s %12s %12s %s" % ("case", "surf", "rays", "max rel dx", "max abs dk", "note"))
-    for name in _golden.ALL_CASES:
+    for name in _golden.ALL_CASES + _golden.ABSORBING_CASES:
         case = _golden.load_case(name)
         sysd = engine.DeviceSystem(case.table, 0)
         e = np.asarray(case.E0)
-        res = sysd.trace(engine.to_device_rays(case.x0, dev), engine.to_device_rays(case.k0, dev),
-                         engine.to_device_rays(e.real, dev),
-                         engine.to_device_rays(e.imag, dev) if np.iscomplexobj(e) else None)
-        dense = _golden.dense_from_engine(res)
+        absorbing = name in _golden.ABSORBING_CASES           # complex eps: complex k, compared as such
+        res = sysd.trace(engine.to_device_rays(case.x0, dev, pitched=not absorbing),
+                         engine.to_device_rays(np.real(case.k0), dev, pitched=not absorbing),
+                         engine.to_device_rays(e.real, dev, pitched=not absorbing),
+                         engine.to_device_rays(e.imag, dev, pitched=not absorbing) if np.iscomplexobj(e) else None)
+        dense = _golden.dense_from_engine(res, complex_k=absorbing)
         explicit = name in _golden.EXPLICIT_CASES
         r = _golden.compare_dense_to_reference(case, dense, rtol_x=1.0, atol_k=1.0,
                                                explicit_tol=explicit_tolerance if explicit else None)
         raw = _golden.compare_dense_to_reference(case, dense, rtol_x=1.0, atol_k=1.0) if explicit else r
         note = ""
+        if absorbing:
+            note = "complex eps: dk over the real and imaginary parts of the wave vectors"
         if explicit:
             note = "raw (reference fsolve xtol=1e-6): dx %.1e dk %.1e" % (raw["max_rel_x"], raw["max_abs_k"])
         print("%-34s %5d %7d %12.2e %12.2e %s" % (name, case.n_surfaces, case.x0.shape[1], r["max_rel_x"],

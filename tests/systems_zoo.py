@@ -125,6 +125,37 @@ def crystal_mirror(api, eps, tilt_deg=10.0):
     return (s, seq)
 
 
+def crystal_inside(api, eps, tilt_deg=10.0, mirror=True, eps2=None):
+    """a sequence that never leaves the crystal: refraction into a slab, its tilted rear face (a mirror inside
+    the crystal, or an interface to a second crystal), and an end plane whose medium is still a crystal.  With a
+    complex (absorbing) eps every wave vector inside is complex and every interface doubles the rays; nothing
+    downstream depends on the arbitrary E basis an isotropic medium would bring in."""
+    t = tilt_deg * math.pi / 180.
+    s = api.OpticalSystem.p()
+    lc0 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="stop", decz=1.0),
+                                     refname=s.rootcoordinatesystem.name)
+    lc1 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="front", decz=10.0), refname=lc0.name)
+    lc2 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="rear", decz=5.0, tiltx=t),
+                                     refname=lc1.name)
+    lc3 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="end", decz=-5.0 if mirror else 5.0, tiltx=-t),
+                                     refname=lc2.name)
+    elem = api.OpticalElement.p(lc0, name="slab")
+    elem.addMaterial("crystal", api.AnisotropicMaterial.p(lc1, eps, name="crystal"))
+    elem.addMaterial("crystal2", api.AnisotropicMaterial.p(lc2, eps if eps2 is None else eps2, name="crystal2"))
+    behind = "crystal" if mirror else "crystal2"
+    elem.addSurface("stop", api.Surface.p(lc0), (None, None))
+    elem.addSurface("front", api.Surface.p(lc1, shape=api.Conic.p(lc1, curv=0.01),
+                                           aperture=api.CircularAperture.p(lc1, maxradius=10.0)),
+                    (None, "crystal"))
+    elem.addSurface("rear", api.Surface.p(lc2, shape=api.Conic.p(lc2, curv=-0.02),
+                                          aperture=api.CircularAperture.p(lc2, maxradius=10.0)),
+                    ("crystal", behind))
+    elem.addSurface("end", api.Surface.p(lc3), (behind, behind))
+    s.addElement("slab", elem)
+    seq = [("slab", [("stop", {}), ("front", {}), ("rear", {"is_mirror": mirror}), ("end", {})])]
+    return (s, seq)
+
+
 def tilted(api):
     """decentred / tilted frames (both tilt orders), a tilted material frame, a rectangular
     aperture in its own rotated frame, an annular circular aperture, a ModelGlass."""

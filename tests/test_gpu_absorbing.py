@@ -1,0 +1,147 @@
+"""``-m gpu``: crystals with a COMPLEX (absorbing) epsilon tensor (reference: material_anisotropic.py:52-56 accepts
+one; SURVEY.md 8 a12 "c128") for sequences that stay inside crystals -- the engine (prt_trace_ex -> per-surface march
+-> k_interact_aniso_cplx, csrc/prt_aniso_cplx.h) against the reference's own bundles and against the NumPy oracle,
+all through the C ABI."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import _golden
+import systems_zoo as zoo
+from oracle import seqtrace_np as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _eps_of(case, s):
+    m = case.table[s]["material"]
+    return np.asarray(m["eps_re"]) + 1j * np.asarray(m["eps_im"])
+
+
+def _rays(case, dev):
+    from pyrate_amd import engine
+    return [engine.to_device_rays(a, dev, pitched=False) for a in (case.x0, np.real(case.k0), case.E0)]
+
+
+@pytest.mark.parametrize("name", _golden.ABSORBING_CASES)
+def test_hip_vs_reference_absorbing_crystals(name, gpu_device):
+    """hit points (1e-10 relative) and complex wave vectors (1e-10 absolute, real and imaginary part) of every
+    surface against the reference's bundles; image mode gives the last surface's record bit for bit; the E fields
+    solve the wave equation of their complex k"""
+    from pyrate_amd import engine, _lib
+    case = _golden.load_case(name)
+    sysd = engine.DeviceSystem(case.table, 0)
+    assert sysd.complex_eps and not sysd.all_isotropic
+    res = sysd.trace(*_rays(case, gpu_device), want_fields=True)
+    assert res.k_out_im is not None
+    out = _golden.compare_dense_to_reference(case, _golden.dense_from_engine(res, complex_k=True),
+                                             rtol_x=1e-10, atol_k=1e-10)
+    assert out["n_compared"] == sum(case.x0.shape[1] * m for m in (1, 1, 2, 4)) and out["max_abs_k"] < 1e-12
+    assert float(res.k_out_im[-1].abs().max()) > 1e-3 and float(res.k_out_im[0].abs().max()) == 0.0
+    img = sysd.trace(*_rays(case, gpu_device), mode=_lib.MODE_IMAGE)
+    for (a, b) in ((img.x_hit[-1], res.x_hit[-1]), (img.k_out[-1], res.k_out[-1]), (img.k_out_im[-1], res.k_out_im[-1])):
+        assert torch.equal(a, b)
+    for s in (1, 2, 3):
+        eps = _eps_of(case, s)
+        k = res.k_out[s].cpu().numpy() + 1j * res.k_out_im[s].cpu().numpy()
+        (er, ei) = res.e_out[s]
+        E = er.cpu().numpy() + 1j * ei.cpu().numpy()
+        Bm = np.asarray(case.table[s]["B_mat"]).reshape(3, 3)
+        (kl, El) = (Bm.T @ k, Bm.T @ E)
+        # W E = eps E - (k.k) E + k (k.E) = 0, bilinear (material.py:385-392); |E|^2 (1 + |xi|^2) = 1
+        resid = eps @ El - np.sum(kl * kl, axis=0) * El + kl * np.sum(kl * El, axis=0)
+        assert np.abs(resid).max() < 1e-12 * np.abs(eps).max()
+        assert np.all(np.sum(np.abs(El) ** 2, axis=0) < 1.0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_hip_vs_oracle_random_absorbing_crystals(seed, gpu_device):
+    """random complex tensors (symmetric and not, weak and strong loss), curved tilted interfaces, steep incidence,
+    refraction and reflection inside: engine == NumPy oracle (LAPACK) on every surface, complex k included"""
+    from pyrate_amd import engine, systems
+    rng = np.random.RandomState(100 + seed)
+
+    def tensor():
+        a = rng.uniform(1.3, 2.4, 3) ** 2
+        q = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        e = q @ np.diag(a) @ q.T + 1j * (q @ np.diag(rng.uniform(0.0, 0.3, 3) * (10.0 ** -rng.randint(0, 4))) @ q.T)
+        if seed % 2:
+            e = e + 0.02 * rng.normal(size=(3, 3)) * (1 + 0.5j)          # not symmetric
+        return e
+    mirror = bool(seed % 3 == 1)
+    recs = systems.simple_system_records([
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "entry", {}),
+        ({"shape": "Conic", "curv": 0.02}, {"decz": 4.0}, {"eps": tensor()}, "front", {}),
+        ({"shape": "Conic", "curv": -0.015}, {"decz": 6.0}, {"eps": tensor()}, "rear", {"is_mirror": mirror}),
+        ({"shape": "Conic"}, {"decz": -5.0 if mirror else 5.0}, {"eps": tensor()}, "end", {})])
+    n = 96
+    ang = rng.uniform(-0.9, 0.9, n)
+    phi = rng.uniform(0, 2 * np.pi, n)
+    x0 = np.vstack((rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), np.full(n, -1.0)))
+    k0 = np.vstack((np.sin(ang) * np.cos(phi), np.sin(ang) * np.sin(phi), np.cos(ang)))
+    e0 = np.cross(k0, np.array([1., 0.3, 0.]), axisa=0, axisb=0).T.copy()
+    with np.errstate(all="ignore"):
+        ref = oracle.trace(recs, x0, k0, e0)
+    sysd = engine.DeviceSystem(recs, 0)
+    res = sysd.trace(*[engine.to_device_rays(a, gpu_device, pitched=False) for a in (x0, k0, e0)])
+    for s in range(4):
+        xe = res.x_hit[s].cpu().numpy()
+        ke = res.k_out[s].cpu().numpy() + 1j * res.k_out_im[s].cpu().numpy()
+        (xr, kr) = (ref[s]["x_hit"], np.asarray(ref[s]["k_out"], dtype=complex))
+        ok = np.all(np.isfinite(xr), axis=0) & np.all(np.abs(xr) < 1e6, axis=0)
+        assert ok.sum() > 0.8 * ok.size
+        assert np.array_equal(np.all(np.isfinite(xe), axis=0) | ~ok, np.ones(ok.size, bool))
+        assert np.abs(xe[:, ok] - xr[:, ok]).max() < 1e-9
+        ok2 = np.hstack((ok, ok)) if ke.shape[1] == 2 * ok.size else ok
+        assert np.abs(ke[:, ok2] - kr[:, ok2]).max() < 1e-9
+
+
+@pytest.mark.parametrize("name,mirror", [("aniso_absorbing_mirror", True), ("aniso_absorbing_two_crystals", False)])
+def test_dropin_seqtrace_through_absorbing_crystals(name, mirror, gpu_device):
+    """OpticalSystem.seqtrace of the mirror classes: the reference's bundle structure with complex k, bundle by
+    bundle; splitup / the plugin-granular loop say what they cannot do"""
+    from pyrate_amd import _lib
+    api = zoo.mirror_api()
+    case = _golden.load_case(name)
+    (s, seq) = zoo.crystal_inside(api, _eps_of(case, 1), mirror=mirror, eps2=None if mirror else _eps_of(case, 2))
+    ib = api.RayBundle(x0=case.x0, k0=case.k0, Efield0=case.E0, wave=case.wave)
+    rp = s.seqtrace(ib, seq)
+    assert len(rp) == 1 and len(rp[0].raybundles) == len(case.raw_bundles)
+    for (i, (rb, ref)) in enumerate(zip(rp[0].raybundles, case.raw_bundles)):
+        assert rb.x.shape == ref["x"].shape and rb.k.shape == ref["k"].shape, i
+        assert np.array_equal(rb.rayID, ref["id"]) and np.array_equal(rb.valid, ref["valid"].astype(bool)), i
+        assert np.abs(rb.x - ref["x"]).max() < 1e-10 * max(1.0, np.abs(ref["x"]).max())
+        assert np.abs(rb.k - ref["k"]).max() < 1e-10
+        if i >= 3:
+            assert np.iscomplexobj(rb.k) and np.abs(np.imag(rb.k)).max() > 1e-3
+    with pytest.raises(_lib.PrtError):
+        s.seqtrace(ib, seq, splitup=True)
+
+
+def test_absorbing_crystal_tables_the_library_refuses(gpu_device):
+    """an isotropic medium behind an absorbing crystal: no parity target (the reference's E there is an arbitrary
+    null vector) -> UnsupportedError on the host, PRT_ERR_UNSUPPORTED from prt_system_create; k_out_im missing ->
+    PRT_ERR_INVALID_ARG; prt_interact on such a table -> PRT_ERR_UNSUPPORTED"""
+    import copy
+    from pyrate_amd import engine, surface_table, _lib
+    case = _golden.load_case("aniso_absorbing_mirror")
+    bad = copy.deepcopy(case.table)
+    bad[-1]["material"] = {"type": "isotropic", "n": 1.0}
+    with pytest.raises(surface_table.UnsupportedError):
+        engine.DeviceSystem(bad, 0)
+    lib = _lib.load()
+    recs = [surface_table.pack_record(r) for r in bad]
+    table = (surface_table.PrtSurface * len(recs))(*recs)
+    h = ctypes.c_void_p()
+    assert lib.prt_system_create(table, len(recs), 0, ctypes.byref(h)) == _lib.ERR_UNSUPPORTED
+    assert b"stay inside crystals" in lib.prt_last_error()
+    sysd = engine.DeviceSystem(case.table, 0)
+    (x0, k0, e0) = _rays(case, gpu_device)
+    bufs = sysd.alloc_outputs(case.x0.shape[1])
+    a = sysd._trace_args(x0, k0, bufs, e0)
+    a.k_out_im = None
+    assert lib.prt_trace_ex(sysd._h, ctypes.byref(a)) == _lib.ERR_INVALID_ARG
+    with pytest.raises(_lib.PrtError):
+        sysd.interact(1, x0, k0)

@@ -141,8 +141,8 @@ def test_classify_eps():
     assert abs(abs(np.dot(axis, [0.0, math.sin(0.3), math.cos(0.3)])) - 1) < 1e-14
     rec = np.diag([2.4, 2.56, 2.8])
     assert st.classify_eps(rec, np.zeros((3, 3)))[0] == st.ANISO_GENERAL
-    with pytest.raises(st.UnsupportedError):
-        st.classify_eps(np.eye(3), 0.1 * np.eye(3))
+    # a complex (absorbing) tensor has no class of its own: the complex solver takes it as it is
+    assert st.classify_eps(np.eye(3), 0.1 * np.eye(3))[0] == st.ANISO_GENERAL
 
 
 def test_c_abi_exports_every_declared_symbol():
@@ -523,3 +523,20 @@ def test_bench_watchdog_prints_one_json_error_line_and_exits_3():
     code_ok = code.replace("threading.Event().wait(30)", "w.done()").replace("not reached", "finished")
     r = subprocess.run([sys.executable, "-c", code_ok], input="0\n", capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "finished"
+
+
+def test_complex_epsilon_tables_stay_inside_crystals():
+    """a complex (absorbing) epsilon tensor is packed like any other (class GENERAL, eps_im filled); a table in which
+    an isotropic medium follows the absorbing crystal is refused with the reason (no parity target there)"""
+    import copy
+    from pyrate_amd import surface_table
+    case = _golden.load_case("aniso_absorbing_two_crystals")
+    assert surface_table.has_complex_eps(case.table)
+    assert not surface_table.has_complex_eps(_golden.load_case("aniso_doublet_biaxial").table)
+    table = surface_table.pack_table(case.table)
+    assert table[1].aniso_class == surface_table.ANISO_GENERAL
+    assert abs(table[1].eps_im[0] - case.table[1]["material"]["eps_im"][0][0]) == 0.0 and table[1].eps_im[0] != 0.0
+    bad = copy.deepcopy(case.table)
+    bad[-1]["material"] = {"type": "isotropic", "n": 1.5}
+    with pytest.raises(surface_table.UnsupportedError, match="stay inside crystals"):
+        surface_table.pack_table(bad)

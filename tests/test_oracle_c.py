@@ -108,3 +108,17 @@ def test_c_oracle_rejects_out_of_scope_tables():
     assert not seqtrace_c.supports(table)
     with pytest.raises(ValueError):
         seqtrace_c.flat_table(table)
+
+
+@pytest.mark.parametrize("name", _golden.ABSORBING_CASES)
+def test_c_oracle_vs_reference_absorbing_crystals(name):
+    """complex epsilon, complex wave vectors in and out of every interface behind the first (zggev on the complex
+    pencil, like the reference)"""
+    if not seqtrace_c.load().seqtrace_c_has_zggev():
+        pytest.skip("this SciPy does not export zggev")
+    case = _golden.load_case(name)
+    assert seqtrace_c.supports(case.table)
+    out = seqtrace_c.trace(case.table, case.x0, case.k0, case.E0)
+    res = _golden.compare_dense_to_reference(case, _golden.dense_from_oracle(out, complex_k=True),
+                                             rtol_x=1e-12, atol_k=1e-12)
+    assert res["n_compared"] > 0
