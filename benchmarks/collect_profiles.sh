@@ -54,3 +54,9 @@ find $O -name "*agent_info.csv" -delete
 find $O -name "*.db" -delete
 rm -f $O/fresh_?.json
 ls -la $O
+# idle time between two marches of the N > 1 step: the march on the default stream vs on a stream of its own
+for ts in default new; do
+  rocprofv3 --kernel-trace --output-format csv -d $O/gap_$ts -o t -- python bench.py --force-multi --steps 100 --warmup 10 --trace-stream $ts > /dev/null 2> /dev/null
+  python benchmarks/step_gaps.py $(find $O/gap_$ts -name "t_kernel_trace.csv" | head -1) $ts > $O/force_multi_gaps_$ts.json 2> /dev/null
+  rm -rf $O/gap_$ts
+done
