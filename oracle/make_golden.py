@@ -374,6 +374,7 @@ def case_aniso_absorbing():
     dump_case("aniso_absorbing_mirror", s, seq, disk_bundle(24, 4.0, -5.0, field_deg=3.0))
     (s, seq) = zoo.crystal_inside(REFAPI, e1, mirror=False, eps2=e2)
     dump_case("aniso_absorbing_two_crystals", s, seq, disk_bundle(24, 4.0, -5.0, field_deg=-2.0))
+    dump_case("aniso_absorbing_two_crystals_split", s, seq, disk_bundle(12, 4.0, -5.0), splitup=True)
 
 
 def case_zmx():

@@ -16,7 +16,7 @@
 import torch
 
 from .. import _lib, engine
-from ..surface_table import flatten_sequence
+from ..surface_table import flatten_sequence, has_complex_eps
 from . import _dispatch
 from .localcoordinates import LocalCoordinates, LocalCoordinatesTreeBase
 from .material.material_isotropic import ConstantIndexGlass
@@ -61,6 +61,11 @@ class OpticalSystem(LocalCoordinatesTreeBase):
             fused_ok = False      # a bundle that already carries invalid rays: per-surface path
         if fused_ok:
             return [self._seqtrace_fused(initialbundle, records, lengths)]
+        if splitup and has_complex_eps(records) and crystals <= MAX_FUSED_CRYSTALS and initialbundle._dir is None \
+                and (len(initialbundle._valid) == 1 or bool(initialbundle._valid[-1].all())):
+            # absorbing crystals: the forked paths are the branches of ONE dense trace (the per-surface plugin calls
+            # have no complex wave vectors in their signature)
+            return _seqtrace_fused_crystal(initialbundle, records, lengths, split=True)
         return self._seqtrace_generic(initialbundle, elementsequence, splitup)
 
     def image_moments(self, initialbundle, elementsequence):
@@ -204,8 +209,13 @@ def _first_segment(ib):
     return dict(k0=k0)
 
 
-def _seqtrace_fused_crystal(ib, records, lengths):
-    """Sequences through anisotropic media without ``splitup``: one engine trace in the
+def _seqtrace_fused_crystal(ib, records, lengths, split=False):
+    """``split=True`` (absorbing crystals with ``splitup``): the list of the 2^A forked paths instead of one path --
+    path p follows solution bit j of p at the j-th crystal interface (the order OpticalElement.seqtrace builds:
+    existing paths take the first solution, the copies with the second one are appended, optical_element.py:360-375),
+    which is branch p mod 2^level of the dense arrays at every level; its bundles hold N rays each.
+
+    Sequences through anisotropic media without ``splitup``: one engine trace in the
     concatenated dense layout (ray count doubles behind every crystal interface, [sol2, sol3]
     stacking), E of the doubled rays from prt_trace_fields.  Bundle j is carved lazily out of
     the dense arrays of surface j-1: the rays the reference still carries there are the dense
@@ -239,28 +249,34 @@ def _seqtrace_fused_crystal(ib, records, lengths):
             ids_cache[level] = torch.cat((prev, prev))
         return ids_cache[level]
 
-    b0 = _first_bundle(ib, res)
-
-    def make_thunk(j):
+    def make_thunk(j, branch=None):
         s = j - 1
         level = sum(crystal[:s + 1])
+        level_in = sum(crystal[:s])
+
+        def cut(t, lvl):
+            # the slots of one branch of a dense array at doubling level lvl (all of it without a branch)
+            if branch is None:
+                return t
+            lo = (branch % (1 << lvl)) * P
+            return t[..., lo:lo + P]
 
         def thunk(b):
-            mask = dense.valid_out[s]
-            xs = dense.x_hit[s]
-            if crystal[s]:
+            mask = cut(dense.valid_out[s], level)
+            xs = cut(dense.x_hit[s], level_in)
+            if crystal[s] and branch is None:
                 xs = torch.cat((xs, xs), dim=1)
-            arrays = [xs, dense.k_out[s]]
+            arrays = [xs, cut(dense.k_out[s], level)]
             with_kim = crystal[s] and dense.k_out_im is not None
             if crystal[s]:
-                arrays += list(dense.e_out[s])
+                arrays += [cut(t, level) for t in dense.e_out[s]]
             if with_kim:
-                arrays.append(dense.k_out_im[s])        # Im(k): evanescent modes (complex k like the reference's)
+                arrays.append(cut(dense.k_out_im[s], level))   # Im(k): evanescent modes / absorbing crystals
             flags = None
             if j < S:
-                arrays.append(dense.x_hit[j])
-                flags = dense.valid[j]
-            out = engine.compact(mask, arrays, dense_ids(level), flags)
+                arrays.append(cut(dense.x_hit[j], level))
+                flags = cut(dense.valid[j], level)
+            out = engine.compact(mask, arrays, dense_ids(level if branch is None else 0), flags)
             arr = out[0]
             (cx, ck) = (arr[0], arr[1])
             e = (arr[2], arr[3]) if crystal[s] else None
@@ -282,9 +298,13 @@ def _seqtrace_fused_crystal(ib, records, lengths):
             b._k_complex = True if s >= first_crystal else ib._k_complex
         return thunk
 
-    bundles = [b0]
-    for j in range(1, S + 1):
-        b = RayBundle._lazy(make_thunk(j), wave, dev, splitted=crystal[j - 1])
-        b._dir_from_k = not crystal[j - 1]
-        bundles.append(b)
-    return _assemble_path(bundles, lengths, res)
+    def path_of(branch):
+        bundles = [_first_bundle(ib, res)]
+        for j in range(1, S + 1):
+            b = RayBundle._lazy(make_thunk(j, branch), wave, dev, splitted=crystal[j - 1] and branch is None)
+            b._dir_from_k = not crystal[j - 1]
+            bundles.append(b)
+        return _assemble_path(bundles, lengths, res)
+    if split:
+        return [path_of(p) for p in range(1 << sum(crystal))]
+    return path_of(None)

@@ -101,7 +101,7 @@ def test_hip_vs_oracle_random_absorbing_crystals(seed, gpu_device):
 @pytest.mark.parametrize("name,mirror", [("aniso_absorbing_mirror", True), ("aniso_absorbing_two_crystals", False)])
 def test_dropin_seqtrace_through_absorbing_crystals(name, mirror, gpu_device):
     """OpticalSystem.seqtrace of the mirror classes: the reference's bundle structure with complex k, bundle by
-    bundle; splitup / the plugin-granular loop say what they cannot do"""
+    bundle; the plugin-granular loop says what it cannot do"""
     from pyrate_amd import _lib
     api = zoo.mirror_api()
     case = _golden.load_case(name)
@@ -116,8 +116,35 @@ def test_dropin_seqtrace_through_absorbing_crystals(name, mirror, gpu_device):
         assert np.abs(rb.k - ref["k"]).max() < 1e-10
         if i >= 3:
             assert np.iscomplexobj(rb.k) and np.abs(np.imag(rb.k)).max() > 1e-3
-    with pytest.raises(_lib.PrtError):
-        s.seqtrace(ib, seq, splitup=True)
+    with pytest.raises(_lib.PrtError):            # the plugin-granular loop: prt_interact has no complex k
+        s._seqtrace_generic(ib, seq, False)
+
+
+def test_dropin_splitup_through_absorbing_crystals_forks_eight_paths(gpu_device):
+    """splitup=True: 2^3 RayPaths in the reference's order (existing paths take the first solution, the copies with
+    the second one are appended, optical_element.py:360-375), N rays per bundle, complex k -- carved out of one
+    dense trace"""
+    import os
+    api = zoo.mirror_api()
+    case = _golden.load_case("aniso_absorbing_two_crystals_split")
+    (s, seq) = zoo.crystal_inside(api, _eps_of(case, 1), mirror=False, eps2=_eps_of(case, 2))
+    ib = api.RayBundle(x0=case.x0, k0=case.k0, Efield0=case.E0, wave=case.wave)
+    rpaths = s.seqtrace(ib, seq, splitup=True)
+    assert len(rpaths) == case.npaths == 8
+    z = np.load(os.path.join(_golden.GOLDEN_DIR, case.name + ".npz"))
+    kinds = set()
+    for (pi, rp) in enumerate(rpaths):
+        pre = "" if pi == 0 else "p%d_" % pi
+        nb = int(z[pre + "nb"])
+        assert len(rp.raybundles) == nb
+        for i in range(nb):
+            (rb, xr, kr) = (rp.raybundles[i], z[pre + "b%d_x" % i], z[pre + "b%d_k" % i])
+            assert rb.x.shape == xr.shape and rb.k.shape == kr.shape, (pi, i)
+            assert np.array_equal(rb.rayID, z[pre + "b%d_id" % i]) and np.array_equal(rb.valid, z[pre + "b%d_valid" % i].astype(bool))
+            assert np.abs(rb.x - xr).max() < 1e-10 * max(1.0, np.abs(xr).max()), (pi, i)
+            assert np.abs(rb.k - kr).max() < 1e-10, (pi, i)
+        kinds.add(tuple(np.round(np.real(rp.raybundles[-1].k[-1][:, 0]), 9)))
+    assert len(kinds) == 8            # eight different final wave vectors: the paths really are the eight branches
 
 
 def test_absorbing_crystal_tables_the_library_refuses(gpu_device):
