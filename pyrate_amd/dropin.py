@@ -9,11 +9,12 @@ device-resident ``RayBundle`` / ``RayPath``.
     rpaths = dropin.seqtrace(s, initialbundle, seq)        # s: pyrateoptics OpticalSystem
     x_img = rpaths[0].raybundles[-1].x[-1]                 # reference shapes, lazily copied
 
-Sequences through ``AnisotropicMaterial`` are traced the same way when ``splitup`` is False (ray
-doubling in the dense path arrays); ``splitup=True`` (one RayPath per branch) needs this package's
-material classes (``pyrate_amd.raytracer``), whose ``refract`` forks on the GPU.
+Sequences through ``AnisotropicMaterial`` are traced the same way (ray doubling in the dense path
+arrays); with ``splitup=True`` the forked paths (one RayPath per branch) are carved out of that one dense
+trace -- path p follows solution bit j of p at the j-th crystal interface, the order
+``OpticalElement.seqtrace`` builds (optical_element.py:360-375).
 """
-from .raytracer.optical_system import MAX_FUSED_CRYSTALS, seqtrace_fused
+from .raytracer.optical_system import MAX_FUSED_CRYSTALS, seqtrace_fused, _seqtrace_fused_crystal
 from .raytracer.ray import RayBundle
 from .surface_table import UnsupportedError, flatten_sequence
 
@@ -37,5 +38,8 @@ def seqtrace(system, initialbundle, elementsequence, splitup=False, device=None)
     if crystals and (splitup or crystals > MAX_FUSED_CRYSTALS or ib._dir is not None):
         if hasattr(system, "_seqtrace_generic"):
             return system._seqtrace_generic(ib, elementsequence, splitup)
-        raise UnsupportedError("splitup through anisotropic media needs pyrate_amd's material classes")
+        if crystals <= MAX_FUSED_CRYSTALS and ib._dir is None:
+            return _seqtrace_fused_crystal(ib, records, lengths, split=True)
+        raise UnsupportedError("more than %d crystal interfaces (or a bundle with explicit directions) needs "
+                               "pyrate_amd's material classes" % MAX_FUSED_CRYSTALS)
     return [seqtrace_fused(ib, records, lengths)]

@@ -387,3 +387,22 @@ def test_raybundle_local_helpers(api):
 def oracle_sag(shape, x, y):
     from oracle import seqtrace_np
     return seqtrace_np.shape_sag(shape, x, y)
+
+
+@pytest.mark.parametrize("name,which", [("aniso_doublet_uniaxial_split", "doublet"),
+                                        ("aniso_mirror_uniaxial_split", "mirror")])
+def test_dropin_splitup_on_foreign_objects_carves_the_paths_out_of_the_dense_trace(api, name, which):
+    """dropin.seqtrace(..., splitup=True) on an object graph that has no methods of this package (here: stand-ins
+    without ``_seqtrace_generic``): the four forked paths come out of ONE dense trace, in the reference's order"""
+    import types
+    from pyrate_amd import dropin
+    case = _golden.load_case(name)
+    if which == "doublet":
+        (s, seq) = aniso_system(api, "uni")
+    else:
+        (s, seq) = zoo.crystal_mirror(api, np.asarray(case.table[1]["material"]["eps_re"]))
+    foreign = types.SimpleNamespace(elements=s.elements, material_background=s.material_background)
+    rpaths = dropin.seqtrace(foreign, bundle_of(api, case), seq, splitup=True)
+    assert len(rpaths) == case.npaths == 4
+    for (rp, ref) in zip(rpaths, _raw_paths(case)):
+        assert_paths_match(rp, ref)
