@@ -121,14 +121,18 @@ typedef struct prt_surface {
     double B_mat[9];     /* lc of the medium after the interaction                   */
     double n_after;      /* isotropic: refractive index of that medium               */
     double eps_re[9], eps_im[9]; /* anisotropic: its (constant) epsilon tensor       */
-    /* eps_im != 0 (an absorbing crystal; the reference accepts a complex tensor, material_anisotropic.py:52-56):
-     * every wave vector behind that interface is complex.  Supported for tables that STAY inside crystals from
-     * there on (every later medium anisotropic); an isotropic medium behind an absorbing crystal is refused by
-     * prt_system_create (PRT_ERR_UNSUPPORTED): the reference takes E there from an SVD whose null space is
-     * two-dimensional for a complex k (material_isotropic.py:72-128), so the direction of the ray, and every later
-     * hit point, is LAPACK's arbitrary pick.  Such tables are traced by prt_trace_ex with k_out_im (required: the
-     * imaginary parts of the wave vectors, both modes), tight arrays (pitch 0), one launch pair per surface
-     * (csrc/prt_aniso_cplx.h); prt_interact refuses them. */
+    /* Absorbing media.  eps_im != 0: an absorbing crystal (the reference accepts a complex tensor,
+     * material_anisotropic.py:52-56).  ISOTROPIC records: eps_im[0] = Im(n), an absorbing isotropic medium (complex
+     * refractive index, material_isotropic.py:59-63, 137-161); the other entries of eps_re / eps_im are unused
+     * there.  Every wave vector behind the first absorbing medium is complex.  Supported wherever the reference's
+     * result is defined: inside crystals (every later medium anisotropic), and an isotropic medium -- absorbing or
+     * not -- behind the LAST surface of the table (its complex k = k_inplane + xi n is unique).  An isotropic medium
+     * behind an absorbing one BEFORE the last surface is refused by prt_system_create (PRT_ERR_UNSUPPORTED): the
+     * reference takes E there from an SVD whose null space is two-dimensional for a complex k
+     * (material_isotropic.py:72-128), so the direction of the ray, and every later hit point, is LAPACK's arbitrary
+     * pick.  Such tables are traced by prt_trace_ex with k_out_im (required: the imaginary parts of the wave
+     * vectors), tight arrays (pitch 0), the concatenated layout, one launch pair per surface
+     * (csrc/prt_aniso_cplx.h); prt_interact refuses their crystal surfaces. */
     /* host-side classification of a real symmetric eps (an optimisation AND what keeps the
      * touching-sheet directions well conditioned, see csrc/prt_aniso.h):
      * ISOTROPIC: eps = aniso_eo I;  UNIAXIAL: eps = aniso_eo I + (aniso_ee-aniso_eo) c c^T,
@@ -264,7 +268,7 @@ typedef struct prt_trace_args {
      * everything behind it invalid).  With k_out_im != NULL (layout of k_out) such a slot receives the complex k
      * instead -- real part in k_out, imaginary part here, 0 for propagating modes -- from a post-pass over the
      * crystal surfaces (of a conjugate pair the root with Im(xi) > 0; the reference's pick is its sort's).
-     * Tables with a complex epsilon tensor (prt_surface_t.eps_im): REQUIRED, in both modes -- the wave vectors are
+     * Tables with absorbing media (prt_surface_t.eps_im): REQUIRED, in both modes -- the wave vectors are
      * complex, k_out + i k_out_im (PRT_MODE_IMAGE: (3, n_out[S-1]) like k_out). */
     double *k_out_im;
     /* image-plane redirect (all-isotropic tables, PRT_MODE_PATH, 16-B aligned rows): when x_img != NULL the record

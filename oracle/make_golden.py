@@ -375,6 +375,12 @@ def case_aniso_absorbing():
     (s, seq) = zoo.crystal_inside(REFAPI, e1, mirror=False, eps2=e2)
     dump_case("aniso_absorbing_two_crystals", s, seq, disk_bundle(24, 4.0, -5.0, field_deg=-2.0))
     dump_case("aniso_absorbing_two_crystals_split", s, seq, disk_bundle(12, 4.0, -5.0), splitup=True)
+    # ... and where the sequence ENDS in an isotropic medium (the complex k behind the last surface is unique): the
+    # folded beam of the absorbing slab leaving into air; a singlet in front of an absorbing detector (complex n)
+    (s, seq) = zoo.crystal_mirror(REFAPI, e1)
+    dump_case("aniso_absorbing_exit", s, seq, disk_bundle(24, 4.0, -5.0, field_deg=3.0))
+    (s, seq) = zoo.absorbing_detector(REFAPI)
+    dump_case("absorbing_detector", s, seq, disk_bundle(40, 4.0, -5.0, field_deg=12.0))
 
 
 def case_zmx():

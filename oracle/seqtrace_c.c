@@ -422,6 +422,13 @@ int seqtrace_c_general(const double *tab, const double *cf, int S, int64_t N, co
         if (!st[b] || !al[b]) return -1;
     }
     int64_t n = N;
+    /* a table with absorbing media (complex eps / complex index): complex wave vectors are carried into the isotropic
+     * refraction behind the last surface; in lossless tables an evanescent leftover enters with its real part, like
+     * in the NumPy oracle */
+    int absorbing = 0;
+    for (int s = 0; s < S; ++s)
+        for (int q = 53; q < 62; ++q)
+            if (tab[(int64_t)s * PRT_C_REC + q] != 0.0) absorbing = 1;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; ++i) {
         for (int q = 0; q < 3; ++q) {
@@ -464,7 +471,44 @@ int seqtrace_c_general(const double *tab, const double *cf, int S, int64_t N, co
             intersect_part(r, cf, x, d, &ok, xh, nrm);
             for (int q = 0; q < 3; ++q) xr[q * n + i] = xh[q];
             vr[i] = (uint8_t)ok;
-            if (!aniso) {
+            const int cplx_iso = !aniso && absorbing && (r[53] != 0.0 || kim[0] != 0.0 || kim[1] != 0.0 || kim[2] != 0.0);
+            if (cplx_iso) {
+                /* IsotropicMaterial.refract / reflect with a complex incoming k and / or a complex index
+                 * (material_isotropic.py:137-236): the LAST surface of a table with absorbing media */
+                double k1r[3], k1i[3];
+                zc k1[3], kin[3], k2[3];
+                matT_vec(Bm, k, k1r);
+                matT_vec(Bm, kim, k1i);
+                zc kn = 0, kk = 0;
+                for (int q = 0; q < 3; ++q) {
+                    k1[q] = k1r[q] + k1i[q] * I;
+                    kn += k1[q] * nrm[q];
+                }
+                for (int q = 0; q < 3; ++q) {
+                    kin[q] = k1[q] - kn * nrm[q];
+                    kk += kin[q] * kin[q];
+                }
+                const zc nn = r[30] + r[53] * I;
+                const zc sq = nn * nn - kk;
+                /* NumPy's order of complex numbers: by real part, then imaginary part */
+                if (!(creal(sq) > 0 || (creal(sq) == 0 && cimag(sq) > 0)) || !isfinite(nrm[0]) || !isfinite(nrm[1]) ||
+                    !isfinite(nrm[2]))
+                    ok = 0;
+                const zc xi = csqrt(sq);
+                const double sgn = mirror ? -1.0 : 1.0;
+                for (int q = 0; q < 3; ++q) k2[q] = sgn * kin[q] + xi * nrm[q];
+                for (int q = 0; q < 3; ++q) {
+                    const zc kg = Bm[3 * q] * k2[0] + Bm[3 * q + 1] * k2[1] + Bm[3 * q + 2] * k2[2];
+                    kr[q * n + i] = creal(kg);
+                    if (ki) ki[q * n + i] = cimag(kg);
+                    so[(0 + q) * n_final + i] = xh[q];
+                    so[(3 + q) * n_final + i] = creal(kg);
+                    so[(6 + q) * n_final + i] = d[q];
+                    so[(9 + q) * n_final + i] = cimag(kg);
+                }
+                wr[i] = (uint8_t)ok;
+                ao[i] = (uint8_t)ok;
+            } else if (!aniso) {
                 isotropic_part(r, nrm, k, d, &ok);
                 for (int q = 0; q < 3; ++q) {
                     kr[q * n + i] = k[q];

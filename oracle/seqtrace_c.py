@@ -130,6 +130,7 @@ def flat_table(records):
         mat = rec["material"]
         if mat["type"] == "isotropic":
             tab[s, 30] = mat["n"]
+            tab[s, 53] = mat.get("n_im", 0.0)          # absorbing isotropic medium (behind the last surface)
         elif mat["type"] == "anisotropic":
             tab[s, 43] = 1
             tab[s, 44:53] = np.asarray(mat["eps_re"], dtype=float).reshape(9)
@@ -158,7 +159,9 @@ class Workspace(object):
 
     def __init__(self, records, n):
         S = len(records)
-        self.general = any(r["material"]["type"] == "anisotropic" for r in records)
+        # (general path: crystals, or any absorbing medium -- complex wave vectors)
+        self.general = any(r["material"]["type"] == "anisotropic" or r["material"].get("n_im", 0.0) != 0.0
+                           for r in records)
         if not self.general:
             self.x_hit = np.zeros((S, 3, n))
             self.k_out = np.zeros((S, 3, n))
@@ -227,7 +230,8 @@ def trace(records, x0, k0, E0=None, nthreads=0):
                 ids = np.hstack((ids, ids))
                 e = ws.e_re[3 * oo:3 * (oo + no)].reshape(3, no) + 1j * ws.e_im[3 * oo:3 * (oo + no)].reshape(3, no)
             out.append(dict(x_hit=ws.x_hit[3 * oi:3 * (oi + ni)].reshape(3, ni).copy(),
-                            valid=ws.valid[oi:oi + ni].astype(bool), k_out=k if aniso else np.real(k),
+                            valid=ws.valid[oi:oi + ni].astype(bool),
+                            k_out=k if (aniso or np.any(np.imag(k) != 0.0)) else np.real(k),
                             valid_out=ws.valid_out[oo:oo + no].astype(bool), ray_id=ids, E_out=e))
             oi += ni
             oo += no

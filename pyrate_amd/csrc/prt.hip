@@ -327,27 +327,42 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     sys->all_isotropic = 1;
     sys->all_conic = 1;
     sys->shape_level = PRT_SHAPES_CONIC;
-    // Complex (absorbing) epsilon tensors (material_anisotropic.py:52-56): supported for sequences that STAY inside
-    // crystals once they have entered an absorbing one.  Behind an isotropic interface the reference takes E from an
-    // SVD whose null space is two-dimensional for a complex k (material_isotropic.py:72-128): the Poynting direction,
-    // and with it every later hit point, is LAPACK's arbitrary pick -- there is nothing to be compatible with.
+    // Absorbing media -- complex epsilon tensors (material_anisotropic.py:52-56), complex refractive indices (Im n in
+    // eps_im[0] of an isotropic record) -- are supported wherever the reference's result is defined: inside crystals,
+    // and for an isotropic medium behind the LAST surface (its complex k = k_inplane + xi n is unique).  Behind an
+    // EARLIER isotropic interface the reference takes E from an SVD whose null space is two-dimensional for a complex
+    // k (material_isotropic.py:72-128): the Poynting direction, and with it every later hit point, is LAPACK's
+    // arbitrary pick -- there is nothing to be compatible with.
     {
+        auto complex_medium = [](const prt_surface_t &r) {
+            if (r.mat_type == PRT_MAT_ANISOTROPIC) {
+                for (int q = 0; q < 9; ++q)
+                    if (r.eps_im[q] != 0.0) return true;
+                return false;
+            }
+            return r.eps_im[0] != 0.0;
+        };
         int first_complex = -1;
         for (int s = 0; s < n_surfaces && first_complex < 0; ++s)
-            if (table[s].mat_type == PRT_MAT_ANISOTROPIC)
-                for (int q = 0; q < 9; ++q)
-                    if (table[s].eps_im[q] != 0.0) first_complex = s;
+            if (complex_medium(table[s])) first_complex = s;
         if (first_complex >= 0) {
-            for (int s = first_complex; s < n_surfaces; ++s)
-                if (table[s].mat_type != PRT_MAT_ANISOTROPIC) {
+            for (int s = first_complex; s < n_surfaces; ++s) {
+                const bool iso = table[s].mat_type != PRT_MAT_ANISOTROPIC;
+                const bool bad_place = iso && s != n_surfaces - 1;
+                const bool bad_mirror = iso && table[s].eps_im[0] != 0.0 && table[s].interaction == PRT_MIRROR;
+                if (bad_place || bad_mirror) {
                     delete[] recs;
                     free_system(sys);
-                    char msg[200];
-                    snprintf(msg, sizeof msg, "surface %d: an isotropic medium behind the absorbing crystal of surface %d "
-                                              "(complex epsilon) -- only sequences that stay inside crystals are defined",
-                             s, first_complex);
+                    char msg[256];
+                    if (bad_mirror)
+                        snprintf(msg, sizeof msg, "surface %d: a mirror inside an absorbing isotropic medium", s);
+                    else
+                        snprintf(msg, sizeof msg, "surface %d: an isotropic medium behind the absorbing medium of surface "
+                                                  "%d before the last surface of the sequence -- complex wave vectors are "
+                                                  "defined inside crystals and behind the last surface only", s, first_complex);
                     return fail(PRT_ERR_UNSUPPORTED, msg);
                 }
+            }
             sys->complex_eps = 1;
         }
     }
@@ -404,7 +419,7 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     for (int s = 0; s < n_surfaces; ++s) {
         const prt_surface_t &r = table[s];
         prt_dev_surface &d = recs[s];
-        if (r.mat_type != PRT_MAT_ISOTROPIC) sys->all_isotropic = 0;
+        if (r.mat_type != PRT_MAT_ISOTROPIC || sys->complex_eps) sys->all_isotropic = 0;
         if (r.shape_type != PRT_SHAPE_CONIC) sys->all_conic = 0;
         if (r.shape_type == PRT_SHAPE_ASPHERE && sys->shape_level < PRT_SHAPES_ASPHERE) sys->shape_level = PRT_SHAPES_ASPHERE;
         if ((r.shape_type == PRT_SHAPE_XYPOLY || r.shape_type == PRT_SHAPE_BICONIC) && sys->shape_level < PRT_SHAPES_POLY)
@@ -456,8 +471,8 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     if (e == hipSuccess && sys->complex_eps) {
         std::vector<double> im((size_t)n_surfaces * 9, 0.0);
         for (int s = 0; s < n_surfaces; ++s)
-            if (table[s].mat_type == PRT_MAT_ANISOTROPIC)
-                for (int q = 0; q < 9; ++q) im[(size_t)s * 9 + q] = table[s].eps_im[q];
+            for (int q = 0; q < 9; ++q)   // (isotropic records: Im n in slot 0)
+                im[(size_t)s * 9 + q] = (table[s].mat_type == PRT_MAT_ANISOTROPIC || q == 0) ? table[s].eps_im[q] : 0.0;
         e = hipMalloc((void **)&sys->d_eps_im, sizeof(double) * im.size());
         if (e == hipSuccess) e = hipMemcpy(sys->d_eps_im, im.data(), sizeof(double) * im.size(), hipMemcpyHostToDevice);
     }
@@ -605,6 +620,13 @@ static int32_t trace_general(const prt_system_t *sys, int64_t n0, const double *
                                    : ((e_out_im && last) ? e_out_im : (double *)nullptr),
                                vo_dst);
             cur_dir = dir_dst;
+        } else if (sys->complex_eps && last && (cur_k_im || rec->eps_im[0] != 0.0)) {
+            // the last surface of a table with absorbing media: complex k in and / or a complex index behind it
+            hipLaunchKernelGGL(k_interact_iso_cplx, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st,
+                               sys->d_table + s, rec->eps_im[0], n, xh_dst, cur_k, cur_k_im, v_dst, k_dst, kim_dst,
+                               vo_dst);
+            cur_dir = nullptr;
+            cur_k_im = kim_dst;
         } else {
             hipLaunchKernelGGL(k_interact_iso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0, st,
                                sys->d_table + s, n, xh_dst, cur_k, v_dst, k_dst,

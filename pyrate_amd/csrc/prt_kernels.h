@@ -814,6 +814,52 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_interact_aniso_cplx(
     }
 }
 
+// IsotropicMaterial.refract / reflect (material_isotropic.py:137-236) with a complex incoming wave vector and / or
+// a complex refractive index n_re + i n_im behind the surface -- the LAST surface of a table with absorbing media:
+//   kin = k1 - (k1.n) n,  square = n^2 - kin.kin,  valid = square > 0 (NumPy's order of complex numbers: by real part,
+//   then imaginary part),  xi = sqrt(square) (principal branch),  k2 = +-kin + xi n.
+__global__ __launch_bounds__(PRT_BLOCK) void k_interact_iso_cplx(
+    const prt_dev_surface *__restrict__ sf, double n_im, int64_t N, const double *__restrict__ xh_in,
+    const double *__restrict__ k_in, const double *__restrict__ k_im_in, const uint8_t *__restrict__ valid_in,
+    double *__restrict__ k_out, double *__restrict__ k_im_out, uint8_t *__restrict__ valid_out) {
+    const int64_t i = (int64_t)blockIdx.x * PRT_BLOCK + threadIdx.x;
+    if (i >= N) return;
+    const vec3 xh = v3(xh_in[i], xh_in[N + i], xh_in[2 * N + i]);
+    const vec3 kr = v3(k_in[i], k_in[N + i], k_in[2 * N + i]);
+    const vec3 ki = k_im_in ? v3(k_im_in[i], k_im_in[N + i], k_im_in[2 * N + i]) : v3(0.0, 0.0, 0.0);
+    bool valid = valid_in ? (valid_in[i] != 0) : true;
+    const vec3 n = normal_in_material_frame(sf, to_shape_frame(sf, xh));
+    const cvec3 k1 = cv3(matT_vec(sf->B_mat, kr), matT_vec(sf->B_mat, ki));
+    const cx kn = cv_dot(k1, n);
+    const cvec3 kin = cvec3{k1.x - n.x * kn, k1.y - n.y * kn, k1.z - n.z * kn};
+    const cx nn = cx{sf->n_after, n_im};
+    const cx sq = nn * nn - cv_dot(kin, kin);
+    const bool ok = sq.re > 0.0 || (sq.re == 0.0 && sq.im > 0.0);
+    // principal square root
+    const double r = sqrt(sq.re * sq.re + sq.im * sq.im);
+    cx xi;
+    if (sq.re >= 0.0) {
+        xi.re = sqrt(0.5 * (r + sq.re));
+        xi.im = xi.re > 0.0 ? sq.im / (2.0 * xi.re) : 0.0;
+    } else {
+        xi.im = copysign(sqrt(0.5 * (r - sq.re)), sq.im);
+        xi.re = sq.im / (2.0 * xi.im);
+    }
+    valid = valid && ok && isfinite(n.x) && isfinite(n.y) && isfinite(n.z);
+    const double sgn = sf->interaction == PRT_MIRROR ? -1.0 : 1.0;
+    const cvec3 k2 = cvec3{sgn * kin.x + n.x * xi, sgn * kin.y + n.y * xi, sgn * kin.z + n.z * xi};
+    const vec3 o_re = mat_vec(sf->B_mat, cv_re(k2)), o_im = mat_vec(sf->B_mat, cv_im(k2));
+    k_out[i] = o_re.x;
+    k_out[N + i] = o_re.y;
+    k_out[2 * N + i] = o_re.z;
+    if (k_im_out) {
+        k_im_out[i] = o_im.x;
+        k_im_out[N + i] = o_im.y;
+        k_im_out[2 * N + i] = o_im.z;
+    }
+    if (valid_out) valid_out[i] = valid ? 1 : 0;
+}
+
 __global__ __launch_bounds__(PRT_BLOCK) void k_shape_eval(const prt_dev_surface *__restrict__ sf,
                                                           int64_t N, const double *__restrict__ x,
                                                           const double *__restrict__ y,

@@ -275,9 +275,10 @@ class DeviceSystem(object):
         self.records = list(records)
         self.n_surfaces = len(self.records)
         self._table = pack_table(self.records)
-        self.all_isotropic = all(r["material"]["type"] == "isotropic" for r in self.records)
-        # absorbing crystals (complex eps): complex wave vectors, per-surface march, TraceResult.k_out_im always there
+        # absorbing media (complex eps / complex index): complex wave vectors, per-surface march, concatenated layout,
+        # TraceResult.k_out_im always there
         self.complex_eps = surface_table.has_complex_eps(self.records)
+        self.all_isotropic = all(r["material"]["type"] == "isotropic" for r in self.records) and not self.complex_eps
         handle = ctypes.c_void_p()
         torch.cuda.init()
         _lib.check(self.lib.prt_system_create(self._table, self.n_surfaces,

@@ -124,7 +124,7 @@ def seqtrace_fused(ib, records, lengths):
     the reference's bundle structure (lazy, device-resident).  Needs only the surface-table
     records, so it serves any object graph ``flatten_sequence`` understands (this package's
     classes or real pyrateoptics objects, see pyrate_amd/dropin.py)."""
-    if any(r["material"]["type"] == "anisotropic" for r in records):
+    if any(r["material"]["type"] == "anisotropic" for r in records) or has_complex_eps(records):
         return _seqtrace_fused_crystal(ib, records, lengths)
     dev = ib.device
     sysd = _dispatch.system_for(records, dev)
@@ -231,7 +231,10 @@ def _seqtrace_fused_crystal(ib, records, lengths, split=False):
     n = x0.shape[1]
     wave = ib.wave
     crystal = [r["material"]["type"] == "anisotropic" for r in records]
-    first_crystal = crystal.index(True)
+    # first surface behind which the wave vectors are complex numbers in the reference (a crystal interface; the
+    # absorbing isotropic medium behind the last surface)
+    first_crystal = crystal.index(True) if any(crystal) else S - 1
+    absorbing = sysd.complex_eps
     # The dense arrays have a ray pitch P >= n (rows of every level on 128-B lines, engine.alloc_outputs): a branch
     # is P slots of which the first n are rays and the rest carry mask 0 -- so the compaction by ``valid_out`` that
     # carves a bundle out of them drops the padding by itself, and nothing has to be gathered beforehand.
@@ -267,7 +270,7 @@ def _seqtrace_fused_crystal(ib, records, lengths, split=False):
             if crystal[s] and branch is None:
                 xs = torch.cat((xs, xs), dim=1)
             arrays = [xs, cut(dense.k_out[s], level)]
-            with_kim = crystal[s] and dense.k_out_im is not None
+            with_kim = dense.k_out_im is not None and (crystal[s] or (absorbing and s == S - 1))
             if crystal[s]:
                 arrays += [cut(t, level) for t in dense.e_out[s]]
             if with_kim:
@@ -280,7 +283,7 @@ def _seqtrace_fused_crystal(ib, records, lengths, split=False):
             arr = out[0]
             (cx, ck) = (arr[0], arr[1])
             e = (arr[2], arr[3]) if crystal[s] else None
-            b._k_im = [arr[4]] if with_kim else None
+            b._k_im = [arr[4 if crystal[s] else 2]] if with_kim else None
             m = cx.shape[1]
             b._x = [cx]
             b._k = [ck]

@@ -7,9 +7,18 @@ variable / pickup) is host bookkeeping outside the hot path (SURVEY.md section 2
 import uuid
 
 
+def _scalar(value):
+    """float, or complex when the value has an imaginary part (a complex refractive index: the reference's
+    FixedState holds whatever it is given)"""
+    if isinstance(value, complex) or getattr(value, "dtype", None) is not None and getattr(value.dtype, "kind", "") == "c":
+        value = complex(value)
+        return value if value.imag != 0.0 else float(value.real)
+    return float(value)
+
+
 class FloatVariable(object):
     def __init__(self, value, name=""):
-        self._value = float(value)
+        self._value = _scalar(value)
         self.name = name
 
     def evaluate(self):
@@ -19,7 +28,7 @@ class FloatVariable(object):
         return self._value
 
     def set_value(self, value):
-        self._value = float(value)
+        self._value = _scalar(value)
 
     def __repr__(self):
         return "FloatVariable(%r, name=%r)" % (self._value, self.name)

@@ -185,7 +185,8 @@ def describe_material(material, wave):
             raise UnsupportedError("position dependent index (GRIN) is out of scope")
         n = complex(n.reshape(-1)[0])
         if n.imag != 0.0:
-            raise UnsupportedError("complex refractive index is out of scope")
+            # an absorbing isotropic medium: defined as the medium behind the LAST surface only (check_complex_media)
+            return {"type": "isotropic", "n": float(n.real), "n_im": float(n.imag)}
         return {"type": "isotropic", "n": float(n.real)}
     raise UnsupportedError("material %r has neither epstensor nor get_optical_index"
                            % (type(material).__name__,))
@@ -399,6 +400,7 @@ def pack_record(rec, out=None):
     r.mat_type = MAT_CODES[mat["type"]]
     if mat["type"] == "isotropic":
         r.n_after = mat["n"]
+        r.eps_im[0] = float(mat.get("n_im", 0.0))      # Im(n) of an absorbing isotropic medium (prt.h)
     else:
         er = np.asarray(mat["eps_re"], dtype=float).reshape(3, 3)
         ei = np.asarray(mat["eps_im"], dtype=float).reshape(3, 3)
@@ -417,26 +419,47 @@ _PACKED = {}            # JSON of a record -> bytes of its prt_surface_t (an opt
 _PACKED_MAX = 256       # surface per evaluation; the others are reused)
 
 
+def _complex_medium(rec):
+    m = rec["material"]
+    if m["type"] == "anisotropic":
+        return bool(np.any(np.asarray(m["eps_im"], dtype=float) != 0.0))
+    return float(m.get("n_im", 0.0)) != 0.0
+
+
 def has_complex_eps(records):
-    """does some crystal of the table have a complex (absorbing) epsilon tensor?"""
-    return any(r["material"]["type"] == "anisotropic" and np.any(np.asarray(r["material"]["eps_im"], dtype=float) != 0.0)
-               for r in records)
+    """does some medium of the table absorb -- a crystal with a complex epsilon tensor, or an isotropic medium with
+    a complex refractive index?  (Complex wave vectors behind it: per-surface march, ``k_out_im``.)"""
+    return any(_complex_medium(r) for r in records)
+
+
+has_complex_media = has_complex_eps
 
 
 def check_complex_eps(records):
-    """Complex epsilon tensors (material_anisotropic.py:52-56) are supported for sequences that STAY inside crystals
-    once they have entered an absorbing one: behind an isotropic interface the reference takes E -- and with it the
-    direction of the ray -- from an SVD whose null space is two-dimensional for a complex wave vector
-    (material_isotropic.py:72-128); every later hit point is LAPACK's arbitrary pick and nothing can be compatible
-    with it.  libprt enforces the same (prt_system_create)."""
+    """Absorbing media -- complex epsilon tensors (material_anisotropic.py:52-56), complex refractive indices
+    (material_isotropic.py:59-63, 137-161) -- are supported wherever the reference's result is defined: inside
+    crystals (the modes of the complex pencil, their order, the real Poynting direction), and for an isotropic medium
+    behind the LAST surface of the sequence (its complex k = k_inplane + xi n is unique).  Behind any EARLIER
+    isotropic interface the reference takes E -- and with it the direction of the ray -- from an SVD whose null space
+    is two-dimensional for a complex wave vector (material_isotropic.py:72-128); every later hit point is LAPACK's
+    arbitrary pick and nothing can be compatible with it.  libprt enforces the same
+    (prt_system_create)."""
     first = None
+    last = len(records) - 1
     for (s, r) in enumerate(records):
-        m = r["material"]
-        if first is None and m["type"] == "anisotropic" and np.any(np.asarray(m["eps_im"], dtype=float) != 0.0):
+        if first is None and _complex_medium(r):
             first = s
-        if first is not None and m["type"] != "anisotropic":
-            raise UnsupportedError("surface %d: an isotropic medium behind the absorbing crystal of surface %d (complex "
-                                   "epsilon tensor) -- only sequences that stay inside crystals are defined" % (s, first))
+        if first is not None and r["material"]["type"] != "anisotropic" and s != last:
+            what = "an absorbing isotropic medium" if s == first else \
+                "an isotropic medium behind the absorbing medium of surface %d" % first
+            raise UnsupportedError("surface %d: %s before the last surface of the sequence -- complex wave vectors are "
+                                   "defined inside crystals and behind the last surface only" % (s, what))
+        if r["material"]["type"] == "isotropic" and float(r["material"].get("n_im", 0.0)) != 0.0 \
+                and r["interaction"] == "mirror":
+            raise UnsupportedError("surface %d: a mirror inside an absorbing isotropic medium" % s)
+
+
+check_complex_media = check_complex_eps
 
 
 def pack_table(records):

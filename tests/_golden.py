@@ -31,7 +31,9 @@ ANISO_CASES = ["aniso_doublet_isoeps", "aniso_doublet_uniaxial", "aniso_doublet_
                "aniso_mirror_uniaxial", "aniso_mirror_biaxial"]
 ALL_CASES = ISO_CASES + EXPLICIT_CASES + ANISO_CASES
 # complex (absorbing) epsilon tensors, sequences that stay inside crystals: complex wave vectors, compared as such
-ABSORBING_CASES = ["aniso_absorbing_mirror", "aniso_absorbing_two_crystals"]
+ABSORBING_CASES = ["aniso_absorbing_mirror", "aniso_absorbing_two_crystals",
+                   # ... and sequences that END in an isotropic medium (complex k behind the last surface only):
+                   "aniso_absorbing_exit", "absorbing_detector"]
 
 # The reference's Zernike gradient (surface_shape.py:1073-1084) is not the derivative of its own sag
 # for terms with m != 0 (angular part divided by rho instead of rho**2; pinned by

@@ -156,6 +156,29 @@ def crystal_inside(api, eps, tilt_deg=10.0, mirror=True, eps2=None):
     return (s, seq)
 
 
+def absorbing_detector(api, n_abs=3.9 + 0.02j):
+    """a singlet in front of an ABSORBING isotropic medium (complex refractive index, e.g. a silicon detector) behind
+    the last surface: every hit point is real, the last bundle's wave vector is complex
+    (material_isotropic.py:137-161 with a complex index)"""
+    s = api.OpticalSystem.p()
+    lc0 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="stop", decz=1.0),
+                                     refname=s.rootcoordinatesystem.name)
+    lc1 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="front", decz=5.0), refname=lc0.name)
+    lc2 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="back", decz=4.0), refname=lc1.name)
+    lc3 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="detector", decz=20.0, tiltx=0.1), refname=lc2.name)
+    elem = api.OpticalElement.p(lc0, name="lens")
+    elem.addMaterial("glass", api.ConstantIndexGlass.p(lc1, 1.5168))
+    elem.addMaterial("absorber", api.ConstantIndexGlass.p(lc3, n_abs))
+    elem.addSurface("stop", api.Surface.p(lc0), (None, None))
+    elem.addSurface("front", api.Surface.p(lc1, shape=api.Conic.p(lc1, curv=0.02),
+                                           aperture=api.CircularAperture.p(lc1, maxradius=10.0)), (None, "glass"))
+    elem.addSurface("back", api.Surface.p(lc2, shape=api.Conic.p(lc2, curv=-0.03)), ("glass", None))
+    elem.addSurface("detector", api.Surface.p(lc3, shape=api.Conic.p(lc3, curv=-0.01)), (None, "absorber"))
+    s.addElement("lens", elem)
+    seq = [("lens", [("stop", {}), ("front", {}), ("back", {}), ("detector", {})])]
+    return (s, seq)
+
+
 def tilted(api):
     """decentred / tilted frames (both tilt orders), a tilted material frame, a rectangular
     aperture in its own rotated frame, an annular circular aperture, a ModelGlass."""

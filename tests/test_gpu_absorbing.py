@@ -38,12 +38,15 @@ def test_hip_vs_reference_absorbing_crystals(name, gpu_device):
     assert res.k_out_im is not None
     out = _golden.compare_dense_to_reference(case, _golden.dense_from_engine(res, complex_k=True),
                                              rtol_x=1e-10, atol_k=1e-10)
-    assert out["n_compared"] == sum(case.x0.shape[1] * m for m in (1, 1, 2, 4)) and out["max_abs_k"] < 1e-12
+    assert out["n_compared"] >= 4 * case.x0.shape[1] and out["max_abs_k"] < 1e-12
     assert float(res.k_out_im[-1].abs().max()) > 1e-3 and float(res.k_out_im[0].abs().max()) == 0.0
     img = sysd.trace(*_rays(case, gpu_device), mode=_lib.MODE_IMAGE)
-    for (a, b) in ((img.x_hit[-1], res.x_hit[-1]), (img.k_out[-1], res.k_out[-1]), (img.k_out_im[-1], res.k_out_im[-1])):
+    for (a, b) in ((img.x_hit[-1], res.x_hit[-1]), (img.k_out[-1], res.k_out[-1]), (img.k_out_im[-1], res.k_out_im[-1]),
+                   (img.valid_out[-1], res.valid_out[-1])):
         assert torch.equal(a, b)
     for s in (1, 2, 3):
+        if case.table[s]["material"]["type"] != "anisotropic":
+            continue
         eps = _eps_of(case, s)
         k = res.k_out[s].cpu().numpy() + 1j * res.k_out_im[s].cpu().numpy()
         (er, ei) = res.e_out[s]
@@ -98,14 +101,20 @@ def test_hip_vs_oracle_random_absorbing_crystals(seed, gpu_device):
         assert np.abs(ke[:, ok2] - kr[:, ok2]).max() < 1e-9
 
 
-@pytest.mark.parametrize("name,mirror", [("aniso_absorbing_mirror", True), ("aniso_absorbing_two_crystals", False)])
+@pytest.mark.parametrize("name,mirror", [("aniso_absorbing_mirror", True), ("aniso_absorbing_two_crystals", False),
+                                         ("aniso_absorbing_exit", None), ("absorbing_detector", None)])
 def test_dropin_seqtrace_through_absorbing_crystals(name, mirror, gpu_device):
     """OpticalSystem.seqtrace of the mirror classes: the reference's bundle structure with complex k, bundle by
     bundle; the plugin-granular loop says what it cannot do"""
     from pyrate_amd import _lib
     api = zoo.mirror_api()
     case = _golden.load_case(name)
-    (s, seq) = zoo.crystal_inside(api, _eps_of(case, 1), mirror=mirror, eps2=None if mirror else _eps_of(case, 2))
+    if name == "aniso_absorbing_exit":
+        (s, seq) = zoo.crystal_mirror(api, _eps_of(case, 1))
+    elif name == "absorbing_detector":
+        (s, seq) = zoo.absorbing_detector(api)
+    else:
+        (s, seq) = zoo.crystal_inside(api, _eps_of(case, 1), mirror=mirror, eps2=None if mirror else _eps_of(case, 2))
     ib = api.RayBundle(x0=case.x0, k0=case.k0, Efield0=case.E0, wave=case.wave)
     rp = s.seqtrace(ib, seq)
     assert len(rp) == 1 and len(rp[0].raybundles) == len(case.raw_bundles)
@@ -114,10 +123,11 @@ def test_dropin_seqtrace_through_absorbing_crystals(name, mirror, gpu_device):
         assert np.array_equal(rb.rayID, ref["id"]) and np.array_equal(rb.valid, ref["valid"].astype(bool)), i
         assert np.abs(rb.x - ref["x"]).max() < 1e-10 * max(1.0, np.abs(ref["x"]).max())
         assert np.abs(rb.k - ref["k"]).max() < 1e-10
-        if i >= 3:
+        if i >= (5 if name == "absorbing_detector" else 3):
             assert np.iscomplexobj(rb.k) and np.abs(np.imag(rb.k)).max() > 1e-3
-    with pytest.raises(_lib.PrtError):            # the plugin-granular loop: prt_interact has no complex k
-        s._seqtrace_generic(ib, seq, False)
+    if name != "absorbing_detector":
+        with pytest.raises(_lib.PrtError):        # the plugin-granular loop: prt_interact has no complex k
+            s._seqtrace_generic(ib, seq, False)
 
 
 def test_dropin_splitup_through_absorbing_crystals_forks_eight_paths(gpu_device):
@@ -148,14 +158,15 @@ def test_dropin_splitup_through_absorbing_crystals_forks_eight_paths(gpu_device)
 
 
 def test_absorbing_crystal_tables_the_library_refuses(gpu_device):
-    """an isotropic medium behind an absorbing crystal: no parity target (the reference's E there is an arbitrary
-    null vector) -> UnsupportedError on the host, PRT_ERR_UNSUPPORTED from prt_system_create; k_out_im missing ->
+    """an isotropic medium behind an absorbing crystal BEFORE the last surface: no parity target (the reference's E
+    there is an arbitrary null vector) -> UnsupportedError on the host, PRT_ERR_UNSUPPORTED from prt_system_create;
+    k_out_im missing ->
     PRT_ERR_INVALID_ARG; prt_interact on such a table -> PRT_ERR_UNSUPPORTED"""
     import copy
     from pyrate_amd import engine, surface_table, _lib
     case = _golden.load_case("aniso_absorbing_mirror")
     bad = copy.deepcopy(case.table)
-    bad[-1]["material"] = {"type": "isotropic", "n": 1.0}
+    bad[2]["material"] = {"type": "isotropic", "n": 1.0}
     with pytest.raises(surface_table.UnsupportedError):
         engine.DeviceSystem(bad, 0)
     lib = _lib.load()
@@ -163,7 +174,7 @@ def test_absorbing_crystal_tables_the_library_refuses(gpu_device):
     table = (surface_table.PrtSurface * len(recs))(*recs)
     h = ctypes.c_void_p()
     assert lib.prt_system_create(table, len(recs), 0, ctypes.byref(h)) == _lib.ERR_UNSUPPORTED
-    assert b"stay inside crystals" in lib.prt_last_error()
+    assert b"behind the last surface only" in lib.prt_last_error()
     sysd = engine.DeviceSystem(case.table, 0)
     (x0, k0, e0) = _rays(case, gpu_device)
     bufs = sysd.alloc_outputs(case.x0.shape[1])

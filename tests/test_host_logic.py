@@ -526,8 +526,9 @@ def test_bench_watchdog_prints_one_json_error_line_and_exits_3():
 
 
 def test_complex_epsilon_tables_stay_inside_crystals():
-    """a complex (absorbing) epsilon tensor is packed like any other (class GENERAL, eps_im filled); a table in which
-    an isotropic medium follows the absorbing crystal is refused with the reason (no parity target there)"""
+    """a complex (absorbing) epsilon tensor is packed like any other (class GENERAL, eps_im filled), a complex index
+    goes into eps_im[0]; a table in which an isotropic medium follows an absorbing one BEFORE the last surface is
+    refused with the reason (no parity target there)"""
     import copy
     from pyrate_amd import surface_table
     case = _golden.load_case("aniso_absorbing_two_crystals")
@@ -536,7 +537,19 @@ def test_complex_epsilon_tables_stay_inside_crystals():
     table = surface_table.pack_table(case.table)
     assert table[1].aniso_class == surface_table.ANISO_GENERAL
     assert abs(table[1].eps_im[0] - case.table[1]["material"]["eps_im"][0][0]) == 0.0 and table[1].eps_im[0] != 0.0
+    # an isotropic medium behind the LAST surface is fine (its complex k is unique); before it, it is not
+    ok = copy.deepcopy(case.table)
+    ok[-1]["material"] = {"type": "isotropic", "n": 1.5}
+    surface_table.pack_table(ok)
+    ok[-1]["material"] = {"type": "isotropic", "n": 3.9, "n_im": 0.02}
+    assert surface_table.pack_table(ok)[len(ok) - 1].eps_im[0] == 0.02
     bad = copy.deepcopy(case.table)
-    bad[-1]["material"] = {"type": "isotropic", "n": 1.5}
-    with pytest.raises(surface_table.UnsupportedError, match="stay inside crystals"):
+    bad[2]["material"] = {"type": "isotropic", "n": 1.5}
+    with pytest.raises(surface_table.UnsupportedError, match="behind the last surface only"):
+        surface_table.pack_table(bad)
+    det = _golden.load_case("absorbing_detector").table
+    assert surface_table.has_complex_eps(det) and det[-1]["material"]["n_im"] == 0.02
+    bad = copy.deepcopy(det)
+    (bad[1], bad[-1]) = (bad[-1], bad[1])                       # the absorbing glass in the middle
+    with pytest.raises(surface_table.UnsupportedError, match="absorbing isotropic medium"):
         surface_table.pack_table(bad)
