@@ -21,8 +21,9 @@
 //   for the touching sheets), scaled like LAPACK's unit-norm 6-vector [xi E; E]:
 //   |E|^2 (1+|xi|^2) = 1 -- S.n is computed with that scaling and decides the
 //   order of the two transmitted solutions (material.py:144-151).
-// Solutions with complex xi (evanescent) come out as NaN (the reference carries
-// complex k there; out of scope, flagged invalid downstream by checkfinite).
+// Solutions with complex xi (evanescent) come out of THIS code as NaN and are not traced further; the complex k
+// the reference carries there is filled in by a post-pass (prt_kernels.h: k_evanescent_fill, prt_trace_args_t.k_out_im).
+// Complex (absorbing) eps: prt_aniso_cplx.h.
 #pragma once
 #include "prt_device.h"
 
