@@ -127,7 +127,10 @@ class RayBundle(object):
             return
         (kr, ki, kcomplex) = _to_dev(k0, dev)
         if ki is not None:
-            raise NotImplementedError("complex wave vectors (absorbing media) are out of scope")
+            # (complex wave vectors come OUT of a trace through absorbing media or evanescent modes; a bundle that
+            #  starts with one would start inside an absorbing medium, which the engine's first segment does not do)
+            raise NotImplementedError("an initial bundle with complex wave vectors (a start inside an absorbing "
+                                      "medium) is not supported")
         if kr.shape != xr.shape:
             raise ValueError("x0 and k0 must both be (3, N)")
         self._k_complex = kcomplex           # round-trip the caller's dtype
