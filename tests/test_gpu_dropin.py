@@ -345,7 +345,7 @@ def test_raybundle_api_contract(api):
     with pytest.raises(ValueError):
         api.RayBundle(x0, k0[:, :3], None)
     with pytest.raises(NotImplementedError):
-        api.RayBundle(x0, k0 + 0.1j, None)                       # absorbing media: out of scope
+        api.RayBundle(x0, k0 + 0.1j, None)                       # a start inside an absorbing medium
 
 
 def test_custom_ray_ids_survive_compaction(api):

@@ -287,7 +287,7 @@ def test_error_codes_and_unsupported_tables(gpu_device):
     from pyrate_amd.surface_table import UnsupportedError
     recs = systems.aniso_doublet_records(np.eye(3) * 2.25 + 0.1j * np.eye(3), np.eye(3) * 2.5)
     with pytest.raises(UnsupportedError):
-        engine.DeviceSystem(recs, 0)                       # complex epsilon: out of scope
+        engine.DeviceSystem(recs, 0)     # isotropic media behind an absorbing crystal before the last surface
     sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
     x = torch.zeros((3, 8), dtype=torch.float64, device=gpu_device)
     with pytest.raises(ValueError):
