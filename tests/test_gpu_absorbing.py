@@ -183,3 +183,52 @@ def test_absorbing_crystal_tables_the_library_refuses(gpu_device):
     assert lib.prt_trace_ex(sysd._h, ctypes.byref(a)) == _lib.ERR_INVALID_ARG
     with pytest.raises(_lib.PrtError):
         sysd.interact(1, x0, k0)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_hip_vs_oracle_random_sequences_that_end_in_an_isotropic_medium(seed, gpu_device):
+    """the last surface of a table with absorbing media: exit from an absorbing crystal into air at steep incidence
+    (rays dropped by the complex validity rule), lenses in front of absorbing detectors -- dielectric-like and
+    metal-like indices (Re n^2 < 0: NumPy's order of complex numbers drops every ray) -- masks equal, complex k of
+    the survivors equal to the LAPACK / NumPy oracle's"""
+    from pyrate_amd import engine, systems
+    rng = np.random.RandomState(500 + seed)
+    n = 128
+    ang = rng.uniform(-1.2, 1.2, n)
+    phi = rng.uniform(0, 2 * np.pi, n)
+    x0 = np.vstack((rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), np.full(n, -1.0)))
+    k0 = np.vstack((np.sin(ang) * np.cos(phi), np.sin(ang) * np.sin(phi), np.cos(ang)))
+    e0 = np.cross(k0, np.array([1., 0.3, 0.]), axisa=0, axisb=0).T.copy()
+    if seed % 2 == 0:
+        a = rng.uniform(1.3, 2.4, 3) ** 2
+        q = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        eps = q @ np.diag(a) @ q.T + 1j * (q @ np.diag(rng.uniform(0.0, 0.3, 3) * (10.0 ** -rng.randint(0, 4))) @ q.T)
+        recs = systems.simple_system_records([
+            ({"shape": "Conic"}, {"decz": 0.0}, None, "entry", {}),
+            ({"shape": "Conic", "curv": 0.02}, {"decz": 4.0}, {"eps": eps}, "front", {}),
+            ({"shape": "Conic", "curv": -0.05}, {"decz": 6.0}, {"eps": eps}, "rear", {"is_mirror": bool(seed % 4)}),
+            ({"shape": "Conic", "curv": 0.03}, {"decz": -5.0 if seed % 4 else 5.0}, None, "exit", {})])
+    else:
+        n_abs = complex(rng.uniform(0.2, 4.0), rng.uniform(0.0, 3.0) * (10.0 ** -rng.randint(0, 3)))
+        recs = systems.simple_system_records([
+            ({"shape": "Conic"}, {"decz": 0.0}, None, "entry", {}),
+            ({"shape": "Conic", "curv": 0.02}, {"decz": 4.0}, 1.5168, "front", {}),
+            ({"shape": "Conic", "curv": -0.03}, {"decz": 4.0}, None, "back", {}),
+            ({"shape": "Conic", "curv": -0.01}, {"decz": 10.0}, 1.0, "detector", {})])
+        recs[-1]["material"] = {"type": "isotropic", "n": n_abs.real, "n_im": n_abs.imag}
+    with np.errstate(all="ignore"):
+        ref = oracle.trace(recs, x0, k0, e0)
+    sysd = engine.DeviceSystem(recs, 0)
+    assert sysd.complex_eps
+    res = sysd.trace(*[engine.to_device_rays(a, gpu_device, pitched=False) for a in (x0, k0, e0)])
+    (vo, vr) = (res.valid_out[-1].cpu().numpy().astype(bool), ref[-1]["valid_out"])
+    xr = ref[-1]["x_hit"]
+    sane = np.all(np.isfinite(xr), axis=0) & np.all(np.abs(xr) < 1e6, axis=0)
+    assert np.array_equal(vo[sane], vr[sane])
+    keep = sane & vr
+    ke = res.k_out[-1].cpu().numpy() + 1j * res.k_out_im[-1].cpu().numpy()
+    if keep.any():
+        assert np.abs(ke[:, keep] - np.asarray(ref[-1]["k_out"], dtype=complex)[:, keep]).max() < 1e-9
+        assert np.abs(res.x_hit[-1].cpu().numpy()[:, keep] - xr[:, keep]).max() < 1e-9
+    if seed % 2 == 1 and (n_abs * n_abs).real < 0:
+        assert not vr.any()              # metal-like: the reference's validity rule drops every ray
