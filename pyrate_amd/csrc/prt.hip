@@ -29,12 +29,19 @@ struct prt_system {
     void *d_side;              // one device array: the coefficients / term powers / spline data in use
     int32_t complex_eps;       // some crystal of the table has a complex (absorbing) epsilon tensor
     double *d_eps_im;          // (n_surfaces, 9): imaginary parts of the epsilon tensors, only if complex_eps
+    // tables with crystals (at most PRT_FUSED_MAX_CRYSTALS interfaces): what k_trace_general executes
+    prt_hot_surface *d_hot;    // (n_surfaces) hot blocks of the records (prt_device.h)
+    walk_step *d_walk;         // the walk program (prt_kernels.h), n_walk entries + a sentinel
+    int32_t n_walk;
+    int32_t n_aniso;           // crystal interfaces of the table
 };
 
 static void free_system(prt_system *sys) {
     if (!sys) return;
     if (sys->d_side) (void)hipFree(sys->d_side);
     if (sys->d_eps_im) (void)hipFree(sys->d_eps_im);
+    if (sys->d_hot) (void)hipFree(sys->d_hot);
+    if (sys->d_walk) (void)hipFree(sys->d_walk);
     if (sys->d_table) (void)hipFree(sys->d_table);
     delete[] sys->h_table;
     delete sys;
@@ -185,6 +192,81 @@ static void launch_trace_iso(const iso_launch &a, bool vi, bool vo) {
     }
 }
 
+// ---- what the fused crystal march executes: hot blocks and the walk program (prt_kernels.h) ---------------
+static prt_hot_surface hot_block(const prt_surface_t &r) {
+    prt_hot_surface h;
+    memset(&h, 0, sizeof h);
+    const uint32_t bits = (uint32_t)(r.shape_type & 15) | (uint32_t)(r.ap_type & 3) << 4 | (uint32_t)(r.interaction & 1) << 6 |
+                          (uint32_t)(r.mat_type & 1) << 7 | (uint32_t)(r.aniso_class & 3) << 8 | (uint32_t)(r.frame_flags & 7) << 10;
+    const uint64_t w = (uint64_t)bits | (uint64_t)(uint32_t)r.newton_maxit << 32;
+    memcpy(&h.v[0], &w, 8);
+    h.v[1] = r.curv;
+    h.v[2] = r.cc;
+    for (int q = 0; q < 3; ++q) h.v[3 + q] = r.g_shape[q];
+    h.v[6] = r.ap_p0;
+    h.v[7] = r.ap_p1;
+    h.v[8] = r.n_after;
+    h.v[9] = r.aniso_eo;
+    h.v[10] = r.aniso_ee;
+    for (int q = 0; q < 3; ++q) h.v[11 + q] = r.aniso_axis[q];
+    return h;
+}
+
+// The depth-first walk of k_trace_general, written down: at a crystal interface child 1 is parked at the level of
+// that interface and child 0 goes on; at the end of the table the deepest parked child is taken up behind its
+// interface.  One entry per (surface, branch) = per record of the concatenated layout; a sentinel at the end.
+static std::vector<walk_step> build_walk_program(const prt_surface_t *table, int S) {
+    std::vector<int32_t> cum_in(S + 1, 0), cum_out(S + 1, 0), level(S + 1, 0);
+    for (int s = 0, a = 0; s < S; ++s) {
+        level[s] = a;
+        cum_in[s + 1] = cum_in[s] + (1 << a);
+        if (table[s].mat_type == PRT_MAT_ANISOTROPIC) ++a;
+        cum_out[s + 1] = cum_out[s] + (1 << a);
+        level[s + 1] = a;
+    }
+    std::vector<walk_step> prog;
+    struct parked { int level, s_next; int64_t L; };   // (s_next - 1: the surface that parked it)
+    std::vector<parked> stack;   // at most one entry per level, deepest last
+    int s = 0;
+    int64_t L = 0;
+    int resume = 0, s_park = 0;
+    for (;;) {
+        for (; s < S; ++s) {
+            const int a = level[s];
+            walk_step w;
+            const int32_t lp = (int32_t)(L & (((int64_t)1 << a) - 1));
+            w.s_pair = s;
+            w.bits = a | resume << 8 | lp << 16 | ((s == S - 1) ? 1 : 0) << 24;
+            w.cum_in = cum_in[s];
+            w.s_park = resume ? s_park : 0;
+            resume = 0;
+            prog.push_back(w);
+            if (table[s].mat_type == PRT_MAT_ANISOTROPIC) stack.push_back({a, s + 1, L | ((int64_t)1 << a)});
+        }
+        // the deepest parked child whose walk is not empty (a crystal behind the LAST surface parks children that
+        // have nowhere to go)
+        bool found = false;
+        while (!stack.empty()) {
+            const parked c = stack.back();
+            stack.pop_back();
+            if (c.s_next < S) {
+                s = c.s_next;
+                L = c.L;
+                resume = c.level + 1;
+                s_park = c.s_next - 1;
+                found = true;
+                break;
+            }
+        }
+        if (!found) break;
+    }
+    for (size_t t = 0; t + 1 < prog.size(); ++t) prog[t].s_pair |= (prog[t + 1].s_pair & 0xffff) << 16;
+    walk_step end;
+    memset(&end, 0, sizeof end);
+    prog.push_back(end);  // sentinel: what the last step prefetches
+    return prog;
+}
+
 extern "C" {
 
 int32_t prt_abi_version(void) { return PRT_ABI_VERSION; }
@@ -316,6 +398,10 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     sys->d_side = nullptr;
     sys->complex_eps = 0;
     sys->d_eps_im = nullptr;
+    sys->d_hot = nullptr;
+    sys->d_walk = nullptr;
+    sys->n_walk = 0;
+    sys->n_aniso = 0;
     sys->h_table = new (std::nothrow) prt_surface_t[n_surfaces];
     prt_dev_surface *recs = new (std::nothrow) prt_dev_surface[n_surfaces];
     if (!sys->h_table || !recs) {
@@ -480,6 +566,24 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     if (e == hipSuccess)
         e = hipMemcpy(sys->d_table, recs, sizeof(prt_dev_surface) * n_surfaces, hipMemcpyHostToDevice);
     delete[] recs;
+    for (int s = 0; s < n_surfaces; ++s)
+        if (table[s].mat_type == PRT_MAT_ANISOTROPIC) ++sys->n_aniso;
+    if (e == hipSuccess && sys->n_aniso > 0 && sys->n_aniso <= PRT_FUSED_MAX_CRYSTALS && !sys->complex_eps && n_surfaces < 32768) {
+        // the fused crystal march (k_trace_general): hot blocks + walk program
+        try {
+            std::vector<prt_hot_surface> hot((size_t)n_surfaces);
+            for (int s = 0; s < n_surfaces; ++s) hot[s] = hot_block(table[s]);
+            const std::vector<walk_step> prog = build_walk_program(table, n_surfaces);
+            sys->n_walk = (int32_t)prog.size() - 1;
+            e = hipMalloc((void **)&sys->d_hot, sizeof(prt_hot_surface) * hot.size());
+            if (e == hipSuccess) e = hipMemcpy(sys->d_hot, hot.data(), sizeof(prt_hot_surface) * hot.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMalloc((void **)&sys->d_walk, sizeof(walk_step) * prog.size());
+            if (e == hipSuccess) e = hipMemcpy(sys->d_walk, prog.data(), sizeof(walk_step) * prog.size(), hipMemcpyHostToDevice);
+        } catch (...) {  // std::bad_alloc: the ABI never throws
+            free_system(sys);
+            return fail(PRT_ERR_NOMEM, "host alloc");
+        }
+    }
     if (e != hipSuccess) {
         free_system(sys);
         return fail(PRT_ERR_DEVICE, "prt_system_create: table upload", e);
@@ -738,14 +842,12 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
         // concatenated layout with ray pitch out_pitch (0 = n0, tight)
         if (out_pitch == 0) out_pitch = n0;
         static const bool per_surface = getenv("PRT_GENERAL_PER_SURFACE") != nullptr;
-        int n_aniso = 0;
-        for (int s = 0; s < sys->n_surfaces; ++s)
-            if (sys->h_table[s].mat_type == PRT_MAT_ANISOTROPIC) ++n_aniso;
+        const int n_aniso = sys->n_aniso;
         // The fused march walks the tree of split rays depth first inside one launch (k_trace_general);
         // the per-surface march (one launch pair per surface, intermediate arrays) remains for
         // sequences with more crystal interfaces than the kernel has parking slots, and as the
         // independent implementation PRT_GENERAL_PER_SURFACE=1 selects for cross-checks.
-        if (per_surface || n_aniso > PRT_FUSED_MAX_CRYSTALS || sys->complex_eps) {
+        if (per_surface || !sys->d_walk) {  // (more than 8 crystal interfaces, complex epsilon: no walk program)
             if (out_pitch != n0 || in_pitch != n0)
                 return fail(PRT_ERR_UNSUPPORTED, "prt_trace: the per-surface march through crystals (more than 8 crystal "
                                                  "interfaces) takes tight arrays (pitch 0)");
@@ -796,28 +898,30 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
                 general_eps = true;
         // few crystal interfaces: the parking slots of the depth-first walk fit into LDS
         const bool park_lds = n_aniso <= PRT_PARK_LDS_LEVELS;
-        const size_t park_bytes = park_lds ? (size_t)n_aniso * PRT_GENERAL_BLOCK * (9 * sizeof(double) + 1) : 0;
+        // (slot: 9 doubles + 1 byte with biaxial crystals, 6 + 1 without -- prt_kernels.h "What is parked")
+        const size_t park_bytes = park_lds ? (size_t)n_aniso * PRT_GENERAL_BLOCK * ((general_eps ? 9 : 6) * sizeof(double) + 1) : 0;
         const bool conics = sys->all_conic != 0;
-#define PRT_LAUNCH_GS(MODE_, GEN_, LDS_, UNI_, SH_)                                                                 \
-    hipLaunchKernelGGL((k_trace_general<MODE_, GEN_, LDS_, UNI_, SH_>), grid, block, park_bytes, st, sys->d_table, \
-                       sys->n_surfaces, n_aniso, n0, in_pitch, out_pitch, a.x0, a.k0, e_re, e_im, e_mode, a.x_hit, \
-                       a.k_out,                                                                                    \
-                       a.e_out_re, a.e_out_im, a.valid, valid_out, a.nonconv, fu)
-#define PRT_LAUNCH_GU(MODE_, GEN_, LDS_, UNI_)                                   \
-    do {                                                                         \
-        if (conics) PRT_LAUNCH_GS(MODE_, GEN_, LDS_, UNI_, PRT_SHAPES_CONIC);    \
-        else PRT_LAUNCH_GS(MODE_, GEN_, LDS_, UNI_, PRT_SHAPES_ALL);             \
+#define PRT_LAUNCH_GS(MODE_, GEN_, LDS_, E_, SH_)                                                                   \
+    hipLaunchKernelGGL((k_trace_general<MODE_, GEN_, LDS_, E_, SH_>), grid, block, park_bytes, st, sys->d_table,   \
+                       sys->d_hot, sys->d_walk, sys->n_walk, n_aniso, n0, in_pitch, out_pitch, a.x0, a.k0, e_re,  \
+                       e_im, e_mode, a.x_hit, a.k_out,                                                             \
+                       a.e_out_re, a.e_out_im, a.valid, valid_out, a.nonconv, fu, (int32_t)(uni ? 1 : 0))
+#define PRT_LAUNCH_GU(MODE_, GEN_, LDS_, E_)                                   \
+    do {                                                                       \
+        if (conics) PRT_LAUNCH_GS(MODE_, GEN_, LDS_, E_, PRT_SHAPES_CONIC);    \
+        else PRT_LAUNCH_GS(MODE_, GEN_, LDS_, E_, PRT_SHAPES_ALL);             \
     } while (0)
-#define PRT_LAUNCH_GP(MODE_, GEN_, LDS_)                   \
-    do {                                                   \
-        if (uni) PRT_LAUNCH_GU(MODE_, GEN_, LDS_, true);   \
-        else PRT_LAUNCH_GU(MODE_, GEN_, LDS_, false);      \
+#define PRT_LAUNCH_GP(MODE_, GEN_, LDS_)                      \
+    do {                                                      \
+        if (want_e) PRT_LAUNCH_GU(MODE_, GEN_, LDS_, true);   \
+        else PRT_LAUNCH_GU(MODE_, GEN_, LDS_, false);         \
     } while (0)
 #define PRT_LAUNCH_G(MODE_, GEN_)                        \
     do {                                                 \
         if (park_lds) PRT_LAUNCH_GP(MODE_, GEN_, true);  \
         else PRT_LAUNCH_GP(MODE_, GEN_, false);          \
     } while (0)
+        const bool want_e = a.e_out_re != nullptr;
         if (mode == PRT_MODE_PATH) {
             if (general_eps) PRT_LAUNCH_G(PRT_MODE_PATH, true);
             else PRT_LAUNCH_G(PRT_MODE_PATH, false);

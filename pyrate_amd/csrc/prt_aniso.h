@@ -31,6 +31,8 @@ struct aniso_solution {
     vec3 k;       // wave vector, global frame
     vec3 d;       // unit Poynting direction, global frame
     vec3 er, ei;  // E field, global frame (imaginary part 0 for real eps / real xi)
+    vec3 kv;      // the wave vector in the frame of the medium, before a mirror's sign: what closed_form_ray takes
+    bool is_e;    // uniaxial epsilon: the extraordinary wave
 };
 
 struct cplx {
@@ -223,7 +225,8 @@ PRT_DEV vec3 null_vector(const vec3 &r0, const vec3 &r1, const vec3 &r2, int var
 //     (W E = [k^T eps k - eo ee] c = 0 on the extraordinary sheet; D = eps E is perpendicular to k)
 // In three pieces, so that the caller can run the straight-line parts of two solutions side by side (two
 // independent dependency chains in one basic block) and keep the rare fallback in one branch:
-PRT_DEV vec3 closed_form_e(const prt_dev_surface *__restrict__ sf, int cls, const vec3 &kv, double k2, int variant,
+template <class REC>
+PRT_DEV vec3 closed_form_e(const REC *__restrict__ sf, int cls, const vec3 &kv, double k2, int variant,
                            bool &closed) {
     if (cls == PRT_ANISO_ISOTROPIC) {
         const double ax = fabs(kv.x), ay = fabs(kv.y), az = fabs(kv.z);
@@ -253,8 +256,9 @@ PRT_DEV vec3 closed_form_e(const prt_dev_surface *__restrict__ sf, int cls, cons
     return v3(0.0, 0.0, 0.0);
 }
 
-PRT_DEV vec3 generic_e(const prt_dev_surface *__restrict__ sf, const vec3 &kv, double k2, int variant) {
-    const double *__restrict__ eps = sf->eps_re;
+template <class REC>
+PRT_DEV vec3 generic_e(const REC *__restrict__ sf, const vec3 &kv, double k2, int variant) {
+    const double *__restrict__ eps = cold(sf)->eps_re;
     const vec3 w0 = v3(eps[0] - k2 + kv.x * kv.x, eps[1] + kv.x * kv.y, eps[2] + kv.x * kv.z);
     const vec3 w1 = v3(eps[3] + kv.y * kv.x, eps[4] - k2 + kv.y * kv.y, eps[5] + kv.y * kv.z);
     const vec3 w2 = v3(eps[6] + kv.z * kv.x, eps[7] + kv.z * kv.y, eps[8] - k2 + kv.z * kv.z);
@@ -270,7 +274,8 @@ PRT_DEV void scaled_e_and_flux(const vec3 &E0, const vec3 &kv, const vec3 &n, do
     sn_out = dot(S, n);
 }
 
-PRT_DEV void eigen_solution(const prt_dev_surface *__restrict__ sf, int cls, const vec3 &kpa, const vec3 &n,
+template <class REC>
+PRT_DEV void eigen_solution(const REC *__restrict__ sf, int cls, const vec3 &kpa, const vec3 &n,
                             double x, int variant, vec3 &E_out, double &sn_out) {
     const vec3 kv = v3(kpa.x + x * n.x, kpa.y + x * n.y, kpa.z + x * n.z);
     const double k2 = dot(kv, kv);
@@ -294,7 +299,8 @@ PRT_DEV void eigen_solution(const prt_dev_surface *__restrict__ sf, int cls, con
 #else
 #define PRT_ANISO_FALLBACK_ATTR __forceinline__
 #endif
-__device__ PRT_ANISO_FALLBACK_ATTR void four_solution_path(const prt_dev_surface *__restrict__ sf, int cls, const vec3 &kpa,
+template <class REC>
+__device__ PRT_ANISO_FALLBACK_ATTR void four_solution_path(const REC *__restrict__ sf, int cls, const vec3 &kpa,
                                                            const vec3 &n, const double pc[5], double xr[4], bool mirror,
                                                            double x_out[2], vec3 e_out[2]) {
         double xi[4];
@@ -368,24 +374,60 @@ __device__ PRT_ANISO_FALLBACK_ATTR void four_solution_path(const prt_dev_surface
 
 // n: unit surface normal in the frame of the medium (the fused march has it from the intersection it just did:
 // normal_from_grad; the per-surface entry point evaluates the shape at the caller's point)
-template <bool GENERAL = true>
-PRT_DEV void interact_anisotropic_n(const prt_dev_surface *__restrict__ sf, const vec3 &n,
-                                    const vec3 &k_glob, aniso_solution out[2]);
-
-template <bool GENERAL = true, int SHAPES = PRT_SHAPES_ALL>
-PRT_DEV void interact_anisotropic(const prt_dev_surface *__restrict__ sf, const vec3 &p,
-                                  const vec3 &k_glob, aniso_solution out[2]) {
-    interact_anisotropic_n<GENERAL>(sf, normal_in_material_frame<SHAPES>(sf, p), k_glob, out);
+// Wave vector and ray direction (global frame) of ONE solution in a medium whose epsilon is isotropic or uniaxial,
+// from its wave vector kv in the frame of the medium (before a mirror's sign) and the flag "extraordinary wave":
+//   u = kv (ordinary wave, eps = e I)   or   u = eps kv = eo kv + (ee - eo)(kv.c) c (extraordinary),   d = u / |u|
+// (derivation: interact_anisotropic_n).  Exactly the operations interact_anisotropic_n performs for its two
+// solutions, so a child of the crystal march that was parked as (kv, is_e) -- 7 values instead of the 10 of
+// (k, d, alive) -- resumes with bit-identical k and d.
+template <class REC>
+PRT_DEV vec3 closed_form_u(const REC *__restrict__ sf, int cls, const vec3 &kv, bool is_e) {
+    if (cls != PRT_ANISO_UNIAXIAL) return kv;
+    const vec3 c = v3(sf->aniso_axis[0], sf->aniso_axis[1], sf->aniso_axis[2]);
+    const double w = (sf->aniso_ee - sf->aniso_eo) * dot(kv, c);
+    const double f = is_e ? sf->aniso_eo : 1.0, g = is_e ? w : 0.0;
+    return v3(__builtin_fma(g, c.x, f * kv.x), __builtin_fma(g, c.y, f * kv.y), __builtin_fma(g, c.z, f * kv.z));
+}
+template <class REC>
+PRT_DEV void closed_form_finish(const REC *__restrict__ sf, vec3 kv, vec3 d, vec3 &k_glob, vec3 &d_glob) {
+    if (sf->interaction == PRT_MIRROR) {  // material_anisotropic.py:136-137: k negated (S is odd in k)
+        kv = v3(-kv.x, -kv.y, -kv.z);
+        d = v3(-d.x, -d.y, -d.z);
+    }
+    if (!(sf->frame_flags & PRT_FRAME_MAT_IDENTITY)) {
+        kv = mat_vec(cold(sf)->B_mat, kv);
+        d = mat_vec(cold(sf)->B_mat, d);
+    }
+    k_glob = kv;
+    d_glob = d;
+}
+template <class REC>
+PRT_DEV void closed_form_ray(const REC *__restrict__ sf, const vec3 &kv, bool is_e, vec3 &k_glob, vec3 &d_glob) {
+    const vec3 u = closed_form_u(sf, sf->aniso_class, kv, is_e);
+    const double inv = fast_rsqrt(dot(u, u));
+    closed_form_finish(sf, kv, v3(u.x * inv, u.y * inv, u.z * inv), k_glob, d_glob);
 }
 
-template <bool GENERAL>
-PRT_DEV void interact_anisotropic_n(const prt_dev_surface *__restrict__ sf, const vec3 &n,
-                                    const vec3 &k_glob, aniso_solution out[2]) {
+// want_e (the same for every lane): the caller stores the E fields -- they are computed only then (uniaxial and
+// isotropic epsilon: the ray directions come from closed forms that need no eigenvector)
+template <bool GENERAL = true, class REC>
+PRT_DEV void interact_anisotropic_n(const REC *__restrict__ sf, const vec3 &n,
+                                    const vec3 &k_glob, aniso_solution out[2], bool want_e = true);
+
+template <bool GENERAL = true, int SHAPES = PRT_SHAPES_ALL, class REC>
+PRT_DEV void interact_anisotropic(const REC *__restrict__ sf, const vec3 &p,
+                                  const vec3 &k_glob, aniso_solution out[2], bool want_e = true) {
+    interact_anisotropic_n<GENERAL>(sf, normal_in_material_frame<SHAPES>(sf, p), k_glob, out, want_e);
+}
+
+template <bool GENERAL, class REC>
+PRT_DEV void interact_anisotropic_n(const REC *__restrict__ sf, const vec3 &n,
+                                    const vec3 &k_glob, aniso_solution out[2], bool want_e) {
     const bool mat_id = sf->frame_flags & PRT_FRAME_MAT_IDENTITY;
-    const vec3 k1 = mat_id ? k_glob : matT_vec(sf->B_mat, k_glob);
+    const vec3 k1 = mat_id ? k_glob : matT_vec(cold(sf)->B_mat, k_glob);
     const double kn = dot(k1, n);
     const vec3 kpa = v3(k1.x - kn * n.x, k1.y - kn * n.y, k1.z - kn * n.z);
-    const double *__restrict__ eps = sf->eps_re;
+    const double *__restrict__ eps = cold(sf)->eps_re;
     const double kap2 = dot(kpa, kpa);
     const int cls = sf->aniso_class;
     const bool mirror = sf->interaction == PRT_MIRROR;
@@ -393,6 +435,9 @@ PRT_DEV void interact_anisotropic_n(const prt_dev_surface *__restrict__ sf, cons
     // the two solutions that leave, in the reference's order
     vec3 e_out[2];
     double x_out[2];
+    vec3 d_out[2];        // their unit ray directions (material frame, before a mirror's sign), if have_d
+    bool have_d = false;  // (compile-time after inlining: the closed-form classes set it)
+    bool is_e_out[2] = {false, false};
 
     if (cls == PRT_ANISO_ISOTROPIC || cls == PRT_ANISO_UNIAXIAL) {
         // The four roots come as an ordinary pair -ro < +ro and an extraordinary pair x1 < x2 of a
@@ -431,29 +476,58 @@ PRT_DEV void interact_anisotropic_n(const prt_dev_surface *__restrict__ sf, cons
             x_e = mirror ? fmin(x1, x2) : fmax(x1, x2);
             if (!isfinite(disc)) x_e = __builtin_nan("");
         }
-        // both solutions side by side; the generic null vector (near the optic axis) in ONE rarely taken branch
+        // THE TWO RAYS WITHOUT THEIR EIGENVECTORS.  With E scaled like LAPACK's unit 6-vector, |E|^2 = 1/(1 + xi^2), the
+        // reference's S = |E|^2 k - (k.E) E (material.py:214-223) is  S = S0 / (1 + xi^2),  S0 = k - (k.e) e  for the
+        // unit vector e = E/|E|: the part of k perpendicular to E.  S0 is known without E:
+        //   ordinary wave  (E = k x c, perpendicular to k):           S0 = k
+        //   extraordinary wave (D = eps E perpendicular to k):       S0 is parallel to eps k (the normal of the sheet
+        //       k^T eps k = eo ee of the slowness surface) and |S0|^2 = S0.k, so  S0 = (u.k) u,  u = eps k / |eps k|
+        //   eps = e I: both waves like the ordinary one.
+        // Ray directions d = S0/|S0| and the S.n order of the pair (material.py:147) follow from that -- 160 VALU
+        // instructions less per interface than with the two eigenvectors (k x c, (k.c) k - eo c, their norms, LAPACK's
+        // scaling, the flux), and no loss of digits next to the optic axis, where the extraordinary eigenvector form
+        // cancels (the eigenvectors keep their fall-back there).  E itself is computed only for a caller that stores it.
         const vec3 kv_o = v3(kpa.x + x_o * n.x, kpa.y + x_o * n.y, kpa.z + x_o * n.z);
         const vec3 kv_e = v3(kpa.x + x_e * n.x, kpa.y + x_e * n.y, kpa.z + x_e * n.z);
-        const double k2_o = dot(kv_o, kv_o), k2_e = dot(kv_e, kv_e);
-        bool closed_o, closed_e;
-        vec3 E_o = closed_form_e(sf, cls, kv_o, k2_o, 0, closed_o);
-        vec3 E_e = closed_form_e(sf, cls, kv_e, k2_e, 1, closed_e);
-        if (!(closed_o && closed_e)) {
-            if (!closed_o) E_o = generic_e(sf, kv_o, k2_o, 0);
-            if (!closed_e) E_e = generic_e(sf, kv_e, k2_e, 1);
-        }
-        double s_o, s_e;
-        scaled_e_and_flux(E_o, kv_o, n, x_o, E_o, s_o);
-        scaled_e_and_flux(E_e, kv_e, n, x_e, E_e, s_e);
-        const double key_o = isnan(s_o) ? 0.0 : s_o, key_e = isnan(s_e) ? 0.0 : s_e;
-        const bool sw = key_e < key_o;  // stable: the ordinary solution first on a tie
+        const vec3 u_e = closed_form_u(sf, cls, kv_e, true);
+        const double inv_o = fast_rsqrt(dot(kv_o, kv_o)), inv_e = fast_rsqrt(dot(u_e, u_e));
+        const vec3 d_o = v3(kv_o.x * inv_o, kv_o.y * inv_o, kv_o.z * inv_o);
+        const vec3 d_e = v3(u_e.x * inv_e, u_e.y * inv_e, u_e.z * inv_e);
+        // S.n of the two, compared without dividing:  S0o.n / (1 + xo^2)  vs  S0e.n / (1 + xe^2); an evanescent mode
+        // (NaN) has the key 0, between the backward and the forward propagating modes (see above)
+        const double so_n = dot(kv_o, n), se_n = dot(d_e, kv_e) * dot(d_e, n);
+        const bool nan_o = isnan(so_n), nan_e = isnan(se_n);
+        const double a_o = nan_o ? 0.0 : so_n, a_e = nan_e ? 0.0 : se_n;
+        const double w_o = nan_o ? 1.0 : 1.0 + x_o * x_o, w_e = nan_e ? 1.0 : 1.0 + x_e * x_e;
+        // (eps = e I: the two waves are the same wave, kept in the order of their two E vectors)
+        const bool sw = (cls != PRT_ANISO_ISOTROPIC) && (a_e * w_o < a_o * w_e);  // stable: the ordinary solution first on a tie
         x_out[0] = sw ? x_e : x_o;
         x_out[1] = sw ? x_o : x_e;
-        e_out[0] = v3(sw ? E_e.x : E_o.x, sw ? E_e.y : E_o.y, sw ? E_e.z : E_o.z);
-        e_out[1] = v3(sw ? E_o.x : E_e.x, sw ? E_o.y : E_e.y, sw ? E_o.z : E_e.z);
+        d_out[0] = v3(sw ? d_e.x : d_o.x, sw ? d_e.y : d_o.y, sw ? d_e.z : d_o.z);
+        d_out[1] = v3(sw ? d_o.x : d_e.x, sw ? d_o.y : d_e.y, sw ? d_o.z : d_e.z);
+        have_d = true;
+        is_e_out[0] = sw && cls == PRT_ANISO_UNIAXIAL;
+        is_e_out[1] = !sw && cls == PRT_ANISO_UNIAXIAL;
+        e_out[0] = e_out[1] = v3(0.0, 0.0, 0.0);
+        if (want_e) {
+            // the eigenvectors (closed forms; the generic null vector next to the optic axis), scaled like LAPACK's
+            const double k2_o = dot(kv_o, kv_o), k2_e = dot(kv_e, kv_e);
+            bool closed_o, closed_e;
+            vec3 E_o = closed_form_e(sf, cls, kv_o, k2_o, 0, closed_o);
+            vec3 E_e = closed_form_e(sf, cls, kv_e, k2_e, 1, closed_e);
+            if (!closed_o) E_o = generic_e(sf, kv_o, k2_o, 0);
+            if (!closed_e) E_e = generic_e(sf, kv_e, k2_e, 1);
+            const double sc_o = fast_rsqrt(1.0 + x_o * x_o), sc_e = fast_rsqrt(1.0 + x_e * x_e);
+            E_o = v3(E_o.x * sc_o, E_o.y * sc_o, E_o.z * sc_o);
+            E_e = v3(E_e.x * sc_e, E_e.y * sc_e, E_e.z * sc_e);
+            e_out[0] = v3(sw ? E_e.x : E_o.x, sw ? E_e.y : E_o.y, sw ? E_e.z : E_o.z);
+            e_out[1] = v3(sw ? E_o.x : E_e.x, sw ? E_o.y : E_e.y, sw ? E_o.z : E_e.z);
+        }
     } else if (!GENERAL) {
         x_out[0] = x_out[1] = __builtin_nan("");
         e_out[0] = e_out[1] = v3(0.0, 0.0, 0.0);
+        d_out[0] = d_out[1] = v3(__builtin_nan(""), __builtin_nan(""), __builtin_nan(""));
+        have_d = true;
     } else {
         double pc[5];
         xi_polynomial(eps, n, kpa, pc);
@@ -526,19 +600,26 @@ PRT_DEV void interact_anisotropic_n(const prt_dev_surface *__restrict__ sf, cons
         vec3 E = e_out[b];
         const double x = x_out[b];
         vec3 kv = v3(kpa.x + x * n.x, kpa.y + x * n.y, kpa.z + x * n.z);
-        const double e2 = dot(E, E), ke = dot(kv, E);
-        vec3 S = v3(e2 * kv.x - ke * E.x, e2 * kv.y - ke * E.y, e2 * kv.z - ke * E.z);
+        out[b].kv = kv;
+        out[b].is_e = is_e_out[b];
+        vec3 d;
+        if (have_d) {
+            d = d_out[b];
+        } else {
+            const double e2 = dot(E, E), ke = dot(kv, E);
+            const vec3 S = v3(e2 * kv.x - ke * E.x, e2 * kv.y - ke * E.y, e2 * kv.z - ke * E.z);
+            const double inv = fast_rsqrt(dot(S, S));
+            d = v3(S.x * inv, S.y * inv, S.z * inv);
+        }
         if (mirror) {  // material_anisotropic.py:136-137: k, E negated (S is even in E, odd in k)
             kv = v3(-kv.x, -kv.y, -kv.z);
             E = v3(-E.x, -E.y, -E.z);
-            S = v3(-S.x, -S.y, -S.z);
+            d = v3(-d.x, -d.y, -d.z);
         }
-        const double inv = fast_rsqrt(dot(S, S));
-        vec3 d = v3(S.x * inv, S.y * inv, S.z * inv);
         if (!mat_id) {
-            kv = mat_vec(sf->B_mat, kv);
-            E = mat_vec(sf->B_mat, E);
-            d = mat_vec(sf->B_mat, d);
+            kv = mat_vec(cold(sf)->B_mat, kv);
+            E = mat_vec(cold(sf)->B_mat, E);
+            d = mat_vec(cold(sf)->B_mat, d);
         }
         out[b].k = kv;
         out[b].d = d;

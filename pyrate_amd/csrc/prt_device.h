@@ -45,6 +45,32 @@ struct prt_dev_surface {
 };
 static_assert(sizeof(prt_dev_surface) < 512, "device surface record grew beyond 512 bytes");
 
+// The HOT BLOCK of a surface record: the fields every step of a march through conic surfaces reads, packed into
+// 128 bytes that a wave fetches with two s_load_dwordx16 -- ONE scalar-memory round trip per surface, issued a whole
+// step ahead by the crystal march (k_trace_general), instead of one s_load -> s_waitcnt round trip per field and
+// basic block (the compiler places a scalar load in the block that uses it: ~20 dependent round trips per step).
+// Everything else (rotation matrices of tilted frames, the epsilon tensor of biaxial crystals, coefficient
+// pointers) stays in the full record and is fetched where it is needed.
+//   v[0]  two int32: bits (shape_type | ap_type << 4 | interaction << 6 | mat_type << 7 | aniso_class << 8 |
+//         frame_flags << 10), newton_maxit
+//   v[1..2] curv, cc   v[3..5] g_shape   v[6..7] ap_p0, ap_p1   v[8] n_after
+//   v[9..10] aniso_eo, aniso_ee   v[11..13] aniso_axis   v[14..15] spare
+#define PRT_HOT_DOUBLES 16
+struct prt_hot_surface {
+    double v[PRT_HOT_DOUBLES];
+};
+static_assert(sizeof(prt_hot_surface) == 128, "hot block = two s_load_dwordx16");
+
+// the hot block unpacked into (scalar) registers; same member names as prt_dev_surface, so that the per-ray device
+// functions below take either (`cold()` leads to the fields only the full record has)
+struct hot_rec {
+    int32_t shape_type, ap_type, interaction, mat_type, frame_flags, aniso_class, newton_maxit;
+    double curv, cc, g_shape[3], ap_p0, ap_p1, n_after, aniso_eo, aniso_ee, aniso_axis[3];
+    const prt_dev_surface *full;
+};
+__device__ __forceinline__ const prt_dev_surface *cold(const prt_dev_surface *sf) { return sf; }
+__device__ __forceinline__ const prt_dev_surface *cold(const hot_rec *sf) { return sf->full; }
+
 struct vec3 {
     double x, y, z;
 };
@@ -575,7 +601,8 @@ PRT_DEV double shape_sag(const prt_dev_surface *__restrict__ sf, double x, doubl
 // ---------------------------------------------------------------------------
 // aperture.py:71-139
 // ---------------------------------------------------------------------------
-PRT_DEV bool aperture_ok(const prt_dev_surface *__restrict__ sf, double x, double y) {
+template <class REC>
+PRT_DEV bool aperture_ok(const REC *__restrict__ sf, double x, double y) {
     if (sf->ap_type == PRT_AP_CIRCULAR) {
         const double r2 = x * x + y * y;
         return (r2 >= sf->ap_p0 * sf->ap_p0) && (r2 <= sf->ap_p1 * sf->ap_p1);
@@ -594,16 +621,16 @@ PRT_DEV bool aperture_ok(const prt_dev_surface *__restrict__ sf, double x, doubl
 // ---------------------------------------------------------------------------
 //        g (unnormalised surface gradient at p, shape frame) and g2 = |g|^2 as by-products
 //   d may be any positive multiple of the unit direction, d2 = d.d
-template <int SHAPES = PRT_SHAPES_ALL>
-PRT_DEV void propagate_step(const prt_dev_surface *__restrict__ sf, const vec3 &x, const vec3 &d,
+template <int SHAPES = PRT_SHAPES_ALL, class REC>
+PRT_DEV void propagate_step(const REC *__restrict__ sf, const vec3 &x, const vec3 &d,
                             double d2, vec3 &xh, vec3 &p, vec3 &g, double &g2, bool &valid, bool &nonconv) {
     nonconv = false;
     const int ff = sf->frame_flags;
     vec3 r0 = v3(x.x - sf->g_shape[0], x.y - sf->g_shape[1], x.z - sf->g_shape[2]);
     vec3 dl = d;
     if (!(ff & PRT_FRAME_SHAPE_IDENTITY)) {
-        r0 = matT_vec(sf->B_shape, r0);
-        dl = matT_vec(sf->B_shape, d);
+        r0 = matT_vec(cold(sf)->B_shape, r0);
+        dl = matT_vec(cold(sf)->B_shape, d);
     }
     double t;
     if (SHAPES == PRT_SHAPES_CONIC || sf->shape_type == PRT_SHAPE_CONIC) {
@@ -614,7 +641,7 @@ PRT_DEV void propagate_step(const prt_dev_surface *__restrict__ sf, const vec3 &
         g = conic_grad_on_surface(sf->curv, sf->cc, p, g2);
     } else {
         double fx, fy;
-        t = explicit_t<SHAPES>(sf, r0, dl, nonconv, fx, fy);  // reference: valid all True (surface_shape.py:462)
+        t = explicit_t<SHAPES>(cold(sf), r0, dl, nonconv, fx, fy);  // reference: valid all True (surface_shape.py:462)
         // A ray whose Newton iteration hit the cap has no trustworthy hit point.  The mask after
         // propagate stays reference-compatible (True); the NaN hit point makes the normal NaN, so
         // the ray is dropped by the finite-normal test of the following refraction.  `nonconv` is
@@ -630,7 +657,7 @@ PRT_DEV void propagate_step(const prt_dev_surface *__restrict__ sf, const vec3 &
     if (ff & PRT_FRAME_SHAPE_IDENTITY) {
         xh = v3(p.x + sf->g_shape[0], p.y + sf->g_shape[1], p.z + sf->g_shape[2]);
     } else {
-        xh = mat_vec(sf->B_shape, p);
+        xh = mat_vec(cold(sf)->B_shape, p);
         xh.x += sf->g_shape[0];
         xh.y += sf->g_shape[1];
         xh.z += sf->g_shape[2];
@@ -638,7 +665,7 @@ PRT_DEV void propagate_step(const prt_dev_surface *__restrict__ sf, const vec3 &
     if (sf->ap_type != PRT_AP_NONE) {
         vec3 pa = p;  // aperture frame == shape frame in the common case
         if (!(ff & PRT_FRAME_AP_IS_SHAPE)) {
-            pa = matT_vec(sf->B_ap, v3(xh.x - sf->g_ap[0], xh.y - sf->g_ap[1], xh.z - sf->g_ap[2]));
+            pa = matT_vec(cold(sf)->B_ap, v3(xh.x - cold(sf)->g_ap[0], xh.y - cold(sf)->g_ap[1], xh.z - cold(sf)->g_ap[2]));
         }
         valid = valid && aperture_ok(sf, pa.x, pa.y);
     }
@@ -647,36 +674,36 @@ PRT_DEV void propagate_step(const prt_dev_surface *__restrict__ sf, const vec3 &
 // shape-frame hit point from a global one (used when interact is called on its own)
 PRT_DEV vec3 to_shape_frame(const prt_dev_surface *__restrict__ sf, const vec3 &xh) {
     vec3 r = v3(xh.x - sf->g_shape[0], xh.y - sf->g_shape[1], xh.z - sf->g_shape[2]);
-    if (!(sf->frame_flags & PRT_FRAME_SHAPE_IDENTITY)) r = matT_vec(sf->B_shape, r);
+    if (!(sf->frame_flags & PRT_FRAME_SHAPE_IDENTITY)) r = matT_vec(cold(sf)->B_shape, r);
     return r;
 }
 
 // unit normal in the frame of the medium from the shape-frame gradient g (|g|^2 = g2):
 // Shape.getNormal (surface_shape.py:100-112) + RayBundle.getLocalSurfaceNormal (ray.py:156-161).
 // Spheres have |g| = 1 identically (conic_grad_on_surface): no normalisation.
-template <int SHAPES = PRT_SHAPES_ALL>
-PRT_DEV vec3 normal_from_grad(const prt_dev_surface *__restrict__ sf, const vec3 &g, double g2) {
+template <int SHAPES = PRT_SHAPES_ALL, class REC>
+PRT_DEV vec3 normal_from_grad(const REC *__restrict__ sf, const vec3 &g, double g2) {
     vec3 n = g;
     if (!((SHAPES == PRT_SHAPES_CONIC || sf->shape_type == PRT_SHAPE_CONIC) && sf->cc == 0.0)) {
         const double r = fast_rsqrt(g2);
         n = v3(g.x * r, g.y * r, g.z * r);
     }
     const int ff = sf->frame_flags;
-    if (!(ff & PRT_FRAME_SHAPE_IDENTITY)) n = mat_vec(sf->B_shape, n);
-    if (!(ff & PRT_FRAME_MAT_IDENTITY)) n = matT_vec(sf->B_mat, n);
+    if (!(ff & PRT_FRAME_SHAPE_IDENTITY)) n = mat_vec(cold(sf)->B_shape, n);
+    if (!(ff & PRT_FRAME_MAT_IDENTITY)) n = matT_vec(cold(sf)->B_mat, n);
     return n;
 }
 
 // the same for an arbitrary point of the shape frame (per-surface API: the caller's points
 // need not lie on the surface, so the sag is evaluated like the reference does)
-template <int SHAPES = PRT_SHAPES_ALL>
-PRT_DEV vec3 normal_in_material_frame(const prt_dev_surface *__restrict__ sf, const vec3 &p) {
-    vec3 g = (SHAPES == PRT_SHAPES_CONIC) ? conic_grad(sf->curv, sf->cc, p.x, p.y) : shape_grad(sf, p.x, p.y);
+template <int SHAPES = PRT_SHAPES_ALL, class REC>
+PRT_DEV vec3 normal_in_material_frame(const REC *__restrict__ sf, const vec3 &p) {
+    vec3 g = (SHAPES == PRT_SHAPES_CONIC) ? conic_grad(sf->curv, sf->cc, p.x, p.y) : shape_grad(cold(sf), p.x, p.y);
     const double inv = fast_rsqrt(dot(g, g));
     vec3 n = v3(g.x * inv, g.y * inv, g.z * inv);
     const int ff = sf->frame_flags;
-    if (!(ff & PRT_FRAME_SHAPE_IDENTITY)) n = mat_vec(sf->B_shape, n);
-    if (!(ff & PRT_FRAME_MAT_IDENTITY)) n = matT_vec(sf->B_mat, n);
+    if (!(ff & PRT_FRAME_SHAPE_IDENTITY)) n = mat_vec(cold(sf)->B_shape, n);
+    if (!(ff & PRT_FRAME_MAT_IDENTITY)) n = matT_vec(cold(sf)->B_mat, n);
     return n;
 }
 
@@ -684,11 +711,12 @@ PRT_DEV vec3 normal_in_material_frame(const prt_dev_surface *__restrict__ sf, co
 // IsotropicMaterial.refract / reflect, material_isotropic.py:137-236
 //   k global in -> k global out; valid &= (n2^2 - kin.kin > 0) & finite(normal)
 // ---------------------------------------------------------------------------
-PRT_DEV void interact_isotropic(const prt_dev_surface *__restrict__ sf, const vec3 &n, vec3 &k,
+template <class REC>
+PRT_DEV void interact_isotropic(const REC *__restrict__ sf, const vec3 &n, vec3 &k,
                                 bool &valid) {
     const bool mat_id = sf->frame_flags & PRT_FRAME_MAT_IDENTITY;
     vec3 k1 = k;
-    if (!mat_id) k1 = matT_vec(sf->B_mat, k);
+    if (!mat_id) k1 = matT_vec(cold(sf)->B_mat, k);
     const double kn = dot(k1, n);
     vec3 kin = v3(k1.x - kn * n.x, k1.y - kn * n.y, k1.z - kn * n.z);
     const double n2 = sf->n_after;
@@ -699,5 +727,5 @@ PRT_DEV void interact_isotropic(const prt_dev_surface *__restrict__ sf, const ve
     valid = valid && (square > 0.0) && isfinite(kn);
     if (sf->interaction == PRT_MIRROR) kin = v3(-kin.x, -kin.y, -kin.z);  // :224
     vec3 k2 = v3(kin.x + xi * n.x, kin.y + xi * n.y, kin.z + xi * n.z);
-    k = mat_id ? k2 : mat_vec(sf->B_mat, k2);
+    k = mat_id ? k2 : mat_vec(cold(sf)->B_mat, k2);
 }

@@ -376,6 +376,11 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
 #ifndef PRT_GENERAL_WAVES
 #define PRT_GENERAL_WAVES 4
 #endif
+// ... and of the instantiation for conic surfaces + uniaxial / isotropic crystals without E output (BASELINE
+// configs[3]), which needs 79 VGPRs and 98 B of LDS per thread
+#ifndef PRT_UNIAXIAL_WAVES
+#define PRT_UNIAXIAL_WAVES 4
+#endif
 // diagnostic builds only (benchmarks/ab_crystal.py): every store of the march lands in a 16k-ray window that
 // stays in L2 -- what the march costs when HBM takes no part
 #ifdef PRT_DIAG_L2_STORES
@@ -383,8 +388,12 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
 #else
 #define PRT_DIAG_STORE_INDEX(i) (i)
 #endif
-// PARK_LDS: the parking slots live in LDS ([level][value][thread]: conflict-free, 9 doubles + 1 byte per
-// level and thread) instead of private memory.  For up to PRT_PARK_LDS_LEVELS crystal interfaces the block's
+// What is parked.  Tables whose crystals are all uniaxial / isotropic (GENERAL = false): hit point, the child's wave
+// vector in the frame of the crystal, and a byte (alive | extraordinary << 1) -- 6 doubles + 1 byte; k and the ray
+// direction are rebuilt from them when the child is taken up (closed_form_ray, prt_aniso.h: bit-identical to what
+// the interface computed).  98 B per thread for two levels: six blocks of 256 threads per CU, where the 146 B of
+// (x, k, d, alive) allowed four.  Biaxial crystals (GENERAL): hit point, k, d, alive -- 9 doubles + 1 byte.
+// PARK_LDS: the parking slots live in LDS ([level][value][thread]: conflict-free) instead of private memory.  For up to PRT_PARK_LDS_LEVELS crystal interfaces the block's
 // slots (37 KB) leave room for four blocks per CU.  Private-memory slots are real HBM / L2 traffic: PMC
 // 1.20 GB per launch instead of 0.82 GB on BASELINE configs[3] (0.75 GB algorithmic), and 0.193 instead of
 // 0.162 ms in path mode, 0.139 instead of 0.125 ms in image mode (same arrays, benchmarks/ab_crystal.py).
@@ -409,16 +418,79 @@ PRT_DEV PRT_GLOBAL_AS T *uniform_ptr(T *p) {
 #ifndef PRT_GENERAL_BLOCK
 #define PRT_GENERAL_BLOCK 256
 #endif
+
+// THE WALK PROGRAM.  The depth-first walk through the tree of split rays is the same for every ray of every
+// launch on a table: which surface comes next, at which level, where a parked child is resumed, at which
+// (pitch-relative) offsets the records land.  prt_system_create writes it down once as a list of steps
+// (host: build_walk_program); the kernel executes the list.  What the kernel used to work out per step in
+// scalar arithmetic -- the offsets of the concatenated layout, 64-bit multiplies per row base; a scan of the table
+// at every resume -- is read instead, and because the NEXT step is known, its walk entry and the hot block of its
+// surface (prt_device.h) are fetched one step ahead: the scalar loads of step t+1 are in flight while step t
+// computes, and no step begins by waiting for its own record.
+//   s         surface of this step                         next_s   surface of the FOLLOWING step (prefetch)
+//   (16 bits each; a, resume, lp, last: a byte each)
+//   a         doublings so far = level of a crystal interface met at this step
+//   resume    j + 1: before this step the child parked at level j is taken up; 0: the state is carried on
+//   lp        which of the 2^a branches of this level the step's ray is (row block of the concatenated layout)
+//   cum_in    sum of 2^a over the earlier surfaces: offset of the surface's block of x_hit / valid, in units of
+//             the ray pitch P; the same for k_out / valid_out is cum_in + 2^a - 1
+//   s_park    the surface at which the child taken up by `resume` was parked
+//   last      1: s is the last surface of the table (the one record image mode writes)
+struct walk_step {
+    int32_t s_pair;   // s | next_s << 16
+    int32_t bits;     // a | resume << 8 | lp << 16 | last << 24
+    int32_t cum_in;   // (cum_out = cum_in + 2^a - 1: every earlier crystal interface of level j added 2^j)
+    int32_t s_park;   // resume: the surface whose crystal interface parked the child that is taken up
+};
+static_assert(sizeof(walk_step) == 16, "walk entry = one s_load_dwordx4");
+
+typedef double prt_d8 __attribute__((ext_vector_type(8)));
+typedef int32_t prt_i4 __attribute__((ext_vector_type(4)));
+// volatile: the load stays where it is written (the optimiser would sink a plain load of constant memory into the
+// basic block of its first use -- back to one round trip per field) and stays one wide scalar load.
+// The hot block comes in two halves (prt_device.h): the EARLY half (what the intersection and the aperture need)
+// and the LATE half (what the interaction needs).
+PRT_DEV prt_d8 load_hot_half(const prt_hot_surface *hot, int32_t s, int half) {
+    const PRT_CONST_AS volatile prt_d8 *p = (const PRT_CONST_AS volatile prt_d8 *)(uint64_t)(hot + s);
+    return p[half];
+}
+PRT_DEV void unpack_hot_early(const prt_d8 &h0, const prt_dev_surface *full, hot_rec &r) {
+    const uint64_t w = __builtin_bit_cast(uint64_t, (double)h0[0]);
+    const uint32_t bits = (uint32_t)w;
+    r.newton_maxit = (int32_t)(w >> 32);
+    r.shape_type = bits & 15;
+    r.ap_type = (bits >> 4) & 3;
+    r.interaction = (bits >> 6) & 1;
+    r.mat_type = (bits >> 7) & 1;
+    r.aniso_class = (bits >> 8) & 3;
+    r.frame_flags = (bits >> 10) & 7;
+    r.curv = h0[1];
+    r.cc = h0[2];
+    r.g_shape[0] = h0[3]; r.g_shape[1] = h0[4]; r.g_shape[2] = h0[5];
+    r.ap_p0 = h0[6];
+    r.ap_p1 = h0[7];
+    r.full = full;
+}
+PRT_DEV void unpack_hot_late(const prt_d8 &h1, hot_rec &r) {
+    r.n_after = h1[0];
+    r.aniso_eo = h1[1];
+    r.aniso_ee = h1[2];
+    r.aniso_axis[0] = h1[3]; r.aniso_axis[1] = h1[4]; r.aniso_axis[2] = h1[5];
+}
+
 // SHAPES: the shape code compiled in (as in k_trace_iso): tables whose surfaces are all conics get an
 // instantiation without any Newton / polynomial / spline code.
-template <int MODE, bool GENERAL = true, bool PARK_LDS = false, bool UNI = false, int SHAPES = PRT_SHAPES_ALL>
-__global__ __launch_bounds__(PRT_GENERAL_BLOCK, PRT_GENERAL_WAVES) void k_trace_general(
-    const prt_dev_surface *__restrict__ tab, int32_t S, int32_t A, int64_t N, int64_t in_pitch, int64_t P,
+// WANT_E: the caller stores the E fields behind the crystal interfaces (e_out); without it no eigenvector is computed
+// for uniaxial / isotropic epsilon (prt_aniso.h).  uni: the uniform first segment (run-time flag: prologue only).
+template <int MODE, bool GENERAL = true, bool PARK_LDS = false, bool WANT_E = false, int SHAPES = PRT_SHAPES_ALL>
+__global__ __launch_bounds__(PRT_GENERAL_BLOCK, (!GENERAL && !WANT_E && SHAPES == PRT_SHAPES_CONIC) ? PRT_UNIAXIAL_WAVES : PRT_GENERAL_WAVES) void k_trace_general(
+    const prt_dev_surface *__restrict__ tab, const prt_hot_surface *__restrict__ hot,
+    const walk_step *__restrict__ walk, int32_t n_steps, int32_t A, int64_t N, int64_t in_pitch, int64_t P,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, double *__restrict__ xh_out,
     double *__restrict__ k_out, double *__restrict__ e_out, double *__restrict__ e_out_im,
     uint8_t *__restrict__ valid_out_hit, uint8_t *__restrict__ valid_out_refr,
-    uint8_t *__restrict__ nonconv_out = nullptr, first_uniform fu = first_uniform()) {
+    uint8_t *__restrict__ nonconv_out = nullptr, first_uniform fu = first_uniform(), int32_t uni = 0) {
     const uint32_t tid = threadIdx.x;
     const int64_t blk = (int64_t)blockIdx.x * PRT_GENERAL_BLOCK;
     const int64_t i = blk + tid;
@@ -428,7 +500,7 @@ __global__ __launch_bounds__(PRT_GENERAL_BLOCK, PRT_GENERAL_WAVES) void k_trace_
     // 0.151 ms on BASELINE configs[3], whose 998012 rays put every row at an odd multiple of 32 B
     vec3 x = v3(x0[i], x0[in_pitch + i], x0[2 * in_pitch + i]);
     vec3 k, d;
-    if (UNI) {  // uniform first segment: only x0 is read
+    if (uni) {  // uniform first segment: only x0 is read
         k = v3(fu.k[0], fu.k[1], fu.k[2]);
         d = uniform_first_direction(e_mode, fu, k);
     } else {
@@ -438,142 +510,154 @@ __global__ __launch_bounds__(PRT_GENERAL_BLOCK, PRT_GENERAL_WAVES) void k_trace_
         first_direction<false>(e_mode, e_re, e_im, in_pitch, i, false, kk, dd);
         d = dd[0];
     }
+    // the first walk entry and hot block (the following ones are fetched a step ahead, inside the loop)
+    const PRT_CONST_AS volatile prt_i4 *wp = (const PRT_CONST_AS volatile prt_i4 *)(uint64_t)walk;
+    prt_i4 w = wp[0];
     // all input loads land here, so that no wait inside the walk ever counts stores (PRT_WAIT_VMEM_LOADS)
     PRT_WAIT_VMEM_LOADS();
     bool valid = true;
     double d2 = 1.0;
-    // per level: child 1 of the crystal interface of that level (hit point, k, d, alive)
+    // per level: child 1 of the crystal interface of that level
+    constexpr int PV = GENERAL ? 9 : 6;  // doubles per slot
     extern __shared__ double park_lds[];
-    double parked[PARK_LDS ? 1 : PRT_FUSED_MAX_CRYSTALS][10];
-    uint8_t *park_lds_alive = reinterpret_cast<uint8_t *>(park_lds + (size_t)A * 9 * PRT_GENERAL_BLOCK);
-    uint32_t pending = 0;                        // levels with a parked child (wave-uniform)
-    int64_t L = 0;                               // choices made so far: bit j = child taken at level j
-    int32_t s = 0;                               // next surface
-    int a = 0;                                   // doublings so far = level of the next crystal interface
-    int64_t off_in = 0, off_out = 0;             // ray offsets of surface s in the concatenated arrays
-    for (;;) {
-        for (; s < S; ++s) {
-            const prt_dev_surface *__restrict__ sf = tab + s;
-            const bool store = (MODE == PRT_MODE_PATH || s == S - 1);
-            const bool crystal = sf->mat_type == PRT_MAT_ANISOTROPIC;
-            const int64_t n_in = P << a;
-            const int a_out = crystal ? a + 1 : a;
-            const int64_t n_out = P << a_out;
-            const int64_t base_in = (MODE == PRT_MODE_PATH) ? off_in : 0;
-            const int64_t base_out = (MODE == PRT_MODE_PATH) ? off_out : 0;
-            double *xo = xh_out + 3 * base_in;
-            double *ko = k_out + 3 * base_out;
-            const int64_t Lp = L & (((int64_t)1 << a) - 1);
-            // store addresses = wave-uniform row base (scalar registers) + the thread's 32-bit offset: the
-            // form global_store takes with a scalar base, no 64-bit vector arithmetic per store
-            const int64_t idx_in = PRT_DIAG_STORE_INDEX(blk) + P * Lp;
-            const bool alive = valid;
-            vec3 xh, p, g;
-            double g2;
-            bool ncv;
-            propagate_step<SHAPES>(sf, x, d, d2, xh, p, g, g2, valid, ncv);
-            if (store) {
-                PRT_GLOBAL_AS double *xrow = uniform_ptr(xo + idx_in);
-                PRT_GSTORE(xrow + tid, xh.x);
-                PRT_GSTORE(xrow + n_in + tid, xh.y);
-                PRT_GSTORE(xrow + 2 * n_in + tid, xh.z);
-                PRT_GSTORE_MASK(uniform_ptr(valid_out_hit + base_in + idx_in) + tid, (uint8_t)(valid ? 1 : 0));
-                if (nonconv_out) uniform_ptr(nonconv_out + base_in + idx_in)[tid] = ncv ? 1 : 0;
-            }
-            x = xh;
-            if (crystal) {
-                aniso_solution sol[2];
-                // (the normal is evaluated from the hit point like the per-surface entry point does -- not taken from
-                // the intersection's gradient: for eps = e I the eigenvectors are an arbitrary basis picked by
-                // comparisons of k's components, and the two paths must pick the same one)
-                interact_anisotropic<GENERAL, SHAPES>(sf, p, k, sol);
-                valid = alive;  // no validity filtering at a crystal interface (ray.py:68)
-                if (store) {
+    double parked[PARK_LDS ? 1 : PRT_FUSED_MAX_CRYSTALS][PV + 1];
+    uint8_t *park_lds_alive = reinterpret_cast<uint8_t *>(park_lds + (size_t)A * PV * PRT_GENERAL_BLOCK);
+    for (int32_t t = 0; t < n_steps; ++t) {
+        // ---- this step's scalars; the next step's loads go out before anything is computed ----
+        // ONE scalar-memory round trip per step: both halves of this step's hot block (the late half is not needed
+        // before the interaction) and the NEXT walk entry, so that the next step knows its surface when it begins
+        const int32_t s = w[0] & 0xffff;
+        const prt_d8 h0 = load_hot_half(hot, s, 0);
+        const prt_d8 h1 = load_hot_half(hot, s, 1);
+        const prt_i4 wn = wp[t + 1];  // (the program ends with a sentinel entry)
+        const int32_t a = w[1] & 0xff, resume = (w[1] >> 8) & 0xff;
+        const int64_t lp = (w[1] >> 16) & 0xff, cum_in = (MODE == PRT_MODE_PATH) ? w[2] : 0;
+        const int64_t cum_out = (MODE == PRT_MODE_PATH) ? cum_in + (((int64_t)1 << a) - 1) : 0;
+        const bool last_surface = (w[1] >> 24) != 0;
+        hot_rec rec;
+        unpack_hot_early(h0, tab + s, rec);
+        const hot_rec *__restrict__ sf = &rec;
+        if (resume) {  // take up the child parked at level resume - 1
+            const int j = resume - 1;
+            double pv[PV];
+            uint8_t pb;
+            if (PARK_LDS) {
+                const double *slot = park_lds + (size_t)j * PV * PRT_GENERAL_BLOCK + threadIdx.x;
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        const int64_t idx_out = PRT_DIAG_STORE_INDEX(blk) + P * (Lp + ((int64_t)b << a));
-                        PRT_GLOBAL_AS double *krow = uniform_ptr(ko + idx_out);
-                        PRT_GSTORE(krow + tid, sol[b].k.x);
-                        PRT_GSTORE(krow + n_out + tid, sol[b].k.y);
-                        PRT_GSTORE(krow + 2 * n_out + tid, sol[b].k.z);
-                        if (e_out) {
-                            PRT_GLOBAL_AS double *eo = uniform_ptr(e_out + 3 * base_out + idx_out);
-                            eo[tid] = sol[b].er.x;
-                            (eo + n_out)[tid] = sol[b].er.y;
-                            (eo + 2 * n_out)[tid] = sol[b].er.z;
-                            if (e_out_im) {
-                                PRT_GLOBAL_AS double *ei = uniform_ptr(e_out_im + 3 * base_out + idx_out);
-                                ei[tid] = sol[b].ei.x;
-                                (ei + n_out)[tid] = sol[b].ei.y;
-                                (ei + 2 * n_out)[tid] = sol[b].ei.z;
-                            }
+                for (int q = 0; q < PV; ++q) pv[q] = slot[q * PRT_GENERAL_BLOCK];
+                pb = park_lds_alive[j * PRT_GENERAL_BLOCK + threadIdx.x];
+            } else {
+#pragma unroll
+                for (int q = 0; q < PV; ++q) pv[q] = parked[j][q];
+                pb = (uint8_t)parked[j][PV];
+            }
+            x = v3(pv[0], pv[1], pv[2]);
+            valid = (pb & 1) != 0;
+            if (GENERAL) {
+                k = v3(pv[3], pv[4], pv[5]);
+                d = v3(pv[PV - 3], pv[PV - 2], pv[PV - 1]);
+            } else {  // rebuild k and d from the parked wave vector, with the record of the parking surface
+                const int32_t sp = w[3];
+                hot_rec prec;
+                unpack_hot_early(load_hot_half(hot, sp, 0), tab + sp, prec);
+                unpack_hot_late(load_hot_half(hot, sp, 1), prec);
+                closed_form_ray(&prec, v3(pv[3], pv[4], pv[5]), (pb & 2) != 0, k, d);
+            }
+            d2 = 1.0;
+        }
+        const bool store = (MODE == PRT_MODE_PATH || last_surface);
+        const bool crystal = sf->mat_type == PRT_MAT_ANISOTROPIC;
+        const int64_t n_in = P << a;
+        const int a_out = crystal ? a + 1 : a;
+        const int64_t n_out = P << a_out;
+        // store addresses = wave-uniform row base (scalar registers) + the thread's 32-bit offset: the
+        // form global_store takes with a scalar base, no 64-bit vector arithmetic per store
+        const int64_t row = PRT_DIAG_STORE_INDEX(blk) + P * lp;
+        const bool alive = valid;
+        vec3 xh, p, g;
+        double g2;
+        bool ncv;
+        propagate_step<SHAPES>(sf, x, d, d2, xh, p, g, g2, valid, ncv);
+        if (store) {
+            PRT_GLOBAL_AS double *xrow = uniform_ptr(xh_out + 3 * P * cum_in + row);
+            PRT_GSTORE(xrow + tid, xh.x);
+            PRT_GSTORE(xrow + n_in + tid, xh.y);
+            PRT_GSTORE(xrow + 2 * n_in + tid, xh.z);
+            PRT_GSTORE_MASK(uniform_ptr(valid_out_hit + P * cum_in + row) + tid, (uint8_t)(valid ? 1 : 0));
+            if (nonconv_out) uniform_ptr(nonconv_out + P * cum_in + row)[tid] = ncv ? 1 : 0;
+        }
+        x = xh;
+        unpack_hot_late(h1, rec);
+        if (crystal) {
+            aniso_solution sol[2];
+            // The normal: from the gradient the intersection left behind (for a sphere it IS the unit normal) -- unless
+            // the E fields are wanted: for eps = e I they are an arbitrary basis picked by comparisons of k's components,
+            // and the per-surface entry point, which evaluates the normal from the hit point, must pick the same one.
+            if (WANT_E) interact_anisotropic<GENERAL, SHAPES>(sf, p, k, sol, true);
+            else interact_anisotropic_n<GENERAL>(sf, normal_from_grad<SHAPES>(sf, g, g2), k, sol, false);
+            valid = alive;  // no validity filtering at a crystal interface (ray.py:68)
+            if (store) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int64_t row_out = row + ((P * b) << a);
+                    PRT_GLOBAL_AS double *krow = uniform_ptr(k_out + 3 * P * cum_out + row_out);
+                    PRT_GSTORE(krow + tid, sol[b].k.x);
+                    PRT_GSTORE(krow + n_out + tid, sol[b].k.y);
+                    PRT_GSTORE(krow + 2 * n_out + tid, sol[b].k.z);
+                    if (WANT_E && e_out) {
+                        PRT_GLOBAL_AS double *eo = uniform_ptr(e_out + 3 * P * cum_out + row_out);
+                        eo[tid] = sol[b].er.x;
+                        (eo + n_out)[tid] = sol[b].er.y;
+                        (eo + 2 * n_out)[tid] = sol[b].er.z;
+                        if (e_out_im) {
+                            PRT_GLOBAL_AS double *ei = uniform_ptr(e_out_im + 3 * P * cum_out + row_out);
+                            ei[tid] = sol[b].ei.x;
+                            (ei + n_out)[tid] = sol[b].ei.y;
+                            (ei + 2 * n_out)[tid] = sol[b].ei.z;
                         }
-                        if (valid_out_refr) PRT_GSTORE_MASK(uniform_ptr(valid_out_refr + base_out + idx_out) + tid, (uint8_t)(alive ? 1 : 0));
                     }
+                    if (valid_out_refr) PRT_GSTORE_MASK(uniform_ptr(valid_out_refr + P * cum_out + row_out) + tid, (uint8_t)(alive ? 1 : 0));
+                }
+            }
+            {
+                double pv[PV];
+                pv[0] = xh.x; pv[1] = xh.y; pv[2] = xh.z;
+                uint8_t pb = alive ? 1 : 0;
+                if (GENERAL) {
+                    pv[3] = sol[1].k.x; pv[4] = sol[1].k.y; pv[5] = sol[1].k.z;
+                    pv[PV - 3] = sol[1].d.x; pv[PV - 2] = sol[1].d.y; pv[PV - 1] = sol[1].d.z;
+                } else {
+                    pv[3] = sol[1].kv.x; pv[4] = sol[1].kv.y; pv[5] = sol[1].kv.z;
+                    pb |= sol[1].is_e ? 2 : 0;
                 }
                 if (PARK_LDS) {
-                    double *slot = park_lds + (size_t)a * 9 * PRT_GENERAL_BLOCK + threadIdx.x;
-                    slot[0 * PRT_GENERAL_BLOCK] = xh.x; slot[1 * PRT_GENERAL_BLOCK] = xh.y; slot[2 * PRT_GENERAL_BLOCK] = xh.z;
-                    slot[3 * PRT_GENERAL_BLOCK] = sol[1].k.x; slot[4 * PRT_GENERAL_BLOCK] = sol[1].k.y; slot[5 * PRT_GENERAL_BLOCK] = sol[1].k.z;
-                    slot[6 * PRT_GENERAL_BLOCK] = sol[1].d.x; slot[7 * PRT_GENERAL_BLOCK] = sol[1].d.y; slot[8 * PRT_GENERAL_BLOCK] = sol[1].d.z;
-                    park_lds_alive[a * PRT_GENERAL_BLOCK + threadIdx.x] = alive ? 1 : 0;
+                    double *slot = park_lds + (size_t)a * PV * PRT_GENERAL_BLOCK + threadIdx.x;
+#pragma unroll
+                    for (int q = 0; q < PV; ++q) slot[q * PRT_GENERAL_BLOCK] = pv[q];
+                    park_lds_alive[a * PRT_GENERAL_BLOCK + threadIdx.x] = pb;
                 } else {
-                    double *slot = parked[a];
-                    slot[0] = xh.x; slot[1] = xh.y; slot[2] = xh.z;
-                    slot[3] = sol[1].k.x; slot[4] = sol[1].k.y; slot[5] = sol[1].k.z;
-                    slot[6] = sol[1].d.x; slot[7] = sol[1].d.y; slot[8] = sol[1].d.z;
-                    slot[9] = alive ? 1.0 : 0.0;
-                }
-                pending |= 1u << a;
-                k = sol[0].k;
-                d = sol[0].d;
-                d2 = 1.0;
-            } else {
-                const vec3 n = normal_from_grad<SHAPES>(sf, g, g2);
-                interact_isotropic(sf, n, k, valid);
-                d = k;
-                d2 = sf->n_after * sf->n_after;
-                if (store) {
-                    PRT_GLOBAL_AS double *krow = uniform_ptr(ko + idx_in);
-                    PRT_GSTORE(krow + tid, k.x);
-                    PRT_GSTORE(krow + n_out + tid, k.y);
-                    PRT_GSTORE(krow + 2 * n_out + tid, k.z);
-                    if (valid_out_refr) PRT_GSTORE_MASK(uniform_ptr(valid_out_refr + base_out + idx_in) + tid, (uint8_t)(valid ? 1 : 0));
+#pragma unroll
+                    for (int q = 0; q < PV; ++q) parked[a][q] = pv[q];
+                    parked[a][PV] = (double)pb;
                 }
             }
-            off_in += n_in;
-            off_out += n_out;
-            a = a_out;
-        }
-        if (pending == 0) break;
-        // resume the deepest parked child: level j, just behind the (j+1)-th crystal interface
-        const int j = 31 - __builtin_clz(pending);
-        pending &= ~(1u << j);
-        if (PARK_LDS) {
-            const double *slot = park_lds + (size_t)j * 9 * PRT_GENERAL_BLOCK + threadIdx.x;
-            x = v3(slot[0 * PRT_GENERAL_BLOCK], slot[1 * PRT_GENERAL_BLOCK], slot[2 * PRT_GENERAL_BLOCK]);
-            k = v3(slot[3 * PRT_GENERAL_BLOCK], slot[4 * PRT_GENERAL_BLOCK], slot[5 * PRT_GENERAL_BLOCK]);
-            d = v3(slot[6 * PRT_GENERAL_BLOCK], slot[7 * PRT_GENERAL_BLOCK], slot[8 * PRT_GENERAL_BLOCK]);
-            valid = park_lds_alive[j * PRT_GENERAL_BLOCK + threadIdx.x] != 0;
+            k = sol[0].k;
+            d = sol[0].d;
+            d2 = 1.0;
         } else {
-            const double *slot = parked[j];
-            x = v3(slot[0], slot[1], slot[2]);
-            k = v3(slot[3], slot[4], slot[5]);
-            d = v3(slot[6], slot[7], slot[8]);
-            valid = slot[9] != 0.0;
+            const vec3 n = normal_from_grad<SHAPES>(sf, g, g2);
+            interact_isotropic(sf, n, k, valid);
+            d = k;
+            d2 = sf->n_after * sf->n_after;
+            if (store) {
+                PRT_GLOBAL_AS double *krow = uniform_ptr(k_out + 3 * P * cum_out + row);
+                PRT_GSTORE(krow + tid, k.x);
+                PRT_GSTORE(krow + n_out + tid, k.y);
+                PRT_GSTORE(krow + 2 * n_out + tid, k.z);
+                if (valid_out_refr) PRT_GSTORE_MASK(uniform_ptr(valid_out_refr + P * cum_out + row) + tid, (uint8_t)(valid ? 1 : 0));
+            }
         }
-        d2 = 1.0;
-        L = (L & (((int64_t)1 << j) - 1)) | ((int64_t)1 << j);
-        // surface index and offsets behind that interface (wave-uniform scan of the table)
-        off_in = 0;
-        off_out = 0;
-        a = 0;
-        for (s = 0; a <= j; ++s) {
-            const bool cr = tab[s].mat_type == PRT_MAT_ANISOTROPIC;
-            off_in += P << a;
-            if (cr) ++a;
-            off_out += P << a;
-        }
+        w = wn;
     }
 }
 
@@ -745,7 +829,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_interact_aniso(
     // compaction used); rays compacted away earlier must stay dead.
     const uint8_t alive = alive_in ? alive_in[i] : (uint8_t)1;
     aniso_solution sol[2];
-    interact_anisotropic(sf, p, k, sol);
+    interact_anisotropic(sf, p, k, sol, e_re_out != nullptr);
     const int64_t M = 2 * N;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
