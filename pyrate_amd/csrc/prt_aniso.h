@@ -374,6 +374,25 @@ __device__ PRT_ANISO_FALLBACK_ATTR void four_solution_path(const REC *__restrict
 
 // n: unit surface normal in the frame of the medium (the fused march has it from the intersection it just did:
 // normal_from_grad; the per-surface entry point evaluates the shape at the caller's point)
+// Energy flux of a solution in a crystal with a SYMMETRIC real epsilon, without its eigenvector.  W = eps - (k.k) I +
+// k k^T is symmetric and singular at a solution; its adjugate is then  adj W = t e e^T  (e the unit null vector,
+// t = tr adj W the product of the two non-zero eigenvalues), so the part of k perpendicular to E is
+//     S0 = k - (k.e) e = k - (adj W) k / tr(adj W)
+// -- six cofactors, one matrix-vector product, no search for the best-conditioned pair of rows, no normalisation of
+// E.  Returned: T = tr(adj W) k - (adj W) k = tr(adj W) S0 and tr(adj W); the caller divides or compares signs.
+// |tr adj W| small against |W|^2 = the two sheets touch (the optic axes of a biaxial crystal): fall back to E.
+PRT_DEV void flux_symmetric(const double *__restrict__ eps, const vec3 &kv, vec3 &T, double &tr, double &fro2) {
+    const double k2 = dot(kv, kv);
+    const double w00 = eps[0] - k2 + kv.x * kv.x, w11 = eps[4] - k2 + kv.y * kv.y, w22 = eps[8] - k2 + kv.z * kv.z;
+    const double w01 = eps[1] + kv.x * kv.y, w02 = eps[2] + kv.x * kv.z, w12 = eps[5] + kv.y * kv.z;
+    const double a00 = w11 * w22 - w12 * w12, a11 = w00 * w22 - w02 * w02, a22 = w00 * w11 - w01 * w01;
+    const double a01 = w02 * w12 - w01 * w22, a02 = w01 * w12 - w02 * w11, a12 = w01 * w02 - w00 * w12;
+    tr = a00 + a11 + a22;
+    fro2 = w00 * w00 + w11 * w11 + w22 * w22 + 2.0 * (w01 * w01 + w02 * w02 + w12 * w12);
+    T = v3(tr * kv.x - (a00 * kv.x + a01 * kv.y + a02 * kv.z), tr * kv.y - (a01 * kv.x + a11 * kv.y + a12 * kv.z),
+           tr * kv.z - (a02 * kv.x + a12 * kv.y + a22 * kv.z));
+}
+
 // Wave vector and ray direction (global frame) of ONE solution in a medium whose epsilon is isotropic or uniaxial,
 // from its wave vector kv in the frame of the medium (before a mirror's sign) and the flag "extraordinary wave":
 //   u = kv (ordinary wave, eps = e I)   or   u = eps kv = eo kv + (ee - eo)(kv.c) c (extraordinary),   d = u / |u|
@@ -539,7 +558,7 @@ PRT_DEV void interact_anisotropic_n(const REC *__restrict__ sf, const vec3 &n,
         bool have = false;
         if (xi0sq > 0.0) have = quartic_roots_bairstow(pc, fast_sqrt(xi0sq), xr);
         const bool all_real = have && isfinite(xr[0]) && isfinite(xr[1]) && isfinite(xr[2]) && isfinite(xr[3]);
-        if (!__all(all_real)) {
+        if (__builtin_expect(!__all(all_real), 0)) {
             cplx z[4];
             quartic_roots(pc, z);
             // sort by real part (insertion), keep real ones
@@ -565,7 +584,7 @@ PRT_DEV void interact_anisotropic_n(const REC *__restrict__ sf, const vec3 &n,
         // wave through the complete path (four_solution_path).  Biaxial doublet, same arrays, builds interleaved: image
         // mode 0.180 -> 0.141 ms, path mode 0.219 -> 0.18 ms; 400-stack crystal stress campaign: 1 578 473 ray-surfaces, no deviation.
         bool fast = __all(all_real);
-        if (fast) {
+        if (__builtin_expect(fast, 1)) {
             double xa = mirror ? xr[0] : xr[2], xb = mirror ? xr[1] : xr[3];
 #pragma unroll
             for (int it = 0; it < 2; ++it) {  // Newton polish on the real polynomial, like below
@@ -578,21 +597,51 @@ PRT_DEV void interact_anisotropic_n(const REC *__restrict__ sf, const vec3 &n,
                 const double db = fb * fast_rcp(fpb);
                 if (isfinite(db) && fabs(db) < 1e-6 * fmax(1.0, fabs(xb))) xb -= db;
             }
-            vec3 Ea, Eb;
-            double sa, sb;
-            eigen_solution(sf, cls, kpa, n, xa, 0, Ea, sa);
-            eigen_solution(sf, cls, kpa, n, xb, 1, Eb, sb);
-            const bool ok = mirror ? (sa < 0.0 && sb < 0.0) : (sa > 0.0 && sb > 0.0);
-            fast = __all(ok);
-            if (fast) {  // ascending S.n inside the pair (material.py:147)
-                const bool sw = sb < sa;
-                x_out[0] = sw ? xb : xa;
-                x_out[1] = sw ? xa : xb;
-                e_out[0] = v3(sw ? Eb.x : Ea.x, sw ? Eb.y : Ea.y, sw ? Eb.z : Ea.z);
-                e_out[1] = v3(sw ? Ea.x : Eb.x, sw ? Ea.y : Eb.y, sw ? Ea.z : Eb.z);
+            // symmetric epsilon, no E wanted: flux and ray direction of the pair from the adjugate of W (flux_symmetric)
+            const bool sym = eps[1] == eps[3] && eps[2] == eps[6] && eps[5] == eps[7];
+            bool flux_ok = false;
+            if (!want_e && sym) {
+                const vec3 ka = v3(kpa.x + xa * n.x, kpa.y + xa * n.y, kpa.z + xa * n.z);
+                const vec3 kb = v3(kpa.x + xb * n.x, kpa.y + xb * n.y, kpa.z + xb * n.z);
+                vec3 Ta, Tb;
+                double ta, tb, fa2, fb2;
+                flux_symmetric(eps, ka, Ta, ta, fa2);
+                flux_symmetric(eps, kb, Tb, tb, fb2);
+                // S0.n = (T.n)/t;  S.n = S0.n / (1 + xi^2)
+                const double sa = dot(Ta, n) * ta, sb = dot(Tb, n) * tb;  // same sign as S.n (multiplied by t^2 > 0)
+                const bool ok = (fabs(ta) > 1e-9 * fa2) && (fabs(tb) > 1e-9 * fb2) &&
+                                (mirror ? (sa < 0.0 && sb < 0.0) : (sa > 0.0 && sb > 0.0));
+                flux_ok = __all(ok);
+                if (flux_ok) {
+                    // ascending S.n inside the pair: sb / (tb^2 (1 + xb^2)) < sa / (ta^2 (1 + xa^2))
+                    const bool sw = sb * (ta * ta) * (1.0 + xa * xa) < sa * (tb * tb) * (1.0 + xb * xb);
+                    const double ia = copysign(fast_rsqrt(dot(Ta, Ta)), ta), ib = copysign(fast_rsqrt(dot(Tb, Tb)), tb);
+                    const vec3 da = v3(Ta.x * ia, Ta.y * ia, Ta.z * ia), db = v3(Tb.x * ib, Tb.y * ib, Tb.z * ib);
+                    x_out[0] = sw ? xb : xa;
+                    x_out[1] = sw ? xa : xb;
+                    d_out[0] = v3(sw ? db.x : da.x, sw ? db.y : da.y, sw ? db.z : da.z);
+                    d_out[1] = v3(sw ? da.x : db.x, sw ? da.y : db.y, sw ? da.z : db.z);
+                    e_out[0] = e_out[1] = v3(0.0, 0.0, 0.0);
+                    have_d = true;
+                }
+            }
+            if (__builtin_expect(!flux_ok, 0)) {
+                vec3 Ea, Eb;
+                double sa, sb;
+                eigen_solution(sf, cls, kpa, n, xa, 0, Ea, sa);
+                eigen_solution(sf, cls, kpa, n, xb, 1, Eb, sb);
+                const bool ok = mirror ? (sa < 0.0 && sb < 0.0) : (sa > 0.0 && sb > 0.0);
+                fast = __all(ok);
+                if (fast) {  // ascending S.n inside the pair (material.py:147)
+                    const bool sw = sb < sa;
+                    x_out[0] = sw ? xb : xa;
+                    x_out[1] = sw ? xa : xb;
+                    e_out[0] = v3(sw ? Eb.x : Ea.x, sw ? Eb.y : Ea.y, sw ? Eb.z : Ea.z);
+                    e_out[1] = v3(sw ? Ea.x : Eb.x, sw ? Ea.y : Eb.y, sw ? Ea.z : Eb.z);
+                }
             }
         }
-        if (!fast) four_solution_path(sf, cls, kpa, n, pc, xr, mirror, x_out, e_out);
+        if (__builtin_expect(!fast, 0)) four_solution_path(sf, cls, kpa, n, pc, xr, mirror, x_out, e_out);
     }
 
 #pragma unroll
