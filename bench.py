@@ -20,16 +20,24 @@ uses, no scan.
 At N = 1 the default run then measures the other single-GPU configurations under
 the same contract (``configs`` on the same JSON line, each with its own roofline
 and cpu_baseline): configs[2] (even asphere, Newton intersection, 1e7 rays),
-configs[3] (anisotropic doublet, 1e6 -> 4e6 rays) and an XY-polynomial system
-(demo_asphere geometry, 12-term XYPolynomials, 1e7 rays).  ``--config X`` makes X
-the headline and measures X alone.  HBM traffic (roofline.traffic) is measured in
+configs[3] (anisotropic doublet, 1e6 -> 4e6 rays), an XY-polynomial system
+(demo_asphere geometry, 12-term XYPolynomials, 1e7 rays) and the reference's OWN
+benchmark workload (demos/demo_benchmark.py:47-78: 8 surfaces, divergent 10-degree
+bundle -- per-ray k0 / E0 arrays -- at 1e7 rays; BASELINE.md section 2 has the
+reference's rate on it).  ``--config X`` makes X the headline and measures X alone.
+Every configuration is VERIFIED on the arrays its timed launches wrote (``verified``:
+all rays on their surfaces, dispersion relation of every wave vector, a 1e4-ray
+sub-sample against the CPU oracle -- after the timed region, never inside it); the
+script exits non-zero when a deviation exceeds 1e-10.  HBM traffic (roofline.traffic) is measured in
 the same run: the script re-runs the marches under ``rocprofv3 --kernel-trace
 --pmc`` (FETCH_SIZE, WRITE_SIZE and the FP64 instruction counters in separate
 passes) and falls back to the figures on file (profiles/*.json) when rocprofv3 is
 not available.
 
-For N > 1 (configs[4]) the bundle of N x 1.25e7 rays is sharded by rays (weak
-scaling, no collective in the trace) and the five prescription wavelengths are
+For N > 1 (configs[4]) ONE bundle of 1e8 rays is sharded by rays over the GPUs
+(``--scaling strong``, the default: the same raster at every N, what BASELINE's
+north_star calls "1/2/4/8-GPU scaling on a 1e8-ray bundle"; ``--scaling weak``:
+1.25e7 rays per GPU; no collective in the trace) and the five prescription wavelengths are
 cycled over the steps; every step ends with that wavelength's spot statistics (one
 7-double all-reduce) AND its image-plane all-gather (49 B/ray, RCCL), both issued
 on a side stream so that they overlap the next wavelength's trace (two sets of
@@ -69,14 +77,16 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz
 PREWARM_LAUNCHES = 30
 PREWARM_MS = 50.0            # ... and at least this much device time of them (short kernels)
-SINGLE_GPU_CONFIGS = ("doublegauss", "asphere", "aniso", "xypoly")
+SINGLE_GPU_CONFIGS = ("doublegauss", "asphere", "aniso", "xypoly", "benchmark")
+VERIFY_TOL = 1e-10            # BASELINE.json north_star: 1e-10 relative on intersection points and direction cosines
+STRONG_SCALING_RAYS = 100_000_000   # "1/2/4/8-GPU scaling on a 1e8-ray bundle"
 T_START = time.perf_counter()
 
 
 # ------------------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------------------
-def make_workload(config, rays, dev, n_gpus=1, rank=0, multi=False, first_segment="uniform", align=1):
+def make_workload(config, rays, dev, n_gpus=1, rank=0, multi=False, first_segment="uniform", align=1, total_rays=None):
     """records + the device-resident input bundle of one BASELINE configuration.  Every bundle is the
     RectGrid disk raster of the reference, collimated, generated on the device (bit-identical to the host
     raster); rank r owns a contiguous, equal-stride slice of it (pdist.shard_range)."""
@@ -94,8 +104,7 @@ def make_workload(config, rays, dev, n_gpus=1, rank=0, multi=False, first_segmen
         workload = (("demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 double Gauss, "
                      "ConstantIndexGlass d-line), RectGrid disk bundle, BASELINE configs[1]") if not multi else
                     ("demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 double Gauss), 5 wavelengths "
-                     "cycled (Conrady indices), RectGrid disk bundle ray-sharded over the GPUs (1.25e7 rays per "
-                     "GPU: the 1e8-ray bundle at 8 GPUs), BASELINE configs[4]"))
+                     "cycled (Conrady indices), RectGrid disk bundle ray-sharded over the GPUs, BASELINE configs[4]"))
     elif config == "asphere":
         # configs[2]: demo_asphere.py geometry (stop, plane front, even asphere back, image) with the
         # test-suite coefficient set (tests/test_surf_shape.py:115-127) scaled to stay in-domain, bundle
@@ -120,12 +129,28 @@ def make_workload(config, rays, dev, n_gpus=1, rank=0, multi=False, first_segmen
         workload = ("demo_anisotropic_doublet: cemented doublet of two uniaxial crystals (calcite-like, tilted "
                     "axes), k-vector solve + ray doubling at two interfaces (1 -> 2 -> 4 rays), RectGrid disk "
                     "bundle r = 11.43 mm, BASELINE configs[3]")
+    elif config == "benchmark":
+        # the reference's own benchmark (demos/demo_benchmark.py:47-78): 8 surfaces, n = 1.7 / 1.5, a DIVERGENT bundle
+        # from the origin, half angle 10 degrees, RectGrid raster of angles -- every ray has its own k0 and E0
+        records = systems.benchmark_records()
+        bundle = dict(radius=systems.BENCHMARK_HALF_ANGLE)
+        workload = ("demo_benchmark: the reference's own benchmark system (8 Conic surfaces, n = 1.7 / 1.5 around a "
+                    "stop), divergent RectGrid bundle from the origin, half angle 10 deg, per-ray k0 / E0 arrays "
+                    "(demos/demo_benchmark.py:47-78; the reference runs it at 1e5 rays)")
     else:
         raise ValueError(config)
-    (_, n_total) = engine.rect_grid_count(rays * n_gpus, dev)
+    want = total_rays if total_rays is not None else rays * n_gpus
+    if config == "benchmark":
+        from pyrate_amd.sampling2d import raster as praster
+        tables = praster.RectGrid().device_tables(want)
+        (x0, k0, e0, n_total) = engine.raster_bundle_device(tables, "divergent", dev, radius=bundle["radius"])
+        return dict(config=config, records=records, record_sets=[records], x0=x0, k0=k0, e0=e0, uniform=None,
+                    n_total=n_total, n_local=n_total, lo=0, hi=n_total, S=len(records), workload=workload,
+                    bundle=bundle, first_segment="arrays")
+    (_, n_total) = engine.rect_grid_count(want, dev)
     (lo, hi) = pdist.shard_range(n_total, rank, n_gpus, align)
     uniform = first_segment == "uniform"
-    (x0, k0, e0, _) = systems.double_gauss_bundle_device(rays * n_gpus, dev, lo=lo, hi=hi, uniform=uniform, **bundle)
+    (x0, k0, e0, _) = systems.double_gauss_bundle_device(want, dev, lo=lo, hi=hi, uniform=uniform, **bundle)
     uni = None
     if uniform:
         (uni, k0, e0) = (k0, None, None)
@@ -181,7 +206,8 @@ def cpu_baseline(wl, budget_s=4.0, with_numpy=True):
     records = wl["records"]
     S = wl["S"]
     out = {"unit": "ray-surface-ops/s", "host_cpus": os.cpu_count()}
-    m_c = {"doublegauss": 4_000_000, "asphere": 4_000_000, "xypoly": 4_000_000, "aniso": 500_000}[wl["config"]]
+    m_c = {"doublegauss": 4_000_000, "asphere": 4_000_000, "xypoly": 4_000_000, "aniso": 500_000,
+           "benchmark": 4_000_000}[wl["config"]]
     (o, k, e0) = host_bundle(wl, m_c)
     n = o.shape[1]
     if seqtrace_c.supports(records):
@@ -230,6 +256,114 @@ def cpu_baseline(wl, budget_s=4.0, with_numpy=True):
             oracle.trace(records, o[:, :m_e], k[:, :m_e], e0[:, :m_e], with_efield=True)
         dt_e = time.perf_counter() - t2
         out["with_svd_efield"] = {"value": m_e * S / dt_e, "sample": "%d rays, %.1f s" % (m_e, dt_e)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# verification of what the timed launches wrote (after the timed region; oracle/ only as the checker)
+# ------------------------------------------------------------------------------------------------
+def verify_outputs(wl, sysd, ob, with_oracle, m=10_000):
+    """The arrays ``ob`` as the LAST timed launch left them, checked
+      * on every ray, on the device: every valid hit point lies on its surface (|z - F(x, y)| in the shape frame);
+        every outgoing wave vector satisfies the dispersion relation of its medium (isotropic: ||k| - n|; crystal:
+        |det(eps - k.k I + k k^T)| / |eps|^3); no NaN among rays flagged valid;
+      * on a sub-sample of ``m`` rays against the CPU oracle (C restatement where it covers the table, NumPy
+        otherwise): masks equal, hit points relative to max(|x|, 1 mm), wave vectors absolute.
+    Returns the ``verified`` object of the bench line; ``ok`` = everything within VERIFY_TOL."""
+    from pyrate_amd import _lib
+    res = sysd.views(ob)
+    recs = wl["records"]
+    dev = wl["x0"].device
+    n = wl["n_local"]
+    path = ob["mode"] == _lib.MODE_PATH
+    surfaces = list(range(len(recs))) if path else [len(recs) - 1]
+    f64 = dict(dtype=torch.float64, device=dev)
+
+    def worst(values, mask):
+        """max |values| over mask; a NaN under the mask counts as infinite"""
+        v = torch.where(mask, values.abs(), torch.zeros((), **f64))
+        v = torch.nan_to_num(v, nan=float("inf"))
+        return float(v.max().item()) if v.numel() else 0.0
+    (max_resid, max_disp, n_rays_checked) = (0.0, 0.0, 0)
+    for (j, s) in enumerate(surfaces):
+        rec = recs[s]
+        x = res.x_hit[j]
+        k = res.k_out[j]
+        v_hit = res.valid[j].bool()
+        v_out = res.valid_out[j].bool() if res.valid_out[j] is not None else v_hit
+        if res.nonconv is not None and res.nonconv[j] is not None:
+            v_hit = v_hit & ~res.nonconv[j].bool()        # (Newton cap hit: flagged, NaN hit point by contract)
+        g = torch.tensor(rec["g_shape"], **f64)
+        B = torch.tensor(rec["B_shape"], **f64)
+        p = B.T @ (x - g[:, None])
+        sh = rec["shape"]
+        if sh["type"] == "conic":
+            # c (x^2 + y^2 + (1 + cc) z^2) - 2 z = 0, gradient ~ 2 along z: half of it is the distance
+            resid = 0.5 * (sh["curv"] * (p[0] ** 2 + p[1] ** 2 + (1.0 + sh["cc"]) * p[2] ** 2) - 2.0 * p[2])
+        else:
+            (sag, _) = sysd.shape_eval(s, p[0].contiguous(), p[1].contiguous(), want_grad=False)
+            resid = p[2] - sag
+        max_resid = max(max_resid, worst(resid, v_hit))
+        mat = rec["material"]
+        Bm = torch.tensor(rec["B_mat"], **f64)
+        km = k if bool((Bm == torch.eye(3, **f64)).all()) else Bm.T @ k
+        if mat["type"] == "anisotropic":
+            eps = torch.tensor(np.asarray(mat["eps_re"], dtype=float), **f64)
+            k2 = (km ** 2).sum(0)
+            W = [[eps[a, b] + km[a] * km[b] - (k2 if a == b else 0.0) for b in range(3)] for a in range(3)]
+            det = (W[0][0] * (W[1][1] * W[2][2] - W[1][2] * W[2][1]) - W[0][1] * (W[1][0] * W[2][2] - W[1][2] * W[2][0])
+                   + W[0][2] * (W[1][0] * W[2][1] - W[1][1] * W[2][0]))
+            disp = det / float(torch.linalg.norm(eps)) ** 3
+        else:
+            disp = torch.sqrt((km ** 2).sum(0)) - float(mat["n"])
+        max_disp = max(max_disp, worst(disp, v_out))
+        n_rays_checked += int(x.shape[1])
+        del p, resid, disp, km
+    out = {"tolerance": VERIFY_TOL, "max_resid": max_resid, "max_abs_k": max_disp, "n_checked": n_rays_checked,
+           "what": "every ray-surface record of the last timed launch: |z - F(x, y)| of valid hit points (mm); "
+                   "dispersion relation of valid wave vectors (isotropic: ||k| - n|, crystal: |det W| / |eps|^3)",
+           "max_rel_x": None, "oracle_sample": None}
+    ok = max_resid <= VERIFY_TOL and max_disp <= VERIFY_TOL
+    if with_oracle and path:
+        from oracle import seqtrace_np as oracle
+        from oracle import seqtrace_c
+        idx = np.unique(np.linspace(0, n - 1, min(m, n)).astype(np.int64))
+        it = torch.from_numpy(idx).to(dev)
+        o = wl["x0"][:, it].cpu().numpy()
+        if wl["uniform"] is not None:
+            kk = np.repeat(np.array(wl["uniform"].k)[:, None], idx.size, axis=1)
+            ee = np.repeat(np.array(wl["uniform"].e_re)[:, None], idx.size, axis=1)
+        else:
+            (kk, ee) = (wl["k0"][:, it].cpu().numpy(), wl["e0"][:, it].cpu().numpy())
+        (o, kk, ee) = [np.ascontiguousarray(a) for a in (o, kk, ee)]
+        use_c = seqtrace_c.supports(recs) and (sysd.all_isotropic or seqtrace_c.load().seqtrace_c_has_zggev())
+        with np.errstate(all="ignore"):
+            ref = seqtrace_c.trace(recs, o, kk, ee) if use_c else oracle.trace(recs, o, kk, ee)
+        (rel_x, abs_k, mask_diff) = (0.0, 0.0, 0)
+        for s in range(len(recs)):
+            (b_in, b_out) = (res.n_in[s] // n, res.n_out[s] // n)
+            cols_in = torch.cat([it + b * n for b in range(b_in)])
+            cols_out = torch.cat([it + b * n for b in range(b_out)])
+            gx = res.x_hit[s][:, cols_in].cpu().numpy()
+            gk = res.k_out[s][:, cols_out].cpu().numpy()
+            gv = res.valid[s][cols_in].cpu().numpy().astype(bool)
+            gw = (res.valid_out[s][cols_out].cpu().numpy().astype(bool) if res.valid_out[s] is not None else None)
+            rv = np.asarray(ref[s]["valid"], dtype=bool)
+            rw = np.asarray(ref[s]["valid_out"], dtype=bool)
+            mask_diff += int(np.count_nonzero(gv != rv)) + (int(np.count_nonzero(gw != rw)) if gw is not None else 0)
+            if rv.any():
+                dx = np.linalg.norm(gx[:, rv] - ref[s]["x_hit"][:, rv], axis=0)
+                sc = np.maximum(np.linalg.norm(ref[s]["x_hit"][:, rv], axis=0), 1.0)
+                rel_x = max(rel_x, float(np.nan_to_num(dx / sc, nan=np.inf).max()))
+            if rw.any():
+                dk = np.abs(gk[:, rw] - np.real(ref[s]["k_out"][:, rw]))
+                abs_k = max(abs_k, float(np.nan_to_num(dk, nan=np.inf).max()))
+        out["max_rel_x"] = rel_x
+        out["max_abs_k"] = max(out["max_abs_k"], abs_k)
+        out["oracle_sample"] = {"rays": int(idx.size), "oracle": "oracle/seqtrace_c.c" if use_c else "oracle/seqtrace_np.py",
+                                "max_rel_x": rel_x, "max_abs_k": abs_k, "mask_mismatches": mask_diff}
+        ok = ok and rel_x <= VERIFY_TOL and abs_k <= VERIFY_TOL and mask_diff == 0
+    out["ok"] = bool(ok)
     return out
 
 
@@ -287,7 +421,7 @@ def kernel_label(config):
 # ------------------------------------------------------------------------------------------------
 # one single-GPU configuration: K timed steps + kernel time + roofline (+ CPU baseline)
 # ------------------------------------------------------------------------------------------------
-def measure_single(config, args, dev, rays, with_cpu):
+def measure_single(config, args, dev, rays, with_cpu, verify_oracle=None):
     from pyrate_amd import engine, placed, _lib
     wl = make_workload(config, rays, dev, first_segment=args.first_segment)
     sysd = engine.DeviceSystem(wl["records"], dev.index)
@@ -371,6 +505,14 @@ def measure_single(config, args, dev, rays, with_cpu):
                                 "memory_kind_of_inputs": input_kind,
                                 "inputs": "arena" if input_kind is not None else "torch allocator"},
            "roofline": hbm, "cpu_baseline": None, "_iso": iso, "_alg": alg, "_n_local": n_local}
+    # what the timed launches wrote, checked (outside every timed region; the oracle leg runs with the CPU baseline)
+    rec["verified"] = verify_outputs(wl, sysd, ob, with_oracle=with_cpu if verify_oracle is None else verify_oracle)
+    if config == "benchmark":
+        # context, not a published number (vs_baseline stays null): what the reference itself reaches on this workload
+        rec["reference_rate"] = {"value": 7.8e4, "unit": "ray-surface-ops/s",
+                                 "where": "BASELINE.md section 2: the reference's demo_benchmark.py system verbatim in the "
+                                          "survey container (8 vCPU, 99 693 rays, 8.94 s)",
+                                 "ratio": rec["value"] / 7.8e4}
     if with_cpu:
         rec["cpu_baseline"] = cpu_baseline(wl, budget_s=args.cpu_budget, with_numpy=(config == (args.config or "doublegauss")))
     del bufs, ob, x0, k0, e0
@@ -415,13 +557,18 @@ def finish_roofline(rec, traffic, flops, lookup=True):
         if fpl:
             ms = hbm["kernel_ms"]
             tf = fpl / (ms * 1e-3) / 1e12
-            rec["roofline"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": hbm["traffic"],
-                               "flops_per_launch": fpl, "flops_source": src, "kernel": hbm["kernel"],
-                               "kernel_ms": ms, "secondary": hbm,
-                               # all VALU wave instructions (selects, compares, address arithmetic included) at one
-                               # per 4 cycles and SIMD against the 1024 SIMDs at 2.4 GHz: what the kernel is bound by
-                               "valu_issue_frac": (valu * 4.0 / (1024 * 2.4e9) / (ms * 1e-3)) if valu else None}
+            fp64 = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": hbm["traffic"],
+                    "flops_per_launch": fpl, "flops_source": src, "kernel": hbm["kernel"], "kernel_ms": ms,
+                    # all VALU wave instructions (selects, compares, address arithmetic included) at one
+                    # per 4 cycles and SIMD against the 1024 SIMDs at 2.4 GHz
+                    "valu_issue_frac": (valu * 4.0 / (1024 * 2.4e9) / (ms * 1e-3)) if valu else None}
+            # the roof the launch is closer to is its bound (round 4: without the eigenvectors the path-mode march is
+            # a write-bound kernel like the isotropic one; image mode stays on the VALU side)
+            if hbm["frac"] >= max(fp64["frac"], fp64["valu_issue_frac"] or 0.0):
+                rec["roofline"] = dict(hbm, secondary=fp64)
+            else:
+                rec["roofline"] = dict(fp64, secondary=hbm)
         else:
             hbm["note"] = "FP64-VALU bound kernel; no flop count available, HBM fraction shown"
     for k in [k for k in rec if k.startswith("_")]:
@@ -457,15 +604,36 @@ def pmc_inner(args, dev):
         torch.cuda.empty_cache()
 
 
+def _is_march(kernel_name):
+    return "k_trace_general<" in kernel_name or "k_trace_iso<" in kernel_name
+
+
 def _pmc_config_of(kernel_name):
-    """which bench config a march launch belongs to, from its instantiation: k_trace_general -> aniso;
-    k_trace_iso<MODE, VEC_IN, VEC_OUT, SHAPES, ...> with SHAPES 0 / 1 / 2 -> doublegauss / asphere / xypoly"""
+    """fall-back when the counter file has no dispatch ids: which bench config a march launch belongs to, from its
+    instantiation: k_trace_general -> aniso; k_trace_iso<MODE, VEC_IN, VEC_OUT, SHAPES, LDS, MOMENTS, UNI, ...> with
+    SHAPES 1 / 2 -> asphere / xypoly, SHAPES 0 -> doublegauss (uniform first segment) or benchmark (arrays)"""
     if "k_trace_general<" in kernel_name:
         return "aniso"
-    m = re.search(r"k_trace_iso<\s*\d+\s*,\s*\w+\s*,\s*\w+\s*,\s*(\d+)", kernel_name)
+    m = re.search(r"k_trace_iso<\s*\d+\s*,\s*\w+\s*,\s*\w+\s*,\s*(\d+)\s*,\s*\w+\s*,\s*\w+\s*,\s*(\w+)", kernel_name)
     if m:
-        return {0: "doublegauss", 1: "asphere", 2: "xypoly"}.get(int(m.group(1)))
+        sh = int(m.group(1))
+        if sh == 0:
+            return "doublegauss" if m.group(2) in ("1", "true") else "benchmark"
+        return {1: "asphere", 2: "xypoly"}.get(sh)
     return None
+
+
+def _pmc_rows_by_config(rows, configs):
+    """[(config, counter, value)]: pmc_inner launches PMC_LAUNCHES marches per config, in the order of ``configs`` --
+    the i-th march dispatch of the process belongs to configs[i // PMC_LAUNCHES]"""
+    march = [r for r in rows if _is_march(r.get("Kernel_Name", ""))]
+    if march and all(r.get("Dispatch_Id", "").strip().isdigit() for r in march):
+        ids = sorted(set(int(r["Dispatch_Id"]) for r in march))
+        if len(ids) == PMC_LAUNCHES * len(configs):
+            rank_of = {d: i for (i, d) in enumerate(ids)}
+            return [(configs[rank_of[int(r["Dispatch_Id"])] // PMC_LAUNCHES], r["Counter_Name"], float(r["Counter_Value"]))
+                    for r in march]
+    return [(_pmc_config_of(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"])) for r in march]
 
 
 def measure_pmc_live(configs, args, rays_of, timeout_s):
@@ -497,10 +665,9 @@ def measure_pmc_live(configs, args, rays_of, timeout_s):
                                  % ("+".join(counters), res.returncode, res.stderr.decode(errors="replace")[-300:])}, {}
             for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
                 with open(path, newline="") as fh:
-                    for row in csv.DictReader(fh):
-                        cfg = _pmc_config_of(row.get("Kernel_Name", ""))
+                    for (cfg, cname, val) in _pmc_rows_by_config(list(csv.DictReader(fh)), list(configs)):
                         if cfg in configs:
-                            sums.setdefault((cfg, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+                            sums.setdefault((cfg, cname), []).append(val)
     except (subprocess.TimeoutExpired, OSError) as exc:
         return {"error": "rocprofv3 PMC passes: %s" % exc}, {}
     finally:
@@ -578,7 +745,16 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="N = 1: do not measure the other configurations")
     ap.add_argument("--rays", type=int, default=None,
                     help="requested rays per GPU (default: 1e7 at N = 1 = BASELINE configs[1]/[2]; 1e6 for "
-                         "aniso; 1.25e7 at N > 1, so that 8 GPUs trace the 1e8-ray bundle of configs[4])")
+                         "aniso; N > 1: with --scaling weak, 1.25e7, so that 8 GPUs trace the 1e8-ray bundle of configs[4])")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="N > 1: strong (default) = ONE bundle of --rays-total rays (1e8: BASELINE's '1/2/4/8-GPU scaling "
+                         "on a 1e8-ray bundle') split over the N GPUs, the same raster at every N; weak = --rays rays "
+                         "per GPU (1.25e7: the 1e8-ray bundle at 8 GPUs)")
+    ap.add_argument("--rays-total", type=int, default=None,
+                    help="N > 1, --scaling strong: rays of the whole bundle (default 1e8)")
+    ap.add_argument("--no-scaling-point", action="store_true",
+                    help="N = 1 default run: do not also trace the 1e8-ray bundle of the multi-GPU protocol on this one "
+                         "GPU (`scaling_point` of the line: what N = 1 of --scaling strong costs)")
     ap.add_argument("--first-segment", choices=["uniform", "arrays"], default="uniform",
                     help="how the collimated bundle's k0 / E0 reach the march: as one vector each (default; "
                          "prt_trace_ex, only x0 is loaded: 24 B/ray) or as per-ray arrays (72 B/ray)")
@@ -670,6 +846,7 @@ def main():
         pmc_inner(args, dev)
         return
 
+    exit_code = 0
     json_fd = [1]
     base_line = {"metric": "ray_surface_ops_per_s", "unit": "ray-surface-ops/s", "n_gpus": world, "steps": args.steps,
                  "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -694,6 +871,9 @@ def main():
     from pyrate_amd import build as prt_build, _lib
     if use_dist:
         out = run_multi(args, dev, world, rank, local_rank, watchdog)
+        if out is not None and not (out["verified"]["ok"] and out["verified"]["all_ranks_ok"]):
+            out["error"] = "verification failed (deviation above %g)" % VERIFY_TOL
+            exit_code = 4
     else:
         configs = [headline]
         if args.config is None and not args.headline_only and args.mode == "path":
@@ -724,6 +904,23 @@ def main():
         recs = [finish_roofline(r, traffic, flops, lookup=args.traffic != "none") for r in recs]
         head = recs[0]
         out = dict(base_line)
+        scaling_point = None
+        if args.config is None and not args.headline_only and not args.no_scaling_point and args.mode == "path" \
+                and args.rays is None:
+            # the bundle of the multi-GPU protocol (--scaling strong: 1e8 rays, 61 GB of path arrays) on this one GPU
+            watchdog.stage = "scaling point (1e8 rays)"
+            try:
+                sp = measure_single("doublegauss", args, dev, STRONG_SCALING_RAYS, with_cpu=False, verify_oracle=False)
+                scaling_point = {"what": "BASELINE configs[4]'s bundle (--scaling strong: %d rays) traced by ONE GPU, one "
+                                         "wavelength: the N = 1 point of the strong-scaling curve (the headline above is "
+                                         "configs[1] at 1e7 rays)" % sp["rays"],
+                                 "rays_total": sp["rays"], "value": sp["value"], "ms_per_step": sp["ms_per_step"],
+                                 "kernel_ms": sp["roofline"]["kernel_ms"], "hbm_frac": sp["roofline"]["frac"],
+                                 "verified": sp["verified"], "output_placement": sp["output_placement"]}
+                if not sp["verified"]["ok"]:
+                    recs.append(dict(name="scaling_point", verified=sp["verified"]))
+            except (RuntimeError, MemoryError) as exc:          # a device too small / too busy for 66 GB
+                scaling_point = {"error": "not measured: %s" % str(exc)[:200]}
         out.update({"value": head["value"], "ms_per_step": head["ms_per_step"],
                     "config": {"workload": head["workload"], "rays_per_gpu": head["rays"], "rays_total": head["rays"],
                                "surfaces": head["surfaces"], "rays_per_surface": head["rays_per_surface"],
@@ -733,9 +930,15 @@ def main():
                                "output_placement": dict(head["output_placement"], arena=arena_stats),
                                "build": prt_build.build_info(_lib.LIB_PATH),
                                "wall_s": None},
-                    "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"],
+                    "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"], "verified": head["verified"],
+                    "scaling_point": scaling_point,
                     # every single-GPU configuration of BASELINE.json measured by this run, headline first
                     "configs": recs})
+        bad = [r["name"] for r in recs if not r["verified"]["ok"]]
+        recs[:] = [r for r in recs if r["name"] != "scaling_point"]
+        if bad:
+            out["error"] = "verification failed (deviation above %g or a mask mismatch): %s" % (VERIFY_TOL, ", ".join(bad))
+            exit_code = 4
         out["config"]["wall_s"] = time.perf_counter() - T_START
     if use_dist:
         dist.barrier()
@@ -748,6 +951,8 @@ def main():
         sys.stdout.flush()
         os.write(json_fd[0], (json.dumps(out) + "\n").encode())
         sys.stdout.flush()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -757,13 +962,18 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
     from pyrate_amd import build as prt_build, engine, placed, _lib
     from pyrate_amd import distributed as pdist
     n_gpus = world
+    strong = args.scaling == "strong"
+    if strong and args.rays is not None:
+        raise SystemExit("--scaling strong (the default for N > 1) takes --rays-total (rays of the whole bundle); "
+                         "--rays (per GPU) goes with --scaling weak")
     rays = args.rays if args.rays is not None else 12_500_000
+    total_rays = (args.rays_total if args.rays_total is not None else STRONG_SCALING_RAYS) if strong else None
     watchdog.stage = "bundle generation"
     # shards of one common stride that is a multiple of 512 rays: rank r's slot of a gathered row starts on a 4-KiB
     # boundary, so the march can write its image plane straight into it (ImagePlaneGather.own_rows)
     align = 512
     wl = make_workload("doublegauss", rays, dev, n_gpus=n_gpus, rank=rank, multi=True,
-                       first_segment=args.first_segment, align=align)
+                       first_segment=args.first_segment, align=align, total_rays=total_rays)
     (x0, k0, e0d, uni) = (wl["x0"], wl["k0"], wl["e0"], wl["uniform"])
     (n_total, n_local, S) = (wl["n_total"], wl["n_local"], wl["S"])
     sysds = [engine.DeviceSystem(r, local_rank) for r in wl["record_sets"]]
@@ -937,6 +1147,13 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
     watchdog.stage = "kernel timing"
     kernel_ms = sysd.trace_timed(x0, k0, bufs[0], max(args.steps, 5), e0d, uniform=uni)
     torch.cuda.synchronize()
+    # every rank checks what that launch wrote for its shard (all rays on their surfaces, |k| = n); rank 0 reports
+    # its own figures and whether ALL ranks passed
+    watchdog.stage = "verification"
+    verified = verify_outputs(dict(wl, records=wl["record_sets"][0]), sysd, bufs[0], with_oracle=(rank == 0 and not args.no_cpu_baseline))
+    flag = torch.tensor([1.0 if verified["ok"] else 0.0], dtype=torch.float64, device=(dev if args.backend == "nccl" else "cpu"))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    verified["all_ranks_ok"] = bool(flag.item() > 0.5)
     ops_total = n_total * S * args.steps
     if rank != 0:
         return None
@@ -964,13 +1181,20 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
                 "value_with_gather": [n_total * S / (max(kernel_ms, g) * 1e-3) for g in gather_ms],
                 "value_without_gather": n_total * S / (kernel_ms * 1e-3),
                 "basis": "DESIGN.md section 6: step = max(this rank's march, image-plane all-gather of 49 B x %d rays "
-                         "per peer over one xGMI link each at 0.65-0.8 x 153 GB/s); weak scaling, so without the "
-                         "gather the value grows with N" % n_pad}
+                         "per peer over one xGMI link each at 0.65-0.8 x 153 GB/s); %s" % (n_pad, (
+                             "strong scaling: the march shrinks with N, the gather per peer too (49 B x N_total / N), "
+                             "but every rank still RECEIVES 49 B x N_total (N - 1) / N" if strong else
+                             "weak scaling, so without the gather the value grows with N"))}
     return dict({"metric": "ray_surface_ops_per_s", "value": ops_total / elapsed, "unit": "ray-surface-ops/s",
                  "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
                  "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-                 "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"},
-                config={"workload": wl["workload"], "rays_per_gpu": n_local, "rays_total": n_total, "surfaces": S,
+                 "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"},
+                config={"workload": wl["workload"] + (
+                            " -- ONE bundle of %d rays split over %d GPU(s) (strong scaling; the N = 1 line of the default "
+                            "`python bench.py` is BASELINE configs[1] at 1e7 rays and carries this bundle's 1-GPU rate "
+                            "as `scaling_point`)" % (n_total, n_gpus) if strong else
+                            " -- %d rays per GPU (weak scaling)" % n_local),
+                        "rays_per_gpu": n_local, "rays_total": n_total, "surfaces": S,
                         "rays_per_surface": None, "mode": args.mode,
                         "first_segment": "uniform k0 / E0" if uni is not None else "arrays x0, k0, E0",
                         "record_bytes": record_bytes,
@@ -1009,7 +1233,7 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
                         "host_issue_ms_per_step": host_issue_ms, "trace_stream": args.trace_stream,
                         "image_plane_spot": spot,
                         "build": prt_build.build_info(_lib.LIB_PATH)},
-                roofline=roofline, cpu_baseline=None)
+                roofline=roofline, cpu_baseline=None, verified=verified)
 
 
 if __name__ == "__main__":

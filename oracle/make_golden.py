@@ -132,32 +132,45 @@ def case_double_gauss():
     dump_case("double_gauss_wide", s, seq, disk_bundle(400, 20.0, -10.0, field_deg=12.0))
     # F-line indices through the Conrady fit (config 5 uses per-wavelength indices)
     (s2, seq2) = build_rotationally_symmetric_optical_system(systems.double_gauss_tuples(486.1e-6))
-    dump_case("double_gauss_Fline", s2, seq2, disk_bundle(128, 5.0, -10.0, field_deg=-3.0, wave=486.1e-6))
+    dump_case("double_gauss_Fline", s2, seq2, disk_bundle(160, 5.0, -10.0, field_deg=-3.0, wave=486.1e-6))
     # default E field (E = ey): the first segment's Poynting direction is NOT k/|k|
-    dump_case("double_gauss_defaultE", s, seq, disk_bundle(128, 4.0, -10.0, field_deg=4.0, efield=None))
+    dump_case("double_gauss_defaultE", s, seq, disk_bundle(160, 4.0, -10.0, field_deg=4.0, efield=None))
+
+
+def case_benchmark():
+    """the reference's OWN benchmark workload, demos/demo_benchmark.py:47-78: the 8-surface n = 1.7 / 1.5 system and
+    the DIVERGENT 10-degree RectGrid bundle of OpticalSystemAnalysis.divergent_bundle (per-ray wave vectors and E
+    fields: the only BASELINE workload whose first segment is not uniform); BASELINE.md section 2 holds the rate the
+    reference reaches on it"""
+    from pyrateoptics import build_rotationally_symmetric_optical_system
+    from pyrateoptics.raytracer.globalconstants import degree, standard_wavelength
+    (s, seq) = build_rotationally_symmetric_optical_system(systems.benchmark_tuples())
+    osa = OpticalSystemAnalysis(s, seq, name="Analysis")
+    (x0, k0, e0) = osa.divergent_bundle(300, {"radius": 10. * degree, "raster": raster.RectGrid()})
+    dump_case("benchmark_divergent", s, seq, RayBundle(x0=x0, k0=k0, Efield0=e0, wave=standard_wavelength))
 
 
 def case_asphere():
     for (tag, coeffs, curv, cc) in (("mild", [0.0, 1e-7, -1e-10], -1. / 50., -1.),
                                     ("strong", [1e-3, -1e-6, 1e-8], -1. / 30., -1.5)):
         (s, seq) = build_simple_optical_system(systems.asphere_builduplist(coeffs, curv, cc))
-        dump_case("asphere_%s_axis" % tag, s, seq, disk_bundle(96, 11.43, -5.0))
-        dump_case("asphere_%s_field5" % tag, s, seq, disk_bundle(96, 9.0, -5.0, field_deg=5.0))
+        dump_case("asphere_%s_axis" % tag, s, seq, disk_bundle(160, 11.43, -5.0))
+        dump_case("asphere_%s_field5" % tag, s, seq, disk_bundle(160, 9.0, -5.0, field_deg=5.0))
 
 
 def case_xypoly():
     (s, seq) = build_simple_optical_system(zoo.xypoly_builduplist())
-    dump_case("xypoly_axis", s, seq, disk_bundle(96, 8.0, -5.0))
-    dump_case("xypoly_field5", s, seq, disk_bundle(96, 8.0, -5.0, field_deg=5.0))
+    dump_case("xypoly_axis", s, seq, disk_bundle(160, 8.0, -5.0))
+    dump_case("xypoly_field5", s, seq, disk_bundle(160, 8.0, -5.0, field_deg=5.0))
     # the XY-polynomial system bench.py times (`configs`: xypoly), with its bundle geometry
     (s, seq) = build_simple_optical_system(systems.xypoly_builduplist())
-    dump_case("xypoly_bench_field5", s, seq, disk_bundle(96, 9.0, -5.0, field_deg=5.0))
+    dump_case("xypoly_bench_field5", s, seq, disk_bundle(160, 9.0, -5.0, field_deg=5.0))
 
 
 def case_biconic():
     (s, seq) = build_simple_optical_system(zoo.biconic_builduplist())
-    dump_case("biconic_axis", s, seq, disk_bundle(96, 8.0, -5.0))
-    dump_case("biconic_field5", s, seq, disk_bundle(96, 8.0, -5.0, field_deg=5.0))
+    dump_case("biconic_axis", s, seq, disk_bundle(160, 8.0, -5.0))
+    dump_case("biconic_field5", s, seq, disk_bundle(160, 8.0, -5.0, field_deg=5.0))
 
 
 def case_zernike():
@@ -165,11 +178,11 @@ def case_zernike():
     LinearCombination(Asphere + ZernikeFringe) mirror, and the reference's getSag / getGrad of these
     shapes on scattered points (no point at the origin of a Zernike frame: 0/0 there)"""
     (s, seq) = build_simple_optical_system(zoo.zernike_builduplist("Fringe"))
-    dump_case("zernike_fringe_field3", s, seq, disk_bundle(80, 7.5, -5.0, field_deg=3.0))
+    dump_case("zernike_fringe_field3", s, seq, disk_bundle(150, 7.5, -5.0, field_deg=3.0))
     (s, seq) = build_simple_optical_system(zoo.zernike_builduplist("ANSI"))
-    dump_case("zernike_ansi_field2", s, seq, disk_bundle(80, 7.5, -5.0, field_deg=-2.0))
+    dump_case("zernike_ansi_field2", s, seq, disk_bundle(150, 7.5, -5.0, field_deg=-2.0))
     (s, seq) = zoo.zernike_combination_system(REFAPI)
-    dump_case("zernike_combination_mirror", s, seq, disk_bundle(80, 8.0, 0.0, field_deg=1.5))
+    dump_case("zernike_combination_mirror", s, seq, disk_bundle(150, 8.0, 0.0, field_deg=1.5))
     rng = np.random.RandomState(4)
     (x, y) = (rng.uniform(-8, 8, 64), rng.uniform(-8, 8, 64))
     out = {"x": x, "y": y}
@@ -202,7 +215,7 @@ def case_gridsag():
     """GridSag: traced system + the reference's getSag / getGrad on scattered points, some of
     them outside the grid (FITPACK clamps the arguments)"""
     (s, seq) = zoo.gridsag_system(REFAPI)
-    dump_case("gridsag_field2", s, seq, disk_bundle(80, 7.0, -3.0, field_deg=2.0))
+    dump_case("gridsag_field2", s, seq, disk_bundle(150, 7.0, -3.0, field_deg=2.0))
     lc = LocalCoordinates.p(name="gshape")
     sh = GridSag.p(lc, zoo.gridsag_data())
     rng = np.random.RandomState(9)
@@ -232,11 +245,11 @@ def case_prism():
         rd = dict(zoo.PRISM_RAYS)
         rd["raster"] = raster.MeridionalFan()
         osa = OpticalSystemAnalysis(s, seq)
-        osa.aim(20, rd, bundletype="collimated", wave=wave)
+        osa.aim(128, rd, bundletype="collimated", wave=wave)
         ib = osa.initial_bundles[0]
         dump_case("prism_" + tag, s, seq, RayBundle(np.array(ib.x[0]), np.array(ib.k[0]), np.array(ib.Efield[0]),
                                                     wave=wave))
-        rp = raytrace(s, seq, 20, rd, wave=wave)[0][0]
+        rp = raytrace(s, seq, 128, rd, wave=wave)[0][0]
         assert np.array_equal(rp.raybundles[-1].x, osa.trace()[0][0].raybundles[-1].x)
 
 
@@ -302,12 +315,12 @@ def case_mirror():
     """all rays valid (the reference's reflect crashes as soon as one ray is invalid,
     SURVEY.md section 7)."""
     (s, seq) = build_simple_optical_system(zoo.mirrors_builduplist())
-    dump_case("mirrors", s, seq, disk_bundle(128, 10.0, -5.0, field_deg=1.0))
+    dump_case("mirrors", s, seq, disk_bundle(160, 10.0, -5.0, field_deg=1.0))
 
 
 def case_hud():
     (s, seq) = build_simple_optical_system(zoo.hud_like_builduplist())
-    dump_case("hud_biconic_mirrors", s, seq, disk_bundle(120, 9.0, -5.0, field_deg=1.0))
+    dump_case("hud_biconic_mirrors", s, seq, disk_bundle(160, 9.0, -5.0, field_deg=1.0))
 
 
 def case_two_elements():
@@ -325,24 +338,24 @@ def biaxial_eps():
 def case_aniso():
     # (i) the demo's isotropic-as-anisotropic tensors (demo_anisotropic_doublet.py:92-93)
     (s, seq) = zoo.aniso_doublet(REFAPI, 1.5168 ** 2 * np.eye(3), 1.6727 ** 2 * np.eye(3))
-    dump_case("aniso_doublet_isoeps", s, seq, disk_bundle(60, 11.43, -5.0))
+    dump_case("aniso_doublet_isoeps", s, seq, disk_bundle(160, 11.43, -5.0))
     # (ii) birefringent: calcite-like uniaxial, axis tilted 0.3 rad about x; second crystal
     #      uniaxial with another axis
     c = systems.CALCITE_TILTED
     eps1 = systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"])
     eps2 = systems.uniaxial_eps(1.6727, 1.60, (math.sin(0.2), 0.0, math.cos(0.2)))
     (s, seq) = zoo.aniso_doublet(REFAPI, eps1, eps2)
-    dump_case("aniso_doublet_uniaxial", s, seq, disk_bundle(60, 11.43, -5.0, field_deg=2.0))
-    dump_case("aniso_doublet_uniaxial_split", s, seq, disk_bundle(30, 11.43, -5.0), splitup=True)
+    dump_case("aniso_doublet_uniaxial", s, seq, disk_bundle(160, 11.43, -5.0, field_deg=2.0))
+    dump_case("aniso_doublet_uniaxial_split", s, seq, disk_bundle(160, 11.43, -5.0), splitup=True)
     # rays outside the lens apertures: flagged invalid by propagate, but the anisotropic
     # refract does no filtering and starts a fresh all-valid bundle (ray.py:68)
-    dump_case("aniso_doublet_uniaxial_clipped", s, seq, disk_bundle(60, 14.5, -5.0, field_deg=1.0))
+    dump_case("aniso_doublet_uniaxial_clipped", s, seq, disk_bundle(160, 14.5, -5.0, field_deg=1.0))
     # rays removed by an ISOTROPIC refraction (stop with aperture) before the crystal stay removed
     (s, seq) = zoo.aniso_doublet(REFAPI, eps1, eps2, stop_radius=8.0)
-    dump_case("aniso_doublet_uniaxial_stopped", s, seq, disk_bundle(60, 11.43, -5.0, field_deg=1.0))
+    dump_case("aniso_doublet_uniaxial_stopped", s, seq, disk_bundle(160, 11.43, -5.0, field_deg=1.0))
     # (iii) biaxial crystal (three different principal values, rotated)
     (s, seq) = zoo.aniso_doublet(REFAPI, biaxial_eps(), 1.6727 ** 2 * np.eye(3))
-    dump_case("aniso_doublet_biaxial", s, seq, disk_bundle(60, 11.43, -5.0, field_deg=-2.0))
+    dump_case("aniso_doublet_biaxial", s, seq, disk_bundle(160, 11.43, -5.0, field_deg=-2.0))
 
 
 def case_aniso_mirror():
@@ -351,10 +364,10 @@ def case_aniso_mirror():
     c = systems.CALCITE_TILTED
     eps = systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"])
     (s, seq) = zoo.crystal_mirror(REFAPI, eps)
-    dump_case("aniso_mirror_uniaxial", s, seq, disk_bundle(60, 4.0, -5.0, field_deg=3.0))
-    dump_case("aniso_mirror_uniaxial_split", s, seq, disk_bundle(30, 4.0, -5.0), splitup=True)
+    dump_case("aniso_mirror_uniaxial", s, seq, disk_bundle(160, 4.0, -5.0, field_deg=3.0))
+    dump_case("aniso_mirror_uniaxial_split", s, seq, disk_bundle(160, 4.0, -5.0), splitup=True)
     (s, seq) = zoo.crystal_mirror(REFAPI, biaxial_eps(), tilt_deg=7.0)
-    dump_case("aniso_mirror_biaxial", s, seq, disk_bundle(60, 4.0, -5.0, field_deg=-2.0))
+    dump_case("aniso_mirror_biaxial", s, seq, disk_bundle(160, 4.0, -5.0, field_deg=-2.0))
 
 
 def absorbing_eps():
@@ -371,16 +384,16 @@ def case_aniso_absorbing():
     refraction into a second absorbing crystal, end plane inside)"""
     (e1, e2) = absorbing_eps()
     (s, seq) = zoo.crystal_inside(REFAPI, e1, mirror=True)
-    dump_case("aniso_absorbing_mirror", s, seq, disk_bundle(24, 4.0, -5.0, field_deg=3.0))
+    dump_case("aniso_absorbing_mirror", s, seq, disk_bundle(160, 4.0, -5.0, field_deg=3.0))
     (s, seq) = zoo.crystal_inside(REFAPI, e1, mirror=False, eps2=e2)
-    dump_case("aniso_absorbing_two_crystals", s, seq, disk_bundle(24, 4.0, -5.0, field_deg=-2.0))
-    dump_case("aniso_absorbing_two_crystals_split", s, seq, disk_bundle(12, 4.0, -5.0), splitup=True)
+    dump_case("aniso_absorbing_two_crystals", s, seq, disk_bundle(160, 4.0, -5.0, field_deg=-2.0))
+    dump_case("aniso_absorbing_two_crystals_split", s, seq, disk_bundle(160, 4.0, -5.0), splitup=True)
     # ... and where the sequence ENDS in an isotropic medium (the complex k behind the last surface is unique): the
     # folded beam of the absorbing slab leaving into air; a singlet in front of an absorbing detector (complex n)
     (s, seq) = zoo.crystal_mirror(REFAPI, e1)
-    dump_case("aniso_absorbing_exit", s, seq, disk_bundle(24, 4.0, -5.0, field_deg=3.0))
+    dump_case("aniso_absorbing_exit", s, seq, disk_bundle(160, 4.0, -5.0, field_deg=3.0))
     (s, seq) = zoo.absorbing_detector(REFAPI)
-    dump_case("absorbing_detector", s, seq, disk_bundle(40, 4.0, -5.0, field_deg=12.0))
+    dump_case("absorbing_detector", s, seq, disk_bundle(160, 4.0, -5.0, field_deg=12.0))
 
 
 def case_zmx():
@@ -395,7 +408,7 @@ def case_zmx():
     zp = ZMXParser(dst, name="ZMXParser")
     lctmp = LocalCoordinates.p("tmp")
     (s, seq) = zp.create_optical_system({"BK7": ConstantIndexGlass.p(lctmp, 1.5168)})
-    dump_case("zmx_lenssystem", s, seq, disk_bundle(100, 7.0, 0.0, field_deg=1.0, wave=0.55e-3))
+    dump_case("zmx_lenssystem", s, seq, disk_bundle(160, 7.0, 0.0, field_deg=1.0, wave=0.55e-3))
     with open(os.path.join(OUT, "zmx_lenssystem_field.json"), "w") as f:
         fd = zp.read_field()
         json.dump({"field": fd, "bundles": zp.create_initial_bundle(),
@@ -468,7 +481,7 @@ def case_glasscatalog():
             out["error_none"] = str(err)
         tuples = zoo.catalog_doublet_tuples(names)
         (s, seq) = build_rotationally_symmetric_optical_system(tuples, material_db_path=tmp)
-        dump_case("catalog_doublet", s, seq, disk_bundle(80, 9.0, -5.0, field_deg=2.0, wave=0.6563e-3))
+        dump_case("catalog_doublet", s, seq, disk_bundle(150, 9.0, -5.0, field_deg=2.0, wave=0.6563e-3))
     with open(os.path.join(OUT, "glasscatalog.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("glasscatalog.json: %d pages" % len(names))
@@ -508,7 +521,7 @@ def case_spd():
             sp = SPDParser(spdfile, name="synthetic")
             (s, seq) = sp.create_optical_system(options={"gcat": GlassCatalog(tmp), "db_path": tmp})
         out["synthetic"] = _spd_numbers(sp.psys)
-        dump_case("spd_double_gauss_Fline", s, seq, disk_bundle(100, 5.0, -10.0, field_deg=3.0, wave=486.1e-6))
+        dump_case("spd_double_gauss_Fline", s, seq, disk_bundle(160, 5.0, -10.0, field_deg=3.0, wave=486.1e-6))
     for name in ("double_gauss_rudolph_1897_v2.spd", "Thorlabs_AC127_050_A.spd", "Thorlabs_LBF254_050_A.spd"):
         with contextlib.redirect_stdout(io.StringIO()):
             sp = SPDParser(os.path.join(REF, "demos", "data", name), name=name)
@@ -523,6 +536,7 @@ def main():
     np.random.seed(0)
     case_doublet()
     case_double_gauss()
+    case_benchmark()
     case_asphere()
     case_xypoly()
     case_biconic()

@@ -186,6 +186,41 @@ def double_gauss_bundle_device(nrays, device, rpup=5.0, z0=-10.0, field_deg=0.0,
                                            lo=lo, hi=hi, uniform=uniform)
 
 
+# ---- the reference's own benchmark (demos/demo_benchmark.py:47-78) -----------------
+BENCHMARK_HALF_ANGLE = 10.0 * math.pi / 180.    # "radius": 10 * degree of its divergent bundle
+
+
+def benchmark_tuples():
+    """(r, cc, thickness, n_after, name, opts) of demo_benchmark.py:49-58: four lenses of n = 1.7 / 1.5 around a stop"""
+    return [
+        (-5.922, 0, 2.0, 1.7, "surf1", {}),
+        (-3.160, 0, 3.0, None, "surf2", {}),
+        (15.884, 0, 5.0, 1.7, "surf3", {}),
+        (-12.756, 0, 3.0, None, "surf4", {}),
+        (0, 0, 3.0, None, "stop", {"is_stop": True}),
+        (3.125, 0, 2.0, 1.5, "surf5", {}),
+        (1.479, 0, 3.0, None, "surf6", {}),
+        (0, 0, 19.0, None, "surf7", {}),
+    ]
+
+
+def benchmark_records():
+    return simple_system_records(rotsym_builduplist(benchmark_tuples()))
+
+
+def divergent_bundle(nrays, radius=BENCHMARK_HALF_ANGLE, raster=None, n=1.0):
+    """OpticalSystemAnalysis.divergent_bundle (analysis/optical_system_analysis.py:124-165) from the origin into an
+    isotropic background: one start point, per-ray unit vectors fanned out over the raster's angles; E = a unit
+    vector perpendicular to k (the reference's comes from an eigenproblem; the trace does not depend on which)"""
+    (ax, ay) = (raster or rect_grid)(nrays)
+    o = np.zeros((3, ax.shape[0]))
+    u = np.vstack((np.sin(radius * ax) * np.cos(radius * ay), np.sin(radius * ay), np.cos(radius * ax) * np.cos(radius * ay)))
+    k = n * u
+    e = np.cross(k, np.array([1., 0., 0.]), axisa=0, axisb=0).T
+    e = e / np.linalg.norm(e, axis=0)
+    return (o, k, np.ascontiguousarray(e))
+
+
 # ---- config 1: cemented doublet (demos/demo_doublet.py:48-101) --------------------
 def doublet_builduplist(mat1=1.5168, mat2=1.6727):
     ap = {"type": "CircularAperture", "maxradius": 12.7}

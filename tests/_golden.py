@@ -20,7 +20,9 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ISO_CASES = ["doublet", "doublet_clipped", "double_gauss_axis", "double_gauss_field5",
              "double_gauss_wide", "double_gauss_Fline", "double_gauss_defaultE",
              "tilted_frames", "mirrors", "two_elements", "catalog_doublet",
-             "spd_double_gauss_Fline", "prism_red", "prism_blue"]
+             "spd_double_gauss_Fline", "prism_red", "prism_blue",
+             # the reference's own benchmark workload (demos/demo_benchmark.py:47-78): divergent bundle, per-ray k0 / E0
+             "benchmark_divergent"]
 EXPLICIT_CASES = ["asphere_mild_axis", "asphere_mild_field5", "asphere_strong_axis",
                   "asphere_strong_field5", "xypoly_axis", "xypoly_field5", "xypoly_bench_field5", "biconic_axis",
                   "biconic_field5", "hud_biconic_mirrors", "zmx_lenssystem",

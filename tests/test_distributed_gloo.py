@@ -158,3 +158,61 @@ def test_image_plane_gather_world2_gloo(n_total):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def _strong_worker(rank, world, port, q):
+    """one rank of a strong-scaling split: trace the shard of ONE bundle (the CPU oracle stands in for the device
+    march -- per-ray scalar code, so a ray's result does not depend on the shard it is in), all-gather the image
+    plane, hand back a digest of the gathered arrays"""
+    import hashlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import seqtrace_c
+        from pyrate_amd import systems
+        recs = systems.double_gauss_records()
+        (o, k, e0) = systems.double_gauss_bundle(3000, rpup=20.0, field_deg=12.0)       # (rays miss and vignette: masks matter)
+        n_total = o.shape[1]
+        (lo, hi) = pdist.shard_range(n_total, rank, world, align=512)                 # bench.py's alignment
+        out = seqtrace_c.trace(recs, np.ascontiguousarray(o[:, lo:hi]), np.ascontiguousarray(k[:, lo:hi]),
+                               np.ascontiguousarray(e0[:, lo:hi]))[-1]
+        g = pdist.ImagePlaneGather(n_total, torch.device("cpu"), align=512)
+        g.start(torch.from_numpy(np.ascontiguousarray(out["x_hit"])), torch.from_numpy(np.ascontiguousarray(out["k_out"])),
+                torch.from_numpy(np.ascontiguousarray(out["valid_out"]).astype(np.uint8)))
+        (ax, ak, av) = g.finish()
+        h = hashlib.sha256()
+        for a in (ax, ak, av):
+            h.update(np.ascontiguousarray(a.numpy()).tobytes())
+        q.put((rank, n_total, h.hexdigest()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_strong_scaling_split_of_one_bundle_gathers_to_the_same_plane_at_every_world_size():
+    """bench.py --scaling strong: ONE bundle split N ways.  The gathered image plane (hit points, wave vectors, masks;
+    global ray order) is bit-identical at world sizes 1, 2 and 3 -- 2944 rays do not divide evenly into 512-aligned shards by either -- and on every
+    rank, and equals the unsharded trace."""
+    import hashlib
+    from oracle import seqtrace_c
+    from pyrate_amd import systems
+    recs = systems.double_gauss_records()
+    (o, k, e0) = systems.double_gauss_bundle(3000, rpup=20.0, field_deg=12.0)
+    whole = seqtrace_c.trace(recs, o, k, e0)[-1]
+    assert 0 < int(np.count_nonzero(whole["valid_out"])) < o.shape[1]
+    h = hashlib.sha256()
+    for a in (whole["x_hit"], whole["k_out"], np.asarray(whole["valid_out"]).astype(np.uint8)):
+        h.update(np.ascontiguousarray(a).tobytes())
+    ctx = mp.get_context("spawn")
+    for world in (1, 2, 3):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_strong_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        results = [q.get(timeout=180) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert sorted(r[0] for r in results) == list(range(world))
+        assert all(r[1] == o.shape[1] and r[2] == h.hexdigest() for r in results), (world, results)

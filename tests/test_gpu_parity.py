@@ -281,6 +281,53 @@ def test_full_size_properties(gpu_device):
         assert np.max(np.abs(res.k_out[s][:, it].cpu().numpy() - out[s]["k_out"])) < 1e-12
 
 
+def test_reference_benchmark_workload_at_full_size(gpu_device):
+    """The reference's own benchmark (demos/demo_benchmark.py:47-78) at 1e7 rays: 8 surfaces, divergent 10-degree
+    bundle generated on the device -- per-ray k0 / E0 ARRAYS, the first segment the headline configs no longer use.
+    * the device bundle is the reference's divergent_bundle (one origin, unit vectors over the RectGrid of angles)
+    * |k_out| = n_after and hit points on their spheres for every valid ray of every surface
+    * masks and a 1e4-ray sub-sample equal the CPU oracle's
+    * the bundle is symmetric about the axis: so is the image
+    """
+    from pyrate_amd import engine, systems
+    from pyrate_amd.sampling2d import raster
+    recs = systems.benchmark_records()
+    sysd = engine.DeviceSystem(recs, gpu_device.index)
+    (x0, k0, e0, n) = engine.raster_bundle_device(raster.RectGrid().device_tables(10 ** 7), "divergent", gpu_device,
+                                                   radius=systems.BENCHMARK_HALF_ANGLE)
+    assert 0.99e7 < n < 1.01e7 and x0.shape[1] == n
+    (ho, hk, he) = systems.divergent_bundle(10 ** 7)
+    idx = np.linspace(0, n - 1, 10000).astype(np.int64)
+    it = torch.from_numpy(idx).to(gpu_device)
+    assert float(x0.abs().max()) == 0.0                                        # one origin
+    assert np.max(np.abs(k0[:, it].cpu().numpy() - hk[:, idx])) < 1e-15       # the reference's unit vectors
+    assert float((k0 * e0).sum(0).abs().max()) < 1e-15                         # E perpendicular to k
+    res = sysd.trace(x0, k0, e0)
+    torch.cuda.synchronize()
+    n_last = None
+    for (s, rec) in enumerate(recs):
+        v = res.valid_out[s].bool()
+        kn = torch.sqrt((res.k_out[s] ** 2).sum(0))
+        assert float(torch.where(v, (kn - rec["material"]["n"]).abs(), torch.zeros_like(kn)).max()) < 1e-13
+        c = rec["shape"]["curv"]
+        p = res.x_hit[s] - torch.tensor(rec["g_shape"], dtype=torch.float64, device=gpu_device)[:, None]
+        resid = c * (p ** 2).sum(0) - 2 * p[2]      # sphere: c (x^2+y^2+z^2) - 2 z = 0
+        hit = res.valid[s].bool()
+        assert float(torch.where(hit, resid.abs(), torch.zeros_like(resid)).max()) < 1e-12
+        n_last = int(v.sum())
+    assert n_last > 0.5 * n                          # (the steep outer rays of the 10-degree cone are lost on the way)
+    vl = res.valid_out[-1].bool()
+    cen = torch.where(vl, res.x_hit[-1][:2], torch.zeros_like(res.x_hit[-1][:2])).sum(1) / n_last
+    assert float(cen.abs().max()) < 1e-9
+    out = oracle.trace(recs, ho[:, idx], k0[:, it].cpu().numpy(), e0[:, it].cpu().numpy())
+    for s in range(len(recs)):
+        ov = out[s]["valid_out"]
+        assert np.array_equal(res.valid_out[s][it].cpu().numpy().astype(bool), ov)
+        assert np.array_equal(res.valid[s][it].cpu().numpy().astype(bool), out[s]["valid"])
+        assert np.max(np.abs(res.x_hit[s][:, it].cpu().numpy()[:, ov] - out[s]["x_hit"][:, ov]), initial=0.0) < 1e-11
+        assert np.max(np.abs(res.k_out[s][:, it].cpu().numpy()[:, ov] - out[s]["k_out"][:, ov]), initial=0.0) < 1e-12
+
+
 def test_error_codes_and_unsupported_tables(gpu_device):
     """structural misuse raises (like the reference's bare Exceptions), never a silent CPU path"""
     from pyrate_amd import engine, _lib, systems

@@ -145,7 +145,7 @@ def test_bench_multi_rank_path_with_a_watchdog_shorter_than_the_run(gpu_device):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PRT_BENCH_WATCHDOG="0.2", MASTER_PORT=str(_free_port()))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--force-multi", "--steps", "5", "--warmup", "2",
-           "--rays", "1000000"]
+           "--rays-total", "1000000"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 3 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-500:])
@@ -158,31 +158,37 @@ def test_bench_multi_rank_path_with_a_watchdog_shorter_than_the_run(gpu_device):
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-500:])
     line = json.loads(lines[0])
     assert line["value"] > 0 and "expected" in line["config"] and "error" not in line
+    assert line["scaling"] == "strong" and line["verified"]["ok"] and line["verified"]["all_ranks_ok"]
+    assert line["verified"]["max_resid"] <= 1e-10 and line["verified"]["oracle_sample"]["mask_mismatches"] == 0
 
 
-def test_bench_with_eight_ranks_on_this_gpu_gloo_dry_run(gpu_device):
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_with_eight_ranks_on_this_gpu_gloo_dry_run(gpu_device, scaling):
     """the N = 8 launch of the contract (`python bench.py --gpus 8` -> torch.distributed.run, one process per rank)
     with all ranks on this box's GPU and gloo as the backend: rendezvous, equal-stride shards of a bundle that does
-    not divide evenly, per-step exchange (host staged), max-over-ranks timing, ONE JSON line from rank 0.  Plumbing
-    only -- the rate means nothing."""
+    not divide evenly, per-step exchange (host staged), max-over-ranks timing, ONE JSON line from rank 0, every
+    rank's shard verified.  strong: ONE bundle of 8e6 rays split eight ways (the default protocol, at 1e8 rays);
+    weak: 1e6 rays per rank.  Plumbing only -- the rate means nothing.  A run that ends in its watchdog, or in any
+    error other than the box refusing to host eight processes (ports, memory), FAILS: a hang of the N > 1 path must
+    not read as green."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PRT_ARENA_BUDGET_GIB="12", PRT_BENCH_WATCHDOG="240", MASTER_PORT=str(_free_port()))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo",
-                        "--rays", "1000000", "--steps", "3", "--warmup", "1"], env=env, capture_output=True,
-                       text=True, timeout=600, cwd=root)
+    size = ["--rays-total", "8000000"] if scaling == "strong" else ["--scaling", "weak", "--rays", "1000000"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo"] + size +
+                       ["--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    if len(lines) != 1 and ("rendezvous" in r.stderr.lower() or "address already in use" in r.stderr.lower()
-                            or "out of memory" in r.stderr.lower()):
+    if len(lines) != 1 and ("address already in use" in r.stderr.lower() or "out of memory" in r.stderr.lower()):
         pytest.skip("eight processes could not be brought up on this box: " + r.stderr[-300:])
     assert len(lines) == 1, (r.returncode, r.stdout[-800:], r.stderr[-800:])
     line = json.loads(lines[0])
-    if "error" in line:
-        pytest.skip("the dry run ended in its watchdog: " + line["error"])
-    assert r.returncode == 0 and line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+    assert "error" not in line, line["error"]          # (a watchdog hit is a failure)
+    assert r.returncode == 0 and line["n_gpus"] == 8 and line["scaling"] == scaling and line["value"] > 0
     cfg = line["config"]
     assert cfg["rays_per_gpu"] % 512 == 0 and 7 * cfg["rays_per_gpu"] < cfg["rays_total"] <= 8 * cfg["rays_per_gpu"]
+    assert abs(cfg["rays_total"] - 8e6) < 0.01 * 8e6
     assert abs(cfg["image_plane_spot"]["rays"] - cfg["rays_total"]) < 1e-6 * cfg["rays_total"]   # no vignetting at 0 deg
     assert len(cfg["expected"]["ms_per_step_with_gather"]) == 2
+    assert line["verified"]["ok"] and line["verified"]["all_ranks_ok"]
