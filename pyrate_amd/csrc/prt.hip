@@ -1278,11 +1278,15 @@ int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const 
     if (!x_hit || !k || !k_out) return fail(PRT_ERR_INVALID_ARG, "prt_interact: null pointer");
     PRT_ON_DEVICE(sys->device);
     const prt_surface_t *rec = sys->h_table + surface;
+    // Absorbing media (a complex epsilon tensor, a complex refractive index -- also on an ISOTROPIC record, also as the
+    // only record of a one-surface table): the wave vectors are complex, and this entry point has neither a complex k
+    // to take nor one to give back.  Dropping Im(n) silently would return real-index wave vectors and masks that
+    // disagree with the fused path and with the reference.
+    if (sys->complex_eps)
+        return fail(PRT_ERR_UNSUPPORTED, "prt_interact: a table with absorbing media (complex epsilon / complex index) is "
+                                         "traced as a whole (prt_trace_ex with k_out_im; the wave vectors are complex)");
     if (rec->mat_type == PRT_MAT_ANISOTROPIC) {
         if (!dir_out) return fail(PRT_ERR_INVALID_ARG, "prt_interact: anisotropic needs dir_out");
-        if (sys->complex_eps)
-            return fail(PRT_ERR_UNSUPPORTED, "prt_interact: a table with a complex epsilon tensor is traced as a whole "
-                                             "(prt_trace_ex with k_out_im; the wave vectors are complex)");
         hipLaunchKernelGGL(k_interact_aniso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                            (hipStream_t)stream, sys->d_table + surface, n, x_hit, k,
                            (const uint8_t *)nullptr, k_out, dir_out, e_out_re, e_out_im, valid_out);

@@ -62,23 +62,41 @@ def _row_of(t2d, row, start, n, n_pad):
     return t2d.as_strided((n_pad,), (1,), off)
 
 
+_COALESCE_OK = {}      # backend -> does torch's coalescing manager take all_gather_into_tensor here (decided once)
+
+
+def _coalescing_supported(backend):
+    """Whether the rows of a bundle can go out as ONE group.  Decided once per backend, WITHOUT issuing a collective:
+    the manager must exist and take (group, async_ops) -- a signature check.  A call never falls back to
+    one-by-one collectives after it has enqueued something: a rank that re-issued its collectives alone (an error
+    raised on that rank only) would run a different sequence than its peers and hang or mismatch them."""
+    if backend not in _COALESCE_OK:
+        ok = backend == "nccl" and hasattr(dist, "_coalescing_manager") and os.environ.get("PRT_GATHER_COALESCE", "1") != "0"
+        if ok:
+            import inspect
+            try:
+                params = inspect.signature(dist._coalescing_manager).parameters
+                ok = "group" in params and "async_ops" in params
+            except (TypeError, ValueError):
+                ok = False
+        _COALESCE_OK[backend] = ok
+    return _COALESCE_OK[backend]
+
+
 def _all_gather_rows(pairs, group, device):
     """one all_gather_into_tensor per (destination row, source) pair, asynchronous; returns the work handles.
     With RCCL the rows of a bundle go out as ONE group (ncclGroupStart / End through torch's coalescing manager:
-    one launch instead of seven -- the per-collective launch cost is what a step of the single-rank smoke run saw)"""
-    backend = dist.get_backend(group)
-    if backend == "nccl" and hasattr(dist, "_coalescing_manager") and os.environ.get("PRT_GATHER_COALESCE", "1") != "0":
-        try:
-            work = []
-            for dtype in sorted(set(dst.dtype for (dst, _) in pairs), key=str):      # one group per element type
-                with dist._coalescing_manager(group=group, async_ops=True) as cm:
-                    for (dst, src) in pairs:
-                        if dst.dtype == dtype:
-                            dist.all_gather_into_tensor(dst, src, group=group)
-                work.append(cm)
-            return work
-        except (TypeError, RuntimeError, AttributeError, ValueError):
-            pass                      # this torch's manager does not take these collectives: one by one
+    one launch instead of seven -- the per-collective launch cost is what a step of the single-rank smoke run saw).
+    An error inside the group propagates (see _coalescing_supported)."""
+    if _coalescing_supported(dist.get_backend(group)):
+        work = []
+        for dtype in sorted(set(dst.dtype for (dst, _) in pairs), key=str):      # one group per element type
+            with dist._coalescing_manager(group=group, async_ops=True) as cm:
+                for (dst, src) in pairs:
+                    if dst.dtype == dtype:
+                        dist.all_gather_into_tensor(dst, src, group=group)
+            work.append(cm)
+        return work
     return [dist.all_gather_into_tensor(dst, src, group=group, async_op=True) for (dst, src) in pairs]
 
 

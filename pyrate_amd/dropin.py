@@ -16,7 +16,7 @@ trace -- path p follows solution bit j of p at the j-th crystal interface, the o
 """
 from .raytracer.optical_system import MAX_FUSED_CRYSTALS, seqtrace_fused, _seqtrace_fused_crystal
 from .raytracer.ray import RayBundle
-from .surface_table import UnsupportedError, flatten_sequence
+from .surface_table import UnsupportedError, flatten_sequence, has_complex_eps
 
 
 def as_device_bundle(bundle, device=None):
@@ -35,8 +35,12 @@ def seqtrace(system, initialbundle, elementsequence, splitup=False, device=None)
     if not records:
         raise UnsupportedError("empty sequence")
     crystals = sum(r["material"]["type"] != "isotropic" for r in records)
+    if has_complex_eps(records) and (crystals > MAX_FUSED_CRYSTALS or ib._dir is not None):
+        # (absorbing media: complex wave vectors; the plugin-granular loop has no place for them)
+        raise UnsupportedError("a sequence through absorbing media is traced as a whole: no explicit first-segment "
+                               "directions, at most %d crystal interfaces" % MAX_FUSED_CRYSTALS)
     if crystals and (splitup or crystals > MAX_FUSED_CRYSTALS or ib._dir is not None):
-        if hasattr(system, "_seqtrace_generic"):
+        if hasattr(system, "_seqtrace_generic") and not has_complex_eps(records):
             return system._seqtrace_generic(ib, elementsequence, splitup)
         if crystals <= MAX_FUSED_CRYSTALS and ib._dir is None:
             return _seqtrace_fused_crystal(ib, records, lengths, split=True)

@@ -338,7 +338,8 @@ class DeviceSystem(object):
             crystals = sum(r["material"]["type"] == "anisotropic" for r in self.records)
             if pitch is None:
                 pitch = int(self.lib.prt_crystal_pitch(n0))
-            if (crystals > FUSED_MAX_CRYSTALS or os.environ.get("PRT_GENERAL_PER_SURFACE") or pitch < n0
+            # (PRT_GENERAL_PER_SURFACE: PRESENT in the environment, whatever its value -- what libprt's getenv tests)
+            if (crystals > FUSED_MAX_CRYSTALS or "PRT_GENERAL_PER_SURFACE" in os.environ or pitch < n0
                     or self.complex_eps):
                 pitch = 0
             P = pitch or n0

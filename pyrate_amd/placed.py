@@ -19,6 +19,7 @@ import torch
 from . import _lib
 
 SLAB_BYTES = 1 << 30
+MAX_BLOCK_SLABS = 512          # no buffer is longer than the device (record_stream's walk down to a block's base)
 # below this many output bytes a trace keeps using the torch allocator: small path arrays live in the
 # L2 / Infinity Cache for most of the march, and a 1-GiB slab per array would be mostly padding
 PLACED_MIN_BYTES = int(os.environ.get("PRT_PLACED_MIN_BYTES", 512 << 20))
@@ -175,6 +176,9 @@ class PlacedArena(object):
         self._h = handle
         self._wrap = os.environ.get("PRT_PLACED_WRAP", "")       # "", "cai" or "dlpack"
         self._blocks = {}                                        # base pointer -> weak reference to its _Block
+        # _release runs from _Block.__del__ -- any thread, any garbage-collection point, also in the middle of alloc
+        # or record_stream on this thread: every access to _blocks goes through this (re-entrant) lock
+        self._blocks_lock = threading.RLock()
 
     @classmethod
     def for_device(cls, device_index):
@@ -189,7 +193,8 @@ class PlacedArena(object):
         # behind it.  That stream is the current one at the time the last tensor dies -- made to wait first for
         # every other stream the memory was used on (record_stream: a gather on a side stream, ...), so that
         # the release is behind all of its users whatever stream the garbage collector happens to run under.
-        self._blocks.pop(ptr, None)
+        with self._blocks_lock:
+            self._blocks.pop(ptr, None)
         if self._h:
             cur = torch.cuda.current_stream(self.device_index)
             for s in streams:
@@ -227,7 +232,8 @@ class PlacedArena(object):
         for i in range(n):
             rounded = -(-int(sizes[i]) // SLAB_BYTES) * SLAB_BYTES
             block = _Block(self, ptrs[i], rounded, int(kinds[i]))
-            self._blocks[ptrs[i]] = weakref.ref(block)
+            with self._blocks_lock:
+                self._blocks[ptrs[i]] = weakref.ref(block)
             out.append(self._tensor(block))
         return out, [int(k) for k in kinds]
 
@@ -239,11 +245,21 @@ class PlacedArena(object):
         if stream is None:
             stream = torch.cuda.current_stream(self.device_index)
         p = tensor.data_ptr()
-        for (base, ref) in list(self._blocks.items()):
-            blk = ref()
-            if blk is not None and base <= p < base + blk.nbytes:
-                blk.streams.add(stream)
-                return True
+        # buffers are whole 1-GiB slabs at 1-GiB aligned addresses: the block that holds p starts at a multiple of
+        # the slab size at or below it -- a few dictionary look-ups instead of a scan over every live block
+        with self._blocks_lock:
+            base = p - p % SLAB_BYTES
+            for _ in range(MAX_BLOCK_SLABS):
+                ref = self._blocks.get(base)
+                blk = ref() if ref is not None else None
+                if blk is not None:
+                    if p < base + blk.nbytes:
+                        blk.streams.add(stream)
+                        return True
+                    return False
+                base -= SLAB_BYTES
+                if base < 0:
+                    break
         return False
 
     def kind_of(self, tensor):

@@ -16,7 +16,7 @@
 import torch
 
 from .. import _lib, engine
-from ..surface_table import flatten_sequence, has_complex_eps
+from ..surface_table import UnsupportedError, flatten_sequence, has_complex_eps
 from . import _dispatch
 from .localcoordinates import LocalCoordinates, LocalCoordinatesTreeBase
 from .material.material_isotropic import ConstantIndexGlass
@@ -61,11 +61,17 @@ class OpticalSystem(LocalCoordinatesTreeBase):
             fused_ok = False      # a bundle that already carries invalid rays: per-surface path
         if fused_ok:
             return [self._seqtrace_fused(initialbundle, records, lengths)]
-        if splitup and has_complex_eps(records) and crystals <= MAX_FUSED_CRYSTALS and initialbundle._dir is None \
-                and (len(initialbundle._valid) == 1 or bool(initialbundle._valid[-1].all())):
-            # absorbing crystals: the forked paths are the branches of ONE dense trace (the per-surface plugin calls
-            # have no complex wave vectors in their signature)
-            return _seqtrace_fused_crystal(initialbundle, records, lengths, split=True)
+        if has_complex_eps(records):
+            # absorbing media: the per-surface plugin calls have no complex wave vectors in their signature, so there
+            # is no plugin-granular fall-back -- the forked paths of ``splitup`` are the branches of ONE dense trace,
+            # anything else (explicit first directions, a bundle that already carries invalid rays, too many crystal
+            # interfaces) is refused rather than traced with the imaginary parts dropped
+            if splitup and crystals <= MAX_FUSED_CRYSTALS and initialbundle._dir is None \
+                    and (len(initialbundle._valid) == 1 or bool(initialbundle._valid[-1].all())):
+                return _seqtrace_fused_crystal(initialbundle, records, lengths, split=True)
+            raise UnsupportedError("a sequence through absorbing media (complex epsilon / complex index) is traced as a "
+                                   "whole: no explicit first-segment directions, no invalid rays in the initial bundle, "
+                                   "at most %d crystal interfaces" % MAX_FUSED_CRYSTALS)
         return self._seqtrace_generic(initialbundle, elementsequence, splitup)
 
     def image_moments(self, initialbundle, elementsequence):

@@ -125,9 +125,18 @@ def test_dropin_seqtrace_through_absorbing_crystals(name, mirror, gpu_device):
         assert np.abs(rb.k - ref["k"]).max() < 1e-10
         if i >= (5 if name == "absorbing_detector" else 3):
             assert np.iscomplexobj(rb.k) and np.abs(np.imag(rb.k)).max() > 1e-3
-    if name != "absorbing_detector":
-        with pytest.raises(_lib.PrtError):        # the plugin-granular loop: prt_interact has no complex k
-            s._seqtrace_generic(ib, seq, False)
+    # the plugin-granular loop: prt_interact has no complex k -- also for the detector, whose absorbing medium is an
+    # ISOTROPIC record (a one-record table each time Material.refract is called on it)
+    with pytest.raises(_lib.PrtError):
+        s._seqtrace_generic(ib, seq, False)
+    # ... and seqtrace itself refuses what it cannot trace as a whole instead of falling back to that loop
+    from pyrate_amd.surface_table import UnsupportedError
+    ib_bad = api.RayBundle(x0=case.x0, k0=case.k0, Efield0=case.E0, wave=case.wave)
+    ib_bad._ensure()
+    ib_bad._valid[-1][0] = 0                      # a bundle that already carries an invalid ray
+    ib_bad._valid.append(ib_bad._valid[-1].clone())
+    with pytest.raises(UnsupportedError):
+        s.seqtrace(ib_bad, seq)
 
 
 def test_dropin_splitup_through_absorbing_crystals_forks_eight_paths(gpu_device):
