@@ -21,6 +21,8 @@ from . import seqtrace_np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "seqtrace_c.c")
 OUT = os.path.join(HERE, "libseqtrace_c.so")
+OUT_SANITIZED = os.path.join(HERE, "libseqtrace_c_san.so")
+# PRT_ORACLE_C_LIBRARY: load this build of the library instead (tests/test_oracle_c.py: the sanitizer build)
 REC = 72
 SHAPES = {"conic": 0, "asphere": 1, "xypoly": 2, "biconic": 3}
 _lib = None
@@ -39,6 +41,30 @@ def build(force=False):
     subprocess.run([gcc, "-O2", "-fno-math-errno", "-fopenmp", "-shared", "-fPIC", "-o", OUT, SRC, "-lm"],
                    check=True)
     return OUT
+
+
+def build_sanitized(force=False):
+    """the same source with AddressSanitizer + UndefinedBehaviorSanitizer: gcc -O1 -g
+    -fsanitize=address,undefined -> oracle/libseqtrace_c_san.so.  Loaded into an uninstrumented python only with
+    libasan preloaded (``sanitizer_preload``); tests/test_oracle_c.py runs golden cases under it in a subprocess."""
+    if not force and os.path.exists(OUT_SANITIZED) and os.path.getmtime(OUT_SANITIZED) >= os.path.getmtime(SRC):
+        return OUT_SANITIZED
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        raise RuntimeError("gcc not found")
+    subprocess.run([gcc, "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                    "-fno-sanitize-recover=undefined", "-fno-math-errno", "-fopenmp", "-shared", "-fPIC",
+                    "-o", OUT_SANITIZED, SRC, "-lm"], check=True)
+    return OUT_SANITIZED
+
+
+def sanitizer_preload():
+    """path of gcc's libasan.so (what LD_PRELOAD needs for the sanitized library), or None"""
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        return None
+    path = subprocess.run([gcc, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    return os.path.realpath(path) if os.path.isabs(path) and os.path.exists(path) else None
 
 
 def _zggev_pointer():
@@ -60,8 +86,10 @@ def _zggev_pointer():
 def load():
     global _lib
     if _lib is None:
-        build()
-        lib = ctypes.CDLL(OUT)
+        path = os.environ.get("PRT_ORACLE_C_LIBRARY")
+        if not path:
+            path = build()
+        lib = ctypes.CDLL(path)
         lib.seqtrace_c.restype = ctypes.c_int
         lib.seqtrace_c.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64] + \
             [ctypes.c_void_p] * 7 + [ctypes.c_int]

@@ -122,3 +122,60 @@ def test_c_oracle_vs_reference_absorbing_crystals(name):
     res = _golden.compare_dense_to_reference(case, _golden.dense_from_oracle(out, complex_k=True),
                                              rtol_x=1e-12, atol_k=1e-12)
     assert res["n_compared"] > 0
+
+
+SANITIZER_CASES = ["double_gauss_wide", "tilted_frames", "mirrors", "benchmark_divergent",       # conics, frames, apertures
+                   "asphere_strong_field5", "xypoly_field5", "biconic_field5", "hud_biconic_mirrors",   # explicit shapes
+                   "aniso_doublet_uniaxial", "aniso_doublet_biaxial", "aniso_partial_evanescent"]      # crystals (zggev)
+
+
+def test_c_oracle_under_address_and_undefined_behaviour_sanitizers():
+    """the C restatement -- second oracle and multi-core CPU baseline -- built with
+    -fsanitize=address,undefined and run on one golden case per shape family, the frame / aperture / mirror cases and
+    the crystal cases (LAPACK work arrays, the 6x6 pencils): no report from either sanitizer, and the results of the
+    instrumented build equal those of the ordinary one to rounding (the two builds differ in optimisation level).
+    Runs in a subprocess: the instrumented library needs libasan preloaded into the interpreter."""
+    import json
+    import os
+    import subprocess
+    import sys
+    try:
+        lib = seqtrace_c.build_sanitized()
+    except Exception as exc:
+        pytest.skip("no sanitizer build on this box: %s" % exc)
+    asan = seqtrace_c.sanitizer_preload()
+    if asan is None:
+        pytest.skip("gcc's libasan.so not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import _golden\n"
+        "from oracle import seqtrace_c\n"
+        "out = {}\n"
+        "for name in %r:\n"
+        "    case = _golden.load_case(name)\n"
+        "    if not seqtrace_c.supports(case.table):\n"
+        "        out[name] = None\n"
+        "        continue\n"
+        "    res = seqtrace_c.trace(case.table, case.x0, case.k0, case.E0)\n"
+        "    out[name] = [float(np.nansum(np.abs(np.real(r['x_hit'])))) + float(np.nansum(np.abs(np.real(r['k_out'])))) for r in res]\n"
+        "print('RESULT ' + json.dumps(out))\n" % (root, os.path.join(root, "tests"), SANITIZER_CASES))
+    env = dict(os.environ, LD_PRELOAD=asan, PRT_ORACLE_C_LIBRARY=lib, OMP_NUM_THREADS="2",
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=24")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    got = json.loads(line[len("RESULT "):])
+    checked = 0
+    for name in SANITIZER_CASES:
+        case = _golden.load_case(name)
+        if got[name] is None:
+            continue
+        ref = seqtrace_c.trace(case.table, case.x0, case.k0, case.E0)
+        want = [float(np.nansum(np.abs(np.real(q["x_hit"])))) + float(np.nansum(np.abs(np.real(q["k_out"])))) for q in ref]
+        assert np.allclose(got[name], want, rtol=1e-11, atol=0.0), name
+        checked += 1
+    assert checked >= 8
