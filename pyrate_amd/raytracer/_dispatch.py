@@ -1,18 +1,25 @@
-"""Small LRU of device-resident surface tables keyed by their JSON form, so that the
+"""Small LRU of device-resident surface tables keyed by their content, so that the
 plugin-granular calls (Shape.intersect, Material.refract, ...) and repeated seqtrace
 calls of an optimiser loop do not re-upload identical tables."""
-import json
 from collections import OrderedDict
 
 from .. import engine
-from ..surface_table import surface_record
+from ..surface_table import surface_record, table_key
 
 _CACHE = OrderedDict()
 _MAX = 32
+# the same record OBJECTS again = the same table (records are never modified once made; surface_table's memo hands
+# out the same dictionaries for unchanged surfaces): a tuple of ids instead of a content key.  The records are kept,
+# so their ids stay theirs.
+_BY_IDENTITY = {}
 
 
 def system_for(records, device):
-    key = (json.dumps(records, sort_keys=True), device.index)
+    ident = (tuple(map(id, records)), device.index)
+    hit = _BY_IDENTITY.get(ident)
+    if hit is not None and hit[1]._h:
+        return hit[1]
+    key = (table_key(records), device.index)
     sysd = _CACHE.get(key)
     if sysd is None:
         sysd = engine.DeviceSystem(records, device.index)
@@ -22,10 +29,14 @@ def system_for(records, device):
             old.close()
     else:
         _CACHE.move_to_end(key)
+    if len(_BY_IDENTITY) > 256:
+        _BY_IDENTITY.clear()
+    _BY_IDENTITY[ident] = (list(records), sysd)
     return sysd
 
 
 def clear():
+    _BY_IDENTITY.clear()
     while _CACHE:
         (_, old) = _CACHE.popitem()
         old.close()

@@ -31,6 +31,13 @@ class OpticalSystem(LocalCoordinatesTreeBase):
         self.material_background = matbackground
         self.elements = {}
 
+    def _flattened(self, elementsequence, wave):
+        """``flatten_sequence`` of this system.  Cheap when nothing changed: every record comes back from the memo of
+        ``surface_table.surface_record_cached`` (keyed by the epochs of the objects it was read from,
+        variables.py), so an unchanged 12-surface system costs a walk over 12 dictionary look-ups, and the table
+        the records form is recognised by identity (_dispatch.system_for)."""
+        return flatten_sequence(self, elementsequence, wave)
+
     @classmethod
     def p(cls, rootlc=None, matbackground=None, name=""):
         if rootlc is None:
@@ -52,7 +59,7 @@ class OpticalSystem(LocalCoordinatesTreeBase):
     # ------------------------------------------------------------------
     def seqtrace(self, initialbundle, elementsequence, splitup=False):
         # e.g. [("elem1", [("surf1", {}), ("surf2", {"is_mirror": True})]), ("elem2", [...])]
-        (records, lengths) = flatten_sequence(self, elementsequence, initialbundle.wave)
+        (records, lengths) = self._flattened(elementsequence, initialbundle.wave)
         initialbundle._ensure()
         crystals = sum(r["material"]["type"] == "anisotropic" for r in records)
         fused_ok = initialbundle._dir is None and len(records) > 0 \
@@ -81,7 +88,7 @@ class OpticalSystem(LocalCoordinatesTreeBase):
         arrive (prt_trace_moments); 7 doubles cross PCIe.  Returns (moments (7,), reference point (3,)).
         ``engine.spot_from_moments`` turns them into RayBundleAnalysis' centroid / RMS spot size; merit
         functions of optimiser loops can use the sums directly."""
-        (records, _) = flatten_sequence(self, elementsequence, initialbundle.wave)
+        (records, _) = self._flattened(elementsequence, initialbundle.wave)
         if any(r["material"]["type"] != "isotropic" for r in records):
             raise Exception("image_moments: isotropic sequences only")
         initialbundle._ensure()

@@ -214,6 +214,49 @@ def surface_record(surface, material, is_mirror, wave):
     }
 
 
+# One table record per (surface, medium behind it, mirror flag, wavelength), remembered together with the EPOCHS of the
+# objects it was read from (raytracer/variables.py: every mutation path of this package's classes advances the epoch of
+# the object it touches): as long as none of them has changed, the record is the record.  An optimiser loop that moves
+# one curvature re-reads one surface, not twelve.  Objects without epochs (the reference's own classes, duck-typed
+# look-alikes) and shapes made of other shapes are read afresh every time, like the reference does.
+_RECORD_MEMO = {}
+_RECORD_MEMO_MAX = 4096
+
+
+def _epochs_of(surface, material):
+    try:
+        shape = surface.shape
+        aperture = surface.aperture
+        if shape.kind == "shape_LinearCombination":
+            return None
+        return (surface._epoch, shape._epoch, shape.lc._epoch, aperture._epoch, aperture.lc._epoch,
+                material._epoch, material.lc._epoch)
+    except AttributeError:
+        return None
+
+
+def surface_record_cached(surface, material, is_mirror, wave):
+    epochs = _epochs_of(surface, material)
+    if epochs is None:
+        return surface_record(surface, material, is_mirror, wave)
+    key = (id(surface), id(material), bool(is_mirror), wave)
+    hit = _RECORD_MEMO.get(key)
+    if hit is not None and hit[0] == epochs:
+        return hit[2]
+    rec = surface_record(surface, material, is_mirror, wave)
+    if len(_RECORD_MEMO) >= _RECORD_MEMO_MAX:
+        _RECORD_MEMO.clear()
+    _RECORD_MEMO[key] = (epochs, (surface, material), rec)      # (the objects are kept: their ids stay theirs)
+    return rec
+
+
+def table_key(records):
+    """hashable content key of a list of records (marshal: binary floats -- a tenth of the cost of json.dumps, whose
+    time goes into printing the shortest decimal form of every double)"""
+    import marshal
+    return marshal.dumps(records, 2)      # (version 2: binary floats, no object back-references: equal content, equal bytes)
+
+
 def flatten_element_sequence(element, sequence, background_medium, wave):
     """The bookkeeping of OpticalElement.seqtrace (optical_element.py:324-379)."""
     records = []
@@ -227,7 +270,7 @@ def flatten_element_sequence(element, sequence, background_medium, wave):
         if refract_flag:
             # findoutWhichMaterial: identity comparison (optical_element.py:109-126)
             current_material = pnmat if (mnmat is current_material) else mnmat
-        records.append(surface_record(surface, current_material, not refract_flag, wave))
+        records.append(surface_record_cached(surface, current_material, not refract_flag, wave))
     return records
 
 
@@ -463,12 +506,11 @@ check_complex_media = check_complex_eps
 
 
 def pack_table(records):
-    import json
     check_complex_eps(records)
     blobs = []
     keep = []
     for rec in records:
-        key = json.dumps(rec, sort_keys=True)
+        key = table_key(rec)
         hit = _PACKED.get(key)
         if hit is None:
             r = pack_record(rec)

@@ -553,3 +553,63 @@ def test_complex_epsilon_tables_stay_inside_crystals():
     (bad[1], bad[-1]) = (bad[-1], bad[1])                       # the absorbing glass in the middle
     with pytest.raises(surface_table.UnsupportedError, match="absorbing isotropic medium"):
         surface_table.pack_table(bad)
+
+
+def test_record_memo_follows_every_mutation_path_of_the_mirror_classes():
+    """surface_table.surface_record_cached hands back the record of the last walk while the epochs of the objects it
+    was read from stand still (raytracer/variables.py).  Every way this package's classes can be changed must move an
+    epoch: after each mutation the memoised walk equals a walk with an empty memo; untouched surfaces keep their
+    record OBJECTS (that is what makes the unchanged case cheap); in-place edits of held arrays raise."""
+    import random
+    from pyrate_amd import surface_table, systems
+    from pyrate_amd.builders import build_simple_optical_system
+    from pyrate_amd.raytracer.aperture import CircularAperture
+    from pyrate_amd.raytracer.surface_shape import Conic
+    wave = 0.5876e-3
+    (s, seq) = build_simple_optical_system(systems.doublet_builduplist() + [
+        ({"shape": "Asphere", "curv": -0.01, "cc": -1.0, "coefficients": [1e-4, 1e-7]}, {"decz": 3.0, "tiltx": 0.01},
+         {"eps": systems.uniaxial_eps(1.6, 1.5, (0, 0, 1))}, "extra", {})])
+    elem = s.elements["stdelem"]
+
+    def fresh():
+        surface_table._RECORD_MEMO.clear()
+        return surface_table.flatten_sequence(s, seq, wave)[0]
+
+    def memoised():
+        return surface_table.flatten_sequence(s, seq, wave)[0]
+    base = memoised()
+    again = memoised()
+    assert all(a is b for (a, b) in zip(base, again))                       # nothing changed: the same objects
+    front = elem.surfaces["front"]
+    extra = elem.surfaces["extra"]
+    mutations = [
+        lambda: front.shape.curvature.set_value(front.shape.curvature() * 1.01),
+        lambda: extra.shape.params["A4"].set_value(2e-7),
+        lambda: extra.shape.annotations.__setitem__("newton_maxit", 17),
+        lambda: (front.shape.lc.decz.set_value(front.shape.lc.decz() + 0.1), s.rootcoordinatesystem.update()),
+        lambda: (extra.shape.lc.tiltx.set_value(0.02), s.rootcoordinatesystem.update()),
+        lambda: front.aperture.annotations.__setitem__("maxradius", 11.0),
+        lambda: setattr(elem.surfaces["cement"], "aperture", CircularAperture.p(elem.surfaces["cement"].shape.lc, maxradius=9.0)),
+        lambda: setattr(elem.surfaces["rear"], "shape", Conic.p(elem.surfaces["rear"].shape.lc, curv=-0.004)),
+        lambda: elem.materials[elem.annotations["surf_mat_connection"]["front"][1]].n.set_value(1.6),
+        lambda: setattr(elem.materials[elem.annotations["surf_mat_connection"]["extra"][1]], "epstensor",
+                        systems.uniaxial_eps(1.7, 1.5, (0, 1, 0))),
+    ]
+    rng = random.Random(3)
+    for trial in range(40):
+        before = memoised()
+        which = rng.randrange(len(mutations))
+        mutations[which]()
+        after = memoised()
+        truth = fresh()
+        assert after == truth, (trial, which)
+        memoised()
+        changed = [i for (i, (a, b)) in enumerate(zip(before, truth)) if a != b]
+        kept = [i for (i, (a, b)) in enumerate(zip(before, after)) if a is b]
+        assert not (set(kept) & set(changed)), (trial, which)
+        if which in (0, 1, 2, 5, 8):                  # one object touched, no frame update: every other record is kept
+            assert len(kept) >= len(truth) - 2, (trial, which, kept)
+    with pytest.raises(ValueError):
+        front.shape.lc.globalcoordinates[2] = 5.0               # held arrays are read-only: no silent stale table
+    with pytest.raises(ValueError):
+        elem.materials[elem.annotations["surf_mat_connection"]["extra"][1]].epstensor[0, 0] = 3.0
