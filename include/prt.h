@@ -515,10 +515,13 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
  *                     the write streams cost 3 % of the march); further parts get a kind no other part
  *                     of the call uses when slabs of one are at hand.  To find the kinds the arena
  *                     may take up to max_hunt_slabs extra slabs from the driver for the duration
- *                     of the call (-1: default = half of the memory that is free at the time of the call, at most
- *                     256 -- a kind is 96 GiB, so the third can be 192 slabs away; about 2.5 ms per slab, once; a
- *                     hunt also stops after 2 s of probing, PRT_ARENA_HUNT_MS); if the device cannot offer that many kinds
- *                     the call still succeeds and kinds[] tells.  avoid_mask (bit q = kind q):
+ *                     of the call (-1: default = 32, and never more than half of the memory that is free at the
+ *                     time of the call; about 1.5 ms per slab; a hunt also stops after 50 ms of probing.  A request
+ *                     that does not find its kinds within that settles for fewer -- kinds[] tells -- and the next
+ *                     request continues the hunt from the slabs this one left behind.  PRT_ARENA_HUNT=full lifts
+ *                     the bounds to 256 slabs / 2 s: a kind is 96 GiB, so the third can be 192 slabs away;
+ *                     PRT_ARENA_HUNT_SLABS / PRT_ARENA_HUNT_MS set them one by one); if the device cannot offer
+ *                     that many kinds the call still succeeds and kinds[] tells.  avoid_mask (bit q = kind q):
  *                     kinds this request leaves to others if it can -- a caller that allocates its
  *                     input arrays separately passes 3, which keeps them out of kinds 0 and 1, the
  *                     ones a two-part output request takes first.
@@ -558,6 +561,10 @@ int32_t prt_arena_trim(prt_arena_t *arena);
 int32_t prt_arena_set_budget(prt_arena_t *arena, int64_t max_live_slabs);
 int32_t prt_arena_kind_of(prt_arena_t *arena, const void *ptr, int32_t *kind);
 int32_t prt_arena_stats(prt_arena_t *arena, int64_t *out, int32_t n_out, double *rates, int32_t n_rates);
+/* "compute partition/memory partition[; note]": the partition modes the arena found in sysfs (amdgpu's
+ * current_compute_partition / current_memory_partition; "unknown" where the files are missing), and -- outside
+ * SPX / NPS1, where the three kinds of HBM were characterised -- the note that slabs are not classified. */
+const char *prt_arena_note(prt_arena_t *arena);
 
 #ifdef __cplusplus
 }

@@ -179,6 +179,7 @@ PROTOTYPES["prt_arena_set_budget"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c
 PROTOTYPES["prt_arena_kind_of"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)])
 PROTOTYPES["prt_arena_stats"] = (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int32,
                                                  ctypes.POINTER(ctypes.c_double), ctypes.c_int32])
+PROTOTYPES["prt_arena_note"] = (ctypes.c_char_p, [ctypes.c_void_p])
 
 _lib = None
 

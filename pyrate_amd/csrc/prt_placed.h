@@ -74,7 +74,21 @@ struct prt_arena {
     int64_t va_reserved = 0;       // bytes of address space taken so far (never returned, see above)
     int64_t slab_budget = -1;      // cap on the slabs held at any time (created - released); < 0: none
     int64_t cache_cap = 64;        // cap on the slabs of cached (unused, still mapped) buffers + free slabs
-    double hunt_ms_cap = 2000.0;   // a hunt for kinds stops taking slabs after this long (it then settles for fewer)
+    // A hunt for kinds is BOUNDED per call: at most hunt_slab_cap slabs beyond what the request needs and hunt_ms_cap
+    // milliseconds of probing; a request that cannot get its kinds within that settles for fewer (kinds[] says so),
+    // and the NEXT request continues the hunt from the slabs this one left behind.  Defaults 32 slabs / 50 ms --
+    // a first call costs tens of milliseconds, not the 100-170 ms of an unbounded walk through a long run of one
+    // kind; PRT_ARENA_HUNT=full (benchmarks: the steady-state placement on the first allocation) lifts both to
+    // 256 slabs / 2 s, PRT_ARENA_HUNT_MS / PRT_ARENA_HUNT_SLABS set them individually.
+    double hunt_ms_cap = 50.0;
+    int32_t hunt_slab_cap = 32;
+    // The three kinds were observed with the device in its default partition modes (compute SPX, memory NPS1).  In
+    // another mode the address interleave is a different one and the probe's two-rate picture may not exist: the
+    // arena then does not classify at all (every slab is kind 0, no probes) and says so (prt_arena_note).
+    bool classify = true;
+    char compute_partition[32] = "";
+    char memory_partition[32] = "";
+    char note[256] = "";
     std::vector<prt_slab> free_slabs;
     std::vector<prt_placed_buffer *> buffers;      // in use and cached
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -203,7 +217,12 @@ static hipError_t arena_new_slab(prt_arena *a, hipStream_t st, prt_slab *out, bo
         return e;
     }
     int32_t kind = -1;
-    e = arena_classify(a, (double *)va, st, &kind);
+    if (!a->classify) {          // unknown interleave (partition mode): one kind, no probes
+        kind = 0;                // (the first slab becomes kind 0's representative below, like a classified one)
+        e = hipSuccess;
+    } else {
+        e = arena_classify(a, (double *)va, st, &kind);
+    }
     if (e != hipSuccess) {
         (void)hipMemUnmap(va, PRT_SLAB_BYTES);
         (void)hipMemRelease(s.handle);
@@ -331,7 +350,44 @@ int32_t prt_arena_create(int32_t device, prt_arena_t **out) {
         a->slab_budget = (int64_t)(total_b / PRT_SLAB_BYTES) * 3 / 4;
     if (const char *v = getenv("PRT_ARENA_BUDGET_GIB")) a->slab_budget = atoll(v);
     if (const char *v = getenv("PRT_ARENA_CACHE_GIB")) a->cache_cap = atoll(v);
+    if (const char *v = getenv("PRT_ARENA_HUNT")) {
+        if (strcmp(v, "full") == 0) {
+            a->hunt_ms_cap = 2000.0;
+            a->hunt_slab_cap = 256;
+        }
+    }
     if (const char *v = getenv("PRT_ARENA_HUNT_MS")) a->hunt_ms_cap = atof(v);
+    if (const char *v = getenv("PRT_ARENA_HUNT_SLABS")) a->hunt_slab_cap = atoi(v);
+    // partition modes of the device, from sysfs (amdgpu: current_compute_partition / current_memory_partition beside
+    // the PCI device); unknown (no such files: an older driver, a container without sysfs) counts as the default
+    {
+        char bus[64] = "";
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) == hipSuccess) {
+            for (char *c = bus; *c; ++c) *c = (char)tolower((unsigned char)*c);
+            auto read_mode = [&](const char *file, char *dst, size_t cap) {
+                char path[256];
+                snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/%s", bus, file);
+                FILE *f = fopen(path, "r");
+                if (!f) return;
+                if (fgets(dst, (int)cap, f)) {
+                    size_t n = strlen(dst);
+                    while (n > 0 && (dst[n - 1] == '\n' || dst[n - 1] == ' ')) dst[--n] = 0;
+                }
+                fclose(f);
+            };
+            read_mode("current_compute_partition", a->compute_partition, sizeof a->compute_partition);
+            read_mode("current_memory_partition", a->memory_partition, sizeof a->memory_partition);
+        }
+        const bool spx = a->compute_partition[0] == 0 || strcmp(a->compute_partition, "SPX") == 0;
+        const bool nps1 = a->memory_partition[0] == 0 || strcmp(a->memory_partition, "NPS1") == 0;
+        if (!(spx && nps1) && !getenv("PRT_ARENA_CLASSIFY")) {
+            a->classify = false;
+            snprintf(a->note, sizeof a->note,
+                     "partition mode %s / %s: the three kinds of HBM were characterised in SPX / NPS1 only -- slabs are "
+                     "not classified (one kind, no probes; PRT_ARENA_CLASSIFY=1 forces the probes)",
+                     a->compute_partition[0] ? a->compute_partition : "?", a->memory_partition[0] ? a->memory_partition : "?");
+        }
+    }
     *out = a;
     return PRT_OK;
 }
@@ -425,9 +481,9 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
         // a kind is 96 GiB, so the third one can be 192 slabs of the other two away -- but a hunt holds what it walks
         // through: by default it may take at most half of what is free right now (and never more than 256 slabs)
         size_t free_b = 0, total_b = 0;
-        max_hunt_slabs = 256;
+        max_hunt_slabs = a->hunt_slab_cap;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            max_hunt_slabs = (int32_t)std::min<size_t>(256, free_b / PRT_SLAB_BYTES / 2);
+            max_hunt_slabs = (int32_t)std::min<size_t>((size_t)std::max(0, a->hunt_slab_cap), free_b / PRT_SLAB_BYTES / 2);
     }
     hipStream_t st = (hipStream_t)stream;
     size_t need[8];
@@ -605,6 +661,16 @@ int32_t prt_arena_stats(prt_arena_t *a, int64_t *out, int32_t n_out, double *rat
     double r[4] = {a->bw_same, a->bw_cross, a->probe_ms_total, (double)a->va_reserved};
     for (int i = 0; i < n_rates && i < 4; ++i) rates[i] = r[i];
     return PRT_OK;
+}
+
+// "compute partition / memory partition[; note]" -- what the arena read from sysfs when it was created, and, if it
+// does not classify slabs in this mode, why.  The pointer stays valid for the arena's lifetime.
+const char *prt_arena_note(prt_arena_t *a) {
+    if (!a) return "";
+    static thread_local char buf[400];
+    snprintf(buf, sizeof buf, "%s/%s%s%s", a->compute_partition[0] ? a->compute_partition : "unknown",
+             a->memory_partition[0] ? a->memory_partition : "unknown", a->note[0] ? "; " : "", a->note);
+    return buf;
 }
 
 }  // extern "C"

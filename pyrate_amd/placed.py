@@ -282,4 +282,10 @@ class PlacedArena(object):
                 "slabs_free": v[4], "slabs_in_use": v[5], "slabs_cached": v[6], "slab_bytes": v[7],
                 "slabs_per_kind": [v[8], v[9], v[10], v[11]], "probe_same_kind_GBps": r[0],
                 "probe_cross_kind_GBps": r[1], "probe_ms_total": r[2], "address_space_reserved_GiB": r[3] / 2 ** 30,
-                "tensor_wrap": self._wrap}
+                "tensor_wrap": self._wrap, "partition_and_note": self.note(),
+                "hunt": os.environ.get("PRT_ARENA_HUNT", "bounded (32 slabs / 50 ms per call)")}
+
+    def note(self):
+        """'compute partition/memory partition[; note]' (prt_arena_note)"""
+        v = self.lib.prt_arena_note(self._h)
+        return v.decode() if v else ""

@@ -192,3 +192,35 @@ def test_bench_with_eight_ranks_on_this_gpu_gloo_dry_run(gpu_device, scaling):
     assert abs(cfg["image_plane_spot"]["rays"] - cfg["rays_total"]) < 1e-6 * cfg["rays_total"]   # no vignetting at 0 deg
     assert len(cfg["expected"]["ms_per_step_with_gather"]) == 2
     assert line["verified"]["ok"] and line["verified"]["all_ranks_ok"]
+
+
+def test_bench_line_names_the_torch_allocator_fallback(gpu_device):
+    """with the arena switched off (PRT_ARENA=off: a driver without the virtual-memory API, a device in another
+    partition mode ...) bench.py still measures -- path arrays from the torch allocator -- and the line SAYS so
+    (config.output_placement); the results are the same bits (verified against the oracle like every run)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PRT_ARENA="off")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "doublegauss", "--rays", "1000000",
+                        "--steps", "5", "--warmup", "2", "--traffic", "none", "--cpu-budget", "0.2"], env=env,
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-800:])
+    line = json.loads(lines[0])
+    op = line["config"]["output_placement"]
+    assert op["policy"] == "torch" and "torch allocator" in op["note"], op
+    assert line["verified"]["ok"] and line["verified"]["oracle_sample"]["mask_mismatches"] == 0
+    assert line["verified"]["max_rel_x"] < 1e-12
+
+
+def test_arena_reports_partition_mode_and_bounded_hunt(gpu_device):
+    """the arena reads the device's partition modes once (sysfs) and reports them; its default hunt is bounded"""
+    from pyrate_amd import placed
+    if placed.DISABLED is not None:
+        pytest.skip("arena switched off: " + str(placed.DISABLED))
+    st = placed.PlacedArena.for_device(gpu_device.index).stats()
+    assert "/" in st["partition_and_note"]
+    (compute, memory) = st["partition_and_note"].split(";")[0].split("/")
+    assert compute in ("SPX", "DPX", "TPX", "QPX", "CPX", "unknown") and memory.startswith(("NPS", "unknown"))
+    if compute in ("SPX", "unknown") and memory in ("NPS1", "unknown"):
+        assert ";" not in st["partition_and_note"]          # the mode the kinds were characterised in: classification on
