@@ -8,14 +8,16 @@
 # configuration by benchmarks/kernel_trace_summary.py; issue-side SQ counters of the crystal march; fresh-process
 # repeats; the N > 1 code path with one rank; A/Bs; cold start of the drop-in; parity report.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 python bench.py > $O/bench_line.json 2> $O/bench_line.err
 STEPS=50
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps $STEPS --warmup 10 --no-cpu-baseline --traffic none > $O/bench_line_under_rocprof.json 2> $O/stats.err
-for cfg in "doublegauss:k_trace_iso<0, true, true, 0," "asphere:k_trace_iso<0, true, true, 1," "xypoly:k_trace_iso<0, true, true, 2," "aniso:k_trace_general<0,"; do
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps $STEPS --warmup 10 --no-cpu-baseline --traffic none --no-scaling-point > $O/bench_line_under_rocprof.json 2> $O/stats.err
+# (k_trace_iso<MODE, VEC_IN, VEC_OUT, SHAPES, LDS_TAB, MOMENTS, UNI, IMG>: the double Gauss runs with the uniform first
+# segment, the reference's benchmark workload -- a divergent bundle -- with k0 / E0 arrays)
+for cfg in "doublegauss:k_trace_iso<0, true, true, 0, false, false, true," "benchmark:k_trace_iso<0, true, true, 0, false, false, false," "asphere:k_trace_iso<0, true, true, 1," "xypoly:k_trace_iso<0, true, true, 2," "aniso:k_trace_general<0,"; do
   python benchmarks/kernel_trace_summary.py $O/stats "${cfg#*:}" $STEPS > $O/${cfg%%:*}_kernel_trace_summary.json 2>> $O/stats.err
 done
 find $O/stats -name "*kernel_stats.csv" | head -1 | while read f; do cp "$f" $O/bench_kernel_stats.csv; done
@@ -39,13 +41,16 @@ print(json.dumps([{"ms_per_step": r["ms_per_step"], "kernel_ms": r["roofline"]["
 PY
 python bench.py --first-segment arrays --headline-only --no-cpu-baseline > $O/bench_line_arrays.json 2> /dev/null
 python bench.py --rays 100000000 --steps 3 --warmup 1 --headline-only --no-cpu-baseline --traffic none > $O/bench_1e8_rays_line.json 2> $O/bench_1e8.err
-for gm in inplace copy; do python bench.py --force-multi --steps 50 --warmup 10 --gather-mode $gm > $O/bench_force_multi_$gm.json 2> $O/bench_force_multi_$gm.err; done
-python bench.py --force-multi --steps 50 --warmup 10 --exchange stats > $O/bench_force_multi_stats.json 2> /dev/null
-python bench.py --force-multi --steps 50 --warmup 10 --trace-stream default > $O/bench_force_multi_inplace_default_stream.json 2> /dev/null
-python bench.py --force-multi --steps 50 --warmup 10 --exchange gather-direct > $O/bench_force_multi_direct.json 2> /dev/null
+for gm in inplace copy; do python bench.py --force-multi --scaling weak --steps 50 --warmup 10 --gather-mode $gm > $O/bench_force_multi_$gm.json 2> $O/bench_force_multi_$gm.err; done
+python bench.py --force-multi --scaling weak --steps 50 --warmup 10 --exchange stats > $O/bench_force_multi_stats.json 2> /dev/null
+python bench.py --force-multi --scaling weak --steps 50 --warmup 10 --trace-stream default > $O/bench_force_multi_inplace_default_stream.json 2> /dev/null
+python bench.py --force-multi --scaling weak --steps 50 --warmup 10 --exchange gather-direct > $O/bench_force_multi_direct.json 2> /dev/null
 python benchmarks/ab_crystal.py > $O/ab_crystal.json 2> $O/ab_crystal.err
 python benchmarks/ab_shapes.py > $O/ab_shapes.json 2> $O/ab_shapes.err
 python benchmarks/dropin_call_time.py > $O/dropin_call_time.json 2> $O/dropin.err
+python benchmarks/call_latency.py > $O/call_latency.json 2> $O/call_latency.err
+# the N > 1 protocol as the driver runs it (--scaling strong: the 1e8-ray bundle), with one rank going through RCCL
+python bench.py --force-multi --steps 20 --warmup 5 > $O/bench_force_multi_strong_1e8.json 2> $O/bench_force_multi_strong.err
 python tests/parity_report.py > $O/parity_report.txt 2> $O/parity_report.err
 # keep only the summaries (the raw traces are large)
 find $O -name "*counter_collection.csv" -delete
@@ -56,7 +61,7 @@ rm -f $O/fresh_?.json
 ls -la $O
 # idle time between two marches of the N > 1 step: the march on the default stream vs on a stream of its own
 for ts in default new; do
-  rocprofv3 --kernel-trace --output-format csv -d $O/gap_$ts -o t -- python bench.py --force-multi --steps 100 --warmup 10 --trace-stream $ts > /dev/null 2> /dev/null
+  rocprofv3 --kernel-trace --output-format csv -d $O/gap_$ts -o t -- python bench.py --force-multi --scaling weak --steps 100 --warmup 10 --trace-stream $ts > /dev/null 2> /dev/null
   python benchmarks/step_gaps.py $(find $O/gap_$ts -name "t_kernel_trace.csv" | head -1) $ts > $O/force_multi_gaps_$ts.json 2> /dev/null
   rm -rf $O/gap_$ts
 done

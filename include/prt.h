@@ -167,6 +167,15 @@ int32_t prt_sizeof_surface(void);             /* sizeof(prt_surface_t): ABI chec
 int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_t device,
                           prt_system_t **out);
 int32_t prt_system_destroy(prt_system_t *sys);
+/* The table of an existing system replaced IN PLACE, ordered on `stream`: what a loop of "change a parameter, trace"
+ * calls per step (the reference's optimiser, optimize/optimize.py:73-91, re-reads the object graph on every
+ * seqtrace; here the changed table costs one small asynchronous copy from page-locked staging memory -- no allocation,
+ * no blocking copy).  The new table must fit the system's device arrays: the same number of surfaces, a coefficient
+ * side array no longer than the one allocated at creation, the same absorbing-media status and, with crystals, a
+ * walk of the same length; otherwise PRT_ERR_UNSUPPORTED and nothing is touched (create a new system).  Launches
+ * enqueued on `stream` before the call see the old table, launches enqueued afterwards the new one; traces of this
+ * system on other streams must have completed. */
+int32_t prt_system_update(prt_system_t *sys, const prt_surface_t *table, int32_t n_surfaces, void *stream);
 int32_t prt_system_num_surfaces(const prt_system_t *sys);
 /* rays entering / leaving every surface for n0 input rays (anisotropic
  * interfaces double the count, material_anisotropic.py:87-100).  n_in, n_out:

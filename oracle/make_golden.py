@@ -408,7 +408,9 @@ def case_zmx():
     zp = ZMXParser(dst, name="ZMXParser")
     lctmp = LocalCoordinates.p("tmp")
     (s, seq) = zp.create_optical_system({"BK7": ConstantIndexGlass.p(lctmp, 1.5168)})
-    dump_case("zmx_lenssystem", s, seq, disk_bundle(160, 7.0, 0.0, field_deg=1.0, wave=0.55e-3))
+    # (89 rays, not more: the reference hands the WHOLE t-vector to hybrd with xtol = 1e-6 relative to its norm, so its
+    # per-ray error grows with the bundle; thirteen such surfaces in a row stay within 1e-8 mm at this size)
+    dump_case("zmx_lenssystem", s, seq, disk_bundle(100, 7.0, 0.0, field_deg=1.0, wave=0.55e-3))
     with open(os.path.join(OUT, "zmx_lenssystem_field.json"), "w") as f:
         fd = zp.read_field()
         json.dump({"field": fd, "bundles": zp.create_initial_bundle(),

@@ -40,6 +40,7 @@ PROTOTYPES = {
     "prt_system_create": (ctypes.c_int32, [ctypes.POINTER(PrtSurface), ctypes.c_int32,
                                            ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]),
     "prt_system_destroy": (ctypes.c_int32, [ctypes.c_void_p]),
+    "prt_system_update": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(PrtSurface), ctypes.c_int32, ctypes.c_void_p]),
     "prt_system_num_surfaces": (ctypes.c_int32, [ctypes.c_void_p]),
     "prt_system_ray_counts": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.POINTER(ctypes.c_int64),

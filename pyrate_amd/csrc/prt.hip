@@ -34,7 +34,15 @@ struct prt_system {
     walk_step *d_walk;         // the walk program (prt_kernels.h), n_walk entries + a sentinel
     int32_t n_walk;
     int32_t n_aniso;           // crystal interfaces of the table
+    // prt_system_update: capacities of the device arrays, and the ring of page-locked staging slots of its copies
+    size_t side_capacity, walk_capacity;
+    char *stage;
+    size_t stage_slot_bytes;
+    hipEvent_t stage_ev[4];
+    uint32_t stage_used;
+    int stage_next;
 };
+#define PRT_STAGE_SLOTS 4
 
 static void free_system(prt_system *sys) {
     if (!sys) return;
@@ -42,6 +50,12 @@ static void free_system(prt_system *sys) {
     if (sys->d_eps_im) (void)hipFree(sys->d_eps_im);
     if (sys->d_hot) (void)hipFree(sys->d_hot);
     if (sys->d_walk) (void)hipFree(sys->d_walk);
+    for (int q = 0; q < 4; ++q)
+        if (sys->stage_ev[q]) {
+            (void)hipEventSynchronize(sys->stage_ev[q]);
+            (void)hipEventDestroy(sys->stage_ev[q]);
+        }
+    if (sys->stage) (void)hipHostFree(sys->stage);
     if (sys->d_table) (void)hipFree(sys->d_table);
     delete[] sys->h_table;
     delete sys;
@@ -377,42 +391,29 @@ static int32_t check_record(const prt_surface_t *r, int idx) {
     return PRT_OK;
 }
 
-int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_t device,
-                          prt_system_t **out) {
-    if (!table || !out || n_surfaces <= 0) return fail(PRT_ERR_INVALID_ARG, "prt_system_create: null/empty");
-    *out = nullptr;
+// What prt_system_create uploads and prt_system_update re-uploads, built on the host: the device records (coefficient
+// pointers as OFFSETS into the side array until `relocate` adds its base), the side array, the hot blocks and the
+// walk program of tables with crystals, the imaginary parts of absorbing media, and the dispatch facts.
+struct table_image {
+    std::vector<prt_dev_surface> recs;
+    std::vector<char> side;            // side_bytes + slack
+    std::vector<prt_hot_surface> hot;
+    std::vector<walk_step> walk;       // empty: no fused crystal march for this table
+    std::vector<double> eps_im;        // (S, 9), only if complex_eps
+    int32_t all_isotropic = 1, all_conic = 1, shape_level = PRT_SHAPES_CONIC, complex_eps = 0, n_aniso = 0;
+    void relocate(const char *d_side) {
+        for (prt_dev_surface &d : recs) {
+            d.coeffs = (const double *)(d_side + (uintptr_t)d.coeffs);
+            d.pows = (const void *)(d_side + (uintptr_t)d.pows);
+        }
+    }
+};
+
+static int32_t build_table_image(const prt_surface_t *table, int32_t n_surfaces, table_image &im) {
     for (int s = 0; s < n_surfaces; ++s) {
         int32_t rc = check_record(table + s, s);
         if (rc != PRT_OK) return rc;
     }
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0) return fail(PRT_ERR_NO_DEVICE, "no HIP device visible", e);
-    if (device < 0 || device >= ndev) return fail(PRT_ERR_INVALID_ARG, "device index out of range");
-    PRT_ON_DEVICE(device);
-    prt_system *sys = new (std::nothrow) prt_system();
-    if (!sys) return fail(PRT_ERR_NOMEM, "host alloc");
-    sys->device = device;
-    sys->n_surfaces = n_surfaces;
-    sys->d_table = nullptr;
-    sys->d_side = nullptr;
-    sys->complex_eps = 0;
-    sys->d_eps_im = nullptr;
-    sys->d_hot = nullptr;
-    sys->d_walk = nullptr;
-    sys->n_walk = 0;
-    sys->n_aniso = 0;
-    sys->h_table = new (std::nothrow) prt_surface_t[n_surfaces];
-    prt_dev_surface *recs = new (std::nothrow) prt_dev_surface[n_surfaces];
-    if (!sys->h_table || !recs) {
-        delete[] recs;
-        free_system(sys);
-        return fail(PRT_ERR_NOMEM, "host alloc");
-    }
-    memcpy(sys->h_table, table, sizeof(prt_surface_t) * n_surfaces);
-    sys->all_isotropic = 1;
-    sys->all_conic = 1;
-    sys->shape_level = PRT_SHAPES_CONIC;
     // Absorbing media -- complex epsilon tensors (material_anisotropic.py:52-56), complex refractive indices (Im n in
     // eps_im[0] of an isotropic record) -- are supported wherever the reference's result is defined: inside crystals,
     // and for an isotropic medium behind the LAST surface (its complex k = k_inplane + xi n is unique).  Behind an
@@ -437,8 +438,6 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
                 const bool bad_place = iso && s != n_surfaces - 1;
                 const bool bad_mirror = iso && table[s].eps_im[0] != 0.0 && table[s].interaction == PRT_MIRROR;
                 if (bad_place || bad_mirror) {
-                    delete[] recs;
-                    free_system(sys);
                     char msg[256];
                     if (bad_mirror)
                         snprintf(msg, sizeof msg, "surface %d: a mirror inside an absorbing isotropic medium", s);
@@ -449,7 +448,7 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
                     return fail(PRT_ERR_UNSUPPORTED, msg);
                 }
             }
-            sys->complex_eps = 1;
+            im.complex_eps = 1;
         }
     }
     // side array: per surface its doubles (coefficients -- for an asphere part followed by the products
@@ -470,125 +469,211 @@ int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_
     // slack behind the last entry: asphere_prefetch reads PRT_ASPHERE_PREFETCH doubles from the start of a
     // surface's coefficients whatever their number, xypoly_eval one 32-byte chunk beyond the last
     const size_t PRT_SIDE_SLACK = 8 + 8 * PRT_ASPHERE_PREFETCH;
-    size_t side_bytes = 0;
-    std::vector<std::vector<char>> poly;
-    std::vector<char> poly_dense;
     try {
-        poly.resize(n_surfaces);
-        poly_dense.resize(n_surfaces, 0);
+        size_t side_bytes = 0;
+        std::vector<std::vector<char>> poly((size_t)n_surfaces);
+        std::vector<char> poly_dense((size_t)n_surfaces, 0);
         for (int s = 0; s < n_surfaces; ++s) {
             bool dense = false;
             poly[s] = poly_rows(table[s], &dense);
             poly_dense[s] = (dense && table[s].shape_type == PRT_SHAPE_XYPOLY) ? 1 : 0;
             side_bytes += 8 * n_doubles(table[s]) + poly[s].size();
         }
+        im.side.assign(side_bytes + PRT_SIDE_SLACK, 0);
+        im.recs.resize((size_t)n_surfaces);
+        char *h_side = im.side.data();
+        size_t off = 0;
+        for (int s = 0; s < n_surfaces; ++s) {
+            const prt_surface_t &r = table[s];
+            prt_dev_surface &d = im.recs[s];
+            if (r.mat_type != PRT_MAT_ISOTROPIC || im.complex_eps) im.all_isotropic = 0;
+            if (r.mat_type == PRT_MAT_ANISOTROPIC) ++im.n_aniso;
+            if (r.shape_type != PRT_SHAPE_CONIC) im.all_conic = 0;
+            if (r.shape_type == PRT_SHAPE_ASPHERE && im.shape_level < PRT_SHAPES_ASPHERE) im.shape_level = PRT_SHAPES_ASPHERE;
+            if ((r.shape_type == PRT_SHAPE_XYPOLY || r.shape_type == PRT_SHAPE_BICONIC) && im.shape_level < PRT_SHAPES_POLY)
+                im.shape_level = PRT_SHAPES_POLY;
+            if (r.shape_type == PRT_SHAPE_COMBO || r.shape_type == PRT_SHAPE_GRIDSAG) im.shape_level = PRT_SHAPES_ALL;
+            memset(&d, 0, sizeof d);
+            d.shape_type = r.shape_type;
+            d.n_coeffs = r.n_coeffs;
+            d.ap_type = r.ap_type;
+            d.interaction = r.interaction;
+            d.mat_type = r.mat_type;
+            d.frame_flags = r.frame_flags;
+            d.newton_maxit = r.newton_maxit;
+            d.aniso_class = r.aniso_class;
+            d.n_asphere = r.n_asphere;
+            d.grid_nx = r.grid_nx;
+            d.grid_ny = r.grid_ny;
+            d.poly_dense = poly_dense[s];
+            d.curv = r.curv;
+            d.cc = r.cc;
+            memcpy(d.B_shape, r.B_shape, sizeof d.B_shape);
+            memcpy(d.g_shape, r.g_shape, sizeof d.g_shape);
+            memcpy(d.B_ap, r.B_ap, sizeof d.B_ap);
+            memcpy(d.g_ap, r.g_ap, sizeof d.g_ap);
+            d.ap_p0 = r.ap_p0;
+            d.ap_p1 = r.ap_p1;
+            memcpy(d.B_mat, r.B_mat, sizeof d.B_mat);
+            d.n_after = r.n_after;
+            memcpy(d.eps_re, r.eps_re, sizeof d.eps_re);
+            d.aniso_eo = r.aniso_eo;
+            d.aniso_ee = r.aniso_ee;
+            memcpy(d.aniso_axis, r.aniso_axis, sizeof d.aniso_axis);
+            d.curv_y = r.curv_y;
+            d.cc_y = r.cc_y;
+            d.asphere_scale = r.asphere_scale;
+            const size_t nd = n_doubles(r);
+            d.coeffs = (const double *)(uintptr_t)off;          // (offset: table_image::relocate)
+            const size_t na = n_asphere_part(r);
+            memcpy(h_side + off, r.shape_type == PRT_SHAPE_GRIDSAG ? (const void *)r.aux : (const void *)r.coeffs,
+                   8 * (nd - na));
+            for (size_t n = 0; n < na; ++n) ((double *)(h_side + off))[nd - na + n] = (double)(n + 1) * r.coeffs[n];
+            off += 8 * nd;
+            d.pows = (const void *)(uintptr_t)off;
+            if (!poly[s].empty()) memcpy(h_side + off, poly[s].data(), poly[s].size());
+            off += poly[s].size();
+        }
+        if (im.complex_eps) {
+            im.eps_im.assign((size_t)n_surfaces * 9, 0.0);
+            for (int s = 0; s < n_surfaces; ++s)
+                for (int q = 0; q < 9; ++q)   // (isotropic records: Im n in slot 0)
+                    im.eps_im[(size_t)s * 9 + q] = (table[s].mat_type == PRT_MAT_ANISOTROPIC || q == 0) ? table[s].eps_im[q] : 0.0;
+        }
+        if (im.n_aniso > 0 && im.n_aniso <= PRT_FUSED_MAX_CRYSTALS && !im.complex_eps && n_surfaces < 32768) {
+            // the fused crystal march (k_trace_general): hot blocks + walk program
+            im.hot.resize((size_t)n_surfaces);
+            for (int s = 0; s < n_surfaces; ++s) im.hot[s] = hot_block(table[s]);
+            im.walk = build_walk_program(table, n_surfaces);
+        }
     } catch (...) {  // std::bad_alloc: the ABI never throws
-        delete[] recs;
+        return fail(PRT_ERR_NOMEM, "host alloc");
+    }
+    return PRT_OK;
+}
+
+static void adopt_image_facts(prt_system *sys, const table_image &im) {
+    sys->all_isotropic = im.all_isotropic;
+    sys->all_conic = im.all_conic;
+    sys->shape_level = im.shape_level;
+    sys->complex_eps = im.complex_eps;
+    sys->n_aniso = im.n_aniso;
+    sys->n_walk = im.walk.empty() ? 0 : (int32_t)im.walk.size() - 1;
+}
+
+int32_t prt_system_create(const prt_surface_t *table, int32_t n_surfaces, int32_t device,
+                          prt_system_t **out) {
+    if (!table || !out || n_surfaces <= 0) return fail(PRT_ERR_INVALID_ARG, "prt_system_create: null/empty");
+    *out = nullptr;
+    table_image im;
+    int32_t rc = build_table_image(table, n_surfaces, im);
+    if (rc != PRT_OK) return rc;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(PRT_ERR_NO_DEVICE, "no HIP device visible", e);
+    if (device < 0 || device >= ndev) return fail(PRT_ERR_INVALID_ARG, "device index out of range");
+    PRT_ON_DEVICE(device);
+    prt_system *sys = new (std::nothrow) prt_system();
+    if (!sys) return fail(PRT_ERR_NOMEM, "host alloc");
+    memset((void *)sys, 0, sizeof *sys);
+    sys->device = device;
+    sys->n_surfaces = n_surfaces;
+    sys->h_table = new (std::nothrow) prt_surface_t[n_surfaces];
+    if (!sys->h_table) {
         free_system(sys);
         return fail(PRT_ERR_NOMEM, "host alloc");
     }
-    char *h_side = new (std::nothrow) char[side_bytes + PRT_SIDE_SLACK];
-    if (!h_side) {
-        delete[] recs;
-        free_system(sys);
-        return fail(PRT_ERR_NOMEM, "host alloc");
-    }
-    memset(h_side, 0, side_bytes + PRT_SIDE_SLACK);
-    e = hipMalloc(&sys->d_side, side_bytes + PRT_SIDE_SLACK);
+    memcpy(sys->h_table, table, sizeof(prt_surface_t) * n_surfaces);
+    adopt_image_facts(sys, im);
+    sys->side_capacity = im.side.size();
+    e = hipMalloc(&sys->d_side, im.side.size());
     if (e != hipSuccess) {
-        delete[] recs;
-        delete[] h_side;
         free_system(sys);
         return fail(PRT_ERR_NOMEM, "hipMalloc(coefficients)", e);
     }
-    size_t off = 0;
-    for (int s = 0; s < n_surfaces; ++s) {
-        const prt_surface_t &r = table[s];
-        prt_dev_surface &d = recs[s];
-        if (r.mat_type != PRT_MAT_ISOTROPIC || sys->complex_eps) sys->all_isotropic = 0;
-        if (r.shape_type != PRT_SHAPE_CONIC) sys->all_conic = 0;
-        if (r.shape_type == PRT_SHAPE_ASPHERE && sys->shape_level < PRT_SHAPES_ASPHERE) sys->shape_level = PRT_SHAPES_ASPHERE;
-        if ((r.shape_type == PRT_SHAPE_XYPOLY || r.shape_type == PRT_SHAPE_BICONIC) && sys->shape_level < PRT_SHAPES_POLY)
-            sys->shape_level = PRT_SHAPES_POLY;
-        if (r.shape_type == PRT_SHAPE_COMBO || r.shape_type == PRT_SHAPE_GRIDSAG) sys->shape_level = PRT_SHAPES_ALL;
-        memset(&d, 0, sizeof d);
-        d.shape_type = r.shape_type;
-        d.n_coeffs = r.n_coeffs;
-        d.ap_type = r.ap_type;
-        d.interaction = r.interaction;
-        d.mat_type = r.mat_type;
-        d.frame_flags = r.frame_flags;
-        d.newton_maxit = r.newton_maxit;
-        d.aniso_class = r.aniso_class;
-        d.n_asphere = r.n_asphere;
-        d.grid_nx = r.grid_nx;
-        d.grid_ny = r.grid_ny;
-        d.poly_dense = poly_dense[s];
-        d.curv = r.curv;
-        d.cc = r.cc;
-        memcpy(d.B_shape, r.B_shape, sizeof d.B_shape);
-        memcpy(d.g_shape, r.g_shape, sizeof d.g_shape);
-        memcpy(d.B_ap, r.B_ap, sizeof d.B_ap);
-        memcpy(d.g_ap, r.g_ap, sizeof d.g_ap);
-        d.ap_p0 = r.ap_p0;
-        d.ap_p1 = r.ap_p1;
-        memcpy(d.B_mat, r.B_mat, sizeof d.B_mat);
-        d.n_after = r.n_after;
-        memcpy(d.eps_re, r.eps_re, sizeof d.eps_re);
-        d.aniso_eo = r.aniso_eo;
-        d.aniso_ee = r.aniso_ee;
-        memcpy(d.aniso_axis, r.aniso_axis, sizeof d.aniso_axis);
-        d.curv_y = r.curv_y;
-        d.cc_y = r.cc_y;
-        d.asphere_scale = r.asphere_scale;
-        const size_t nd = n_doubles(r);
-        d.coeffs = (const double *)((char *)sys->d_side + off);
-        const size_t na = n_asphere_part(r);
-        memcpy(h_side + off, r.shape_type == PRT_SHAPE_GRIDSAG ? (const void *)r.aux : (const void *)r.coeffs,
-               8 * (nd - na));
-        for (size_t n = 0; n < na; ++n) ((double *)(h_side + off))[nd - na + n] = (double)(n + 1) * r.coeffs[n];
-        off += 8 * nd;
-        d.pows = (const void *)((char *)sys->d_side + off);
-        if (!poly[s].empty()) memcpy(h_side + off, poly[s].data(), poly[s].size());
-        off += poly[s].size();
-    }
-    e = hipMemcpy(sys->d_side, h_side, side_bytes + PRT_SIDE_SLACK, hipMemcpyHostToDevice);
-    delete[] h_side;
-    if (e == hipSuccess && sys->complex_eps) {
-        std::vector<double> im((size_t)n_surfaces * 9, 0.0);
-        for (int s = 0; s < n_surfaces; ++s)
-            for (int q = 0; q < 9; ++q)   // (isotropic records: Im n in slot 0)
-                im[(size_t)s * 9 + q] = (table[s].mat_type == PRT_MAT_ANISOTROPIC || q == 0) ? table[s].eps_im[q] : 0.0;
-        e = hipMalloc((void **)&sys->d_eps_im, sizeof(double) * im.size());
-        if (e == hipSuccess) e = hipMemcpy(sys->d_eps_im, im.data(), sizeof(double) * im.size(), hipMemcpyHostToDevice);
+    im.relocate((const char *)sys->d_side);
+    e = hipMemcpy(sys->d_side, im.side.data(), im.side.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && im.complex_eps) {
+        e = hipMalloc((void **)&sys->d_eps_im, sizeof(double) * im.eps_im.size());
+        if (e == hipSuccess)
+            e = hipMemcpy(sys->d_eps_im, im.eps_im.data(), sizeof(double) * im.eps_im.size(), hipMemcpyHostToDevice);
     }
     if (e == hipSuccess) e = hipMalloc((void **)&sys->d_table, sizeof(prt_dev_surface) * n_surfaces);
     if (e == hipSuccess)
-        e = hipMemcpy(sys->d_table, recs, sizeof(prt_dev_surface) * n_surfaces, hipMemcpyHostToDevice);
-    delete[] recs;
-    for (int s = 0; s < n_surfaces; ++s)
-        if (table[s].mat_type == PRT_MAT_ANISOTROPIC) ++sys->n_aniso;
-    if (e == hipSuccess && sys->n_aniso > 0 && sys->n_aniso <= PRT_FUSED_MAX_CRYSTALS && !sys->complex_eps && n_surfaces < 32768) {
-        // the fused crystal march (k_trace_general): hot blocks + walk program
-        try {
-            std::vector<prt_hot_surface> hot((size_t)n_surfaces);
-            for (int s = 0; s < n_surfaces; ++s) hot[s] = hot_block(table[s]);
-            const std::vector<walk_step> prog = build_walk_program(table, n_surfaces);
-            sys->n_walk = (int32_t)prog.size() - 1;
-            e = hipMalloc((void **)&sys->d_hot, sizeof(prt_hot_surface) * hot.size());
-            if (e == hipSuccess) e = hipMemcpy(sys->d_hot, hot.data(), sizeof(prt_hot_surface) * hot.size(), hipMemcpyHostToDevice);
-            if (e == hipSuccess) e = hipMalloc((void **)&sys->d_walk, sizeof(walk_step) * prog.size());
-            if (e == hipSuccess) e = hipMemcpy(sys->d_walk, prog.data(), sizeof(walk_step) * prog.size(), hipMemcpyHostToDevice);
-        } catch (...) {  // std::bad_alloc: the ABI never throws
-            free_system(sys);
-            return fail(PRT_ERR_NOMEM, "host alloc");
-        }
+        e = hipMemcpy(sys->d_table, im.recs.data(), sizeof(prt_dev_surface) * n_surfaces, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !im.walk.empty()) {
+        e = hipMalloc((void **)&sys->d_hot, sizeof(prt_hot_surface) * im.hot.size());
+        if (e == hipSuccess)
+            e = hipMemcpy(sys->d_hot, im.hot.data(), sizeof(prt_hot_surface) * im.hot.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&sys->d_walk, sizeof(walk_step) * im.walk.size());
+        if (e == hipSuccess)
+            e = hipMemcpy(sys->d_walk, im.walk.data(), sizeof(walk_step) * im.walk.size(), hipMemcpyHostToDevice);
+        sys->walk_capacity = im.walk.size();
     }
     if (e != hipSuccess) {
         free_system(sys);
         return fail(PRT_ERR_DEVICE, "prt_system_create: table upload", e);
     }
     *out = sys;
+    return PRT_OK;
+}
+
+// The table of an existing system replaced IN PLACE, stream-ordered: the optimiser's pattern (SURVEY.md 3.5 -- one
+// curvature moved, trace, the next one moved, trace) costs one small asynchronous copy per trace instead of the three
+// allocations, three blocking copies and three frees of a destroy + create.  The new table must have the shape of the
+// old one: the same number of surfaces, a side array that fits the one allocated, the same absorbing-media status
+// and -- with crystals -- a walk program that fits; otherwise PRT_ERR_UNSUPPORTED, nothing touched, and the caller
+// creates a new system.  Ordering: the copies are enqueued on `stream` -- launches enqueued there before see the old
+// table, launches enqueued there afterwards the new one; traces of this system on OTHER streams must have completed.
+// The host side of the copies is a ring of page-locked staging slots (a slot is reused only after its copy has
+// finished), so the call never waits for the device in steady state.
+int32_t prt_system_update(prt_system_t *sys, const prt_surface_t *table, int32_t n_surfaces, void *stream) {
+    if (!sys || !table) return fail(PRT_ERR_INVALID_ARG, "prt_system_update: null argument");
+    if (n_surfaces != sys->n_surfaces) return fail(PRT_ERR_UNSUPPORTED, "prt_system_update: another number of surfaces");
+    table_image im;
+    int32_t rc = build_table_image(table, n_surfaces, im);
+    if (rc != PRT_OK) return rc;
+    if (im.side.size() > sys->side_capacity || im.complex_eps != sys->complex_eps ||
+        im.walk.empty() != (sys->d_walk == nullptr) || im.walk.size() > sys->walk_capacity)
+        return fail(PRT_ERR_UNSUPPORTED, "prt_system_update: the new table does not fit the system's device arrays");
+    PRT_ON_DEVICE(sys->device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t b_recs = sizeof(prt_dev_surface) * (size_t)n_surfaces, b_side = im.side.size();
+    const size_t b_hot = sizeof(prt_hot_surface) * im.hot.size(), b_walk = sizeof(walk_step) * im.walk.size();
+    const size_t b_im = sizeof(double) * im.eps_im.size();
+    const size_t need = b_recs + b_side + b_hot + b_walk + b_im;
+    if (!sys->stage || need > sys->stage_slot_bytes) {
+        if (sys->stage) {
+            for (int q = 0; q < PRT_STAGE_SLOTS; ++q)
+                if (sys->stage_ev[q]) (void)hipEventSynchronize(sys->stage_ev[q]);
+            (void)hipHostFree(sys->stage);
+            sys->stage = nullptr;
+        }
+        sys->stage_slot_bytes = (need + 4095) / 4096 * 4096;
+        HIP_TRY(hipHostMalloc((void **)&sys->stage, sys->stage_slot_bytes * PRT_STAGE_SLOTS, hipHostMallocDefault));
+        for (int q = 0; q < PRT_STAGE_SLOTS; ++q)
+            if (!sys->stage_ev[q]) HIP_TRY(hipEventCreateWithFlags(&sys->stage_ev[q], hipEventDisableTiming));
+        sys->stage_used = 0;
+    }
+    const int slot = sys->stage_next;
+    sys->stage_next = (slot + 1) % PRT_STAGE_SLOTS;
+    if (sys->stage_used & (1u << slot)) HIP_TRY(hipEventSynchronize(sys->stage_ev[slot]));   // its last copy is done
+    char *h = sys->stage + (size_t)slot * sys->stage_slot_bytes;
+    im.relocate((const char *)sys->d_side);
+    memcpy(h, im.recs.data(), b_recs);
+    memcpy(h + b_recs, im.side.data(), b_side);
+    if (b_hot) memcpy(h + b_recs + b_side, im.hot.data(), b_hot);
+    if (b_walk) memcpy(h + b_recs + b_side + b_hot, im.walk.data(), b_walk);
+    if (b_im) memcpy(h + b_recs + b_side + b_hot + b_walk, im.eps_im.data(), b_im);
+    HIP_TRY(hipMemcpyAsync(sys->d_table, h, b_recs, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(sys->d_side, h + b_recs, b_side, hipMemcpyHostToDevice, st));
+    if (b_hot) HIP_TRY(hipMemcpyAsync(sys->d_hot, h + b_recs + b_side, b_hot, hipMemcpyHostToDevice, st));
+    if (b_walk) HIP_TRY(hipMemcpyAsync(sys->d_walk, h + b_recs + b_side + b_hot, b_walk, hipMemcpyHostToDevice, st));
+    if (b_im) HIP_TRY(hipMemcpyAsync(sys->d_eps_im, h + b_recs + b_side + b_hot + b_walk, b_im, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(sys->stage_ev[slot], st));
+    sys->stage_used |= 1u << slot;
+    memcpy(sys->h_table, table, sizeof(prt_surface_t) * n_surfaces);
+    adopt_image_facts(sys, im);
     return PRT_OK;
 }
 

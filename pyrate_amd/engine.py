@@ -285,6 +285,28 @@ class DeviceSystem(object):
                                               self.device.index, ctypes.byref(handle)))
         self._h = handle
 
+    def update(self, records):
+        """Replace the table IN PLACE (prt_system_update: one asynchronous copy on the current stream, no allocation).
+        True if the library took the new table; False if it does not fit this system's device arrays (another
+        number of surfaces, a longer coefficient array, crystals where there were none ...) -- nothing has changed
+        then and the caller builds a new DeviceSystem.  Traces enqueued on the current stream before the call see
+        the old table."""
+        records = list(records)
+        if len(records) != self.n_surfaces:
+            return False
+        complex_eps = surface_table.has_complex_eps(records)
+        if complex_eps != self.complex_eps:
+            return False
+        table = pack_table(records)
+        rc = self.lib.prt_system_update(self._h, table, self.n_surfaces, _stream_handle(self.device))
+        if rc == _lib.ERR_UNSUPPORTED:
+            return False
+        _lib.check(rc)
+        self.records = records
+        self._table = table
+        self.all_isotropic = all(r["material"]["type"] == "isotropic" for r in records) and not complex_eps
+        return True
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.prt_system_destroy(self._h)

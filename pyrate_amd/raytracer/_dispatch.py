@@ -18,11 +18,13 @@ def system_for(records, device):
     ident = (tuple(map(id, records)), device.index)
     hit = _BY_IDENTITY.get(ident)
     if hit is not None and hit[1]._h:
-        return hit[1]
+        return _on_stream(hit[1], device)
     key = (table_key(records), device.index)
     sysd = _CACHE.get(key)
     if sysd is None:
-        sysd = engine.DeviceSystem(records, device.index)
+        sysd = _recycled(records, device, key)
+        if sysd is None:
+            sysd = engine.DeviceSystem(records, device.index)
         _CACHE[key] = sysd
         while len(_CACHE) > _MAX:
             (_, old) = _CACHE.popitem(last=False)
@@ -32,7 +34,50 @@ def system_for(records, device):
     if len(_BY_IDENTITY) > 256:
         _BY_IDENTITY.clear()
     _BY_IDENTITY[ident] = (list(records), sysd)
+    return _on_stream(sysd, device)
+
+
+def _on_stream(sysd, device):
+    """remember the stream this system's launches go out on (the caller launches on the current one); a system that
+    has been used on more than one stream is never overwritten in place (_recycled)"""
+    import torch
+    cur = torch.cuda.current_stream(device).cuda_stream
+    seen = getattr(sysd, "_dispatch_stream", None)
+    if seen is None:
+        sysd._dispatch_stream = cur
+    elif seen != cur:
+        sysd._dispatch_stream = -1
     return sysd
+
+
+# A table never seen before is the NORMAL case of an optimiser loop (every merit evaluation moves a parameter).  Rather
+# than building a new device system for it -- three allocations, three blocking copies, and sooner or later three
+# frees for the one that falls out of the cache --, the least recently used cached system of the same size is
+# overwritten in place (DeviceSystem.update: one asynchronous copy, ordered on the current stream behind the launches
+# that still use the old content).  Only once the cache holds sixteen tables (wavelength / field sweeps that alternate
+# between a handful of tables keep them all), and only if the old system's launches went out on the stream that is
+# current now (the copy is ordered against that stream only).
+_RECYCLE_FROM = 16
+
+
+def _recycled(records, device, key):
+    if len(_CACHE) < _RECYCLE_FROM:
+        return None
+    import torch
+    stream = torch.cuda.current_stream(device).cuda_stream
+    for (old_key, cand) in _CACHE.items():                # oldest first
+        if old_key[1] != device.index or cand.n_surfaces != len(records) or not cand._h:
+            continue
+        if getattr(cand, "_dispatch_stream", None) != stream:
+            continue
+        if cand.update(records):
+            del _CACHE[old_key]
+            for (ident, (_, s)) in list(_BY_IDENTITY.items()):
+                if s is cand:
+                    del _BY_IDENTITY[ident]
+            return cand
+        return None
+    return None
 
 
 def clear():

@@ -221,6 +221,7 @@ def surface_record(surface, material, is_mirror, wave):
 # look-alikes) and shapes made of other shapes are read afresh every time, like the reference does.
 _RECORD_MEMO = {}
 _RECORD_MEMO_MAX = 4096
+_MEMO_RECORD_IDS = set()      # ids of the records the memo holds (replaced records stay alive in _RECORD_INFO until it is cleared)
 
 
 def _epochs_of(surface, material):
@@ -243,18 +244,60 @@ def surface_record_cached(surface, material, is_mirror, wave):
     hit = _RECORD_MEMO.get(key)
     if hit is not None and hit[0] == epochs:
         return hit[2]
+    if hit is not None:                       # the superseded record leaves the identity tables with its id
+        _MEMO_RECORD_IDS.discard(id(hit[2]))
+        _RECORD_INFO.pop(id(hit[2]), None)
     rec = surface_record(surface, material, is_mirror, wave)
     if len(_RECORD_MEMO) >= _RECORD_MEMO_MAX:
         _RECORD_MEMO.clear()
+        _MEMO_RECORD_IDS.clear()
+        _RECORD_INFO.clear()
     _RECORD_MEMO[key] = (epochs, (surface, material), rec)      # (the objects are kept: their ids stay theirs)
+    _MEMO_RECORD_IDS.add(id(rec))
     return rec
 
 
-def table_key(records):
-    """hashable content key of a list of records (marshal: binary floats -- a tenth of the cost of json.dumps, whose
-    time goes into printing the shortest decimal form of every double)"""
+def _record_key(rec):
+    """content key of ONE record (marshal, version 2: binary floats -- a tenth of the cost of json.dumps, whose time
+    goes into printing the shortest decimal form of every double --, no object back-references: equal content,
+    equal bytes)"""
     import marshal
-    return marshal.dumps(records, 2)      # (version 2: binary floats, no object back-references: equal content, equal bytes)
+    return marshal.dumps(rec, 2)
+
+
+# per record OBJECT: (the record, its content key, its packed prt_surface_t bytes, what those bytes point to).  The
+# records of an unchanged surface are the same dictionaries call after call (surface_record_cached), so neither the
+# key nor the packed form is computed twice for them.  Only for the records of that memo: a table a caller built by
+# hand is keyed by content every time (it may have been edited in between).
+_RECORD_INFO = {}
+_RECORD_INFO_MAX = 4096
+
+
+def _record_info(rec):
+    owned = _RECORD_INFO.get(id(rec))
+    if owned is not None and owned[0] is rec:
+        return owned
+    key = _record_key(rec)
+    packed = _PACKED.get(key)
+    if packed is None:
+        r = pack_record(rec)
+        packed = (bytes(r), getattr(r, "_keepalive", None))
+        if len(_PACKED) >= _PACKED_MAX:
+            _PACKED.clear()
+        _PACKED[key] = packed
+    hit = (rec, key, packed[0], packed[1])
+    if id(rec) in _MEMO_RECORD_IDS:          # (only records this module made and keeps: nobody else holds them to edit)
+        if len(_RECORD_INFO) >= _RECORD_INFO_MAX:
+            _RECORD_INFO.clear()
+        _RECORD_INFO[id(rec)] = hit
+    return hit
+
+
+def table_key(records):
+    """hashable content key of a list of records (or of one record)"""
+    if isinstance(records, dict):
+        return _record_key(records)
+    return tuple(_record_info(r)[1] for r in records)
 
 
 def flatten_element_sequence(element, sequence, background_medium, wave):
@@ -507,19 +550,9 @@ check_complex_media = check_complex_eps
 
 def pack_table(records):
     check_complex_eps(records)
-    blobs = []
-    keep = []
-    for rec in records:
-        key = table_key(rec)
-        hit = _PACKED.get(key)
-        if hit is None:
-            r = pack_record(rec)
-            hit = (bytes(r), getattr(r, "_keepalive", None))
-            if len(_PACKED) >= _PACKED_MAX:
-                _PACKED.clear()
-            _PACKED[key] = hit
-        blobs.append(hit[0])
-        keep.append(hit[1])
+    infos = [_record_info(rec) for rec in records]
+    blobs = [i[2] for i in infos]
+    keep = [i[3] for i in infos]
     table = (PrtSurface * len(records)).from_buffer_copy(b"".join(blobs))
     table._keepalive = keep          # arrays the records' aux pointers refer to
     return table

@@ -11,6 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The arena's hunt for its kinds of HBM is bounded per call by default (32 slabs / 50 ms: the product's first call
+    # must be cheap, and the next calls continue the hunt).  The placement tests of this suite ask what the arena does
+    # once it KNOWS the device's kinds, so the test session lifts the bound like bench.py does; the bounded default
+    # itself is checked in a fresh process (test_gpu_perf.py: test_arena_default_hunt_is_bounded).
+    os.environ.setdefault("PRT_ARENA_HUNT", "full")
     # A process that has hundreds of GiB of device memory mapped must not write a core file if it ever dies:
     # once a crash inside the HIP runtime filled the box's disk that way and took the following run with it.
     try:

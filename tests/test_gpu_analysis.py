@@ -363,7 +363,7 @@ def test_raytrace_prism_like_the_reference_demo(gpu_device, tag, wave):
     (s, seq) = zoo.prism(api)
     rd = dict(zoo.PRISM_RAYS)
     rd["raster"] = raster.MeridionalFan()
-    r = raytrace(s, seq, 20, rd, wave=wave)
+    r = raytrace(s, seq, 128, rd, wave=wave)
     rp = r[0][0]
     assert np.allclose(rp.raybundles[0].x[0], case.x0, rtol=0, atol=1e-14)
     assert np.allclose(np.real(rp.raybundles[0].k[0]), np.real(case.k0), rtol=0, atol=1e-15)

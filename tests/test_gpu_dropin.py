@@ -406,3 +406,91 @@ def test_dropin_splitup_on_foreign_objects_carves_the_paths_out_of_the_dense_tra
     assert len(rpaths) == case.npaths == 4
     for (rp, ref) in zip(rpaths, _raw_paths(case)):
         assert_paths_match(rp, ref)
+
+
+def test_system_update_in_place_equals_a_new_system(gpu_device):
+    """prt_system_update (DeviceSystem.update): a table replaced in place, stream-ordered, gives exactly the trace of
+    a system created from that table -- conic, asphere (longer / shorter coefficient lists within the capacity) and
+    crystal tables (hot blocks + walk program); a table that does not fit is refused and nothing changes; traces
+    enqueued before an update see the old table"""
+    import torch
+    from pyrate_amd import engine, systems
+    (o, k, e0) = systems.double_gauss_bundle(4000, field_deg=3.0)
+    (x0, k0, e0d) = [engine.to_device_rays(a, gpu_device) for a in (o, k, e0)]
+
+    def trace(sysd):
+        r = sysd.trace(x0, k0, e0d)
+        S = sysd.n_surfaces
+        return [r.x_hit[s].clone() for s in range(S)] + [r.k_out[s].clone() for s in range(S)] + \
+               [r.valid_out[s].clone() for s in range(S)]
+
+    def same(a, b):
+        return all(torch.equal(torch.nan_to_num(p), torch.nan_to_num(q)) for (p, q) in zip(a, b))
+    recs_a = systems.double_gauss_records()
+    recs_b = systems.double_gauss_records(486.1e-6)
+    sys_a = engine.DeviceSystem(recs_a, 0)
+    ref_a = trace(sys_a)
+    ref_b = trace(engine.DeviceSystem(recs_b, 0))
+    assert not same(ref_a, ref_b)
+    queued = sys_a.trace(x0, k0, e0d)                    # enqueued BEFORE the update: must see table a
+    assert sys_a.update(recs_b)
+    got_b = trace(sys_a)
+    assert same(got_b, ref_b)
+    assert same([queued.x_hit[-1], queued.k_out[-1]], [ref_a[11], ref_a[23]])
+    for _ in range(12):                                  # the staging ring wraps around
+        assert sys_a.update(recs_a) and same(trace(sys_a), ref_a)
+        assert sys_a.update(recs_b) and same(trace(sys_a), ref_b)
+    assert not sys_a.update(recs_a[:-1])                 # another number of surfaces: refused, nothing changed
+    assert not sys_a.update(systems.asphere_records() + recs_a[4:])    # needs a longer side array than allocated
+    assert same(trace(sys_a), ref_b)
+    # aspheres: fewer coefficients fit the arrays of more
+    (o4, k4, e4) = systems.double_gauss_bundle(3000, rpup=9.0, z0=-5.0, field_deg=5.0)
+    (x4, k4d, e4d) = [engine.to_device_rays(a, gpu_device) for a in (o4, k4, e4)]
+    big = systems.asphere_records(coefficients=(1e-3, -1e-6, 1e-8, 1e-11), curv=-1. / 30., cc=-1.5)
+    small = systems.asphere_records(coefficients=(5e-4, -2e-6), curv=-1. / 40., cc=-1.0)
+    s_big = engine.DeviceSystem(big, 0)
+    want = engine.DeviceSystem(small, 0).trace(x4, k4d, e4d)
+    assert s_big.update(small)
+    got = s_big.trace(x4, k4d, e4d)
+    assert all(torch.equal(torch.nan_to_num(got.x_hit[q]), torch.nan_to_num(want.x_hit[q])) and
+               torch.equal(torch.nan_to_num(got.k_out[q]), torch.nan_to_num(want.k_out[q])) for q in range(4))
+    # crystals: another pair of tensors, same structure
+    c = systems.CALCITE_TILTED
+    rec1 = systems.aniso_doublet_records(systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"]), systems.uniaxial_eps(1.67, 1.60, (0.2, 0.0, 0.98)))
+    rec2 = systems.aniso_doublet_records(systems.uniaxial_eps(1.60, 1.52, (0.0, 0.1, 0.99)), systems.uniaxial_eps(1.70, 1.62, (0.3, 0.0, 0.95)))
+    (oc, kc, ec) = systems.double_gauss_bundle(2000, rpup=11.0, z0=-5.0, field_deg=1.0)
+    (xc, kcd, ecd) = [engine.to_device_rays(a, gpu_device, pitched=False) for a in (oc, kc, ec)]
+    s1 = engine.DeviceSystem(rec1, 0)
+    want = engine.DeviceSystem(rec2, 0).trace(xc, kcd, ecd)
+    assert s1.update(rec2)
+    got = s1.trace(xc, kcd, ecd)
+    assert all(torch.equal(torch.nan_to_num(got.x_hit[q]), torch.nan_to_num(want.x_hit[q])) and
+               torch.equal(torch.nan_to_num(got.k_out[q]), torch.nan_to_num(want.k_out[q])) for q in range(5))
+    assert float((got.k_out[2] - engine.DeviceSystem(rec1, 0).trace(xc, kcd, ecd).k_out[2]).abs().nan_to_num().max()) > 1e-3
+    assert not s1.update(systems.doublet_records())      # no crystals: another structure (no walk program)
+
+
+def test_dispatch_recycles_device_systems_for_tables_never_seen_before(gpu_device):
+    """the optimiser's pattern through the drop-in layer: every call a new table.  The device-system cache overwrites
+    its oldest entry in place (same results as fresh systems; the cache does not grow; tables that alternate are
+    still found)"""
+    from pyrate_amd import systems
+    from pyrate_amd.builders import build_rotationally_symmetric_optical_system
+    from pyrate_amd.raytracer import _dispatch
+    from pyrate_amd.raytracer.ray import RayBundle
+    _dispatch.clear()
+    (s, seq) = build_rotationally_symmetric_optical_system(systems.double_gauss_tuples())
+    (o, k, e0) = systems.double_gauss_bundle(2000, field_deg=2.0)
+    ib = RayBundle(o, k, e0, wave=systems.DLINE)
+    curv = s.elements["stdelem"].surfaces["lens1front"].shape.curvature
+    c0 = curv()
+    outs = []
+    for i in range(40):
+        curv.set_value(c0 * (1.0 + 1e-4 * i))
+        outs.append(s.seqtrace(ib, seq)[0].raybundles[-1].x[-1].copy())
+    assert len(_dispatch._CACHE) <= _dispatch._RECYCLE_FROM + 1
+    _dispatch.clear()
+    for i in (39, 0, 17):
+        curv.set_value(c0 * (1.0 + 1e-4 * i))
+        assert np.array_equal(s.seqtrace(ib, seq)[0].raybundles[-1].x[-1], outs[i])       # fresh systems: same bits
+    curv.set_value(c0)

@@ -224,3 +224,28 @@ def test_arena_reports_partition_mode_and_bounded_hunt(gpu_device):
     assert compute in ("SPX", "DPX", "TPX", "QPX", "CPX", "unknown") and memory.startswith(("NPS", "unknown"))
     if compute in ("SPX", "unknown") and memory in ("NPS1", "unknown"):
         assert ";" not in st["partition_and_note"]          # the mode the kinds were characterised in: classification on
+
+
+def test_arena_default_hunt_is_bounded(gpu_device):
+    """a fresh process with the library's defaults: the first arena allocation takes at most 32 slabs beyond what it
+    needs and probes for at most ~50 ms -- whatever order the driver hands its memory out in -- and still returns
+    usable arrays (fewer kinds if the hunt ended early: the placement says which)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "import torch\n"
+            "from pyrate_amd import engine, placed, systems\n"
+            "sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)\n"
+            "bufs = sysd.alloc_outputs(10_000_000, packed_flags=True, placement='arena')\n"
+            "st = placed.PlacedArena.for_device(0).stats()\n"
+            "print('RESULT ' + json.dumps({'stats': st, 'kinds': bufs['placement']['kinds']}))\n" % root)
+    env = {k: v for (k, v) in os.environ.items() if not k.startswith("PRT_ARENA")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    st = out["stats"]
+    need = 2 * 3                                   # x_hit (+ masks) and k_out of 1e7 rays x 12 surfaces: 3 GiB each
+    assert st["slabs_created"] <= need + 32 + 3    # (+ one representative slab per kind, never handed out)
+    assert st["probe_ms_total"] <= 50.0 + 10.0     # the bound is checked between slabs: one more slab may slip in
+    assert st["hunt"].startswith("bounded") and len(out["kinds"]) == 2
