@@ -249,7 +249,7 @@ static std::vector<walk_step> build_walk_program(const prt_surface_t *table, int
             const int a = level[s];
             walk_step w;
             const int32_t lp = (int32_t)(L & (((int64_t)1 << a) - 1));
-            w.s_pair = s;
+            w.s = s;
             w.bits = a | resume << 8 | lp << 16 | ((s == S - 1) ? 1 : 0) << 24;
             w.cum_in = cum_in[s];
             w.s_park = resume ? s_park : 0;
@@ -274,7 +274,6 @@ static std::vector<walk_step> build_walk_program(const prt_surface_t *table, int
         }
         if (!found) break;
     }
-    for (size_t t = 0; t + 1 < prog.size(); ++t) prog[t].s_pair |= (prog[t + 1].s_pair & 0xffff) << 16;
     walk_step end;
     memset(&end, 0, sizeof end);
     prog.push_back(end);  // sentinel: what the last step prefetches
@@ -540,7 +539,7 @@ static int32_t build_table_image(const prt_surface_t *table, int32_t n_surfaces,
                 for (int q = 0; q < 9; ++q)   // (isotropic records: Im n in slot 0)
                     im.eps_im[(size_t)s * 9 + q] = (table[s].mat_type == PRT_MAT_ANISOTROPIC || q == 0) ? table[s].eps_im[q] : 0.0;
         }
-        if (im.n_aniso > 0 && im.n_aniso <= PRT_FUSED_MAX_CRYSTALS && !im.complex_eps && n_surfaces < 32768) {
+        if (im.n_aniso > 0 && im.n_aniso <= PRT_FUSED_MAX_CRYSTALS && !im.complex_eps) {
             // the fused crystal march (k_trace_general): hot blocks + walk program
             im.hot.resize((size_t)n_surfaces);
             for (int s = 0; s < n_surfaces; ++s) im.hot[s] = hot_block(table[s]);

@@ -46,8 +46,8 @@ struct prt_dev_surface {
 static_assert(sizeof(prt_dev_surface) < 512, "device surface record grew beyond 512 bytes");
 
 // The HOT BLOCK of a surface record: the fields every step of a march through conic surfaces reads, packed into
-// 128 bytes that a wave fetches with two s_load_dwordx16 -- ONE scalar-memory round trip per surface, issued a whole
-// step ahead by the crystal march (k_trace_general), instead of one s_load -> s_waitcnt round trip per field and
+// 128 bytes that a wave fetches with two s_load_dwordx16 -- ONE scalar-memory round trip per step of the crystal
+// march (k_trace_general), issued at the top of the step, instead of one s_load -> s_waitcnt round trip per field and
 // basic block (the compiler places a scalar load in the block that uses it: ~20 dependent round trips per step).
 // Everything else (rotation matrices of tilted frames, the epsilon tensor of biaxial crystals, coefficient
 // pointers) stays in the full record and is fetched where it is needed.

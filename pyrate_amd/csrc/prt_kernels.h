@@ -424,20 +424,19 @@ PRT_DEV PRT_GLOBAL_AS T *uniform_ptr(T *p) {
 // (pitch-relative) offsets the records land.  prt_system_create writes it down once as a list of steps
 // (host: build_walk_program); the kernel executes the list.  What the kernel used to work out per step in
 // scalar arithmetic -- the offsets of the concatenated layout, 64-bit multiplies per row base; a scan of the table
-// at every resume -- is read instead, and because the NEXT step is known, its walk entry and the hot block of its
-// surface (prt_device.h) are fetched one step ahead: the scalar loads of step t+1 are in flight while step t
-// computes, and no step begins by waiting for its own record.
-//   s         surface of this step                         next_s   surface of the FOLLOWING step (prefetch)
-//   (16 bits each; a, resume, lp, last: a byte each)
-//   a         doublings so far = level of a crystal interface met at this step
-//   resume    j + 1: before this step the child parked at level j is taken up; 0: the state is carried on
+// at every resume -- is read instead, and the loads of a step go out together at its top: the two halves of the
+// surface's hot block (prt_device.h) and the walk entry of the NEXT step -- one scalar-memory round trip per step.
+// (Fetching the next step's hot block a step ahead as well was tried: the 32 extra SGPRs spilled)
+//   s         surface of this step
+//   a         doublings so far = level of a crystal interface met at this step        (a, resume, lp, last: a
+//   resume    j + 1: before this step the child parked at level j is taken up; 0: the state is carried on  byte each)
 //   lp        which of the 2^a branches of this level the step's ray is (row block of the concatenated layout)
 //   cum_in    sum of 2^a over the earlier surfaces: offset of the surface's block of x_hit / valid, in units of
 //             the ray pitch P; the same for k_out / valid_out is cum_in + 2^a - 1
 //   s_park    the surface at which the child taken up by `resume` was parked
 //   last      1: s is the last surface of the table (the one record image mode writes)
 struct walk_step {
-    int32_t s_pair;   // s | next_s << 16
+    int32_t s;
     int32_t bits;     // a | resume << 8 | lp << 16 | last << 24
     int32_t cum_in;   // (cum_out = cum_in + 2^a - 1: every earlier crystal interface of level j added 2^j)
     int32_t s_park;   // resume: the surface whose crystal interface parked the child that is taken up
@@ -526,7 +525,7 @@ __global__ __launch_bounds__(PRT_GENERAL_BLOCK, (!GENERAL && !WANT_E && SHAPES =
         // ---- this step's scalars; the next step's loads go out before anything is computed ----
         // ONE scalar-memory round trip per step: both halves of this step's hot block (the late half is not needed
         // before the interaction) and the NEXT walk entry, so that the next step knows its surface when it begins
-        const int32_t s = w[0] & 0xffff;
+        const int32_t s = w[0];
         const prt_d8 h0 = load_hot_half(hot, s, 0);
         const prt_d8 h1 = load_hot_half(hot, s, 1);
         const prt_i4 wn = wp[t + 1];  // (the program ends with a sentinel entry)

@@ -475,7 +475,9 @@ class DeviceSystem(object):
             setattr(a, name, None if t is None else t.data_ptr())
         if bufs.get("e_re") is not None:
             a.e_out_re = bufs["e_re"].data_ptr()
-            a.e_out_im = bufs["e_im"].data_ptr()
+            # Im(E) is zero for a real epsilon and real wave vectors: the array (zeros from alloc_outputs) is handed to
+            # the march only for tables with absorbing media -- 24 B per leaving ray the lossless march need not write
+            a.e_out_im = bufs["e_im"].data_ptr() if self.complex_eps else None
         if bufs.get("k_im") is not None:
             a.k_out_im = bufs["k_im"].data_ptr()
         img = bufs.get("image_rows")
