@@ -57,7 +57,33 @@ x0 = ib._x[-1]
 bufs = sysd.alloc_outputs(o.shape[1], packed_flags=True)
 sysd.trace_timed(x0, None, bufs, 10, uniform=ib._uniform)
 kernel_ms = sysd.trace_timed(x0, None, bufs, 30, uniform=ib._uniform)
-print(json.dumps({"cold_start": {"import_s": t_import, "bundle_upload_ms": t_bundle * 1e3,
+# ---- BASELINE configs[3] through the drop-in layer: the crystal doublet at 1e6 rays (lazy E fields: the trace itself
+# computes no eigenvectors; the first look at an E field traces once more with them)
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import systems_zoo as zoo
+api = zoo.mirror_api()
+c = systems.CALCITE_TILTED
+(sc, seqc) = zoo.aniso_doublet(api, systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"]),
+                               systems.uniaxial_eps(1.6727, 1.60, (np.sin(0.2), 0.0, np.cos(0.2))))
+(oc, kc) = systems.collimated_bundle(1000000, 11.43, -5.0)
+ec = np.ascontiguousarray(np.cross(kc, np.array([1., 0., 0.]), axisa=0, axisb=0).T)
+ibc = api.RayBundle(x0=oc, k0=kc, Efield0=ec, wave=systems.DLINE)
+for _ in range(5):
+    rpc = sc.seqtrace(ibc, seqc)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20):
+    rpc = sc.seqtrace(ibc, seqc)
+t_issue = (time.perf_counter() - t0) * 1e3 / 20
+torch.cuda.synchronize()
+crystal_ms = (time.perf_counter() - t0) * 1e3 / 20
+t0 = time.perf_counter()
+e_last = rpc[0].raybundles[-1].Efield
+crystal_first_efield_ms = (time.perf_counter() - t0) * 1e3
+crystal = {"rays_in": int(oc.shape[1]), "rays_at_the_image": int(e_last.shape[2]),
+           "dropin_seqtrace_ms_back_to_back": crystal_ms, "host_issue_ms": t_issue,
+           "first_look_at_an_E_field_ms": crystal_first_efield_ms}
+print(json.dumps({"crystal_doublet": crystal, "cold_start": {"import_s": t_import, "bundle_upload_ms": t_bundle * 1e3,
                                  "first_seqtrace_ms": t_first * 1e3, "second_seqtrace_ms": t_second * 1e3,
                                  "first_look_at_the_image_plane_ms": t_first_result * 1e3,
                                  "arena_after_first_call": arena_cold,

@@ -326,7 +326,7 @@ class DeviceSystem(object):
         return list(n_in), list(n_out)
 
     def alloc_outputs(self, n0, mode=_lib.MODE_PATH, with_valid_out=True, pitch=None, want_fields=False,
-                      packed_flags=False, placement="auto", extra_bytes=(), want_nonconv=False):
+                      packed_flags=False, placement="auto", extra_bytes=(), want_nonconv=False, want_k_im=False):
         """Output buffers for trace_into.  All-isotropic tables get ROW-PITCHED arrays
         ((S,3,pitch) / (S,pitch), pitch = prt_recommended_pitch(n0) unless given: rows aligned
         to 128-B lines are worth ~35 % HBM write bandwidth); tables with anisotropic media get
@@ -432,8 +432,12 @@ class DeviceSystem(object):
             bufs["e_re"] = torch.zeros(nk, dtype=torch.float64, device=dev)
             bufs["e_im"] = torch.zeros(nk, dtype=torch.float64, device=dev)
             if mode == _lib.MODE_PATH and pitch:      # (the fused march; the per-surface march has no such report)
-                # imaginary parts of the wave vectors: non-zero in the slots of evanescent modes (prt.h k_out_im)
-                bufs["k_im"] = torch.zeros(nk, dtype=torch.float64, device=dev)
+                # imaginary parts of the wave vectors: non-zero in the slots of evanescent modes (prt.h k_out_im;
+                # the library zeroes the array itself before its post-pass fills those slots)
+                bufs["k_im"] = torch.empty(nk, dtype=torch.float64, device=dev)
+        if want_k_im and not want_fields and not self.all_isotropic and mode == _lib.MODE_PATH and pitch:
+            # the complex wave vectors of evanescent modes alone (the fused march's post-pass), without the E fields
+            bufs["k_im"] = torch.empty(nk, dtype=torch.float64, device=dev)
         if self.complex_eps:
             # absorbing crystals: the wave vectors ARE complex (prt.h: k_out_im is required for such tables)
             bufs["k_im"] = torch.zeros(nk, dtype=torch.float64, device=dev)
@@ -558,9 +562,11 @@ class DeviceSystem(object):
         return ms.value
 
     def trace(self, x0, k0, e0_re=None, e0_im=None, mode=_lib.MODE_PATH, want_fields=False,
-              packed_flags=False, want_nonconv=False, uniform=None, first_dir=None):
+              packed_flags=False, want_nonconv=False, uniform=None, first_dir=None, want_k_im=False):
         """OpticalSystem.seqtrace on device tensors; returns a TraceResult of views.
         ``uniform``: a UniformFirst instead of k0 / e0 (collimated bundle: k0 may be None).
+        ``want_k_im`` (tables with crystals, without ``want_fields``): ``TraceResult.k_out_im``, the imaginary parts
+        of the wave vectors of evanescent modes, WITHOUT the E fields -- the march then computes no eigenvectors.
         ``want_nonconv``: also fill ``TraceResult.nonconv`` (per surface, 1 where the Newton iteration of
         an explicit shape ended at its cap; with ``packed_flags`` it is always there, bit 2 of the flags)."""
         n0 = x0.shape[1]
@@ -576,7 +582,7 @@ class DeviceSystem(object):
         with torch.cuda.device(self.device):
             bufs = self.alloc_outputs(n0, mode, want_fields=want_fields,
                                       packed_flags=packed_flags and self.all_isotropic,
-                                      want_nonconv=want_nonconv and not want_fields)
+                                      want_nonconv=want_nonconv and not want_fields, want_k_im=want_k_im)
             self.trace_into(x0, k0, bufs, e0_re, e0_im, uniform=uniform, first_dir=first_dir)
         return self.views(bufs)
 

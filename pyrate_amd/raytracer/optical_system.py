@@ -185,6 +185,21 @@ def seqtrace_fused(ib, records, lengths):
     return _assemble_path(bundles, lengths, res)
 
 
+class _LazyFields(object):
+    """(E_re, E_im) of a bundle behind a crystal interface, made when somebody looks: ``pair[0]``, ``pair[1]``"""
+
+    def __init__(self, make):
+        self._make = make
+        self._pair = None
+
+    def __getitem__(self, i):
+        if self._pair is None:
+            (er, ei) = self._make()
+            self._pair = (er, ei)
+            self._make = None
+        return self._pair[i]
+
+
 def _first_bundle(ib, res):
     """bundle 0 of a traced path: copy of the initial bundle + the first hit point.  The copy is taken now (the
     caller may go on using ``ib``); the mask arithmetic of the appended point (two small kernels) waits until
@@ -240,7 +255,24 @@ def _seqtrace_fused_crystal(ib, records, lengths, split=False):
     sysd = _dispatch.system_for(records, dev)
     S = len(records)
     x0 = ib._x[-1]
-    res = sysd.trace(x0, mode=_lib.MODE_PATH, want_fields=True, **_first_segment(ib))
+    first = _first_segment(ib)
+    # The E fields of the doubled rays (material_anisotropic.py:91-99) are what RayBundle.Efield shows and what a
+    # caller needs who goes on from one of these bundles by hand -- not what the trace needs: ray directions come
+    # from closed forms (prt_aniso.h).  Lossless crystals are therefore traced WITHOUT fields (no eigenvectors, a
+    # third of the time), and the first look at an E field traces the sequence once more with them
+    # (``dense_fields``; the table is looked up again by content: the device system of this call may have been
+    # overwritten for another table in the meantime).  Absorbing media keep the fields: their march is per surface.
+    eager_fields = sysd.complex_eps
+    res = sysd.trace(x0, mode=_lib.MODE_PATH, want_fields=eager_fields, want_k_im=not eager_fields, **first)
+    fields_cache = []
+
+    def dense_fields():
+        if eager_fields:
+            return res.padded
+        if not fields_cache:
+            again = _dispatch.system_for(records, dev).trace(x0, mode=_lib.MODE_PATH, want_fields=True, **first)
+            fields_cache.append(again.padded)
+        return fields_cache[0]
     n = x0.shape[1]
     wave = ib.wave
     crystal = [r["material"]["type"] == "anisotropic" for r in records]
@@ -284,7 +316,7 @@ def _seqtrace_fused_crystal(ib, records, lengths, split=False):
                 xs = torch.cat((xs, xs), dim=1)
             arrays = [xs, cut(dense.k_out[s], level)]
             with_kim = dense.k_out_im is not None and (crystal[s] or (absorbing and s == S - 1))
-            if crystal[s]:
+            if crystal[s] and eager_fields:
                 arrays += [cut(t, level) for t in dense.e_out[s]]
             if with_kim:
                 arrays.append(cut(dense.k_out_im[s], level))   # Im(k): evanescent modes / absorbing crystals
@@ -295,8 +327,14 @@ def _seqtrace_fused_crystal(ib, records, lengths, split=False):
             out = engine.compact(mask, arrays, dense_ids(level if branch is None else 0), flags)
             arr = out[0]
             (cx, ck) = (arr[0], arr[1])
-            e = (arr[2], arr[3]) if crystal[s] else None
-            b._k_im = [arr[4 if crystal[s] else 2]] if with_kim else None
+            n_e = 2 if (crystal[s] and eager_fields) else 0
+            if n_e:
+                e = (arr[2], arr[3])
+            elif crystal[s]:
+                e = _LazyFields(lambda: engine.compact(mask, [cut(t, level) for t in dense_fields().e_out[s]])[0])
+            else:
+                e = None
+            b._k_im = [arr[2 + n_e]] if with_kim else None
             m = cx.shape[1]
             b._x = [cx]
             b._k = [ck]
