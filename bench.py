@@ -914,6 +914,13 @@ def main():
             # the bundle of the multi-GPU protocol (--scaling strong: 1e8 rays, 61 GB of path arrays) on this one GPU
             watchdog.stage = "scaling point (1e8 rays)"
             try:
+                # (the arena starts over: the 2 x 29 slabs of this bundle are taken and classified like in a process
+                # of their own, not pieced together from what the smaller configurations left cached)
+                if args.placement == "arena":
+                    from pyrate_amd import placed
+                    torch.cuda.synchronize()
+                    placed.PlacedArena.for_device(dev.index).trim()
+                torch.cuda.empty_cache()
                 sp = measure_single("doublegauss", args, dev, STRONG_SCALING_RAYS, with_cpu=False, verify_oracle=False)
                 scaling_point = {"what": "BASELINE configs[4]'s bundle (--scaling strong: %d rays) traced by ONE GPU, one "
                                          "wavelength: the N = 1 point of the strong-scaling curve (the headline above is "
