@@ -107,7 +107,10 @@ def main():
         out["sizes"][str(n_req)] = rec
         if os.environ.get("PRT_LATENCY_PROFILE") and n_req == 1000:      # where the host's time goes (stderr)
             import cProfile, pstats
-            for (tag, fn) in (("seqtrace", f_seq), ("image_moments", f_mom)):
+            def f_new():
+                change_new()
+                f_seq()
+            for (tag, fn) in (("seqtrace", f_seq), ("image_moments", f_mom), ("seqtrace with a table never seen before", f_new)):
                 prof = cProfile.Profile()
                 prof.enable()
                 for _ in range(500):

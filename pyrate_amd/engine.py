@@ -284,6 +284,7 @@ class DeviceSystem(object):
         _lib.check(self.lib.prt_system_create(self._table, self.n_surfaces,
                                               self.device.index, ctypes.byref(handle)))
         self._h = handle
+        self._counts = {}          # ray_counts by n0
 
     def update(self, records):
         """Replace the table IN PLACE (prt_system_update: one asynchronous copy on the current stream, no allocation).
@@ -304,6 +305,7 @@ class DeviceSystem(object):
         _lib.check(rc)
         self.records = records
         self._table = table
+        self._counts = {}
         self.all_isotropic = all(r["material"]["type"] == "isotropic" for r in records) and not complex_eps
         return True
 
@@ -320,10 +322,15 @@ class DeviceSystem(object):
 
     # -- bookkeeping ------------------------------------------------------
     def ray_counts(self, n0):
-        n_in = (ctypes.c_int64 * self.n_surfaces)()
-        n_out = (ctypes.c_int64 * self.n_surfaces)()
-        _lib.check(self.lib.prt_system_ray_counts(self._h, n0, n_in, n_out))
-        return list(n_in), list(n_out)
+        hit = self._counts.get(n0)
+        if hit is None:
+            n_in = (ctypes.c_int64 * self.n_surfaces)()
+            n_out = (ctypes.c_int64 * self.n_surfaces)()
+            _lib.check(self.lib.prt_system_ray_counts(self._h, n0, n_in, n_out))
+            if len(self._counts) > 64:
+                self._counts.clear()
+            hit = self._counts[n0] = (tuple(n_in), tuple(n_out))
+        return list(hit[0]), list(hit[1])
 
     def alloc_outputs(self, n0, mode=_lib.MODE_PATH, with_valid_out=True, pitch=None, want_fields=False,
                       packed_flags=False, placement="auto", extra_bytes=(), want_nonconv=False, want_k_im=False):

@@ -16,11 +16,28 @@
 import torch
 
 from .. import _lib, engine
-from ..surface_table import UnsupportedError, flatten_sequence, has_complex_eps
+from ..surface_table import UNTRACKED_READS, UnsupportedError, flatten_sequence, has_complex_eps
 from . import _dispatch
 from .localcoordinates import LocalCoordinates, LocalCoordinatesTreeBase
 from .material.material_isotropic import ConstantIndexGlass
 from .ray import RayBundle, RayPath
+from .variables import mutation_epoch
+
+
+class _Records(list):
+    """the flattened records of a sequence + the facts the dispatch needs about them (computed once per walk)"""
+    __slots__ = ("crystals", "complex_eps")
+
+    def __init__(self, records):
+        list.__init__(self, records)
+        self.crystals = sum(r["material"]["type"] == "anisotropic" for r in records)
+        self.complex_eps = has_complex_eps(records)
+
+
+def _facts(records):
+    if isinstance(records, _Records):
+        return records.crystals, records.complex_eps
+    return (sum(r["material"]["type"] == "anisotropic" for r in records), has_complex_eps(records))
 
 
 class OpticalSystem(LocalCoordinatesTreeBase):
@@ -30,13 +47,30 @@ class OpticalSystem(LocalCoordinatesTreeBase):
         LocalCoordinatesTreeBase.__init__(self, rootlc, name=name)
         self.material_background = matbackground
         self.elements = {}
+        object.__setattr__(self, "_last_flat", None)     # (not a mutation of the system: OpticalSystem._flattened)
 
     def _flattened(self, elementsequence, wave):
-        """``flatten_sequence`` of this system.  Cheap when nothing changed: every record comes back from the memo of
-        ``surface_table.surface_record_cached`` (keyed by the epochs of the objects it was read from,
-        variables.py), so an unchanged 12-surface system costs a walk over 12 dictionary look-ups, and the table
-        the records form is recognised by identity (_dispatch.system_for)."""
-        return flatten_sequence(self, elementsequence, wave)
+        """``flatten_sequence`` of this system -- or its result of the last call, when NOTHING has been mutated since
+        (``variables.mutation_epoch``: every mutation path of this package's classes advances it) and the sequence
+        is equal, entry by entry, to the one of that call (a copy is kept: the caller's list is his to edit).  The
+        check costs a comparison of two short nested lists; repeated traces of an unchanged system (field points,
+        the merit evaluations between two optimiser steps) skip the walk through the object graph altogether.
+        After a mutation the walk itself is cheap where nothing changed (``surface_table.surface_record_cached``)."""
+        last = self._last_flat
+        now = mutation_epoch()
+        if last is not None and last[0] == now and last[1] == wave and last[2] == elementsequence:
+            return last[3], last[4]
+        untracked = UNTRACKED_READS[0]
+        (records, lengths) = flatten_sequence(self, elementsequence, wave)
+        records = _Records(records)
+        try:
+            saved = [(ek, [(sk, dict(opts)) for (sk, opts) in sub]) for (ek, sub) in elementsequence]
+        except (TypeError, ValueError):
+            saved = None
+        if UNTRACKED_READS[0] != untracked:
+            saved = None             # a record came from an object without mutation epochs: nothing to vouch for it
+        object.__setattr__(self, "_last_flat", None if saved is None else (mutation_epoch(), wave, saved, records, lengths))
+        return records, lengths
 
     @classmethod
     def p(cls, rootlc=None, matbackground=None, name=""):
@@ -61,14 +95,14 @@ class OpticalSystem(LocalCoordinatesTreeBase):
         # e.g. [("elem1", [("surf1", {}), ("surf2", {"is_mirror": True})]), ("elem2", [...])]
         (records, lengths) = self._flattened(elementsequence, initialbundle.wave)
         initialbundle._ensure()
-        crystals = sum(r["material"]["type"] == "anisotropic" for r in records)
+        (crystals, complex_media) = _facts(records)
         fused_ok = initialbundle._dir is None and len(records) > 0 \
             and (crystals == 0 or (not splitup and crystals <= MAX_FUSED_CRYSTALS))
         if fused_ok and len(initialbundle._valid) > 1 and not bool(initialbundle._valid[-1].all()):
             fused_ok = False      # a bundle that already carries invalid rays: per-surface path
         if fused_ok:
             return [self._seqtrace_fused(initialbundle, records, lengths)]
-        if has_complex_eps(records):
+        if complex_media:
             # absorbing media: the per-surface plugin calls have no complex wave vectors in their signature, so there
             # is no plugin-granular fall-back -- the forked paths of ``splitup`` are the branches of ONE dense trace,
             # anything else (explicit first directions, a bundle that already carries invalid rays, too many crystal
@@ -137,7 +171,8 @@ def seqtrace_fused(ib, records, lengths):
     the reference's bundle structure (lazy, device-resident).  Needs only the surface-table
     records, so it serves any object graph ``flatten_sequence`` understands (this package's
     classes or real pyrateoptics objects, see pyrate_amd/dropin.py)."""
-    if any(r["material"]["type"] == "anisotropic" for r in records) or has_complex_eps(records):
+    (crystals, complex_media) = _facts(records)
+    if crystals or complex_media:
         return _seqtrace_fused_crystal(ib, records, lengths)
     dev = ib.device
     sysd = _dispatch.system_for(records, dev)

@@ -236,9 +236,13 @@ def _epochs_of(surface, material):
         return None
 
 
+UNTRACKED_READS = [0]      # records read from objects without epochs (a caller that caches whole walks must not, then)
+
+
 def surface_record_cached(surface, material, is_mirror, wave):
     epochs = _epochs_of(surface, material)
     if epochs is None:
+        UNTRACKED_READS[0] += 1
         return surface_record(surface, material, is_mirror, wave)
     key = (id(surface), id(material), bool(is_mirror), wave)
     hit = _RECORD_MEMO.get(key)

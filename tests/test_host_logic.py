@@ -613,3 +613,46 @@ def test_record_memo_follows_every_mutation_path_of_the_mirror_classes():
         front.shape.lc.globalcoordinates[2] = 5.0               # held arrays are read-only: no silent stale table
     with pytest.raises(ValueError):
         elem.materials[elem.annotations["surf_mat_connection"]["extra"][1]].epstensor[0, 0] = 3.0
+
+
+def test_whole_walk_is_reused_only_while_nothing_can_have_changed():
+    """OpticalSystem._flattened hands back the records of the last call only if the mutation epoch stands still, the
+    wavelength is the same and the sequence equals, entry by entry, the one of that call (the caller's list may be
+    edited in place); a system that holds an object WITHOUT mutation epochs (a duck-typed stand-in, a class of the
+    reference) is walked every time"""
+    from pyrate_amd import systems
+    from pyrate_amd.builders import build_simple_optical_system
+    wave = 0.5876e-3
+    (s, seq) = build_simple_optical_system(systems.doublet_builduplist())
+    (r1, _) = s._flattened(seq, wave)
+    (r2, _) = s._flattened(seq, wave)
+    assert r2 is r1                                                 # the same list: no walk
+    assert s._flattened([(seq[0][0], list(seq[0][1]))], wave)[0] is r1   # an equal sequence in another list
+    seq[0][1][2] = (seq[0][1][2][0], {"is_mirror": True})          # the caller edits his sequence in place
+    (r3, _) = s._flattened(seq, wave)
+    assert r3 is not r1 and r3[2]["interaction"] == "mirror" and r1[2]["interaction"] == "refract"
+    assert s._flattened(seq, 0.4861e-3)[0] is not r3                # another wavelength
+    (r4, _) = s._flattened(seq, wave)
+    s.elements["stdelem"].surfaces["front"].shape.curvature.set_value(0.02)
+    (r5, _) = s._flattened(seq, wave)
+    assert r5 is not r4 and r5[1]["shape"]["curv"] == 0.02 and r5[0] is r4[0]   # one surface re-read
+
+    class ForeignShape(object):                                     # no epochs: its state can change unseen
+        kind = "shape_Conic"
+
+        def __init__(self, lc):
+            self.lc = lc
+            self.c = 0.01
+
+        def curvature(self):
+            return self.c
+
+        def conic(self):
+            return 0.0
+    front = s.elements["stdelem"].surfaces["front"]
+    foreign = ForeignShape(front.shape.lc)
+    front.shape = foreign
+    (a, _) = s._flattened(seq, wave)
+    foreign.c = 0.03                                                # ... and does
+    (b, _) = s._flattened(seq, wave)
+    assert a[1]["shape"]["curv"] == 0.01 and b[1]["shape"]["curv"] == 0.03
