@@ -15,9 +15,18 @@ _BY_IDENTITY = {}
 
 
 def system_for(records, device):
+    # the very list OpticalSystem._flattened handed out last time (nothing changed since): its device system hangs on
+    # it -- valid while that system has not been overwritten for another table (DeviceSystem.update counts)
+    pinned = getattr(records, "device_systems", None)
+    if pinned is not None:
+        ent = pinned.get(device.index)
+        if ent is not None and ent[0]._h and ent[0].updates == ent[1]:
+            return _on_stream(ent[0], device)
     ident = (tuple(map(id, records)), device.index)
     hit = _BY_IDENTITY.get(ident)
     if hit is not None and hit[1]._h:
+        if pinned is not None:
+            pinned[device.index] = (hit[1], hit[1].updates)
         return _on_stream(hit[1], device)
     key = (table_key(records), device.index)
     sysd = _CACHE.get(key)
@@ -34,14 +43,15 @@ def system_for(records, device):
     if len(_BY_IDENTITY) > 256:
         _BY_IDENTITY.clear()
     _BY_IDENTITY[ident] = (list(records), sysd)
+    if pinned is not None:
+        pinned[device.index] = (sysd, sysd.updates)
     return _on_stream(sysd, device)
 
 
 def _on_stream(sysd, device):
     """remember the stream this system's launches go out on (the caller launches on the current one); a system that
     has been used on more than one stream is never overwritten in place (_recycled)"""
-    import torch
-    cur = torch.cuda.current_stream(device).cuda_stream
+    cur = engine.raw_stream(device)
     seen = getattr(sysd, "_dispatch_stream", None)
     if seen is None:
         sysd._dispatch_stream = cur
@@ -63,8 +73,7 @@ _RECYCLE_FROM = 16
 def _recycled(records, device, key):
     if len(_CACHE) < _RECYCLE_FROM:
         return None
-    import torch
-    stream = torch.cuda.current_stream(device).cuda_stream
+    stream = engine.raw_stream(device)
     for (old_key, cand) in _CACHE.items():                # oldest first
         if old_key[1] != device.index or cand.n_surfaces != len(records) or not cand._h:
             continue

@@ -26,10 +26,11 @@ from .variables import mutation_epoch
 
 class _Records(list):
     """the flattened records of a sequence + the facts the dispatch needs about them (computed once per walk)"""
-    __slots__ = ("crystals", "complex_eps")
+    __slots__ = ("crystals", "complex_eps", "device_systems")
 
     def __init__(self, records):
         list.__init__(self, records)
+        self.device_systems = {}      # device index -> (DeviceSystem, its update count): raytracer/_dispatch.py
         self.crystals = sum(r["material"]["type"] == "anisotropic" for r in records)
         self.complex_eps = has_complex_eps(records)
 
@@ -188,7 +189,7 @@ def seqtrace_fused(ib, records, lengths):
     wave = ib.wave
     kc = ib._k_complex
 
-    b0 = _first_bundle(ib, res)
+    c0 = ib.clone()           # taken now: the caller may go on using (and appending to) ``ib``
 
     def make_thunk(j):
         def thunk(b):
@@ -216,8 +217,12 @@ def seqtrace_fused(ib, records, lengths):
             b._k_complex = kc
         return thunk
 
-    bundles = [b0] + [RayBundle._lazy(make_thunk(j), wave, dev) for j in range(1, S + 1)]
-    return _assemble_path(bundles, lengths, res)
+    def bundles():
+        return _bundle_list([_first_bundle(c0, res)] + [RayBundle._lazy(make_thunk(j), wave, dev)
+                                                        for j in range(1, S + 1)], lengths)
+    path = RayPath._deferred(bundles)
+    path.dense = res                                  # dense device arrays for GPU consumers
+    return path
 
 
 class _LazyFields(object):
@@ -235,26 +240,31 @@ class _LazyFields(object):
         return self._pair[i]
 
 
-def _first_bundle(ib, res):
-    """bundle 0 of a traced path: copy of the initial bundle + the first hit point.  The copy is taken now (the
-    caller may go on using ``ib``); the mask arithmetic of the appended point (two small kernels) waits until
-    somebody looks at the bundle, like the compaction of the later bundles"""
-    c0 = ib.clone()
-
+def _first_bundle(c0, res):
+    """bundle 0 of a traced path: ``c0`` -- a copy of the initial bundle, taken by the caller at trace time (the user
+    may go on using the original) -- + the first hit point.  The mask arithmetic of the appended point (two small
+    kernels) waits until somebody looks at the bundle, like the compaction of the later bundles"""
     def thunk(b):
         c0._append_device(res.x_hit[0], res.valid[0] * c0._valid[-1])
         b.__dict__.update(c0.__dict__)
-    return RayBundle._lazy(thunk, ib.wave, ib.device, splitted=ib.splitted)
+    return RayBundle._lazy(thunk, c0.wave, c0.device, splitted=c0.splitted)
+
+
+def _bundle_list(bundles, lengths):
+    """the reference's list for a path through elements of ``lengths`` surfaces: initial bundle, then per element
+    the bundle it starts from once more (the element restarts with the same bundle) and one bundle per surface"""
+    out = [bundles[0]]
+    idx = 0
+    for L in lengths:
+        out.append(bundles[idx])
+        out.extend(bundles[idx + 1:idx + L + 1])
+        idx += L
+    return out
 
 
 def _assemble_path(bundles, lengths, res):
-    path = RayPath(bundles[0])
-    idx = 0
-    for L in lengths:
-        path.appendRayBundle(bundles[idx])           # the element restarts with the same bundle
-        for l in range(L):
-            path.appendRayBundle(bundles[idx + l + 1])
-        idx += L
+    path = RayPath()
+    path.raybundles = _bundle_list(bundles, lengths)
     path.dense = res                                  # dense device arrays for GPU consumers
     return path
 
@@ -388,7 +398,7 @@ def _seqtrace_fused_crystal(ib, records, lengths, split=False):
         return thunk
 
     def path_of(branch):
-        bundles = [_first_bundle(ib, res)]
+        bundles = [_first_bundle(ib.clone(), res)]
         for j in range(1, S + 1):
             b = RayBundle._lazy(make_thunk(j, branch), wave, dev, splitted=crystal[j - 1] and branch is None)
             b._dir_from_k = not crystal[j - 1]

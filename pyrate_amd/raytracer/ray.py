@@ -397,7 +397,31 @@ class RayPath(object):
     """list of RayBundles (ray.py:207-260)"""
 
     def __init__(self, initialraybundle=None):
-        self.raybundles = [] if initialraybundle is None else [initialraybundle]
+        self._make = None
+        self._bundles = [] if initialraybundle is None else [initialraybundle]
+
+    @classmethod
+    def _deferred(cls, make):
+        """a path whose list of bundles is built by ``make()`` when somebody first looks at ``raybundles`` -- the
+        bundles of a traced path are lazy views of the dense device arrays anyway, and an optimiser loop that reads
+        ``path.dense`` (or only the last bundle) need not pay for thirteen of them per call"""
+        self = cls.__new__(cls)
+        self._make = make
+        self._bundles = None
+        return self
+
+    @property
+    def raybundles(self):
+        if self._make is not None:
+            make = self._make
+            self._make = None
+            self._bundles = make()
+        return self._bundles
+
+    @raybundles.setter
+    def raybundles(self, value):
+        self._make = None
+        self._bundles = value
 
     def appendRayBundle(self, raybundle):
         self.raybundles.append(raybundle)

@@ -656,3 +656,35 @@ def test_whole_walk_is_reused_only_while_nothing_can_have_changed():
     foreign.c = 0.03                                                # ... and does
     (b, _) = s._flattened(seq, wave)
     assert a[1]["shape"]["curv"] == 0.01 and b[1]["shape"]["curv"] == 0.03
+
+
+def test_deferred_raypath_is_a_plain_list_once_somebody_looks():
+    """RayPath._deferred: the bundle list of a traced path is built on first access and is an ordinary list from
+    then on (append / += / assignment / containsSplitted behave like the reference's attribute, ray.py:207-260)"""
+    from pyrate_amd.raytracer.ray import RayPath
+
+    class B(object):
+        def __init__(self, tag, splitted=False):
+            (self.tag, self.splitted) = (tag, splitted)
+
+        def clone(self):
+            return B(self.tag, self.splitted)
+    calls = []
+
+    def make():
+        calls.append(1)
+        return [B(0), B(1, True)]
+    p = RayPath._deferred(make)
+    p.dense = "dense arrays"
+    assert calls == []                                   # nothing built by the trace itself
+    assert [b.tag for b in p.raybundles] == [0, 1] and type(p.raybundles) is list
+    assert p.raybundles is p.raybundles and calls == [1]
+    p.appendRayBundle(B(2))
+    q = RayPath(B(9))
+    q.appendRayPath(p)
+    assert [b.tag for b in q.raybundles] == [9, 0, 1, 2] and q.containsSplitted()
+    c = RayPath._deferred(make).clone()                  # cloning looks, too
+    assert [b.tag for b in c.raybundles] == [0, 1] and calls == [1, 1]
+    r = RayPath._deferred(make)
+    r.raybundles = []                                    # plain assignment wins over the pending builder
+    assert r.raybundles == [] and calls == [1, 1]
