@@ -34,6 +34,7 @@
  *                        AnisotropicMaterial.refract raytracer/material/material_anisotropic.py:70-113
  *                        AnisotropicMaterial.reflect raytracer/material/material_anisotropic.py:115-155
  *                        RayBundle.getLocalSurfaceNormal  raytracer/ray.py:156-161
+ *   prt_interact_cplx    the same calls with complex wave vectors (absorbing media)
  *   prt_shape_eval       Shape.getSag / getGrad / getNormal   raytracer/surface_shape.py:71-112
  *   prt_compact          boolean fancy indexing [:, valid]    raytracer/material/material_isotropic.py:194-199
  *
@@ -132,7 +133,7 @@ typedef struct prt_surface {
      * (material_isotropic.py:72-128), so the direction of the ray, and every later hit point, is LAPACK's arbitrary
      * pick.  Such tables are traced by prt_trace_ex with k_out_im (required: the imaginary parts of the wave
      * vectors), tight arrays (pitch 0), the concatenated layout, one launch pair per surface
-     * (csrc/prt_aniso_cplx.h); prt_interact refuses their crystal surfaces. */
+     * (csrc/prt_aniso_cplx.h); one surface at a time: prt_interact_cplx (prt_interact has no complex k and refuses). */
     /* host-side classification of a real symmetric eps (an optimisation AND what keeps the
      * touching-sheet directions well conditioned, see csrc/prt_aniso.h):
      * ISOTROPIC: eps = aniso_eo I;  UNIAXIAL: eps = aniso_eo I + (aniso_ee-aniso_eo) c c^T,
@@ -371,6 +372,22 @@ int32_t prt_propagate(const prt_system_t *sys, int32_t surface, int64_t n, const
 int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const double *x_hit,
                      const double *k, const uint8_t *valid_in, double *k_out, double *dir_out,
                      double *e_out_re, double *e_out_im, uint8_t *valid_out, void *stream);
+
+/*
+ * The same plugin call with COMPLEX wave vectors (absorbing media: a complex epsilon tensor,
+ * material_anisotropic.py:52-56, 70-113; a complex refractive index, material_isotropic.py:137-199; and whatever
+ * comes behind them): k = k_re + i k_im in (k_im NULL: real), k_out_re / k_out_im out, both required.
+ *   anisotropic: (3,2n) outputs in [sol2, sol3] stacking, dir_out (3,2n) required, e_out_* (3,2n) or NULL,
+ *                valid_out (2n) all 1; lossless crystals are taken too (a complex k may enter one).
+ *   isotropic:   k = k_inplane + xi n with the complex xi (principal square root), valid_out = valid_in and
+ *                Re(xi^2) > 0 (NumPy's order of complex numbers); dir_out is not written: the reference's ray
+ *                direction behind such an interface is an arbitrary null vector of an SVD (see eps_im above), so
+ *                a sequence ends there.  A mirror inside an absorbing isotropic medium: PRT_ERR_UNSUPPORTED.
+ */
+int32_t prt_interact_cplx(const prt_system_t *sys, int32_t surface, int64_t n, const double *x_hit,
+                          const double *k_re, const double *k_im, const uint8_t *valid_in, double *k_out_re,
+                          double *k_out_im, double *dir_out, double *e_out_re, double *e_out_im, uint8_t *valid_out,
+                          void *stream);
 
 /* Shape.getSag / getGrad: x, y (n) in the shape frame -> sag (n) and/or grad (3,n)
  * (either output may be NULL). */

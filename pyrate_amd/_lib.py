@@ -63,6 +63,9 @@ PROTOTYPES = {
     "prt_interact": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                       c_double_p, c_double_p, c_u8_p, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_u8_p, c_stream]),
+    "prt_interact_cplx": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p,
+                                           c_double_p, c_u8_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                                           c_double_p, c_u8_p, c_stream]),
     "prt_shape_eval": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                         c_double_p, c_double_p, c_double_p, c_double_p,
                                         c_stream]),

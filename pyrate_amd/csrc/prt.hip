@@ -1367,8 +1367,9 @@ int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const 
     // to take nor one to give back.  Dropping Im(n) silently would return real-index wave vectors and masks that
     // disagree with the fused path and with the reference.
     if (sys->complex_eps)
-        return fail(PRT_ERR_UNSUPPORTED, "prt_interact: a table with absorbing media (complex epsilon / complex index) is "
-                                         "traced as a whole (prt_trace_ex with k_out_im; the wave vectors are complex)");
+        return fail(PRT_ERR_UNSUPPORTED, "prt_interact: a table with absorbing media (complex epsilon / complex index) has "
+                                         "complex wave vectors: prt_interact_cplx (one surface) or prt_trace_ex with "
+                                         "k_out_im (the whole sequence)");
     if (rec->mat_type == PRT_MAT_ANISOTROPIC) {
         if (!dir_out) return fail(PRT_ERR_INVALID_ARG, "prt_interact: anisotropic needs dir_out");
         hipLaunchKernelGGL(k_interact_aniso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
@@ -1378,6 +1379,34 @@ int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const 
         hipLaunchKernelGGL(k_interact_iso, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0,
                            (hipStream_t)stream, sys->d_table + surface, n, x_hit, k, valid_in,
                            k_out, dir_out, valid_out);
+    }
+    HIP_TRY(hipGetLastError());
+    return PRT_OK;
+}
+
+int32_t prt_interact_cplx(const prt_system_t *sys, int32_t surface, int64_t n, const double *x_hit,
+                          const double *k_re, const double *k_im, const uint8_t *valid_in, double *k_out_re,
+                          double *k_out_im, double *dir_out, double *e_out_re, double *e_out_im, uint8_t *valid_out,
+                          void *stream) {
+    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0)
+        return fail(PRT_ERR_INVALID_ARG, "prt_interact_cplx: bad system / surface / count");
+    if (n == 0) return PRT_OK;
+    if (!x_hit || !k_re || !k_out_re || !k_out_im) return fail(PRT_ERR_INVALID_ARG, "prt_interact_cplx: null pointer");
+    PRT_ON_DEVICE(sys->device);
+    const prt_surface_t *rec = sys->h_table + surface;
+    if (rec->mat_type == PRT_MAT_ANISOTROPIC) {
+        if (!dir_out) return fail(PRT_ERR_INVALID_ARG, "prt_interact_cplx: anisotropic needs dir_out");
+        // (every ray leaves a crystal interface, like in k_interact_aniso: AnisotropicMaterial.refract restarts validity)
+        hipLaunchKernelGGL(k_interact_aniso_cplx, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0, (hipStream_t)stream,
+                           sys->d_table + surface, sys->d_eps_im ? sys->d_eps_im + (size_t)surface * 9 : (const double *)nullptr,
+                           n, x_hit, k_re, k_im, (const uint8_t *)nullptr, k_out_re, k_out_im, dir_out, e_out_re, e_out_im,
+                           valid_out);
+    } else {
+        if (rec->eps_im[0] != 0.0 && rec->interaction == PRT_MIRROR)
+            return fail(PRT_ERR_UNSUPPORTED, "prt_interact_cplx: a mirror inside an absorbing isotropic medium");
+        hipLaunchKernelGGL(k_interact_iso_cplx, dim3(nblocks(n, PRT_BLOCK)), dim3(PRT_BLOCK), 0, (hipStream_t)stream,
+                           sys->d_table + surface, rec->eps_im[0], n, x_hit, k_re, k_im, valid_in, k_out_re, k_out_im,
+                           valid_out);
     }
     HIP_TRY(hipGetLastError());
     return PRT_OK;

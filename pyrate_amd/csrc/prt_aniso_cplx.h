@@ -195,7 +195,7 @@ PRT_DEV void interact_anisotropic_cplx(const prt_dev_surface *__restrict__ sf, c
                                        const vec3 &n, const vec3 &k_re, const vec3 &k_im,
                                        aniso_solution_cplx out[2]) {
     cx eps[9];
-    for (int q = 0; q < 9; ++q) eps[q] = cx{sf->eps_re[q], eps_im[q]};
+    for (int q = 0; q < 9; ++q) eps[q] = cx{sf->eps_re[q], eps_im ? eps_im[q] : 0.0};     // (NULL: a lossless crystal)
     const cvec3 k1 = cv3(matT_vec(sf->B_mat, k_re), matT_vec(sf->B_mat, k_im));
     const cx kn = cv_dot(k1, n);
     const cvec3 kpa = cvec3{k1.x - n.x * kn, k1.y - n.y * kn, k1.z - n.z * kn};

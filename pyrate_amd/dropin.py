@@ -35,12 +35,11 @@ def seqtrace(system, initialbundle, elementsequence, splitup=False, device=None)
     if not records:
         raise UnsupportedError("empty sequence")
     crystals = sum(r["material"]["type"] != "isotropic" for r in records)
-    if has_complex_eps(records) and (crystals > MAX_FUSED_CRYSTALS or ib._dir is not None):
-        # (absorbing media: complex wave vectors; the plugin-granular loop has no place for them)
-        raise UnsupportedError("a sequence through absorbing media is traced as a whole: no explicit first-segment "
-                               "directions, at most %d crystal interfaces" % MAX_FUSED_CRYSTALS)
-    if crystals and (splitup or crystals > MAX_FUSED_CRYSTALS or ib._dir is not None):
-        if hasattr(system, "_seqtrace_generic") and not has_complex_eps(records):
+    absorbing = has_complex_eps(records)
+    if (crystals or absorbing) and (splitup or crystals > MAX_FUSED_CRYSTALS or ib._dir is not None):
+        if absorbing and splitup and crystals <= MAX_FUSED_CRYSTALS and ib._dir is None:
+            return _seqtrace_fused_crystal(ib, records, lengths, split=True)
+        if hasattr(system, "_seqtrace_generic"):        # (the plugin-granular loop of pyrate_amd's own classes)
             return system._seqtrace_generic(ib, elementsequence, splitup)
         if crystals <= MAX_FUSED_CRYSTALS and ib._dir is None:
             return _seqtrace_fused_crystal(ib, records, lengths, split=True)

@@ -661,6 +661,30 @@ class DeviceSystem(object):
                                              _stream_handle(self.device)))
         return k_out, dir_out, valid_out, e_re, e_im
 
+    def interact_cplx(self, surface, x_hit, k_re, k_im=None, valid_in=None, want_e=False):
+        """Material.refract / reflect at one surface with complex wave vectors (prt_interact_cplx: absorbing media
+        and what comes behind them).  Returns (k_out_re, k_out_im, dir_out, valid_out, e_re, e_im); ``dir_out`` is
+        None behind an isotropic interface (include/prt.h)."""
+        (x_hit, k_re, k_im) = [_rows_contiguous(t) for t in (x_hit, k_re, k_im)]
+        _check_rays(x_hit, "x_hit")
+        n = x_hit.shape[1]
+        aniso = self.records[surface]["material"]["type"] == "anisotropic"
+        m = 2 * n if aniso else n
+        with torch.cuda.device(self.device):
+            k_out = torch.empty((3, m), dtype=torch.float64, device=self.device)
+            k_out_im = torch.empty((3, m), dtype=torch.float64, device=self.device)
+            dir_out = torch.empty((3, m), dtype=torch.float64, device=self.device) if aniso else None
+            valid_out = torch.empty(m, dtype=torch.uint8, device=self.device)
+            e_re = e_im = None
+            if aniso and want_e:
+                e_re = torch.empty((3, m), dtype=torch.float64, device=self.device)
+                e_im = torch.empty((3, m), dtype=torch.float64, device=self.device)
+            _lib.check(self.lib.prt_interact_cplx(self._h, surface, n, _ptr(x_hit), _ptr(k_re), _ptr(k_im),
+                                                  _ptr(valid_in), _ptr(k_out), _ptr(k_out_im), _ptr(dir_out),
+                                                  _ptr(e_re), _ptr(e_im), _ptr(valid_out),
+                                                  _stream_handle(self.device)))
+        return k_out, k_out_im, dir_out, valid_out, e_re, e_im
+
     def shape_eval(self, surface, x, y, want_sag=True, want_grad=True):
         """Shape.getSag / getGrad on the device; x, y 1-d float64 tensors (shape frame)."""
         n = x.shape[0]

@@ -34,7 +34,14 @@ def propagate_bundle(raybundle, shape, aperture):
     if raybundle._dir is not None:
         direction = raybundle._dir                # rays inside an anisotropic medium
     elif raybundle._dir_from_k:
-        pass                                      # behind an isotropic interface: d = k/|k|
+        # behind an isotropic interface: d = k/|k| -- for a REAL k.  With a complex one (an isotropic medium behind an
+        # absorbing one) the reference takes E from an SVD with a two-dimensional null space, and the ray direction
+        # with it: LAPACK's arbitrary pick, nothing to be compatible with (include/prt.h, eps_im)
+        if getattr(raybundle, "_k_im", None) is not None:
+            from ...surface_table import UnsupportedError
+            raise UnsupportedError("propagate: a bundle with complex wave vectors that left an isotropic interface has "
+                                   "no defined ray direction (complex wave vectors are defined inside crystals and "
+                                   "behind the last surface only)")
     else:
         e = raybundle._e[-1]                      # user bundle: Poynting direction of (k, E)
         if e is None:
@@ -56,6 +63,9 @@ def interact_bundle(material, raybundle, surface, mirror, splitup):
     k = raybundle._k[-1]
     aniso = sysd.records[0]["material"]["type"] == "anisotropic"
     ids = raybundle.ray_ids_dev()
+    k_im = getattr(raybundle, "_k_im", None)
+    if sysd.complex_eps or k_im is not None:
+        return _interact_bundle_cplx(sysd, raybundle, x_hit, k, None if k_im is None else k_im[-1], ids, aniso, splitup)
     if not aniso:
         (k_out, _d, valid_out, _, _) = sysd.interact(0, x_hit, k, valid_in=raybundle._valid[-1])
         # return only valid rays (material_isotropic.py:194-199), on the device
@@ -80,6 +90,41 @@ def interact_bundle(material, raybundle, surface, mirror, splitup):
             [x_hit], [k_out[:, sl].contiguous()], [ones], ids, raybundle.wave, dev,
             e_list=[(e_re[:, sl].contiguous(), e_im[:, sl].contiguous())],
             direction=dir_out[:, sl].contiguous(), dir_from_k=False, k_complex=True))
+    return tuple(out)
+
+
+def _interact_bundle_cplx(sysd, raybundle, x_hit, k, k_im, ids, aniso, splitup):
+    """interact_bundle for complex wave vectors (prt_interact_cplx): an absorbing medium behind the surface, or a
+    bundle that comes out of one.  Same bundle structure as the real case; the new bundles carry Im(k)."""
+    dev = raybundle.device
+    wave = raybundle.wave
+
+    def with_k_im(bundle, kim):
+        bundle._k_im = [kim]
+        return bundle
+    if not aniso:
+        (k_out, k_out_im, _d, valid_out, _, _) = sysd.interact_cplx(0, x_hit, k, k_im, valid_in=raybundle._valid[-1])
+        ((xc, kc, kic), idc, _) = engine.compact(valid_out, [x_hit, k_out, k_out_im], ids)
+        ones = torch.ones(xc.shape[1], dtype=torch.uint8, device=dev)
+        return (with_k_im(RayBundle._from_device([xc], [kc], [ones], idc, wave, dev, dir_from_k=True, k_complex=True),
+                          kic),)
+    (k_out, k_out_im, dir_out, _v, e_re, e_im) = sysd.interact_cplx(0, x_hit, k, k_im, want_e=True)
+    n = x_hit.shape[1]
+    if not splitup:
+        x2 = torch.cat((x_hit, x_hit), dim=1).contiguous()
+        id2 = torch.cat((ids, ids))
+        ones = torch.ones(2 * n, dtype=torch.uint8, device=dev)
+        return (with_k_im(RayBundle._from_device([x2], [k_out], [ones], id2, wave, dev, e_list=[(e_re, e_im)],
+                                                 direction=dir_out, dir_from_k=False, k_complex=True, splitted=True),
+                          k_out_im),)
+    out = []
+    for b in range(2):
+        sl = slice(b * n, (b + 1) * n)
+        ones = torch.ones(n, dtype=torch.uint8, device=dev)
+        out.append(with_k_im(RayBundle._from_device(
+            [x_hit], [k_out[:, sl].contiguous()], [ones], ids, wave, dev,
+            e_list=[(e_re[:, sl].contiguous(), e_im[:, sl].contiguous())],
+            direction=dir_out[:, sl].contiguous(), dir_from_k=False, k_complex=True), k_out_im[:, sl].contiguous()))
     return tuple(out)
 
 

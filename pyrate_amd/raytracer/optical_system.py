@@ -103,17 +103,13 @@ class OpticalSystem(LocalCoordinatesTreeBase):
             fused_ok = False      # a bundle that already carries invalid rays: per-surface path
         if fused_ok:
             return [self._seqtrace_fused(initialbundle, records, lengths)]
-        if complex_media:
-            # absorbing media: the per-surface plugin calls have no complex wave vectors in their signature, so there
-            # is no plugin-granular fall-back -- the forked paths of ``splitup`` are the branches of ONE dense trace,
-            # anything else (explicit first directions, a bundle that already carries invalid rays, too many crystal
-            # interfaces) is refused rather than traced with the imaginary parts dropped
-            if splitup and crystals <= MAX_FUSED_CRYSTALS and initialbundle._dir is None \
-                    and (len(initialbundle._valid) == 1 or bool(initialbundle._valid[-1].all())):
-                return _seqtrace_fused_crystal(initialbundle, records, lengths, split=True)
-            raise UnsupportedError("a sequence through absorbing media (complex epsilon / complex index) is traced as a "
-                                   "whole: no explicit first-segment directions, no invalid rays in the initial bundle, "
-                                   "at most %d crystal interfaces" % MAX_FUSED_CRYSTALS)
+        if complex_media and splitup and crystals <= MAX_FUSED_CRYSTALS and initialbundle._dir is None \
+                and (len(initialbundle._valid) == 1 or bool(initialbundle._valid[-1].all())):
+            # absorbing media: the forked paths of ``splitup`` are the branches of ONE dense trace
+            return _seqtrace_fused_crystal(initialbundle, records, lengths, split=True)
+        # everything else -- explicit first directions, a bundle that already carries invalid rays, more crystal
+        # interfaces than the dense arrays hold -- goes through the plugin-granular loop (complex wave vectors
+        # included: prt_interact_cplx)
         return self._seqtrace_generic(initialbundle, elementsequence, splitup)
 
     def image_moments(self, initialbundle, elementsequence):

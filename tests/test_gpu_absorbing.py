@@ -105,7 +105,7 @@ def test_hip_vs_oracle_random_absorbing_crystals(seed, gpu_device):
                                          ("aniso_absorbing_exit", None), ("absorbing_detector", None)])
 def test_dropin_seqtrace_through_absorbing_crystals(name, mirror, gpu_device):
     """OpticalSystem.seqtrace of the mirror classes: the reference's bundle structure with complex k, bundle by
-    bundle; the plugin-granular loop says what it cannot do"""
+    bundle -- from the fused dense trace and from the plugin-granular loop"""
     from pyrate_amd import _lib
     api = zoo.mirror_api()
     case = _golden.load_case(name)
@@ -125,18 +125,36 @@ def test_dropin_seqtrace_through_absorbing_crystals(name, mirror, gpu_device):
         assert np.abs(rb.k - ref["k"]).max() < 1e-10
         if i >= (5 if name == "absorbing_detector" else 3):
             assert np.iscomplexobj(rb.k) and np.abs(np.imag(rb.k)).max() > 1e-3
-    # the plugin-granular loop: prt_interact has no complex k -- also for the detector, whose absorbing medium is an
-    # ISOTROPIC record (a one-record table each time Material.refract is called on it)
-    with pytest.raises(_lib.PrtError):
-        s._seqtrace_generic(ib, seq, False)
-    # ... and seqtrace itself refuses what it cannot trace as a whole instead of falling back to that loop
-    from pyrate_amd.surface_table import UnsupportedError
+    # the plugin-granular loop (Material.propagate / refract / reflect per surface, complex wave vectors through
+    # prt_interact_cplx -- also for the detector, whose absorbing medium is an ISOTROPIC record, a one-record table
+    # each time Material.refract is called on it): the same bundles
+    rg = s._seqtrace_generic(ib, seq, False)
+    assert len(rg) == 1 and len(rg[0].raybundles) == len(case.raw_bundles)
+    for (i, (rb, ref)) in enumerate(zip(rg[0].raybundles, case.raw_bundles)):
+        assert rb.x.shape == ref["x"].shape and rb.k.shape == ref["k"].shape, i
+        assert np.array_equal(rb.rayID, ref["id"]) and np.array_equal(rb.valid, ref["valid"].astype(bool)), i
+        assert np.abs(rb.x - ref["x"]).max() < 1e-10 * max(1.0, np.abs(ref["x"]).max()), i
+        assert np.abs(rb.k - ref["k"]).max() < 1e-10, i
+    assert np.iscomplexobj(rg[0].raybundles[-1].k) and np.abs(np.imag(rg[0].raybundles[-1].k)).max() > 1e-3
+    # ... and that loop is where seqtrace sends what it cannot trace as a whole: a bundle that already carries an
+    # invalid ray.  The rays are independent, so what comes out are the reference's bundles without that ray
+    # (dropped by the compaction behind the first isotropic interface; crystal interfaces keep every ray)
     ib_bad = api.RayBundle(x0=case.x0, k0=case.k0, Efield0=case.E0, wave=case.wave)
     ib_bad._ensure()
-    ib_bad._valid[-1][0] = 0                      # a bundle that already carries an invalid ray
+    ib_bad._valid[-1][0] = 0
     ib_bad._valid.append(ib_bad._valid[-1].clone())
-    with pytest.raises(UnsupportedError):
-        s.seqtrace(ib_bad, seq)
+    ib_bad._x.append(ib_bad._x[-1])
+    ib_bad._k.append(ib_bad._k[-1])
+    ib_bad._e.append(ib_bad._e[-1])
+    rb_bad = s.seqtrace(ib_bad, seq)
+    assert len(rb_bad) == 1 and len(rb_bad[0].raybundles) == len(case.raw_bundles)
+    for (i, (rb, ref)) in enumerate(zip(rb_bad[0].raybundles, case.raw_bundles)):
+        if i < 2:
+            continue                  # (the initial bundle itself, with its extra point)
+        keep = ref["id"] != 0
+        assert np.array_equal(rb.rayID, ref["id"][keep]), i
+        assert np.abs(rb.x - ref["x"][:, :, keep]).max() < 1e-10 * max(1.0, np.abs(ref["x"]).max()), i
+        assert np.abs(rb.k - ref["k"][:, :, keep]).max() < 1e-10, i
 
 
 def test_dropin_splitup_through_absorbing_crystals_forks_eight_paths(gpu_device):
