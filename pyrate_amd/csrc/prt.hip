@@ -1111,9 +1111,16 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
     if (L.moments) {
         const unsigned nb = (unsigned)nblocks(n0, PRT_MARCH_BLOCK * 2);
         const unsigned ng = (nb + PRT_BLOCK - 1) / PRT_BLOCK;
-        double *stage = a.moments_scratch_dev + (int64_t)MOM_VALUES * nb;
-        hipLaunchKernelGGL(k_moments_stage, dim3(ng), dim3(PRT_BLOCK), 0, st, (int)nb, a.moments_scratch_dev, stage);
-        hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, (int)ng, stage, a.moments_out7_dev);
+        if (ng == 1) {
+            // up to 256 march blocks (131072 rays): the final kernel adds the rows itself -- thread t takes row t, then
+            // the same fixed tree the staging kernel would have used: the same bits, one launch less per call
+            hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, (int)nb, a.moments_scratch_dev,
+                               a.moments_out7_dev);
+        } else {
+            double *stage = a.moments_scratch_dev + (int64_t)MOM_VALUES * nb;
+            hipLaunchKernelGGL(k_moments_stage, dim3(ng), dim3(PRT_BLOCK), 0, st, (int)nb, a.moments_scratch_dev, stage);
+            hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(PRT_BLOCK), 0, st, (int)ng, stage, a.moments_out7_dev);
+        }
     } else if (moments) {
         // unaligned or odd-pitch buffers: the plain trace above followed by the two-kernel reduction (with
         // packed flags the selecting mask is bit 1 of the flags byte)

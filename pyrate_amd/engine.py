@@ -901,14 +901,23 @@ def raster_bundle_device(tables_list, kind, device, radius=1.0, start=(0., 0., 0
 class MomentsWorkspace(object):
     """device scratch + result vectors for bundle_moments_async (no allocation per call)"""
 
-    def __init__(self, device, n_results=2, n_rays=0):
-        """n_rays: size the scratch for DeviceSystem.trace_moments_into of bundles up to n_rays"""
+    def __init__(self, device, n_results=2, n_rays=0, host_results=False):
+        """n_rays: size the scratch for DeviceSystem.trace_moments_into of bundles up to n_rays.
+        ``host_results``: the result vectors live in page-locked HOST memory that the device writes directly (56
+        bytes across PCIe from the last reduction kernel; the caller synchronises the stream and reads
+        ``host[slot]``, a NumPy view) -- for results that go to the host anyway (a merit function) this saves the
+        device-to-host copy call; results that feed a collective stay on the device (default)."""
         lib = _lib.load()
         self.device = device
         self.scratch = torch.empty(max(lib.prt_moments_scratch_doubles(0),
                                        lib.prt_trace_moments_scratch_doubles(n_rays)),
                                    dtype=torch.float64, device=device)
-        self.out = [torch.zeros(7, dtype=torch.float64, device=device) for _ in range(n_results)]
+        self.host = None
+        if host_results:
+            self.out = [torch.zeros(7, dtype=torch.float64, pin_memory=True) for _ in range(n_results)]
+            self.host = [t.numpy() for t in self.out]
+        else:
+            self.out = [torch.zeros(7, dtype=torch.float64, device=device) for _ in range(n_results)]
 
 
 def bundle_moments_async(x, mask, ws, slot=0, mode=0, ref_dev=None, ref_kind=0):

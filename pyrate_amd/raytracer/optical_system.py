@@ -134,10 +134,12 @@ class OpticalSystem(LocalCoordinatesTreeBase):
             if len(cache) > 8:
                 cache.clear()
             cache[key] = (sysd.alloc_outputs(n, _lib.MODE_IMAGE, packed_flags=True),
-                          engine.MomentsWorkspace(dev, n_results=1, n_rays=n))
+                          engine.MomentsWorkspace(dev, n_results=1, n_rays=n, host_results=True))
         (bufs, ws) = cache[key]
-        m = sysd.trace_moments_into(x0, first.pop("k0"), bufs, ws, slot=0, **first)
-        return (m.cpu().numpy(), sysd.moments_reference())
+        sysd.trace_moments_into(x0, first.pop("k0"), bufs, ws, slot=0, **first)
+        # the seven doubles were written to page-locked host memory by the reduction kernel itself
+        torch.cuda.current_stream(dev).synchronize()
+        return (ws.host[0].copy(), sysd.moments_reference())
 
     _moment_buffers = {}
 
