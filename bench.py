@@ -752,6 +752,24 @@ class Watchdog(object):
         self._done.set()
 
 
+def _start_over_after_device_fault(exc, watchdog):
+    """A device fault ends the HIP context of this process; nothing measured so far can be verified any more.  The
+    measurement starts over ONCE in a fresh process image (same command line) and the line says so (`attempts`,
+    `first_attempt_error`); a second fault is an error.  Returns False if ``exc`` is no device fault or this already
+    is the second attempt; does not return otherwise."""
+    fault = any(w in str(exc) for w in ("illegal memory access", "hipErrorIllegalAddress", "memory access fault"))
+    if not fault or os.environ.get("PRT_BENCH_ATTEMPT"):
+        return False
+    print("bench.py: device fault during '%s' (%s); starting over in a fresh process" % (watchdog.stage, str(exc)[:300]),
+          file=sys.stderr, flush=True)
+    watchdog.done()
+    os.environ["PRT_BENCH_ATTEMPT"] = "2"
+    os.environ["PRT_BENCH_FIRST_ERROR"] = ("%s: %s" % (watchdog.stage, str(exc)))[:400]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+
+
 def _inject_device_fault(dev):
     """test hook (PRT_BENCH_INJECT_FAULT=<config>): a kernel that writes to addresses nothing is mapped at, on the
     current stream -- what a fault of the device looks like to this process from then on"""
@@ -921,20 +939,8 @@ def main():
                     _inject_device_fault(dev)        # (test hook: tests/test_gpu_perf.py)
                 recs.append(measure_single(c, args, dev, rays_of[c], with_cpu=not args.no_cpu_baseline))
         except (RuntimeError, _lib.PrtError) as exc:
-            # A device fault ends the HIP context of this process; nothing measured so far can be verified any more.
-            # The measurement starts over ONCE in a fresh process image (same command line) and the line says so
-            # (`attempts`, `first_attempt_error`); a second fault is an error.
-            fault = any(w in str(exc) for w in ("illegal memory access", "hipErrorIllegalAddress", "memory access fault"))
-            if not fault or os.environ.get("PRT_BENCH_ATTEMPT"):
+            if not _start_over_after_device_fault(exc, watchdog):
                 raise
-            print("bench.py: device fault while measuring (%s); starting over in a fresh process" % str(exc)[:300],
-                  file=sys.stderr, flush=True)
-            watchdog.done()
-            os.environ["PRT_BENCH_ATTEMPT"] = "2"
-            os.environ["PRT_BENCH_FIRST_ERROR"] = ("%s: %s" % (watchdog.stage, str(exc)))[:400]
-            sys.stdout.flush()
-            sys.stderr.flush()
-            os.execv(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
         traffic, flops = None, None
         # (a run that is itself being profiled -- rocprofv3 -- python bench.py -- does not start a profiler of its own)
         profiled = any("rocprof" in os.environ.get(v, "").lower() for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES",
@@ -979,6 +985,7 @@ def main():
                 if not sp["verified"]["ok"]:
                     recs.append(dict(name="scaling_point", verified=sp["verified"]))
             except (RuntimeError, MemoryError) as exc:          # a device too small / too busy for 66 GB
+                _start_over_after_device_fault(exc, watchdog)   # (returns unless this was a fault of the device)
                 scaling_point = {"error": "not measured: %s" % str(exc)[:200]}
         out.update({"value": head["value"], "ms_per_step": head["ms_per_step"],
                     "config": {"workload": head["workload"], "rays_per_gpu": head["rays"], "rays_total": head["rays"],

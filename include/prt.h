@@ -545,7 +545,8 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
  *                     time of the call; about 1.5 ms per slab; a hunt also stops after 50 ms of probing.  A request
  *                     that does not find its kinds within that settles for fewer -- kinds[] tells -- and the next
  *                     request continues the hunt from the slabs this one left behind.  PRT_ARENA_HUNT=full lifts
- *                     the bounds to 256 slabs / 2 s: a kind is 96 GiB, so the third can be 192 slabs away;
+ *                     the bounds to 256 slabs / 2 s / nine tenths of the free memory (and the arena's default budget
+ *                     to nine tenths of the device): a kind is 96 GiB, so the third can be 192 slabs away;
  *                     PRT_ARENA_HUNT_SLABS / PRT_ARENA_HUNT_MS set them one by one); if the device cannot offer
  *                     that many kinds the call still succeeds and kinds[] tells.  avoid_mask (bit q = kind q):
  *                     kinds this request leaves to others if it can -- a caller that allocates its

@@ -82,6 +82,12 @@ struct prt_arena {
     // 256 slabs / 2 s, PRT_ARENA_HUNT_MS / PRT_ARENA_HUNT_SLABS set them individually.
     double hunt_ms_cap = 50.0;
     int32_t hunt_slab_cap = 32;
+    // ... and in the share of the memory free at the time that a hunt may hold while it walks (it holds what it walks
+    // through: a slab given back would be handed out again).  Half by default; PRT_ARENA_HUNT=full: nine tenths -- on
+    // a freshly booted box the driver hands out one kind after the other, 91-96 GiB each, so the third kind lies up
+    // to 190 slabs deep and half of the free memory (143 slabs) never reaches it (seen: the first process of a box
+    // settled for two kinds, inputs sharing one with x_hit, 0.80 instead of 0.835 of the HBM peak).
+    double hunt_free_share = 0.5;
     // The three kinds were observed with the device in its default partition modes (compute SPX, memory NPS1).  In
     // another mode the address interleave is a different one and the probe's two-rate picture may not exist: the
     // arena then does not classify at all (every slab is kind 0, no probes) and says so (prt_arena_note).
@@ -348,12 +354,15 @@ int32_t prt_arena_create(int32_t device, prt_arena_t **out) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0)
         a->slab_budget = (int64_t)(total_b / PRT_SLAB_BYTES) * 3 / 4;
+    if (const char *v = getenv("PRT_ARENA_HUNT"))      // (a full hunt may have to hold two whole kinds: 190 of 268 slabs)
+        if (strcmp(v, "full") == 0 && total_b > 0) a->slab_budget = (int64_t)(total_b / PRT_SLAB_BYTES) * 9 / 10;
     if (const char *v = getenv("PRT_ARENA_BUDGET_GIB")) a->slab_budget = atoll(v);
     if (const char *v = getenv("PRT_ARENA_CACHE_GIB")) a->cache_cap = atoll(v);
     if (const char *v = getenv("PRT_ARENA_HUNT")) {
         if (strcmp(v, "full") == 0) {
             a->hunt_ms_cap = 2000.0;
             a->hunt_slab_cap = 256;
+            a->hunt_free_share = 0.9;
         }
     }
     if (const char *v = getenv("PRT_ARENA_HUNT_MS")) a->hunt_ms_cap = atof(v);
@@ -479,11 +488,13 @@ int32_t prt_arena_alloc(prt_arena_t *a, int32_t n_parts, const int64_t *bytes, v
     std::lock_guard<std::mutex> lock(a->mu);
     if (max_hunt_slabs < 0) {
         // a kind is 96 GiB, so the third one can be 192 slabs of the other two away -- but a hunt holds what it walks
-        // through: by default it may take at most half of what is free right now (and never more than 256 slabs)
+        // through: by default it may take at most half of what is free right now (hunt_free_share; never more than
+        // hunt_slab_cap slabs)
         size_t free_b = 0, total_b = 0;
         max_hunt_slabs = a->hunt_slab_cap;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-            max_hunt_slabs = (int32_t)std::min<size_t>((size_t)std::max(0, a->hunt_slab_cap), free_b / PRT_SLAB_BYTES / 2);
+            max_hunt_slabs = (int32_t)std::min<size_t>((size_t)std::max(0, a->hunt_slab_cap),
+                                                       (size_t)((double)(free_b / PRT_SLAB_BYTES) * a->hunt_free_share));
     }
     hipStream_t st = (hipStream_t)stream;
     size_t need[8];
