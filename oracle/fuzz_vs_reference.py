@@ -168,7 +168,7 @@ def main():
         except Exception as exc:
             bad.append((seed, "exception", repr(exc)[:200]))
     print("systems %d, compared ray-surfaces %d, failures %d" % (_n, ncmp, len(bad)))
-    for b in bad[:30]:
+    for b in bad[:200]:
         print(b)
 
 
