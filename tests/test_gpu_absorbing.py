@@ -259,3 +259,53 @@ def test_hip_vs_oracle_random_sequences_that_end_in_an_isotropic_medium(seed, gp
         assert np.abs(res.x_hit[-1].cpu().numpy()[:, keep] - xr[:, keep]).max() < 1e-9
     if seed % 2 == 1 and (n_abs * n_abs).real < 0:
         assert not vr.any()              # metal-like: the reference's validity rule drops every ray
+
+
+def test_interact_cplx_is_interact_where_nothing_is_complex_and_says_what_it_refuses(gpu_device):
+    """prt_interact_cplx on LOSSLESS tables with a real incoming k: the wave vectors, ray directions and fields of
+    prt_interact (crystal: both solutions; isotropic: k and mask), imaginary parts zero away from evanescent modes;
+    null pointers / a mirror inside an absorbing isotropic medium are refused with the codes the header names"""
+    from pyrate_amd import engine, surface_table, _lib
+    case = _golden.load_case("aniso_doublet_uniaxial")
+    sysd = engine.DeviceSystem(case.table, 0)
+    assert not sysd.complex_eps
+    (x0, k0, e0) = _rays(case, gpu_device)
+    res = sysd.trace(x0, k0, e0)
+    crystal = [s for (s, r) in enumerate(case.table) if r["material"]["type"] == "anisotropic"][0]
+    n_in = case.x0.shape[1]
+    xh = res.x_hit[crystal][:, :n_in].contiguous()
+    kin = (res.k_out[crystal - 1] if crystal else k0)[:, :n_in].contiguous()
+    (k_a, d_a, v_a, er_a, ei_a) = sysd.interact(crystal, xh, kin, want_e=True)
+    (k_b, kim_b, d_b, v_b, er_b, ei_b) = sysd.interact_cplx(crystal, xh, kin, None, want_e=True)
+    real_modes = (kim_b.abs().sum(dim=0) < 1e-12)           # (the complex solver leaves rounding-size imaginary parts)
+    assert int(real_modes.sum()) > 0.9 * real_modes.numel()
+    assert float((k_a - k_b)[:, real_modes].abs().max()) < 1e-12
+    assert float((d_a - d_b)[:, real_modes].abs().max()) < 1e-10
+    assert torch.equal(v_a, v_b)
+    # E is defined up to a sign / phase per solver: compare the projectors E E^H
+    Ea = (er_a + 1j * ei_a)[:, real_modes]
+    Eb = (er_b + 1j * ei_b)[:, real_modes]
+    overlap = (Ea.conj() * Eb).sum(dim=0).abs() / (Ea.abs().pow(2).sum(dim=0).sqrt() * Eb.abs().pow(2).sum(dim=0).sqrt())
+    assert float((overlap - 1).abs().max()) < 1e-9
+    iso = [s for (s, r) in enumerate(case.table) if r["material"]["type"] == "isotropic" and s > 0][-1]
+    xi = res.x_hit[iso]
+    ki = res.k_out[iso - 1]
+    vin = res.valid[iso]
+    (k_c, _, v_c, _, _) = sysd.interact(iso, xi, ki, valid_in=vin)
+    (k_d, kim_d, dir_d, v_d, _, _) = sysd.interact_cplx(iso, xi, ki, None, valid_in=vin)
+    assert dir_d is None and torch.equal(v_c, v_d)
+    ok = v_c.bool()
+    assert float((k_c - k_d)[:, ok].abs().max()) < 1e-12 and float(kim_d[:, ok].abs().max()) < 1e-12
+    # refusals
+    lib = _lib.load()
+    n = xi.shape[1]
+    buf = torch.empty((3, n), dtype=torch.float64, device=gpu_device)
+    args = [ctypes.c_void_p(t.data_ptr()) if t is not None else None for t in (xi.contiguous(), ki.contiguous())]
+    rc = lib.prt_interact_cplx(sysd._h, iso, n, args[0], args[1], None, None, ctypes.c_void_p(buf.data_ptr()), None, None, None,
+                               None, None, None)
+    assert rc == _lib.ERR_INVALID_ARG                      # k_out_im is required
+    rc = lib.prt_interact_cplx(sysd._h, crystal, n_in, ctypes.c_void_p(xh.data_ptr()), ctypes.c_void_p(kin.data_ptr()), None, None,
+                               ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(buf.data_ptr()), None, None, None, None, None)
+    assert rc == _lib.ERR_INVALID_ARG                      # a crystal interface needs dir_out
+    assert lib.prt_interact_cplx(sysd._h, 99, n, args[0], args[1], None, None, None, None, None, None, None, None, None) \
+        == _lib.ERR_INVALID_ARG

@@ -218,6 +218,10 @@ def test_bench_starts_over_once_after_a_device_fault(gpu_device):
     context of the process; bench.py starts over once in a fresh process image and the line says so -- the driver's
     single `python bench.py` still yields a verified measurement"""
     import json, os, subprocess, sys
+    if not os.environ.get("PRT_TEST_INJECT_FAULT"):
+        # a deliberate device fault is nothing to run on a shared box unasked (it passed on two boxes of round 4:
+        # PRT_TEST_INJECT_FAULT=1 python -m pytest tests/test_gpu_perf.py -k device_fault)
+        pytest.skip("opt-in: set PRT_TEST_INJECT_FAULT=1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PRT_BENCH_INJECT_FAULT="doublegauss")
     env.pop("PRT_BENCH_ATTEMPT", None)
