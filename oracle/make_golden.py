@@ -211,6 +211,21 @@ def case_zernike():
     print("zernike_shapes.npz: %s" % ", ".join(shapes.keys()))
 
 
+def case_rotated_combination():
+    """LinearCombination whose polynomial part lives in a frame decentred and rotated about the surface's axis
+    (surface_shape.py:709-748: every part is evaluated in its own frame, gradients are rotated back): the traced
+    system and the reference's getSag / getGrad on scattered points"""
+    (s, seq) = zoo.rotated_combination_system(REFAPI)
+    dump_case("rotated_combination_lens", s, seq, disk_bundle(160, 7.0, 0.0, field_deg=2.0))
+    shape = s.elements["rc"].surfaces["front"].shape
+    rng = np.random.RandomState(11)
+    (x, y) = (rng.uniform(-8, 8, 96), rng.uniform(-8, 8, 96))
+    from pyrate_amd.surface_table import describe_shape
+    np.savez_compressed(os.path.join(OUT, "rotated_combination_shape.npz"), x=x, y=y, sag=shape.getSag(x, y),
+                        grad=shape.getGrad(x, y), record_json=np.array(json.dumps(describe_shape(shape))))
+    print("rotated_combination_shape.npz")
+
+
 def case_gridsag():
     """GridSag: traced system + the reference's getSag / getGrad on scattered points, some of
     them outside the grid (FITPACK clamps the arguments)"""
@@ -536,6 +551,10 @@ def case_spd():
 def main():
     os.makedirs(OUT, exist_ok=True)
     np.random.seed(0)
+    if len(sys.argv) > 1:                      # python oracle/make_golden.py case_xypoly case_gridsag: these cases only
+        for name in sys.argv[1:]:
+            globals()[name]()
+        return
     case_doublet()
     case_double_gauss()
     case_benchmark()
@@ -543,6 +562,7 @@ def main():
     case_xypoly()
     case_biconic()
     case_zernike()
+    case_rotated_combination()
     case_gridsag()
     case_prism()
     case_rasters()

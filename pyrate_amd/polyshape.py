@@ -117,6 +117,38 @@ def shifted(terms, dx, dy):
     return out
 
 
+def rotated(terms, rot):
+    """terms of p(xs, ys) with (xs, ys) = rot^T (x, y), rot = [[r00, r01], [r10, r11]] (the 2 x 2 block of a rotation
+    about z that takes part coordinates to combination coordinates): every monomial xs^i ys^j becomes a
+    homogeneous polynomial of the same degree, so the set of degrees -- and the dense triangle the device
+    evaluates -- stays what it was"""
+    ((r00, r01), (r10, r11)) = rot
+    if r00 == 1.0 and r11 == 1.0 and r01 == 0.0 and r10 == 0.0:
+        return dict(terms)
+    xs = {(1, 0): r00, (0, 1): r10}          # xs = r00 x + r10 y
+    ys = {(1, 0): r01, (0, 1): r11}          # ys = r01 x + r11 y
+    out = {}
+    powers_x = {0: {(0, 0): 1.0}}
+    powers_y = {0: {(0, 0): 1.0}}
+
+    def power(cache, base, e):
+        if e not in cache:
+            cache[e] = _mul_float(power(cache, base, e - 1), base)
+        return cache[e]
+    for ((i, j), c) in terms.items():
+        for (key, v) in _mul_float(power(powers_x, xs, i), power(powers_y, ys, j)).items():
+            out[key] = out.get(key, 0.0) + c * v
+    return out
+
+
+def _mul_float(p, q):
+    out = {}
+    for ((a, b), u) in p.items():
+        for ((c, d), v) in q.items():
+            out[(a + c, b + d)] = out.get((a + c, b + d), 0.0) + u * v
+    return out
+
+
 def add_scaled(acc, terms, factor):
     for (key, c) in terms.items():
         acc[key] = acc.get(key, 0.0) + factor * c

@@ -249,7 +249,8 @@ class ZernikeStandard(Zernike):
 class LinearCombination(ExplicitShape):
     """z = sum_i c_i F_i, each F_i evaluated in its own frame (surface_shape.py:709-775).  The engine
     takes combinations of one Conic / Asphere with polynomial shapes (XYPolynomials, Zernike) whose
-    frames are translated against the combination's (the Zemax "Zernike fringe sag" surface)."""
+    frames are translated against the combination's and rotated about its z axis (the Zemax "Zernike
+    fringe sag" surface); a part tilted against the axis is refused (surface_table.describe_shape says why)."""
     kind = "shape_LinearCombination"
 
     @classmethod

@@ -142,18 +142,27 @@ def describe_shape(shape):
         return {"type": "gridsag", "tx": [float(v) for v in tx], "ty": [float(v) for v in ty],
                 "c": [float(v) for v in c]}
     if kind == "shape_LinearCombination":
-        # sum_i c_i F_i evaluated in each part's own frame (surface_shape.py:713-730); the frames may
-        # differ from the combination's by a translation only
+        # sum_i c_i F_i evaluated in each part's own frame (surface_shape.py:713-730); the frames may differ from the
+        # combination's by a translation and a rotation ABOUT THE COMBINATION'S z AXIS.  A part tilted about x or y is
+        # refused: the reference's F then mixes the part's lateral coordinates into z (the z row of the rotation),
+        # and its gradF (:732-748: the rotated part gradients, z divided by the coefficient sum) is no longer the
+        # gradient of that F -- true -dF/dx = R_zz times the reference's x component -- so hit points and normals
+        # would have to come from two different functions.
         parts = []
         for (coefficient, part) in zip(shape.annotations["list_shape_coefficients"], shape.list_shapes):
             rel = np.asarray(shape.lc.localbasis).T.dot(np.asarray(part.lc.localbasis))
-            if not np.allclose(rel, np.eye(3), rtol=0, atol=1e-14):
-                raise UnsupportedError("LinearCombination: part %r is rotated against the combination's "
-                                       "frame" % getattr(part, "name", part))
+            about_z = np.allclose(rel[2], (0.0, 0.0, 1.0), rtol=0, atol=1e-14) and \
+                np.allclose(rel[:, 2], (0.0, 0.0, 1.0), rtol=0, atol=1e-14)
+            if not about_z:
+                raise UnsupportedError("LinearCombination: part %r is tilted against the combination's axis (rotations "
+                                       "about z and translations only)" % getattr(part, "name", part))
             offset = np.asarray(shape.lc.localbasis).T.dot(
                 np.asarray(part.lc.globalcoordinates) - np.asarray(shape.lc.globalcoordinates))
-            parts.append({"coefficient": float(coefficient), "offset": _vec3(offset),
-                          "shape": describe_shape(part)})
+            entry = {"coefficient": float(coefficient), "offset": _vec3(offset), "shape": describe_shape(part)}
+            if not np.allclose(rel, np.eye(3), rtol=0, atol=1e-14):
+                # part coordinates -> combination coordinates: (x, y) = rot (xs, ys) + offset
+                entry["rot"] = [[float(rel[0, 0]), float(rel[0, 1])], [float(rel[1, 0]), float(rel[1, 1])]]
+            parts.append(entry)
         return {"type": "combination", "parts": parts}
     raise UnsupportedError("shape kind %r is outside the HIP engine's scope "
                            "(Conic, Asphere, Biconic, XYPolynomials, ZernikeFringe, ZernikeANSI, "
@@ -382,16 +391,19 @@ def _pack_combination(r, shape):
     asph = None
     for part in shape["parts"]:
         (c, (dx, dy, dz), sh) = (part["coefficient"], part["offset"], part["shape"])
+        rot = part.get("rot", ((1.0, 0.0), (0.0, 1.0)))
+
+        def placed(terms):
+            # p((xs, ys) = rot^T ((x, y) - (dx, dy))): rotate first, then shift the rotated polynomial
+            return polyshape.shifted(polyshape.rotated(terms, rot), dx, dy)
         if sh["type"] in ("conic", "asphere"):
             if asph is not None or dx != 0.0 or dy != 0.0:
                 raise UnsupportedError("LinearCombination: one conic / asphere part, centred on the axis")
-            asph = (c, sh)
+            asph = (c, sh)                       # (rotationally symmetric: a rotation about its axis changes nothing)
         elif sh["type"] == "xypoly":
-            polyshape.add_scaled(mono, polyshape.shifted(polyshape.xy_terms(sh["normradius"], sh["terms"]),
-                                                         dx, dy), c)
+            polyshape.add_scaled(mono, placed(polyshape.xy_terms(sh["normradius"], sh["terms"])), c)
         elif sh["type"] == "zernike":
-            polyshape.add_scaled(mono, polyshape.shifted(
-                polyshape.zernike_terms(sh["indexing"], sh["normradius"], sh["coeffs"]), dx, dy), c)
+            polyshape.add_scaled(mono, placed(polyshape.zernike_terms(sh["indexing"], sh["normradius"], sh["coeffs"])), c)
         else:
             raise UnsupportedError("LinearCombination of a %s shape" % sh["type"])
         if dz != 0.0:

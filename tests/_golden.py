@@ -27,6 +27,8 @@ EXPLICIT_CASES = ["asphere_mild_axis", "asphere_mild_field5", "asphere_strong_ax
                   "asphere_strong_field5", "xypoly_axis", "xypoly_field5", "xypoly_bench_field5", "biconic_axis",
                   "biconic_field5", "hud_biconic_mirrors", "zmx_lenssystem",
                   "zernike_fringe_field3", "zernike_ansi_field2", "zernike_combination_mirror",
+                  # LinearCombination whose polynomial part is decentred and rotated about the surface's axis
+                  "rotated_combination_lens",
                   "gridsag_field2"]
 ANISO_CASES = ["aniso_doublet_isoeps", "aniso_doublet_uniaxial", "aniso_doublet_biaxial",
                "aniso_doublet_uniaxial_clipped", "aniso_doublet_uniaxial_stopped",

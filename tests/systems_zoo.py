@@ -264,6 +264,32 @@ def zernike_combination_system(api):
     return (s, [("zc", [("mirror", {"is_mirror": True}), ("img", {})])])
 
 
+def rotated_combination_system(api):
+    """a freeform lens surface as the reference composes one: LinearCombination of a conic asphere and an XY
+    polynomial whose frame is decentred AND rotated about the surface's axis (tiltz) -- surface_shape.py:709-748
+    evaluates every part in its own frame -- in refraction, followed by a plane back surface and an image plane"""
+    s = api.OpticalSystem.p(name="rotcombo")
+    lc0 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="obj", decz=0.0),
+                                     refname=s.rootcoordinatesystem.name)
+    lc1 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="front", decz=12.0, tilty=0.05), refname=lc0.name)
+    lcp = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="front_poly", decx=0.8, decy=-0.5, tiltz=0.6),
+                                     refname=lc1.name)
+    lc2 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="back", decz=6.0), refname=lc1.name)
+    lc3 = s.addLocalCoordinateSystem(api.LocalCoordinates.p(name="img", decz=40.0), refname=lc2.name)
+    shape = api.LinearCombination.p(lc1, list_of_coefficients_and_shapes=[
+        (0.9, api.Asphere.p(lc1, curv=1. / 35., cc=-0.6, coefficients=[0.0, 3e-6])),
+        (1.2, api.XYPolynomials.p(lcp, normradius=10.0, coefficients=[(1, 0, 0.02), (0, 2, 0.05), (2, 1, -0.04),
+                                                                      (3, 0, 0.03), (1, 3, 0.02), (0, 4, -0.015)]))])
+    elem = api.OpticalElement.p(lc0, name="rc")
+    elem.addMaterial("glass", api.ConstantIndexGlass.p(lc1, 1.6))
+    elem.addSurface("front", api.Surface.p(lc1, shape=shape, aperture=api.CircularAperture.p(lc1, maxradius=9.0)),
+                    (None, "glass"))
+    elem.addSurface("back", api.Surface.p(lc2), ("glass", None))
+    elem.addSurface("img", api.Surface.p(lc3), (None, None))
+    s.addElement("rc", elem)
+    return (s, [("rc", [("front", {}), ("back", {}), ("img", {})])])
+
+
 def evanescent_slab(api):
     """plane crystal slab (uniaxial, n_o = 1.35, n_e = 2.1, axis along x) immersed in a dense
     medium (n = 1.9): beyond ~45 degrees one of the two transmitted modes is evanescent"""

@@ -340,6 +340,18 @@ def test_zernike_shape_evaluation_on_the_device(gpu_device):
     assert np.all(np.isfinite(shapes["fringe"].getGrad(np.zeros(1), np.zeros(1))))
 
 
+def test_rotated_combination_shape_evaluation_on_the_device(gpu_device):
+    """getSag / getGrad of a LinearCombination whose polynomial part is decentred and rotated about the axis ==
+    the reference's values on scattered points (prt_shape_eval on the monomials rotated and shifted on the host)"""
+    import os
+    api = zoo.mirror_api()
+    z = np.load(os.path.join(_golden.GOLDEN_DIR, "rotated_combination_shape.npz"))
+    (s, seq) = zoo.rotated_combination_system(api)
+    sh = s.elements["rc"].surfaces["front"].shape
+    assert np.allclose(sh.getSag(z["x"], z["y"]), z["sag"], rtol=0, atol=2e-14)
+    assert np.allclose(sh.getGrad(z["x"], z["y"]), z["grad"], rtol=0, atol=2e-14)
+
+
 def test_gridsag_shape_evaluation_on_the_device(gpu_device):
     """bicubic B-spline on the device == scipy / FITPACK in the reference: sag and gradient on
     scattered points incl. grid corners and points outside the grid (clamped arguments)"""

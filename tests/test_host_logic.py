@@ -283,6 +283,36 @@ def test_zernike_and_combination_shapes_equal_reference():
     assert recs["combination"]["parts"][1]["offset"] == [0.7, -1.1, 0.0]
 
 
+def test_combination_part_rotated_about_the_axis_equals_reference(api):
+    """LinearCombination with a polynomial part in a frame decentred AND rotated about the combination's z axis
+    (surface_shape.py:709-748): the oracle's sag / gradient == the reference's getSag / getGrad; the monomial
+    expansion the device evaluates (rotate, then shift) == the same sag; the mirror classes flatten to the
+    reference's record; a part TILTED against the axis is refused (the reference's gradF is then not the gradient
+    of its F)"""
+    from oracle import seqtrace_np as oracle
+    from pyrate_amd import polyshape
+    z = np.load(os.path.join(_golden.GOLDEN_DIR, "rotated_combination_shape.npz"))
+    rec = json.loads(str(z["record_json"]))
+    (x, y) = (z["x"], z["y"])
+    assert "rot" in rec["parts"][1] and "rot" not in rec["parts"][0]
+    assert np.allclose(oracle.shape_sag(rec, x, y), z["sag"], rtol=0, atol=1e-14)
+    assert np.allclose(oracle.shape_grad(rec, x, y), z["grad"], rtol=0, atol=1e-14)
+    (F, r) = _packed_polynomial(rec, x, y)
+    assert np.allclose(F, z["sag"], rtol=0, atol=2e-14) and r.n_coeffs <= st.PRT_MAX_COEFFS
+    # rotated(): a quarter turn maps x -> y, y -> -x
+    quarter = polyshape.rotated({(2, 1): 1.0}, ((0.0, -1.0), (1.0, 0.0)))          # xs = y, ys = -x: xs^2 ys = -x y^2
+    assert {k: round(v, 15) for (k, v) in quarter.items() if abs(v) > 1e-15} == {(1, 2): -1.0}
+    (s, seq) = zoo.rotated_combination_system(api)
+    _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("rotated_combination_lens").table)
+    lc = api.LocalCoordinates.p(name="c")
+    lct = lc.addChild(api.LocalCoordinates.p(name="tilted", tiltx=0.1))
+    lc.update()
+    bad = api.LinearCombination.p(lc, list_of_coefficients_and_shapes=[
+        (1.0, api.XYPolynomials.p(lct, normradius=1.0, coefficients=[(2, 0, 0.01)]))])
+    with pytest.raises(st.UnsupportedError):
+        st.describe_shape(bad)
+
+
 def test_zernike_index_maps_and_monomials():
     from pyrate_amd import polyshape
     assert [polyshape.fringe_nm(j) for j in (1, 2, 3, 4, 5, 9, 16, 36)] == \
