@@ -149,6 +149,16 @@ def test_seqtrace_gridsag_surface(api):
     assert_paths_match(rpaths[0], case.raw_bundles, loose_x=1e-8)      # reference: fsolve, xtol 1e-4
 
 
+def test_seqtrace_rotated_combination_surface(api):
+    """a LinearCombination lens surface whose polynomial part is decentred and rotated about the axis, built from
+    the mirror classes: every bundle == the reference's (hit points on the freeform surface by its fsolve, xtol
+    1e-6), from the fused trace and from the plugin-granular loop"""
+    case = _golden.load_case("rotated_combination_lens")
+    (s, seq) = zoo.rotated_combination_system(api)
+    assert_paths_match(s.seqtrace(bundle_of(api, case), seq)[0], case.raw_bundles, loose_x=1e-7)
+    assert_paths_match(s._seqtrace_generic(bundle_of(api, case), seq, False)[0], case.raw_bundles, loose_x=1e-7)
+
+
 def test_plugin_granular_path_matches_fused(api):
     """OpticalElement.seqtrace (Material.propagate / refract per surface + device compaction)
     gives the same RayPath as the fused launch"""
