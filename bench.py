@@ -594,6 +594,18 @@ def finish_roofline(rec, traffic, flops, lookup=True):
                 rec["roofline"] = dict(fp64, secondary=hbm)
         else:
             hbm["note"] = "FP64-VALU bound kernel; no flop count available, HBM fraction shown"
+    else:
+        # isotropic marches are HBM bound; the FP64 / VALU-issue side is carried as the secondary roof when the counters
+        # were taken in this run (it is what separates the Newton marches from the conic ones: DESIGN.md section 5)
+        fl = (flops or {}).get(rec["name"])
+        if fl and fl.get("flops_per_launch"):
+            ms = hbm["kernel_ms"]
+            tf = fl["flops_per_launch"] / (ms * 1e-3) / 1e12
+            valu = fl.get("valu_wave_instructions")
+            hbm["secondary"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_launch": fl["flops_per_launch"],
+                                "flops_source": fl["source"],
+                                "valu_issue_frac": (valu * 4.0 / (1024 * 2.4e9) / (ms * 1e-3)) if valu else None}
     for k in [k for k in rec if k.startswith("_")]:
         del rec[k]
     return rec
