@@ -547,7 +547,8 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
  *                     request continues the hunt from the slabs this one left behind.  PRT_ARENA_HUNT=full lifts
  *                     the bounds to 256 slabs / 2 s / nine tenths of the free memory (and the arena's default budget
  *                     to nine tenths of the device): a kind is 96 GiB, so the third can be 192 slabs away;
- *                     PRT_ARENA_HUNT_SLABS / PRT_ARENA_HUNT_MS set them one by one); if the device cannot offer
+ *                     PRT_ARENA_HUNT_SLABS / PRT_ARENA_HUNT_MS set them one by one; PRT_ARENA_TRACE prints every
+ *                     probe's rate to stderr); if the device cannot offer
  *                     that many kinds the call still succeeds and kinds[] tells.  avoid_mask (bit q = kind q):
  *                     kinds this request leaves to others if it can -- a caller that allocates its
  *                     input arrays separately passes 3, which keeps them out of kinds 0 and 1, the

@@ -92,6 +92,7 @@ struct prt_arena {
     // another mode the address interleave is a different one and the probe's two-rate picture may not exist: the
     // arena then does not classify at all (every slab is kind 0, no probes) and says so (prt_arena_note).
     bool classify = true;
+    bool trace = false;            // PRT_ARENA_TRACE: every probe's rate on stderr (diagnostics)
     char compute_partition[32] = "";
     char memory_partition[32] = "";
     char note[256] = "";
@@ -147,6 +148,7 @@ static hipError_t arena_probe_rate(prt_arena *a, double *lo, double *hi, int64_t
     }
     a->n_probes += 1;
     *gbs = 72.0 * row_len * 8 / 1e6 / best;
+    if (a->trace) fprintf(stderr, "prt_arena probe %p | %p rows of %lld: %.1f GB/s\n", (void *)lo, (void *)hi, (long long)row_len, *gbs);
     return hipGetLastError();
 }
 
@@ -365,6 +367,7 @@ int32_t prt_arena_create(int32_t device, prt_arena_t **out) {
             a->hunt_free_share = 0.9;
         }
     }
+    a->trace = getenv("PRT_ARENA_TRACE") != nullptr;
     if (const char *v = getenv("PRT_ARENA_HUNT_MS")) a->hunt_ms_cap = atof(v);
     if (const char *v = getenv("PRT_ARENA_HUNT_SLABS")) a->hunt_slab_cap = atoi(v);
     // partition modes of the device, from sysfs (amdgpu: current_compute_partition / current_memory_partition beside
