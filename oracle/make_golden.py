@@ -338,6 +338,18 @@ def case_hud():
     dump_case("hud_biconic_mirrors", s, seq, disk_bundle(160, 9.0, -5.0, field_deg=1.0))
 
 
+def case_hud_patent():
+    """the head-up-display prism of demos/demo_hud.py (US patent 5 701 202; the reference's demos/demo_hud.py): 14
+    surfaces, frames hung on the object frame, biconic faces with large b coefficients -- one of them hit twice, in
+    transmission and in reflection.  Disk bundles at 0 and -15 degrees (at -15 degrees the hit points on the first
+    face lie 33-35 mm out, where the biconic's evaluation is noisy: the case that showed the engine dropping a ray
+    whose Newton steps sat at the rounding noise)."""
+    from demos import demo_hud
+    (s, seq) = demo_hud.build(REFAPI)
+    dump_case("hud_patent_axis", s, seq, disk_bundle(160, 2.0, 0.0))
+    dump_case("hud_patent_field-15", s, seq, disk_bundle(160, 2.0, 0.0, field_deg=-15.0))
+
+
 def case_two_elements():
     (s, seq) = zoo.two_element_system(REFAPI)
     dump_case("two_elements", s, seq, disk_bundle(200, 7.0, -2.0, field_deg=1.5))
@@ -570,6 +582,7 @@ def main():
     case_tilted()
     case_mirror()
     case_hud()
+    case_hud_patent()
     case_two_elements()
     case_aniso()
     case_aniso_mirror()

@@ -173,7 +173,7 @@ static inline void intersect_part(const double *r, const double *cf, const doubl
     } else {
         /* per-ray Newton from t = 0 (see the header); valid stays True like the reference's (:462) */
         t = 0.0;
-        int settled = 0;
+        int settled = 0, noise_floor = 0;
         for (int it = 0; it < NEWTON_MAXIT && !settled; ++it) {
             double F, gx, gy, gz;
             shape_eval(r, cf, r0[0] + t * dl[0], r0[1] + t * dl[1], &F, &gx, &gy, &gz);
@@ -183,8 +183,10 @@ static inline void intersect_part(const double *r, const double *cf, const doubl
             t -= dt;
             const double scale = fabs(t) > 1.0 ? fabs(t) : 1.0;
             settled = !isfinite(dt) || (fabs(dt) <= NEWTON_TOL * scale);
+            noise_floor = fabs(dt) <= 1e-11 * scale;
         }
-        if (!settled) t = NAN;
+        /* steps at the rounding noise of g / g' when the cap is reached: converged (csrc/prt_device.h explicit_t) */
+        if (!settled && !noise_floor) t = NAN;
     }
     p[0] = r0[0] + dl[0] * t; p[1] = r0[1] + dl[1] * t; p[2] = r0[2] + dl[2] * t;
     mat_vec(Bs, p, xh);

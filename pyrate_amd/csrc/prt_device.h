@@ -543,7 +543,7 @@ PRT_DEV void explicit_prefetch(const prt_dev_surface *__restrict__ sf, explicit_
 // The reference gives the N-vector to MINPACK hybrd (xtol 1e-6); here every ray
 // runs scalar Newton to machine precision.  The loop is wave-uniform: a wave
 // leaves when all its lanes have converged (or the cap is hit); converged lanes
-// keep their t.  *nonconv reports lanes that hit the cap.
+// keep their t.  *nonconv reports lanes that hit the cap while still moving (last step > 1e-11).
 // gx, gy: in-plane derivatives (Fx, Fy) at the last iterate -- the step that ended the
 // iteration was <= 1e-15, so they are the derivatives at the root to rounding and the
 // normal does not need another evaluation of the shape.
@@ -553,6 +553,7 @@ PRT_DEV double explicit_t(const prt_dev_surface *__restrict__ sf, const vec3 &r0
                           bool &nonconv, double &gx, double &gy) {
     double t = 0.0;
     bool done = false;
+    bool at_noise_floor = false;   // the last step was <= 1e-11 (relative): see below
     gx = 0.0;
     gy = 0.0;
     const int maxit = sf->newton_maxit > 0 ? sf->newton_maxit : 30;
@@ -572,10 +573,15 @@ PRT_DEV double explicit_t(const prt_dev_surface *__restrict__ sf, const vec3 &r0
             const double scale = fmax(1.0, fabs(t));
             // NaN/Inf steps stop the lane too (t is already non-finite -> ray invalid later)
             done = !(fabs(dt) > 1e-15 * scale) || !isfinite(dt);
+            at_noise_floor = !(fabs(dt) > 1e-11 * scale);
         }
         if (__all(done)) break;
     }
-    nonconv = !done;
+    // A lane that reaches the cap while its steps have long been at the rounding noise of g / g' -- a shape whose
+    // evaluation is noisy (a biconic with a large b_n: (r^2 - b (x^2 - y^2))^n cancels), a hit point far out, 1e-15 of
+    // |t| below that noise -- HAS converged, to the 1e-11 its last step shows (the parity bar is 1e-10, the reference's
+    // fsolve stops at 1e-6): it keeps its t.  Only lanes that are still moving at the cap are reported.
+    nonconv = !done && !at_noise_floor;
     return t;
 }
 

@@ -25,7 +25,10 @@ ISO_CASES = ["doublet", "doublet_clipped", "double_gauss_axis", "double_gauss_fi
              "benchmark_divergent"]
 EXPLICIT_CASES = ["asphere_mild_axis", "asphere_mild_field5", "asphere_strong_axis",
                   "asphere_strong_field5", "xypoly_axis", "xypoly_field5", "xypoly_bench_field5", "biconic_axis",
-                  "biconic_field5", "hud_biconic_mirrors", "zmx_lenssystem",
+                  "biconic_field5", "hud_biconic_mirrors",
+                  # the patent HUD prism of demos/demo_hud.py: biconic faces with large b_n, hit points far out
+                  "hud_patent_axis", "hud_patent_field-15",
+                  "zmx_lenssystem",
                   "zernike_fringe_field3", "zernike_ansi_field2", "zernike_combination_mirror",
                   # LinearCombination whose polynomial part is decentred and rotated about the surface's axis
                   "rotated_combination_lens",

@@ -113,3 +113,31 @@ def test_bench_contract_line(gpu_device):
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in d["cpu_baseline"], key
     assert d["value"] > 1e8 and d["cpu_baseline"]["kind"] == "port"
+
+
+def test_smoke_rainbow(gpu_device, capsys):
+    """water droplet, one internal reflection through one surface visited twice: the whole fan comes back, 24-29
+    degrees from the antisolar direction, the two colours half a degree apart"""
+    from demos import demo_rainbow
+    bow = demo_rainbow.main(11)
+    assert 22.0 < bow["red"] < 32.0 and 22.0 < bow["blue"] < 32.0 and 0.2 < abs(bow["red"] - bow["blue"]) < 1.0
+    assert capsys.readouterr().out.count("11 of 11 rays come back") == 2
+
+
+def test_smoke_mirrors(gpu_device, capsys):
+    """three tilted spherical mirrors + an off-axis paraboloid: every ray of every field reaches the first two image
+    planes; the axial field focuses best behind the paraboloid"""
+    from demos import demo_mirrors
+    out = demo_mirrors.main(300)
+    n0 = out[(0.0, "image1")][0]
+    assert n0 > 250 and all(out[(f, "image1")][0] == n0 for f in (0.0, 0.5, -0.5))
+    assert out[(0.0, "image2")][1] < out[(0.0, "image1")][1]
+    assert capsys.readouterr().out.count("mirrors, field") == 3
+
+
+def test_smoke_hud(gpu_device, capsys):
+    """free-form prism with biconic faces, one of them used in transmission and in reflection: the axial fan gets through"""
+    from demos import demo_hud
+    out = demo_hud.main(9)
+    assert out[0.0] == 9 and out[15.0] > 0 and out[-15.0] > 0
+    assert capsys.readouterr().out.count("hud, field") == 3

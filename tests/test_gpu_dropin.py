@@ -149,6 +149,19 @@ def test_seqtrace_gridsag_surface(api):
     assert_paths_match(rpaths[0], case.raw_bundles, loose_x=1e-8)      # reference: fsolve, xtol 1e-4
 
 
+@pytest.mark.parametrize("name", ["hud_patent_axis", "hud_patent_field-15"])
+def test_seqtrace_hud_patent_prism(api, name):
+    """demos/demo_hud.py's prism (14 surfaces, biconic faces, one hit twice) built from the mirror classes: every
+    bundle == the reference's, no ray lost -- at -15 degrees the hit points on the first face lie where the
+    biconic's evaluation is noisy and the Newton steps stall at 1e-14 instead of 1e-15 (explicit_t's noise floor)"""
+    from demos import demo_hud
+    case = _golden.load_case(name)
+    (s, seq) = demo_hud.build(api)
+    rp = s.seqtrace(bundle_of(api, case), seq)[0]
+    assert rp.raybundles[-1].num_rays == case.raw_bundles[-1]["x"].shape[-1] == 140
+    assert_paths_match(rp, case.raw_bundles, loose_x=1e-7)
+
+
 def test_seqtrace_rotated_combination_surface(api):
     """a LinearCombination lens surface whose polynomial part is decentred and rotated about the axis, built from
     the mirror classes: every bundle == the reference's (hit points on the freeform surface by its fsolve, xtol
