@@ -141,3 +141,23 @@ def test_smoke_hud(gpu_device, capsys):
     out = demo_hud.main(9)
     assert out[0.0] == 9 and out[15.0] > 0 and out[-15.0] > 0
     assert capsys.readouterr().out.count("hud, field") == 3
+
+
+def test_smoke_anisotropic_ord_eo(gpu_device, capsys):
+    """uniaxial plate, divergent fan: splitup forks into the ordinary and the extraordinary path, which separate
+    off the axis; without splitup the doubled rays travel in one path"""
+    from demos import demo_anisotropic_ord_eo
+    r = demo_anisotropic_ord_eo.main(10)
+    assert r["paths"] == 2 and 0.01 < r["gap_max"] < 1.0 and r["rays_one_path"] == 2 * r["rays_in"]
+    assert "splitted: True" in capsys.readouterr().out
+
+
+def test_smoke_tilted_image(gpu_device, capsys):
+    """the image frame is tilted after the system was built (set_value + update): the next trace sees it -- the fans
+    land elsewhere on the tilted surface, the off-axis fans no longer symmetric"""
+    from demos import demo_tilted_image
+    (before, after) = demo_tilted_image.main(11)
+    assert abs(before[1][0] + before[2][0]) < 1e-9 and abs(before[0][0]) < 1e-9          # symmetric before the tilt
+    assert abs(after[1][0] - before[1][0]) > 1e-3 and abs(after[1][0] + after[2][0]) > 1e-6
+    assert all(a[2] == 11 for a in after)
+    assert capsys.readouterr().out.count("tilted image, field") == 3
