@@ -14,6 +14,7 @@ import sys
 import os
 import types
 
+_extra = len(sys.argv) > 3
 sys.argv = sys.argv[:3]
 _n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 _first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -27,6 +28,9 @@ from oracle import seqtrace_np as oracle          # noqa: E402
 from test_oracle_golden import explicit_tolerance  # noqa: E402
 
 A = mg.REFAPI
+# python oracle/fuzz_vs_reference.py n first extra: also biconic / XY-polynomial surfaces and wider bundles (another
+# random stream than the campaigns on record, which ran without)
+EXTRA_SHAPES = _extra or bool(os.environ.get("PRT_FUZZ_EXTRA_SHAPES"))
 
 
 def random_eps(rng):
@@ -59,9 +63,21 @@ def random_system(rng, crystals):
                       tilty=float(rng.uniform(-0.12, 0.12)), tiltThenDecenter=int(rng.randint(0, 2)))
         lc = s.addLocalCoordinateSystem(A.LocalCoordinates.p(name="s%d" % j, **kw), refname=lc_prev.name)
         curv = float(rng.uniform(-1, 1) / rng.uniform(12, 80))
-        if (not crystals) and rng.rand() < 0.25:
+        kind = rng.rand()
+        if (not crystals) and kind < 0.25:
             shape = A.Asphere.p(lc, curv=curv, cc=float(rng.uniform(-1.5, 0.5)),
                                 coefficients=[float(rng.uniform(-1, 1) * 1e-4), float(rng.uniform(-1, 1) * 1e-7)])
+        elif (not crystals) and EXTRA_SHAPES and kind < 0.40:
+            # biconics with the large b_n of free-form prisms (demos/demo_hud.py: b up to 29): noisy far from the axis
+            shape = A.Biconic.p(lc, curvx=curv, curvy=float(curv * rng.uniform(0.6, 1.4)),
+                                ccx=float(rng.uniform(-0.5, 0.3)), ccy=float(rng.uniform(-0.5, 0.3)),
+                                coefficients=[(0.0, 0.0), (float(rng.uniform(-1, 1) * 1e-7), float(rng.uniform(-30, 30))),
+                                              (float(rng.uniform(-1, 1) * 1e-10), float(rng.uniform(-3, 3)))])
+        elif (not crystals) and EXTRA_SHAPES and kind < 0.50:
+            shape = A.XYPolynomials.p(lc, normradius=float(rng.uniform(5, 12)),
+                                      coefficients=[(2, 0, float(rng.uniform(-0.1, 0.1))), (0, 2, float(rng.uniform(-0.1, 0.1))),
+                                                    (2, 1, float(rng.uniform(-0.05, 0.05))), (0, 3, float(rng.uniform(-0.05, 0.05))),
+                                                    (4, 0, float(rng.uniform(-0.02, 0.02)))])
         else:
             shape = A.Conic.p(lc, curv=curv, cc=float(rng.choice([0.0, rng.uniform(-1.5, 1.0)])))
         aper = None
@@ -121,7 +137,8 @@ def main():
         try:
             (s, seq) = random_system(rng, crystals)
             n = 24
-            x0 = np.vstack((rng.uniform(-2.5, 2.5, n), rng.uniform(-2.5, 2.5, n), np.full(n, -1.0)))
+            half = 6.0 if (EXTRA_SHAPES and not crystals) else 2.5
+            x0 = np.vstack((rng.uniform(-half, half, n), rng.uniform(-half, half, n), np.full(n, -1.0)))
             steep = 0.45 if crystals else 0.2
             u = np.vstack((rng.uniform(-steep, steep, n), rng.uniform(-steep, steep, n), np.ones(n)))
             k0 = u / np.sqrt(np.sum(u ** 2, axis=0))
