@@ -209,7 +209,8 @@ int32_t prt_system_ray_counts(const prt_system_t *sys, int64_t n0, int64_t *n_in
  *   valid_out may be NULL.
  *   nonconv (may be NULL; layout of valid): 1 where the Newton iteration of an explicit shape
  *   (Asphere, Biconic, XYPolynomials, ...) ended at its iteration cap instead of converging, 0
- *   elsewhere.  The reference has no such mask -- ExplicitShape.intersect reports valid = True for
+ *   elsewhere.  Converged: a step <= 1e-15 relative to max(1, |t|), or -- at the cap -- a last step <= 1e-11
+ *   (a shape whose evaluation is noisy far from its axis stalls at 1e-14; that ray HAS converged and keeps its point).  The reference has no such mask -- ExplicitShape.intersect reports valid = True for
  *   every ray, converged or not (surface_shape.py:462) -- and `valid` stays reference-compatible: a
  *   capped ray keeps valid = 1, gets a NaN hit point and is dropped by the next refraction.  nonconv is
  *   what lets a caller tell such a ray from one that left the domain of the shape.
