@@ -183,6 +183,9 @@ def case_zernike():
     dump_case("zernike_ansi_field2", s, seq, disk_bundle(150, 7.5, -5.0, field_deg=-2.0))
     (s, seq) = zoo.zernike_combination_system(REFAPI)
     dump_case("zernike_combination_mirror", s, seq, disk_bundle(150, 8.0, 0.0, field_deg=1.5))
+    # m = 0 terms only: the one kind of Zernike surface whose reference NORMALS are right -- the whole path compares
+    (s, seq) = build_simple_optical_system(zoo.zernike_builduplist("Fringe", symmetric=True))
+    dump_case("zernike_fringe_symmetric_field3", s, seq, disk_bundle(150, 7.5, -5.0, field_deg=3.0))
     rng = np.random.RandomState(4)
     (x, y) = (rng.uniform(-8, 8, 64), rng.uniform(-8, 8, 64))
     out = {"x": x, "y": y}

@@ -230,9 +230,17 @@ ZERNIKE_ANSI_COEFFS = [0.0, -0.01, 0.02, 0.015, 0.03, -0.02, 0.006, -0.005, 0.00
                        0.001, 0.0008, -0.0005]
 
 
-def zernike_builduplist(indexing="Fringe"):
+# rotationally symmetric fringe terms only (Z4 defocus, Z9 / Z16 / Z25 spherical): for m = 0 the reference's Zernike
+# gradient IS the derivative of its sag (to 6e-12, checked against the reference), so its normals are a parity target
+ZERNIKE_FRINGE_SYMMETRIC = [0.04 if j == 4 else 0.008 if j == 9 else 0.001 if j == 16 else 0.00015 if j == 25 else 0.0
+                            for j in range(1, 26)]
+
+
+def zernike_builduplist(indexing="Fringe", symmetric=False):
     """a freeform back surface given as a Zernike series (25 fringe / 15 ANSI terms, up to 8th order)"""
     coeffs = ZERNIKE_FRINGE_COEFFS if indexing == "Fringe" else ZERNIKE_ANSI_COEFFS
+    if symmetric:
+        coeffs = ZERNIKE_FRINGE_SYMMETRIC
     return [
         ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
         ({"shape": "Conic", "curv": 1. / 60.}, {"decz": 5.0}, 1.5168, "front", {}),

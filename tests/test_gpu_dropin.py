@@ -142,6 +142,14 @@ def test_seqtrace_zernike_surfaces(api, name, builder):
     assert np.allclose(np.real(img.k[0]), np.real(out[-1]["k_out"])[:, ok], rtol=0, atol=1e-12)
 
 
+def test_seqtrace_symmetric_zernike_surface_whole_path(api):
+    """a Zernike surface with m = 0 terms only: the reference's gradient is right there, so EVERY bundle -- also the
+    ones behind the refraction at the Zernike surface -- is compared with the reference's"""
+    case = _golden.load_case("zernike_fringe_symmetric_field3")
+    (s, seq) = api.build_simple_optical_system(zoo.zernike_builduplist("Fringe", symmetric=True))
+    assert_paths_match(s.seqtrace(bundle_of(api, case), seq)[0], case.raw_bundles, loose_x=1e-7)
+
+
 def test_seqtrace_gridsag_surface(api):
     case = _golden.load_case("gridsag_field2")
     (s, seq) = zoo.gridsag_system(api)
