@@ -333,6 +333,17 @@ def test_mirror_zernike_tables_equal_reference(api):
     _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("zernike_combination_mirror").table)
 
 
+def test_mirror_hud_prism_table_equals_reference(api):
+    """demos/demo_hud.py built from the mirror classes flattens to the table the reference's own classes gave
+    (14 surfaces, every frame hung on the object frame with tiltThenDecenter=False, one biconic face twice); the
+    symmetric Zernike lens likewise"""
+    from demos import demo_hud
+    (s, seq) = demo_hud.build(api)
+    _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("hud_patent_axis").table)
+    (s, seq) = api.build_simple_optical_system(zoo.zernike_builduplist("Fringe", symmetric=True))
+    _assert_tables_equal(_flatten(s, seq, zoo.DLINE)[0], _golden.load_case("zernike_fringe_symmetric_field3").table)
+
+
 def test_gridsag_oracle_and_table(api):
     """GridSag: oracle (scipy spline rebuilt from the record's knots / coefficients) == the
     reference's getSag / getGrad; the mirror class flattens to the reference's record"""
