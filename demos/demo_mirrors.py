@@ -32,14 +32,16 @@ PRESCRIPTION = (
 IMAGES = ("image1", "image2", "image3")
 
 
-def build():
+def build(builder=None):
+    """``builder``: the ``build_simple_optical_system`` to use (tests pass the reference's own to generate golden
+    vectors); default: this package's"""
     rows = []
     for (key, shape, frame, options, clear) in PRESCRIPTION:
         spec = dict(shape, shape="Conic")
         if clear is not None:
             spec["aperture"] = {"type": "CircularAperture", "maxradius": clear}
         rows.append((spec, frame, None, key, options))           # None: air behind every surface
-    return build_simple_optical_system(rows, name="TMA")
+    return (builder or build_simple_optical_system)(rows, name="TMA")
 
 
 def main(nrays=300):

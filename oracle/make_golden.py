@@ -353,6 +353,14 @@ def case_hud_patent():
     dump_case("hud_patent_field-15", s, seq, disk_bundle(160, 2.0, 0.0, field_deg=-15.0))
 
 
+def case_tma_paraboloid():
+    """demos/demo_mirrors.py (the reference's demos/demo_mirrors.py): three tilted, decentred spherical mirrors with an
+    intermediate image and an off-axis paraboloid used 35 mm from its vertex; all reflections in air"""
+    from demos import demo_mirrors
+    (s, seq) = demo_mirrors.build(build_simple_optical_system)
+    dump_case("tma_paraboloid_field0p5", s, seq, disk_bundle(160, 2.0, -5.0, field_deg=0.5))
+
+
 def case_two_elements():
     (s, seq) = zoo.two_element_system(REFAPI)
     dump_case("two_elements", s, seq, disk_bundle(200, 7.0, -2.0, field_deg=1.5))
@@ -586,6 +594,7 @@ def main():
     case_mirror()
     case_hud()
     case_hud_patent()
+    case_tma_paraboloid()
     case_two_elements()
     case_aniso()
     case_aniso_mirror()

@@ -20,6 +20,8 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ISO_CASES = ["doublet", "doublet_clipped", "double_gauss_axis", "double_gauss_field5",
              "double_gauss_wide", "double_gauss_Fline", "double_gauss_defaultE",
              "tilted_frames", "mirrors", "two_elements", "catalog_doublet",
+             # demos/demo_mirrors.py: three tilted spherical mirrors + an off-axis paraboloid far from its vertex
+             "tma_paraboloid_field0p5",
              "spd_double_gauss_Fline", "prism_red", "prism_blue",
              # the reference's own benchmark workload (demos/demo_benchmark.py:47-78): divergent bundle, per-ray k0 / E0
              "benchmark_divergent"]

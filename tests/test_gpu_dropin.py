@@ -170,6 +170,15 @@ def test_seqtrace_hud_patent_prism(api, name):
     assert_paths_match(rp, case.raw_bundles, loose_x=1e-7)
 
 
+def test_seqtrace_three_mirror_anastigmat_with_off_axis_paraboloid(api):
+    """demos/demo_mirrors.py built with this package's builder: every bundle == the reference's (8 surfaces, four
+    reflections in air, the paraboloid hit 35 mm from its vertex)"""
+    from demos import demo_mirrors
+    case = _golden.load_case("tma_paraboloid_field0p5")
+    (s, seq) = demo_mirrors.build(api.build_simple_optical_system)
+    assert_paths_match(s.seqtrace(bundle_of(api, case), seq)[0], case.raw_bundles)
+
+
 def test_seqtrace_rotated_combination_surface(api):
     """a LinearCombination lens surface whose polynomial part is decentred and rotated about the axis, built from
     the mirror classes: every bundle == the reference's (hit points on the freeform surface by its fsolve, xtol
