@@ -168,6 +168,8 @@ def test_seqtrace_hud_patent_prism(api, name):
     rp = s.seqtrace(bundle_of(api, case), seq)[0]
     assert rp.raybundles[-1].num_rays == case.raw_bundles[-1]["x"].shape[-1] == 140
     assert_paths_match(rp, case.raw_bundles, loose_x=1e-7)
+    # the plugin-granular loop (Surface.intersect / Material.refract / reflect per surface) through the same prism
+    assert_paths_match(s._seqtrace_generic(bundle_of(api, case), seq, False)[0], case.raw_bundles, loose_x=1e-7)
 
 
 def test_seqtrace_three_mirror_anastigmat_with_off_axis_paraboloid(api):
