@@ -912,7 +912,10 @@ def main():
     exit_code = 0
     json_fd = [1]
     base_line = {"metric": "ray_surface_ops_per_s", "unit": "ray-surface-ops/s", "n_gpus": world, "steps": args.steps,
-                 "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                 "warmup": args.warmup, "higher_is_better": True,
+                 # (the protocol `--gpus N` follows: ONE bundle split N ways by default -- the N = 1 line's headline is
+                 #  BASELINE configs[1] at 1e7 rays, its `scaling_point` the 1e8-ray bundle of that protocol on one GPU)
+                 "scaling": args.scaling, "vs_baseline": None,
                  "dtype": "f64", "data": "synthetic"}
     wd_s = args.watchdog if args.watchdog is not None else (900.0 if use_dist else 0.0)
     if os.environ.get("PRT_BENCH_WATCHDOG"):
