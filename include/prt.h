@@ -178,6 +178,18 @@ int32_t prt_system_destroy(prt_system_t *sys);
  * system on other streams must have completed. */
 int32_t prt_system_update(prt_system_t *sys, const prt_surface_t *table, int32_t n_surfaces, void *stream);
 int32_t prt_system_num_surfaces(const prt_system_t *sys);
+/* Which layout of the path arrays prt_trace_ex takes for this table (the ONE place that decides; callers that
+ * allocate the arrays ask instead of re-deriving it from the table):
+ *   PRT_LAYOUT_ROW_PITCHED            all-isotropic table: (S, 3, out_pitch) rows, any out_pitch >= n0
+ *   PRT_LAYOUT_CONCATENATED_PITCHED   crystals, fused walk (k_trace_general): concatenated layout with a ray pitch
+ *                                     P >= n0 (prt_crystal_pitch), or tight (pitch 0)
+ *   PRT_LAYOUT_CONCATENATED_TIGHT     crystals, per-surface march (more than 8 crystal interfaces, absorbing media,
+ *                                     PRT_GENERAL_PER_SURFACE set): tight arrays only (pitch 0)
+ * Negative: an error code. */
+#define PRT_LAYOUT_ROW_PITCHED 0
+#define PRT_LAYOUT_CONCATENATED_PITCHED 1
+#define PRT_LAYOUT_CONCATENATED_TIGHT 2
+int32_t prt_system_layout(const prt_system_t *sys);
 /* rays entering / leaving every surface for n0 input rays (anisotropic
  * interfaces double the count, material_anisotropic.py:87-100).  n_in, n_out:
  * host arrays of n_surfaces int64. */

@@ -23,6 +23,7 @@ ERR_NOMEM = -5         # PRT_ERR_NOMEM
 MODE_PATH = 0
 MODE_IMAGE = 1
 MODE_FLAGS = 2          # OR-ed in: both masks of a record in one byte (include/prt.h)
+(LAYOUT_ROW_PITCHED, LAYOUT_CONCATENATED_PITCHED, LAYOUT_CONCATENATED_TIGHT) = (0, 1, 2)      # prt_system_layout
 
 c_double_p = ctypes.c_void_p      # device pointers travel as raw addresses
 c_u8_p = ctypes.c_void_p
@@ -42,6 +43,7 @@ PROTOTYPES = {
     "prt_system_destroy": (ctypes.c_int32, [ctypes.c_void_p]),
     "prt_system_update": (ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(PrtSurface), ctypes.c_int32, ctypes.c_void_p]),
     "prt_system_num_surfaces": (ctypes.c_int32, [ctypes.c_void_p]),
+    "prt_system_layout": (ctypes.c_int32, [ctypes.c_void_p]),
     "prt_system_ray_counts": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int64,
                                                ctypes.POINTER(ctypes.c_int64),
                                                ctypes.POINTER(ctypes.c_int64)]),

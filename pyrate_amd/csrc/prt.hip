@@ -683,6 +683,19 @@ int32_t prt_system_destroy(prt_system_t *sys) {
     return PRT_OK;
 }
 
+// PRT_GENERAL_PER_SURFACE (present in the environment, whatever its value): tables with crystals take the per-surface
+// march also where the fused walk would do -- the independent implementation, for cross-checks
+static bool general_per_surface_forced() {
+    static const bool forced = getenv("PRT_GENERAL_PER_SURFACE") != nullptr;
+    return forced;
+}
+
+int32_t prt_system_layout(const prt_system_t *sys) {
+    if (!sys) return fail(PRT_ERR_INVALID_ARG, "null system");
+    if (sys->all_isotropic) return PRT_LAYOUT_ROW_PITCHED;
+    return (sys->d_walk && !general_per_surface_forced()) ? PRT_LAYOUT_CONCATENATED_PITCHED : PRT_LAYOUT_CONCATENATED_TIGHT;
+}
+
 int32_t prt_system_num_surfaces(const prt_system_t *sys) {
     if (!sys) return fail(PRT_ERR_INVALID_ARG, "null system");
     return sys->n_surfaces;
@@ -925,7 +938,7 @@ static int32_t trace_launch(const prt_system_t *sys, const prt_trace_args_t &a) 
     if (!sys->all_isotropic) {
         // concatenated layout with ray pitch out_pitch (0 = n0, tight)
         if (out_pitch == 0) out_pitch = n0;
-        static const bool per_surface = getenv("PRT_GENERAL_PER_SURFACE") != nullptr;
+        const bool per_surface = general_per_surface_forced();
         const int n_aniso = sys->n_aniso;
         // The fused march walks the tree of split rays depth first inside one launch (k_trace_general);
         // the per-surface march (one launch pair per surface, intermediate arrays) remains for

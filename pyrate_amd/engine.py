@@ -17,7 +17,6 @@ from .surface_table import pack_table
 
 
 COMPACT_MAX_ROWS = 24         # PRT_COMPACT_MAX_ROWS (include/prt.h)
-FUSED_MAX_CRYSTALS = 8       # PRT_FUSED_MAX_CRYSTALS: crystal interfaces the fused walk parks (csrc/prt_kernels.h)
 
 
 def _torch_alloc(make):
@@ -382,12 +381,14 @@ class DeviceSystem(object):
             # concatenated layout with ray pitch (include/prt.h): n0 rounded up to 128 puts every row of every
             # level on a 128-B line (0.124 instead of 0.151 ms on BASELINE configs[3]); tight (pitch 0) for the
             # per-surface march (more crystal interfaces than the fused walk parks)
-            crystals = sum(r["material"]["type"] == "anisotropic" for r in self.records)
             if pitch is None:
                 pitch = int(self.lib.prt_crystal_pitch(n0))
-            # (PRT_GENERAL_PER_SURFACE: PRESENT in the environment, whatever its value -- what libprt's getenv tests)
-            if (crystals > FUSED_MAX_CRYSTALS or "PRT_GENERAL_PER_SURFACE" in os.environ or pitch < n0
-                    or self.complex_eps):
+            # which march the library will run for this table is the library's decision (prt_system_layout: crystal
+            # interfaces against the walk's parking slots, absorbing media, PRT_GENERAL_PER_SURFACE)
+            layout = int(self.lib.prt_system_layout(self._h))
+            if layout < 0:
+                _lib.check(layout)
+            if layout != _lib.LAYOUT_CONCATENATED_PITCHED or pitch < n0:
                 pitch = 0
             P = pitch or n0
             (pin, pout) = ([c // n0 * P if n0 else 0 for c in n_in], [c // n0 * P if n0 else 0 for c in n_out])

@@ -309,3 +309,20 @@ def test_interact_cplx_is_interact_where_nothing_is_complex_and_says_what_it_ref
     assert rc == _lib.ERR_INVALID_ARG                      # a crystal interface needs dir_out
     assert lib.prt_interact_cplx(sysd._h, 99, n, args[0], args[1], None, None, None, None, None, None, None, None, None) \
         == _lib.ERR_INVALID_ARG
+
+
+def test_system_layout_is_the_librarys_decision(gpu_device):
+    """prt_system_layout: row-pitched for isotropic tables, concatenated with a ray pitch where the fused crystal walk
+    runs, tight where the per-surface march does (absorbing media here) -- what DeviceSystem.alloc_outputs asks instead
+    of re-deriving it"""
+    from pyrate_amd import engine, systems, _lib
+    lib = _lib.load()
+    iso = engine.DeviceSystem(systems.double_gauss_records(), 0)
+    assert lib.prt_system_layout(iso._h) == _lib.LAYOUT_ROW_PITCHED
+    crystal = engine.DeviceSystem(_golden.load_case("aniso_doublet_uniaxial").table, 0)
+    assert lib.prt_system_layout(crystal._h) == _lib.LAYOUT_CONCATENATED_PITCHED
+    assert crystal.alloc_outputs(1000)["pitch"] == lib.prt_crystal_pitch(1000) >= 1000
+    absorbing = engine.DeviceSystem(_golden.load_case("aniso_absorbing_mirror").table, 0)
+    assert lib.prt_system_layout(absorbing._h) == _lib.LAYOUT_CONCATENATED_TIGHT
+    assert absorbing.alloc_outputs(1000)["pitch"] == 0
+    assert lib.prt_system_layout(None) == _lib.ERR_INVALID_ARG
