@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 5
+#define PRT_ABI_VERSION 6
 #define PRT_COMPACT_MAX_ROWS 24 /* rows prt_compact moves per call */
 #define PRT_MAX_COEFFS 128 /* asphere A2.. coefficients and / or XY-polynomial terms */
 

@@ -29,7 +29,7 @@ c_double_p = ctypes.c_void_p      # device pointers travel as raw addresses
 c_u8_p = ctypes.c_void_p
 c_stream = ctypes.c_void_p
 
-ABI_VERSION = 5          # PRT_ABI_VERSION of include/prt.h
+ABI_VERSION = 6          # PRT_ABI_VERSION of include/prt.h
 
 # name -> (restype, argtypes); must list every symbol declared in include/prt.h
 PROTOTYPES = {

@@ -156,7 +156,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(_lib.PROTOTYPES.keys())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.prt_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.prt_abi_version() == _lib.ABI_VERSION == 6
     assert lib.prt_sizeof_surface() == ctypes.sizeof(st.PrtSurface)
     assert lib.prt_strerror(-2) == b"unsupported shape/material"
     # argument validation happens before any device work
