@@ -162,24 +162,28 @@ static hipError_t arena_probe_rate(prt_arena *a, double *lo, double *hi, int64_t
 // Does the slab at `mem` straddle a boundary between two kinds?  (Three of the 284 GiB of a device do.)  Such a slab is
 // FAST against itself -- its halves are different kinds --, which makes it useless as the yardstick of a hunt (every
 // same-kind pair would pass for slow: no kind would ever be told from another) and, fast against every
-// representative as well, it would pass for a kind of its own.  Test: the halves against each other (`full_self`,
-// measured by the caller) against each half against ITSELF (all 72 rows inside one half; the boundary lies in at
-// most one of them): a pure slab gives about the same rate three times, a straddler 1.23 x more across than within.
-// Relative, so the clocks of the moment drop out.
-static hipError_t arena_is_straddler(prt_arena *a, double *mem, double full_self, hipStream_t st, bool *straddler) {
+// representative as well, it would pass for a kind of its own.  Test, with three probes of the SAME size (so that
+// the fixed cost of a launch and the clocks of the moment drop out): 36 rows in each half ("across") against all 72
+// rows inside the first half and all 72 inside the second ("within"; the boundary lies in at most one of them).  A
+// pure slab gives the same rate three times (measured: within 5 %); a straddler is 1.2 x faster where its two kinds meet.
+static hipError_t arena_is_straddler(prt_arena *a, double *mem, hipStream_t st, bool *straddler) {
+    *straddler = false;
+    if (a->straddlers.size() >= 4) return hipSuccess;      // a device has three: more than that and the test is off
     const int64_t quarter_len = (int64_t)(PRT_SLAB_BYTES / 2 / 72 / 8) / 512 * 512;
     const int64_t half_doubles = (int64_t)(PRT_SLAB_BYTES / 2 / 8);
-    double within[2] = {0.0, 0.0};
+    double across = 0.0, within[2] = {0.0, 0.0};
+    hipError_t e = arena_probe_rate(a, mem, mem + half_doubles, quarter_len, st, &across);
+    if (e != hipSuccess) return e;
     for (int h = 0; h < 2; ++h) {
         double *base = mem + h * half_doubles;
-        hipError_t e = arena_probe_rate(a, base, base + 36 * quarter_len, quarter_len, st, &within[h]);
-        if (e != hipSuccess) return e;
+        if ((e = arena_probe_rate(a, base, base + 36 * quarter_len, quarter_len, st, &within[h])) != hipSuccess) return e;
     }
-    // (the within-half probes write half as much per launch and read ~10 % low for it: a pure slab shows 1.08-1.17
-    //  here, a straddler 1.37 = 1.23 x that bias)
-    *straddler = full_self > 1.26 * std::min(within[0], within[1]);
-    if (a->trace) fprintf(stderr, "prt_arena straddler test %p: halves against each other %.1f, within %.1f / %.1f GB/s -> %s\n",
-                          (void *)mem, full_self, within[0], within[1], *straddler ? "STRADDLER" : "pure");
+    // (the boundary may lie anywhere: in the middle -- `across` is the fast one --, or inside a half -- that half is fast
+    //  within itself: any one of the three probes 1.12 x faster than another gives the slab away)
+    const double hi = std::max(across, std::max(within[0], within[1])), lo = std::min(across, std::min(within[0], within[1]));
+    *straddler = hi > 1.12 * lo;
+    if (a->trace) fprintf(stderr, "prt_arena straddler test %p: across the halves %.1f, within %.1f / %.1f GB/s -> %s\n",
+                          (void *)mem, across, within[0], within[1], *straddler ? "STRADDLER" : "pure");
     return hipSuccess;
 }
 
@@ -199,7 +203,7 @@ static hipError_t arena_classify(prt_arena *a, double *mem, hipStream_t st, int3
             prev = r;
         }
         bool straddler = false;
-        if ((e = arena_is_straddler(a, mem, r > prev ? r : prev, st, &straddler)) != hipSuccess) return e;
+        if ((e = arena_is_straddler(a, mem, st, &straddler)) != hipSuccess) return e;
         if (straddler) {              // no yardstick from this one: the next slab of the hunt gives it
             *kind = PRT_ARENA_STRADDLER;
             return hipSuccess;
@@ -230,7 +234,7 @@ static hipError_t arena_classify(prt_arena *a, double *mem, hipStream_t st, int3
             // ... unless this slab reads high against itself because it straddles two kinds (that is also why it is
             // fast with every representative): it is neither a new kind nor a reason to move the yardstick
             bool straddler = false;
-            if ((e = arena_is_straddler(a, mem, self_now, st, &straddler)) != hipSuccess) return e;
+            if ((e = arena_is_straddler(a, mem, st, &straddler)) != hipSuccess) return e;
             if (straddler) {
                 *kind = PRT_ARENA_STRADDLER;
                 return hipSuccess;
