@@ -679,7 +679,10 @@ def measure_pmc_live(configs, args, rays_of, timeout_s):
     if exe is None:
         return {"error": "rocprofv3 not found"}, {}
     tmp = tempfile.mkdtemp(prefix="prt_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    # No arena under the profiler: the bytes and instructions of a launch do not depend on where its arrays lie, and
+    # with counters attached every probe launch of a hunt costs milliseconds -- the hunt for the inputs' third kind of
+    # HBM, 190 slabs deep on a freshly booted box, once ate the whole time budget of the passes.
+    env = dict(os.environ, TMPDIR="/tmp", PRT_ARENA="off")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     sums = {}
