@@ -729,3 +729,28 @@ def test_deferred_raypath_is_a_plain_list_once_somebody_looks():
     r = RayPath._deferred(make)
     r.raybundles = []                                    # plain assignment wins over the pending builder
     assert r.raybundles == [] and calls == [1, 1]
+
+
+def test_polynomial_rotation_and_shift_algebra():
+    """polyshape.rotated / shifted: p(R^T (x - d)) evaluated term by term == the polynomial evaluated at the transformed
+    point, for random polynomials, angles and offsets; a rotation followed by its inverse is the identity"""
+    from pyrate_amd import polyshape
+    rng = np.random.RandomState(5)
+    (x, y) = (rng.uniform(-3, 3, 40), rng.uniform(-3, 3, 40))
+
+    def evaluate(terms, u, v):
+        return sum(c * u ** i * v ** j for ((i, j), c) in terms.items())
+    for trial in range(25):
+        terms = {(int(i), int(j)): float(rng.uniform(-1, 1)) for (i, j) in rng.randint(0, 6, size=(int(rng.randint(1, 9)), 2))}
+        a = float(rng.uniform(-np.pi, np.pi))
+        rot = ((np.cos(a), -np.sin(a)), (np.sin(a), np.cos(a)))
+        (dx, dy) = (float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)))
+        placed = polyshape.shifted(polyshape.rotated(terms, rot), dx, dy)
+        (u, v) = (x - dx, y - dy)
+        (xs, ys) = (rot[0][0] * u + rot[1][0] * v, rot[0][1] * u + rot[1][1] * v)            # rot^T (u, v)
+        want = evaluate(terms, xs, ys)
+        assert np.allclose(evaluate(placed, x, y), want, rtol=1e-11, atol=1e-11 * np.abs(want).max())
+        assert max(i + j for (i, j) in placed) <= max(i + j for (i, j) in terms)              # the degree stays
+        back = polyshape.rotated(polyshape.rotated(terms, rot), ((rot[0][0], rot[1][0]), (rot[0][1], rot[1][1])))
+        assert np.allclose(evaluate(back, x, y), evaluate(terms, x, y), rtol=1e-10, atol=1e-10)
+    assert polyshape.rotated({(2, 1): 1.0}, ((1.0, 0.0), (0.0, 1.0))) == {(2, 1): 1.0}
