@@ -58,7 +58,7 @@ from pyrate_amd import systems  # noqa: E402
 import systems_zoo as zoo  # noqa: E402
 from pyrate_amd.surface_table import flatten_sequence  # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("PRT_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")      # (a scratch directory for re-generation checks)
 DLINE = 0.5876e-3
 
 
