@@ -125,7 +125,9 @@ def test_c_oracle_vs_reference_absorbing_crystals(name):
 
 
 SANITIZER_CASES = ["double_gauss_wide", "tilted_frames", "mirrors", "benchmark_divergent",       # conics, frames, apertures
+                   "tma_paraboloid_field0p5",                                                         # off-axis paraboloid
                    "asphere_strong_field5", "xypoly_field5", "biconic_field5", "hud_biconic_mirrors",   # explicit shapes
+                   "hud_patent_field-15",                      # 14 surfaces, Newton steps at the noise floor of a biconic
                    "aniso_doublet_uniaxial", "aniso_doublet_biaxial", "aniso_partial_evanescent"]      # crystals (zggev)
 
 
