@@ -268,7 +268,8 @@ def test_arena_default_hunt_is_bounded(gpu_device):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     st = out["stats"]
     need = 2 * 3                                   # x_hit (+ masks) and k_out of 1e7 rays x 12 surfaces: 3 GiB each
-    assert st["slabs_created"] <= need + 32 + 3    # (+ one representative slab per kind, never handed out)
+    # (+ one representative slab per kind, never handed out; + at most four slabs parked because they straddle two kinds)
+    assert st["slabs_created"] <= need + 32 + 3 + 4
     # the bound is checked between slabs: one more slab may slip in, and a slab costs up to ten probes (the yardstick of
     # a hunt is measured until two readings agree) of 1.2-3 ms each -- the first GPU work of a process runs on ramping clocks
     assert st["probe_ms_total"] <= 50.0 + 30.0
