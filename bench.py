@@ -5,64 +5,42 @@ bench.py -- ray-surface-ops/s of the sequential-raytrace hot path on MI355X.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of OpticalSystem.seqtrace over one bundle.  Headline workload:
-BASELINE.json configs[1], the 12-surface Rudolph double Gauss (12 spherical Conic
-surfaces, ConstantIndexGlass d-line indices), ~1e7 rays PER GPU (RectGrid disk
-raster, collimated on-axis), float64, full path materialised (hit point, outgoing
-wave vector and validity at every surface written to HBM).  Inputs are resident in
-HBM before the timed region.  BASELINE's bundles are collimated: k0 and E0 are one
-vector for the whole bundle and travel as such (prt_trace_ex, uniform first
-segment: the march reads only x0; ``--first-segment arrays`` feeds per-ray arrays).
-The path arrays come from the engine's placement-aware arena (x_hit and k_out in
-two different kinds of HBM) -- the allocation the product path
-uses, no scan.
+One "step" = one pass of OpticalSystem.seqtrace over one bundle.  Headline workload: BASELINE.json configs[1], the
+12-surface Rudolph double Gauss (12 spherical Conic surfaces, ConstantIndexGlass d-line indices), ~1e7 rays PER GPU
+(RectGrid disk raster, collimated on-axis), float64, full path materialised (hit point, outgoing wave vector and
+validity at every surface written to HBM).  Inputs are resident in HBM before the timed region.  metric:
+ray-surface-ops/s = rays x surfaces / seconds (the reference's own definition, demos/demo_benchmark.py:82-85).
 
-At N = 1 the default run then measures the other single-GPU configurations under
-the same contract (``configs`` on the same JSON line, each with its own roofline
-and cpu_baseline): configs[2] (even asphere, Newton intersection, 1e7 rays),
-configs[3] (anisotropic doublet, 1e6 -> 4e6 rays), an XY-polynomial system
-(demo_asphere geometry, 12-term XYPolynomials, 1e7 rays) and the reference's OWN
-benchmark workload (demos/demo_benchmark.py:47-78: 8 surfaces, divergent 10-degree
-bundle -- per-ray k0 / E0 arrays -- at 1e7 rays; BASELINE.md section 2 has the
-reference's rate on it).  ``--config X`` makes X the headline and measures X alone.
-Every configuration is VERIFIED on the arrays its timed launches wrote (``verified``:
-all rays on their surfaces, dispersion relation of every wave vector, a 1e4-ray
-sub-sample against the CPU oracle -- after the timed region, never inside it); the
-script exits non-zero when a deviation exceeds 1e-10.  HBM traffic (roofline.traffic) is measured in
-the same run: the script re-runs the marches under ``rocprofv3 --kernel-trace
---pmc`` (FETCH_SIZE, WRITE_SIZE and the FP64 instruction counters in separate
-passes) and falls back to the figures on file (profiles/*.json) when rocprofv3 is
-not available.
+Output contract: the LAST line of stdout is ONE compact JSON record (< 8 KB, asserted) -- metric, value, unit, n_gpus,
+steps, warmup, ms_per_step, dtype, config{workload, rays, surfaces, mode, build, configs_summary}, roofline{bound,
+achieved, peak, frac, traffic, traffic_ratio_to_algorithmic, kernel, kernel_ms, algorithmic_bytes_per_launch},
+cpu_baseline{value, cores, host_cpus, kind, sample}, verified{ok, max_rel_x, max_abs_k, n_checked}, scaling_point{rays,
+ms, frac, ok}, e2e{...}.  Everything else (one full record per configuration, prose, arena statistics) goes to
+``bench_detail.json`` beside this script (and to gpurun_out/ when that directory exists); nothing else is written to
+stdout.
 
-For N > 1 (configs[4]) ONE bundle of 1e8 rays is sharded by rays over the GPUs
-(``--scaling strong``, the default: the same raster at every N, what BASELINE's
-north_star calls "1/2/4/8-GPU scaling on a 1e8-ray bundle"; ``--scaling weak``:
-1.25e7 rays per GPU; no collective in the trace) and the five prescription wavelengths are
-cycled over the steps; every step ends with that wavelength's spot statistics (one
-7-double all-reduce) AND its image-plane all-gather (49 B/ray, RCCL), both issued
-on a side stream so that they overlap the next wavelength's trace (two sets of
-path arrays); the timed region ends when everything has completed.  The rate of
-the same steps without the gather is measured right after and reported beside it.
-A watchdog (N > 1: on by default) prints a JSON line with an ``error`` field
-instead of hanging.
+At N = 1 the default run measures, under the same contract, the other single-GPU configurations (configs[2] even
+asphere, configs[3] crystal doublet, an XY-polynomial system, the reference's OWN benchmark workload) and the other
+shipped paths (biaxial crystals, the per-surface crystal march, the plugin-granular calls, image mode with fused
+moments): ``config.configs_summary = {name: [ms per step, fraction of its roof, verified, traffic / algorithmic]}``;
+then the 1e8-ray bundle of the multi-GPU protocol on this one GPU (``scaling_point``) and the end-to-end time of the
+drop-in call with host arrays in (``e2e``).  Every configuration is VERIFIED on the arrays its timed launches wrote
+(benchmarks/verify.py; never inside a timed region); the script exits 4 when a deviation exceeds 1e-10.  HBM traffic
+(roofline.traffic) is measured in the same run by rocprofv3 PMC passes (benchmarks/pmc.py).
 
-metric: ray-surface-ops/s = rays x surfaces / seconds (the reference's own
-definition, demos/demo_benchmark.py:82-85).
+For N > 1 (configs[4]) ONE bundle of 1e8 rays is sharded by rays over the GPUs (``--scaling strong``; no collective in
+the trace), the five prescription wavelengths are cycled over the steps, and every step ends with that wavelength's
+spot statistics (one 7-double all-reduce) and its image-plane all-gather (49 B/ray) on a side stream, overlapping the
+next trace (benchmarks/multirank.py).  A watchdog prints a JSON line with an ``error`` field instead of hanging.
 
-Prints ONE JSON line (rank 0).
+The parts: benchmarks/workloads.py (configurations), configs.py (measurements), verify.py, cpu_baseline.py, pmc.py,
+multirank.py.
 """
 import argparse
-import csv
 import ctypes
-import glob
 import json
 import os
-import re
-import shutil
-import subprocess
 import sys
-import tempfile
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -70,376 +48,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # The arena's hunt for its kinds of HBM is bounded per call in the library (32 slabs / 50 ms: a product's first call
 # must not cost 150 ms); a benchmark wants the steady-state placement from its first allocation on, so it lifts
-# the bound -- and says so in the line (config.output_placement.arena.hunt).  Set before libprt reads it.
+# the bound -- and says so (bench_detail.json: arena.hunt).  Set before libprt reads it.
 os.environ.setdefault("PRT_ARENA_HUNT", "full")
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz
-PREWARM_LAUNCHES = 30
-PREWARM_MS = 50.0            # ... and at least this much device time of them (short kernels)
-SINGLE_GPU_CONFIGS = ("doublegauss", "asphere", "aniso", "xypoly", "benchmark")
-# the other shipped paths, measured beside the BASELINE configurations by the default run:
-#   aniso_biaxial   configs[3]'s geometry with two BIAXIAL crystals: the quartic solver of the fused crystal march
-#                   (material/material.py:407-454 in the reference)
-#   aniso_chain     nine crystal interfaces: more than the fused walk parks -> the per-surface march, two launches
-#                   per surface (k_propagate + k_interact_aniso), rays doubling 1 -> 512
-#   plugin          the double Gauss through the plugin-granular calls, prt_propagate + prt_interact per surface: the
-#                   literal Material.propagate / Surface.intersect / Material.refract loop of
-#                   optical_element.py:336-375 (SURVEY 8d's 98 B per ray-surface-op)
-#   image_moments   the double Gauss in image mode with the fused spot moments: the optimiser's call
-#                   (optimize/optimize.py:73-91: trace + merit), bound by FP64 arithmetic, not by HBM
-SECONDARY_MARCH_CONFIGS = ("aniso_biaxial", "aniso_chain")
-SECONDARY_CUSTOM_CONFIGS = ("plugin", "image_moments")
-VERIFY_TOL = 1e-10            # BASELINE.json north_star: 1e-10 relative on intersection points and direction cosines
-STRONG_SCALING_RAYS = 100_000_000   # "1/2/4/8-GPU scaling on a 1e8-ray bundle"
+from benchmarks import pmc
+from benchmarks.multirank import Watchdog, run_multi
+from benchmarks.workloads import (SECONDARY_CUSTOM_CONFIGS, SECONDARY_MARCH_CONFIGS, SHORT_WORKLOAD, SINGLE_GPU_CONFIGS,
+                                  VERIFY_TOL)
+
+MAX_LINE_BYTES = 8192          # the driver keeps a bounded tail of stdout: a longer line cannot be parsed (round 5)
 T_START = time.perf_counter()
-# experiment switch (round 5): the two host-side code paths bench.py had when round 4 saw its three device faults -- the
-# CPU-baseline sample copied device -> PAGEABLE host memory (the runtime pins those 96 MB in place and tears the pinning
-# down when NumPy frees the array) and the verification's frame transform as a BLAS product.  Off by default.
-R4_HOST_PATHS = os.environ.get("PRT_BENCH_R4_HOST_PATHS", "0") == "1"
-R4_PAGEABLE = R4_HOST_PATHS or os.environ.get("PRT_BENCH_R4_PAGEABLE", "0") == "1"      # (each of the two alone)
-R4_BLAS = R4_HOST_PATHS or os.environ.get("PRT_BENCH_R4_BLAS", "0") == "1"
 
 
-# ------------------------------------------------------------------------------------------------
-# workloads
-# ------------------------------------------------------------------------------------------------
-def make_workload(config, rays, dev, n_gpus=1, rank=0, multi=False, first_segment="uniform", align=1, total_rays=None):
-    """records + the device-resident input bundle of one BASELINE configuration.  Every bundle is the
-    RectGrid disk raster of the reference, collimated, generated on the device (bit-identical to the host
-    raster); rank r owns a contiguous, equal-stride slice of it (pdist.shard_range)."""
-    from pyrate_amd import engine, systems
-    from pyrate_amd import distributed as pdist
-    record_sets = None
-    if config == "doublegauss":
-        # N = 1: BASELINE configs[1] (d line).  N > 1: configs[4] -- the same lens at the five
-        # wavelengths of the prescription (spd:5), per-wavelength indices from the Conrady fit
-        # through the (d, F, C) indices; step i traces wavelength i % 5.
-        records = systems.double_gauss_records()
-        if multi:
-            record_sets = [systems.double_gauss_records(w) for w in systems.DOUBLE_GAUSS_WAVES_MM]
-        bundle = dict()
-        workload = (("demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 double Gauss, "
-                     "ConstantIndexGlass d-line), RectGrid disk bundle, BASELINE configs[1]") if not multi else
-                    ("demo_doublegauss: 12 spherical Conic surfaces (Rudolph 1897 double Gauss), 5 wavelengths "
-                     "cycled (Conrady indices), RectGrid disk bundle ray-sharded over the GPUs, BASELINE configs[4]"))
-    elif config == "asphere":
-        # configs[2]: demo_asphere.py geometry (stop, plane front, even asphere back, image) with the
-        # test-suite coefficient set (tests/test_surf_shape.py:115-127) scaled to stay in-domain, bundle
-        # radius 9, 5 degree field: the Newton iteration count varies over the wavefront
-        records = systems.asphere_records(coefficients=(1e-3, -1e-6, 1e-8), curv=-1. / 30., cc=-1.5)
-        bundle = dict(rpup=9.0, z0=-5.0, field_deg=5.0)
-        workload = ("demo_asphere: stop, plane, even asphere (curv -1/30, cc -1.5, A2..A6 = 1e-3, -1e-6, 1e-8; "
-                    "Newton intersection), image; RectGrid disk bundle r = 9 mm at 5 deg, BASELINE configs[2]")
-    elif config == "xypoly":
-        # the XYPolynomials shape of BASELINE's north_star on the geometry of configs[2]
-        records = systems.xypoly_records()
-        bundle = dict(rpup=9.0, z0=-5.0, field_deg=5.0)
-        workload = ("demo_asphere geometry with an XYPolynomials back surface (12 terms up to degree 4: paraboloid "
-                    "-r^2/60 + small terms of every order; Newton intersection); RectGrid disk bundle r = 9 mm at "
-                    "5 deg -- the XY-polynomial companion of BASELINE configs[2]")
-    elif config == "aniso":
-        c = systems.CALCITE_TILTED
-        records = systems.aniso_doublet_records(
-            systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"]),
-            systems.uniaxial_eps(1.6727, 1.60, (np.sin(0.2), 0.0, np.cos(0.2))))
-        bundle = dict(rpup=11.43, z0=-5.0)
-        workload = ("demo_anisotropic_doublet: cemented doublet of two uniaxial crystals (calcite-like, tilted "
-                    "axes), k-vector solve + ray doubling at two interfaces (1 -> 2 -> 4 rays), RectGrid disk "
-                    "bundle r = 11.43 mm, BASELINE configs[3]")
-    elif config == "aniso_biaxial":
-        def rot(ax, ay, az):
-            (ca, sa, cb, sb, cg, sg) = (np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az))
-            rx = np.array([[1, 0, 0], [0, ca, -sa], [0, sa, ca]])
-            ry = np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]])
-            rz = np.array([[cg, -sg, 0], [sg, cg, 0], [0, 0, 1]])
-            return rz.dot(ry).dot(rx)
-        (r1, r2) = (rot(0.4, 0.25, -0.3), rot(-0.2, 0.35, 0.15))
-        records = systems.aniso_doublet_records(r1.dot(np.diag([1.55 ** 2, 1.60 ** 2, 1.68 ** 2])).dot(r1.T),
-                                                r2.dot(np.diag([1.62 ** 2, 1.66 ** 2, 1.71 ** 2])).dot(r2.T))
-        bundle = dict(rpup=11.43, z0=-5.0)
-        workload = ("configs[3]'s cemented doublet with two BIAXIAL crystals (principal indices 1.55 / 1.60 / 1.68 and "
-                    "1.62 / 1.66 / 1.71, rotated): the quartic k-vector solve of the fused crystal march, 1 -> 2 -> 4 rays")
-    elif config == "aniso_chain":
-        c = systems.CALCITE_TILTED
-        eps = systems.uniaxial_eps(c["n_o"], c["n_e"], c["axis"])
-        build = [({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {})]
-        for q in range(9):
-            build.append(({"shape": "Conic", "curv": 0.002 * (q - 4)}, {"decz": 2.0}, {"eps": eps * (1 + 0.01 * q)},
-                          "c%d" % q, {}))
-        build.append(({"shape": "Conic"}, {"decz": 5.0}, None, "image", {}))
-        records = systems.simple_system_records(build)
-        bundle = dict(rpup=2.0, z0=-10.0)
-        workload = ("nine uniaxial crystal interfaces in a row (more than the fused walk parks): the per-surface march, "
-                    "k_propagate + k_interact_aniso per surface, rays doubling 1 -> 512 (11 surfaces)")
-    elif config == "benchmark":
-        # the reference's own benchmark (demos/demo_benchmark.py:47-78): 8 surfaces, n = 1.7 / 1.5, a DIVERGENT bundle
-        # from the origin, half angle 10 degrees, RectGrid raster of angles -- every ray has its own k0 and E0
-        records = systems.benchmark_records()
-        bundle = dict(radius=systems.BENCHMARK_HALF_ANGLE)
-        workload = ("demo_benchmark: the reference's own benchmark system (8 Conic surfaces, n = 1.7 / 1.5 around a "
-                    "stop), divergent RectGrid bundle from the origin, half angle 10 deg, per-ray k0 / E0 arrays "
-                    "(demos/demo_benchmark.py:47-78; the reference runs it at 1e5 rays)")
-    else:
-        raise ValueError(config)
-    want = total_rays if total_rays is not None else rays * n_gpus
-    if config == "benchmark":
-        from pyrate_amd.sampling2d import raster as praster
-        tables = praster.RectGrid().device_tables(want)
-        (x0, k0, e0, n_total) = engine.raster_bundle_device(tables, "divergent", dev, radius=bundle["radius"])
-        return dict(config=config, records=records, record_sets=[records], x0=x0, k0=k0, e0=e0, uniform=None,
-                    n_total=n_total, n_local=n_total, lo=0, hi=n_total, S=len(records), workload=workload,
-                    bundle=bundle, first_segment="arrays")
-    (_, n_total) = engine.rect_grid_count(want, dev)
-    (lo, hi) = pdist.shard_range(n_total, rank, n_gpus, align)
-    uniform = first_segment == "uniform"
-    (x0, k0, e0, _) = systems.double_gauss_bundle_device(want, dev, lo=lo, hi=hi, uniform=uniform, **bundle)
-    uni = None
-    if uniform:
-        (uni, k0, e0) = (k0, None, None)
-    if config in ("aniso", "aniso_biaxial", "aniso_chain"):            # the crystal marches take tight arrays
-        (x0, k0, e0) = [None if t is None else t.contiguous() for t in (x0, k0, e0)]
-    return dict(config=config, records=records, record_sets=record_sets or [records], x0=x0, k0=k0, e0=e0,
-                uniform=uni, n_total=n_total, n_local=hi - lo, lo=lo, hi=hi, S=len(records), workload=workload,
-                bundle=bundle, first_segment=first_segment)
-
-
-def host_bundle(wl, m):
-    """the first m rays of a workload's bundle as host arrays (x0, k0, E0) for the CPU baselines"""
-    m = min(m, wl["n_local"])
-
-    def to_host(t):
-        # through a page-locked staging array: a 96-MB copy straight into pageable memory makes the runtime pin
-        # those pages in place, and the pinned range is torn down again when NumPy frees the array
-        if R4_PAGEABLE:         # (experiment: round 4's form, the suspected trigger of its device faults -- DESIGN.md 5)
-            return t[:, :m].cpu().numpy()
-        stage = torch.empty((3, m), dtype=torch.float64, pin_memory=True)
-        stage.copy_(t[:, :m])
-        return stage.numpy().copy()
-    x = to_host(wl["x0"])
-    if wl["uniform"] is not None:
-        k = np.repeat(np.array(wl["uniform"].k)[:, None], m, axis=1)
-        e = np.repeat(np.array(wl["uniform"].e_re)[:, None], m, axis=1)
-    else:
-        (k, e) = (to_host(wl["k0"]), to_host(wl["e0"]))
-    return np.ascontiguousarray(x), np.ascontiguousarray(k), np.ascontiguousarray(e)
-
-
-def input_bytes_per_ray(wl):
-    """x0 24 B (+ k0 24 B + E0 24 B when the first segment travels as arrays)"""
-    return 24 if wl["uniform"] is not None else 72
-
-
-def algorithmic_bytes(wl, sysd, mode, record_bytes):
-    """HBM bytes one launch of the fused march must move: the inputs once; per surface
-    x_hit 24 B + k_out 24 B + one byte holding both masks (SURVEY 8d's 49-B ray-surface record; 50 B with the
-    masks in two arrays).  Tables with crystals (concatenated layout, real k): per surface x_hit 24 B + mask
-    1 B per entering ray and k_out 24 B + mask 1 B per leaving ray (crystal interfaces double the rays)."""
-    n = wl["n_local"]
-    read = input_bytes_per_ray(wl) * n
-    if wl["config"] == "aniso_chain" and mode == "path":
-        # the per-surface march: every surface reads the state of the rays that enter it (x, k, mask: 49 B) and writes
-        # the record of those that leave (49 B) -- SURVEY 8d's 98 B per op, with the ray count doubling at crystals
-        (n_in, n_out) = sysd.ray_counts(n)
-        return 49 * (sum(n_in) + sum(n_out))
-    if not sysd.all_isotropic:
-        (n_in, n_out) = sysd.ray_counts(n)
-        return read + (25 * (sum(n_in) + sum(n_out)) if mode == "path" else 25 * (n_in[-1] + n_out[-1]))
-    return read + n * record_bytes * (wl["S"] if mode == "path" else 1)
-
-
-# ------------------------------------------------------------------------------------------------
-# CPU baselines (test oracles timed on the GPU box's host cores; reported, not the target)
-# ------------------------------------------------------------------------------------------------
-def cpu_baseline(wl, budget_s=4.0, with_numpy=True):
-    """CPU restatements of the reference algorithm (test oracles, geometry only -- i.e. WITHOUT
-    the reference's SVD E-field step that is 91% of its time) on a bounded sample of the same
-    workload, timed on this box's host cores:
-      value: C / OpenMP port (oracle/seqtrace_c.c) on the best of a few thread counts
-      numpy_single_core: the NumPy port (oracle/seqtrace_np.py), one process
-      with_svd_efield: NumPy port incl. the SVD E-field step, the reference's true cost profile (headline only)"""
-    from oracle import seqtrace_np as oracle
-    from oracle import seqtrace_c
-    records = wl["records"]
-    S = wl["S"]
-    out = {"unit": "ray-surface-ops/s", "host_cpus": os.cpu_count()}
-    m_c = {"doublegauss": 4_000_000, "asphere": 4_000_000, "xypoly": 4_000_000, "aniso": 500_000,
-           "benchmark": 4_000_000, "aniso_biaxial": 200_000, "aniso_chain": 2_000}[wl["config"]]
-    (o, k, e0) = host_bundle(wl, m_c)
-    n = o.shape[1]
-    if seqtrace_c.supports(records):
-        ws = seqtrace_c.Workspace(records, n)               # outputs allocated and touched once
-        seqtrace_c.trace_arrays(records, o, k, e0, workspace=ws)                            # warm-up
-        # the port is memory bound on the host; pick the best of a few thread counts, then time it
-        nmax = seqtrace_c.load().seqtrace_c_threads()
-        best = (None, 0.0)
-        for nt in sorted(set(max(1, nmax // q) for q in (1, 2, 4, 8))):
-            t0 = time.perf_counter()
-            seqtrace_c.trace_arrays(records, o, k, e0, nthreads=nt, workspace=ws)
-            rate = n * S / (time.perf_counter() - t0)
-            if rate > best[1]:
-                best = (nt, rate)
-        reps = 0
-        t0 = time.perf_counter()
-        while True:
-            used = seqtrace_c.trace_arrays(records, o, k, e0, nthreads=best[0], workspace=ws)[-1]
-            reps += 1
-            dt_c = time.perf_counter() - t0
-            if dt_c > budget_s or reps >= 30:
-                break
-        out.update({"value": reps * n * S / dt_c, "cores": used, "kind": "port",
-                    "sample": "C/OpenMP oracle (oracle/seqtrace_c.c): %d x (first %d of the %d rays x %d surfaces, "
-                              "path written to host RAM), %.1f s" % (reps, n, wl["n_local"], S, dt_c)})
-    if with_numpy or "value" not in out:
-        m_np = min(n, {"aniso": 20_000}.get(wl["config"], 500_000))
-        t1 = time.perf_counter()
-        done = 0
-        with np.errstate(all="ignore"):
-            while done < m_np:
-                hi = min(done + 100_000, m_np)
-                oracle.trace(records, o[:, done:hi], k[:, done:hi], e0[:, done:hi])
-                done = hi
-        dt_np = time.perf_counter() - t1
-        npy = {"value": m_np * S / dt_np, "sample": "NumPy oracle (oracle/seqtrace_np.py), first %d rays in chunks "
-                                                    "of 100000, one process, %.1f s" % (m_np, dt_np)}
-        if "value" in out:
-            out["numpy_single_core"] = npy
-        else:
-            out.update(npy, cores=1, kind="port")
-    if wl["config"] == "doublegauss" and with_numpy:
-        m_e = min(n, 50_000)
-        t2 = time.perf_counter()
-        with np.errstate(all="ignore"):
-            oracle.trace(records, o[:, :m_e], k[:, :m_e], e0[:, :m_e], with_efield=True)
-        dt_e = time.perf_counter() - t2
-        out["with_svd_efield"] = {"value": m_e * S / dt_e, "sample": "%d rays, %.1f s" % (m_e, dt_e)}
-    return out
-
-
-# ------------------------------------------------------------------------------------------------
-# verification of what the timed launches wrote (after the timed region; oracle/ only as the checker)
-# ------------------------------------------------------------------------------------------------
-def verify_outputs(wl, sysd, ob, with_oracle, m=10_000):
-    """The arrays ``ob`` as the LAST timed launch left them, checked
-      * on every ray, on the device: every valid hit point lies on its surface (|z - F(x, y)| in the shape frame);
-        every outgoing wave vector satisfies the dispersion relation of its medium (isotropic: ||k| - n|; crystal:
-        |det(eps - k.k I + k k^T)| / |eps|^3); no NaN among rays flagged valid;
-      * on a sub-sample of ``m`` rays against the CPU oracle (C restatement where it covers the table, NumPy
-        otherwise): masks equal, hit points relative to max(|x|, 1 mm), wave vectors absolute.
-    Returns the ``verified`` object of the bench line; ``ok`` = everything within VERIFY_TOL."""
-    from pyrate_amd import _lib
-    res = sysd.views(ob)
-    recs = wl["records"]
-    dev = wl["x0"].device
-    n = wl["n_local"]
-    path = ob["mode"] == _lib.MODE_PATH
-    surfaces = list(range(len(recs))) if path else [len(recs) - 1]
-    f64 = dict(dtype=torch.float64, device=dev)
-
-    def to_frame(v, B, g):
-        """B^T (v - g) row by row: elementwise kernels only (a (3 x 3) @ (3 x 1e7) product would go to the BLAS)"""
-        B = np.asarray(B, dtype=float).reshape(3, 3)
-        if R4_BLAS:             # (experiment: round 4's form -- a (3 x 3) @ (3 x 1e7) product through the BLAS)
-            Bt = torch.tensor(B, **f64)
-            p = Bt.T @ (v - torch.tensor(np.asarray(g, dtype=float), **f64)[:, None] if g is not None else v)
-            return [p[0], p[1], p[2]]
-        d = [v[c] - float(g[c]) if g is not None and float(g[c]) != 0.0 else v[c] for c in range(3)]
-        if np.array_equal(B, np.eye(3)):
-            return d
-        return [float(B[0, r]) * d[0] + float(B[1, r]) * d[1] + float(B[2, r]) * d[2] for r in range(3)]
-
-    def worst(values, mask):
-        """max |values| over mask; a NaN under the mask counts as infinite"""
-        v = torch.where(mask, values.abs(), torch.zeros((), **f64))
-        v = torch.nan_to_num(v, nan=float("inf"))
-        return float(v.max().item()) if v.numel() else 0.0
-    (max_resid, max_disp, n_rays_checked) = (0.0, 0.0, 0)
-    for (j, s) in enumerate(surfaces):
-        rec = recs[s]
-        x = res.x_hit[j]
-        k = res.k_out[j]
-        v_hit = res.valid[j].bool()
-        v_out = res.valid_out[j].bool() if res.valid_out[j] is not None else v_hit
-        if res.nonconv is not None and res.nonconv[j] is not None:
-            v_hit = v_hit & ~res.nonconv[j].bool()        # (Newton cap hit: flagged, NaN hit point by contract)
-        p = to_frame(x, rec["B_shape"], rec["g_shape"])
-        sh = rec["shape"]
-        if sh["type"] == "conic":
-            # c (x^2 + y^2 + (1 + cc) z^2) - 2 z = 0, gradient ~ 2 along z: half of it is the distance
-            resid = 0.5 * (sh["curv"] * (p[0] ** 2 + p[1] ** 2 + (1.0 + sh["cc"]) * p[2] ** 2) - 2.0 * p[2])
-        else:
-            (sag, _) = sysd.shape_eval(s, p[0].contiguous(), p[1].contiguous(), want_grad=False)
-            resid = p[2] - sag
-        max_resid = max(max_resid, worst(resid, v_hit))
-        mat = rec["material"]
-        km = to_frame(k, rec["B_mat"], None)
-        if mat["type"] == "anisotropic":
-            eps = torch.tensor(np.asarray(mat["eps_re"], dtype=float), **f64)
-            k2 = km[0] ** 2 + km[1] ** 2 + km[2] ** 2
-            W = [[eps[a, b] + km[a] * km[b] - (k2 if a == b else 0.0) for b in range(3)] for a in range(3)]
-            det = (W[0][0] * (W[1][1] * W[2][2] - W[1][2] * W[2][1]) - W[0][1] * (W[1][0] * W[2][2] - W[1][2] * W[2][0])
-                   + W[0][2] * (W[1][0] * W[2][1] - W[1][1] * W[2][0]))
-            disp = det / float(torch.linalg.norm(eps)) ** 3
-        else:
-            disp = torch.sqrt(km[0] ** 2 + km[1] ** 2 + km[2] ** 2) - float(mat["n"])
-        max_disp = max(max_disp, worst(disp, v_out))
-        n_rays_checked += int(x.shape[1])
-        del p, resid, disp, km
-    out = {"tolerance": VERIFY_TOL, "max_resid": max_resid, "max_abs_k": max_disp, "n_checked": n_rays_checked,
-           "what": "every ray-surface record of the last timed launch: |z - F(x, y)| of valid hit points (mm); "
-                   "dispersion relation of valid wave vectors (isotropic: ||k| - n|, crystal: |det W| / |eps|^3)",
-           "max_rel_x": None, "oracle_sample": None}
-    ok = max_resid <= VERIFY_TOL and max_disp <= VERIFY_TOL
-    if with_oracle and path:
-        from oracle import seqtrace_np as oracle
-        from oracle import seqtrace_c
-        idx = np.unique(np.linspace(0, n - 1, min(m, n)).astype(np.int64))
-        it = torch.from_numpy(idx).to(dev)
-        o = wl["x0"][:, it].cpu().numpy()
-        if wl["uniform"] is not None:
-            kk = np.repeat(np.array(wl["uniform"].k)[:, None], idx.size, axis=1)
-            ee = np.repeat(np.array(wl["uniform"].e_re)[:, None], idx.size, axis=1)
-        else:
-            (kk, ee) = (wl["k0"][:, it].cpu().numpy(), wl["e0"][:, it].cpu().numpy())
-        (o, kk, ee) = [np.ascontiguousarray(a) for a in (o, kk, ee)]
-        use_c = seqtrace_c.supports(recs) and (sysd.all_isotropic or seqtrace_c.load().seqtrace_c_has_zggev())
-        with np.errstate(all="ignore"):
-            ref = seqtrace_c.trace(recs, o, kk, ee) if use_c else oracle.trace(recs, o, kk, ee)
-        (rel_x, abs_k, mask_diff) = (0.0, 0.0, 0)
-        for s in range(len(recs)):
-            (b_in, b_out) = (res.n_in[s] // n, res.n_out[s] // n)
-            cols_in = torch.cat([it + b * n for b in range(b_in)])
-            cols_out = torch.cat([it + b * n for b in range(b_out)])
-            gx = res.x_hit[s][:, cols_in].cpu().numpy()
-            gk = res.k_out[s][:, cols_out].cpu().numpy()
-            gv = res.valid[s][cols_in].cpu().numpy().astype(bool)
-            gw = (res.valid_out[s][cols_out].cpu().numpy().astype(bool) if res.valid_out[s] is not None else None)
-            rv = np.asarray(ref[s]["valid"], dtype=bool)
-            rw = np.asarray(ref[s]["valid_out"], dtype=bool)
-            mask_diff += int(np.count_nonzero(gv != rv)) + (int(np.count_nonzero(gw != rw)) if gw is not None else 0)
-            if rv.any():
-                dx = np.linalg.norm(gx[:, rv] - ref[s]["x_hit"][:, rv], axis=0)
-                sc = np.maximum(np.linalg.norm(ref[s]["x_hit"][:, rv], axis=0), 1.0)
-                rel_x = max(rel_x, float(np.nan_to_num(dx / sc, nan=np.inf).max()))
-            if rw.any():
-                dk = np.abs(gk[:, rw] - np.real(ref[s]["k_out"][:, rw]))
-                abs_k = max(abs_k, float(np.nan_to_num(dk, nan=np.inf).max()))
-        out["max_rel_x"] = rel_x
-        out["max_abs_k"] = max(out["max_abs_k"], abs_k)
-        out["oracle_sample"] = {"rays": int(idx.size), "oracle": "oracle/seqtrace_c.c" if use_c else "oracle/seqtrace_np.py",
-                                "max_rel_x": rel_x, "max_abs_k": abs_k, "mask_mismatches": mask_diff}
-        ok = ok and rel_x <= VERIFY_TOL and abs_k <= VERIFY_TOL and mask_diff == 0
-    out["ok"] = bool(ok)
-    return out
-
-
-# ------------------------------------------------------------------------------------------------
-# helpers
-# ------------------------------------------------------------------------------------------------
 def _flush_c_stdio():
     try:
         ctypes.CDLL(None).fflush(None)
@@ -455,543 +78,7 @@ def _stdout_of_other_ranks_to_stderr():
         os.dup2(2, 1)
 
 
-def _lookup(fname, key):
-    """a per-launch figure measured by rocprofv3 PMC passes of an EARLIER run of the same workload
-    (benchmarks/collect_profiles.sh) -- looked up, not measured in this run"""
-    path = os.path.join(ROOT, "profiles", fname)
-    try:
-        with open(path) as f:
-            return json.load(f).get(key)
-    except (OSError, ValueError):
-        return None
-
-
-def alloc_outputs_or_torch(sysd, n_local, mode, packed, placement, pitch, count=1):
-    """the path arrays of a run: from the arena (the product path's allocation for arrays of this size) or,
-    where the device / driver offers no placement control, from the torch allocator -- and says so"""
-    note = None
-    try:
-        bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed, placement=placement, pitch=pitch)
-                for _ in range(count)]
-    except RuntimeError as exc:
-        if placement != "arena":
-            raise
-        note = "arena unavailable (%s): path arrays from the torch allocator" % exc
-        print("bench.py: " + note, file=sys.stderr)
-        placement = "torch"
-        bufs = [sysd.alloc_outputs(n_local, mode, packed_flags=packed, placement=placement, pitch=pitch)
-                for _ in range(count)]
-    return bufs, placement, note
-
-
-def kernel_label(config):
-    if config == "aniso_chain":
-        return "k_propagate + k_interact_aniso per surface"
-    return "k_trace_general" if config.startswith("aniso") else "k_trace_iso"
-
-
-# ------------------------------------------------------------------------------------------------
-# one single-GPU configuration: K timed steps + kernel time + roofline (+ CPU baseline)
-# ------------------------------------------------------------------------------------------------
-def measure_single(config, args, dev, rays, with_cpu, verify_oracle=None):
-    from pyrate_amd import engine, placed, _lib
-    wl = make_workload(config, rays, dev, first_segment=args.first_segment)
-    sysd = engine.DeviceSystem(wl["records"], dev.index)
-    iso = sysd.all_isotropic
-    mode = _lib.MODE_PATH if args.mode == "path" else _lib.MODE_IMAGE
-    packed = iso and not args.two_mask_arrays
-    record_bytes = 49 if packed else 50
-    placement = args.placement if mode == _lib.MODE_PATH else "torch"
-    (x0, k0, e0, uni, n_local) = (wl["x0"], wl["k0"], wl["e0"], wl["uniform"], wl["n_local"])
-    if args.inputs == "torch" and iso:
-        # A/B: the inputs in torch-allocated arrays instead of arena memory of a third kind
-        moved = []
-        for t in (x0, k0, e0):
-            if t is None:
-                moved.append(None)
-                continue
-            buf = torch.empty((3, t.stride(0)), dtype=torch.float64, device=dev)[:, :n_local]
-            buf.copy_(t)
-            moved.append(buf)
-        (x0, k0, e0) = moved
-        torch.cuda.synchronize()
-    pitch = engine.recommended_pitch(n_local) if iso else None
-    (bufs, placement, placement_note) = alloc_outputs_or_torch(sysd, n_local, mode, packed, placement, pitch)
-    ob = bufs[0]
-    arena_obj = placed.PlacedArena.for_device(dev.index) if placement == "arena" else None
-    input_kind = arena_obj.kind_of(x0) if arena_obj is not None else None
-
-    launch = sysd.launcher(x0, k0, ob, e0, uniform=uni)     # the argument struct is built once
-    if os.environ.get("PRT_BENCH_DEBUG"):
-        def span(t):
-            return None if t is None else "%#x+%#x" % (t.data_ptr(), t.numel() * t.element_size())
-        print("bench.py debug %s: x0 %s (pitch %s) k0 %s e0 %s | x_hit %s k_out %s valid %s | kinds %s input %s | arena %s | torch %s"
-              " | fds %d | free/total %s"
-              % (config, span(x0), x0.stride(0), span(k0), span(e0), span(ob["x_hit"]), span(ob["k_out"]), span(ob["valid"]),
-                 ob["placement"], input_kind, arena_obj.stats() if arena_obj is not None else None,
-                 (torch.cuda.memory_allocated(), torch.cuda.memory_reserved()), len(os.listdir("/proc/self/fd")),
-                 torch.cuda.mem_get_info()), file=sys.stderr, flush=True)
-
-    # device wake-up (not one of the W warm-up steps): after idle the first ~25 ms of launches run at ramping
-    # clocks; 30 plain launches of the same kernel -- and, for kernels as short as the crystal march (0.12 ms), as many
-    # more as it takes to fill 50 ms -- bring the chip to its steady state before anything is counted
-    for _ in range(PREWARM_LAUNCHES):
-        launch()
-    torch.cuda.synchronize()
-    est_ms = sysd.trace_timed(x0, k0, ob, 10, e0, uniform=uni)
-    prewarm = PREWARM_LAUNCHES + 10
-    while prewarm * est_ms < PREWARM_MS:
-        launch()
-        prewarm += 1
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        launch()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        launch()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    # dominant kernel: average launch duration from HIP events on the launch stream
-    kernel_ms = sysd.trace_timed(x0, k0, ob, max(args.steps, 5), e0, uniform=uni)
-    torch.cuda.synchronize()
-
-    S = wl["S"]
-    alg = algorithmic_bytes(wl, sysd, args.mode, record_bytes)
-    achieved = alg / (kernel_ms * 1e-3) / 1e9
-    hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-           "traffic": None, "traffic_source": None, "kernel": kernel_label(config), "kernel_ms": kernel_ms,
-           "algorithmic_bytes_per_launch": alg, "bytes_per_ray_surface_op": alg / (n_local * S)}
-    if config == "doublegauss" and args.mode == "path":
-        hbm["frac_at_98B_per_op_convention"] = (n_local * S * 98 / (kernel_ms * 1e-3) / 1e9) / HBM_PEAK_GBS
-    kinds_out = ob["placement"].get("kinds")
-    if placement_note is None and kinds_out and len(set(kinds_out[:2])) < 2:
-        placement_note = ("x_hit and k_out share a kind of HBM (the arena found no second kind within its "
-                          "hunt): expect the 5.6 TB/s regime of same-kind write streams")
-    elif placement_note is None and arena_obj is not None and iso and input_kind is not None \
-            and kinds_out and input_kind in kinds_out[:2]:
-        placement_note = "the inputs share a kind of HBM with a path array (no third kind found): about 5 % slower"
-    (n_in, n_out) = sysd.ray_counts(n_local)
-    rec = {"name": config, "workload": wl["workload"], "value": n_local * S * args.steps / elapsed,
-           "unit": "ray-surface-ops/s", "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": elapsed / args.steps * 1e3, "dtype": "f64", "prewarm_launches": prewarm,
-           "rays": n_local, "surfaces": S, "mode": args.mode,
-           "rays_per_surface": None if iso else {"entering": n_in, "leaving": n_out},
-           "first_segment": ("uniform k0 / E0 (collimated bundle: one vector each, 24 B/ray of loads)"
-                             if uni is not None else "arrays x0, k0, E0 (72 B/ray of loads)"),
-           "record_bytes": record_bytes if iso else 25,
-           "masks": ("valid | valid_out << 1 in one byte" if packed else "two byte arrays"),
-           "output_placement": {"policy": ob["placement"]["policy"], "note": placement_note,
-                                "memory_kinds_of_x_hit_and_k_out": kinds_out,
-                                "memory_kind_of_inputs": input_kind,
-                                "inputs": "arena" if input_kind is not None else "torch allocator"},
-           "roofline": hbm, "cpu_baseline": None, "_iso": iso, "_alg": alg, "_n_local": n_local}
-    # what the timed launches wrote, checked (outside every timed region; the oracle leg runs with the CPU baseline)
-    rec["verified"] = verify_outputs(wl, sysd, ob, with_oracle=with_cpu if verify_oracle is None else verify_oracle)
-    if config == "benchmark":
-        # context, not a published number (vs_baseline stays null): what the reference itself reaches on this workload
-        rec["reference_rate"] = {"value": 7.8e4, "unit": "ray-surface-ops/s",
-                                 "where": "BASELINE.md section 2: the reference's demo_benchmark.py system verbatim in the "
-                                          "survey container (8 vCPU, 99 693 rays, 8.94 s)",
-                                 "ratio": rec["value"] / 7.8e4}
-    if with_cpu:
-        rec["cpu_baseline"] = cpu_baseline(wl, budget_s=args.cpu_budget, with_numpy=(config == (args.config or "doublegauss")))
-    del bufs, ob, x0, k0, e0
-    return rec
-
-
-def _event_timed(fn, steps, warmup):
-    """average milliseconds of fn() over `steps` calls, HIP events on the current stream (the stream fn launches on)"""
-    for _ in range(warmup):
-        fn()
-    torch.cuda.synchronize()
-    (a, b) = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-    t0 = time.perf_counter()
-    a.record()
-    for _ in range(steps):
-        fn()
-    b.record()
-    torch.cuda.synchronize()
-    return a.elapsed_time(b) / steps, (time.perf_counter() - t0) / steps * 1e3
-
-
-def measure_plugin(args, dev, rays):
-    """The double Gauss through the PLUGIN-GRANULAR calls: per surface one prt_propagate (Material.propagate ->
-    Surface.intersect) and one prt_interact (Material.refract), the loop of optical_element.py:336-375 -- what a
-    caller gets who drives the trace surface by surface.  Roof: SURVEY 8d's 98 B per ray-surface-op (every call
-    re-reads the state it works on).  Verified: the last surface's record equals the fused march's, bit for bit."""
-    from pyrate_amd import engine, _lib
-    wl = make_workload("doublegauss", rays, dev, first_segment="arrays")
-    sysd = engine.DeviceSystem(wl["records"], dev.index)
-    (x0, k0, e0, n, S) = (wl["x0"], wl["k0"], wl["e0"], wl["n_local"], wl["S"])
-    last = {}
-
-    def sweep():
-        (x, k, valid) = (x0, k0, None)
-        for s in range(S):
-            if s == 0:
-                (xh, v) = sysd.propagate(0, x, k, e_re=e0, valid_in=None)
-            else:
-                (xh, v) = sysd.propagate(s, x, k, default_e=False, valid_in=valid)
-            (k, _, valid, _, _) = sysd.interact(s, xh, k, valid_in=v)
-            x = xh
-        last.update(x=x, k=k, valid=valid, hit=v)
-    steps = max(5, min(args.steps, 20))
-    (ms, wall_ms) = _event_timed(sweep, steps, 3)
-    ops = n * S
-    achieved = 98.0 * ops / (ms * 1e-3) / 1e9
-    # the fused march on the same bundle (image mode: the last surface's record)
-    ob = sysd.alloc_outputs(n, _lib.MODE_IMAGE, packed_flags=False, placement="torch")
-    sysd.trace_into(x0, k0, ob, e0)
-    torch.cuda.synchronize()
-    res = sysd.views(ob)
-    m = res.valid_out[0].bool()
-    # (masks bit for bit; values to rounding: the per-surface calls take a unit direction where the fused march takes
-    #  k itself -- the same hit point computed with differently scaled intermediates)
-    masks_equal = bool(torch.equal(last["valid"], res.valid_out[0]) and torch.equal(last["hit"], res.valid[0]))
-    scale = res.x_hit[0][:, m].norm(dim=0).clamp_min(1.0)
-    rel_x = float(((last["x"][:, m] - res.x_hit[0][:, m]).abs().max(dim=0).values / scale).max()) if bool(m.any()) else 0.0
-    abs_k = float((last["k"][:, m] - res.k_out[0][:, m]).abs().max()) if bool(m.any()) else 0.0
-    same = masks_equal and rel_x <= VERIFY_TOL and abs_k <= VERIFY_TOL
-    rec = {"name": "plugin", "workload": "the double Gauss of configs[1] (%d rays x %d surfaces) through the plugin-granular "
-                                         "calls: prt_propagate + prt_interact per surface, arrays from the torch allocator "
-                                         "(Material.propagate / Surface.intersect / Material.refract, "
-                                         "optical_element.py:336-375)" % (n, S),
-           "value": ops / (wall_ms * 1e-3), "unit": "ray-surface-ops/s", "steps": steps, "ms_per_step": wall_ms,
-           "rays": n, "surfaces": S, "mode": "per-surface calls", "dtype": "f64",
-           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_propagate + k_interact_iso",
-                        "kernel_ms": ms, "algorithmic_bytes_per_launch": 98.0 * ops, "bytes_per_ray_surface_op": 98.0,
-                        "note": "kernel_ms = device time of one sweep over the 12 surfaces (24 launches), HIP events",
-                        # what the two kernels of a surface really move: propagate reads x, k, direction (72 B) and
-                        # writes x_hit + mask (25 B); interact reads x_hit, k, mask (49 B) and writes k_out, the ray
-                        # direction and a mask (49 B)
-                        "actual_bytes_per_ray_surface_op": 195.0,
-                        "frac_at_actual_traffic": 195.0 * ops / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-           "verified": {"ok": same, "what": "the last surface's record against the fused march's on the same bundle: both "
-                                            "masks bit for bit, hit points (relative) and wave vectors (absolute) to "
-                                            "rounding", "masks_equal": masks_equal, "max_rel_x": rel_x, "max_abs_k": abs_k,
-                        "tolerance": VERIFY_TOL, "n_checked": n},
-           "cpu_baseline": None, "_custom": True}
-    del ob, res, last
-    return rec
-
-
-def measure_image_moments(args, dev, rays):
-    """The optimiser's call (optimize/optimize.py:73-91: trace, then a merit function of the image plane): ONE
-    image-mode launch of the double Gauss that reduces the spot moments itself (prt_trace_moments) -- no path arrays,
-    7 doubles out.  Bound by FP64 arithmetic, not HBM: the roofline is the FP64 vector peak (flops per launch: the
-    path-mode march's, measured by this run's PMC pass -- the two modes do the same arithmetic)."""
-    from pyrate_amd import engine, _lib
-    wl = make_workload("doublegauss", rays, dev, first_segment=args.first_segment)
-    sysd = engine.DeviceSystem(wl["records"], dev.index)
-    (x0, k0, e0, uni, n, S) = (wl["x0"], wl["k0"], wl["e0"], wl["uniform"], wl["n_local"], wl["S"])
-    ob = sysd.alloc_outputs(n, _lib.MODE_IMAGE, packed_flags=True, placement="torch",
-                            pitch=engine.recommended_pitch(n))
-    ws = engine.MomentsWorkspace(dev, n_rays=n)
-
-    def call():
-        sysd.trace_moments_into(x0, k0, ob, ws, 0, e0, uniform=uni)
-    for _ in range(PREWARM_LAUNCHES):
-        call()
-    (ms, wall_ms) = _event_timed(call, args.steps, args.warmup)
-    mom = ws.out[0].cpu().numpy()
-    (cnt, cen, rms) = engine.spot_from_moments(mom, sysd.moments_reference())
-    # the same statistics from the image-plane arrays the launch wrote (torch, float64)
-    res = sysd.views(ob)
-    m = res.valid_out[0].bool()
-    xs = res.x_hit[0][:, m]
-    cen_ref = xs.mean(dim=1)
-    rms_ref = float(torch.sqrt(((xs - cen_ref[:, None]) ** 2).sum() / (int(m.sum()) - 1)))
-    dev_c = float((torch.tensor(cen, dtype=torch.float64, device=dev) - cen_ref).abs().max())
-    ok = bool(int(cnt) == int(m.sum()) and dev_c <= 1e-10 and abs(rms - rms_ref) <= 1e-10 * max(1.0, rms_ref))
-    rec = {"name": "image_moments", "workload": "the double Gauss of configs[1] (%d rays x %d surfaces), IMAGE mode with "
-                                                "the spot moments reduced by the same launch (prt_trace_moments): trace "
-                                                "+ merit function of an optimiser step, no path arrays" % (n, S),
-           "value": n * S / (wall_ms * 1e-3), "unit": "ray-surface-ops/s", "steps": args.steps, "ms_per_step": wall_ms,
-           "rays": n, "surfaces": S, "mode": "image + moments", "dtype": "f64",
-           "roofline": {"bound": "fp64_valu", "achieved": None, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": None, "traffic": None, "kernel": "k_trace_iso<image, moments> + k_moments_stage/final",
-                        "kernel_ms": ms, "hbm_frac": (24.0 + 49.0) * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-           "verified": {"ok": ok, "what": "count, centroid and RMS spot radius from the launch's 7 moments against the "
-                                          "same statistics of the image-plane arrays it wrote", "count": int(cnt),
-                        "max_abs_centroid_difference": dev_c, "rms_difference": abs(rms - rms_ref), "n_checked": n},
-           "cpu_baseline": None, "_custom": True}
-    del ob, res, ws
-    return rec
-
-
-def finish_roofline(rec, traffic, flops, lookup=True):
-    """fill roofline.traffic (+ the FP64 roof of the crystal march) from the live PMC passes or the files"""
-    if rec.get("_custom"):
-        if rec["name"] == "image_moments":
-            fl = (flops or {}).get("doublegauss")
-            if fl and fl.get("flops_per_launch"):
-                r = rec["roofline"]
-                r["achieved"] = fl["flops_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12
-                r["frac"] = r["achieved"] / FP64_VALU_PEAK_TFLOPS
-                r["flops_per_launch"] = fl["flops_per_launch"]
-                r["flops_source"] = "the path-mode double Gauss march of this run (same arithmetic): " + fl["source"]
-                valu = fl.get("valu_wave_instructions")
-                r["valu_issue_frac"] = (valu * 4.0 / (1024 * 2.4e9) / (r["kernel_ms"] * 1e-3)) if valu else None
-        for k in [k for k in rec if k.startswith("_")]:
-            del rec[k]
-        return rec
-    hbm = rec["roofline"]
-    live = (traffic or {}).get(rec["name"])
-    if live and live.get("bytes_per_launch"):
-        hbm["traffic"] = live["bytes_per_launch"]
-        hbm["traffic_ratio_to_algorithmic"] = live["bytes_per_launch"] / rec["_alg"]
-        hbm["traffic_source"] = live["source"]
-    elif lookup:
-        fkey = ("%s_%d_uniform" if rec["first_segment"].startswith("uniform") else "%s_%d") \
-            % (rec["mode"], rec["_n_local"])
-        if rec["name"] != "doublegauss":
-            fkey = rec["name"] + "_" + fkey
-        tent = _lookup("hbm_traffic.json", fkey)
-        if tent:
-            hbm["traffic"] = tent["bytes_per_launch"]
-            hbm["traffic_source"] = ("profiles/hbm_traffic.json[%s]: rocprofv3 PMC passes of an earlier run of this "
-                                     "workload, looked up by ray count -- NOT measured in this run%s"
-                                     % (fkey, "" if not traffic else " (" + str(traffic.get("error")) + ")"))
-    if not rec["_iso"]:
-        # crystal march: FP64-VALU bound (SURVEY.md 8d) -- flops per launch from SQ instruction counters,
-        # HBM as the secondary roof
-        fl = (flops or {}).get(rec["name"])
-        src = None
-        if fl and fl.get("flops_per_launch"):
-            (fpl, valu, src) = (fl["flops_per_launch"], fl.get("valu_wave_instructions"), fl["source"])
-        else:
-            fent = _lookup("fp64_flops.json", "%s_%s_%d" % (rec["name"], rec["mode"], rec["_n_local"]))
-            (fpl, valu) = (None, None)
-            if fent:
-                fpl = fent["flops_per_launch"]
-                valu = fent.get("counters", {}).get("SQ_INSTS_VALU")
-                src = ("profiles/fp64_flops.json: SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 of an earlier PMC run of "
-                       "this workload (2 flop per FMA, 64 lanes per wave instruction), looked up -- NOT measured "
-                       "in this run")
-        if fpl:
-            ms = hbm["kernel_ms"]
-            tf = fpl / (ms * 1e-3) / 1e12
-            fp64 = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": tf / FP64_VALU_PEAK_TFLOPS, "traffic": hbm["traffic"],
-                    "flops_per_launch": fpl, "flops_source": src, "kernel": hbm["kernel"], "kernel_ms": ms,
-                    # all VALU wave instructions (selects, compares, address arithmetic included) at one
-                    # per 4 cycles and SIMD against the 1024 SIMDs at 2.4 GHz
-                    "valu_issue_frac": (valu * 4.0 / (1024 * 2.4e9) / (ms * 1e-3)) if valu else None}
-            # the roof the launch is closer to is its bound (round 4: without the eigenvectors the path-mode march is
-            # a write-bound kernel like the isotropic one; image mode stays on the VALU side)
-            if hbm["frac"] >= max(fp64["frac"], fp64["valu_issue_frac"] or 0.0):
-                rec["roofline"] = dict(hbm, secondary=fp64)
-            else:
-                rec["roofline"] = dict(fp64, secondary=hbm)
-        else:
-            hbm["note"] = "FP64-VALU bound kernel; no flop count available, HBM fraction shown"
-    else:
-        # isotropic marches are HBM bound; the FP64 / VALU-issue side is carried as the secondary roof when the counters
-        # were taken in this run (it is what separates the Newton marches from the conic ones: DESIGN.md section 5)
-        fl = (flops or {}).get(rec["name"])
-        if fl and fl.get("flops_per_launch"):
-            ms = hbm["kernel_ms"]
-            tf = fl["flops_per_launch"] / (ms * 1e-3) / 1e12
-            valu = fl.get("valu_wave_instructions")
-            hbm["secondary"] = {"bound": "fp64_valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_launch": fl["flops_per_launch"],
-                                "flops_source": fl["source"],
-                                "valu_issue_frac": (valu * 4.0 / (1024 * 2.4e9) / (ms * 1e-3)) if valu else None}
-    for k in [k for k in rec if k.startswith("_")]:
-        del rec[k]
-    return rec
-
-
-# ------------------------------------------------------------------------------------------------
-# live PMC: the marches re-run under rocprofv3 (separate --pmc passes, kernel trace only)
-# ------------------------------------------------------------------------------------------------
-PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
-              ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64",
-               "SQ_INSTS_VALU"))
-PMC_LAUNCHES = 6
-
-
-def pmc_inner(args, dev):
-    """what runs under rocprofv3: every requested config's march, a few launches each, nothing else timed"""
-    from pyrate_amd import engine, _lib
-    for config in args.pmc_inner.split(","):
-        wl = make_workload(config, args.rays_of[config], dev, first_segment=args.first_segment)
-        sysd = engine.DeviceSystem(wl["records"], dev.index)
-        iso = sysd.all_isotropic
-        packed = iso and not args.two_mask_arrays
-        mode = _lib.MODE_PATH if args.mode == "path" else _lib.MODE_IMAGE
-        # (placement does not change the bytes a launch moves: plain torch arrays, no arena hunt under the profiler)
-        ob = sysd.alloc_outputs(wl["n_local"], mode, packed_flags=packed, placement="torch",
-                                pitch=engine.recommended_pitch(wl["n_local"]) if iso else None)
-        for _ in range(PMC_LAUNCHES):
-            sysd.trace_into(wl["x0"], wl["k0"], ob, wl["e0"], uniform=wl["uniform"])
-        torch.cuda.synchronize()
-        del ob, wl, sysd
-        torch.cuda.empty_cache()
-
-
-def _is_march(kernel_name):
-    return "k_trace_general<" in kernel_name or "k_trace_iso<" in kernel_name
-
-
-def _pmc_config_of(kernel_name):
-    """fall-back when the counter file has no dispatch ids: which bench config a march launch belongs to, from its
-    instantiation: k_trace_general -> aniso; k_trace_iso<MODE, VEC_IN, VEC_OUT, SHAPES, LDS, MOMENTS, UNI, ...> with
-    SHAPES 1 / 2 -> asphere / xypoly, SHAPES 0 -> doublegauss (uniform first segment) or benchmark (arrays)"""
-    if "k_trace_general<" in kernel_name:           # <MODE, GENERAL, ...>: GENERAL = the biaxial (quartic) instantiation
-        g = re.search(r"k_trace_general<\s*\d+\s*,\s*(\w+)", kernel_name)
-        return "aniso_biaxial" if g and g.group(1) in ("1", "true") else "aniso"
-    m = re.search(r"k_trace_iso<\s*\d+\s*,\s*\w+\s*,\s*\w+\s*,\s*(\d+)\s*,\s*\w+\s*,\s*\w+\s*,\s*(\w+)", kernel_name)
-    if m:
-        sh = int(m.group(1))
-        if sh == 0:
-            return "doublegauss" if m.group(2) in ("1", "true") else "benchmark"
-        return {1: "asphere", 2: "xypoly"}.get(sh)
-    return None
-
-
-def _pmc_rows_by_config(rows, configs):
-    """[(config, counter, value)]: pmc_inner launches PMC_LAUNCHES marches per config, in the order of ``configs`` --
-    the i-th march dispatch of the process belongs to configs[i // PMC_LAUNCHES]"""
-    march = [r for r in rows if _is_march(r.get("Kernel_Name", ""))]
-    if march and all(r.get("Dispatch_Id", "").strip().isdigit() for r in march):
-        ids = sorted(set(int(r["Dispatch_Id"]) for r in march))
-        if len(ids) == PMC_LAUNCHES * len(configs):
-            rank_of = {d: i for (i, d) in enumerate(ids)}
-            return [(configs[rank_of[int(r["Dispatch_Id"])] // PMC_LAUNCHES], r["Counter_Name"], float(r["Counter_Value"]))
-                    for r in march]
-    return [(_pmc_config_of(r["Kernel_Name"]), r["Counter_Name"], float(r["Counter_Value"])) for r in march]
-
-
-def measure_pmc_live(configs, args, rays_of, timeout_s):
-    """(traffic, flops): per config the HBM bytes and FP64 flops of one launch, from rocprofv3 PMC passes over
-    this script's --pmc-inner mode, collected and corrected as MI355X_MICROARCH.md 'HBM' prescribes (separate
-    passes; counters in KiB; FETCH_SIZE doubled on gfx950 for 16 B/lane coalesced reads; WRITE_SIZE as reported)."""
-    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if exe is None:
-        return {"error": "rocprofv3 not found"}, {}
-    tmp = tempfile.mkdtemp(prefix="prt_pmc_", dir="/tmp")
-    # No arena under the profiler: the bytes and instructions of a launch do not depend on where its arrays lie, and
-    # with counters attached every probe launch of a hunt costs milliseconds -- the hunt for the inputs' third kind of
-    # HBM, 190 slabs deep on a freshly booted box, once ate the whole time budget of the passes.
-    env = dict(os.environ, TMPDIR="/tmp", PRT_ARENA="off")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
-        env.pop(k, None)
-    sums = {}
-    t_end = time.perf_counter() + timeout_s
-    try:
-        for (p, counters) in enumerate(PMC_PASSES):
-            left = t_end - time.perf_counter()
-            if left < 10:
-                return {"error": "PMC passes ran out of their time budget (%d s)" % timeout_s}, {}
-            out_dir = os.path.join(tmp, "pass%d" % p)
-            cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out_dir, "--",
-                   sys.executable, os.path.abspath(__file__), "--pmc-inner", ",".join(configs),
-                   "--rays-of", json.dumps(rays_of), "--first-segment", args.first_segment, "--mode", args.mode] + \
-                  (["--two-mask-arrays"] if args.two_mask_arrays else [])
-            res = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left)
-            if res.returncode != 0:
-                return {"error": "rocprofv3 pass %s failed (rc %d): %s"
-                                 % ("+".join(counters), res.returncode, res.stderr.decode(errors="replace")[-300:])}, {}
-            for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
-                with open(path, newline="") as fh:
-                    for (cfg, cname, val) in _pmc_rows_by_config(list(csv.DictReader(fh)), list(configs)):
-                        if cfg in configs:
-                            sums.setdefault((cfg, cname), []).append(val)
-    except (subprocess.TimeoutExpired, OSError) as exc:
-        return {"error": "rocprofv3 PMC passes: %s" % exc}, {}
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-    traffic, flops = {}, {}
-    for cfg in configs:
-        def avg(name):
-            v = sums.get((cfg, name))
-            return (sum(v) / len(v), len(v)) if v else (None, 0)
-        (f, nf) = avg("FETCH_SIZE")
-        (w, nw) = avg("WRITE_SIZE")
-        if f is not None and w is not None:
-            traffic[cfg] = {"bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0, "fetch_bytes": 2.0 * f * 1024.0,
-                            "write_bytes": w * 1024.0, "launches": [nf, nw],
-                            "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc "
-                                      "WRITE_SIZE (separate passes, %d launches each) over `bench.py --pmc-inner`; "
-                                      "2 x FETCH_SIZE (gfx950 counts the 128-B requests of 16 B/lane coalesced "
-                                      "reads at 64 B) + WRITE_SIZE, in KiB" % nf}
-        c = {n: avg(n)[0] for n in PMC_PASSES[2]}
-        if all(v is not None for v in c.values()):
-            flops[cfg] = {"flops_per_launch": 64.0 * (2.0 * c["SQ_INSTS_VALU_FMA_F64"] + c["SQ_INSTS_VALU_ADD_F64"]
-                                                      + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]),
-                          "valu_wave_instructions": c["SQ_INSTS_VALU"],
-                          "source": "measured in this run: rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 "
-                                    "SQ_INSTS_VALU over `bench.py --pmc-inner` (2 flop per FMA, 64 lanes per wave "
-                                    "instruction)"}
-    if not traffic:
-        return {"error": "no march launches found in the rocprofv3 counter files"}, flops
-    return traffic, flops
-
-
-# ------------------------------------------------------------------------------------------------
-# watchdog: a JSON line with an error field instead of a hang
-# ------------------------------------------------------------------------------------------------
-class Watchdog(object):
-    def __init__(self, seconds, rank, json_fd_ref, base):
-        self.seconds = seconds
-        self.stage = "start"
-        self._done = threading.Event()
-        if seconds > 0:
-            t = threading.Thread(target=self._run, args=(rank, json_fd_ref, base), daemon=True)
-            t.start()
-
-    def _run(self, rank, json_fd_ref, base):
-        if self._done.wait(self.seconds):
-            return
-        msg = "watchdog: no result after %g s (stage: %s)" % (self.seconds, self.stage)
-        try:
-            import faulthandler
-            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
-        except Exception:
-            pass
-        if rank == 0:
-            line = dict(base, value=None, ms_per_step=None, error=msg)
-            os.write(json_fd_ref[0], (json.dumps(line) + "\n").encode())
-        os._exit(3)
-
-    def done(self):
-        self._done.set()
-
-
-def _start_over_after_device_fault(exc, watchdog):
-    """A device fault ends the HIP context of this process; nothing measured so far can be verified any more.  The
-    measurement starts over ONCE in a fresh process image (same command line) and the line says so (`attempts`,
-    `first_attempt_error`); a second fault is an error.  Returns False if ``exc`` is no device fault or this already
-    is the second attempt; does not return otherwise."""
-    fault = any(w in str(exc) for w in ("illegal memory access", "hipErrorIllegalAddress", "memory access fault"))
-    if not fault or os.environ.get("PRT_BENCH_ATTEMPT"):
-        return False
-    print("bench.py: device fault during '%s' (%s); starting over in a fresh process" % (watchdog.stage, str(exc)[:300]),
-          file=sys.stderr, flush=True)
-    watchdog.done()
-    os.environ["PRT_BENCH_ATTEMPT"] = "2"
-    os.environ["PRT_BENCH_FIRST_ERROR"] = ("%s: %s" % (watchdog.stage, str(exc)))[:400]
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os.execv(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
-
-
-def _inject_device_fault(dev):
-    """test hook (PRT_BENCH_INJECT_FAULT=<config>): a kernel that writes to addresses nothing is mapped at, on the
-    current stream -- what a fault of the device looks like to this process from then on"""
-    import ctypes
-    from pyrate_amd import _lib
-    k = torch.ones((3, 4096), dtype=torch.float64, device=dev)
-    _lib.load().prt_efield_perp(dev.index, 4096, ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(0x7f0000000000 - (1 << 30)),
-                                ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-
-
-# ------------------------------------------------------------------------------------------------
-def main():
-    _stdout_of_other_ranks_to_stderr()
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # (200 steps = 0.2 s of device time at N = 1: a single scheduling hiccup of the host -- one was seen to cost
@@ -1000,80 +87,161 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=list(SINGLE_GPU_CONFIGS) + list(SECONDARY_MARCH_CONFIGS), default=None,
                     help="measure this configuration alone, as the headline: BASELINE.json configs[1] (doublegauss), "
-                         "configs[2] (asphere), configs[3] (aniso), the XY-polynomial system (xypoly).  Default: "
-                         "doublegauss as the headline, and at N = 1 the other three beside it (`configs`)")
+                         "configs[2] (asphere), configs[3] (aniso), the XY-polynomial system (xypoly) ...")
     ap.add_argument("--headline-only", action="store_true", help="N = 1: do not measure the other configurations")
     ap.add_argument("--configs", default=None, help="N = 1: measure exactly these configurations (comma-separated), the "
                                                     "first one as the headline -- for experiments")
     ap.add_argument("--rays", type=int, default=None,
-                    help="requested rays per GPU (default: 1e7 at N = 1 = BASELINE configs[1]/[2]; 1e6 for "
-                         "aniso; N > 1: with --scaling weak, 1.25e7, so that 8 GPUs trace the 1e8-ray bundle of configs[4])")
+                    help="requested rays per GPU (default: 1e7 at N = 1; N > 1 with --scaling weak: 1.25e7)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
-                    help="N > 1: strong (default) = ONE bundle of --rays-total rays (1e8: BASELINE's '1/2/4/8-GPU scaling "
-                         "on a 1e8-ray bundle') split over the N GPUs, the same raster at every N; weak = --rays rays "
-                         "per GPU (1.25e7: the 1e8-ray bundle at 8 GPUs)")
-    ap.add_argument("--rays-total", type=int, default=None,
-                    help="N > 1, --scaling strong: rays of the whole bundle (default 1e8)")
-    ap.add_argument("--no-scaling-point", action="store_true",
-                    help="N = 1 default run: do not also trace the 1e8-ray bundle of the multi-GPU protocol on this one "
-                         "GPU (`scaling_point` of the line: what N = 1 of --scaling strong costs)")
+                    help="N > 1: strong (default) = ONE bundle of --rays-total rays split over the N GPUs; weak = --rays "
+                         "rays per GPU")
+    ap.add_argument("--rays-total", type=int, default=None, help="N > 1, --scaling strong: rays of the bundle (default 1e8)")
+    ap.add_argument("--no-scaling-point", action="store_true", help="N = 1: skip the 1e8-ray bundle on this one GPU")
+    ap.add_argument("--no-e2e", action="store_true", help="N = 1: skip the end-to-end timing of the drop-in call")
     ap.add_argument("--first-segment", choices=["uniform", "arrays"], default="uniform",
-                    help="how the collimated bundle's k0 / E0 reach the march: as one vector each (default; "
-                         "prt_trace_ex, only x0 is loaded: 24 B/ray) or as per-ray arrays (72 B/ray)")
-    ap.add_argument("--exchange", choices=["gather", "gather-direct", "stats", "final-gather", "none"], default="gather",
-                    help="N>1, what every step ends with: gather = spot-statistics all-reduce + the image-plane "
-                         "all-gather (49 B/ray), overlapped with the next trace (default); gather-direct = the same "
-                         "exchange as peer writes into IPC-mapped receive buffers (one copy per row and peer, all "
-                         "xGMI links at once, no ring; the all-reduce closes it), RCCL backend only; stats = the "
-                         "all-reduce only; final-gather = all-reduce per step, ONE all-gather after the K "
-                         "steps (outside the timed region); none = the bare sharded trace")
-    ap.add_argument("--gather-mode", choices=["inplace", "copy"], default="inplace",
-                    help="N>1, --exchange gather: inplace = the trace writes its image plane straight into its slot of "
-                         "the all-gather's receive buffer and the collectives run in place (default, RCCL); copy = "
-                         "the collectives read the image-plane rows of the path arrays (one more copy of the shard)")
-    ap.add_argument("--two-pass-stats", action="store_true",
-                    help="N>1: per-step spot statistics from two extra passes over the image plane and two "
-                         "all-reduces (default: moments reduced inside the trace kernel, one all-reduce)")
+                    help="how the collimated bundle's k0 / E0 reach the march: one vector each (default; 24 B/ray of "
+                         "loads) or per-ray arrays (72 B/ray)")
+    ap.add_argument("--exchange", choices=["auto", "gather", "gather-direct", "stats", "final-gather", "none"],
+                    default="auto",
+                    help="N > 1, what every step ends with: gather = spot-statistics all-reduce + in-place RCCL all-gather "
+                         "of the image plane; gather-direct = the same exchange as peer writes into IPC-mapped receive "
+                         "buffers; auto (default) = whichever of the two a 3-step probe at start-up finds faster on this "
+                         "node (gather where only it can run); stats = the all-reduce only; final-gather = all-reduce "
+                         "per step, ONE all-gather after the K steps; none = the bare sharded trace")
+    ap.add_argument("--gather-mode", choices=["inplace", "copy"], default="inplace")
+    ap.add_argument("--two-pass-stats", action="store_true")
     ap.add_argument("--placement", choices=["arena", "torch"], default="arena",
-                    help="where the path arrays come from: the engine's placement-aware arena (default; what "
-                         "DeviceSystem.trace uses for arrays of this size) or the torch allocator")
-    ap.add_argument("--inputs", choices=["arena", "torch"], default="arena",
-                    help="where the input arrays live: in a third kind of HBM from the arena (default: "
-                         "what engine.ray_rows / RayBundle do for bundles of this size) or in torch-allocated arrays")
-    ap.add_argument("--two-mask-arrays", action="store_true",
-                    help="write valid and valid_out as two byte arrays (50 B per record) instead of one "
-                         "byte of packed flags (49 B, default)")
+                    help="where the path arrays come from: the engine's placement-aware arena (default) or torch")
+    ap.add_argument("--inputs", choices=["arena", "torch"], default="arena")
+    ap.add_argument("--two-mask-arrays", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="N = 1 default run: do not measure the other shipped paths (aniso_biaxial, aniso_chain, plugin, "
-                         "image_moments) beside the BASELINE configurations")
+                    help="N = 1: skip aniso_biaxial, aniso_chain, plugin, image_moments")
     ap.add_argument("--cpu-budget", type=float, default=4.0, help="seconds of C-port timing per configuration")
     ap.add_argument("--traffic", choices=["auto", "live", "lookup", "none"], default="auto",
-                    help="roofline.traffic: live = rocprofv3 PMC passes over the marches in this run (auto: when "
-                         "rocprofv3 is there, N = 1); lookup = the figures on file (profiles/hbm_traffic.json)")
+                    help="roofline.traffic: live = rocprofv3 PMC passes in this run (auto: when rocprofv3 is there)")
     ap.add_argument("--traffic-timeout", type=float, default=150.0)
     ap.add_argument("--mode", choices=["path", "image"], default="path")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
-                    help="gloo: dry run of the multi-rank path on ONE GPU (all ranks share cuda:0, "
-                         "the gather is staged through host memory); not a measurement")
-    ap.add_argument("--force-multi", action="store_true",
-                    help="run the N>1 code path (5 wavelengths, side-stream all-reduce and all-gather) "
-                         "with whatever world size there is, also 1: RCCL smoke test on a 1-GPU box")
-    ap.add_argument("--trace-stream", choices=["default", "new", "high"], default="new",
-                    help="N > 1: stream of the march -- a new one (default: on the default stream the barrier packets "
-                         "of RCCL's stream and of the side stream can share the march's hardware queue: +4 %% per step), "
-                         "the default stream, or a new high-priority one")
+                    help="gloo: dry run of the multi-rank path on ONE GPU (host-staged gather); not a measurement")
+    ap.add_argument("--force-multi", action="store_true", help="run the N > 1 code path with whatever world size there is")
+    ap.add_argument("--trace-stream", choices=["default", "new", "high"], default="new")
     ap.add_argument("--watchdog", type=float, default=None,
                     help="seconds after which a JSON line with an `error` field is printed and the process exits "
                          "(default: 900 for N > 1, off at N = 1; PRT_BENCH_WATCHDOG overrides)")
+    ap.add_argument("--detail", default=None, help="where the full records go (default: bench_detail.json beside bench.py)")
     ap.add_argument("--pmc-inner", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--rays-of", default=None, help=argparse.SUPPRESS)
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def _r(v, digits=5):
+    """a number as the compact line carries it: 5 significant digits"""
+    if not isinstance(v, float):
+        return v
+    return float("%.*g" % (digits, v)) if v == v and abs(v) != float("inf") else None
+
+
+def compact_single(base, head, recs, scaling_point, e2e, arena_stats, build, wall):
+    """the N = 1 line: numbers only, no prose (the prose is in bench_detail.json)"""
+    rf = head["roofline"]
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio_to_algorithmic", "kernel", "kernel_ms",
+            "algorithmic_bytes_per_launch", "bytes_per_ray_surface_op", "ops_vs_98B_convention")
+    roofline = {k: _r(rf.get(k), 6) for k in keep if k in rf or k in ("traffic", "traffic_ratio_to_algorithmic")}
+    sec = rf.get("secondary")
+    if sec:
+        roofline["secondary"] = {k: _r(sec.get(k)) for k in ("bound", "frac", "valu_issue_frac") if k in sec}
+    cb = head.get("cpu_baseline")
+    cpu = None
+    if cb:
+        cpu = {k: _r(cb.get(k)) for k in ("value", "unit", "cores", "host_cpus", "kind")}
+        cpu["sample"] = str(cb.get("sample", ""))[:160]
+        for extra in ("numpy_single_core", "with_svd_efield"):
+            if cb.get(extra):
+                cpu[extra] = _r(cb[extra]["value"])
+    vf = head["verified"]
+    verified = {k: _r(vf.get(k)) for k in ("ok", "tolerance", "max_resid", "max_rel_x", "max_abs_k", "n_checked")}
+    if vf.get("oracle_sample"):
+        verified["oracle_rays"] = vf["oracle_sample"]["rays"]
+        verified["mask_mismatches"] = vf["oracle_sample"]["mask_mismatches"]
+    summary = {}
+    for r in recs:
+        if "ms_per_step" not in r:
+            continue
+        rr = r["roofline"]
+        summary[r["name"]] = [_r(r["ms_per_step"], 4), _r(rr.get("frac"), 4), bool(r["verified"]["ok"]),
+                              _r(rr.get("traffic_ratio_to_algorithmic"), 4)]
+    op = head.get("output_placement") or {}
+    cfg = {"workload": SHORT_WORKLOAD.get(head["name"], head["name"]), "rays_per_gpu": head["rays"], "rays_total": head["rays"],
+           "surfaces": head["surfaces"], "mode": head["mode"],
+           "first_segment": "uniform" if str(head.get("first_segment", "")).startswith("uniform") else "arrays",
+           "record_bytes": head.get("record_bytes"), "sharding": "none", "wavelengths": 1,
+           "placement": {"policy": op.get("policy"), "kinds": op.get("memory_kinds_of_x_hit_and_k_out"),
+                         "input_kind": op.get("memory_kind_of_inputs"), "note": op.get("note")},
+           "build": build.get("libprt_sha256_16"),
+           "configs_summary_columns": ["ms_per_step", "frac_of_roof", "verified", "traffic_over_algorithmic"],
+           "configs_summary": summary, "wall_s": _r(time.perf_counter() - T_START, 4), "detail": "bench_detail.json"}
+    line = dict(base, value=_r(head["value"], 6), ms_per_step=_r(head["ms_per_step"], 6), config=cfg, roofline=roofline,
+                cpu_baseline=cpu, verified=verified)
+    if scaling_point is not None:
+        if "error" in scaling_point:
+            line["scaling_point"] = {"error": scaling_point["error"][:200]}
+        else:
+            line["scaling_point"] = {"rays": scaling_point["rays_total"], "ms": _r(scaling_point["ms_per_step"]),
+                                     "frac": _r(scaling_point["hbm_frac"]), "ok": bool(scaling_point["verified"]["ok"]),
+                                     "value": _r(scaling_point["value"])}
+            summary["scaling_point_1e8_rays"] = [_r(scaling_point["ms_per_step"], 4), _r(scaling_point["hbm_frac"], 4),
+                                                 bool(scaling_point["verified"]["ok"]), None]
+    if e2e is not None:
+        if "error" in e2e:
+            line["e2e"] = {"error": e2e["error"][:200]}
+        else:
+            line["e2e"] = {k: _r(e2e[k], 4) for k in ("rays", "first_call_ms", "h2d_ms", "seqtrace_call_ms",
+                                                      "seqtrace_device_bundle_ms", "last_bundle_to_host_ms",
+                                                      "full_path_to_host_ms")}
+            line["e2e"]["small_bundle_call_us"] = {k: _r(v, 4) for (k, v) in e2e["small_bundle_call"].items()}
+    return line
+
+
+def write_detail(path, detail):
+    """the full records beside the script (and into gpurun_out/ when the run is a gpurun call)"""
+    targets = [path or os.path.join(ROOT, "bench_detail.json")]
+    if path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        targets.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    for t in targets:
+        try:
+            with open(t, "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError as exc:
+            print("bench.py: could not write %s: %s" % (t, exc), file=sys.stderr)
+
+
+def emit(fd, line):
+    """ONE line, last on stdout, short enough for the driver to keep it whole"""
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= MAX_LINE_BYTES:
+        # never print a line the driver cannot read: drop the optional parts, say so
+        for k in ("e2e", "scaling_point"):
+            line.pop(k, None)
+        line["config"] = {k: v for (k, v) in line["config"].items() if k in ("workload", "rays_per_gpu", "rays_total",
+                                                                             "surfaces", "mode", "build", "detail")}
+        line["truncated"] = "the record outgrew %d bytes; see bench_detail.json" % MAX_LINE_BYTES
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < MAX_LINE_BYTES, len(text)
+    _flush_c_stdio()
+    sys.stdout.flush()
+    os.write(fd, (text + "\n").encode())
+    sys.stdout.flush()
+
+
+def main():
+    _stdout_of_other_ranks_to_stderr()
+    args = parse_args()
     if args.force_multi:
         os.environ["PRT_FORCE_COLLECTIVES"] = "1"
         for (k, v) in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0"), ("MASTER_PORT", "29512")):
             os.environ.setdefault(k, v)
-
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_multi:
         # started as a plain `python bench.py --gpus N`: become the one-process-per-GPU launch the
         # contract describes (torch.distributed.run on this node, rendezvous on 127.0.0.1)
@@ -1102,35 +270,27 @@ def main():
         resource.setrlimit(resource.RLIMIT_CORE, (0, resource.getrlimit(resource.RLIMIT_CORE)[1]))
     except (ImportError, ValueError, OSError):
         pass
-
-    def default_rays(config):
-        return args.rays if args.rays is not None else {"aniso": 1_000_000, "aniso_biaxial": 1_000_000,
-                                                        "aniso_chain": 20_000}.get(config, 10_000_000)
-
     if args.pmc_inner:
         args.rays_of = json.loads(args.rays_of)
-        pmc_inner(args, dev)
+        pmc.inner(args, dev)
         return
 
     exit_code = 0
     json_fd = [1]
     base_line = {"metric": "ray_surface_ops_per_s", "unit": "ray-surface-ops/s", "n_gpus": world, "steps": args.steps,
-                 "warmup": args.warmup, "higher_is_better": True,
-                 # (the protocol `--gpus N` follows: ONE bundle split N ways by default -- the N = 1 line's headline is
-                 #  BASELINE configs[1] at 1e7 rays, its `scaling_point` the 1e8-ray bundle of that protocol on one GPU)
-                 "scaling": args.scaling, "vs_baseline": None,
+                 "warmup": args.warmup, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                  "dtype": "f64", "data": "synthetic"}
     wd_s = args.watchdog if args.watchdog is not None else (900.0 if use_dist else 0.0)
     if os.environ.get("PRT_BENCH_WATCHDOG"):
         wd_s = float(os.environ["PRT_BENCH_WATCHDOG"])
     watchdog = Watchdog(wd_s, rank, json_fd, base_line)
+    # Libraries write to STDOUT behind our back (RCCL's version banner whenever a communicator comes up; rocprofv3's
+    # tool library): the contract is ONE JSON line, last on stdout.  So file descriptor 1 points at stderr for the whole
+    # run and the line goes to a duplicate of the original stdout at the end.
+    sys.stdout.flush()
+    json_fd[0] = os.dup(1)
+    os.dup2(2, 1)
     if use_dist:
-        # RCCL prints a version banner to STDOUT whenever a communicator comes up (first collective of every
-        # process group); the contract is ONE JSON line on stdout.  So file descriptor 1 points at stderr for
-        # the whole run and the line goes to a duplicate of the original stdout at the end.
-        sys.stdout.flush()
-        json_fd[0] = os.dup(1)
-        os.dup2(2, 1)
         watchdog.stage = "init_process_group"
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -1139,422 +299,34 @@ def main():
 
     from pyrate_amd import build as prt_build, _lib
     if use_dist:
-        out = run_multi(args, dev, world, rank, local_rank, watchdog)
-        if out is not None and not (out["verified"]["ok"] and out["verified"]["all_ranks_ok"]):
-            out["error"] = "verification failed (deviation above %g)" % VERIFY_TOL
+        (line, detail) = run_multi(args, dev, world, rank, local_rank, watchdog)
+        if line is not None and not (line["verified"]["ok"] and line["verified"]["all_ranks_ok"]):
+            line["error"] = "verification failed (deviation above %g)" % VERIFY_TOL
             exit_code = 4
     else:
-        configs = [headline]
-        if args.config is None and not args.headline_only and args.mode == "path":
-            configs += [c for c in SINGLE_GPU_CONFIGS if c != headline]
-        if args.configs:
-            configs = [c.strip() for c in args.configs.split(",") if c.strip()]
-            (args.no_secondary, args.no_scaling_point) = (True, True)
-        rays_of = {c: default_rays(c) for c in configs}
-        # the other shipped paths ride along with the default run (SECONDARY_*: the biaxial crystal instantiation, the
-        # per-surface crystal march, the plugin-granular calls, image mode with fused moments)
-        secondary = args.config is None and not args.headline_only and args.mode == "path" and args.rays is None \
-            and not args.no_secondary
-        recs = []
-        try:
-            for c in configs:
-                watchdog.stage = "measure " + c
-                print("bench.py: measuring %s" % c, file=sys.stderr, flush=True)
-                if os.environ.get("PRT_BENCH_INJECT_FAULT") == c and not os.environ.get("PRT_BENCH_ATTEMPT"):
-                    _inject_device_fault(dev)        # (test hook: tests/test_gpu_perf.py)
-                recs.append(measure_single(c, args, dev, rays_of[c], with_cpu=not args.no_cpu_baseline))
-            if secondary:
-                for c in SECONDARY_MARCH_CONFIGS:
-                    watchdog.stage = "measure " + c
-                    print("bench.py: measuring %s" % c, file=sys.stderr, flush=True)
-                    rays_of[c] = 20_000 if c == "aniso_chain" else 1_000_000
-                    recs.append(measure_single(c, args, dev, rays_of[c], with_cpu=False, verify_oracle=False))
-                    configs.append(c)
-                for (c, fn) in (("plugin", measure_plugin), ("image_moments", measure_image_moments)):
-                    watchdog.stage = "measure " + c
-                    print("bench.py: measuring %s" % c, file=sys.stderr, flush=True)
-                    recs.append(fn(args, dev, 10_000_000))
-                    torch.cuda.empty_cache()
-        except (RuntimeError, _lib.PrtError) as exc:
-            if not _start_over_after_device_fault(exc, watchdog):
-                raise
-        traffic, flops = None, None
-        # (a run that is itself being profiled -- rocprofv3 -- python bench.py -- does not start a profiler of its own)
-        profiled = any("rocprof" in os.environ.get(v, "").lower() for v in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES",
-                                                                            "HSA_TOOLS_LIB", "ROCPROFILER_LIBRARY_PATH"))
-        want_live = args.traffic == "live" or (args.traffic == "auto" and shutil.which("rocprofv3") is not None
-                                               and not profiled)
-        if want_live:
-            watchdog.stage = "PMC passes"
-            # (counters are attributed to a configuration by its place in the dispatch order of the march kernels: only
-            #  configurations that ARE one march launch per trace take part)
-            (traffic, flops) = measure_pmc_live([c for c in configs if c != "aniso_chain"], args, rays_of,
-                                                args.traffic_timeout)
-            if "error" in traffic:
-                print("bench.py: live HBM traffic unavailable: %s" % traffic["error"], file=sys.stderr)
-        arena_stats = None
-        if args.placement == "arena":
-            from pyrate_amd import placed
-            try:
-                arena_stats = placed.PlacedArena.for_device(dev.index).stats()
-            except Exception:
-                arena_stats = None
-        recs = [finish_roofline(r, traffic, flops, lookup=args.traffic != "none") for r in recs]
-        head = recs[0]
-        out = dict(base_line)
-        scaling_point = None
-        if args.config is None and not args.headline_only and not args.no_scaling_point and args.mode == "path" \
-                and args.rays is None:
-            # the bundle of the multi-GPU protocol (--scaling strong: 1e8 rays, 61 GB of path arrays) on this one GPU
-            watchdog.stage = "scaling point (1e8 rays)"
-            try:
-                # (the arena starts over: the 2 x 29 slabs of this bundle are taken and classified like in a process
-                # of their own, not pieced together from what the smaller configurations left cached)
-                if args.placement == "arena":
-                    from pyrate_amd import placed
-                    torch.cuda.synchronize()
-                    placed.PlacedArena.for_device(dev.index).trim()
-                torch.cuda.empty_cache()
-                sp = measure_single("doublegauss", args, dev, STRONG_SCALING_RAYS, with_cpu=False, verify_oracle=False)
-                scaling_point = {"what": "BASELINE configs[4]'s bundle (--scaling strong: %d rays) traced by ONE GPU, one "
-                                         "wavelength: the N = 1 point of the strong-scaling curve (the headline above is "
-                                         "configs[1] at 1e7 rays)" % sp["rays"],
-                                 "rays_total": sp["rays"], "value": sp["value"], "ms_per_step": sp["ms_per_step"],
-                                 "kernel_ms": sp["roofline"]["kernel_ms"], "hbm_frac": sp["roofline"]["frac"],
-                                 "verified": sp["verified"], "output_placement": sp["output_placement"]}
-                if not sp["verified"]["ok"]:
-                    recs.append(dict(name="scaling_point", verified=sp["verified"]))
-            except (RuntimeError, MemoryError) as exc:          # a device too small / too busy for 66 GB
-                _start_over_after_device_fault(exc, watchdog)   # (returns unless this was a fault of the device)
-                scaling_point = {"error": "not measured: %s" % str(exc)[:200]}
-        out.update({"value": head["value"], "ms_per_step": head["ms_per_step"],
-                    "config": {"workload": head["workload"], "rays_per_gpu": head["rays"], "rays_total": head["rays"],
-                               "surfaces": head["surfaces"], "rays_per_surface": head["rays_per_surface"],
-                               "mode": head["mode"], "first_segment": head["first_segment"],
-                               "record_bytes": head["record_bytes"], "masks": head["masks"], "sharding": "none",
-                               "wavelengths": 1, "prewarm_launches": head["prewarm_launches"],
-                               "output_placement": dict(head["output_placement"], arena=arena_stats),
-                               "build": prt_build.build_info(_lib.LIB_PATH),
-                               # every configuration of this run in three numbers: [ms per step, fraction of its roof,
-                               # verified] -- so that a reader of a truncated line still has them all
-                               "configs_summary": {r["name"]: [round(r["ms_per_step"], 4),
-                                                               (round(r["roofline"]["frac"], 4)
-                                                                if r["roofline"].get("frac") is not None else None),
-                                                               bool(r["verified"]["ok"])]
-                                                   for r in recs if "ms_per_step" in r},
-                               "wall_s": None},
-                    "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"], "verified": head["verified"],
-                    "scaling_point": scaling_point,
-                    # every single-GPU configuration of BASELINE.json measured by this run, headline first
-                    "configs": recs})
-        if scaling_point and scaling_point.get("hbm_frac") is not None:
-            out["config"]["configs_summary"]["scaling_point_1e8_rays"] = [round(scaling_point["ms_per_step"], 4),
-                                                                          round(scaling_point["hbm_frac"], 4),
-                                                                          bool(scaling_point["verified"]["ok"])]
+        from benchmarks import configs
+        (recs, scaling_point, e2e, arena_stats, wall) = configs.run_single_gpu(args, dev, watchdog, headline)
+        build = prt_build.build_info(_lib.LIB_PATH)
+        # (the full records are on disk before anything is condensed: a bug in the condensing loses nothing measured)
+        raw = dict(configs=recs, scaling_point=scaling_point, e2e=e2e, arena=arena_stats, build=build, wall_s_by_stage=wall)
+        write_detail(args.detail, raw)
+        line = compact_single(base_line, recs[0], recs, scaling_point, e2e, arena_stats, build, wall)
         bad = [r["name"] for r in recs if not r["verified"]["ok"]]
-        recs[:] = [r for r in recs if r["name"] != "scaling_point"]
+        if scaling_point and "error" not in scaling_point and not scaling_point["verified"]["ok"]:
+            bad.append("scaling_point")
         if bad:
-            out["error"] = "verification failed (deviation above %g or a mask mismatch): %s" % (VERIFY_TOL, ", ".join(bad))
+            line["error"] = "verification failed (deviation above %g or a mask mismatch): %s" % (VERIFY_TOL, ", ".join(bad))
             exit_code = 4
-        out["config"]["wall_s"] = time.perf_counter() - T_START
-        if os.environ.get("PRT_BENCH_ATTEMPT"):
-            out["attempts"] = int(os.environ["PRT_BENCH_ATTEMPT"])
-            out["first_attempt_error"] = os.environ.get("PRT_BENCH_FIRST_ERROR")
+        detail = dict(raw, compact_line=line)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     watchdog.done()
     if rank == 0:
-        # the JSON line is the LAST thing on stdout: RCCL writes a version banner through C stdio
-        # (block-buffered on a pipe, so it would otherwise surface at exit, after the line)
-        _flush_c_stdio()
-        sys.stdout.flush()
-        os.write(json_fd[0], (json.dumps(out) + "\n").encode())
-        sys.stdout.flush()
+        write_detail(args.detail, detail)
+        emit(json_fd[0], line)
     if exit_code:
         sys.exit(exit_code)
-
-
-# ------------------------------------------------------------------------------------------------
-# N > 1 (and --force-multi): BASELINE configs[4]
-# ------------------------------------------------------------------------------------------------
-def run_multi(args, dev, world, rank, local_rank, watchdog):
-    from pyrate_amd import build as prt_build, engine, placed, _lib
-    from pyrate_amd import distributed as pdist
-    n_gpus = world
-    strong = args.scaling == "strong"
-    if strong and args.rays is not None:
-        raise SystemExit("--scaling strong (the default for N > 1) takes --rays-total (rays of the whole bundle); "
-                         "--rays (per GPU) goes with --scaling weak")
-    rays = args.rays if args.rays is not None else 12_500_000
-    total_rays = (args.rays_total if args.rays_total is not None else STRONG_SCALING_RAYS) if strong else None
-    watchdog.stage = "bundle generation"
-    # shards of one common stride that is a multiple of 512 rays: rank r's slot of a gathered row starts on a 4-KiB
-    # boundary, so the march can write its image plane straight into it (ImagePlaneGather.own_rows)
-    align = 512
-    wl = make_workload("doublegauss", rays, dev, n_gpus=n_gpus, rank=rank, multi=True,
-                       first_segment=args.first_segment, align=align, total_rays=total_rays)
-    (x0, k0, e0d, uni) = (wl["x0"], wl["k0"], wl["e0"], wl["uniform"])
-    (n_total, n_local, S) = (wl["n_total"], wl["n_local"], wl["S"])
-    sysds = [engine.DeviceSystem(r, local_rank) for r in wl["record_sets"]]
-    sysd = sysds[0]
-    mode = _lib.MODE_PATH if args.mode == "path" else _lib.MODE_IMAGE
-    exchange = args.exchange
-    direct = exchange == "gather-direct"
-    if direct and (args.backend != "nccl" or args.mode != "path" or args.two_pass_stats):
-        raise SystemExit("--exchange gather-direct: RCCL backend, path mode, fused statistics")
-    do_stats = exchange in ("gather", "gather-direct", "stats", "final-gather")
-    do_step_gather = exchange in ("gather", "gather-direct")
-    do_final_gather = exchange == "final-gather"
-    fused_stats = do_stats and not args.two_pass_stats
-    # side-stream jobs in flight: the job of step i overlaps the trace of step i+1.  The fused
-    # statistics only touch 7-double vectors; the gather reads the image-plane rows of the path
-    # arrays, so with it the path arrays are double-buffered.
-    nbuf = 2 if (do_stats or do_step_gather) else 1
-    n_out_bufs = 2 if (do_step_gather or (do_stats and not fused_stats)) else 1
-    packed = not args.two_mask_arrays
-    record_bytes = 49 if packed else 50
-    placement = args.placement if mode == _lib.MODE_PATH else "torch"
-    # one row pitch on every rank: a gathered row is read n_pad elements deep (pdist.ImagePlaneGather)
-    pitch = engine.recommended_pitch(pdist.shard_stride(n_total, n_gpus, align))
-    if args.inputs == "torch":
-        moved = []
-        for t in (x0, k0, e0d):
-            if t is None:
-                moved.append(None)
-                continue
-            buf = torch.empty((3, t.stride(0)), dtype=torch.float64, device=dev)[:, :n_local]
-            buf.copy_(t)
-            moved.append(buf)
-        (x0, k0, e0d) = moved
-        torch.cuda.synchronize()
-    watchdog.stage = "output allocation (arena)"
-    (bufs, placement, placement_note) = alloc_outputs_or_torch(sysd, n_local, mode, packed, placement, pitch,
-                                                                count=n_out_bufs)
-    arena_obj = placed.PlacedArena.for_device(local_rank) if placement == "arena" else None
-    input_kind = arena_obj.kind_of(x0) if arena_obj is not None else None
-    host_staged = (args.backend == "gloo")
-    stats = [pdist.SpotStatistics(dev, n_rays=n_local) for _ in range(nbuf)] if do_stats else []
-    if direct:
-        gathers = [pdist.DirectImagePlaneGather(n_total, dev, align=align) for _ in range(nbuf)]
-    else:
-        gathers = ([pdist.ImagePlaneGather(n_total, dev, stage_on_host=host_staged, align=align)
-                    for _ in range(nbuf if do_step_gather else 1)] if (do_step_gather or do_final_gather) else [])
-    # in place: the march of slot b deposits its image plane in gathers[b]'s receive buffer (prt_trace_ex redirect)
-    inplace = do_step_gather and (args.gather_mode == "inplace" or direct) and not host_staged and mode == _lib.MODE_PATH
-    if inplace:
-        for b in range(nbuf):
-            bufs[b % n_out_bufs] = dict(bufs[b % n_out_bufs], image_rows=gathers[b].own_rows())
-    comm_stream = torch.cuda.Stream(device=dev)
-    if args.trace_stream != "default":
-        # the march on a stream of its own (high priority: a hardware queue that RCCL's stream and the side stream
-        # do not share -- their barrier packets otherwise sit between two marches in the same queue)
-        torch.cuda.synchronize()
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1 if args.trace_stream == "high" else 0))
-    main_stream = torch.cuda.current_stream(dev)
-    side_done = [None] * nbuf          # event: side-stream work of slot b has finished
-    traced = [torch.cuda.Event() for _ in range(nbuf)]          # events are made once and re-recorded every step
-    side_events = [torch.cuda.Event() for _ in range(nbuf)]
-
-    def image_rows(ob):
-        """image-plane rows of a buffer set: (x, k, mask byte row) -- views, nothing is copied"""
-        v = sysd.views(ob)
-        return v.x_hit[-1], v.k_out[-1], (v.flags[-1] if packed else v.valid_out[-1])
-
-    def step(i, with_gather=True):
-        b = i % nbuf
-        if side_done[b] is not None:
-            main_stream.wait_event(side_done[b])      # slot b (and its path arrays) are free again
-        ob = bufs[b % n_out_bufs]
-        if fused_stats:
-            stats[b].trace_and_start(sysds[i % len(sysds)], x0, k0, ob, e0d, uniform=uni)
-        else:
-            sysds[i % len(sysds)].trace_into(x0, k0, ob, e0d, uniform=uni)
-        if do_stats or do_step_gather:
-            ev = traced[b]
-            ev.record(main_stream)
-            gather_now = do_step_gather and with_gather
-            if (gather_now and not inplace) or (do_stats and not fused_stats):
-                (xi, ki, vi) = image_rows(ob)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ev)
-                if direct and gather_now:
-                    gathers[b].start_in_place()      # peer writes; the all-reduce below is their fence
-                if fused_stats:
-                    stats[b].reduce()
-                elif do_stats:
-                    stats[b].start(xi, sysd.views(ob).valid_out[-1])
-                if gather_now and not direct:
-                    if inplace:
-                        gathers[b].start_in_place()
-                    else:
-                        gathers[b].start(xi, ki, vi)
-                    gathers[b].wait()
-                done = side_events[b]
-                done.record(comm_stream)
-                side_done[b] = done
-
-    def final_gather(last_step):
-        """the one-off image-plane all-gather of the last traced bundle (49 B/ray)"""
-        (xi, ki, vi) = image_rows(bufs[(last_step % nbuf) % n_out_bufs])
-        ev = torch.cuda.Event()
-        ev.record(main_stream)
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(ev)
-            gathers[0].start(xi, ki, vi)
-            gathers[0].wait()
-        comm_stream.synchronize()
-
-    def finish():
-        """every step's work (trace + per-step exchange) has completed"""
-        comm_stream.synchronize()
-        torch.cuda.synchronize()
-
-    issue_s = [0.0]
-
-    def timed_region(n_steps, **kw):
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n_steps):
-            step(i, **kw)
-        issue_s[0] = time.perf_counter() - t0          # the host is done issuing; the device may still be busy
-        finish()
-        dist.barrier()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        t = torch.tensor([dt], dtype=torch.float64, device=(dev if args.backend == "nccl" else "cpu"))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    watchdog.stage = "warm-up"
-    for _ in range(PREWARM_LAUNCHES):
-        sysd.trace_into(x0, k0, bufs[0], e0d, uniform=uni)
-    torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(i)
-    finish()
-    if do_final_gather and args.warmup > 0:
-        final_gather(args.warmup - 1)          # warms the all-gather path too
-    if os.environ.get("PRT_BENCH_HOST_PROFILE"):       # where the host's time per step goes (stderr)
-        import cProfile, pstats
-        prof = cProfile.Profile()
-        prof.enable()
-        for i in range(200):
-            step(i)
-        prof.disable()
-        finish()
-        pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
-    watchdog.stage = "timed region"
-    elapsed = timed_region(args.steps)
-    host_issue_ms = issue_s[0] / args.steps * 1e3
-    # the same steps without the image-plane all-gather, measured right after (reported beside)
-    watchdog.stage = "timed region without gather"
-    elapsed_without_gather = timed_region(args.steps, with_gather=False) if do_step_gather else None
-    # the final image-plane gather of --exchange final-gather is not one of the K steps: timed on its own
-    final_gather_ms = None
-    if do_final_gather:
-        dist.barrier()
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        final_gather(args.steps - 1)
-        dist.barrier()
-        final_gather_ms = (time.perf_counter() - tg) * 1e3
-    spot = None
-    if do_stats:
-        (cnt, cen, rms) = stats[(args.steps - 1) % nbuf].result()
-        spot = {"rays": float(cnt), "centroid_mm": [float(c) for c in cen], "rms_spot_mm": rms}
-    watchdog.stage = "kernel timing"
-    kernel_ms = sysd.trace_timed(x0, k0, bufs[0], max(args.steps, 5), e0d, uniform=uni)
-    torch.cuda.synchronize()
-    # every rank checks what that launch wrote for its shard (all rays on their surfaces, |k| = n); rank 0 reports
-    # its own figures and whether ALL ranks passed
-    watchdog.stage = "verification"
-    verified = verify_outputs(dict(wl, records=wl["record_sets"][0]), sysd, bufs[0], with_oracle=(rank == 0 and not args.no_cpu_baseline))
-    flag = torch.tensor([1.0 if verified["ok"] else 0.0], dtype=torch.float64, device=(dev if args.backend == "nccl" else "cpu"))
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    verified["all_ranks_ok"] = bool(flag.item() > 0.5)
-    ops_total = n_total * S * args.steps
-    if rank != 0:
-        return None
-    alg = algorithmic_bytes(wl, sysd, args.mode, record_bytes)
-    achieved = alg / (kernel_ms * 1e-3) / 1e9
-    fkey = ("%s_%d_uniform" if uni is not None else "%s_%d") % (args.mode, n_local)
-    tent = _lookup("hbm_traffic.json", fkey)
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": tent["bytes_per_launch"] if tent else None,
-                "traffic_source": ("profiles/hbm_traffic.json[%s]: looked up, NOT measured in this run" % fkey)
-                if tent else None,
-                "kernel": "k_trace_iso", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg,
-                "bytes_per_ray_surface_op": alg / (n_local * S),
-                "note": "per rank (rank 0's march); every rank runs the same launch on its shard"}
-    kinds_out = bufs[0]["placement"].get("kinds")
-    # what DESIGN.md section 6 expects for this run (so that a measured curve can be read against it): the trace of
-    # one shard takes what the 1-GPU march takes at this size (kernel_ms); the per-step all-gather moves
-    # 49 B x n_pad to each of the N-1 peers over one xGMI link each (point-to-point, ~153 GB/s per link and
-    # direction, 0.65-0.8 of it reached) and overlaps the next trace -> a step costs max(trace, gather)
-    n_pad = pdist.shard_stride(n_total, n_gpus, align)
-    gather_ms = [49.0 * n_pad / (f * 153e9) * 1e3 for f in (0.8, 0.65)] if n_gpus > 1 else [0.0, 0.0]
-    expected = {"trace_ms_per_step": kernel_ms,
-                "gather_ms_per_step_at_0.8_and_0.65_of_the_link_rate": gather_ms,
-                "ms_per_step_with_gather": [max(kernel_ms, g) for g in gather_ms],
-                "value_with_gather": [n_total * S / (max(kernel_ms, g) * 1e-3) for g in gather_ms],
-                "value_without_gather": n_total * S / (kernel_ms * 1e-3),
-                "basis": "DESIGN.md section 6: step = max(this rank's march, image-plane all-gather of 49 B x %d rays "
-                         "per peer over one xGMI link each at 0.65-0.8 x 153 GB/s); %s" % (n_pad, (
-                             "strong scaling: the march shrinks with N, the gather per peer too (49 B x N_total / N), "
-                             "but every rank still RECEIVES 49 B x N_total (N - 1) / N" if strong else
-                             "weak scaling, so without the gather the value grows with N"))}
-    return dict({"metric": "ray_surface_ops_per_s", "value": ops_total / elapsed, "unit": "ray-surface-ops/s",
-                 "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-                 "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-                 "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"},
-                config={"workload": wl["workload"] + (
-                            " -- ONE bundle of %d rays split over %d GPU(s) (strong scaling; the N = 1 line of the default "
-                            "`python bench.py` is BASELINE configs[1] at 1e7 rays and carries this bundle's 1-GPU rate "
-                            "as `scaling_point`)" % (n_total, n_gpus) if strong else
-                            " -- %d rays per GPU (weak scaling)" % n_local),
-                        "rays_per_gpu": n_local, "rays_total": n_total, "surfaces": S,
-                        "rays_per_surface": None, "mode": args.mode,
-                        "first_segment": "uniform k0 / E0" if uni is not None else "arrays x0, k0, E0",
-                        "record_bytes": record_bytes,
-                        "masks": ("valid | valid_out << 1 in one byte" if packed else "two byte arrays"),
-                        "sharding": "rays", "wavelengths": len(sysds), "prewarm_launches": PREWARM_LAUNCHES,
-                        "output_placement": {"policy": bufs[0]["placement"]["policy"], "note": placement_note,
-                                             "memory_kinds_of_x_hit_and_k_out": kinds_out,
-                                             "memory_kind_of_inputs": input_kind,
-                                             "inputs": "arena" if input_kind is not None else "torch allocator",
-                                             "arena": arena_obj.stats() if arena_obj is not None else None},
-                        "image_plane_exchange": {
-                            "per_step": {"gather": "spot moments from the trace kernel + one 7-double all-reduce, then "
-                                                   "image-plane all-gather 49 B/ray (7 row collectives straight into "
-                                                   "the [row][global ray] layout%s), side stream, overlaps the next trace"
-                                                   % (", IN PLACE: the march wrote the shard's rows into its slot of the "
-                                                      "receive buffer" if inplace else ""),
-                                         "gather-direct": "spot moments from the trace kernel; the march writes the "
-                                                          "shard's image plane into its slot of the rank's receive "
-                                                          "buffer, then one device-to-device copy per row and peer into "
-                                                          "the peers' IPC-mapped receive buffers (49 B/ray to each of the "
-                                                          "N-1 peers, one stream per peer), closed by the 7-double "
-                                                          "all-reduce; side stream, overlaps the next trace",
-                                         "stats": "spot moments from the trace kernel + one 7-double all-reduce (side stream)",
-                                         "final-gather": "spot moments + one 7-double all-reduce (side stream)",
-                                         "none": "none"}[exchange]
-                                        + ("" if fused_stats or not do_stats else " [two-pass statistics]"),
-                            "final": ("image-plane all-gather 49 B/ray, once after the K timed steps"
-                                      if do_final_gather else "none"),
-                            "final_gather_ms": final_gather_ms,
-                            "ms_per_step_without_gather": (elapsed_without_gather / args.steps * 1e3
-                                                           if elapsed_without_gather else None),
-                            "value_without_gather": (ops_total / elapsed_without_gather
-                                                     if elapsed_without_gather else None),
-                            "backend": "rccl" if args.backend == "nccl" else "gloo dry run (host staged)",
-                            "row_batching": pdist.gather_batch_mode()},
-                        "expected": expected,
-                        "host_issue_ms_per_step": host_issue_ms, "trace_stream": args.trace_stream,
-                        "image_plane_spot": spot,
-                        "build": prt_build.build_info(_lib.LIB_PATH)},
-                roofline=roofline, cpu_baseline=None, verified=verified)
 
 
 if __name__ == "__main__":

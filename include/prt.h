@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 6
+#define PRT_ABI_VERSION 7
 #define PRT_COMPACT_MAX_ROWS 24 /* rows prt_compact moves per call */
 #define PRT_MAX_COEFFS 128 /* asphere A2.. coefficients and / or XY-polynomial terms */
 
@@ -389,6 +389,31 @@ int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const 
                      double *e_out_re, double *e_out_im, uint8_t *valid_out, void *stream);
 
 /*
+ * prt_propagate / prt_interact for BIG isotropic bundles: every array has a ROW PITCH (elements between the starts of
+ * two component rows; 0 = n, tight), so that rows can start on 128-B lines (prt_recommended_pitch) -- a thread owns two
+ * adjacent rays and moves them with one 16-B access per row when all pointers are 16-B aligned and all pitches even
+ * (any other layout is taken too, 8 B at a time).  Same reference interface as above (Material.propagate ->
+ * Surface.intersect, raytracer/material/material_isotropic.py:238-247, raytracer/surface.py:116-135;
+ * IsotropicMaterial.refract / reflect, material_isotropic.py:163-236), same results to rounding, same masks.
+ *   prt_propagate_rows: x (3, n | x_pitch); k, dir, e_re, e_im (3, n | k_pitch), selected as in prt_propagate; with
+ *     dir == NULL, e_re == NULL and use_default_e == 0 the ray direction is k itself (parallel to the Poynting vector
+ *     behind an isotropic interface, ray.py:136-152; the intersection is homogeneous in the direction).
+ *     Writes x_hit (3, n | out_pitch), valid (n), nonconv (n) or NULL.
+ *   prt_interact_rows: records with an ISOTROPIC, lossless medium behind the surface only (PRT_ERR_UNSUPPORTED
+ *     otherwise: crystals double the rays, prt_interact).  x_hit (3, n | x_pitch), k (3, n | k_pitch), valid_in (n) or
+ *     NULL -> k_out (3, n | out_pitch), valid_out (n) or NULL, dir_out (3, n | out_pitch) or NULL (unit k; nobody
+ *     needs it between two of these calls).
+ * 148 B of HBM traffic per ray and surface for the pair (each call reads the 49-B state it works on and writes 25 B).
+ */
+int32_t prt_propagate_rows(const prt_system_t *sys, int32_t surface, int64_t n, const double *x, int64_t x_pitch,
+                           const double *k, int64_t k_pitch, const double *dir, const double *e_re,
+                           const double *e_im, int32_t use_default_e, const uint8_t *valid_in, double *x_hit,
+                           int64_t out_pitch, uint8_t *valid, uint8_t *nonconv, void *stream);
+int32_t prt_interact_rows(const prt_system_t *sys, int32_t surface, int64_t n, const double *x_hit, int64_t x_pitch,
+                          const double *k, int64_t k_pitch, const uint8_t *valid_in, double *k_out,
+                          int64_t out_pitch, double *dir_out, uint8_t *valid_out, void *stream);
+
+/*
  * The same plugin call with COMPLEX wave vectors (absorbing media: a complex epsilon tensor,
  * material_anisotropic.py:52-56, 70-113; a complex refractive index, material_isotropic.py:137-199; and whatever
  * comes behind them): k = k_re + i k_im in (k_im NULL: real), k_out_re / k_out_im out, both required.
@@ -589,11 +614,18 @@ int32_t prt_trace_timed(const prt_system_t *sys, int64_t n0, int64_t in_pitch, c
  *   prt_arena_kind_of kind index of a pointer inside one of the arena's buffers.
  *   prt_arena_stats   out[0..12): kinds seen, probes run, slabs created, slabs released, free slabs,
  *                     slabs in use, slabs cached, slab size in bytes, slabs per kind (4 entries);
- *                     rates[0..4): last same-kind probe rate, last cross-kind probe rate (GB/s),
- *                     total probe time (ms), bytes of address space reserved so far.
+ *                     rates[0..8): last same-kind probe rate, last cross-kind probe rate (GB/s),
+ *                     total probe time (ms), bytes of address space handed out so far, base of the first address
+ *                     window, number of windows, 1 if every window landed at its hinted address, window size.
  * Address space: the arena maps every virtual address at most once and never returns a range to the
  * runtime -- with ROCm 7.0 / 7.2 a range that is unmapped and mapped again keeps translating to the old
  * physical pages (csrc/prt_placed.h).  Only address space leaks (1 GiB per slab tested), not memory.
+ * All of its addresses come from windows it reserves for itself at 0x2000'0000'0000 + 8 TiB x device (ABI v7; 1 TiB
+ * each, PRT_ARENA_VA_WINDOW_GIB / PRT_ARENA_VA_BASE): tens of TiB away from the heap and from the mmap area, so an
+ * arena mapping can never land on addresses the host allocator has just given back -- e.g. the destination of a
+ * pageable device-to-host copy, which the runtime keeps registered with the GPU driver for a while
+ * (benchmarks/va_reuse_probe.hip; until ABI v6 half of the reservations behind such a copy covered its range).
+ * A prt_arena_alloc that maps memory synchronises the whole device: never call it during stream capture.
  * Thread-safe (one lock per arena).
  */
 #define PRT_ARENA_MAX_KINDS 4

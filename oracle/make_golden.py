@@ -86,9 +86,10 @@ def dump_case(name, s, seq, bundle, splitup=False):
     ``<name>_tight``: the same system and bundle with ``annotations["tol"] = 1e-14`` on every explicit shape
     (surface_shape.py:396, 457-458: the xtol handed to fsolve, 1e-6 by default), i.e. with the reference itself
     converged -- compared with a flat 1e-10 and no allowance (tests: test_*_explicit_tight)"""
-    _dump_case(name, s, seq, bundle, splitup)
     import _golden
-    if name in _golden.EXPLICIT_CASES:
+    if name not in _golden.EXPLICIT_TIGHT_ONLY:
+        _dump_case(name, s, seq, bundle, splitup)
+    if name in _golden.EXPLICIT_CASES + _golden.EXPLICIT_TIGHT_ONLY:
         shapes = [sf.shape for sf in _sequence_surfaces(s, seq) if "tol" in sf.shape.annotations]
         saved = [sh.annotations["tol"] for sh in shapes]
         for sh in shapes:
@@ -209,6 +210,11 @@ def case_asphere():
         (s, seq) = build_simple_optical_system(systems.asphere_builduplist(coeffs, curv, cc))
         dump_case("asphere_%s_axis" % tag, s, seq, disk_bundle(160, 11.43, -5.0))
         dump_case("asphere_%s_field5" % tag, s, seq, disk_bundle(160, 9.0, -5.0, field_deg=5.0))
+    # grazing incidence (round 6): angles of incidence up to 84.4 degrees on a near-hemisphere
+    g = zoo.GRAZING_DOME
+    (s, seq) = build_simple_optical_system(zoo.grazing_dome_builduplist())
+    dump_case("asphere_grazing_field30", s, seq, disk_bundle(160, g["rpup"], g["z0"], field_deg=g["tilt_deg"],
+                                                             yshift=zoo.grazing_dome_bundle_centre()))
 
 
 def case_xypoly():

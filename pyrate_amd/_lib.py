@@ -30,7 +30,7 @@ c_double_p = ctypes.c_void_p      # device pointers travel as raw addresses
 c_u8_p = ctypes.c_void_p
 c_stream = ctypes.c_void_p
 
-ABI_VERSION = 6          # PRT_ABI_VERSION of include/prt.h
+ABI_VERSION = 7          # PRT_ABI_VERSION of include/prt.h
 
 # name -> (restype, argtypes); must list every symbol declared in include/prt.h
 PROTOTYPES = {
@@ -66,6 +66,12 @@ PROTOTYPES = {
     "prt_interact": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64,
                                       c_double_p, c_double_p, c_u8_p, c_double_p, c_double_p,
                                       c_double_p, c_double_p, c_u8_p, c_stream]),
+    "prt_propagate_rows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, c_double_p, ctypes.c_int64,
+                                            c_double_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p, ctypes.c_int32,
+                                            c_u8_p, c_double_p, ctypes.c_int64, c_u8_p, c_u8_p, c_stream]),
+    "prt_interact_rows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, c_double_p, ctypes.c_int64,
+                                           c_double_p, ctypes.c_int64, c_u8_p, c_double_p, ctypes.c_int64, c_double_p,
+                                           c_u8_p, c_stream]),
     "prt_interact_cplx": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, c_double_p, c_double_p,
                                            c_double_p, c_u8_p, c_double_p, c_double_p, c_double_p, c_double_p,
                                            c_double_p, c_u8_p, c_stream]),

@@ -12,6 +12,8 @@
 #include <new>
 #include <mutex>
 #include <vector>
+#include <algorithm>
+#include <initializer_list>
 #include "prt_kernels.h"
 
 
@@ -676,15 +678,23 @@ int32_t prt_system_update(prt_system_t *sys, const prt_surface_t *table, int32_t
     if (b_im) memcpy(h + b_recs + b_side + b_hot + b_walk, im.eps_im.data(), b_im);
     // From the first enqueue on there is no way back: a failure leaves the device with pieces of two tables.  The
     // system is then POISONED (every later call on it fails with PRT_ERR_DEVICE; the caller destroys it).
-    hipError_t ce = hipMemcpyAsync(sys->d_table, h, b_recs, hipMemcpyHostToDevice, st);
-    if (ce == hipSuccess && b_side) ce = hipMemcpyAsync(sys->d_side, h + b_recs, b_side, hipMemcpyHostToDevice, st);
-    if (ce == hipSuccess && b_hot) ce = hipMemcpyAsync(sys->d_hot, h + b_recs + b_side, b_hot, hipMemcpyHostToDevice, st);
-    if (ce == hipSuccess && b_walk)
-        ce = hipMemcpyAsync(sys->d_walk, h + b_recs + b_side + b_hot, b_walk, hipMemcpyHostToDevice, st);
-    if (ce == hipSuccess && b_im)
-        ce = hipMemcpyAsync(sys->d_eps_im, h + b_recs + b_side + b_hot + b_walk, b_im, hipMemcpyHostToDevice, st);
-    if (ce == hipSuccess) ce = hipEventRecord(sys->stage_ev[slot], st);
-    if (ce != hipSuccess || getenv("PRT_TEST_FAIL_UPDATE")) {
+    // (test hook, only in processes started with PRT_TEST_HOOKS in the environment -- read once --: PRT_TEST_FAIL_UPDATE=k
+    //  makes the k-th enqueue of this call fail INSTEAD of being issued, so that the ones before it are on the stream
+    //  and the ones behind it are not: the partial update the poisoning exists for)
+    static const bool test_hooks = getenv("PRT_TEST_HOOKS") != nullptr;
+    int fail_at = 0, step_no = 0;
+    if (test_hooks)
+        if (const char *v = getenv("PRT_TEST_FAIL_UPDATE")) fail_at = std::max(1, atoi(v));
+    auto enqueue = [&](void *dst, const void *src, size_t bytes) {
+        return (++step_no == fail_at) ? hipErrorUnknown : hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    };
+    hipError_t ce = enqueue(sys->d_table, h, b_recs);
+    if (ce == hipSuccess && b_side) ce = enqueue(sys->d_side, h + b_recs, b_side);
+    if (ce == hipSuccess && b_hot) ce = enqueue(sys->d_hot, h + b_recs + b_side, b_hot);
+    if (ce == hipSuccess && b_walk) ce = enqueue(sys->d_walk, h + b_recs + b_side + b_hot, b_walk);
+    if (ce == hipSuccess && b_im) ce = enqueue(sys->d_eps_im, h + b_recs + b_side + b_hot + b_walk, b_im);
+    if (ce == hipSuccess) ce = (++step_no == fail_at) ? hipErrorUnknown : hipEventRecord(sys->stage_ev[slot], st);
+    if (ce != hipSuccess) {
         sys->poisoned = 1;
         sys->stage_used &= ~(1u << slot);
         return fail(PRT_ERR_DEVICE, "prt_system_update: a copy of the new table failed after others were enqueued; the "
@@ -1423,6 +1433,97 @@ int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const 
                            (hipStream_t)stream, sys->d_table + surface, n, x_hit, k, valid_in,
                            k_out, dir_out, valid_out);
     }
+    HIP_TRY(hipGetLastError());
+    return PRT_OK;
+}
+
+// every pointer 16-B aligned and every pitch even: one dwordx4 access moves the two rays a thread owns
+static bool rows_vectorisable(std::initializer_list<const void *> ptrs, std::initializer_list<int64_t> pitches) {
+    for (const void *p : ptrs)
+        if (p && (reinterpret_cast<uintptr_t>(p) & 15u)) return false;
+    for (int64_t q : pitches)
+        if (q & 1) return false;
+    return true;
+}
+
+// EXPERIMENT (round 6): the direction a per-surface kernel walks the bundle in.  PRT_ROWS_PINGPONG=1: interact walks
+// it backwards, propagate forwards -- each kernel then starts with the rays its predecessor touched LAST, whose lines
+// may still sit in the memory-side cache (256 MB; a kernel moves 740 MB).
+static int32_t rows_direction(int which) {
+    static const int mode = getenv("PRT_ROWS_PINGPONG") ? atoi(getenv("PRT_ROWS_PINGPONG")) : 0;
+    return (mode == 1 && which == 1) || (mode == 2 && which == 0) ? 1 : 0;
+}
+
+static int rows_shape_level(int32_t shape_type) {
+    if (shape_type == PRT_SHAPE_CONIC) return PRT_SHAPES_CONIC;
+    if (shape_type == PRT_SHAPE_ASPHERE) return PRT_SHAPES_ASPHERE;
+    if (shape_type == PRT_SHAPE_XYPOLY || shape_type == PRT_SHAPE_BICONIC) return PRT_SHAPES_POLY;
+    return PRT_SHAPES_ALL;
+}
+
+int32_t prt_propagate_rows(const prt_system_t *sys, int32_t surface, int64_t n, const double *x, int64_t x_pitch,
+                           const double *k, int64_t k_pitch, const double *dir, const double *e_re, const double *e_im,
+                           int32_t use_default_e, const uint8_t *valid_in, double *x_hit, int64_t out_pitch,
+                           uint8_t *valid, uint8_t *nonconv, void *stream) {
+    PRT_SYS_USABLE(sys);
+    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0)
+        return fail(PRT_ERR_INVALID_ARG, "prt_propagate_rows: bad system / surface / count");
+    if (n == 0) return PRT_OK;
+    if (!x || (!k && !dir) || !x_hit || !valid) return fail(PRT_ERR_INVALID_ARG, "prt_propagate_rows: null pointer");
+    if (!x_pitch) x_pitch = n;
+    if (!k_pitch) k_pitch = n;
+    if (!out_pitch) out_pitch = n;
+    if (x_pitch < n || k_pitch < n || out_pitch < n)
+        return fail(PRT_ERR_INVALID_ARG, "prt_propagate_rows: a row pitch shorter than the bundle");
+    PRT_ON_DEVICE(sys->device);
+    const bool vec = rows_vectorisable({x, k, dir, e_re, e_im, x_hit}, {x_pitch, k_pitch, out_pitch}) &&
+                     !((reinterpret_cast<uintptr_t>(valid_in) | reinterpret_cast<uintptr_t>(valid) |
+                        reinterpret_cast<uintptr_t>(nonconv)) & 1u);
+    const dim3 grid(nblocks((n + 1) / 2, PRT_MARCH_BLOCK)), block(PRT_MARCH_BLOCK);
+    const int e_mode = e_mode_of(e_re, use_default_e);
+#define PRT_LAUNCH_PROPAGATE_ROWS(VEC_, SH_)                                                                          \
+    hipLaunchKernelGGL((k_propagate_rows<VEC_, SH_>), grid, block, 0, (hipStream_t)stream, sys->d_table + surface, n, x, \
+                       x_pitch, k, k_pitch, dir, e_re, e_im, e_mode, valid_in, x_hit, out_pitch, valid, nonconv,           \
+                       rows_direction(0))
+    // (the instantiation with this surface's shape code alone: a conic needs 60-odd registers, the general case 128)
+    const int level = rows_shape_level(sys->h_table[surface].shape_type);
+    if (!vec) PRT_LAUNCH_PROPAGATE_ROWS(false, PRT_SHAPES_ALL);
+    else if (level == PRT_SHAPES_CONIC) PRT_LAUNCH_PROPAGATE_ROWS(true, PRT_SHAPES_CONIC);
+    else if (level == PRT_SHAPES_ASPHERE) PRT_LAUNCH_PROPAGATE_ROWS(true, PRT_SHAPES_ASPHERE);
+    else if (level == PRT_SHAPES_POLY) PRT_LAUNCH_PROPAGATE_ROWS(true, PRT_SHAPES_POLY);
+    else PRT_LAUNCH_PROPAGATE_ROWS(true, PRT_SHAPES_ALL);
+#undef PRT_LAUNCH_PROPAGATE_ROWS
+    HIP_TRY(hipGetLastError());
+    return PRT_OK;
+}
+
+int32_t prt_interact_rows(const prt_system_t *sys, int32_t surface, int64_t n, const double *x_hit, int64_t x_pitch,
+                          const double *k, int64_t k_pitch, const uint8_t *valid_in, double *k_out, int64_t out_pitch,
+                          double *dir_out, uint8_t *valid_out, void *stream) {
+    PRT_SYS_USABLE(sys);
+    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0)
+        return fail(PRT_ERR_INVALID_ARG, "prt_interact_rows: bad system / surface / count");
+    if (n == 0) return PRT_OK;
+    if (!x_hit || !k || !k_out) return fail(PRT_ERR_INVALID_ARG, "prt_interact_rows: null pointer");
+    if (sys->complex_eps || sys->h_table[surface].mat_type == PRT_MAT_ANISOTROPIC)
+        return fail(PRT_ERR_UNSUPPORTED, "prt_interact_rows: isotropic, lossless media only (crystals double the rays: "
+                                         "prt_interact; absorbing media: prt_interact_cplx)");
+    if (!x_pitch) x_pitch = n;
+    if (!k_pitch) k_pitch = n;
+    if (!out_pitch) out_pitch = n;
+    if (x_pitch < n || k_pitch < n || out_pitch < n)
+        return fail(PRT_ERR_INVALID_ARG, "prt_interact_rows: a row pitch shorter than the bundle");
+    PRT_ON_DEVICE(sys->device);
+    const bool vec = rows_vectorisable({x_hit, k, k_out, dir_out}, {x_pitch, k_pitch, out_pitch}) &&
+                     !((reinterpret_cast<uintptr_t>(valid_in) | reinterpret_cast<uintptr_t>(valid_out)) & 1u);
+    const dim3 grid(nblocks((n + 1) / 2, PRT_MARCH_BLOCK)), block(PRT_MARCH_BLOCK);
+#define PRT_LAUNCH_INTERACT_ROWS(VEC_, SH_)                                                                            \
+    hipLaunchKernelGGL((k_interact_iso_rows<VEC_, SH_>), grid, block, 0, (hipStream_t)stream, sys->d_table + surface, n, \
+                       x_hit, x_pitch, k, k_pitch, valid_in, k_out, out_pitch, dir_out, valid_out, rows_direction(1))
+    if (!vec) PRT_LAUNCH_INTERACT_ROWS(false, PRT_SHAPES_ALL);
+    else if (sys->h_table[surface].shape_type == PRT_SHAPE_CONIC) PRT_LAUNCH_INTERACT_ROWS(true, PRT_SHAPES_CONIC);
+    else PRT_LAUNCH_INTERACT_ROWS(true, PRT_SHAPES_ALL);
+#undef PRT_LAUNCH_INTERACT_ROWS
     HIP_TRY(hipGetLastError());
     return PRT_OK;
 }

@@ -555,7 +555,9 @@ PRT_DEV void explicit_prefetch(const prt_dev_surface *__restrict__ sf, explicit_
 // K = g''/2g', about half the curvature along the ray.  Until round 4 a lane was done when a step came out <= 1e-15
 // (relative to max(1, |t|)) -- the evaluation that produced that step only OBSERVED that the step before it had
 // already arrived: a quarter of the work of the four evaluations a ray of BASELINE configs[2] takes (steps 1,
-// 1e-3, 1e-9, 1e-17 of |t|).  Now a lane is done behind the first step <= 1e-8: what is left, K (1e-8 |t|)^2, is
+// 1e-3, 1e-9, 1e-17 of |t|).  Now a lane is done behind the first step <= 1e-8 that is also <= 1e-3 of the step
+// before it (the signature of quadratic convergence; grazing incidence up to 84 degrees still shows it:
+// tests/golden/asphere_grazing_field30_tight.npz): what is left, K (1e-8 |t|)^2, is
 // below the rounding of t for K |t| <= 1 (a ray that flies a hundred curvature radii to its surface is the limit;
 // beyond it the error grows like K |t| 1e-16 -- still five digits inside the parity bar).  The FIRST evaluation
 // never ends the iteration that way (a start point that happens to lie 1e-9 off the surface gets its second one).
@@ -595,6 +597,7 @@ PRT_DEV double explicit_t(const prt_dev_surface *__restrict__ sf, const vec3 &r0
         // (first evaluation: nothing in front of it -- fx_prev := Fx makes the correction vanish; a lane that is done
         //  keeps t, gx, gy -- a ray's result must not depend on its neighbours in the wave --, the rest is scratch)
         const double ratio = dt * __builtin_amdgcn_rcp(dt_prev);
+        const bool contracted = it > 0 && fabs(dt) <= 1e-3 * fabs(dt_prev);
         const double gxn = __builtin_fma(Fx - (it > 0 ? fx_prev : Fx), ratio, Fx);
         const double gyn = __builtin_fma(Fy - (it > 0 ? fy_prev : Fy), ratio, Fy);
         const double tn = t - dt;
@@ -607,7 +610,13 @@ PRT_DEV double explicit_t(const prt_dev_surface *__restrict__ sf, const vec3 &r0
             gx = gxn;
             gy = gyn;
             // a NaN step stops the lane too (t is NaN already: the ray is invalid later); an infinite one makes the next NaN
-            done = !(adt > (it > 0 ? 1e-8 : 1e-15) * scale);
+            // The 1e-8 exit is taken only behind a step that CONTRACTED like Newton does at a simple root (|dt| <= 1e-3
+            // |dt_prev|: quadratic convergence that ends at 1e-8 comes from 1e-4 or better).  A lane that creeps towards
+            // a (near-)double root -- steps halving, the remaining error as large as the step itself -- keeps
+            // iterating to the 1e-15 rule or to the cap, where it is reported (round 6).
+            // (two compares against wave-uniform thresholds, combined as lane masks: a per-lane threshold would be two
+            //  more vector registers in a kernel that sits at its 96-register cap)
+            done = !(adt > 1e-8 * scale) && (contracted || !(adt > 1e-15 * scale));
             at_noise_floor = !(adt > 1e-11 * scale);
         }
         if (__all(done)) break;

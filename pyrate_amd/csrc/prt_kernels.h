@@ -245,15 +245,13 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
     // XCD gets ONE contiguous eighth of the bundle, so that its L2 and its translation caches see an eighth of every
     // one of the 84 rows instead of slices all along them: 1e8 rays (rows 0.8 GB apart) 10.35 -> 9.96 ms, nothing
     // lost at 1e7 (round 5, same arrays, builds interleaved: profiles/r05_ab_xcd_swizzle_*.json).  A ray's result does not
-    // depend on where it is computed; -DPRT_NO_XCD_SWIZZLE gives the linear map back (A/B).
-#ifndef PRT_NO_XCD_SWIZZLE
-    const int64_t per_xcd = (int64_t)gridDim.x / 8;
-    const int64_t blk = (int64_t)(blockIdx.x % 8) * per_xcd + (int64_t)(blockIdx.x / 8);
-#else
-    const int64_t blk = blockIdx.x;
-#endif
+    // depend on where it is computed.
     // (the grid is rounded up to a multiple of 8 blocks -- launch_iso_inst --, which makes b -> blk a bijection of
-    //  [0, gridDim.x); the up to seven blocks behind the last ray have nothing to do)
+    //  [0, gridDim.x); the up to seven blocks behind the last ray have nothing to do.  A launch whose grid is NOT a
+    //  multiple of 8 gets the linear map: the swizzle would skip ray blocks and compute others twice -- ADVICE r5)
+    const int64_t per_xcd = (int64_t)gridDim.x / 8;
+    const int64_t blk = (gridDim.x & 7u) ? (int64_t)blockIdx.x
+                                         : (int64_t)(blockIdx.x % 8) * per_xcd + (int64_t)(blockIdx.x / 8);
     if (blk * (2 * PRT_MARCH_BLOCK) >= N) return;
     const int64_t i = (blk * PRT_MARCH_BLOCK + threadIdx.x) * 2;
     if (!MOMENTS && i >= N) return;
@@ -831,6 +829,113 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_interact_iso(
         dir_out[2 * N + i] = d.z;
     }
     if (valid_out) valid_out[i] = valid ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// The same two steps for BIG isotropic bundles (prt_propagate_rows / prt_interact_rows): row-pitched arrays, a thread
+// owns two adjacent rays (16 B per lane and access: one dwordx4 per row like the fused march), non-temporal hints --
+// every array is read once and written once.  Bytes per ray and surface: propagate 49 in (x, k, mask) + 25 out
+// (x_hit, mask), interact 49 in + 25 out (k_out, mask): 148 B, against the 195 B of the tight one-ray-per-thread
+// kernels above when they also write the ray direction.  After an isotropic interaction the ray direction is parallel
+// to k (E is perpendicular to k: ray.py:136-152), and conic_t / explicit_t are homogeneous in d, so the step takes the
+// unnormalised k with d2 = k.k -- what the fused march does (k_trace_iso).
+// ---------------------------------------------------------------------------
+template <bool VEC>
+PRT_DEV void load_mask2(const uint8_t *__restrict__ m, int64_t i, bool second, bool b[2]) {
+    if (!m) {
+        b[0] = b[1] = true;
+    } else if (VEC && second) {
+        const unsigned v = *reinterpret_cast<const uint16_t *>(m + i);
+        b[0] = (v & 0xFFu) != 0;
+        b[1] = (v >> 8) != 0;
+    } else {
+        b[0] = m[i] != 0;
+        b[1] = second ? (m[i + 1] != 0) : b[0];
+    }
+}
+
+template <bool VEC>
+PRT_DEV void store_mask2(uint8_t *__restrict__ m, int64_t i, bool second, const bool b[2]) {
+    if (VEC && second) {         // (the byte behind an odd bundle's last ray is not ours)
+        *reinterpret_cast<uint16_t *>(m + i) = (uint16_t)((b[0] ? 1u : 0u) | (b[1] ? 0x100u : 0u));
+    } else {
+        m[i] = b[0] ? 1 : 0;
+        if (second) m[i + 1] = b[1] ? 1 : 0;
+    }
+}
+
+// SHAPES: the shape code compiled in (the surface's own: conics alone need half the registers of the general case)
+template <bool VEC, int SHAPES>
+__global__ __launch_bounds__(PRT_MARCH_BLOCK) void k_propagate_rows(
+    const prt_dev_surface *__restrict__ sf, int64_t N, const double *__restrict__ x_in, int64_t x_pitch,
+    const double *__restrict__ k_in, int64_t k_pitch, const double *__restrict__ dir_in,
+    const double *__restrict__ e_re, const double *__restrict__ e_im, int32_t e_mode,
+    const uint8_t *__restrict__ valid_in, double *__restrict__ xh_out, int64_t out_pitch,
+    uint8_t *__restrict__ valid_out, uint8_t *__restrict__ nonconv_out, int32_t reverse) {
+    const int64_t blk = reverse ? (int64_t)gridDim.x - 1 - blockIdx.x : (int64_t)blockIdx.x;
+    const int64_t i = (blk * PRT_MARCH_BLOCK + threadIdx.x) * 2;
+    if (i >= N) return;
+    const bool second = (i + 1 < N);
+    vec3 x[2], d[2];
+    double d2[2] = {1.0, 1.0};
+    rayio<VEC>::load(x_in, x_pitch, i, second, x);
+    if (dir_in) {
+        rayio<VEC>::load(dir_in, k_pitch, i, second, d);
+    } else {
+        vec3 k[2];
+        rayio<VEC>::load(k_in, k_pitch, i, second, k);
+        if (e_mode == 0) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                d[r] = k[r];
+                d2[r] = dot(k[r], k[r]);
+            }
+        } else {
+            first_direction<VEC>(e_mode, e_re, e_im, k_pitch, i, second, k, d);
+        }
+    }
+    bool valid[2], ncv[2];
+    load_mask2<VEC>(valid_in, i, second, valid);
+    PRT_WAIT_VMEM_LOADS();
+    vec3 xh[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        vec3 p, g;
+        double g2;
+        propagate_step<SHAPES>(sf, x[r], d[r], d2[r], xh[r], p, g, g2, valid[r], ncv[r]);
+    }
+    rayio<VEC>::store(xh_out, out_pitch, i, second, xh);
+    store_mask2<VEC>(valid_out, i, second, valid);
+    if (nonconv_out) store_mask2<VEC>(nonconv_out, i, second, ncv);
+}
+
+template <bool VEC, int SHAPES>
+__global__ __launch_bounds__(PRT_MARCH_BLOCK) void k_interact_iso_rows(
+    const prt_dev_surface *__restrict__ sf, int64_t N, const double *__restrict__ xh_in, int64_t x_pitch,
+    const double *__restrict__ k_in, int64_t k_pitch, const uint8_t *__restrict__ valid_in,
+    double *__restrict__ k_out, int64_t out_pitch, double *__restrict__ dir_out,
+    uint8_t *__restrict__ valid_out, int32_t reverse) {
+    const int64_t blk = reverse ? (int64_t)gridDim.x - 1 - blockIdx.x : (int64_t)blockIdx.x;
+    const int64_t i = (blk * PRT_MARCH_BLOCK + threadIdx.x) * 2;
+    if (i >= N) return;
+    const bool second = (i + 1 < N);
+    vec3 xh[2], k[2];
+    bool valid[2];
+    rayio<VEC>::load(xh_in, x_pitch, i, second, xh);
+    rayio<VEC>::load(k_in, k_pitch, i, second, k);
+    load_mask2<VEC>(valid_in, i, second, valid);
+    PRT_WAIT_VMEM_LOADS();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const vec3 p = to_shape_frame(sf, xh[r]);
+        interact_isotropic(sf, normal_in_material_frame<SHAPES>(sf, p), k[r], valid[r]);
+    }
+    rayio<VEC>::store(k_out, out_pitch, i, second, k);
+    if (dir_out) {
+        vec3 d[2] = {normalized(k[0]), normalized(k[1])};
+        rayio<VEC>::store(dir_out, out_pitch, i, second, d);
+    }
+    if (valid_out) store_mask2<VEC>(valid_out, i, second, valid);
 }
 
 __global__ __launch_bounds__(PRT_BLOCK) void k_interact_aniso(

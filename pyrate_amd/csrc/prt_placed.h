@@ -15,7 +15,7 @@
 // slabs of ONE kind, mapped to contiguous virtual addresses (hipMemMap); the buffers of one request
 // get different kinds.  Slabs and mapped buffers are cached for reuse.
 //
-// One rule shapes the code: A VIRTUAL ADDRESS IS MAPPED ONCE AND NEVER AGAIN.  With this ROCm stack
+// Two rules shape the code.  First: A VIRTUAL ADDRESS IS MAPPED ONCE AND NEVER AGAIN.  With this ROCm stack
 // (7.0 / 7.2) a range that is unmapped (hipMemUnmap) and then mapped to other physical memory keeps
 // translating to the OLD pages: data written through addresses of their own never showed up through
 // the remapped range, and probe stores issued through a re-used range landed in a live path array
@@ -24,6 +24,22 @@
 // are not handed back to the runtime (hipMemAddressFree would allow the next reservation to return the
 // same addresses).  Address space is the only thing that leaks: 1 GiB of it per slab tested, out of
 // the 128 TiB a process has.
+//
+// Second (round 6): THE ARENA'S ADDRESSES COME FROM A WINDOW OF ITS OWN, FAR AWAY FROM THE HOST ALLOCATOR.  Until round 5
+// every mapping reserved its range with hipMemAddressReserve(addr = 0), i.e. wherever the kernel's mmap puts the next
+// anonymous mapping -- which is where the host allocator has just given memory back: benchmarks/va_reuse_probe.hip
+// (profiles/r06a_va_reuse_probe.txt): after a PAGEABLE device-to-host copy into a malloc'ed array and free(), 6 of 12
+// reservations COVERED the freed range.  The runtime pins the pages of a big pageable destination in place for the DMA
+// (a user-pointer registration with the GPU driver) and tears that registration down lazily, so a device mapping made
+// at those addresses a moment later shares them with a dying host registration -- the one construction under which
+// "memory that was mapped a microsecond ago" can lose its translation, and it is exactly what the intermittent
+// first-process fault of round 4 had in front of it (a 96-MB `.cpu().numpy()` of an arena-backed array, freed, then the
+// next configuration's arena allocation + launch: DESIGN.md section 5).  Now the arena reserves ONE window of address
+// space per TiB it uses, at a hinted address (0x2000'0000'0000 + 8 TiB x device: 32 TiB up, tens of TiB away from the
+// heap below and from the mmap area near 0x7f00'0000'0000 above; the runtime honours the hint, probe H) and carves
+// every range out of it, front to back, never twice.  Whatever a caller copies to pageable memory and frees, a host
+// address and an arena address cannot coincide.  PRT_ARENA_VA_WINDOW_GIB (default 1024) / PRT_ARENA_VA_BASE (hex) /
+// PRT_ARENA_VA_WINDOW=off (the round-5 form, for experiments).
 #pragma once
 #include <mutex>
 #include <vector>
@@ -71,7 +87,16 @@ struct prt_arena {
     void *rep_va[PRT_ARENA_MAX_KINDS] = {nullptr, nullptr, nullptr, nullptr};
     int32_t last_kind = 0;         // kind of the previous slab: slabs come in long runs of one kind
     double self_rate = 0.0;        // yardstick of the current hunt: a slab against itself, GB/s
-    int64_t va_reserved = 0;       // bytes of address space taken so far (never returned, see above)
+    int64_t va_reserved = 0;       // bytes of address space handed out so far (never returned, see above)
+    // the window the ranges are carved from (second rule above)
+    bool win_on = true;
+    char *win_base = nullptr;      // current window, slab aligned
+    size_t win_bytes = 0, win_used = 0;
+    size_t win_cfg_bytes = (size_t)1 << 40;
+    uintptr_t win_next_hint = 0;   // where the next window is asked for
+    uintptr_t win_first = 0;       // base of the first window (statistics)
+    int32_t n_windows = 0;
+    bool win_all_hinted = true;    // every window landed where it was asked for
     int64_t slab_budget = -1;      // cap on the slabs held at any time (created - released); < 0: none
     int64_t cache_cap = 64;        // cap on the slabs of cached (unused, still mapped) buffers + free slabs
     // A hunt for kinds is BOUNDED per call: at most hunt_slab_cap slabs beyond what the request needs and hunt_ms_cap
@@ -112,12 +137,58 @@ struct prt_arena {
 // (slab-aligned: the runtime ignores the alignment argument beyond 2 MiB, so a slab more is reserved and
 // the start rounded up -- a 1-GiB slab at a 1-GiB aligned address can be mapped by the largest page
 // table fragments)
-static hipError_t arena_fresh_va(prt_arena *a, void **va, size_t bytes) {
+static hipError_t arena_new_window(prt_arena *a, size_t at_least) {
+    const size_t size = std::max(a->win_cfg_bytes, (at_least + 2 * PRT_SLAB_BYTES - 1) / PRT_SLAB_BYTES * PRT_SLAB_BYTES);
     void *raw = nullptr;
-    hipError_t e = hipMemAddressReserve(&raw, bytes + PRT_SLAB_BYTES, PRT_SLAB_BYTES, nullptr, 0);
-    if (e != hipSuccess) return e;
-    a->va_reserved += (int64_t)(bytes + PRT_SLAB_BYTES);
-    *va = (void *)(((uintptr_t)raw + PRT_SLAB_BYTES - 1) / PRT_SLAB_BYTES * PRT_SLAB_BYTES);
+    hipError_t e = hipErrorOutOfMemory;
+    bool hinted = false;
+    for (int attempt = 0; attempt < 16; ++attempt) {          // (a hint that is taken: the next window-sized step up)
+        void *hint = (void *)a->win_next_hint;
+        raw = nullptr;
+        e = hipMemAddressReserve(&raw, size, PRT_SLAB_BYTES, hint, 0);
+        a->win_next_hint += size;
+        if (e == hipSuccess && raw == hint) {
+            hinted = true;
+            break;
+        }
+        if (e == hipSuccess) (void)hipMemAddressFree(raw, size);      // (nothing was ever mapped there)
+        else (void)hipGetLastError();
+        raw = nullptr;
+    }
+    if (!hinted) {          // no hint was honoured: wherever the runtime likes (the round-5 behaviour), and say so
+        e = hipMemAddressReserve(&raw, size, PRT_SLAB_BYTES, nullptr, 0);
+        if (e != hipSuccess) return e;
+        a->win_all_hinted = false;
+    }
+    char *base = (char *)(((uintptr_t)raw + PRT_SLAB_BYTES - 1) / PRT_SLAB_BYTES * PRT_SLAB_BYTES);
+    a->win_base = base;
+    a->win_bytes = size - (size_t)(base - (char *)raw);
+    a->win_bytes = a->win_bytes / PRT_SLAB_BYTES * PRT_SLAB_BYTES;
+    a->win_used = 0;
+    if (a->n_windows == 0) a->win_first = (uintptr_t)base;
+    a->n_windows += 1;
+    if (a->trace) fprintf(stderr, "prt_arena: address window %d at %p, %zu GiB%s\n", a->n_windows, (void *)base,
+                          a->win_bytes >> 30, hinted ? "" : " (no hint honoured)");
+    return hipSuccess;
+}
+
+static hipError_t arena_fresh_va(prt_arena *a, void **va, size_t bytes) {
+    if (!a->win_on) {          // the round-5 form: one reservation per mapping, wherever mmap puts it
+        void *raw = nullptr;
+        hipError_t e = hipMemAddressReserve(&raw, bytes + PRT_SLAB_BYTES, PRT_SLAB_BYTES, nullptr, 0);
+        if (e != hipSuccess) return e;
+        a->va_reserved += (int64_t)(bytes + PRT_SLAB_BYTES);
+        *va = (void *)(((uintptr_t)raw + PRT_SLAB_BYTES - 1) / PRT_SLAB_BYTES * PRT_SLAB_BYTES);
+        return hipSuccess;
+    }
+    bytes = (bytes + PRT_SLAB_BYTES - 1) / PRT_SLAB_BYTES * PRT_SLAB_BYTES;
+    if (!a->win_base || a->win_used + bytes > a->win_bytes) {
+        hipError_t e = arena_new_window(a, bytes);          // (the rest of the old window is simply left behind)
+        if (e != hipSuccess) return e;
+    }
+    *va = a->win_base + a->win_used;
+    a->win_used += bytes;
+    a->va_reserved += (int64_t)bytes;
     return hipSuccess;
 }
 
@@ -474,6 +545,10 @@ int32_t prt_arena_create(int32_t device, prt_arena_t **out) {
         }
     }
     a->trace = getenv("PRT_ARENA_TRACE") != nullptr;
+    a->win_next_hint = (uintptr_t)0x200000000000ull + (uintptr_t)device * ((uintptr_t)8 << 40);
+    if (const char *v = getenv("PRT_ARENA_VA_BASE")) a->win_next_hint = (uintptr_t)strtoull(v, nullptr, 16) / PRT_SLAB_BYTES * PRT_SLAB_BYTES;
+    if (const char *v = getenv("PRT_ARENA_VA_WINDOW_GIB")) a->win_cfg_bytes = (size_t)std::max(4ll, atoll(v)) << 30;
+    if (const char *v = getenv("PRT_ARENA_VA_WINDOW")) a->win_on = !(strcmp(v, "off") == 0 || strcmp(v, "0") == 0);
     if (const char *v = getenv("PRT_ARENA_HUNT_MS")) a->hunt_ms_cap = atof(v);
     if (const char *v = getenv("PRT_ARENA_HUNT_SLABS")) a->hunt_slab_cap = atoi(v);
     // partition modes of the device, from sysfs (amdgpu: current_compute_partition / current_memory_partition beside
@@ -782,8 +857,10 @@ int32_t prt_arena_stats(prt_arena_t *a, int64_t *out, int32_t n_out, double *rat
     }
     v[7] = (int64_t)(PRT_SLAB_BYTES);
     for (int i = 0; i < n_out && i < 12; ++i) out[i] = v[i];
-    double r[4] = {a->bw_same, a->bw_cross, a->probe_ms_total, (double)a->va_reserved};
-    for (int i = 0; i < n_rates && i < 4; ++i) rates[i] = r[i];
+    // (addresses fit a double exactly: 47 bits)
+    double r[8] = {a->bw_same, a->bw_cross, a->probe_ms_total, (double)a->va_reserved, (double)a->win_first,
+                   (double)a->n_windows, (a->win_on && a->win_all_hinted) ? 1.0 : 0.0, (double)a->win_cfg_bytes};
+    for (int i = 0; i < n_rates && i < 8; ++i) rates[i] = r[i];
     return PRT_OK;
 }
 

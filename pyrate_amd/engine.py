@@ -628,44 +628,111 @@ class DeviceSystem(object):
         return TraceResult.from_buffers(bufs)
 
     # -- per-surface plugin granularity -------------------------------------
+    def _step_arrays(self, n, reads, placement, n_masks=1):
+        """output arrays of one per-surface call on ``n`` rays: a (3, n) float64 array and ``n_masks`` byte rows.
+        Big bundles (``placement`` "auto": from placed.PLACED_INPUT_MIN_BYTES per array on) get ROW-PITCHED arrays
+        (rows on 128-B lines) out of arena memory of a kind that none of the arrays in ``reads`` lies in
+        (placed.RowPool); everything else comes from the torch allocator, tight."""
+        dev = self.device
+        big = 24 * n >= placed.PLACED_INPUT_MIN_BYTES
+        if placement not in ("auto", "arena", "torch"):
+            raise ValueError("placement must be 'auto', 'arena' or 'torch'")
+        if placement == "arena" and placed.DISABLED is not None:
+            raise RuntimeError("placement='arena' but the arena is switched off: %s" % placed.DISABLED)
+        if placement == "arena" or (placement == "auto" and big and placed.DISABLED is None):
+            try:
+                arena = placed.PlacedArena.for_device(dev.index)
+                avoid = [arena.kind_of(t) for t in reads if t is not None]
+                pitch = recommended_pitch(n)
+                mrow = -(-n // 4096) * 4096
+                (buf, _) = placed.row_pool.take(dev, 24 * pitch + n_masks * mrow, avoid)
+                arr = buf[:24 * pitch].view(torch.float64).view(3, pitch)[:, :n]
+                masks = [buf[24 * pitch + q * mrow:24 * pitch + q * mrow + n] for q in range(n_masks)]
+                return arr, masks
+            except _lib.PrtError as exc:
+                if placement == "arena":
+                    raise
+                if exc.code != _lib.ERR_NOMEM:
+                    placed.disable("prt_arena_alloc failed: %s" % exc)
+        return _torch_alloc(lambda: (torch.empty((3, n), dtype=torch.float64, device=dev),
+                                     [torch.empty(n, dtype=torch.uint8, device=dev) for _ in range(n_masks)]))
+
+    @staticmethod
+    def _row_pitch(t, name):
+        """row pitch of a (3, n) array that the rows entry points can take as it is; None: needs a tight copy"""
+        if t is None or t.shape[1] == 0:
+            return 0
+        if t.dtype != torch.float64 or t.dim() != 2 or t.shape[0] != 3 or not t.is_cuda:
+            raise ValueError("%s must be a (3, N) float64 device tensor" % name)
+        return t.stride(0) if (t.stride(1) == 1 and t.stride(0) >= t.shape[1]) else None
+
     def propagate(self, surface, x, k, direction=None, e_re=None, e_im=None,
-                  default_e=True, valid_in=None, want_nonconv=False):
+                  default_e=True, valid_in=None, want_nonconv=False, placement="auto"):
         """Material.propagate / Surface.intersect for one surface.  Returns (x_hit, valid), with
-        ``want_nonconv`` (x_hit, valid, nonconv)."""
-        (x, k, direction, e_re, e_im) = [_rows_contiguous(t) for t in (x, k, direction, e_re, e_im)]
-        _check_rays(x, "x")
+        ``want_nonconv`` (x_hit, valid, nonconv).  (3, n) arrays with a row pitch are taken as they are.
+        ``placement``: where x_hit comes from -- "auto": big bundles get a row-pitched array in arena memory of another
+        kind of HBM than the arrays the call reads (``_step_arrays``); "torch": tight, from the torch allocator."""
+        if self._row_pitch(x, "x") is None:
+            x = x.contiguous()
+        # k, the direction and E share one pitch in the entry point
+        group = [t for t in (k, direction, e_re, e_im) if t is not None]
+        pitches = set(self._row_pitch(t, "k / direction / E") for t in group)
+        if None in pitches or len(pitches) > 1:
+            (k, direction, e_re, e_im) = [_rows_contiguous(t) for t in (k, direction, e_re, e_im)]
         n = x.shape[1]
+        lead = direction if direction is not None else k
         with torch.cuda.device(self.device):
-            x_hit = torch.empty((3, n), dtype=torch.float64, device=self.device)
-            valid = torch.empty(n, dtype=torch.uint8, device=self.device)
-            nonconv = torch.empty(n, dtype=torch.uint8, device=self.device) if want_nonconv else None
-            _lib.check(self.lib.prt_propagate(self._h, surface, n, _ptr(x), _ptr(k),
-                                              _ptr(direction), _ptr(e_re), _ptr(e_im),
-                                              1 if default_e else 0, _ptr(valid_in), _ptr(x_hit),
-                                              _ptr(valid), _ptr(nonconv), _stream_handle(self.device)))
+            (x_hit, masks) = self._step_arrays(n, (x, lead), placement, n_masks=2 if want_nonconv else 1)
+            valid = masks[0]
+            nonconv = masks[1] if want_nonconv else None
+            _lib.check(self.lib.prt_propagate_rows(self._h, surface, n, _ptr(x), x.stride(0) if n else 0, _ptr(k),
+                                                   lead.stride(0) if (n and lead is not None) else 0,
+                                                   _ptr(direction), _ptr(e_re), _ptr(e_im),
+                                                   1 if default_e else 0, _ptr(valid_in), _ptr(x_hit),
+                                                   x_hit.stride(0) if n else 0, _ptr(valid), _ptr(nonconv),
+                                                   _stream_handle(self.device)))
         return (x_hit, valid, nonconv) if want_nonconv else (x_hit, valid)
 
-    def interact(self, surface, x_hit, k, valid_in=None, want_e=False):
-        """Material.refract / reflect at one surface.  Returns
-        (k_out, dir_out, valid_out, e_re, e_im)."""
-        (x_hit, k) = [_rows_contiguous(t) for t in (x_hit, k)]
-        _check_rays(x_hit, "x_hit")
-        n = x_hit.shape[1]
+    def interact(self, surface, x_hit, k, valid_in=None, want_e=False, want_dir=None, placement="auto"):
+        """Material.refract / reflect at one surface.  Returns (k_out, dir_out, valid_out, e_re, e_im).
+        Isotropic medium behind the surface: ``dir_out`` is None unless ``want_dir`` (the ray direction is k / |k| there,
+        and the next ``propagate`` takes k itself); row-pitched arrays are taken as they are; ``placement`` as in
+        ``propagate``.  Crystals: (3, 2n) tight outputs, ``dir_out`` always."""
         aniso = self.records[surface]["material"]["type"] == "anisotropic"
-        m = 2 * n if aniso else n
+        n = x_hit.shape[1]
+        if aniso or self.complex_eps:
+            (x_hit, k) = [_rows_contiguous(t) for t in (x_hit, k)]
+            _check_rays(x_hit, "x_hit")
+            m = 2 * n if aniso else n
+            with torch.cuda.device(self.device):
+                k_out = torch.empty((3, m), dtype=torch.float64, device=self.device)
+                dir_out = torch.empty((3, m), dtype=torch.float64, device=self.device)
+                valid_out = torch.empty(m, dtype=torch.uint8, device=self.device)
+                e_re = e_im = None
+                if aniso and want_e:
+                    e_re = torch.empty((3, m), dtype=torch.float64, device=self.device)
+                    e_im = torch.empty((3, m), dtype=torch.float64, device=self.device)
+                _lib.check(self.lib.prt_interact(self._h, surface, n, _ptr(x_hit), _ptr(k),
+                                                 _ptr(valid_in), _ptr(k_out), _ptr(dir_out),
+                                                 _ptr(e_re), _ptr(e_im), _ptr(valid_out),
+                                                 _stream_handle(self.device)))
+            return k_out, dir_out, valid_out, e_re, e_im
+        if self._row_pitch(x_hit, "x_hit") is None:
+            x_hit = x_hit.contiguous()
+        if self._row_pitch(k, "k") is None:
+            k = k.contiguous()
         with torch.cuda.device(self.device):
-            k_out = torch.empty((3, m), dtype=torch.float64, device=self.device)
-            dir_out = torch.empty((3, m), dtype=torch.float64, device=self.device)
-            valid_out = torch.empty(m, dtype=torch.uint8, device=self.device)
-            e_re = e_im = None
-            if aniso and want_e:
-                e_re = torch.empty((3, m), dtype=torch.float64, device=self.device)
-                e_im = torch.empty((3, m), dtype=torch.float64, device=self.device)
-            _lib.check(self.lib.prt_interact(self._h, surface, n, _ptr(x_hit), _ptr(k),
-                                             _ptr(valid_in), _ptr(k_out), _ptr(dir_out),
-                                             _ptr(e_re), _ptr(e_im), _ptr(valid_out),
-                                             _stream_handle(self.device)))
-        return k_out, dir_out, valid_out, e_re, e_im
+            (k_out, masks) = self._step_arrays(n, (x_hit, k), placement)
+            dir_out = None
+            if want_dir:
+                (dir_out, _) = self._step_arrays(n, (x_hit, k), "torch", n_masks=0)
+                if k_out.stride(0) != dir_out.stride(0):        # (dir_out shares k_out's pitch in the entry point)
+                    dir_out = torch.empty((3, k_out.stride(0)), dtype=torch.float64, device=self.device)[:, :n]
+            _lib.check(self.lib.prt_interact_rows(self._h, surface, n, _ptr(x_hit), x_hit.stride(0) if n else 0, _ptr(k),
+                                                  k.stride(0) if n else 0, _ptr(valid_in), _ptr(k_out),
+                                                  k_out.stride(0) if n else 0, _ptr(dir_out), _ptr(masks[0]),
+                                                  _stream_handle(self.device)))
+        return k_out, dir_out, masks[0], None, None
 
     def interact_cplx(self, surface, x_hit, k_re, k_im=None, valid_in=None, want_e=False):
         """Material.refract / reflect at one surface with complex wave vectors (prt_interact_cplx: absorbing media

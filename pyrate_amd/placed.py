@@ -56,6 +56,7 @@ def record_stream(tensor, stream=None):
 def trim_all():
     """hand every arena's cached (unused) memory back to the driver -- what the engine does when a torch
     allocation runs out of memory (the caching allocator cannot reclaim what the arena holds)"""
+    row_pool.clear()
     for arena in list(PlacedArena._instances.values()):
         try:
             arena.trim()
@@ -83,6 +84,45 @@ class InputRows(object):
 
 
 input_rows = InputRows()
+
+
+class RowPool(object):
+    """Arrays of the PER-SURFACE calls (DeviceSystem.propagate / interact on big bundles), carved front to back out of
+    1-GiB arena buffers of a CHOSEN kind: a (3, pitch) array of 1e7 rays is a quarter of a slab, so four of them share
+    one.  ``take`` avoids the kinds its caller names -- the kinds of the arrays the same kernel READS -- so that a
+    kernel's two input arrays and its output array lie in three different kinds of HBM whenever the device offers them
+    (loads that share a kind with the write stream cost the stream ~5 %).  A buffer goes back to the
+    arena when the last array carved from it dies (and the pool has moved on to another one); within a buffer no byte
+    is handed out twice."""
+
+    def __init__(self):
+        self._cur = {}            # (device index, kind) -> [uint8 buffer, bytes handed out]
+        self._lock = threading.Lock()
+
+    def take(self, device, nbytes, avoid_kinds=()):
+        """(uint8 tensor of ``nbytes`` bytes at a 4-KiB aligned address, its kind)"""
+        nbytes = -(-int(nbytes) // 4096) * 4096
+        avoid = set(int(q) for q in avoid_kinds if q is not None and q >= 0)
+        with self._lock:
+            for ((d, kind), ent) in self._cur.items():
+                if d == device.index and kind not in avoid and ent[1] + nbytes <= ent[0].numel():
+                    lo = ent[1]
+                    ent[1] += nbytes
+                    return ent[0][lo:lo + nbytes], kind
+            mask = 0
+            for q in avoid:
+                mask |= 1 << q
+            size = max(SLAB_BYTES, -(-nbytes // SLAB_BYTES) * SLAB_BYTES)
+            (parts, kinds) = PlacedArena.for_device(device.index).alloc([size], n_distinct=1, avoid_mask=mask)
+            self._cur[(device.index, kinds[0])] = [parts[0], nbytes]
+            return parts[0][:nbytes], kinds[0]
+
+    def clear(self):
+        with self._lock:
+            self._cur.clear()
+
+
+row_pool = RowPool()
 
 
 class _Block(object):
@@ -276,12 +316,16 @@ class PlacedArena(object):
 
     def stats(self):
         v = (ctypes.c_int64 * 12)()
-        r = (ctypes.c_double * 4)()
-        _lib.check(self.lib.prt_arena_stats(self._h, v, 12, r, 4))
+        r = (ctypes.c_double * 8)()
+        _lib.check(self.lib.prt_arena_stats(self._h, v, 12, r, 8))
         return {"kinds_seen": v[0], "probes": v[1], "slabs_created": v[2], "slabs_released": v[3],
                 "slabs_free": v[4], "slabs_in_use": v[5], "slabs_cached": v[6], "slab_bytes": v[7],
                 "slabs_per_kind": [v[8], v[9], v[10], v[11]], "probe_same_kind_GBps": r[0],
                 "probe_cross_kind_GBps": r[1], "probe_ms_total": r[2], "address_space_reserved_GiB": r[3] / 2 ** 30,
+                # the window of address space every mapping is carved from (csrc/prt_placed.h, second rule): far away
+                # from anything the host allocator hands out
+                "va_window_first": int(r[4]), "va_windows": int(r[5]), "va_window_hinted": bool(r[6]),
+                "va_window_GiB": r[7] / 2 ** 30,
                 "tensor_wrap": self._wrap, "partition_and_note": self.note(),
                 "hunt": os.environ.get("PRT_ARENA_HUNT", "bounded (32 slabs / 50 ms per call)")}
 

@@ -86,7 +86,10 @@ def _recycled(records, device, key):
         try:
             took = cand.update(records)
         except Exception:
-            # the update failed on the device: the system is closed (engine.DeviceSystem.update) -- out of the caches
+            # the update failed -- on the device (the system is poisoned: engine.DeviceSystem.update closed it) or
+            # before anything reached it (packing the records): either way the candidate leaves the caches CLOSED,
+            # so that its device arrays do not leak
+            cand.close()
             del _CACHE[old_key]
             for (ident, (_, s)) in list(_BY_IDENTITY.items()):
                 if s is cand:

@@ -181,8 +181,14 @@ class Named(object):
     def __setstate__(self, state):
         # copy.copy / copy.deepcopy / pickle hand the attribute dictionary over without calling __setattr__: adopt
         # every value here, so that the copy's dictionaries and variables move the COPY's epoch from now on
+        # (a dictionary that already HAS an owner is somebody else's -- copy.copy passes the original's own attribute
+        #  dictionary as the state --: the copy gets a tracked dictionary of its own with the same entries, the
+        #  original keeps its one and its epoch)
         for (k, v) in state.items():
             if isinstance(v, TrackedDict):
-                v._rehome(self)
+                if v._owner is None:
+                    v._rehome(self)
+                elif v._owner is not self:
+                    v = TrackedDict(dict(v), owner=self)
             object.__setattr__(self, k, _adopt(self, v))
         _touch(self)

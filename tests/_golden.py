@@ -44,7 +44,11 @@ ALL_CASES = ISO_CASES + EXPLICIT_CASES + ANISO_CASES
 # every explicit-shape case once more with the REFERENCE converged (oracle/make_golden.py: annotations["tol"] = 1e-14 on
 # every explicit shape instead of the default xtol = 1e-6, surface_shape.py:396, 457-458): compared with the flat
 # 1e-10 of north_star, no allowance; the fixture carries the reference's own residual |z - F(x, y)| per surface
-EXPLICIT_TIGHT_CASES = [c + "_tight" for c in EXPLICIT_CASES]
+# cases that exist ONLY with the reference converged: a near-hemisphere hit at up to 84.4 degrees of incidence (round 6:
+# Newton's g' = d . grad is 0.1 there) -- with its default xtol the reference's fsolve gives up on this bundle
+# ("not making good progress"), so there is no out-of-the-box result to compare with
+EXPLICIT_TIGHT_ONLY = ["asphere_grazing_field30"]
+EXPLICIT_TIGHT_CASES = [c + "_tight" for c in EXPLICIT_CASES + EXPLICIT_TIGHT_ONLY]
 REF_RESIDUAL_MAX = 1e-12        # [mm] what "the reference is converged on every ray" means for a tight fixture
 # complex (absorbing) epsilon tensors, sequences that stay inside crystals: complex wave vectors, compared as such
 ABSORBING_CASES = ["aniso_absorbing_mirror", "aniso_absorbing_two_crystals",

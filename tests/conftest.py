@@ -16,6 +16,9 @@ def pytest_configure(config):
     # once it KNOWS the device's kinds, so the test session lifts the bound like bench.py does; the bounded default
     # itself is checked in a fresh process (test_gpu_perf.py: test_arena_default_hunt_is_bounded).
     os.environ.setdefault("PRT_ARENA_HUNT", "full")
+    # the library's fault-injection hook (PRT_TEST_FAIL_UPDATE) exists only in processes that ask for it before the
+    # library's first call (csrc/prt.hip: prt_system_update)
+    os.environ.setdefault("PRT_TEST_HOOKS", "1")
     # A process that has hundreds of GiB of device memory mapped must not write a core file if it ever dies:
     # once a crash inside the HIP runtime filled the box's disk that way and took the following run with it.
     try:

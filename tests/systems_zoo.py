@@ -391,6 +391,31 @@ def biconic_builduplist():
     ]
 
 
+GRAZING_DOME = dict(radius=20.0, decz=30.0, tilt_deg=30.0, rpup=5.0, margin=0.03, z0=-5.0)
+
+
+def grazing_dome_builduplist():
+    """an even asphere that is nearly a hemisphere (R = 20 mm + a small r^4 term), convex towards a bundle tilted by 30
+    degrees whose topmost rays pass 0.03 mm below the line that touches the dome: angles of incidence up to 84.4 degrees --
+    the Newton iteration's g'(t) = d . grad is 0.1 there, where ADVICE r5 (medium) suspected the 1e-8 stop rule"""
+    g = GRAZING_DOME
+    return [
+        ({"shape": "Conic"}, {"decz": 0.0}, None, "stop", {"is_stop": True}),
+        ({"shape": "Asphere", "curv": 1. / g["radius"], "cc": 0.0, "coefficients": [0.0, 1e-7, 0.0]},
+         {"decz": g["decz"]}, 1.5168, "dome", {}),
+        ({"shape": "Conic"}, {"decz": 40.0}, None, "image", {}),
+    ]
+
+
+def grazing_dome_bundle_centre():
+    """start height (at z0) of the centre of the bundle whose top ray misses the tangent line by ``margin``"""
+    import math
+    g = GRAZING_DOME
+    th = math.radians(g["tilt_deg"])
+    (yt, zt) = (g["radius"] * math.cos(th), g["decz"] + g["radius"] - g["radius"] * math.sin(th))
+    return yt - (zt - g["z0"]) * math.tan(th) - g["margin"] - g["rpup"]
+
+
 def mirrors_builduplist():
     """paraboloid mirror + tilted flat fold mirror"""
     return [

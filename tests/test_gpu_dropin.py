@@ -544,7 +544,9 @@ def test_a_failed_in_place_update_poisons_the_system_and_leaves_the_caches(gpu_d
     """prt_system_update enqueues up to five copies; a failure after the first leaves the device with
     pieces of two tables.  The library then refuses the system for good (PRT_ERR_DEVICE from every entry point),
     DeviceSystem.update closes it, and the dispatch cache of the drop-in layer drops it -- the next trace builds a
-    fresh system and is right.  (PRT_TEST_FAIL_UPDATE makes the library report the failure after its copies.)"""
+    fresh system and is right.  (PRT_TEST_FAIL_UPDATE=k -- honoured only with PRT_TEST_HOOKS, conftest.py -- makes the
+    k-th enqueue of an update fail instead of being issued: k = 2 leaves the new records on the stream and the old
+    coefficient arrays in place, the partial update the poisoning exists for.)"""
     import ctypes
     from pyrate_amd import _lib, engine, systems
     from pyrate_amd.builders import build_rotationally_symmetric_optical_system
@@ -555,7 +557,7 @@ def test_a_failed_in_place_update_poisons_the_system_and_leaves_the_caches(gpu_d
     sysd = engine.DeviceSystem(systems.double_gauss_records(), 0)
     ref = sysd.trace(x0, k0, e0d).x_hit[-1].clone()
     handle = sysd._h
-    monkeypatch.setenv("PRT_TEST_FAIL_UPDATE", "1")
+    monkeypatch.setenv("PRT_TEST_FAIL_UPDATE", "2")
     with pytest.raises(_lib.PrtError) as err:
         sysd.update(systems.double_gauss_records(486.1e-6))
     assert err.value.code == _lib.ERR_DEVICE and "unusable" in str(err.value)
@@ -590,7 +592,7 @@ def test_a_failed_in_place_update_poisons_the_system_and_leaves_the_caches(gpu_d
     assert all(v._h for v in _dispatch._CACHE.values())
     curv.set_value(c0)
     got = s.seqtrace(ib, seq)[0].raybundles[-1].x[-1]
-    assert np.allclose(got, ref.cpu().numpy()[:, :got.shape[1]], rtol=0, atol=0) or got.shape[1] <= ref.shape[1]
+    assert np.array_equal(got, ref.cpu().numpy())          # same bundle, same table: the same bits
     _dispatch.clear()
     del handle
 

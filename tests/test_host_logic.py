@@ -156,7 +156,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(_lib.PROTOTYPES.keys())
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.prt_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.prt_abi_version() == _lib.ABI_VERSION == 7
     assert lib.prt_sizeof_surface() == ctypes.sizeof(st.PrtSurface)
     assert lib.prt_strerror(-2) == b"unsupported shape/material"
     # argument validation happens before any device work
@@ -840,14 +840,14 @@ def test_frame_tree_update_moves_only_the_frames_that_moved():
 
 
 def test_bench_attributes_march_launches_to_their_configurations():
-    """bench.py's live PMC pass: a counter row belongs to a configuration by its place in the dispatch order of the
-    march kernels; the fall-back (a counter file without dispatch ids) reads the instantiation from the kernel name --
-    round 5: the biaxial crystal march (GENERAL = true) is a configuration of its own"""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
-    f = bench._pmc_config_of
+    """bench.py's live PMC pass (benchmarks/pmc.py): a counter row belongs to a configuration by its place in the
+    dispatch order of the kernels that count -- the marches (one launch per trace) and, for the per-surface paths
+    (plugin, aniso_chain), the k_propagate / k_interact launches, a known number per trace; the fall-back (a counter file
+    without dispatch ids) reads the march's instantiation from the kernel name"""
+    import sys
+    sys.path.insert(0, ROOT)
+    from benchmarks import pmc, workloads
+    f = pmc.config_of_march
     assert f("void k_trace_iso<0, true, true, 0, false, false, true, false>(prt_dev_surface const*)") == "doublegauss"
     assert f("void k_trace_iso<0, true, true, 0, false, false, false, false>(...)") == "benchmark"
     assert f("void k_trace_iso<0, true, true, 1, false, false, true, false>(...)") == "asphere"
@@ -855,13 +855,33 @@ def test_bench_attributes_march_launches_to_their_configurations():
     assert f("void k_trace_general<0, false, true, false, 0>(...)") == "aniso"
     assert f("void k_trace_general<0, true, true, false, 0>(...)") == "aniso_biaxial"
     assert f("void k_propagate(...)") is None
+    L = pmc.PMC_LAUNCHES
     rows = [{"Kernel_Name": "void k_trace_iso<0, true, true, 0, false, false, true, false>()", "Dispatch_Id": str(10 + i),
-             "Counter_Name": "WRITE_SIZE", "Counter_Value": "1"} for i in range(bench.PMC_LAUNCHES)] + \
+             "Counter_Name": "WRITE_SIZE", "Counter_Value": "1"} for i in range(L)] + \
            [{"Kernel_Name": "void k_trace_general<0, true, true, false, 0>()", "Dispatch_Id": str(40 + i),
-             "Counter_Name": "WRITE_SIZE", "Counter_Value": "2"} for i in range(bench.PMC_LAUNCHES)] + \
+             "Counter_Name": "WRITE_SIZE", "Counter_Value": "2"} for i in range(L)] + \
            [{"Kernel_Name": "void k_rectgrid_mask()", "Dispatch_Id": "5", "Counter_Name": "WRITE_SIZE", "Counter_Value": "9"}]
-    got = bench._pmc_rows_by_config(rows, ["doublegauss", "aniso_biaxial"])
-    assert sorted(set(c for (c, _, _) in got)) == ["aniso_biaxial", "doublegauss"] and len(got) == 2 * bench.PMC_LAUNCHES
+    got = pmc.rows_by_config(rows, ["doublegauss", "aniso_biaxial"])
+    assert sorted(set(c for (c, _, _) in got)) == ["aniso_biaxial", "doublegauss"] and len(got) == 2 * L
     assert all(v == (1.0 if c == "doublegauss" else 2.0) for (c, _, v) in got)
-    assert set(bench.SECONDARY_MARCH_CONFIGS) | set(bench.SECONDARY_CUSTOM_CONFIGS) == \
+    # a per-surface configuration between two marches: 2 surfaces -> 4 kernels per trace
+    sweep = []
+    for t in range(L):
+        for q in range(2):
+            sweep.append({"Kernel_Name": "void k_propagate_rows<true>()", "Dispatch_Id": str(100 + 4 * t + 2 * q),
+                          "Counter_Name": "WRITE_SIZE", "Counter_Value": "3"})
+            sweep.append({"Kernel_Name": "void k_interact_iso_rows<true>()", "Dispatch_Id": str(101 + 4 * t + 2 * q),
+                          "Counter_Name": "WRITE_SIZE", "Counter_Value": "4"})
+    tail = [{"Kernel_Name": "void k_trace_general<0, false, true, false, 0>()", "Dispatch_Id": str(500 + i),
+             "Counter_Name": "WRITE_SIZE", "Counter_Value": "5"} for i in range(L)]
+    got = pmc.rows_by_config(rows[:L] + sweep + tail, ["doublegauss", "plugin", "aniso"], {"plugin": 4})
+    by = {}
+    for (c, _, v) in got:
+        by.setdefault(c, []).append(v)
+    assert sorted(by) == ["aniso", "doublegauss", "plugin"]
+    assert len(by["plugin"]) == 4 * L and sum(by["plugin"]) == (3 + 4) * 2 * L and set(by["aniso"]) == {5.0}
+    # a count that does not add up (another kernel of these names slipped in): only the marches, by their names
+    got = pmc.rows_by_config(rows[:L] + sweep[:-1] + tail, ["doublegauss", "plugin", "aniso"], {"plugin": 4})
+    assert sorted(set(c for (c, _, _) in got)) == ["aniso", "doublegauss"]
+    assert set(workloads.SECONDARY_MARCH_CONFIGS) | set(workloads.SECONDARY_CUSTOM_CONFIGS) == \
         {"aniso_biaxial", "aniso_chain", "plugin", "image_moments"}
