@@ -1,67 +1,48 @@
 #!/bin/bash
-# Everything under profiles/ that comes from a GPU box, in one go (run from the repo root on an MI355X):
-#   bash benchmarks/collect_profiles.sh <tag>      -> gpurun_out/<tag>/...
-# bench.py's default run measures every single-GPU configuration (headline + `configs`) and takes the HBM traffic /
-# FP64 instruction counters itself (rocprofv3 PMC passes over its --pmc-inner mode, separate passes, kernel trace
-# only -- never combined with sys / hip / hsa tracing).  Here: that line; the same command under
-# rocprofv3 --kernel-trace --stats (the per-kernel averages the line's kernel_ms must agree with), summarised per
-# configuration by benchmarks/kernel_trace_summary.py; issue-side SQ counters of the crystal march; fresh-process
-# repeats; the N > 1 code path with one rank; A/Bs; cold start of the drop-in; parity report.
+# What the figures of DESIGN.md section 5 come from, in one go (run from the repo root on an MI355X, ~6 minutes):
+#   bash benchmarks/collect_profiles.sh <tag>      -> gpurun_out/<tag>/...   (copy what is to be judged into profiles/)
+# bench.py's default run measures every configuration and takes the HBM traffic / FP64 instruction counters itself
+# (rocprofv3 PMC passes over its --pmc-inner mode: separate passes, kernel trace only).  Here: that line (the FIRST GPU
+# process of the box: what the driver's run is) + its detail file; the same command under rocprofv3 --kernel-trace
+# --stats (the per-kernel averages the line's kernel_ms must agree with), summarised per configuration; fresh-process
+# repeats; the 1e8-ray bundle alone; the N > 1 code path with one rank through RCCL; parity and ISA reports.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r06}
 O=gpurun_out/$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-python bench.py > $O/bench_line.json 2> $O/bench_line.err
+python bench.py --detail $O/bench_detail.json > $O/bench_line.json 2> $O/bench_line.err; echo "bench rc=$?" > $O/rc.txt
 STEPS=50
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps $STEPS --warmup 10 --no-cpu-baseline --traffic none --no-scaling-point --no-secondary > $O/bench_line_under_rocprof.json 2> $O/stats.err
-# (k_trace_iso<MODE, VEC_IN, VEC_OUT, SHAPES, LDS_TAB, MOMENTS, UNI, IMG>: the double Gauss runs with the uniform first
-# segment, the reference's benchmark workload -- a divergent bundle -- with k0 / E0 arrays)
-for cfg in "doublegauss:k_trace_iso<0, true, true, 0, false, false, true," "benchmark:k_trace_iso<0, true, true, 0, false, false, false," "asphere:k_trace_iso<0, true, true, 1," "xypoly:k_trace_iso<0, true, true, 2," "aniso:k_trace_general<0,"; do
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps $STEPS --warmup 10 --no-cpu-baseline --traffic none --no-scaling-point --no-e2e --detail $O/bench_detail_under_rocprof.json > $O/bench_line_under_rocprof.json 2> $O/stats.err
+# (k_trace_iso<MODE, VEC_IN, VEC_OUT, SHAPES, MOMENTS, UNI, IMG>: the double Gauss runs with the uniform first segment, the
+#  reference's benchmark workload -- a divergent bundle -- with k0 / E0 arrays)
+for cfg in "doublegauss:k_trace_iso<0, true, true, 0, false, true," "benchmark:k_trace_iso<0, true, true, 0, false, false," "asphere:k_trace_iso<0, true, true, 1," "xypoly:k_trace_iso<0, true, true, 2," "aniso:k_trace_general<0, false," "aniso_biaxial:k_trace_general<0, true," "plugin_propagate:k_propagate_rows<" "plugin_interact:k_interact_iso_rows<"; do
   python benchmarks/kernel_trace_summary.py $O/stats "${cfg#*:}" $STEPS > $O/${cfg%%:*}_kernel_trace_summary.json 2>> $O/stats.err
 done
 find $O/stats -name "*kernel_stats.csv" | head -1 | while read f; do cp "$f" $O/bench_kernel_stats.csv; done
-# issue-side counters of the crystal march (separate passes)
-B="python bench.py --config aniso --no-cpu-baseline --traffic none --steps 20 --warmup 5"
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_WAVES --output-format csv -d $O/aniso_pmc/f64 -- $B > /dev/null 2> $O/aniso_f64.err
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/aniso_pmc/sq1 -- $B > /dev/null 2> $O/aniso_sq1.err
-rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU --output-format csv -d $O/aniso_pmc/sq2 -- $B > /dev/null 2> $O/aniso_sq2.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/aniso_pmc/fetch -- $B > /dev/null 2> $O/aniso_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/aniso_pmc/write -- $B > /dev/null 2> $O/aniso_write.err
-python benchmarks/pmc_summary.py $O/aniso_pmc k_trace_general > $O/aniso_pmc_counters.json 2>> $O/aniso_f64.err
-# the headline in fresh processes
-for i in 1 2 3 4 5; do python bench.py --headline-only --no-cpu-baseline --traffic none > $O/fresh_$i.json 2> /dev/null; done
+for i in 1 2 3 4 5; do python bench.py --headline-only --no-cpu-baseline --traffic none --detail /tmp/fresh_detail.json > $O/fresh_$i.json 2> /dev/null; done
 python - "$O" <<'PY' > $O/five_fresh_processes.json
 import json, sys
-rows = [json.load(open("%s/fresh_%d.json" % (sys.argv[1], i))) for i in range(1, 6)]
-print(json.dumps([{"ms_per_step": r["ms_per_step"], "kernel_ms": r["roofline"]["kernel_ms"], "frac": r["roofline"]["frac"],
-                   "kinds": r["config"]["output_placement"]["memory_kinds_of_x_hit_and_k_out"],
-                   "input_kind": r["config"]["output_placement"]["memory_kind_of_inputs"],
-                   "arena": r["config"]["output_placement"]["arena"]} for r in rows], indent=1))
+rows = []
+for i in range(1, 6):
+    try:
+        rows.append(json.loads(open("%s/fresh_%d.json" % (sys.argv[1], i)).read().strip().splitlines()[-1]))
+    except Exception as exc:
+        rows.append({"error": str(exc)})
+print(json.dumps([r if "error" in r else
+                  {"ms_per_step": r["ms_per_step"], "kernel_ms": r["roofline"]["kernel_ms"], "frac": r["roofline"]["frac"],
+                   "placement": r["config"]["placement"]} for r in rows], indent=1))
 PY
-python bench.py --first-segment arrays --headline-only --no-cpu-baseline > $O/bench_line_arrays.json 2> /dev/null
-python bench.py --rays 100000000 --steps 3 --warmup 1 --headline-only --no-cpu-baseline --traffic none > $O/bench_1e8_rays_line.json 2> $O/bench_1e8.err
-for gm in inplace copy; do python bench.py --force-multi --scaling weak --steps 50 --warmup 10 --gather-mode $gm > $O/bench_force_multi_$gm.json 2> $O/bench_force_multi_$gm.err; done
-python bench.py --force-multi --scaling weak --steps 50 --warmup 10 --exchange stats > $O/bench_force_multi_stats.json 2> /dev/null
-python bench.py --force-multi --scaling weak --steps 50 --warmup 10 --trace-stream default > $O/bench_force_multi_inplace_default_stream.json 2> /dev/null
-python bench.py --force-multi --scaling weak --steps 50 --warmup 10 --exchange gather-direct > $O/bench_force_multi_direct.json 2> /dev/null
-python benchmarks/ab_crystal.py > $O/ab_crystal.json 2> $O/ab_crystal.err
-python benchmarks/ab_shapes.py > $O/ab_shapes.json 2> $O/ab_shapes.err
-python benchmarks/dropin_call_time.py > $O/dropin_call_time.json 2> $O/dropin.err
-python benchmarks/call_latency.py > $O/call_latency.json 2> $O/call_latency.err
-# the N > 1 protocol as the driver runs it (--scaling strong: the 1e8-ray bundle), with one rank going through RCCL
-python bench.py --force-multi --steps 20 --warmup 5 > $O/bench_force_multi_strong_1e8.json 2> $O/bench_force_multi_strong.err
+python bench.py --rays 100000000 --steps 3 --warmup 1 --headline-only --no-cpu-baseline --traffic none --detail /tmp/d.json > $O/bench_1e8_rays_line.json 2> $O/bench_1e8.err
+# the N > 1 protocol as the driver runs it (--scaling strong: the 1e8-ray bundle, 5 wavelengths), one rank through RCCL
+python bench.py --force-multi --steps 20 --warmup 5 --detail $O/bench_force_multi_strong_detail.json > $O/bench_force_multi_strong_1e8.json 2> $O/bench_force_multi_strong.err
 python tests/parity_report.py > $O/parity_report.txt 2> $O/parity_report.err
+python benchmarks/isa_report.py > $O/isa_report.json 2> /dev/null
 # keep only the summaries (the raw traces are large)
 find $O -name "*counter_collection.csv" -delete
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*agent_info.csv" -delete
 find $O -name "*.db" -delete
+rm -rf $O/stats
 rm -f $O/fresh_?.json
-ls -la $O
-# idle time between two marches of the N > 1 step: the march on the default stream vs on a stream of its own
-for ts in default new; do
-  rocprofv3 --kernel-trace --output-format csv -d $O/gap_$ts -o t -- python bench.py --force-multi --scaling weak --steps 100 --warmup 10 --trace-stream $ts > /dev/null 2> /dev/null
-  python benchmarks/step_gaps.py $(find $O/gap_$ts -name "t_kernel_trace.csv" | head -1) $ts > $O/force_multi_gaps_$ts.json 2> /dev/null
-  rm -rf $O/gap_$ts
-done
+cat $O/rc.txt; ls $O

@@ -70,7 +70,10 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
     if exchange == "auto":
         # the choice between the two forms of the image-plane gather is MEASURED at start-up (below) where both can run:
         # RCCL, more than one rank, path mode, fused statistics
-        can_probe = rccl and world > 1 and args.mode == "path" and not args.two_pass_stats and args.gather_mode == "inplace"
+        # (PRT_BENCH_PROBE_DRY=1: also under gloo -- the dry run of this very code with several ranks on ONE GPU)
+        dry = os.environ.get("PRT_BENCH_PROBE_DRY", "0") == "1"
+        can_probe = (rccl or dry) and world > 1 and args.mode == "path" and not args.two_pass_stats \
+            and args.gather_mode == "inplace"
         exchange = "probe" if can_probe else "gather"
     if exchange == "gather-direct" and (not rccl or args.mode != "path" or args.two_pass_stats):
         raise SystemExit("--exchange gather-direct: RCCL backend, path mode, fused statistics")
@@ -108,7 +111,8 @@ def run_multi(args, dev, world, rank, local_rank, watchdog):
         else:
             gathers = []
         # in place: the march of slot b deposits its image plane in gathers[b]'s receive buffer (prt_trace_ex redirect)
-        inplace = kind in ("gather", "gather-direct") and (args.gather_mode == "inplace" or direct) and not host_staged \
+        # (the direct form always: its receive buffers are device buffers whatever the backend)
+        inplace = (direct or (kind == "gather" and args.gather_mode == "inplace" and not host_staged)) \
             and mode == _lib.MODE_PATH
         return {"kind": kind, "direct": direct, "gathers": gathers, "inplace": inplace}
 

@@ -66,12 +66,12 @@ def is_per_surface(kernel_name):
 
 def config_of_march(kernel_name):
     """fall-back when the counter file has no dispatch ids: which bench config a march launch belongs to, from its
-    instantiation: k_trace_general -> aniso; k_trace_iso<MODE, VEC_IN, VEC_OUT, SHAPES, LDS, MOMENTS, UNI, ...> with
+    instantiation: k_trace_general -> aniso; k_trace_iso<MODE, VEC_IN, VEC_OUT, SHAPES, MOMENTS, UNI, IMG> with
     SHAPES 1 / 2 -> asphere / xypoly, SHAPES 0 -> doublegauss (uniform first segment) or benchmark (arrays)"""
     if "k_trace_general<" in kernel_name:           # <MODE, GENERAL, ...>: GENERAL = the biaxial (quartic) instantiation
         g = re.search(r"k_trace_general<\s*\d+\s*,\s*(\w+)", kernel_name)
         return "aniso_biaxial" if g and g.group(1) in ("1", "true") else "aniso"
-    m = re.search(r"k_trace_iso<\s*\d+\s*,\s*\w+\s*,\s*\w+\s*,\s*(\d+)\s*,\s*\w+\s*,\s*\w+\s*,\s*(\w+)", kernel_name)
+    m = re.search(r"k_trace_iso<\s*\d+\s*,\s*\w+\s*,\s*\w+\s*,\s*(\d+)\s*,\s*\w+\s*,\s*(\w+)", kernel_name)
     if m:
         sh = int(m.group(1))
         if sh == 0:

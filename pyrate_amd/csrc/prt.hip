@@ -167,11 +167,11 @@ struct iso_launch {
     hipStream_t st;
 };
 
-template <int MODE, bool VI, bool VO, int SH, bool LDS, bool MOM, bool UNI, bool IMG = false>
+template <int MODE, bool VI, bool VO, int SH, bool MOM, bool UNI, bool IMG = false>
 static void launch_iso_inst(const iso_launch &a) {
     // (a multiple of 8 blocks: the kernel deals contiguous eighths of the bundle to the 8 XCDs, prt_kernels.h)
     const dim3 grid((nblocks(a.n0, PRT_MARCH_BLOCK * 2) + 7u) / 8u * 8u), block(PRT_MARCH_BLOCK);
-    hipLaunchKernelGGL((k_trace_iso<MODE, VI, VO, SH, LDS, MOM, UNI, IMG>), grid, block, 0, a.st, a.sys->d_table,
+    hipLaunchKernelGGL((k_trace_iso<MODE, VI, VO, SH, MOM, UNI, IMG>), grid, block, 0, a.st, a.sys->d_table,
                        a.sys->n_surfaces, a.n0, a.in_pitch, a.x0, a.k0, a.e_re, a.e_im, a.e_mode, a.out_pitch,
                        a.x_hit, a.k_out, a.valid, a.valid_out, a.rx, a.ry, a.rz, a.partials, a.packed_flags,
                        a.nonconv, a.fu, (int32_t)(a.uni ? 1 : 0), a.img);
@@ -182,28 +182,25 @@ static void launch_iso_inst(const iso_launch &a) {
 // the uniform first segment as a run-time flag (moments: two-kernel reduction behind the trace, see trace_launch).
 template <int MODE, int SH>
 static void launch_iso_shape(const iso_launch &a, bool vi, bool vo) {
-    static const bool lds_table = getenv("PRT_LDS_TABLE") != nullptr;
     if (a.redirect) {  // (path mode, aligned rows: checked by the caller)
         if (MODE == PRT_MODE_PATH) {
-            if (a.moments && a.uni) launch_iso_inst<PRT_MODE_PATH, true, true, SH, false, true, true, true>(a);
-            else if (a.moments) launch_iso_inst<PRT_MODE_PATH, true, true, SH, false, true, false, true>(a);
-            else if (a.uni) launch_iso_inst<PRT_MODE_PATH, true, true, SH, false, false, true, true>(a);
-            else launch_iso_inst<PRT_MODE_PATH, true, true, SH, false, false, false, true>(a);
+            if (a.moments && a.uni) launch_iso_inst<PRT_MODE_PATH, true, true, SH, true, true, true>(a);
+            else if (a.moments) launch_iso_inst<PRT_MODE_PATH, true, true, SH, true, false, true>(a);
+            else if (a.uni) launch_iso_inst<PRT_MODE_PATH, true, true, SH, false, true, true>(a);
+            else launch_iso_inst<PRT_MODE_PATH, true, true, SH, false, false, true>(a);
         }
     } else if (a.moments) {
-        if (a.uni) launch_iso_inst<MODE, true, true, SH, false, true, true>(a);
-        else launch_iso_inst<MODE, true, true, SH, false, true, false>(a);
+        if (a.uni) launch_iso_inst<MODE, true, true, SH, true, true>(a);
+        else launch_iso_inst<MODE, true, true, SH, true, false>(a);
     } else if (vi && vo) {
-        if (SH == PRT_SHAPES_CONIC && lds_table && !a.uni && a.sys->n_surfaces <= PRT_LDS_TAB_MAX)
-            launch_iso_inst<MODE, true, true, PRT_SHAPES_CONIC, true, false, false>(a);
-        else if (a.uni) launch_iso_inst<MODE, true, true, SH, false, false, true>(a);
-        else launch_iso_inst<MODE, true, true, SH, false, false, false>(a);
+        if (a.uni) launch_iso_inst<MODE, true, true, SH, false, true>(a);
+        else launch_iso_inst<MODE, true, true, SH, false, false>(a);
     } else if (vi) {
-        launch_iso_inst<MODE, true, false, SH, false, false, false>(a);
+        launch_iso_inst<MODE, true, false, SH, false, false>(a);
     } else if (vo) {
-        launch_iso_inst<MODE, false, true, SH, false, false, false>(a);
+        launch_iso_inst<MODE, false, true, SH, false, false>(a);
     } else {
-        launch_iso_inst<MODE, false, false, SH, false, false, false>(a);
+        launch_iso_inst<MODE, false, false, SH, false, false>(a);
     }
 }
 

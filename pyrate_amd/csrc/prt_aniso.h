@@ -292,15 +292,10 @@ PRT_DEV void eigen_solution(const REC *__restrict__ sf, int cls, const vec3 &kpa
 // epsilon tensors isotropic or uniaxial) and that code is compiled out.
 // The complete path of the general (biaxial) class: eigenvectors and S.n of all four solutions, the reference's sort
 // (material.py:147), the two that leave.  It runs only where the pair test of the fast path fails (evanescent
-// modes, a failed Bairstow split, an exotic slowness surface).  Inlined: as a real call (-DPRT_ANISO_NOINLINE_FALLBACK)
-// the callee is compiled without the kernel's register budget -- 214 VGPRs, 2 waves per SIMD for the whole kernel.
-#ifdef PRT_ANISO_NOINLINE_FALLBACK
-#define PRT_ANISO_FALLBACK_ATTR __attribute__((noinline))
-#else
-#define PRT_ANISO_FALLBACK_ATTR __forceinline__
-#endif
+// modes, a failed Bairstow split, an exotic slowness surface).  Inlined: as a real call (tried in round 4) the callee is
+// compiled without the kernel's register budget -- 214 VGPRs, 2 waves per SIMD for the whole kernel.
 template <class REC>
-__device__ PRT_ANISO_FALLBACK_ATTR void four_solution_path(const REC *__restrict__ sf, int cls, const vec3 &kpa,
+__device__ __forceinline__ void four_solution_path(const REC *__restrict__ sf, int cls, const vec3 &kpa,
                                                            const vec3 &n, const double pc[5], double xr[4], bool mirror,
                                                            double x_out[2], vec3 e_out[2]) {
         double xi[4];

@@ -1,8 +1,9 @@
 // prt_kernels.h -- the __global__ kernels of libprt.so (launched from prt.hip).
 //
-//   k_trace_iso<MODE,VEC_IN,VEC_OUT,SHAPES,LDS_TAB>    whole isotropic sequence in one launch
+//   k_trace_iso<MODE,VEC_IN,VEC_OUT,SHAPES,MOMENTS,UNI,IMG>   whole isotropic sequence in one launch
 //   k_trace_general<MODE>                              whole sequence through crystals (leaf re-tracing)
-//   k_propagate / k_interact_iso / k_interact_aniso    one plugin-granular step
+//   k_propagate / k_interact_iso / k_interact_aniso    one plugin-granular step (tight arrays, one ray per thread)
+//   k_propagate_rows / k_interact_iso_rows             the same for big isotropic bundles (row-pitched, two rays per thread)
 //   k_shape_eval, k_efield_perp, k_poynting_dir, k_path_sums
 //   k_moments_partial / k_moments_final                deterministic bundle moments
 //   k_compact_count / k_compact_scan / k_compact_scatter   order-preserving compaction
@@ -13,9 +14,7 @@
 #include "prt_aniso.h"
 #include "prt_aniso_cplx.h"
 
-#ifndef PRT_BLOCK
 #define PRT_BLOCK 256
-#endif
 #define CMP_ITEMS 4  // mask bytes per thread in the compaction / raster kernels
 #define CMP_TILE (PRT_BLOCK * CMP_ITEMS)
 
@@ -40,16 +39,10 @@ struct rayio {
                              vec3 v[2]) {
         if (VEC) {
             // non-temporal hint: every input is read once (+1.7 % on the path-mode march, +4 % in image
-            // mode, same arrays, benchmarks/ab_variants.py; PRT_PLAIN_LOADS builds the other variant)
-#ifndef PRT_PLAIN_LOADS
+            // mode, same arrays: profiles/r02*_ab_variants*.json)
             const prt_double2 x = __builtin_nontemporal_load(reinterpret_cast<const prt_double2 *>(a + i));
             const prt_double2 y = __builtin_nontemporal_load(reinterpret_cast<const prt_double2 *>(a + pitch + i));
             const prt_double2 z = __builtin_nontemporal_load(reinterpret_cast<const prt_double2 *>(a + 2 * pitch + i));
-#else
-            const prt_double2 x = *reinterpret_cast<const prt_double2 *>(a + i);
-            const prt_double2 y = *reinterpret_cast<const prt_double2 *>(a + pitch + i);
-            const prt_double2 z = *reinterpret_cast<const prt_double2 *>(a + 2 * pitch + i);
-#endif
             v[0] = v3(x.x, y.x, z.x);
             v[1] = v3(x.y, y.y, z.y);
         } else {
@@ -61,19 +54,12 @@ struct rayio {
                               const vec3 v[2]) {
         if (VEC) {
             // non-temporal hint: a path array is written once and not read by this kernel again; with
-            // x_hit and k_out in two kinds of HBM it is worth 2 % (1.016 vs 1.038 ms, same arrays,
-            // benchmarks/ab_variants.py; PRT_PLAIN_STORES builds the other variant).  Of the cache-policy bits a
+            // x_hit and k_out in two kinds of HBM it is worth 2 % (1.016 vs 1.038 ms, same arrays).  Of the cache-policy bits a
             // gfx950 store can carry, "nt" alone is the best: nt 0.975 ms, sc0 nt 0.976, sc1 nt / sc0 sc1 nt 0.979,
             // none / sc0 sc1 0.996-0.999 (inline-asm stores, profiles/r02zd_ab_store_cache_policy_bits.json)
-#ifndef PRT_PLAIN_STORES
             __builtin_nontemporal_store(prt_double2{v[0].x, v[1].x}, reinterpret_cast<prt_double2 *>(a + i));
             __builtin_nontemporal_store(prt_double2{v[0].y, v[1].y}, reinterpret_cast<prt_double2 *>(a + pitch + i));
             __builtin_nontemporal_store(prt_double2{v[0].z, v[1].z}, reinterpret_cast<prt_double2 *>(a + 2 * pitch + i));
-#else
-            *reinterpret_cast<prt_double2 *>(a + i) = prt_double2{v[0].x, v[1].x};
-            *reinterpret_cast<prt_double2 *>(a + pitch + i) = prt_double2{v[0].y, v[1].y};
-            *reinterpret_cast<prt_double2 *>(a + 2 * pitch + i) = prt_double2{v[0].z, v[1].z};
-#endif
         } else {
             a[i] = v[0].x;
             a[pitch + i] = v[0].y;
@@ -157,11 +143,10 @@ PRT_DEV vec3 uniform_first_direction(int e_mode, const first_uniform &fu, const 
 // ---------------------------------------------------------------------------
 // fused isotropic march: OpticalElement.seqtrace's loop (optical_element.py:336-375)
 // ---------------------------------------------------------------------------
-// LDS_TAB = true is the measured alternative of DESIGN.md ("surface table placement"): the block
-// first copies the table into LDS and the march reads the records from there (ds_read broadcast
-// into VGPRs) instead of through the scalar cache (s_load into SGPRs).  Kept only for that A/B
-// (PRT_LDS_TABLE=1); it is slower and uses more VGPRs.
-#define PRT_LDS_TAB_MAX 16
+// The surface table is read through the scalar cache (s_load into SGPRs).  The alternative of north_star -- the block
+// copies the table into LDS and the march reads the records from there (ds_read broadcast into VGPRs) -- was built and
+// measured in rounds 2-5 (template parameter LDS_TAB, removed in round 6): 90 instead of 66 VGPRs, 5 instead of 7 waves,
+// +2.5 % in image mode, no difference in path mode.
 // SHAPES (prt_device.h): the shape code compiled into the instantiation.  The host guarantees that the
 // table holds nothing else: conics only -> no Newton / polynomial code at all (68 VGPRs, 7 waves per SIMD:
 // the double Gauss); conics + even aspheres (BASELINE configs[2]); every shape (116 VGPRs, 4 waves).
@@ -179,11 +164,7 @@ PRT_DEV vec3 uniform_first_direction(int e_mode, const first_uniform &fu, const 
 // at the un-park steps).  One explicit wait in front of the loop removes all of them.
 // s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt = imm[3:0] | imm[15:14], expcnt = imm[6:4] = 7 and lgkmcnt = imm[11:8] = 15
 // left alone)
-#ifndef PRT_NO_LOAD_FENCE
 #define PRT_WAIT_VMEM_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)
-#else
-#define PRT_WAIT_VMEM_LOADS() ((void)0)
-#endif
 // Image mode of the all-conic march is FP64-VALU bound: 8 waves/SIMD (63 VGPRs, no spills) instead
 // of the allocator's 7 is worth 5 % there (0.47 -> 0.446 ms); path mode is HBM bound and unaffected.
 // UNI = true: the uniform first segment, decided at compile time (the aligned instantiations); the unaligned
@@ -196,33 +177,19 @@ struct img_redirect {
     uint8_t *valid, *valid_out;
     int64_t pitch;
 };
-template <int MODE, bool VEC_IN, bool VEC_OUT, int SHAPES = PRT_SHAPES_ALL, bool LDS_TAB = false,
-          bool MOMENTS = false, bool UNI = false, bool IMG = false>
-#ifndef PRT_PATH_WAVES
-#define PRT_PATH_WAVES 1
-#endif
+template <int MODE, bool VEC_IN, bool VEC_OUT, int SHAPES = PRT_SHAPES_ALL, bool MOMENTS = false, bool UNI = false,
+          bool IMG = false>
 // Block size of the fused isotropic march only.  A/B of builds on the SAME arrays in one process
 // (scratch/ab_same_buffers.py; placement alone is worth +-10 %): path mode 64 threads 1.038-1.043,
 // 128 threads 1.035-1.046, 256 threads 1.055-1.062, 512 threads 1.078-1.080 ms; image mode
 // indifferent.  The write-bound march prefers many small blocks (finer-grained refill of the CUs).
-#ifndef PRT_MARCH_BLOCK
 #define PRT_MARCH_BLOCK 128
-#endif
-#ifdef PRT_PATH_WAVES_MAX   // experiment: cap the occupancy of every march instantiation
-__attribute__((amdgpu_waves_per_eu(1, PRT_PATH_WAVES_MAX)))
-#endif
 // asphere level: 82 VGPRs on its own = 5 waves; forcing 6 (80 VGPRs, 2-14 spilled dwords) is no faster in
 // path mode and 6 % slower in image mode (benchmarks/ab_variants.py asphere)
-#ifndef PRT_ASPHERE_WAVES
 #define PRT_ASPHERE_WAVES 5
-#endif
-#ifndef PRT_POLY_WAVES
 #define PRT_POLY_WAVES 5
-#endif
-#ifndef PRT_NEWTON_IMAGE_WAVES      // image mode of the asphere / polynomial levels (round 5 A/B: 5 waves with a 20-B spill against 4 without)
-#define PRT_NEWTON_IMAGE_WAVES 5
-#endif
-__global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LDS_TAB) ? (MODE == PRT_MODE_IMAGE ? 8 : PRT_PATH_WAVES) : ((SHAPES == PRT_SHAPES_ASPHERE || SHAPES == PRT_SHAPES_POLY) && MODE == PRT_MODE_IMAGE ? PRT_NEWTON_IMAGE_WAVES : (SHAPES == PRT_SHAPES_ASPHERE ? PRT_ASPHERE_WAVES : (SHAPES == PRT_SHAPES_POLY ? PRT_POLY_WAVES : 1)))) void k_trace_iso(
+#define PRT_NEWTON_IMAGE_WAVES 5      // image mode of the asphere / polynomial levels (round 5 A/B: 5 waves with a 20-B spill against 4 without)
+__global__ __launch_bounds__(PRT_MARCH_BLOCK, SHAPES == PRT_SHAPES_CONIC ? (MODE == PRT_MODE_IMAGE ? 8 : 1) : ((SHAPES == PRT_SHAPES_ASPHERE || SHAPES == PRT_SHAPES_POLY) && MODE == PRT_MODE_IMAGE ? PRT_NEWTON_IMAGE_WAVES : (SHAPES == PRT_SHAPES_ASPHERE ? PRT_ASPHERE_WAVES : (SHAPES == PRT_SHAPES_POLY ? PRT_POLY_WAVES : 1)))) void k_trace_iso(
     const prt_dev_surface *__restrict__ tab_g, int32_t S, int64_t N, int64_t in_pitch,
     const double *__restrict__ x0, const double *__restrict__ k0, const double *__restrict__ e_re,
     const double *__restrict__ e_im, int32_t e_mode, int64_t out_pitch,
@@ -232,15 +199,6 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
     uint8_t *__restrict__ nonconv_out = nullptr, first_uniform fu = first_uniform(), int32_t uni_rt = 0,
     img_redirect img = img_redirect()) {
     const prt_dev_surface *__restrict__ tab = tab_g;
-    if (LDS_TAB) {
-        __shared__ prt_dev_surface lds_tab[PRT_LDS_TAB_MAX];
-        const int words = S * (int)(sizeof(prt_dev_surface) / 8);
-        const double *src = reinterpret_cast<const double *>(tab_g);
-        double *dst = reinterpret_cast<double *>(lds_tab);
-        for (int w = threadIdx.x; w < words; w += PRT_MARCH_BLOCK) dst[w] = src[w];
-        __syncthreads();
-        tab = lds_tab;
-    }
     // Blocks are dealt to the XCDs round robin (block b runs on XCD b % 8: observed, not promised -- speed only).  Every
     // XCD gets ONE contiguous eighth of the bundle, so that its L2 and its translation caches see an eighth of every
     // one of the 84 rows instead of slices all along them: 1e8 rays (rows 0.8 GB apart) 10.35 -> 9.96 ms, nothing
@@ -371,38 +329,17 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
 // ---------------------------------------------------------------------------
 #define PRT_FUSED_MAX_CRYSTALS 8
 // non-temporal hint on the path stores of the crystal march (written once, never read back by the
-// kernel): 0.213 instead of 0.254 ms on BASELINE configs[3] (benchmarks/ab_crystal.py; PRT_GENERAL_PLAIN_STORES
-// builds the other variant)
-#ifndef PRT_GENERAL_PLAIN_STORES
+// kernel): 0.213 instead of 0.254 ms on BASELINE configs[3] (profiles/r02zc_ab_crystal_store_variants.json)
 #define PRT_GSTORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
-#define PRT_GSTORE(ptr, val) (*(ptr) = (val))
-#endif
 // ... but NOT on the byte masks: a wave's 64 mask bytes are half a cache line, and with the hint each of them
 // goes to memory on its own -- 0.164 ms with the hint, 0.149 without, 0.149 with no mask stores at all
-// (profiles/r02zc_ab_crystal_store_variants.json; PRT_GENERAL_NT_MASKS / PRT_DIAG_NO_MASKS build those)
-#if defined(PRT_DIAG_NO_MASKS)
-#define PRT_GSTORE_MASK(ptr, val) ((void)0)
-#elif defined(PRT_GENERAL_NT_MASKS)
-#define PRT_GSTORE_MASK(ptr, val) PRT_GSTORE(ptr, val)
-#else
+// (profiles/r02zc_ab_crystal_store_variants.json)
 #define PRT_GSTORE_MASK(ptr, val) (*(ptr) = (val))
-#endif
-#ifndef PRT_GENERAL_WAVES
+// (three waves with 165 VGPRs and no spill are 4-5 % slower: profiles/r05_ab_crystal_general_3_waves_no_spill.json)
 #define PRT_GENERAL_WAVES 4
-#endif
 // ... and of the instantiation for conic surfaces + uniaxial / isotropic crystals without E output (BASELINE
 // configs[3]), which needs 79 VGPRs and 98 B of LDS per thread
-#ifndef PRT_UNIAXIAL_WAVES
 #define PRT_UNIAXIAL_WAVES 4
-#endif
-// diagnostic builds only (benchmarks/ab_crystal.py): every store of the march lands in a 16k-ray window that
-// stays in L2 -- what the march costs when HBM takes no part
-#ifdef PRT_DIAG_L2_STORES
-#define PRT_DIAG_STORE_INDEX(i) ((i) & 16383)
-#else
-#define PRT_DIAG_STORE_INDEX(i) (i)
-#endif
 // What is parked.  Tables whose crystals are all uniaxial / isotropic (GENERAL = false): hit point, the child's wave
 // vector in the frame of the crystal, and a byte (alive | extraordinary << 1) -- 6 doubles + 1 byte; k and the ray
 // direction are rebuilt from them when the child is taken up (closed_form_ray, prt_aniso.h: bit-identical to what
@@ -412,9 +349,7 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK, (SHAPES == PRT_SHAPES_CONIC && !LD
 // slots (37 KB) leave room for four blocks per CU.  Private-memory slots are real HBM / L2 traffic: PMC
 // 1.20 GB per launch instead of 0.82 GB on BASELINE configs[3] (0.75 GB algorithmic), and 0.193 instead of
 // 0.162 ms in path mode, 0.139 instead of 0.125 ms in image mode (same arrays, benchmarks/ab_crystal.py).
-#ifndef PRT_PARK_LDS_LEVELS
 #define PRT_PARK_LDS_LEVELS 2
-#endif
 // A pointer every lane of the wave agrees on, pinned to scalar registers: "p + threadIdx" then compiles to
 // the scalar-base form of global_load / global_store (64-bit base in SGPRs + 32-bit lane offset) instead of
 // a 64-bit vector add per access -- and the optimiser cannot fold the lane index back into the base.
@@ -430,9 +365,7 @@ PRT_DEV PRT_GLOBAL_AS T *uniform_ptr(T *p) {
 
 // Block size of the crystal march alone (the walk is the same for every ray, so blocks share nothing but
 // the LDS parking slots): PRT_GENERAL_BLOCK threads.
-#ifndef PRT_GENERAL_BLOCK
 #define PRT_GENERAL_BLOCK 256
-#endif
 
 // THE WALK PROGRAM.  The depth-first walk through the tree of split rays is the same for every ray of every
 // launch on a table: which surface comes next, at which level, where a parked child is resumed, at which
@@ -586,7 +519,7 @@ __global__ __launch_bounds__(PRT_GENERAL_BLOCK, (!GENERAL && !WANT_E && SHAPES =
         const int64_t n_out = P << a_out;
         // store addresses = wave-uniform row base (scalar registers) + the thread's 32-bit offset: the
         // form global_store takes with a scalar base, no 64-bit vector arithmetic per store
-        const int64_t row = PRT_DIAG_STORE_INDEX(blk) + P * lp;
+        const int64_t row = blk + P * lp;
         const bool alive = valid;
         vec3 xh, p, g;
         double g2;

@@ -848,15 +848,15 @@ def test_bench_attributes_march_launches_to_their_configurations():
     sys.path.insert(0, ROOT)
     from benchmarks import pmc, workloads
     f = pmc.config_of_march
-    assert f("void k_trace_iso<0, true, true, 0, false, false, true, false>(prt_dev_surface const*)") == "doublegauss"
-    assert f("void k_trace_iso<0, true, true, 0, false, false, false, false>(...)") == "benchmark"
-    assert f("void k_trace_iso<0, true, true, 1, false, false, true, false>(...)") == "asphere"
-    assert f("void k_trace_iso<0, true, true, 2, false, false, true, false>(...)") == "xypoly"
+    assert f("void k_trace_iso<0, true, true, 0, false, true, false>(prt_dev_surface const*)") == "doublegauss"
+    assert f("void k_trace_iso<0, true, true, 0, false, false, false>(...)") == "benchmark"
+    assert f("void k_trace_iso<0, true, true, 1, false, true, false>(...)") == "asphere"
+    assert f("void k_trace_iso<0, true, true, 2, false, true, false>(...)") == "xypoly"
     assert f("void k_trace_general<0, false, true, false, 0>(...)") == "aniso"
     assert f("void k_trace_general<0, true, true, false, 0>(...)") == "aniso_biaxial"
     assert f("void k_propagate(...)") is None
     L = pmc.PMC_LAUNCHES
-    rows = [{"Kernel_Name": "void k_trace_iso<0, true, true, 0, false, false, true, false>()", "Dispatch_Id": str(10 + i),
+    rows = [{"Kernel_Name": "void k_trace_iso<0, true, true, 0, false, true, false>()", "Dispatch_Id": str(10 + i),
              "Counter_Name": "WRITE_SIZE", "Counter_Value": "1"} for i in range(L)] + \
            [{"Kernel_Name": "void k_trace_general<0, true, true, false, 0>()", "Dispatch_Id": str(40 + i),
              "Counter_Name": "WRITE_SIZE", "Counter_Value": "2"} for i in range(L)] + \

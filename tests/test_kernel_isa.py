@@ -35,20 +35,19 @@ def test_no_flat_memory_operations_in_the_march_kernels(isa):
 
 
 def _iso_args(name):
-    """k_trace_iso<MODE,VEC_IN,VEC_OUT,SHAPES,LDS_TAB,MOMENTS,UNI,IMG> -> the eight template arguments"""
+    """k_trace_iso<MODE,VEC_IN,VEC_OUT,SHAPES,MOMENTS,UNI,IMG> -> the seven template arguments"""
     return [int(v) for v in name[len("k_trace_iso<"):-1].split(",")]
 
 
 def test_store_only_loops_never_wait_on_the_memory_counter(isa):
-    """conic (SHAPES = 0), asphere (1) and polynomial / biconic (2) instantiations without the LDS-table variant,
-    path mode: their surface loop contains stores and scalar loads only, so no vmcnt wait may appear in it --
+    """conic (SHAPES = 0), asphere (1) and polynomial / biconic (2) instantiations, path mode: their surface loop contains stores and scalar loads only, so no vmcnt wait may appear in it --
     with the uniform first segment and the fused moments as well"""
     seen = 0
     for (name, k) in isa.items():
         if not name.startswith("k_trace_iso<"):
             continue
-        (mode, _vi, _vo, shapes, lds, _mom, _uni, _img) = _iso_args(name)
-        if mode == 0 and shapes in (0, 1, 2) and not lds:
+        (mode, _vi, _vo, shapes, _mom, _uni, _img) = _iso_args(name)
+        if mode == 0 and shapes in (0, 1, 2):
             assert k["vmcnt_waits_in_loops"] == 0 and k["scratch_bytes_per_lane"] == 0, name
             seen += 1
     assert seen >= 20
@@ -56,14 +55,14 @@ def test_store_only_loops_never_wait_on_the_memory_counter(isa):
 
 def test_registers_and_occupancy_of_the_baseline_instantiations(isa):
     for uni in (0, 1):                            # arrays k0 / E0, and the uniform first segment of collimated bundles
-        head = isa["k_trace_iso<0,1,1,0,0,0,%d,0>" % uni]   # BASELINE configs[1]: path mode, 2 rays per lane, conics only
+        head = isa["k_trace_iso<0,1,1,0,0,%d,0>" % uni]   # BASELINE configs[1]: path mode, 2 rays per lane, conics only
         assert head["scratch_bytes_per_lane"] == 0 and head["waves_per_simd"] >= 7 and head["vgprs"] <= 72
-        asph = isa["k_trace_iso<0,1,1,1,0,0,%d,0>" % uni]   # configs[2]: conics + even aspheres
+        asph = isa["k_trace_iso<0,1,1,1,0,%d,0>" % uni]   # configs[2]: conics + even aspheres
         assert asph["scratch_bytes_per_lane"] == 0 and asph["waves_per_simd"] >= 5 and asph["vgprs"] <= 96
         # conics + aspheres + XY polynomials + biconics (north_star's shapes + SURVEY 8 f3): <= 96 VGPRs = 5 waves
-        poly = isa["k_trace_iso<0,1,1,2,0,0,%d,0>" % uni]
+        poly = isa["k_trace_iso<0,1,1,2,0,%d,0>" % uni]
         assert poly["scratch_bytes_per_lane"] == 0 and poly["waves_per_simd"] >= 5 and poly["vgprs"] <= 96
-        image = isa["k_trace_iso<1,1,1,0,0,0,%d,0>" % uni]  # image mode of the conic march: capped at 64 VGPRs for 8 waves
+        image = isa["k_trace_iso<1,1,1,0,0,%d,0>" % uni]  # image mode of the conic march: capped at 64 VGPRs for 8 waves
         assert image["waves_per_simd"] == 8
     # configs[3]: conic surfaces, uniaxial crystals, parking slots in LDS, no E output (k_trace_general<MODE, GENERAL,
     # PARK_LDS, WANT_E, SHAPES>): no scratch, NO vmcnt wait inside the walk, and -- the ray directions coming from
@@ -74,5 +73,5 @@ def test_registers_and_occupancy_of_the_baseline_instantiations(isa):
     assert crystal["vmcnt_waits_in_loops"] == 0
     # path rows through a scalar base + lane offset; only the byte masks keep 64-bit lane addresses
     assert crystal["scalar_base_stores"] >= 12 and crystal["vector_address_stores"] <= 6
-    allshapes = isa["k_trace_iso<0,1,1,3,0,0,0,0>"]   # every explicit shape compiled in (sag grids, combinations)
+    allshapes = isa["k_trace_iso<0,1,1,3,0,0,0>"]   # every explicit shape compiled in (sag grids, combinations)
     assert allshapes["scratch_bytes_per_lane"] == 0 and allshapes["waves_per_simd"] >= 4
