@@ -433,6 +433,8 @@ def measure_e2e(dev, rays=10_000_000, small_rays=1000, calls=200):
     """The reference times the whole ``s.seqtrace(...)`` call (demos/demo_benchmark.py:76-78).  Here: the double Gauss of
     configs[1] through ``dropin.seqtrace`` with HOST arrays in and ``list[RayPath]`` out (lazy: results stay on the
     device until looked at), all times wall clock and synchronised:
+      first_call_ms             the first call on this bundle size in this (warm) process: table upload, arena buffers of a
+                                new size, launch
       h2d_ms                    upload of the bundle (x0 alone: a collimated bundle is recognised as uniform)
       seqtrace_call_ms          host arrays in -> list[RayPath] out (upload + table + launch), steady state (median of 5)
       seqtrace_device_bundle_ms the same call on a bundle that is already on the device
@@ -617,9 +619,6 @@ def run_single_gpu(args, dev, watchdog, headline):
     e2e = None
     if full and not args.no_e2e and args.rays is None:
         stage("end to end (drop-in call)")
-        if args.placement == "arena" and placed.DISABLED is None:
-            torch.cuda.synchronize()
-            placed.PlacedArena.for_device(dev.index).trim()
         try:
             e2e = measure_e2e(dev)
         except (RuntimeError, MemoryError) as exc:
