@@ -885,3 +885,55 @@ def test_bench_attributes_march_launches_to_their_configurations():
     assert sorted(set(c for (c, _, _) in got)) == ["aniso", "doublegauss"]
     assert set(workloads.SECONDARY_MARCH_CONFIGS) | set(workloads.SECONDARY_CUSTOM_CONFIGS) == \
         {"aniso_biaxial", "aniso_chain", "plugin", "image_moments"}
+
+
+def test_bench_condenses_a_full_run_into_a_line_the_driver_can_keep():
+    """Round 5's bench line had grown to 25 KB and the driver could not parse it; nothing in the tree could have caught
+    that.  ``bench.compact_single`` + ``bench.emit`` on the FULL records of a real default run (profiles/
+    r06b_bench_detail.json: nine configurations, scaling point, end to end): the line is one JSON object of < 8 KB with
+    the contract's keys, the roofline is reproducible from its own parts, every configuration appears in the summary --
+    and a record that does outgrow the limit is cut down (and says so) instead of being printed."""
+    import importlib.util
+    import json
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_for_compaction", os.path.join(ROOT, "bench.py"))
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    with open(os.path.join(ROOT, "profiles", "r06b_bench_detail.json")) as f:
+        detail = json.load(f)
+    base = {"metric": "ray_surface_ops_per_s", "unit": "ray-surface-ops/s", "n_gpus": 1, "steps": 200, "warmup": 20,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+    recs = detail["configs"]
+    line = bench.compact_single(base, recs[0], recs, detail["scaling_point"], detail["e2e"], detail["arena"], detail["build"],
+                                detail["wall_s_by_stage"])
+    (r, w) = os.pipe()
+    bench.emit(w, line)
+    os.close(w)
+    text = os.read(r, 1 << 16).decode()
+    os.close(r)
+    assert text.endswith("\n") and text.count("\n") == 1 and len(text) < 8192 and len(text) < 4096, len(text)
+    d = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "verified", "scaling_point", "e2e"):
+        assert key in d, key
+    rf = d["roofline"]
+    assert abs(rf["algorithmic_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9 / rf["peak"] - rf["frac"]) < 1e-4
+    assert rf["traffic"] is not None and abs(rf["traffic_ratio_to_algorithmic"] - 1.0) < 0.01 and rf["ops_vs_98B_convention"] > 1
+    assert set(d["config"]["configs_summary"]) == {"doublegauss", "asphere", "aniso", "xypoly", "benchmark", "aniso_biaxial",
+                                                   "aniso_chain", "plugin", "image_moments", "scaling_point_1e8_rays"}
+    assert d["config"]["configs_summary"]["plugin"][3] is not None          # measured traffic of the per-surface path
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["verified"]["ok"]
+    # a record that outgrows the limit is cut down, not printed
+    fat = dict(line, config=dict(line["config"], configs_summary={("cfg%d" % i): [1.0, 0.5, True, 1.0, "x" * 90] for i in range(90)}))
+    (r, w) = os.pipe()
+    bench.emit(w, fat)
+    os.close(w)
+    text = os.read(r, 1 << 16).decode()
+    os.close(r)
+    cut = json.loads(text)
+    assert len(text) < 8192 and "truncated" in cut and cut["roofline"] == line["roofline"] and cut["value"] == line["value"]
