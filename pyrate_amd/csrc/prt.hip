@@ -1443,14 +1443,6 @@ static bool rows_vectorisable(std::initializer_list<const void *> ptrs, std::ini
     return true;
 }
 
-// EXPERIMENT (round 6): the direction a per-surface kernel walks the bundle in.  PRT_ROWS_PINGPONG=1: interact walks
-// it backwards, propagate forwards -- each kernel then starts with the rays its predecessor touched LAST, whose lines
-// may still sit in the memory-side cache (256 MB; a kernel moves 740 MB).
-static int32_t rows_direction(int which) {
-    static const int mode = getenv("PRT_ROWS_PINGPONG") ? atoi(getenv("PRT_ROWS_PINGPONG")) : 0;
-    return (mode == 1 && which == 1) || (mode == 2 && which == 0) ? 1 : 0;
-}
-
 static int rows_shape_level(int32_t shape_type) {
     if (shape_type == PRT_SHAPE_CONIC) return PRT_SHAPES_CONIC;
     if (shape_type == PRT_SHAPE_ASPHERE) return PRT_SHAPES_ASPHERE;
@@ -1480,8 +1472,7 @@ int32_t prt_propagate_rows(const prt_system_t *sys, int32_t surface, int64_t n, 
     const int e_mode = e_mode_of(e_re, use_default_e);
 #define PRT_LAUNCH_PROPAGATE_ROWS(VEC_, SH_)                                                                          \
     hipLaunchKernelGGL((k_propagate_rows<VEC_, SH_>), grid, block, 0, (hipStream_t)stream, sys->d_table + surface, n, x, \
-                       x_pitch, k, k_pitch, dir, e_re, e_im, e_mode, valid_in, x_hit, out_pitch, valid, nonconv,           \
-                       rows_direction(0))
+                       x_pitch, k, k_pitch, dir, e_re, e_im, e_mode, valid_in, x_hit, out_pitch, valid, nonconv)
     // (the instantiation with this surface's shape code alone: a conic needs 60-odd registers, the general case 128)
     const int level = rows_shape_level(sys->h_table[surface].shape_type);
     if (!vec) PRT_LAUNCH_PROPAGATE_ROWS(false, PRT_SHAPES_ALL);
@@ -1516,7 +1507,7 @@ int32_t prt_interact_rows(const prt_system_t *sys, int32_t surface, int64_t n, c
     const dim3 grid(nblocks((n + 1) / 2, PRT_MARCH_BLOCK)), block(PRT_MARCH_BLOCK);
 #define PRT_LAUNCH_INTERACT_ROWS(VEC_, SH_)                                                                            \
     hipLaunchKernelGGL((k_interact_iso_rows<VEC_, SH_>), grid, block, 0, (hipStream_t)stream, sys->d_table + surface, n, \
-                       x_hit, x_pitch, k, k_pitch, valid_in, k_out, out_pitch, dir_out, valid_out, rows_direction(1))
+                       x_hit, x_pitch, k, k_pitch, valid_in, k_out, out_pitch, dir_out, valid_out)
     if (!vec) PRT_LAUNCH_INTERACT_ROWS(false, PRT_SHAPES_ALL);
     else if (sys->h_table[surface].shape_type == PRT_SHAPE_CONIC) PRT_LAUNCH_INTERACT_ROWS(true, PRT_SHAPES_CONIC);
     else PRT_LAUNCH_INTERACT_ROWS(true, PRT_SHAPES_ALL);

@@ -772,6 +772,9 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_interact_iso(
 // kernels above when they also write the ray direction.  After an isotropic interaction the ray direction is parallel
 // to k (E is perpendicular to k: ray.py:136-152), and conic_t / explicit_t are homogeneous in d, so the step takes the
 // unnormalised k with d2 = k.k -- what the fused march does (k_trace_iso).
+// (Tried in round 6 and removed: each kernel walking the bundle in the opposite direction of its predecessor, so that it
+// starts with the lines touched last -- memory-side cache, 256 MB against 740 MB per kernel: 2.954 -> 2.947 ms per sweep,
+// nothing: profiles/r06d_ab_plugin_traversal_and_placement.txt.)
 // ---------------------------------------------------------------------------
 template <bool VEC>
 PRT_DEV void load_mask2(const uint8_t *__restrict__ m, int64_t i, bool second, bool b[2]) {
@@ -804,9 +807,8 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK) void k_propagate_rows(
     const double *__restrict__ k_in, int64_t k_pitch, const double *__restrict__ dir_in,
     const double *__restrict__ e_re, const double *__restrict__ e_im, int32_t e_mode,
     const uint8_t *__restrict__ valid_in, double *__restrict__ xh_out, int64_t out_pitch,
-    uint8_t *__restrict__ valid_out, uint8_t *__restrict__ nonconv_out, int32_t reverse) {
-    const int64_t blk = reverse ? (int64_t)gridDim.x - 1 - blockIdx.x : (int64_t)blockIdx.x;
-    const int64_t i = (blk * PRT_MARCH_BLOCK + threadIdx.x) * 2;
+    uint8_t *__restrict__ valid_out, uint8_t *__restrict__ nonconv_out) {
+    const int64_t i = ((int64_t)blockIdx.x * PRT_MARCH_BLOCK + threadIdx.x) * 2;
     if (i >= N) return;
     const bool second = (i + 1 < N);
     vec3 x[2], d[2];
@@ -847,9 +849,8 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK) void k_interact_iso_rows(
     const prt_dev_surface *__restrict__ sf, int64_t N, const double *__restrict__ xh_in, int64_t x_pitch,
     const double *__restrict__ k_in, int64_t k_pitch, const uint8_t *__restrict__ valid_in,
     double *__restrict__ k_out, int64_t out_pitch, double *__restrict__ dir_out,
-    uint8_t *__restrict__ valid_out, int32_t reverse) {
-    const int64_t blk = reverse ? (int64_t)gridDim.x - 1 - blockIdx.x : (int64_t)blockIdx.x;
-    const int64_t i = (blk * PRT_MARCH_BLOCK + threadIdx.x) * 2;
+    uint8_t *__restrict__ valid_out) {
+    const int64_t i = ((int64_t)blockIdx.x * PRT_MARCH_BLOCK + threadIdx.x) * 2;
     if (i >= N) return;
     const bool second = (i + 1 < N);
     vec3 xh[2], k[2];

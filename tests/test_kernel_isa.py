@@ -75,3 +75,19 @@ def test_registers_and_occupancy_of_the_baseline_instantiations(isa):
     assert crystal["scalar_base_stores"] >= 12 and crystal["vector_address_stores"] <= 6
     allshapes = isa["k_trace_iso<0,1,1,3,0,0,0>"]   # every explicit shape compiled in (sag grids, combinations)
     assert allshapes["scratch_bytes_per_lane"] == 0 and allshapes["waves_per_simd"] >= 4
+
+
+def test_the_per_surface_kernels_of_big_bundles(isa):
+    """k_propagate_rows<VEC, SHAPES> / k_interact_iso_rows<VEC, SHAPES> (round 6: Material.propagate / refract at plugin
+    granularity): the instantiation for a conic surface -- what the double Gauss runs, 24 launches per sweep -- keeps the
+    register count of a streaming kernel (8 waves per SIMD), no instantiation spills or uses flat addressing, and the
+    two-rays-per-thread form moves a row with global_load / global_store dwordx4"""
+    conic_p = isa["k_propagate_rows<1,0>"]
+    conic_i = isa["k_interact_iso_rows<1,0>"]
+    assert conic_p["vgprs"] <= 64 and conic_p["waves_per_simd"] == 8 and conic_i["vgprs"] <= 64 and conic_i["waves_per_simd"] == 8
+    names = [n for n in isa if n.startswith(("k_propagate_rows<", "k_interact_iso_rows<"))]
+    assert len(names) == 8, names          # propagate: 4 shape classes (VEC) + the unaligned fall-back; interact: conic, general, fall-back
+    for n in names:
+        assert isa[n]["scratch_bytes_per_lane"] == 0 and isa[n]["flat_memory_ops"] == 0, n
+    for level in (1, 2):                   # aspheres; XY polynomials / biconics: their own Newton code only
+        assert isa["k_propagate_rows<1,%d>" % level]["vgprs"] <= 72, level
