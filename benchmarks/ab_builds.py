@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 
 import torch
 
-import bench
+from benchmarks import workloads as bench
 from pyrate_amd import engine, _lib
 
 dev = torch.device("cuda", 0)

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
-import bench
+from benchmarks import workloads as bench
 from pyrate_amd import engine, _lib
 
 

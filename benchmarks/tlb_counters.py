@@ -32,7 +32,7 @@ LAUNCHES = 6
 
 def inner(rays):
     import torch
-    import bench
+    from benchmarks import workloads as bench
     from pyrate_amd import engine, _lib
     dev = torch.device("cuda", 0)
     wl = bench.make_workload("doublegauss", rays, dev)
