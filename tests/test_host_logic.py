@@ -937,3 +937,45 @@ def test_bench_condenses_a_full_run_into_a_line_the_driver_can_keep():
     os.close(r)
     cut = json.loads(text)
     assert len(text) < 8192 and "truncated" in cut and cut["roofline"] == line["roofline"] and cut["value"] == line["value"]
+
+
+def test_row_pool_carves_arrays_out_of_buffers_of_a_kind_its_caller_does_not_read(monkeypatch):
+    """placed.RowPool (round 6: the arrays of DeviceSystem.propagate / interact on big bundles): pieces are carved front
+    to back out of 1-GiB arena buffers, never twice; a request names the kinds of HBM to stay out of (the kinds of the
+    arrays the same kernel READS) and gets a piece of another kind -- from a buffer at hand if one has room, else a new
+    buffer asked for with exactly that avoid mask.  (A fake arena stands in for the device.)"""
+    import torch
+    from pyrate_amd import placed
+
+    class MetaArena(object):          # (a meta tensor has the sizes of a 1-GiB buffer without the memory)
+        def __init__(self):
+            self.calls = []
+
+        def alloc(self, sizes, n_distinct=2, avoid_mask=0, max_hunt_slabs=-1):
+            self.calls.append((list(sizes), n_distinct, avoid_mask))
+            kind = [q for q in range(3) if not (avoid_mask >> q) & 1][0]
+            return [torch.empty(int(s), dtype=torch.uint8, device="meta") for s in sizes], [kind]
+    arena = MetaArena()
+    monkeypatch.setattr(placed.PlacedArena, "for_device", classmethod(lambda cls, index: arena))
+    pool = placed.RowPool()
+    dev = torch.device("cuda", 0)            # (only its index is looked at)
+    piece = 250 << 20
+    (a, ka) = pool.take(dev, piece, avoid_kinds=(0, 1))
+    assert ka == 2 and arena.calls == [([1 << 30], 1, 0b011)] and a.numel() == piece
+    (b, kb) = pool.take(dev, piece, avoid_kinds=(0, None))          # kind 2's buffer has room: no new buffer
+    assert kb == 2 and len(arena.calls) == 1
+    assert b.storage_offset() == a.storage_offset() + piece and b.storage_offset() % 4096 == 0      # front to back
+    (c, kc) = pool.take(dev, piece, avoid_kinds=(2, 1))
+    assert kc == 0 and arena.calls[-1] == ([1 << 30], 1, 0b110)
+    for _ in range(2):
+        pool.take(dev, piece, avoid_kinds=(0, 1))                      # kind 2's buffer: 4 pieces of 250 MiB fit
+    assert len(arena.calls) == 2
+    (d, kd) = pool.take(dev, piece, avoid_kinds=(0, 1))                # the fifth does not: a new buffer of that kind
+    assert kd == 2 and len(arena.calls) == 3 and d.storage_offset() == 0
+    (e, ke) = pool.take(dev, 3 << 30, avoid_kinds=())                  # bigger than a slab: a buffer of its own size
+    assert arena.calls[-1][0] == [3 << 30] and e.numel() == 3 << 30
+    (f, kf) = pool.take(dev, 1000, avoid_kinds=(ke,))
+    assert kf != ke and f.numel() == 4096                              # pieces are whole 4-KiB pages
+    pool.clear()
+    pool.take(dev, piece, avoid_kinds=())
+    assert arena.calls[-1][0] == [1 << 30]
