@@ -163,9 +163,10 @@ def _event_timed(fn, steps, warmup):
     return a.elapsed_time(b) / steps, (time.perf_counter() - t0) / steps * 1e3
 
 
-def plugin_sweep(dev, rays, placement="auto", tap=None):
+def plugin_sweep(dev, rays, placement="auto", tap=None, fused=False):
     """(sweep, ctx): ``sweep()`` drives the double Gauss surface by surface through DeviceSystem.propagate /
-    DeviceSystem.interact (prt_propagate_rows + prt_interact_rows), the loop of optical_element.py:336-375; ``tap(s, x_hit,
+    DeviceSystem.interact (prt_propagate_rows + prt_interact_rows), the loop of optical_element.py:336-375 -- or, ``fused``,
+    through DeviceSystem.surface_step (prt_surface_step_rows: both calls of a surface in one launch); ``tap(s, x_hit,
     valid_hit, k_out, valid_out)`` sees every surface's arrays.  ``ctx['last']`` = the last surface's arrays."""
     from pyrate_amd import engine
     wl = make_workload("doublegauss", rays, dev, first_segment="arrays")
@@ -177,11 +178,15 @@ def plugin_sweep(dev, rays, placement="auto", tap=None):
         (x, k, valid) = (x0, k0, None)
         see = ctx["tap"]
         for s in range(S):
-            if s == 0:
-                (xh, v) = sysd.propagate(0, x, k, e_re=e0, valid_in=None, placement=placement)
+            if fused:
+                (xh, k, v, valid) = sysd.surface_step(s, x, k, e_re=e0 if s == 0 else None, default_e=False,
+                                                      valid_in=valid, placement=placement)
             else:
-                (xh, v) = sysd.propagate(s, x, k, default_e=False, valid_in=valid, placement=placement)
-            (k, _, valid, _, _) = sysd.interact(s, xh, k, valid_in=v, placement=placement)
+                if s == 0:
+                    (xh, v) = sysd.propagate(0, x, k, e_re=e0, valid_in=None, placement=placement)
+                else:
+                    (xh, v) = sysd.propagate(s, x, k, default_e=False, valid_in=valid, placement=placement)
+                (k, _, valid, _, _) = sysd.interact(s, xh, k, valid_in=v, placement=placement)
             x = xh
             if see is not None:
                 see(s, xh, v, k, valid)
@@ -189,16 +194,18 @@ def plugin_sweep(dev, rays, placement="auto", tap=None):
     return sweep, ctx
 
 
-def measure_plugin(args, dev, rays, with_oracle=True, m=10_000):
+def measure_plugin(args, dev, rays, with_oracle=True, m=10_000, fused=False):
     """The double Gauss through the PLUGIN-GRANULAR calls: per surface one propagate (Material.propagate ->
     Surface.intersect) and one interact (Material.refract), the loop of optical_element.py:336-375 -- what a
     caller gets who drives the trace surface by surface.  Roof: SURVEY 8d's 98 B per ray-surface-op (one read and one
     write of the 49-B state per surface); two calls per surface cannot move less than 148 B (each of them reads the state
     it works on).  Verified: every surface's record of a 1e4-ray sample against the CPU oracle, and the last surface's
-    record of ALL rays against the fused march (masks bit for bit)."""
+    record of ALL rays against the fused march (masks bit for bit).
+    ``fused`` (config ``surface_step``): one launch per surface, DeviceSystem.surface_step = both calls of the surface
+    (prt_surface_step_rows) -- 98 B per op, SURVEY 8d's figure itself."""
     from pyrate_amd import engine, _lib
     placement = "auto" if args.placement == "arena" else "torch"
-    (sweep, ctx) = plugin_sweep(dev, rays, placement=placement)
+    (sweep, ctx) = plugin_sweep(dev, rays, placement=placement, fused=fused)
     (wl, sysd) = (ctx["wl"], ctx["sysd"])
     (x0, k0, e0, n, S) = (wl["x0"], wl["k0"], wl["e0"], wl["n_local"], wl["S"])
     steps = max(5, min(args.steps, 20))
@@ -256,20 +263,25 @@ def measure_plugin(args, dev, rays, with_oracle=True, m=10_000):
     if placement == "auto" and placed.DISABLED is None:
         arena = placed.PlacedArena.for_device(dev.index)
         kinds = [arena.kind_of(last[q]) for q in ("x", "k")]
-    rec = {"name": "plugin", "workload": "the double Gauss of configs[1] (%d rays x %d surfaces) through the plugin-granular "
-                                         "calls: DeviceSystem.propagate + DeviceSystem.interact per surface "
-                                         "(Material.propagate / Surface.intersect / Material.refract, "
-                                         "optical_element.py:336-375)" % (n, S),
+    floor = 98.0 if fused else 148.0
+    rec = {"name": "surface_step" if fused else "plugin",
+           "workload": ("the double Gauss of configs[1] (%d rays x %d surfaces) surface by surface: " % (n, S)) + (
+               "DeviceSystem.surface_step per surface (prt_surface_step_rows: Material.propagate + Material.refract of a surface "
+               "in one launch, the loop body of optical_element.py:336-375)" if fused else
+               "the plugin-granular calls, DeviceSystem.propagate + DeviceSystem.interact per surface (Material.propagate / "
+               "Surface.intersect / Material.refract, optical_element.py:336-375)"),
            "value": ops / (wall_ms * 1e-3), "unit": "ray-surface-ops/s", "steps": steps, "ms_per_step": wall_ms,
            "rays": n, "surfaces": S, "mode": "per-surface calls", "dtype": "f64",
            "output_placement": {"policy": placement, "kinds_of_last_x_and_k": kinds},
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_propagate_rows + k_interact_iso_rows",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "k_surface_step_rows" if fused else "k_propagate_rows + k_interact_iso_rows",
                         "kernel_ms": ms, "algorithmic_bytes_per_launch": 98.0 * ops, "bytes_per_ray_surface_op": 98.0,
-                        "note": "kernel_ms = device time of one sweep over the 12 surfaces (24 launches), HIP events; "
-                                "floor of two calls per surface: 148 B per op (each call reads the 49-B state it works on)",
-                        "floor_bytes_per_ray_surface_op": 148.0,
-                        "frac_at_floor_traffic": 148.0 * ops / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                        "note": ("kernel_ms = device time of one sweep over the 12 surfaces (12 launches), HIP events" if fused
+                                 else "kernel_ms = device time of one sweep over the 12 surfaces (24 launches), HIP events; "
+                                      "floor of two calls per surface: 148 B per op (each call reads the 49-B state it works on)"),
+                        "floor_bytes_per_ray_surface_op": floor,
+                        "frac_at_floor_traffic": floor * ops / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "verified": {"ok": bool(ok), "what": "every surface's record of a sample against the CPU oracle; the last surface's "
                                                 "record of all rays against the fused march's (masks bit for bit)",
                         "oracle_sample": sample, "max_rel_x": sample["max_rel_x"] if sample else None,
@@ -552,9 +564,9 @@ def run_single_gpu(args, dev, watchdog, headline):
     per_trace = {}
     for c in list(configs):
         stage("measure " + c)
-        if c == "plugin":                # (--configs plugin: the custom measurements on their own, for experiments)
-            recs.append(measure_plugin(args, dev, rays_of[c], with_oracle=not args.no_cpu_baseline))
-            per_trace["plugin"] = 2 * recs[-1]["surfaces"]
+        if c in ("plugin", "surface_step"):    # (--configs plugin: the custom measurements on their own, for experiments)
+            recs.append(measure_plugin(args, dev, rays_of[c], with_oracle=not args.no_cpu_baseline, fused=(c == "surface_step")))
+            per_trace[c] = (1 if c == "surface_step" else 2) * recs[-1]["surfaces"]
         elif c == "image_moments":
             recs.append(measure_image_moments(args, dev, rays_of[c]))
             configs.remove(c)            # (no PMC pass of its own)

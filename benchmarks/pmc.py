@@ -24,7 +24,7 @@ PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
               ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64",
                "SQ_INSTS_VALU"))
 PMC_LAUNCHES = 6
-PER_SURFACE_CONFIGS = ("plugin", "aniso_chain")       # traces that are two launches per surface
+PER_SURFACE_CONFIGS = ("plugin", "surface_step", "aniso_chain")       # traces that are one or two launches per surface
 
 
 def inner(args, dev):
@@ -33,8 +33,8 @@ def inner(args, dev):
     from pyrate_amd import engine, _lib
     from . import workloads, configs
     for config in args.pmc_inner.split(","):
-        if config == "plugin":
-            (sweep, _) = configs.plugin_sweep(dev, args.rays_of[config], placement="torch")
+        if config in ("plugin", "surface_step"):
+            (sweep, _) = configs.plugin_sweep(dev, args.rays_of[config], placement="torch", fused=(config == "surface_step"))
             for _ in range(PMC_LAUNCHES):
                 sweep()
             torch.cuda.synchronize()
@@ -61,7 +61,7 @@ def is_march(kernel_name):
 
 
 def is_per_surface(kernel_name):
-    return "k_propagate" in kernel_name or "k_interact_" in kernel_name
+    return "k_propagate" in kernel_name or "k_interact_" in kernel_name or "k_surface_step" in kernel_name
 
 
 def config_of_march(kernel_name):

@@ -404,6 +404,11 @@ int32_t prt_interact(const prt_system_t *sys, int32_t surface, int64_t n, const 
  *     NULL -> k_out (3, n | out_pitch), valid_out (n) or NULL, dir_out (3, n | out_pitch) or NULL (unit k; nobody
  *     needs it between two of these calls).
  * 148 B of HBM traffic per ray and surface for the pair (each call reads the 49-B state it works on and writes 25 B).
+ *   prt_surface_step_rows: BOTH calls of one surface in one launch -- the loop body of OpticalElement.seqtrace
+ *     (raytracer/optical_element.py:336-375: propagate to the surface, then refract | reflect there) for records with an
+ *     isotropic, lossless medium behind the surface: x, k (+ dir / E as in prt_propagate_rows), valid_in -> x_hit, k_out
+ *     (3, n | out_pitch), valid (n: hit the surface inside the aperture), valid_out (n: and left it), nonconv (n) or NULL.
+ *     98 B per ray and surface (SURVEY.md 8d's figure: the 49-B state read once, the 49-B record written once).
  */
 int32_t prt_propagate_rows(const prt_system_t *sys, int32_t surface, int64_t n, const double *x, int64_t x_pitch,
                            const double *k, int64_t k_pitch, const double *dir, const double *e_re,
@@ -412,6 +417,11 @@ int32_t prt_propagate_rows(const prt_system_t *sys, int32_t surface, int64_t n, 
 int32_t prt_interact_rows(const prt_system_t *sys, int32_t surface, int64_t n, const double *x_hit, int64_t x_pitch,
                           const double *k, int64_t k_pitch, const uint8_t *valid_in, double *k_out,
                           int64_t out_pitch, double *dir_out, uint8_t *valid_out, void *stream);
+int32_t prt_surface_step_rows(const prt_system_t *sys, int32_t surface, int64_t n, const double *x, int64_t x_pitch,
+                              const double *k, int64_t k_pitch, const double *dir, const double *e_re,
+                              const double *e_im, int32_t use_default_e, const uint8_t *valid_in, double *x_hit,
+                              double *k_out, int64_t out_pitch, uint8_t *valid, uint8_t *valid_out, uint8_t *nonconv,
+                              void *stream);
 
 /*
  * The same plugin call with COMPLEX wave vectors (absorbing media: a complex epsilon tensor,

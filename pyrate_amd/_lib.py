@@ -69,6 +69,10 @@ PROTOTYPES = {
     "prt_propagate_rows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, c_double_p, ctypes.c_int64,
                                             c_double_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p, ctypes.c_int32,
                                             c_u8_p, c_double_p, ctypes.c_int64, c_u8_p, c_u8_p, c_stream]),
+    "prt_surface_step_rows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, c_double_p, ctypes.c_int64,
+                                               c_double_p, ctypes.c_int64, c_double_p, c_double_p, c_double_p, ctypes.c_int32,
+                                               c_u8_p, c_double_p, c_double_p, ctypes.c_int64, c_u8_p, c_u8_p, c_u8_p,
+                                               c_stream]),
     "prt_interact_rows": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, c_double_p, ctypes.c_int64,
                                            c_double_p, ctypes.c_int64, c_u8_p, c_double_p, ctypes.c_int64, c_double_p,
                                            c_u8_p, c_stream]),

@@ -1516,6 +1516,45 @@ int32_t prt_interact_rows(const prt_system_t *sys, int32_t surface, int64_t n, c
     return PRT_OK;
 }
 
+int32_t prt_surface_step_rows(const prt_system_t *sys, int32_t surface, int64_t n, const double *x, int64_t x_pitch,
+                              const double *k, int64_t k_pitch, const double *dir, const double *e_re, const double *e_im,
+                              int32_t use_default_e, const uint8_t *valid_in, double *x_hit, double *k_out,
+                              int64_t out_pitch, uint8_t *valid, uint8_t *valid_out, uint8_t *nonconv, void *stream) {
+    PRT_SYS_USABLE(sys);
+    if (!sys || surface < 0 || surface >= sys->n_surfaces || n < 0)
+        return fail(PRT_ERR_INVALID_ARG, "prt_surface_step_rows: bad system / surface / count");
+    if (n == 0) return PRT_OK;
+    if (!x || !k || !x_hit || !k_out || !valid || !valid_out)
+        return fail(PRT_ERR_INVALID_ARG, "prt_surface_step_rows: null pointer");
+    if (sys->complex_eps || sys->h_table[surface].mat_type == PRT_MAT_ANISOTROPIC)
+        return fail(PRT_ERR_UNSUPPORTED, "prt_surface_step_rows: isotropic, lossless media only (crystals double the rays: "
+                                         "prt_propagate + prt_interact; absorbing media: prt_interact_cplx)");
+    if (!x_pitch) x_pitch = n;
+    if (!k_pitch) k_pitch = n;
+    if (!out_pitch) out_pitch = n;
+    if (x_pitch < n || k_pitch < n || out_pitch < n)
+        return fail(PRT_ERR_INVALID_ARG, "prt_surface_step_rows: a row pitch shorter than the bundle");
+    PRT_ON_DEVICE(sys->device);
+    const bool vec = rows_vectorisable({x, k, dir, e_re, e_im, x_hit, k_out}, {x_pitch, k_pitch, out_pitch}) &&
+                     !((reinterpret_cast<uintptr_t>(valid_in) | reinterpret_cast<uintptr_t>(valid) |
+                        reinterpret_cast<uintptr_t>(valid_out) | reinterpret_cast<uintptr_t>(nonconv)) & 1u);
+    const dim3 grid(nblocks((n + 1) / 2, PRT_MARCH_BLOCK)), block(PRT_MARCH_BLOCK);
+    const int e_mode = e_mode_of(e_re, use_default_e);
+#define PRT_LAUNCH_STEP_ROWS(VEC_, SH_)                                                                                  \
+    hipLaunchKernelGGL((k_surface_step_rows<VEC_, SH_>), grid, block, 0, (hipStream_t)stream, sys->d_table + surface, n, \
+                       x, x_pitch, k, k_pitch, dir, e_re, e_im, e_mode, valid_in, x_hit, k_out, out_pitch, valid,        \
+                       valid_out, nonconv)
+    const int level = rows_shape_level(sys->h_table[surface].shape_type);
+    if (!vec) PRT_LAUNCH_STEP_ROWS(false, PRT_SHAPES_ALL);
+    else if (level == PRT_SHAPES_CONIC) PRT_LAUNCH_STEP_ROWS(true, PRT_SHAPES_CONIC);
+    else if (level == PRT_SHAPES_ASPHERE) PRT_LAUNCH_STEP_ROWS(true, PRT_SHAPES_ASPHERE);
+    else if (level == PRT_SHAPES_POLY) PRT_LAUNCH_STEP_ROWS(true, PRT_SHAPES_POLY);
+    else PRT_LAUNCH_STEP_ROWS(true, PRT_SHAPES_ALL);
+#undef PRT_LAUNCH_STEP_ROWS
+    HIP_TRY(hipGetLastError());
+    return PRT_OK;
+}
+
 int32_t prt_interact_cplx(const prt_system_t *sys, int32_t surface, int64_t n, const double *x_hit,
                           const double *k_re, const double *k_im, const uint8_t *valid_in, double *k_out_re,
                           double *k_out_im, double *dir_out, double *e_out_re, double *e_out_im, uint8_t *valid_out,

@@ -872,6 +872,57 @@ __global__ __launch_bounds__(PRT_MARCH_BLOCK) void k_interact_iso_rows(
     if (valid_out) store_mask2<VEC>(valid_out, i, second, valid);
 }
 
+// ONE SURFACE of the march as a launch of its own (prt_surface_step_rows): Material.propagate + Material.refract | reflect
+// at a surface with an isotropic, lossless medium behind it -- the loop body of OpticalElement.seqtrace
+// (optical_element.py:336-375) and SURVEY section 2's K1 / K2 kernels in their per-surface form.  Reads the 49-B state
+// (x, k, mask), writes the 49-B record (x_hit, k_out, masks): SURVEY 8d's 98 B per ray-surface-op.  The arithmetic is
+// the fused march's (k_trace_iso: the normal comes from the gradient the intersection left behind).
+template <bool VEC, int SHAPES>
+__global__ __launch_bounds__(PRT_MARCH_BLOCK) void k_surface_step_rows(
+    const prt_dev_surface *__restrict__ sf, int64_t N, const double *__restrict__ x_in, int64_t x_pitch,
+    const double *__restrict__ k_in, int64_t k_pitch, const double *__restrict__ dir_in,
+    const double *__restrict__ e_re, const double *__restrict__ e_im, int32_t e_mode,
+    const uint8_t *__restrict__ valid_in, double *__restrict__ xh_out, double *__restrict__ k_out, int64_t out_pitch,
+    uint8_t *__restrict__ valid_hit, uint8_t *__restrict__ valid_out, uint8_t *__restrict__ nonconv_out) {
+    const int64_t i = ((int64_t)blockIdx.x * PRT_MARCH_BLOCK + threadIdx.x) * 2;
+    if (i >= N) return;
+    const bool second = (i + 1 < N);
+    vec3 x[2], k[2], d[2];
+    double d2[2] = {1.0, 1.0};
+    rayio<VEC>::load(x_in, x_pitch, i, second, x);
+    rayio<VEC>::load(k_in, k_pitch, i, second, k);
+    if (dir_in) {
+        rayio<VEC>::load(dir_in, k_pitch, i, second, d);
+    } else if (e_mode == 0) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            d[r] = k[r];
+            d2[r] = dot(k[r], k[r]);
+        }
+    } else {
+        first_direction<VEC>(e_mode, e_re, e_im, k_pitch, i, second, k, d);
+    }
+    bool valid[2], vhit[2], ncv[2];
+    load_mask2<VEC>(valid_in, i, second, valid);
+    PRT_WAIT_VMEM_LOADS();
+    vec3 xh[2], nrm[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        vec3 p, g;
+        double g2;
+        propagate_step<SHAPES>(sf, x[r], d[r], d2[r], xh[r], p, g, g2, valid[r], ncv[r]);
+        vhit[r] = valid[r];
+        nrm[r] = normal_from_grad<SHAPES>(sf, g, g2);
+    }
+    rayio<VEC>::store(xh_out, out_pitch, i, second, xh);          // (the hit points go out before the interaction: k_trace_iso)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) interact_isotropic(sf, nrm[r], k[r], valid[r]);
+    rayio<VEC>::store(k_out, out_pitch, i, second, k);
+    store_mask2<VEC>(valid_hit, i, second, vhit);
+    store_mask2<VEC>(valid_out, i, second, valid);
+    if (nonconv_out) store_mask2<VEC>(nonconv_out, i, second, ncv);
+}
+
 __global__ __launch_bounds__(PRT_BLOCK) void k_interact_aniso(
     const prt_dev_surface *__restrict__ sf, int64_t N, const double *__restrict__ xh_in,
     const double *__restrict__ k_in, const uint8_t *__restrict__ alive_in,

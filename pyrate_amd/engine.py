@@ -693,6 +693,36 @@ class DeviceSystem(object):
                                                    _stream_handle(self.device)))
         return (x_hit, valid, nonconv) if want_nonconv else (x_hit, valid)
 
+    def surface_step(self, surface, x, k, direction=None, e_re=None, e_im=None, default_e=True, valid_in=None,
+                     want_nonconv=False, placement="auto"):
+        """``propagate`` + ``interact`` of ONE surface in one launch (prt_surface_step_rows): the loop body of
+        OpticalElement.seqtrace (optical_element.py:336-375) for a surface with an isotropic, lossless medium behind
+        it.  Returns (x_hit, k_out, valid, valid_out), with ``want_nonconv`` also nonconv.  98 B of HBM traffic per
+        ray (the 49-B state read once, the 49-B record written once) against the 148 B of the two separate calls.
+        ``placement`` "auto": big bundles get row-pitched arrays from the arena, x_hit in the kind of HBM that neither
+        x nor k lies in, k_out in x's kind -- the two write streams in two kinds, like the fused march."""
+        if self.records[surface]["material"]["type"] == "anisotropic" or self.complex_eps:
+            raise ValueError("surface_step: isotropic, lossless media only (crystals: propagate + interact)")
+        if self._row_pitch(x, "x") is None:
+            x = x.contiguous()
+        group = [t for t in (k, direction, e_re, e_im) if t is not None]
+        pitches = set(self._row_pitch(t, "k / direction / E") for t in group)
+        if None in pitches or len(pitches) > 1:
+            (k, direction, e_re, e_im) = [_rows_contiguous(t) for t in (k, direction, e_re, e_im)]
+        n = x.shape[1]
+        with torch.cuda.device(self.device):
+            (x_hit, m1) = self._step_arrays(n, (x, k), placement, n_masks=2 if want_nonconv else 1)
+            (k_out, m2) = self._step_arrays(n, (k, x_hit), placement, n_masks=1)
+            if n and k_out.stride(0) != x_hit.stride(0):          # (one pitch for both outputs in the entry point)
+                k_out = torch.empty((3, x_hit.stride(0)), dtype=torch.float64, device=self.device)[:, :n]
+            nonconv = m1[1] if want_nonconv else None
+            _lib.check(self.lib.prt_surface_step_rows(self._h, surface, n, _ptr(x), x.stride(0) if n else 0, _ptr(k),
+                                                      k.stride(0) if n else 0, _ptr(direction), _ptr(e_re), _ptr(e_im),
+                                                      1 if default_e else 0, _ptr(valid_in), _ptr(x_hit), _ptr(k_out),
+                                                      x_hit.stride(0) if n else 0, _ptr(m1[0]), _ptr(m2[0]),
+                                                      _ptr(nonconv), _stream_handle(self.device)))
+        return (x_hit, k_out, m1[0], m2[0], nonconv) if want_nonconv else (x_hit, k_out, m1[0], m2[0])
+
     def interact(self, surface, x_hit, k, valid_in=None, want_e=False, want_dir=None, placement="auto"):
         """Material.refract / reflect at one surface.  Returns (k_out, dir_out, valid_out, e_re, e_im).
         Isotropic medium behind the surface: ``dir_out`` is None unless ``want_dir`` (the ray direction is k / |k| there,
