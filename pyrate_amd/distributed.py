@@ -299,22 +299,57 @@ class DirectImagePlaneGather(ImagePlaneGather):
         super().__init__(n_total, device, group=group, align=align)
         if not dist.is_initialized():
             raise ValueError("DirectImagePlaneGather needs an initialised process group")
-        from torch.multiprocessing.reductions import reduce_tensor
-        mine = (reduce_tensor(self.recv_f), reduce_tensor(self.recv_v))
+        # Bringing the peer mappings up can fail on ONE rank (no IPC between two devices, no memory): every rank walks
+        # through the same collectives whatever happened locally, learns what happened elsewhere, and all of them
+        # raise together -- a rank that left early would leave its peers waiting in a collective for good.
+        mine = None
+        try:
+            mine = self._export_handles()
+        except Exception as exc:          # noqa: BLE001 -- reported to the peers below, then raised by all
+            self._local_error = "export: %s" % str(exc)[:200]
         handles = [None] * self.world
         dist.all_gather_object(handles, mine, group=group)
+        missing = [r for (r, h) in enumerate(handles) if h is None]
         self.peer_f, self.peer_v, self._streams = {}, {}, {}
-        for (r, (hf, hv)) in enumerate(handles):
-            if r == self.rank:
-                continue
-            # tensors in THIS process whose storage is rank r's buffer (on rank r's GPU; written over xGMI)
-            self.peer_f[r] = hf[0](*hf[1])
-            self.peer_v[r] = hv[0](*hv[1])
+        ok = not missing
+        if ok:
+            try:
+                for (r, h) in enumerate(handles):
+                    if r != self.rank:
+                        # tensors in THIS process whose storage is rank r's buffer (on rank r's GPU; written over xGMI)
+                        (self.peer_f[r], self.peer_v[r]) = self._open_peer(h)
+                self._make_streams(device)
+            except Exception as exc:      # noqa: BLE001
+                self._local_error = "open: %s" % str(exc)[:200]
+                ok = False
+        opened = [None] * self.world
+        dist.all_gather_object(opened, ok, group=group)
+        if missing or not all(opened):
+            self.peer_f, self.peer_v, self._streams = {}, {}, {}
+            raise RuntimeError("DirectImagePlaneGather: the peer buffers could not be brought up on every rank "
+                               "(no export on ranks %s, no mapping on ranks %s%s)"
+                               % (missing, [r for (r, o) in enumerate(opened) if not o],
+                                  "; here: " + self._local_error if getattr(self, "_local_error", None) else ""))
+        dist.barrier(group=group)          # every rank has opened every buffer before anybody writes
+
+    _local_error = None
+
+    def _export_handles(self):
+        """what a peer needs to map this rank's receive buffers (torch's CUDA IPC)"""
+        from torch.multiprocessing.reductions import reduce_tensor
+        return (reduce_tensor(self.recv_f), reduce_tensor(self.recv_v))
+
+    @staticmethod
+    def _open_peer(handle):
+        (hf, hv) = handle
+        return hf[0](*hf[1]), hv[0](*hv[1])
+
+    def _make_streams(self, device):
+        for r in self.peer_f:
             self._streams[r] = torch.cuda.Stream(device=device)
         self._ready = torch.cuda.Event()
         self._done = {r: torch.cuda.Event() for r in self.peer_f}
         self._token = torch.zeros(1, dtype=torch.float32, device=device)
-        dist.barrier(group=group)          # every rank has opened every buffer before anybody writes
 
     def start_in_place(self):
         """copies of this rank's slot into every peer's buffer; enqueued behind the work of the current stream,

@@ -238,3 +238,67 @@ def test_strong_scaling_split_of_one_bundle_gathers_to_the_same_plane_at_every_w
             assert p.exitcode == 0
         assert sorted(r[0] for r in results) == list(range(world))
         assert all(r[1] == o.shape[1] and r[2] == h.hexdigest() for r in results), (world, results)
+
+
+class _FakeDirectGather(pdist.DirectImagePlaneGather):
+    """DirectImagePlaneGather without CUDA IPC: the handles are plain tuples, a 'peer buffer' is a local tensor; a
+    chosen rank fails at a chosen stage -- what the bring-up protocol is there for"""
+    fail = (None, None)          # (stage, rank)
+
+    def _export_handles(self):
+        if self.fail == ("export", self.rank):
+            raise RuntimeError("no IPC handle on this rank")
+        return ("handle of rank", self.rank)
+
+    def _open_peer(self, handle):
+        if self.fail == ("open", self.rank):
+            raise RuntimeError("peer %d cannot be mapped here" % handle[1])
+        return torch.zeros_like(self.recv_f), torch.zeros_like(self.recv_v)
+
+    def _make_streams(self, device):
+        self._streams = {r: None for r in self.peer_f}
+
+
+def _bringup_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        outcomes = []
+        for fail in ((None, None), ("export", 1), ("open", 0), ("open", world - 1)):
+            _FakeDirectGather.fail = fail
+            try:
+                g = _FakeDirectGather(4096, torch.device("cpu"))
+                outcomes.append(("up", sorted(g.peer_f)))
+            except RuntimeError as exc:
+                outcomes.append(("refused", "could not be brought up on every rank" in str(exc)))
+        # ... and the ranks are still in step: a collective after all of that completes
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        q.put((rank, outcomes, float(t.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_direct_gather_bring_up_fails_on_all_ranks_or_on_none(world):
+    """The peer-write form of the image-plane exchange needs every rank to export its receive buffers and to map every
+    peer's.  If ONE rank cannot (no IPC between two devices, no memory), ALL ranks must learn it and raise together --
+    a rank that raised alone would leave its peers waiting inside a collective for good, and bench.py's start-up probe
+    (--exchange auto) relies on every rank dropping the direct form before anybody uses it.  Fake handles, real
+    collectives (gloo): a failure at either stage on any rank -> every rank refuses, nobody hangs, and the next
+    collective still completes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bringup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for (rank, outcomes, total) in results:
+        assert outcomes[0] == ("up", [r for r in range(world) if r != rank])
+        assert outcomes[1:] == [("refused", True)] * 3
+        assert total == world
