@@ -49,6 +49,13 @@ ALL_CASES = ISO_CASES + EXPLICIT_CASES + ANISO_CASES
 # ("not making good progress"), so there is no out-of-the-box result to compare with
 EXPLICIT_TIGHT_ONLY = ["asphere_grazing_field30"]
 EXPLICIT_TIGHT_CASES = [c + "_tight" for c in EXPLICIT_CASES + EXPLICIT_TIGHT_ONLY]
+# What the engine's RAW deviation from the converged reference is asserted to stay below on a tight fixture (the bar
+# itself is 1e-10, flat).  The 19 twins measure <= 2.6e-15.  At grazing incidence the wave vectors carry the error of the
+# Newton loop's gradient, which is moved to the root along the secant of the last two evaluations instead of being
+# evaluated there (prt_device.h explicit_t): 1/2 g'' dt (dt + dt_prev) -- with the 1e-8 exit up to ~1e-12 where the
+# surface's gradient bends fastest along the ray (the host build of the kernels measures 1.6e-12 on the dome).
+TIGHT_RAW_CAP = {"asphere_grazing_field30_tight": 2e-11}
+TIGHT_RAW_CAP_DEFAULT = 1e-12
 REF_RESIDUAL_MAX = 1e-12        # [mm] what "the reference is converged on every ray" means for a tight fixture
 # complex (absorbing) epsilon tensors, sequences that stay inside crystals: complex wave vectors, compared as such
 ABSORBING_CASES = ["aniso_absorbing_mirror", "aniso_absorbing_two_crystals",

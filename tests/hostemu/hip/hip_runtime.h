@@ -1,0 +1,323 @@
+// TEST INFRASTRUCTURE -- not part of the product, never shipped, never loaded by pyrate_amd.
+//
+// A stand-in for <hip/hip_runtime.h> that lets the UNMODIFIED sources of libprt (pyrate_amd/csrc/prt.hip and its
+// headers) be compiled by a host C++ compiler (clang++ for x86-64, with AddressSanitizer / UBSan) into
+// tests/hostemu/_build/libprt_hostemu.so.  The build container has no GPU and GPU sanitizers are not available on
+// the pool: this is the "sanitizers on the CPU build" of the kernels.  What it gives the `-m "not gpu"` suite:
+//   * every index computation of every kernel (row pitches, two-rays-per-thread tails, the concatenated crystal
+//     layout, the walk program, partial last blocks) runs under ASan on exact-size NumPy arrays;
+//   * the arithmetic of the kernels -- the same C++ expressions, the same launch-site logic of prt.hip (which
+//     instantiation, which grid, which layout) -- is compared with the oracle and the golden vectors before a GPU
+//     has seen a change.
+// What it is NOT: a model of the hardware.  Threads of a block run as cooperative fibres on one OS thread (a block at a
+// time, blocks in order), `__syncthreads` / wave shuffles / ballots are rendezvous points between the fibres,
+// v_rcp_f64 / v_rsq_f64 are exact divisions, memory is malloc'ed.  Results agree with the GPU's to rounding, not to
+// the bit.  "Device pointers" are host pointers.  The product has no CPU path: pyrate_amd/_lib.py loads
+// pyrate_amd/csrc/libprt.so (the gfx950 build) or raises.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+#include <chrono>
+#include <functional>
+#include <vector>
+
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define HOSTEMU_ASAN 1
+#include <sanitizer/common_interface_defs.h>
+#endif
+#endif
+
+// ---- language ----------------------------------------------------------------------------------------------------
+#define __host__
+#define __device__
+#define __global__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+// block-static and dynamic LDS arrays: one block runs at a time on one OS thread, so one instance per array is the
+// block's instance (`thread_local` is valid both on a block-scope definition and after `extern`)
+#define __shared__ thread_local
+
+struct dim3 {
+    uint32_t x, y, z;
+    constexpr dim3(uint32_t x_ = 1, uint32_t y_ = 1, uint32_t z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+inline dim3 threadIdx, blockIdx, blockDim, gridDim;
+#define warpSize 64
+
+// ---- the fibres of a block ------------------------------------------------------------------------------------------
+namespace hostemu {
+constexpr int WAVE = 64;
+constexpr size_t STACK_BYTES = 512 * 1024;
+
+struct fibre {
+    ucontext_t ctx;
+    char *stack = nullptr;
+    bool done = false;
+    dim3 tid;
+#ifdef HOSTEMU_ASAN
+    void *fake_stack = nullptr;
+#endif
+};
+
+struct block_state {
+    std::vector<fibre> fibres;
+    ucontext_t sched;
+    int current = -1;
+    int live = 0;
+    // block barrier
+    int arrived = 0;
+    uint64_t generation = 0;
+    // wave rendezvous (shuffles, ballots): per wave
+    int wave_live[16];
+    int wave_arrived[16];
+    uint64_t wave_generation[16];
+    double wave_buf[16][WAVE];
+    uint64_t wave_bits[16];
+    uint64_t wave_active[16];
+    uint64_t progress = 0;   // barrier releases + finished threads: the deadlock check of run_block
+    const std::function<void()> *body = nullptr;
+#ifdef HOSTEMU_ASAN
+    void *sched_fake = nullptr;
+    const void *sched_bottom = nullptr;
+    size_t sched_size = 0;
+#endif
+};
+inline block_state *g_block = nullptr;
+inline std::vector<char *> g_stacks;   // reused between blocks
+
+inline void switch_to_sched(bool dying) {
+    block_state &b = *g_block;
+    fibre &f = b.fibres[b.current];
+#ifdef HOSTEMU_ASAN
+    __sanitizer_start_switch_fiber(dying ? nullptr : &f.fake_stack, b.sched_bottom, b.sched_size);
+#endif
+    swapcontext(&f.ctx, &b.sched);
+#ifdef HOSTEMU_ASAN
+    __sanitizer_finish_switch_fiber(f.fake_stack, &b.sched_bottom, &b.sched_size);
+#endif
+    (void)dying;
+}
+
+inline void yield() { switch_to_sched(false); }
+
+inline void trampoline() {
+    block_state &b = *g_block;
+#ifdef HOSTEMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &b.sched_bottom, &b.sched_size);
+#endif
+    (*b.body)();
+    fibre &f = b.fibres[b.current];
+    f.done = true;
+    b.live -= 1;
+    b.progress += 1;
+    const int w = b.current / WAVE;
+    b.wave_live[w] -= 1;
+    // a thread that has returned no longer takes part in barriers: release who waits for it
+    if (b.live > 0 && b.arrived == b.live) { b.arrived = 0; b.generation += 1; }
+    if (b.wave_live[w] > 0 && b.wave_arrived[w] == b.wave_live[w]) { b.wave_arrived[w] = 0; b.wave_generation[w] += 1; }
+    switch_to_sched(true);
+}
+
+inline void block_barrier() {
+    block_state &b = *g_block;
+    const uint64_t mine = b.generation;
+    b.arrived += 1;
+    if (b.arrived == b.live) { b.arrived = 0; b.generation += 1; b.progress += 1; return; }
+    while (b.generation == mine) yield();
+}
+
+inline void wave_barrier() {
+    block_state &b = *g_block;
+    const int w = b.current / WAVE;
+    const uint64_t mine = b.wave_generation[w];
+    b.wave_arrived[w] += 1;
+    if (b.wave_arrived[w] == b.wave_live[w]) { b.wave_arrived[w] = 0; b.wave_generation[w] += 1; b.progress += 1; return; }
+    while (b.wave_generation[w] == mine) yield();
+}
+
+inline void run_block(dim3 block, const std::function<void()> &body) {
+    const int n = (int)(block.x * block.y * block.z);
+    block_state b;
+    b.fibres.resize(n);
+    b.body = &body;
+    b.live = n;
+    for (int w = 0; w < 16; ++w) {
+        b.wave_live[w] = 0; b.wave_arrived[w] = 0; b.wave_generation[w] = 0; b.wave_bits[w] = 0; b.wave_active[w] = 0;
+    }
+    if (n > 16 * WAVE) { fprintf(stderr, "hostemu: block of %d threads\n", n); abort(); }
+    while ((int)g_stacks.size() < n) g_stacks.push_back((char *)malloc(STACK_BYTES));
+    g_block = &b;
+    for (int t = 0; t < n; ++t) {
+        fibre &f = b.fibres[t];
+        f.stack = g_stacks[t];
+        f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+        b.wave_live[t / WAVE] += 1;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = STACK_BYTES;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+    int idle_passes = 0;
+    while (b.live > 0) {
+        const uint64_t before = b.progress;
+        for (int t = 0; t < n; ++t) {
+            fibre &f = b.fibres[t];
+            if (f.done) continue;
+            b.current = t;
+            threadIdx = f.tid;
+#ifdef HOSTEMU_ASAN
+            __sanitizer_start_switch_fiber(&b.sched_fake, f.stack, STACK_BYTES);
+#endif
+            swapcontext(&b.sched, &f.ctx);
+#ifdef HOSTEMU_ASAN
+            __sanitizer_finish_switch_fiber(b.sched_fake, nullptr, nullptr);
+#endif
+        }
+        idle_passes = (b.progress == before) ? idle_passes + 1 : 0;
+        if (idle_passes > 2) {
+            fprintf(stderr, "hostemu: block (%u,%u,%u) is stuck at a barrier / wave vote that not all of its live threads "
+                            "reach (divergent __syncthreads / __all / __shfl)\n", blockIdx.x, blockIdx.y, blockIdx.z);
+            abort();
+        }
+    }
+    g_block = nullptr;
+}
+
+inline void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+    gridDim = grid;
+    blockDim = block;
+    for (uint32_t bz = 0; bz < grid.z; ++bz)
+        for (uint32_t by = 0; by < grid.y; ++by)
+            for (uint32_t bx = 0; bx < grid.x; ++bx) {
+                blockIdx = dim3(bx, by, bz);
+                run_block(block, body);
+            }
+}
+}  // namespace hostemu
+
+// `kernel` may be a parenthesised template-id; calling it by name keeps its default arguments
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    ((void)(shmem), (void)(stream), hostemu::launch(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); }))
+
+inline void __syncthreads() { hostemu::block_barrier(); }
+
+template <typename T>
+inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    hostemu::block_state &b = *hostemu::g_block;
+    const int w = b.current / hostemu::WAVE, lane = b.current % hostemu::WAVE;
+    static_assert(sizeof(T) <= sizeof(double), "hostemu shuffle: 8-byte values");
+    double slot = 0.0;
+    memcpy(&slot, &v, sizeof(T));
+    b.wave_buf[w][lane] = slot;
+    hostemu::wave_barrier();
+    T r = v;
+    const int src = lane + (int)delta;
+    if (src < width && (lane / width) == (src / width) && src < hostemu::WAVE &&
+        w * hostemu::WAVE + src < (int)b.fibres.size() && !b.fibres[w * hostemu::WAVE + src].done)
+        memcpy(&r, &b.wave_buf[w][src], sizeof(T));
+    hostemu::wave_barrier();
+    return r;
+}
+
+// wave votes: a rendezvous of the wave's live lanes (the kernels vote in converged control flow only; a vote inside a
+// divergent branch would stall here and is reported by the scheduler's deadlock check)
+inline unsigned long long hostemu_vote(int pred, unsigned long long *active) {
+    hostemu::block_state &b = *hostemu::g_block;
+    const int w = b.current / hostemu::WAVE, lane = b.current % hostemu::WAVE;
+    if (pred) b.wave_bits[w] |= (1ull << lane);
+    b.wave_active[w] |= (1ull << lane);
+    hostemu::wave_barrier();
+    const unsigned long long r = b.wave_bits[w];
+    *active = b.wave_active[w];
+    hostemu::wave_barrier();
+    b.wave_bits[w] &= ~(1ull << lane);   // behind the second rendezvous every lane has read the words
+    b.wave_active[w] &= ~(1ull << lane);
+    return r;
+}
+inline unsigned long long __ballot(int pred) { unsigned long long a; return hostemu_vote(pred, &a); }
+inline int __all(int pred) { unsigned long long a; const unsigned long long r = hostemu_vote(pred, &a); return r == a; }
+inline int __any(int pred) { unsigned long long a; return hostemu_vote(pred, &a) != 0; }
+#define __popcll(x) __builtin_popcountll(x)
+
+struct double2 { double x, y; };
+inline double2 make_double2(double x, double y) { return double2{x, y}; }
+
+// ---- gfx950 builtins the kernels use ---------------------------------------------------------------------------
+#define __builtin_amdgcn_rcp(x) (1.0 / (x))
+#define __builtin_amdgcn_rsq(x) (1.0 / __builtin_sqrt(x))
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+
+// ---- runtime ---------------------------------------------------------------------------------------------------------
+typedef int hipError_t;
+enum {
+    hipSuccess = 0,
+    hipErrorInvalidValue = 1,
+    hipErrorOutOfMemory = 2,
+    hipErrorNotSupported = 801,
+    hipErrorUnknown = 999
+};
+typedef struct hostemu_stream *hipStream_t;
+struct hostemu_event { std::chrono::steady_clock::time_point t; };
+typedef hostemu_event *hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum { hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
+enum hipMemoryType { hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; void *devicePointer; void *hostPointer; };
+typedef void *hipMemGenericAllocationHandle_t;
+enum hipMemAllocationType { hipMemAllocationTypePinned = 1 };
+enum hipMemLocationType { hipMemLocationTypeDevice = 1 };
+enum hipMemAccessFlags { hipMemAccessFlagsProtReadWrite = 3 };
+struct hipMemLocation { hipMemLocationType type; int id; };
+struct hipMemAllocationProp { hipMemAllocationType type; int requestedHandleType; hipMemLocation location; void *win32HandleMetaData; };
+struct hipMemAccessDesc { hipMemLocation location; hipMemAccessFlags flags; };
+
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "hostemu: error"; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipDeviceGetPCIBusId(char *s, int n, int) { snprintf(s, n, "0000:00:00.0"); return hipSuccess; }
+// exact sizes, so that AddressSanitizer sees the first byte past an array
+inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> inline hipError_t hipMalloc(T **p, size_t n) { return hipMalloc((void **)p, n); }
+inline hipError_t hipMallocAsync(void **p, size_t n, hipStream_t) { return hipMalloc(p, n); }
+template <typename T> inline hipError_t hipMallocAsync(T **p, size_t n, hipStream_t s) { return hipMallocAsync((void **)p, n, s); }
+inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipFreeAsync(void *p, hipStream_t) { free(p); return hipSuccess; }
+inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = (size_t)8 << 30; *t = (size_t)16 << 30; return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hostemu_event(); return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *p) {
+    a->type = hipMemoryTypeDevice; a->device = 0; a->devicePointer = (void *)p; a->hostPointer = nullptr;
+    return hipSuccess;
+}
+// no virtual-memory management: the placement arena (prt_placed.h) reports that it cannot be created
+inline hipError_t hipMemAddressReserve(void **, size_t, size_t, void *, unsigned long long) { return hipErrorNotSupported; }
+inline hipError_t hipMemAddressFree(void *, size_t) { return hipErrorNotSupported; }
+inline hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *, size_t, const hipMemAllocationProp *, unsigned long long) { return hipErrorNotSupported; }
+inline hipError_t hipMemRelease(hipMemGenericAllocationHandle_t) { return hipErrorNotSupported; }
+inline hipError_t hipMemMap(void *, size_t, size_t, hipMemGenericAllocationHandle_t, unsigned long long) { return hipErrorNotSupported; }
+inline hipError_t hipMemUnmap(void *, size_t) { return hipErrorNotSupported; }
+inline hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size_t) { return hipErrorNotSupported; }

@@ -81,7 +81,8 @@ def test_hip_vs_reference_explicit_tight(name, gpu_device):
     r = _golden.compare_dense_to_reference(case, _golden.dense_from_engine(res), rtol_x=1e-10, atol_k=1e-10,
                                            explicit_tol=None)
     assert r["n_compared"] > 0 and r["max_allowance_x"] == 0.0 and r["max_allowance_k"] == 0.0
-    assert r["raw_rel_x"] < 1e-12 and r["raw_abs_k"] < 1e-12, r          # measured: <= 1.0e-15 / 2.6e-15
+    cap = _golden.TIGHT_RAW_CAP.get(name, _golden.TIGHT_RAW_CAP_DEFAULT)
+    assert r["raw_rel_x"] < cap and r["raw_abs_k"] < cap, r          # measured on the 19 twins: <= 1.0e-15 / 2.6e-15
     print("%s: raw deviation from the converged reference %.2e (x, relative) %.2e (k)" % (name, r["raw_rel_x"], r["raw_abs_k"]))
 
 

@@ -223,6 +223,20 @@ def test_no_product_module_imports_the_oracle():
         assert "seqtrace_np" not in src and "seqtrace_c" not in src, path
 
 
+def test_no_product_module_knows_the_host_build_of_the_kernels():
+    """tests/hostemu (libprt's sources compiled for the host: the sanitizer build of the `-m "not gpu"` suite) is test
+    infrastructure too: nothing under pyrate_amd/, bench.py, benchmarks/ or __graft_entry__.py mentions it, and the
+    library path of the product cannot be pointed at it by accident (another file name, built by tests/ only)"""
+    import glob
+    paths = glob.glob(os.path.join(ROOT, "pyrate_amd", "**", "*.py"), recursive=True) + \
+        glob.glob(os.path.join(ROOT, "benchmarks", "*.py")) + glob.glob(os.path.join(ROOT, "pyrate_amd", "csrc", "*")) + \
+        [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for path in paths:
+        if path.endswith((".so", ".json")):
+            continue
+        assert "hostemu" not in open(path, errors="replace").read(), path
+
+
 def test_catalog_material_dispersion_matches_reference(api):
     """CatalogMaterial n(wavelength) for every dispersion formula type == the reference's
     material_glasscat.py (values generated by oracle/make_golden.py: tests/golden/dispersion.json);

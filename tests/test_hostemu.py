@@ -1,0 +1,344 @@
+"""The sources of libprt compiled for the HOST (tests/hostemu: a stand-in HIP runtime, the threads of a block as fibres)
+against the reference's golden vectors and the oracle -- CPU only, no GPU needed.
+
+This is a check of the kernels' SOURCE: the same C++ expressions, the same launch-site logic of prt.hip (which
+instantiation, which layout, which grid), every index computation under AddressSanitizer / UBSan.  It is not the product
+(pyrate_amd loads the gfx950 build or raises) and not a measurement; the `-m gpu` suite runs the same comparisons on the
+device build.  Tolerances are the `-m gpu` suite's (BASELINE.json: 1e-10 relative on hit points and direction cosines).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import _golden
+from oracle import seqtrace_np as oracle
+from test_oracle_golden import explicit_tolerance
+
+hostemu = pytest.importorskip("hostemu")
+
+try:
+    hostemu.build()
+except Exception as exc:                                    # no clang++ on this box
+    pytest.skip("no host build of libprt: %s" % exc, allow_module_level=True)
+
+
+def host_trace(case, **kw):
+    hs = hostemu.HostSystem(case.table)
+    e = np.asarray(case.E0)
+    return hs, hs.trace(case.x0, np.real(case.k0), e.real, e.imag if np.iscomplexobj(e) else None, **kw)
+
+
+@pytest.mark.parametrize("name", _golden.ISO_CASES)
+def test_host_build_vs_reference_isotropic(name):
+    case = _golden.load_case(name)
+    (hs, dense) = host_trace(case)
+    r = _golden.compare_dense_to_reference(case, dense, rtol_x=1e-10, atol_k=1e-10)
+    assert r["n_compared"] > 0 and r["max_rel_x"] < 1e-13 and r["max_abs_k"] < 1e-13
+    assert hs.padding_untouched            # nothing written beyond ray n0 - 1 of a pitched row
+
+
+@pytest.mark.parametrize("name", _golden.EXPLICIT_CASES)
+def test_host_build_vs_reference_explicit(name):
+    case = _golden.load_case(name)
+    (_, dense) = host_trace(case)
+    r = _golden.compare_dense_to_reference(case, dense, rtol_x=1e-10, atol_k=1e-10, explicit_tol=explicit_tolerance)
+    assert r["raw_rel_x"] <= _golden.RAW_CAP and r["raw_abs_k"] <= _golden.RAW_CAP, r
+    for (s, rec) in enumerate(case.table):
+        if rec["shape"]["type"] == "conic":
+            continue
+        p = oracle.g2l_points(np.asarray(rec["B_shape"]), np.asarray(rec["g_shape"]), dense[s]["x_hit"])
+        assert np.nanmax(np.abs(p[2] - oracle.shape_sag(rec["shape"], p[0], p[1]))) < 1e-13
+
+
+@pytest.mark.parametrize("name", _golden.EXPLICIT_TIGHT_CASES)
+def test_host_build_vs_converged_reference_explicit(name):
+    """the tight twins (reference converged to 1e-14) incl. the grazing-incidence case of round 6: flat 1e-10, no
+    allowance -- the Newton stop rule (1e-8 exit behind an observed contraction, prt_device.h explicit_t) as compiled"""
+    case = _golden.load_case(name)
+    (_, dense) = host_trace(case, want_nonconv=True)
+    r = _golden.compare_dense_to_reference(case, dense, rtol_x=1e-10, atol_k=1e-10, explicit_tol=None)
+    assert r["n_compared"] > 0 and r["max_allowance_x"] == 0.0 and r["max_allowance_k"] == 0.0
+    cap = _golden.TIGHT_RAW_CAP.get(name, _golden.TIGHT_RAW_CAP_DEFAULT)
+    assert r["raw_rel_x"] < cap and r["raw_abs_k"] < cap, r
+    for d in dense:
+        assert not np.any(d["nonconv"][d["valid"].astype(bool)])
+
+
+@pytest.mark.parametrize("name", _golden.ANISO_CASES)
+def test_host_build_vs_reference_anisotropic(name):
+    case = _golden.load_case(name)
+    (_, dense) = host_trace(case)
+    _golden.compare_dense_to_reference(case, dense, rtol_x=1e-10, atol_k=1e-10)
+
+
+@pytest.mark.parametrize("name", _golden.ABSORBING_CASES)
+def test_host_build_vs_reference_absorbing(name):
+    case = _golden.load_case(name)
+    (hs, dense) = host_trace(case, want_fields=True)
+    assert hs.complex_eps
+    out = _golden.compare_dense_to_reference(case, dense, rtol_x=1e-10, atol_k=1e-10)
+    assert out["n_compared"] > 0 and out["max_abs_k"] < 1e-12
+
+
+@pytest.mark.parametrize("name", _golden.ISO_CASES + _golden.EXPLICIT_CASES + _golden.ANISO_CASES)
+def test_host_build_vs_oracle_dense(name):
+    """every ray, valid or not: masks identical, values within 1e-11 where both are finite and valid"""
+    case = _golden.load_case(name)
+    (_, dense) = host_trace(case)
+    out = oracle.trace(case.table, case.x0, case.k0, case.E0)
+    for s in range(case.n_surfaces):
+        assert np.array_equal(dense[s]["valid"].astype(bool), out[s]["valid"]), (name, s)
+        assert np.array_equal(dense[s]["valid_out"].astype(bool), out[s]["valid_out"]), (name, s)
+        v = out[s]["valid"]
+        xo = out[s]["x_hit"][:, v]
+        assert np.max(np.abs(dense[s]["x_hit"][:, v] - xo) / _golden.relative_scale(xo), initial=0.0) < 1e-11
+        vo = out[s]["valid_out"] & np.all(np.isfinite(np.real(out[s]["k_out"])), axis=0)
+        assert np.max(np.abs(dense[s]["k_out"][:, vo] - np.real(out[s]["k_out"])[:, vo]), initial=0.0) < 1e-11
+
+
+@pytest.mark.parametrize("name", ["double_gauss_wide", "tilted_frames", "asphere_strong_field5", "aniso_doublet_uniaxial",
+                                  "aniso_doublet_biaxial"])
+def test_host_build_layouts_and_modes_agree(name):
+    """image mode, the flags byte, tight / recommended / odd output pitches, pitched inputs: the same records"""
+    from pyrate_amd import _lib as P
+    case = _golden.load_case(name)
+    (hs, ref) = host_trace(case)
+    n0 = case.x0.shape[1]
+
+    def same(a, b, tol=1e-13):
+        assert np.array_equal(a["valid"], b["valid"]) and np.array_equal(a["valid_out"], b["valid_out"])
+        m = a["valid_out"].astype(bool)
+        assert np.allclose(a["x_hit"][:, a["valid"].astype(bool)], b["x_hit"][:, a["valid"].astype(bool)], rtol=tol, atol=tol)
+        assert np.allclose(a["k_out"][:, m], b["k_out"][:, m], rtol=0, atol=tol)
+    (_, img) = host_trace(case, mode=P.MODE_IMAGE)
+    assert len(img) == 1
+    same(img[0], ref[-1])
+    variants = [dict(pitch=0), dict(in_pitch=n0 + 6)]
+    if hs.all_isotropic:
+        variants += [dict(pitch=n0 + 1), dict(pitch=n0 + 2, in_pitch=n0 + 3), dict(flags=True)]
+    else:
+        variants += [dict(pitch=n0 + 3)]
+    for kw in variants:
+        (_, got) = host_trace(case, **kw)
+        for s in range(case.n_surfaces):
+            same(got[s], ref[s])
+
+
+def _walk_surface_by_surface(case, pitch, n=None):
+    hs = hostemu.HostSystem(case.table)
+    e = np.asarray(case.E0)
+    sl = slice(0, n)
+    (x, k) = (case.x0[:, sl], np.real(case.k0)[:, sl])
+    (e_re, e_im) = (e.real[:, sl], e.imag[:, sl] if np.iscomplexobj(e) else None)
+    out = oracle.trace(case.table, case.x0[:, sl], case.k0[:, sl], case.E0[:, sl])
+    valid = None
+    (xs, ks, valid_s) = (x, k, None)
+    for s in range(case.n_surfaces):
+        first = dict(e_re=e_re, e_im=e_im) if s == 0 else dict(default_e=False)
+        # the two calls (Material.propagate, Material.refract) ...
+        (xh, v, nc) = hs.propagate_rows(s, x, k, valid_in=valid, pitch=pitch, want_nonconv=True, **first)
+        (k2, vo) = hs.interact_rows(s, xh, k, valid_in=v, pitch=pitch)
+        # ... and the fused step of the same surface
+        (xh_f, k2_f, v_f, vo_f, nc_f) = hs.surface_step_rows(s, xs, ks, valid_in=valid_s, pitch=pitch, want_nonconv=True, **first)
+        for (got_x, got_k, got_v, got_vo) in ((xh, k2, v, vo), (xh_f, k2_f, v_f, vo_f)):
+            assert np.array_equal(got_v.astype(bool), out[s]["valid"]), (s, pitch)
+            assert np.array_equal(got_vo.astype(bool), out[s]["valid_out"]), (s, pitch)
+            m = out[s]["valid_out"]
+            xo = out[s]["x_hit"][:, m]
+            assert np.max(np.abs(got_x[:, m] - xo) / _golden.relative_scale(xo), initial=0.0) < 1e-11
+            assert np.max(np.abs(got_k[:, m] - np.real(out[s]["k_out"])[:, m]), initial=0.0) < 1e-11
+        assert np.array_equal(nc, nc_f)
+        (x, k, valid) = (xh, k2, vo)
+        (xs, ks, valid_s) = (xh_f, k2_f, vo_f)
+
+
+@pytest.mark.parametrize("name", ["double_gauss_wide", "tilted_frames", "xypoly_field5", "mirrors", "asphere_strong_field5",
+                                  "biconic_field5", "doublet_clipped", "asphere_grazing_field30_tight"])
+def test_host_build_per_surface_calls_and_the_fused_surface_step(name):
+    """prt_propagate_rows + prt_interact_rows (Material.propagate / refract, two calls per surface) and
+    prt_surface_step_rows (both in one launch; never on a GPU before round 6's last session) against the oracle, surface
+    by surface -- with the aligned two-rays-per-thread form (even pitch) and the 8-B fall-back (tight arrays of odd
+    length), and odd ray counts in both"""
+    case = _golden.load_case(name)
+    n0 = case.x0.shape[1]
+    for (pitch, n) in ((n0 + (n0 % 2) + 2, n0), (None, n0), (n0 + 1 - (n0 % 2), n0 - 1), (None, n0 - 1 if (n0 - 1) % 2 else n0 - 2),
+                       (4, 3), (None, 1)):
+        _walk_surface_by_surface(case, pitch, n)
+
+
+def test_host_build_refuses_crystals_in_the_row_calls():
+    case = _golden.load_case("aniso_doublet_uniaxial")
+    hs = hostemu.HostSystem(case.table)
+    s_c = [s for (s, r) in enumerate(case.table) if r["material"]["type"] == "anisotropic"][0]
+    (x, k) = (case.x0, np.real(case.k0))
+    with pytest.raises(hostemu.HostemuError) as ei:
+        hs.surface_step_rows(s_c, x, k)
+    assert ei.value.code == -2
+    with pytest.raises(hostemu.HostemuError):
+        hs.interact_rows(s_c, x, k)
+
+
+def test_host_build_many_blocks_and_the_xcd_block_map():
+    """bundles of several hundred blocks with ray counts that are not multiples of anything: the XCD-contiguous block map
+    of the march (grid a multiple of 8, partial rows by ray block) visits every ray exactly once"""
+    from pyrate_amd import systems
+    recs = systems.double_gauss_records()
+    for n in (2 * 128 * 8 * 3 + 1, 2 * 128 * 19 - 3, 5000):
+        (o, k, e0) = systems.double_gauss_bundle(n, field_deg=4.0)
+        n = o.shape[1]
+        hs = hostemu.HostSystem(recs)
+        dense = hs.trace(o, k, e0)
+        out = oracle.trace(recs, o, k, e0)
+        assert hs.padding_untouched
+        for s in range(len(recs)):
+            assert np.array_equal(dense[s]["valid_out"].astype(bool), out[s]["valid_out"])
+            m = out[s]["valid_out"]
+            assert np.max(np.abs(dense[s]["x_hit"][:, m] - out[s]["x_hit"][:, m]), initial=0.0) < 1e-11
+        # the uniform first segment (collimated bundle: only x0 is read) gives the array form's records
+        if np.ptp(k, axis=1).max() == 0.0:
+            uni = hs.trace(o, uniform=(k[:, 0], e0[:, 0], P_FIRST_E_UNIFORM()))
+            for s in range(len(recs)):
+                assert np.array_equal(uni[s]["valid_out"], dense[s]["valid_out"])
+                m = dense[s]["valid_out"].astype(bool)
+                assert np.array_equal(uni[s]["x_hit"][:, m], dense[s]["x_hit"][:, m])
+
+
+def P_FIRST_E_UNIFORM():
+    from pyrate_amd import _lib as P
+    return P.FIRST_E_UNIFORM
+
+
+SANITIZER_SCRIPT = r'''
+import sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+import numpy as np
+import _golden, hostemu
+from pyrate_amd import _lib as P
+from oracle import seqtrace_np as oracle
+import test_hostemu as T
+worst = 0.0
+for name in %(cases)r:
+    case = _golden.load_case(name)
+    (hs, dense) = T.host_trace(case, want_nonconv=True)
+    out = oracle.trace(case.table, case.x0, case.k0, case.E0)
+    for s in range(case.n_surfaces):
+        assert np.array_equal(dense[s]["valid_out"].astype(bool), out[s]["valid_out"]), (name, s)
+        m = out[s]["valid_out"] & np.all(np.isfinite(np.real(out[s]["k_out"])), axis=0)
+        ko = out[s]["k_out"] if np.iscomplexobj(dense[s]["k_out"]) else np.real(out[s]["k_out"])
+        worst = max(worst, float(np.max(np.abs(dense[s]["k_out"][:, m] - ko[:, m]), initial=0.0)))
+    n0 = case.x0.shape[1]
+    T.host_trace(case, mode=P.MODE_IMAGE)
+    T.host_trace(case, pitch=0)
+    T.host_trace(case, in_pitch=n0 + 5)
+    if hs.all_isotropic:
+        T.host_trace(case, pitch=n0 + 1)
+        T.host_trace(case, flags=True)
+        for (pitch, n) in ((n0 + (n0 %% 2) + 2, n0), (None, n0 - 1), (n0 + 1 - (n0 %% 2), n0 - 1), (None, 1)):
+            T._walk_surface_by_surface(case, pitch, n)
+    else:
+        T.host_trace(case, want_fields=True, want_k_im=True)
+T.test_host_build_many_blocks_and_the_xcd_block_map()
+T.test_host_build_device_side_helpers()
+print("RESULT " + json.dumps({"worst_k": worst}))
+'''
+
+SANITIZER_CASES = ["double_gauss_wide", "tilted_frames", "mirrors", "benchmark_divergent", "doublet_clipped",
+                   "asphere_strong_field5", "xypoly_field5", "biconic_field5", "asphere_grazing_field30_tight",
+                   "aniso_doublet_isoeps", "aniso_doublet_uniaxial", "aniso_doublet_biaxial", "aniso_absorbing_two_crystals"]
+
+
+def test_host_build_under_address_and_undefined_behaviour_sanitizers():
+    """the kernels' sources with -fsanitize=address,undefined (GPU sanitizers are not available on the pool): whole
+    sequences in every layout and mode, the per-surface calls with odd sizes and unaligned arrays, the crystal march's
+    concatenated layout, the moments / compaction / raster kernels -- on exact-size arrays, no report from either
+    sanitizer, results equal the oracle's.  Runs in a subprocess: the instrumented library needs the sanitizer
+    runtime preloaded into the interpreter."""
+    try:
+        lib = hostemu.build(sanitize=True)
+    except Exception as exc:
+        pytest.skip("no sanitizer build on this box: %s" % exc)
+    asan = hostemu.sanitizer_preload()
+    if asan is None:
+        pytest.skip("clang's shared asan runtime not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [c for c in SANITIZER_CASES if os.path.exists(os.path.join(_golden.GOLDEN_DIR, c + ".npz"))]
+    script = SANITIZER_SCRIPT % dict(root=root, tests=os.path.join(root, "tests"), cases=cases)
+    env = dict(os.environ, LD_PRELOAD=asan, PRT_HOSTEMU_LIBRARY=lib,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23:detect_stack_use_after_return=0",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=1500)
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0, r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert res["worst_k"] < 1e-11
+
+
+def test_host_build_device_side_helpers():
+    """the kernels that synchronise (fibres at __syncthreads, wave shuffles, ballots): deterministic bundle moments,
+    order-preserving compaction, the shape evaluation entry point"""
+    import ctypes
+    lib = hostemu.load()
+    rng = np.random.RandomState(5)
+    for n in (1, 63, 64, 257, 5000):
+        x = np.ascontiguousarray(rng.normal(size=(3, n)))
+        mask = (rng.uniform(size=n) < 0.7).astype(np.uint8)
+        out = (ctypes.c_double * 7)()
+        ref3 = (ctypes.c_double * 3)(0.1, -0.2, 0.3)
+        rc = lib.prt_bundle_moments(0, n, n, x.ctypes.data, mask.ctypes.data, 0, ref3, out, None)
+        assert rc == 0, lib.prt_last_error()
+        v = x[:, mask.astype(bool)] - np.array([0.1, -0.2, 0.3])[:, None]
+        want = np.concatenate([[v.shape[1]], v.sum(axis=1), (v * v).sum(axis=1)])
+        assert np.allclose(np.array(out[:]), want, rtol=1e-12, atol=1e-12)
+        # compaction of two (3, n) arrays + ids behind the mask keeps the order
+        src = [np.ascontiguousarray(rng.normal(size=n)) for _ in range(6)]
+        dst = [np.full(n, np.nan) for _ in range(6)]
+        srcp = (ctypes.c_void_p * 6)(*[a.ctypes.data for a in src])
+        dstp = (ctypes.c_void_p * 6)(*[a.ctypes.data for a in dst])
+        ids = np.arange(n, dtype=np.int64) * 3
+        ids_out = np.full(n, -1, dtype=np.int64)
+        scratch = np.zeros(int(lib.prt_compact_scratch_bytes(n)), dtype=np.uint8)
+        count = ctypes.c_int64(-1)
+        rc = lib.prt_compact(n, mask.ctypes.data, 6, srcp, dstp, ids.ctypes.data, ids_out.ctypes.data, None, None,
+                             scratch.ctypes.data, ctypes.byref(count), None)
+        assert rc == 0, lib.prt_last_error()
+        m = mask.astype(bool)
+        assert count.value == int(m.sum())
+        for (a, b) in zip(src, dst):
+            assert np.array_equal(b[:count.value], a[m])
+        assert np.array_equal(ids_out[:count.value], ids[m])
+    case = _golden.load_case("asphere_strong_field5")
+    hs = hostemu.HostSystem(case.table)
+    s = [i for (i, r) in enumerate(case.table) if r["shape"]["type"] != "conic"][0]
+    (xx, yy) = (np.linspace(-3, 3, 77), np.linspace(2, -2, 77))
+    (sag, grad) = hs.shape_eval(s, xx, yy)
+    assert np.allclose(sag, oracle.shape_sag(case.table[s]["shape"], xx, yy), rtol=1e-13, atol=1e-14)
+
+
+def test_the_sanitizer_build_does_see_an_overrun():
+    """negative control of the test above: an output array five doubles short -> AddressSanitizer reports the write of
+    the kernel (a frame of k_propagate_rows), inside a fibre"""
+    try:
+        lib = hostemu.build(sanitize=True)
+    except Exception as exc:
+        pytest.skip("no sanitizer build on this box: %s" % exc)
+    asan = hostemu.sanitizer_preload()
+    if asan is None:
+        pytest.skip("clang's shared asan runtime not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys\nsys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, _golden, hostemu\n"
+        "case = _golden.load_case('double_gauss_wide')\n"
+        "hs = hostemu.HostSystem(case.table)\n"
+        "n = case.x0.shape[1]\n"
+        "x = np.ascontiguousarray(case.x0); k = np.ascontiguousarray(np.real(case.k0))\n"
+        "short = np.empty(3 * n - 5); valid = np.zeros(n, dtype=np.uint8)\n"
+        "hs.lib.prt_propagate_rows(hs._h, 0, n, x.ctypes.data, n, k.ctypes.data, n, None, None, None, 0, None,\n"
+        "                          short.ctypes.data, n, valid.ctypes.data, None, None)\n" % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, LD_PRELOAD=asan, PRT_HOSTEMU_LIBRARY=lib, ASAN_OPTIONS="detect_leaks=0:exitcode=23")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 23 and "heap-buffer-overflow" in r.stderr and "k_propagate_rows" in r.stderr, r.stderr[-3000:]
