@@ -262,46 +262,6 @@ def test_bench_with_eight_ranks_on_this_gpu_gloo_dry_run(gpu_device, scaling):
     assert len(lines[0]) < 8192 and cfg["ms_trace"] > 0 and cfg["ms_total"] >= cfg["ms_gather"] >= 0
 
 
-def test_scale_preflight_dry_run_and_the_exchange_probe(gpu_device, tmp_path):
-    """benchmarks/scale_preflight.sh -- the script for the first contact with a multi-GPU node -- dry-run on this one
-    GPU with gloo: N = 1 and N = 2, both exchanges, one compact line per run, every rank verified; and the start-up
-    PROBE that chooses between the in-place all-gather and the direct peer writes (bench.py --exchange auto), run for
-    real with two ranks on this GPU (PRT_BENCH_PROBE_DRY=1: gloo instead of RCCL, which refuses two ranks on one
-    device): both forms are timed, one is chosen, the line says which."""
-    import json, os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PRT_ARENA_BUDGET_GIB="24", PRT_BENCH_WATCHDOG="300")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
-        env.pop(k, None)
-    out = str(tmp_path / "scale")
-    r = subprocess.run(["bash", os.path.join(root, "benchmarks", "scale_preflight.sh"), out, "2", "--backend", "gloo",
-                        "--rays-total", "2000000", "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True,
-                       timeout=1200, cwd=root)
-    rows = [json.loads(l) for l in open(os.path.join(out, "summary.jsonl")) if l.strip()]
-    assert len(rows) == 4, (r.stdout[-800:], r.stderr[-800:])
-    for row in rows:
-        assert not row.get("error"), row
-        assert row["value"] > 0 and all(row["ok_per_rank"]) and len(row["ok_per_rank"]) == row["n_gpus"]
-        assert row["scaling_point"]["ok"] and abs(row["scaling_point"]["rays"] - 2e6) < 0.02 * 2e6
-        assert row["exchange"] == ("gather" if row["exchange_asked"] == "auto" else "stats")
-        assert row["ms_total"] > 0 and row["ms_trace"] > 0
-    n1 = json.loads(open(os.path.join(out, "n1_default.json")).read().strip().splitlines()[-1])
-    assert n1["n_gpus"] == 1 and n1["verified"]["ok"] and len(json.dumps(n1)) < 8192
-    # the probe itself, two ranks on this GPU
-    env2 = dict(env, PRT_BENCH_PROBE_DRY="1", MASTER_PORT=str(_free_port()))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--rays-total",
-                        "2000000", "--steps", "3", "--warmup", "1"], env=env2, capture_output=True, text=True, timeout=900,
-                       cwd=root)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
-    line = json.loads(lines[0])
-    probe = line["config"]["exchange_probe_ms"]
-    assert set(probe) == {"gather", "gather-direct"} and probe["gather"] > 0
-    chosen = line["config"]["exchange"]
-    assert chosen in ("gather", "gather-direct") and probe[chosen] == min(v for v in probe.values() if v is not None)
-    assert line["verified"]["ok"] and line["verified"]["all_ranks_ok"] and "error" not in line
-
-
 def test_bench_line_names_the_torch_allocator_fallback(gpu_device):
     """with the arena switched off (PRT_ARENA=off: a driver without the virtual-memory API, a device in another
     partition mode ...) bench.py still measures -- path arrays from the torch allocator -- and the line SAYS so

@@ -342,3 +342,37 @@ def test_the_sanitizer_build_does_see_an_overrun():
     env = dict(os.environ, LD_PRELOAD=asan, PRT_HOSTEMU_LIBRARY=lib, ASAN_OPTIONS="detect_leaks=0:exitcode=23")
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 23 and "heap-buffer-overflow" in r.stderr and "k_propagate_rows" in r.stderr, r.stderr[-3000:]
+
+
+def test_host_build_table_update_in_place_and_the_poisoned_system(monkeypatch):
+    """prt_system_update (the optimiser's pattern): the updated system traces like a fresh one of the new table; a
+    table that does not fit is refused with nothing touched; an enqueue that fails half way (PRT_TEST_FAIL_UPDATE=k,
+    honoured only with PRT_TEST_HOOKS: conftest.py) poisons the system -- every later call is refused"""
+    import ctypes
+    from pyrate_amd import systems, _lib as P
+    from pyrate_amd.surface_table import pack_table
+    (o, k, e0) = systems.double_gauss_bundle(300, field_deg=2.0)
+    (rec_d, rec_f) = (systems.double_gauss_records(), systems.double_gauss_records(486.1e-6))
+    hs = hostemu.HostSystem(rec_d)
+    fresh = hostemu.HostSystem(rec_f).trace(o, k, e0)
+    before = hs.trace(o, k, e0)
+    assert hs.lib.prt_system_update(hs._h, pack_table(rec_f), len(rec_f), None) == 0
+    after = hs.trace(o, k, e0)
+    assert not np.array_equal(before[-1]["x_hit"], after[-1]["x_hit"])
+    for (a, b) in zip(after, fresh):
+        assert np.array_equal(a["x_hit"], b["x_hit"], equal_nan=True) and np.array_equal(a["valid_out"], b["valid_out"])
+    # another number of surfaces / an asphere where the system has no coefficient array: refused, the table stays
+    assert hs.lib.prt_system_update(hs._h, pack_table(rec_f[:-1]), len(rec_f) - 1, None) == P.ERR_UNSUPPORTED
+    asph = systems.asphere_records()
+    assert hs.lib.prt_system_update(hs._h, pack_table((asph * 3)[:len(rec_f)]), len(rec_f), None) == P.ERR_UNSUPPORTED
+    assert np.array_equal(hs.trace(o, k, e0)[-1]["x_hit"], after[-1]["x_hit"], equal_nan=True)
+    for fail_at in (1, 2):
+        victim = hostemu.HostSystem(rec_d)
+        monkeypatch.setenv("PRT_TEST_FAIL_UPDATE", str(fail_at))
+        rc = victim.lib.prt_system_update(victim._h, pack_table(rec_f), len(rec_f), None)
+        monkeypatch.delenv("PRT_TEST_FAIL_UPDATE")
+        assert rc == P.ERR_DEVICE and b"unusable" in victim.lib.prt_last_error()
+        with pytest.raises(hostemu.HostemuError) as err:
+            victim.trace(o, k, e0)
+        assert err.value.code == P.ERR_DEVICE and "unusable" in str(err.value)
+        assert victim.lib.prt_system_update(victim._h, pack_table(rec_f), len(rec_f), None) == P.ERR_DEVICE
