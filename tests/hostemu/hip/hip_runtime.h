@@ -50,15 +50,30 @@ inline dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define warpSize 64
 
 // ---- the fibres of a block ------------------------------------------------------------------------------------------
+// A block's threads are fibres on one OS thread, resumed round robin.  __syncthreads is a rendezvous of the block's live
+// threads.  Wave votes and shuffles are rendezvous of lanes of ONE wave at ONE textual call site: the hardware evaluates
+// them over the lanes that are active there (the exec mask), e.g. the `__all(done)` of the Newton loop inside
+// `if (i < N) { ... }` over the lanes that have a ray while the others wait at the reduction behind the branch.  The
+// emulation: a lane that reaches such a call waits; when every live lane of its wave is waiting somewhere (at call
+// sites of this kind or at the block barrier), ONE group -- the lanes waiting at one site -- is let through as the
+// active set; votes before shuffles (the kernels vote inside divergent regions and shuffle only where a wave has
+// reconverged), lower site number first.  A block in which nobody can be let through is reported, not left spinning.
 namespace hostemu {
 constexpr int WAVE = 64;
+constexpr int MAX_THREADS = 1024;
 constexpr size_t STACK_BYTES = 512 * 1024;
+enum { KIND_VOTE = 0, KIND_SHUFFLE = 1 };
 
 struct fibre {
     ucontext_t ctx;
     char *stack = nullptr;
     bool done = false;
     dim3 tid;
+    // waiting at a wave call site
+    bool waiting = false, released = false;
+    int site = 0, kind = 0;
+    uint64_t group = 0;        // the lanes let through together with this one
+    bool at_block_barrier = false;
 #ifdef HOSTEMU_ASAN
     void *fake_stack = nullptr;
 #endif
@@ -69,17 +84,12 @@ struct block_state {
     ucontext_t sched;
     int current = -1;
     int live = 0;
-    // block barrier
-    int arrived = 0;
+    int arrived = 0;           // block barrier
     uint64_t generation = 0;
-    // wave rendezvous (shuffles, ballots): per wave
-    int wave_live[16];
-    int wave_arrived[16];
-    uint64_t wave_generation[16];
-    double wave_buf[16][WAVE];
-    uint64_t wave_bits[16];
-    uint64_t wave_active[16];
-    uint64_t progress = 0;   // barrier releases + finished threads: the deadlock check of run_block
+    int wave_live[MAX_THREADS / WAVE];
+    double wave_buf[MAX_THREADS / WAVE][WAVE];
+    uint64_t wave_bits[MAX_THREADS / WAVE];
+    uint64_t progress = 0;     // releases + finished threads: the deadlock check of run_block
     const std::function<void()> *body = nullptr;
 #ifdef HOSTEMU_ASAN
     void *sched_fake = nullptr;
@@ -105,6 +115,55 @@ inline void switch_to_sched(bool dying) {
 
 inline void yield() { switch_to_sched(false); }
 
+// every live lane of wave w waiting?  then let the lanes of one call site through
+inline void wave_decide(int w) {
+    block_state &b = *g_block;
+    const int n = (int)b.fibres.size();
+    int blocked = 0;
+    bool have = false;
+    int best_kind = 0, best_site = 0;
+    for (int lane = 0; lane < WAVE; ++lane) {
+        const int t = w * WAVE + lane;
+        if (t >= n) break;
+        const fibre &f = b.fibres[t];
+        if (f.done) continue;
+        if (f.at_block_barrier) { blocked += 1; continue; }
+        if (f.waiting && !f.released) {
+            blocked += 1;
+            if (!have || f.kind < best_kind || (f.kind == best_kind && f.site < best_site)) {
+                have = true; best_kind = f.kind; best_site = f.site;
+            }
+        }
+    }
+    if (!have || blocked < b.wave_live[w]) return;
+    uint64_t group = 0;
+    for (int lane = 0; lane < WAVE && w * WAVE + lane < n; ++lane) {
+        const fibre &f = b.fibres[w * WAVE + lane];
+        if (!f.done && f.waiting && !f.released && f.kind == best_kind && f.site == best_site) group |= 1ull << lane;
+    }
+    for (int lane = 0; lane < WAVE && w * WAVE + lane < n; ++lane)
+        if ((group >> lane) & 1) {
+            fibre &f = b.fibres[w * WAVE + lane];
+            f.released = true; f.waiting = false; f.group = group;
+        }
+    b.progress += 1;
+}
+
+// returns the set of lanes that passed this call site together (the active lanes of the vote / shuffle)
+inline uint64_t wave_rendezvous(int site, int kind) {
+    block_state &b = *g_block;
+    const int t = b.current, w = t / WAVE;
+    fibre &f = b.fibres[t];
+    f.waiting = true; f.released = false; f.site = site; f.kind = kind; f.group = 0;
+    for (;;) {
+        wave_decide(w);
+        if (f.released) break;
+        yield();
+    }
+    f.released = false;
+    return f.group;
+}
+
 inline void trampoline() {
     block_state &b = *g_block;
 #ifdef HOSTEMU_ASAN
@@ -119,37 +178,30 @@ inline void trampoline() {
     b.wave_live[w] -= 1;
     // a thread that has returned no longer takes part in barriers: release who waits for it
     if (b.live > 0 && b.arrived == b.live) { b.arrived = 0; b.generation += 1; }
-    if (b.wave_live[w] > 0 && b.wave_arrived[w] == b.wave_live[w]) { b.wave_arrived[w] = 0; b.wave_generation[w] += 1; }
+    if (b.wave_live[w] > 0) wave_decide(w);
     switch_to_sched(true);
 }
 
 inline void block_barrier() {
     block_state &b = *g_block;
+    fibre &f = b.fibres[b.current];
     const uint64_t mine = b.generation;
     b.arrived += 1;
     if (b.arrived == b.live) { b.arrived = 0; b.generation += 1; b.progress += 1; return; }
+    f.at_block_barrier = true;
+    wave_decide(b.current / WAVE);      // (lanes of this wave may wait at a wave call site for "everybody else is blocked")
     while (b.generation == mine) yield();
-}
-
-inline void wave_barrier() {
-    block_state &b = *g_block;
-    const int w = b.current / WAVE;
-    const uint64_t mine = b.wave_generation[w];
-    b.wave_arrived[w] += 1;
-    if (b.wave_arrived[w] == b.wave_live[w]) { b.wave_arrived[w] = 0; b.wave_generation[w] += 1; b.progress += 1; return; }
-    while (b.wave_generation[w] == mine) yield();
+    f.at_block_barrier = false;
 }
 
 inline void run_block(dim3 block, const std::function<void()> &body) {
     const int n = (int)(block.x * block.y * block.z);
+    if (n > MAX_THREADS) { fprintf(stderr, "hostemu: block of %d threads\n", n); abort(); }
     block_state b;
     b.fibres.resize(n);
     b.body = &body;
     b.live = n;
-    for (int w = 0; w < 16; ++w) {
-        b.wave_live[w] = 0; b.wave_arrived[w] = 0; b.wave_generation[w] = 0; b.wave_bits[w] = 0; b.wave_active[w] = 0;
-    }
-    if (n > 16 * WAVE) { fprintf(stderr, "hostemu: block of %d threads\n", n); abort(); }
+    for (int w = 0; w < MAX_THREADS / WAVE; ++w) { b.wave_live[w] = 0; b.wave_bits[w] = 0; }
     while ((int)g_stacks.size() < n) g_stacks.push_back((char *)malloc(STACK_BYTES));
     g_block = &b;
     for (int t = 0; t < n; ++t) {
@@ -181,8 +233,11 @@ inline void run_block(dim3 block, const std::function<void()> &body) {
         }
         idle_passes = (b.progress == before) ? idle_passes + 1 : 0;
         if (idle_passes > 2) {
-            fprintf(stderr, "hostemu: block (%u,%u,%u) is stuck at a barrier / wave vote that not all of its live threads "
-                            "reach (divergent __syncthreads / __all / __shfl)\n", blockIdx.x, blockIdx.y, blockIdx.z);
+            int at_sites = 0;
+            for (int t = 0; t < n; ++t) at_sites += (!b.fibres[t].done && b.fibres[t].waiting) ? 1 : 0;
+            fprintf(stderr, "hostemu: block (%u,%u,%u) is stuck: %d live threads, %d at the block barrier, %d at wave votes / "
+                            "shuffles -- a __syncthreads that not every live thread reaches\n",
+                    blockIdx.x, blockIdx.y, blockIdx.z, b.live, b.arrived, at_sites);
             abort();
         }
     }
@@ -199,6 +254,33 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
                 run_block(block, body);
             }
 }
+
+template <typename T>
+inline T shfl_down(int site, T v, unsigned delta, int width = 64) {
+    block_state &b = *g_block;
+    const int w = b.current / WAVE, lane = b.current % WAVE;
+    static_assert(sizeof(T) <= sizeof(double), "hostemu shuffle: 8-byte values");
+    double slot = 0.0;
+    memcpy(&slot, &v, sizeof(T));
+    b.wave_buf[w][lane] = slot;
+    const uint64_t active = wave_rendezvous(2 * site, KIND_SHUFFLE);
+    T r = v;       // (a source lane that is not active: the hardware's result is undefined; here the lane's own value)
+    const int src = lane + (int)delta;
+    if (src < WAVE && (lane / width) == (src / width) && ((active >> src) & 1)) memcpy(&r, &b.wave_buf[w][src], sizeof(T));
+    wave_rendezvous(2 * site + 1, KIND_SHUFFLE);      // everybody has read before anybody writes again
+    return r;
+}
+
+inline unsigned long long vote(int site, int pred, unsigned long long *active) {
+    block_state &b = *g_block;
+    const int w = b.current / WAVE, lane = b.current % WAVE;
+    if (pred) b.wave_bits[w] |= (1ull << lane);
+    else b.wave_bits[w] &= ~(1ull << lane);
+    *active = wave_rendezvous(2 * site, KIND_VOTE);
+    const unsigned long long r = b.wave_bits[w] & *active;
+    wave_rendezvous(2 * site + 1, KIND_VOTE);
+    return r;
+}
 }  // namespace hostemu
 
 // `kernel` may be a parenthesised template-id; calling it by name keeps its default arguments
@@ -206,43 +288,14 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
     ((void)(shmem), (void)(stream), hostemu::launch(dim3(grid), dim3(block), [&]() { kernel(__VA_ARGS__); }))
 
 inline void __syncthreads() { hostemu::block_barrier(); }
-
-template <typename T>
-inline T __shfl_down(T v, unsigned delta, int width = 64) {
-    hostemu::block_state &b = *hostemu::g_block;
-    const int w = b.current / hostemu::WAVE, lane = b.current % hostemu::WAVE;
-    static_assert(sizeof(T) <= sizeof(double), "hostemu shuffle: 8-byte values");
-    double slot = 0.0;
-    memcpy(&slot, &v, sizeof(T));
-    b.wave_buf[w][lane] = slot;
-    hostemu::wave_barrier();
-    T r = v;
-    const int src = lane + (int)delta;
-    if (src < width && (lane / width) == (src / width) && src < hostemu::WAVE &&
-        w * hostemu::WAVE + src < (int)b.fibres.size() && !b.fibres[w * hostemu::WAVE + src].done)
-        memcpy(&r, &b.wave_buf[w][src], sizeof(T));
-    hostemu::wave_barrier();
-    return r;
-}
-
-// wave votes: a rendezvous of the wave's live lanes (the kernels vote in converged control flow only; a vote inside a
-// divergent branch would stall here and is reported by the scheduler's deadlock check)
-inline unsigned long long hostemu_vote(int pred, unsigned long long *active) {
-    hostemu::block_state &b = *hostemu::g_block;
-    const int w = b.current / hostemu::WAVE, lane = b.current % hostemu::WAVE;
-    if (pred) b.wave_bits[w] |= (1ull << lane);
-    b.wave_active[w] |= (1ull << lane);
-    hostemu::wave_barrier();
-    const unsigned long long r = b.wave_bits[w];
-    *active = b.wave_active[w];
-    hostemu::wave_barrier();
-    b.wave_bits[w] &= ~(1ull << lane);   // behind the second rendezvous every lane has read the words
-    b.wave_active[w] &= ~(1ull << lane);
-    return r;
-}
-inline unsigned long long __ballot(int pred) { unsigned long long a; return hostemu_vote(pred, &a); }
-inline int __all(int pred) { unsigned long long a; const unsigned long long r = hostemu_vote(pred, &a); return r == a; }
-inline int __any(int pred) { unsigned long long a; return hostemu_vote(pred, &a) != 0; }
+// (one site number per textual call)
+#define __shfl_down(...) hostemu::shfl_down(__COUNTER__ + 1, __VA_ARGS__)
+inline unsigned long long hostemu_ballot(int site, int pred) { unsigned long long a; return hostemu::vote(site, pred, &a); }
+inline int hostemu_all(int site, int pred) { unsigned long long a; const unsigned long long r = hostemu::vote(site, pred, &a); return r == a; }
+inline int hostemu_any(int site, int pred) { unsigned long long a; return hostemu::vote(site, pred, &a) != 0; }
+#define __ballot(p) hostemu_ballot(__COUNTER__ + 1, (p))
+#define __all(p) hostemu_all(__COUNTER__ + 1, (p))
+#define __any(p) hostemu_any(__COUNTER__ + 1, (p))
 #define __popcll(x) __builtin_popcountll(x)
 
 struct double2 { double x, y; };

@@ -376,3 +376,45 @@ def test_host_build_table_update_in_place_and_the_poisoned_system(monkeypatch):
             victim.trace(o, k, e0)
         assert err.value.code == P.ERR_DEVICE and "unusable" in str(err.value)
         assert victim.lib.prt_system_update(victim._h, pack_table(rec_f), len(rec_f), None) == P.ERR_DEVICE
+
+
+def test_host_build_fused_image_plane_moments():
+    """prt_trace_moments: the march's MOMENTS epilogue (wave shuffles, a block barrier, per-block partials, a second
+    launch that adds them in a fixed order) = count / sum v / sum v^2 of the image-plane arrays the same launch wrote"""
+    import ctypes
+    from pyrate_amd import systems, _lib as P
+    lib = hostemu.load()
+    for (recs, n_ask) in ((systems.double_gauss_records(), 3000), (systems.asphere_records(), 700)):
+        (o, k, e0) = systems.double_gauss_bundle(n_ask, field_deg=3.0) if len(recs) > 4 else \
+            systems.double_gauss_bundle(n_ask, rpup=9.0, z0=-5.0)
+        n = o.shape[1]
+        hs = hostemu.HostSystem(recs)
+        pitch = int(lib.prt_recommended_pitch(n))
+        (x_img, k_img) = (np.full((3, pitch), np.nan), np.full((3, pitch), np.nan))
+        (v_img, w_img) = (np.zeros(pitch, dtype=np.uint8), np.zeros(pitch, dtype=np.uint8))
+        out7 = np.full(7, np.nan)
+        scratch = np.zeros(int(lib.prt_trace_moments_scratch_doubles(n)))
+        ref3 = (ctypes.c_double * 3)(0.0, 0.0, float(recs[-1]["g_shape"][2]))
+        (oc, kc, ec) = [np.ascontiguousarray(a) for a in (o, k, np.real(e0))]
+        rc = lib.prt_trace_moments(hs._h, n, 0, oc.ctypes.data, kc.ctypes.data, ec.ctypes.data, None, P.MODE_IMAGE, pitch,
+                                   x_img.ctypes.data, k_img.ctypes.data, v_img.ctypes.data, w_img.ctypes.data, ref3,
+                                   out7.ctypes.data, scratch.ctypes.data, None)
+        assert rc == 0, lib.prt_last_error()
+        dense = hs.trace(o, k, e0, mode=P.MODE_IMAGE)
+        m = dense[0]["valid_out"].astype(bool)
+        assert np.array_equal(w_img[:n].astype(bool), m) and m.sum() > 100
+        assert np.array_equal(x_img[:, :n][:, m], dense[0]["x_hit"][:, m])
+        v = dense[0]["x_hit"][:, m] - np.array(ref3[:])[:, None]
+        want = np.concatenate([[m.sum()], v.sum(axis=1), (v * v).sum(axis=1)])
+        assert np.allclose(out7, want, rtol=1e-12, atol=1e-12), (out7, want)
+
+
+def test_the_stand_in_runtime_votes_over_active_lanes_and_shuffles_where_waves_reconverge(tmp_path):
+    """self-test of tests/hostemu/hip/hip_runtime.h (selftest_votes.cpp): `__all` inside `if (i < N)` is a vote of the
+    lanes that are there, the reduction behind the branch sees every lane"""
+    clang = hostemu.find_clang()
+    exe = str(tmp_path / "selftest_votes")
+    subprocess.run([clang, "-x", "c++", "-std=c++17", "-O1", "-I" + hostemu.HERE, os.path.join(hostemu.HERE, "selftest_votes.cpp"),
+                    "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.split() == ["640", "640", "220"], (r.stdout, r.stderr)
