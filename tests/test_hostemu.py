@@ -243,6 +243,8 @@ for name in %(cases)r:
         T.host_trace(case, want_fields=True, want_k_im=True)
 T.test_host_build_many_blocks_and_the_xcd_block_map()
 T.test_host_build_device_side_helpers()
+T.test_host_build_bundle_generation_and_the_small_helpers()
+T.test_host_build_fused_image_plane_moments()
 print("RESULT " + json.dumps({"worst_k": worst}))
 '''
 
@@ -418,3 +420,100 @@ def test_the_stand_in_runtime_votes_over_active_lanes_and_shuffles_where_waves_r
                     "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.split() == ["640", "640", "220"], (r.stdout, r.stderr)
+
+
+def test_host_build_bundle_generation_and_the_small_helpers():
+    """the remaining kernels of the library on the host build: RectGrid + collimated bundle (bit-identical to the host
+    raster), every deterministic raster against the REFERENCE's bundles (tests/golden/bundles.json: origins bit for
+    bit, wave vectors to a few ulp of libm), Poynting directions, a unit E perpendicular to k, path sums"""
+    import ctypes
+    import math
+    from pyrate_amd import systems, _lib as P
+    from pyrate_amd.sampling2d import raster
+    lib = hostemu.load()
+    # RectGrid + collimated bundle: the whole raster and a shard of it
+    for nray in (50, 1000, 5000):
+        (o, k, e0) = systems.double_gauss_bundle(nray, field_deg=5.0)
+        (npd, ndisk) = (ctypes.c_int64(), ctypes.c_int64())
+        assert lib.prt_rect_grid_count(0, nray, ctypes.byref(npd), ctypes.byref(ndisk), None) == 0
+        total = ndisk.value
+        assert total == o.shape[1] and npd.value == int(round(math.sqrt(nray * 4.0 / math.pi)))
+        field = 5.0 * math.pi / 180.
+        prm = P.PrtCollimated()
+        (prm.radius, prm.startx, prm.starty, prm.startz) = (5.0, 0.0, -10.0 * math.tan(field), -10.0)
+        prm.k[:] = [0.0, math.sin(field), math.cos(field)]
+        prm.e[:] = [0.0, math.cos(field), -math.sin(field)]
+        for (lo, hi) in ((0, total), (total // 3, total // 3 + max(1, total // 2))):
+            m = hi - lo
+            (x, kk, ee) = (np.full((3, m), np.nan), np.full((3, m), np.nan), np.full((3, m), np.nan))
+            rc = lib.prt_collimated_bundle(0, nray, lo, hi, ctypes.byref(prm), m, x.ctypes.data, kk.ctypes.data,
+                                           ee.ctypes.data, None)
+            assert rc == 0, lib.prt_last_error()
+            assert np.array_equal(x, o[:, lo:hi]) and np.array_equal(kk, k[:, lo:hi]) and np.array_equal(ee, e0[:, lo:hi])
+    ref = json.load(open(os.path.join(_golden.GOLDEN_DIR, "bundles.json")))
+    objs = {"rect_60": raster.RectGrid(), "hex_45": raster.HexGrid(), "meridional_9": raster.MeridionalFan(),
+            "sagital_8": raster.SagitalFan(), "circular_49": raster.CircularGrid()}
+    for (key, case) in ref.items():
+        pd = case["props"]
+        tables_list = objs[case["raster"]].device_tables(case["nray"])
+        (gx, gy) = objs[case["raster"]].getGrid(case["nray"])
+        prm = P.PrtBundle()
+        prm.kind = {"collimated": 0, "divergent": 1}[case["bundle"]]
+        (prm.radius, prm.anglex, prm.angley, prm.index) = (pd["radius"], pd["anglex"], pd["angley"], case["index"])
+        prm.start[:] = [pd["startx"], pd["starty"], pd["startz"]]
+        if case["bundle"] == "collimated":
+            unit = np.array([math.sin(pd["angley"]) * math.cos(pd["anglex"]), math.sin(pd["anglex"]),
+                             math.cos(pd["angley"]) * math.cos(pd["anglex"])])
+            prm.k[:] = list(case["index"] * unit)
+            prm.e[:] = [1.0, 0.0, 0.0]
+        structs = []
+        counts = []
+        for (xa, xb, ya, yb, clip) in tables_list:
+            arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (xa, xb, ya, yb)]
+            r = P.PrtRaster()
+            (r.nj, r.ni) = (arrs[0].shape[0], arrs[1].shape[0])
+            (r.xa, r.xb, r.ya, r.yb) = [a.ctypes.data for a in arrs]
+            r.clip = 1 if clip else 0
+            r._keep = arrs
+            c = ctypes.c_int64()
+            assert lib.prt_raster_count(0, ctypes.byref(r), ctypes.byref(c), None) == 0
+            structs.append(r)
+            counts.append(c.value)
+        total = sum(counts)
+        (xr, kr) = (np.array(case["x"]), np.array(case["k"]))
+        assert total == xr.shape[1] == gx.shape[0], key
+        (x, k, e) = (np.full((3, total), np.nan), np.full((3, total), np.nan), np.full((3, total), np.nan))
+        pup = np.full((2, total), np.nan)
+        base = 0
+        for (r, c) in zip(structs, counts):
+            if c:
+                off = base * 8
+                rc = lib.prt_raster_bundle(0, ctypes.byref(r), 0, c, ctypes.byref(prm), total, x.ctypes.data + off,
+                                           k.ctypes.data + off, e.ctypes.data + off, pup.ctypes.data + off, None)
+                assert rc == 0, lib.prt_last_error()
+            base += c
+        assert np.array_equal(pup, np.vstack((gx, gy))), key
+        assert np.array_equal(x, xr), key
+        assert np.abs(k - kr).max() < 2e-15, (key, np.abs(k - kr).max())
+        assert np.abs(np.sqrt((k ** 2).sum(axis=0)) - case["index"]).max() < 4e-16, key
+        if case["bundle"] == "divergent":
+            assert np.abs((e * k).sum(axis=0)).max() < 1e-15 and np.abs((e ** 2).sum(axis=0) - 1).max() < 1e-15
+    # Poynting direction of (k, E) (ray.py:136-152), a unit E perpendicular to k, path sums
+    rng = np.random.RandomState(3)
+    n = 777
+    k = np.ascontiguousarray(rng.normal(size=(3, n)) + np.array([[0.], [0.], [3.]]))
+    (er, ei) = (np.ascontiguousarray(rng.normal(size=(3, n))), np.ascontiguousarray(rng.normal(size=(3, n))))
+    d = np.full((3, n), np.nan)
+    assert lib.prt_poynting_dir(0, n, k.ctypes.data, er.ctypes.data, ei.ctypes.data, 0, d.ctypes.data, None) == 0
+    E = er + 1j * ei
+    S = np.real(np.sum(np.conj(E) * E, axis=0) * k - np.sum(E * k, axis=0) * np.conj(E))
+    assert np.allclose(d, S / np.sqrt(np.sum(S ** 2, axis=0)), rtol=0, atol=1e-14)
+    e = np.full((3, n), np.nan)
+    assert lib.prt_efield_perp(0, n, k.ctypes.data, e.ctypes.data, None) == 0
+    assert np.abs((e * k).sum(axis=0)).max() < 1e-14 and np.abs((e ** 2).sum(axis=0) - 1).max() < 1e-14
+    xs = [np.ascontiguousarray(rng.normal(size=(3, n))) for _ in range(4)]
+    out = np.full(n, np.nan)
+    xt = (ctypes.c_void_p * 4)(*[a.ctypes.data for a in xs])
+    assert lib.prt_path_sums(0, 4, n, xt, None, 0, out.ctypes.data, None) == 0
+    want = sum(np.sqrt(np.sum((xs[i + 1] - xs[i]) ** 2, axis=0)) for i in range(3))
+    assert np.allclose(out, want, rtol=1e-14)
