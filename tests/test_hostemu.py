@@ -245,6 +245,7 @@ T.test_host_build_many_blocks_and_the_xcd_block_map()
 T.test_host_build_device_side_helpers()
 T.test_host_build_bundle_generation_and_the_small_helpers()
 T.test_host_build_fused_image_plane_moments()
+T.test_host_build_empty_bundles_and_argument_errors()
 print("RESULT " + json.dumps({"worst_k": worst}))
 '''
 
@@ -517,3 +518,70 @@ def test_host_build_bundle_generation_and_the_small_helpers():
     assert lib.prt_path_sums(0, 4, n, xt, None, 0, out.ctypes.data, None) == 0
     want = sum(np.sqrt(np.sum((xs[i + 1] - xs[i]) ** 2, axis=0)) for i in range(3))
     assert np.allclose(out, want, rtol=1e-14)
+
+
+def test_host_build_empty_bundles_and_argument_errors():
+    """edges of the C ABI on the host build (also under the sanitizers): empty bundles through every entry point (null
+    arrays allowed), a single ray, and structural misuse -- which is an error code, never a crash: surface index out
+    of range, a bad mode word, a struct of another size, a ray pitch smaller than the ray count, a negative count"""
+    import ctypes
+    from pyrate_amd import systems, _lib as P
+    lib = hostemu.load()
+    recs = systems.double_gauss_records()
+    hs = hostemu.HostSystem(recs)
+    crystal = hostemu.HostSystem(systems.aniso_doublet_records())
+    empty = np.zeros((3, 0))
+    for system in (hs, crystal):
+        for mode in (P.MODE_PATH, P.MODE_IMAGE):
+            a = P.PrtTraceArgs()
+            a.struct_bytes = ctypes.sizeof(P.PrtTraceArgs)
+            (a.mode, a.n0) = (mode, 0)
+            assert lib.prt_trace_ex(system._h, ctypes.byref(a)) == 0
+    assert lib.prt_propagate_rows(hs._h, 0, 0, None, 0, None, 0, None, None, None, 0, None, None, 0, None, None, None) == 0
+    assert lib.prt_interact_rows(hs._h, 0, 0, None, 0, None, 0, None, None, 0, None, None, None) == 0
+    assert lib.prt_surface_step_rows(hs._h, 0, 0, None, 0, None, 0, None, None, None, 0, None, None, None, 0, None, None,
+                                     None, None) == 0
+    assert lib.prt_propagate(hs._h, 0, 0, None, None, None, None, None, 0, None, None, None, None, None) == 0
+    assert lib.prt_interact(hs._h, 0, 0, None, None, None, None, None, None, None, None, None) == 0
+    assert lib.prt_efield_perp(0, 0, None, None, None) == 0 and lib.prt_poynting_dir(0, 0, None, None, None, 0, None, None) == 0
+    out7 = (ctypes.c_double * 7)(*([9.0] * 7))
+    assert lib.prt_bundle_moments(0, 0, 0, None, None, 0, None, out7, None) == 0 and list(out7) == [0.0] * 7
+    kept = ctypes.c_int64(-1)
+    assert lib.prt_compact(0, None, 0, None, None, None, None, None, None, None, ctypes.byref(kept), None) == 0
+    assert kept.value == 0
+    # one ray
+    (o, k, e0) = systems.double_gauss_bundle(20, field_deg=1.0)
+    one = hs.trace(o[:, :1], k[:, :1], e0[:, :1])
+    many = hs.trace(o, k, e0)
+    for (a1, am) in zip(one, many):
+        assert np.array_equal(a1["x_hit"][:, 0], am["x_hit"][:, 0]) and a1["valid_out"][0] == am["valid_out"][0]
+    # misuse
+    x = np.ascontiguousarray(o[:, :8])
+    bad = lambda rc: rc == P.ERR_INVALID_ARG            # noqa: E731
+    assert bad(lib.prt_propagate_rows(hs._h, 99, 8, x.ctypes.data, 8, x.ctypes.data, 8, None, None, None, 0, None,
+                                      x.ctypes.data, 8, None, None, None))
+    assert bad(lib.prt_surface_step_rows(hs._h, -1, 8, x.ctypes.data, 8, x.ctypes.data, 8, None, None, None, 0, None,
+                                         x.ctypes.data, x.ctypes.data, 8, None, None, None, None))
+    assert bad(lib.prt_propagate_rows(hs._h, 0, -3, x.ctypes.data, 8, x.ctypes.data, 8, None, None, None, 0, None,
+                                      x.ctypes.data, 8, None, None, None))
+    a = P.PrtTraceArgs()
+    a.struct_bytes = ctypes.sizeof(P.PrtTraceArgs) - 8
+    (a.mode, a.n0) = (0, 8)
+    assert bad(lib.prt_trace_ex(hs._h, ctypes.byref(a)))                 # a caller built against another layout
+    a.struct_bytes = ctypes.sizeof(P.PrtTraceArgs)
+    a.mode = 7
+    (a.x0, a.k0) = (x.ctypes.data, x.ctypes.data)
+    buf = np.zeros(3 * 12 * 8)
+    mask = np.zeros(12 * 8, dtype=np.uint8)
+    (a.x_hit, a.k_out, a.valid) = (buf.ctypes.data, buf.ctypes.data, mask.ctypes.data)
+    assert bad(lib.prt_trace_ex(hs._h, ctypes.byref(a)))                 # bad mode
+    a.mode = 0
+    a.out_pitch = 4
+    assert bad(lib.prt_trace_ex(hs._h, ctypes.byref(a)))                 # pitch < n0
+    assert bad(lib.prt_trace_ex(None, ctypes.byref(a)))                  # no system
+    assert b"" != lib.prt_last_error()
+    n_in = (ctypes.c_int64 * 12)()
+    assert bad(lib.prt_system_ray_counts(hs._h, -1, n_in, n_in))
+    h = ctypes.c_void_p()
+    from pyrate_amd.surface_table import pack_table
+    assert bad(lib.prt_system_create(pack_table(recs), 0, 0, ctypes.byref(h)))
