@@ -18,7 +18,7 @@ BUILD = os.path.join(HERE, "_build")
 SOURCES = [os.path.join(HERE, "hostemu_prt.cpp"), os.path.join(HERE, "hip", "hip_runtime.h")] + \
     [os.path.join(ROOT, "pyrate_amd", "csrc", f) for f in ("prt.hip", "prt_kernels.h", "prt_device.h", "prt_aniso.h",
                                                            "prt_aniso_cplx.h", "prt_placed.h")] + \
-    [os.path.join(ROOT, "include", "prt.h")]
+    [os.path.join(ROOT, "include", "prt.h"), os.path.abspath(__file__)]          # (this file: the compiler flags)
 CLANG_CANDIDATES = ["/opt/rocm/lib/llvm/bin/clang++", "/opt/rocm/llvm/bin/clang++", "clang++"]
 
 
@@ -49,7 +49,7 @@ def build(sanitize=False, force=False):
     cmd = [clang, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-I" + HERE, "-ffp-contract=on",
            "-fno-math-errno", "-Wall", "-Wno-unused-function", "-Wno-unknown-attributes"]
     if sanitize:
-        cmd += ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared-libsan",
+        cmd += ["-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=undefined,float-cast-overflow", "-shared-libsan",
                 "-fno-omit-frame-pointer"]
     subprocess.run(cmd + [SOURCES[0], "-o", out + ".tmp"], check=True)
     os.replace(out + ".tmp", out)

@@ -246,6 +246,7 @@ T.test_host_build_device_side_helpers()
 T.test_host_build_bundle_generation_and_the_small_helpers()
 T.test_host_build_fused_image_plane_moments()
 T.test_host_build_empty_bundles_and_argument_errors()
+T.test_host_build_poisoned_rays_are_masks_never_crashes()
 print("RESULT " + json.dumps({"worst_k": worst}))
 '''
 
@@ -585,3 +586,62 @@ def test_host_build_empty_bundles_and_argument_errors():
     h = ctypes.c_void_p()
     from pyrate_amd.surface_table import pack_table
     assert bad(lib.prt_system_create(pack_table(recs), 0, 0, ctypes.byref(h)))
+
+
+POISON_CASES = ["double_gauss_wide", "tilted_frames", "asphere_strong_field5", "xypoly_field5", "biconic_field5",
+                "gridsag_field2", "zernike_fringe_field3", "zernike_combination_mirror", "aniso_doublet_uniaxial",
+                "aniso_doublet_biaxial", "aniso_absorbing_two_crystals"]
+
+
+def test_host_build_poisoned_rays_are_masks_never_crashes():
+    """per-ray failure is a mask, never a crash (surface_shape.py:215-216, 321; helpers_math.py:32-37): rays whose inputs
+    are NaN, +-Inf, 1e300, 1e-320 or a zero wave vector go through every shape evaluator (the sag grid's spline
+    interval search, polynomial tables, the crystal solvers) -- under ASan / UBSan in the sanitizer test: no access
+    outside an array, no undefined conversion -- and every OTHER ray of the bundle gets exactly the record it gets
+    without them (a ray's result does not depend on its neighbours in the wave)"""
+    poison = [np.nan, np.inf, -np.inf, 1e300, -1e300, 1e-320, 0.0]
+    for name in POISON_CASES:
+        if not os.path.exists(os.path.join(_golden.GOLDEN_DIR, name + ".npz")):
+            continue
+        case = _golden.load_case(name)
+        (_, clean) = host_trace(case, want_nonconv=True)
+        (x0, k0) = (np.array(case.x0, dtype=float), np.array(np.real(case.k0), dtype=float))
+        n0 = x0.shape[1]
+        hit = np.zeros(n0, dtype=bool)
+        j = 0
+        for (q, v) in enumerate(poison):
+            for arr in (x0, k0):
+                for comp in range(3):
+                    col = (7 * j + 3) % n0
+                    j += 1
+                    if hit[col]:
+                        continue
+                    arr[comp, col] = v
+                    hit[col] = True
+        col = (7 * j + 3) % n0
+        k0[:, col] = 0.0                       # a ray without a direction
+        hit[col] = True
+        e = np.asarray(case.E0)
+        hs = hostemu.HostSystem(case.table)
+        with np.errstate(all="ignore"):
+            dirty = hs.trace(x0, k0, e.real, e.imag if np.iscomplexobj(e) else None, want_nonconv=True)
+        assert (~hit).sum() > n0 // 3
+        for s in range(case.n_surfaces):
+            B_in = dirty[s]["x_hit"].shape[1] // n0
+            B_out = dirty[s]["k_out"].shape[1] // n0
+            keep_in = np.tile(~hit, B_in)
+            keep_out = np.tile(~hit, B_out)
+            assert np.array_equal(dirty[s]["valid"][keep_in], clean[s]["valid"][keep_in]), (name, s)
+            assert np.array_equal(dirty[s]["valid_out"][keep_out], clean[s]["valid_out"][keep_out]), (name, s)
+            assert np.array_equal(dirty[s]["x_hit"][:, keep_in], clean[s]["x_hit"][:, keep_in], equal_nan=True), (name, s)
+            assert np.array_equal(dirty[s]["k_out"][:, keep_out], clean[s]["k_out"][:, keep_out], equal_nan=True), (name, s)
+        if hs.all_isotropic:
+            # the same rays through the per-surface calls and the fused step
+            (x, k, valid) = (x0, k0, None)
+            for s in range(case.n_surfaces):
+                first = dict(e_re=e.real, e_im=e.imag if np.iscomplexobj(e) else None) if s == 0 else dict(default_e=False)
+                (xh, kk, v, vo) = hs.surface_step_rows(s, x, k, valid_in=valid, **first)
+                (xh2, v2) = hs.propagate_rows(s, x, k, valid_in=valid, **first)
+                (k2, vo2) = hs.interact_rows(s, xh2, k, valid_in=v2)
+                assert np.array_equal(vo[~hit], dirty[s]["valid_out"][~hit]) and np.array_equal(vo2[~hit], vo[~hit]), (name, s)
+                (x, k, valid) = (xh, kk, vo)
