@@ -3,7 +3,7 @@
 
     python benchmarks/isa_report.py > profiles/<tag>_isa_report.json
 
-Per instantiation of k_trace_iso / k_trace_general / k_propagate_rows / k_interact_iso_rows: VGPRs, scratch bytes per lane, waves per SIMD, LDS bytes
+Per instantiation of k_trace_iso / k_trace_general / k_propagate_rows / k_interact_iso_rows / k_surface_step_rows: VGPRs, scratch bytes per lane, waves per SIMD, LDS bytes
 per block (hipcc -Rpass-analysis=kernel-resource-usage), and from the instruction stream
   flat_memory_ops        flat_load / flat_store (a pointer whose address space the compiler could not see:
                          per-lane vector memory traffic + lgkmcnt AND vmcnt waits)
@@ -27,7 +27,8 @@ sys.path.insert(0, ROOT)
 from pyrate_amd import build as prt_build
 
 # the marches and the per-surface kernels of big bundles (k_propagate_rows / k_interact_iso_rows)
-MARCH = ("_Z11k_trace_iso", "_Z15k_trace_general", "_Z16k_propagate_rows", "_Z19k_interact_iso_rows")
+MARCH = ("_Z11k_trace_iso", "_Z15k_trace_general", "_Z16k_propagate_rows", "_Z19k_interact_iso_rows",
+         "_Z19k_surface_step_rows")
 
 
 def template_args(mangled):

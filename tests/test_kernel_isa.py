@@ -91,3 +91,17 @@ def test_the_per_surface_kernels_of_big_bundles(isa):
         assert isa[n]["scratch_bytes_per_lane"] == 0 and isa[n]["flat_memory_ops"] == 0, n
     for level in (1, 2):                   # aspheres; XY polynomials / biconics: their own Newton code only
         assert isa["k_propagate_rows<1,%d>" % level]["vgprs"] <= 72, level
+
+
+def test_the_fused_surface_step_kernel(isa):
+    """k_surface_step_rows<VEC, SHAPES> (prt_surface_step_rows: propagate + refract of one surface in one launch): the
+    conic instantiation stays a streaming kernel (8 waves), the Newton levels keep the fused march's five waves, nothing
+    spills or uses flat addressing"""
+    conic = isa["k_surface_step_rows<1,0>"]
+    assert conic["vgprs"] <= 64 and conic["waves_per_simd"] == 8
+    names = [n for n in isa if n.startswith("k_surface_step_rows<")]
+    assert len(names) == 5, names          # 4 shape classes (VEC) + the unaligned fall-back
+    for n in names:
+        assert isa[n]["scratch_bytes_per_lane"] == 0 and isa[n]["flat_memory_ops"] == 0, n
+    for level in (1, 2):
+        assert isa["k_surface_step_rows<1,%d>" % level]["waves_per_simd"] >= 5, level
