@@ -37,9 +37,9 @@ def test_surface_step_matches_the_fused_march_and_the_two_calls(name, gpu_device
         assert torch.equal(v, res.valid[s]) and torch.equal(vo, res.valid_out[s])
         assert torch.equal(v, v_b) and torch.equal(vo, vo_b)
         m = vo.bool()
-        assert torch.allclose(xh[:, m], res.x_hit[s][:, m], rtol=0, atol=1e-12)
-        assert torch.allclose(k2[:, m], res.k_out[s][:, m], rtol=0, atol=1e-13)
-        assert torch.allclose(xh[:, m], xh_b[:, m], rtol=0, atol=1e-12) and torch.allclose(k2[:, m], k2_b[:, m], rtol=0, atol=1e-13)
+        assert torch.allclose(xh[:, m], res.x_hit[s][:, m], rtol=0, atol=1e-11)
+        assert torch.allclose(k2[:, m], res.k_out[s][:, m], rtol=0, atol=1e-12)
+        assert torch.allclose(xh[:, m], xh_b[:, m], rtol=0, atol=1e-11) and torch.allclose(k2[:, m], k2_b[:, m], rtol=0, atol=1e-12)
         (x, k, valid) = (xh, k2, vo)
 
 
@@ -61,8 +61,8 @@ def test_surface_step_on_odd_and_tiny_bundles_and_tight_arrays(n, gpu_device):
             (xh, k2, v, vo, nc) = sysd.surface_step(s, x, kk, valid_in=valid, want_nonconv=True, **first)
             assert torch.equal(v, res.valid[s]) and torch.equal(vo, res.valid_out[s]) and torch.equal(nc, res.nonconv[s])
             m = vo.bool()
-            assert torch.allclose(xh[:, m], res.x_hit[s][:, m], rtol=0, atol=1e-12)
-            assert torch.allclose(k2[:, m], res.k_out[s][:, m], rtol=0, atol=1e-13)
+            assert torch.allclose(xh[:, m], res.x_hit[s][:, m], rtol=0, atol=1e-11)
+            assert torch.allclose(k2[:, m], res.k_out[s][:, m], rtol=0, atol=1e-12)
             (x, kk, valid) = (xh, k2, vo)
     case = _golden.load_case("aniso_doublet_uniaxial")
     crystal = engine.DeviceSystem(case.table, 0)
