@@ -55,3 +55,69 @@ def test_extreme_systems_on_the_host_build(seed, host_engine, monkeypatch):
 @pytest.mark.parametrize("seed", range(16))
 def test_extreme_crystal_stacks_on_the_host_build(seed, host_engine):
     F.test_extreme_crystal_stacks_match_oracle(HOST, seed)
+
+
+# ---- more bodies of the `-m gpu` suite that need nothing but whole-sequence traces and the per-surface calls -------------
+import test_gpu_absorbing as A            # noqa: E402
+import test_gpu_parity as P               # noqa: E402
+import test_gpu_uniform as U              # noqa: E402
+import test_gpu_zz_first_contact as Z     # noqa: E402
+
+
+@pytest.fixture
+def no_device_sync(monkeypatch):
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+
+
+def _params(fn, name):
+    for m in getattr(fn, "pytestmark", []):
+        if m.name == "parametrize" and m.args[0] == name:
+            return list(m.args[1])
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", _params(P.test_per_surface_api_matches_fused, "name"))
+def test_per_surface_api_on_the_host_build(name, host_engine, no_device_sync):
+    P.test_per_surface_api_matches_fused(name, HOST)
+
+
+@pytest.mark.parametrize("name", _params(P.test_image_mode_matches_path_mode, "name"))
+def test_image_mode_on_the_host_build(name, host_engine, no_device_sync):
+    P.test_image_mode_matches_path_mode(name, HOST)
+
+
+@pytest.mark.parametrize("index", range(len(_params(P.test_side_array_layouts_of_the_explicit_shapes, "surface"))))
+def test_side_array_layouts_on_the_host_build(index, host_engine, no_device_sync):
+    P.test_side_array_layouts_of_the_explicit_shapes(_params(P.test_side_array_layouts_of_the_explicit_shapes, "surface")[index], HOST)
+
+
+@pytest.mark.parametrize("body", [P.test_nan_hit_points_on_explicit_shapes_are_dropped_by_the_refraction,
+                                  P.test_shape_eval_closed_forms, P.test_shape_eval_biconic_closed_form,
+                                  P.test_nonconvergence_mask_flags_capped_newton_rays_and_leaves_valid_alone,
+                                  P.test_sharded_crystal_trace_reassembles_to_the_whole_bundle,
+                                  U.test_uniform_bundle_through_more_crystals_than_the_fused_walk_parks],
+                         ids=lambda f: f.__name__[5:])
+def test_single_bodies_on_the_host_build(body, host_engine, no_device_sync):
+    body(HOST)
+
+
+@pytest.mark.parametrize("seed", _params(A.test_hip_vs_oracle_random_absorbing_crystals, "seed"))
+def test_random_absorbing_crystals_on_the_host_build(seed, host_engine, no_device_sync):
+    A.test_hip_vs_oracle_random_absorbing_crystals(seed, HOST)
+
+
+@pytest.mark.parametrize("seed", _params(A.test_hip_vs_oracle_random_sequences_that_end_in_an_isotropic_medium, "seed"))
+def test_random_sequences_behind_absorbing_crystals_on_the_host_build(seed, host_engine, no_device_sync):
+    A.test_hip_vs_oracle_random_sequences_that_end_in_an_isotropic_medium(seed, HOST)
+
+
+@pytest.mark.parametrize("name", _params(Z.test_surface_step_matches_the_fused_march_and_the_two_calls, "name"))
+def test_first_contact_surface_step_body_on_the_host_build(name, host_engine, no_device_sync):
+    """the body of the `-m gpu` test of the fused surface step, which no device has run yet (the adapter's surface_step
+    is prt_surface_step_rows itself; DeviceSystem.surface_step's own Python -- array placement -- needs a device)"""
+    Z.test_surface_step_matches_the_fused_march_and_the_two_calls(name, HOST)
+
+
+@pytest.mark.parametrize("n", _params(Z.test_surface_step_on_odd_and_tiny_bundles_and_tight_arrays, "n"))
+def test_first_contact_surface_step_sizes_on_the_host_build(n, host_engine, no_device_sync):
+    Z.test_surface_step_on_odd_and_tiny_bundles_and_tight_arrays(n, HOST)
