@@ -99,13 +99,21 @@ def _p(a):
     return None if a is None else a.ctypes.data
 
 
-def _rows(a, pitch):
+def _alloc(shape, dtype=np.float64, fill=np.nan, misalign=False):
+    """a C-contiguous array of ``shape``; ``misalign``: its first element sits one element behind a 16-B boundary (doubles:
+    8-B aligned only; bytes: an odd address) -- what the entry points must answer with their 8-B / 1-B access forms"""
+    n = int(np.prod(shape))
+    base = np.full(n + 2, fill, dtype=dtype)
+    assert base.ctypes.data % 16 == 0
+    view = base[1:1 + n] if misalign else base[:n]
+    return view.reshape(shape)
+
+
+def _rows(a, pitch, misalign=False):
     """(3, n) values -> a (3, pitch) array whose first n columns hold them (the rest NaN), C-contiguous"""
     a = np.asarray(a)
     a = np.asarray(np.real(a) if np.iscomplexobj(a) else a, dtype=np.float64)
-    if pitch in (None, 0) or pitch == a.shape[1]:
-        return np.ascontiguousarray(a)
-    out = np.full((3, pitch), np.nan)
+    out = _alloc((3, pitch or a.shape[1]), misalign=misalign)
     out[:, :a.shape[1]] = a
     return out
 
@@ -155,7 +163,7 @@ class HostSystem(object):
 
     # -- whole sequence -------------------------------------------------------------------------------------------------
     def trace(self, x0, k0=None, e0_re=None, e0_im=None, mode=0, pitch=None, in_pitch=None, uniform=None,
-              first_dir=None, want_nonconv=False, want_fields=False, flags=False, want_k_im=False):
+              first_dir=None, want_nonconv=False, want_fields=False, flags=False, want_k_im=False, misalign=False):
         """prt_trace_ex -> the dense per-surface records of tests/_golden.py (x_hit, valid, k_out, valid_out [, nonconv,
         e_re]).  pitch: out_pitch (None: the library's recommendation for the layout, 0: tight); in_pitch: row pitch of
         the input arrays (None: tight); uniform = (k, e | None, kind) replaces k0 / e0 (prt.h PRT_FIRST_*_UNIFORM)."""
@@ -170,11 +178,11 @@ class HostSystem(object):
                 pitch = int(self.lib.prt_recommended_pitch(n0))
             Pp = pitch or n0
             rows = len(n_in)
-            x_hit = np.full((rows, 3, Pp), np.nan)
-            k_out = np.full((rows, 3, Pp), np.nan)
-            valid = np.full((rows, Pp), 7, dtype=np.uint8)
-            valid_out = np.full((rows, Pp), 7, dtype=np.uint8)
-            nonconv = np.zeros((rows, Pp), dtype=np.uint8) if want_nonconv else None
+            x_hit = _alloc((rows, 3, Pp), misalign=misalign)
+            k_out = _alloc((rows, 3, Pp), misalign=misalign)
+            valid = _alloc((rows, Pp), np.uint8, 7, misalign)
+            valid_out = _alloc((rows, Pp), np.uint8, 7, misalign)
+            nonconv = _alloc((rows, Pp), np.uint8, 0, misalign) if want_nonconv else None
         else:
             if pitch is None:
                 pitch = int(self.lib.prt_crystal_pitch(n0))
@@ -193,7 +201,7 @@ class HostSystem(object):
         a.struct_bytes = ctypes.sizeof(P.PrtTraceArgs)
         a.mode = mode | (P.MODE_FLAGS if flags else 0)
         a.n0 = n0
-        keep = [_rows(x0, in_pitch)]
+        keep = [_rows(x0, in_pitch, misalign)]
         a.x0 = _p(keep[0])
         a.in_pitch = in_pitch or 0
         if uniform is not None:
@@ -204,13 +212,13 @@ class HostSystem(object):
                 a.e_uniform_im[:] = [float(np.imag(v)) for v in eu]
             a.first_dir = kind
         else:
-            keep.append(_rows(k0, in_pitch))
+            keep.append(_rows(k0, in_pitch, misalign))
             a.k0 = _p(keep[-1])
             if e0_re is not None:
-                keep.append(_rows(e0_re, in_pitch))
+                keep.append(_rows(e0_re, in_pitch, misalign))
                 a.e0_re = _p(keep[-1])
             if e0_im is not None:
-                keep.append(_rows(e0_im, in_pitch))
+                keep.append(_rows(e0_im, in_pitch, misalign))
                 a.e0_im = _p(keep[-1])
             a.first_dir = P.FIRST_E if first_dir is None else first_dir
         a.out_pitch = pitch
@@ -265,14 +273,14 @@ class HostSystem(object):
 
     # -- one surface at a time (row-pitched arrays, two rays per thread) ---------------------------------------------
     def propagate_rows(self, s, x, k, direction=None, e_re=None, e_im=None, default_e=False, valid_in=None, pitch=None,
-                       want_nonconv=False):
+                       want_nonconv=False, misalign=False):
         n = x.shape[1]
-        (xi, ki) = (_rows(x, pitch), _rows(k, pitch))
+        (xi, ki) = (_rows(x, pitch, misalign), _rows(k, pitch, misalign))
         Pp = pitch or n
-        x_hit = np.full((3, Pp), np.nan)
-        valid = np.full(n, 7, dtype=np.uint8)
-        nonconv = np.zeros(n, dtype=np.uint8) if want_nonconv else None
-        extra = [None if t is None else _rows(t, pitch) for t in (direction, e_re, e_im)]
+        x_hit = _alloc((3, Pp), misalign=misalign)
+        valid = _alloc((n,), np.uint8, 7, misalign)
+        nonconv = _alloc((n,), np.uint8, 0, misalign) if want_nonconv else None
+        extra = [None if t is None else _rows(t, pitch, misalign) for t in (direction, e_re, e_im)]
         vin = None if valid_in is None else np.ascontiguousarray(valid_in, dtype=np.uint8)
         self._check(self.lib.prt_propagate_rows(self._h, s, n, _p(xi), Pp, _p(ki), Pp, _p(extra[0]), _p(extra[1]),
                                                 _p(extra[2]), 1 if default_e else 0, _p(vin), _p(x_hit), Pp, _p(valid),
@@ -280,13 +288,13 @@ class HostSystem(object):
         assert np.all(np.isnan(x_hit[:, n + (n % 2):]))
         return (x_hit[:, :n].copy(), valid) + ((nonconv,) if want_nonconv else ())
 
-    def interact_rows(self, s, x_hit, k, valid_in=None, pitch=None, want_dir=False):
+    def interact_rows(self, s, x_hit, k, valid_in=None, pitch=None, want_dir=False, misalign=False):
         n = x_hit.shape[1]
-        (xi, ki) = (_rows(x_hit, pitch), _rows(k, pitch))
+        (xi, ki) = (_rows(x_hit, pitch, misalign), _rows(k, pitch, misalign))
         Pp = pitch or n
-        k_out = np.full((3, Pp), np.nan)
-        d_out = np.full((3, Pp), np.nan) if want_dir else None
-        valid_out = np.full(n, 7, dtype=np.uint8)
+        k_out = _alloc((3, Pp), misalign=misalign)
+        d_out = _alloc((3, Pp), misalign=misalign) if want_dir else None
+        valid_out = _alloc((n,), np.uint8, 7, misalign)
         vin = None if valid_in is None else np.ascontiguousarray(valid_in, dtype=np.uint8)
         self._check(self.lib.prt_interact_rows(self._h, s, n, _p(xi), Pp, _p(ki), Pp, _p(vin), _p(k_out), Pp, _p(d_out),
                                                _p(valid_out), None))
@@ -294,16 +302,16 @@ class HostSystem(object):
         return (k_out[:, :n].copy(), valid_out) + ((d_out[:, :n].copy(),) if want_dir else ())
 
     def surface_step_rows(self, s, x, k, direction=None, e_re=None, e_im=None, default_e=False, valid_in=None,
-                          pitch=None, want_nonconv=False):
+                          pitch=None, want_nonconv=False, misalign=False):
         n = x.shape[1]
-        (xi, ki) = (_rows(x, pitch), _rows(k, pitch))
+        (xi, ki) = (_rows(x, pitch, misalign), _rows(k, pitch, misalign))
         Pp = pitch or n
-        x_hit = np.full((3, Pp), np.nan)
-        k_out = np.full((3, Pp), np.nan)
-        valid = np.full(n, 7, dtype=np.uint8)
-        valid_out = np.full(n, 7, dtype=np.uint8)
-        nonconv = np.zeros(n, dtype=np.uint8) if want_nonconv else None
-        extra = [None if t is None else _rows(t, pitch) for t in (direction, e_re, e_im)]
+        x_hit = _alloc((3, Pp), misalign=misalign)
+        k_out = _alloc((3, Pp), misalign=misalign)
+        valid = _alloc((n,), np.uint8, 7, misalign)
+        valid_out = _alloc((n,), np.uint8, 7, misalign)
+        nonconv = _alloc((n,), np.uint8, 0, misalign) if want_nonconv else None
+        extra = [None if t is None else _rows(t, pitch, misalign) for t in (direction, e_re, e_im)]
         vin = None if valid_in is None else np.ascontiguousarray(valid_in, dtype=np.uint8)
         self._check(self.lib.prt_surface_step_rows(self._h, s, n, _p(xi), Pp, _p(ki), Pp, _p(extra[0]), _p(extra[1]),
                                                    _p(extra[2]), 1 if default_e else 0, _p(vin), _p(x_hit), _p(k_out), Pp,

@@ -119,7 +119,10 @@ def test_host_build_layouts_and_modes_agree(name):
     same(img[0], ref[-1])
     variants = [dict(pitch=0), dict(in_pitch=n0 + 6)]
     if hs.all_isotropic:
-        variants += [dict(pitch=n0 + 1), dict(pitch=n0 + 2, in_pitch=n0 + 3), dict(flags=True)]
+        # (misalign: every array starts 8 B behind a 16-B boundary, mask rows at odd addresses -- even pitches or not, the
+        #  library must take its 8-B / 1-B access forms; UBSan's alignment check watches in the sanitizer run)
+        variants += [dict(pitch=n0 + 1), dict(pitch=n0 + 2, in_pitch=n0 + 3), dict(flags=True),
+                     dict(misalign=True), dict(misalign=True, pitch=n0 + 2 + n0 % 2, in_pitch=n0 + 4 + n0 % 2, want_nonconv=True)]
     else:
         variants += [dict(pitch=n0 + 3)]
     for kw in variants:
@@ -128,7 +131,7 @@ def test_host_build_layouts_and_modes_agree(name):
             same(got[s], ref[s])
 
 
-def _walk_surface_by_surface(case, pitch, n=None):
+def _walk_surface_by_surface(case, pitch, n=None, misalign=False):
     hs = hostemu.HostSystem(case.table)
     e = np.asarray(case.E0)
     sl = slice(0, n)
@@ -140,10 +143,11 @@ def _walk_surface_by_surface(case, pitch, n=None):
     for s in range(case.n_surfaces):
         first = dict(e_re=e_re, e_im=e_im) if s == 0 else dict(default_e=False)
         # the two calls (Material.propagate, Material.refract) ...
-        (xh, v, nc) = hs.propagate_rows(s, x, k, valid_in=valid, pitch=pitch, want_nonconv=True, **first)
-        (k2, vo) = hs.interact_rows(s, xh, k, valid_in=v, pitch=pitch)
+        (xh, v, nc) = hs.propagate_rows(s, x, k, valid_in=valid, pitch=pitch, want_nonconv=True, misalign=misalign, **first)
+        (k2, vo) = hs.interact_rows(s, xh, k, valid_in=v, pitch=pitch, misalign=misalign)
         # ... and the fused step of the same surface
-        (xh_f, k2_f, v_f, vo_f, nc_f) = hs.surface_step_rows(s, xs, ks, valid_in=valid_s, pitch=pitch, want_nonconv=True, **first)
+        (xh_f, k2_f, v_f, vo_f, nc_f) = hs.surface_step_rows(s, xs, ks, valid_in=valid_s, pitch=pitch, want_nonconv=True,
+                                                             misalign=misalign, **first)
         for (got_x, got_k, got_v, got_vo) in ((xh, k2, v, vo), (xh_f, k2_f, v_f, vo_f)):
             assert np.array_equal(got_v.astype(bool), out[s]["valid"]), (s, pitch)
             assert np.array_equal(got_vo.astype(bool), out[s]["valid_out"]), (s, pitch)
@@ -168,6 +172,7 @@ def test_host_build_per_surface_calls_and_the_fused_surface_step(name):
     for (pitch, n) in ((n0 + (n0 % 2) + 2, n0), (None, n0), (n0 + 1 - (n0 % 2), n0 - 1), (None, n0 - 1 if (n0 - 1) % 2 else n0 - 2),
                        (4, 3), (None, 1)):
         _walk_surface_by_surface(case, pitch, n)
+    _walk_surface_by_surface(case, n0 + (n0 % 2) + 2, n0, misalign=True)       # even pitch, bases 8 B off a 16-B boundary
 
 
 def test_host_build_refuses_crystals_in_the_row_calls():
@@ -239,6 +244,8 @@ for name in %(cases)r:
         T.host_trace(case, flags=True)
         for (pitch, n) in ((n0 + (n0 %% 2) + 2, n0), (None, n0 - 1), (n0 + 1 - (n0 %% 2), n0 - 1), (None, 1)):
             T._walk_surface_by_surface(case, pitch, n)
+        T._walk_surface_by_surface(case, n0 + (n0 %% 2) + 2, n0, misalign=True)
+        T.host_trace(case, misalign=True, pitch=n0 + 2 + n0 %% 2, in_pitch=n0 + 4 + n0 %% 2, want_nonconv=True)
     else:
         T.host_trace(case, want_fields=True, want_k_im=True)
 T.test_host_build_many_blocks_and_the_xcd_block_map()
