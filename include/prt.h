@@ -122,6 +122,8 @@ typedef struct prt_surface {
     double B_mat[9];     /* lc of the medium after the interaction                   */
     double n_after;      /* isotropic: refractive index of that medium               */
     double eps_re[9], eps_im[9]; /* anisotropic: its (constant) epsilon tensor       */
+    /* A real tensor whose antisymmetric part is <= 1e-14 of its largest entry (a symmetric tensor rotated into place,
+     * R diag R^T) is used as its symmetric part: the crystal solver's cheapest route needs eps[i][j] == eps[j][i]. */
     /* Absorbing media.  eps_im != 0: an absorbing crystal (the reference accepts a complex tensor,
      * material_anisotropic.py:52-56).  ISOTROPIC records: eps_im[0] = Im(n), an absorbing isotropic medium (complex
      * refractive index, material_isotropic.py:59-63, 137-161); the other entries of eps_re / eps_im are unused

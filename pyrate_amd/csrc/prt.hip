@@ -524,6 +524,23 @@ static int32_t build_table_image(const prt_surface_t *table, int32_t n_surfaces,
             memcpy(d.B_mat, r.B_mat, sizeof d.B_mat);
             d.n_after = r.n_after;
             memcpy(d.eps_re, r.eps_re, sizeof d.eps_re);
+            if (r.mat_type == PRT_MAT_ANISOTROPIC && !im.complex_eps) {
+                // A lossless crystal's tensor is symmetric; one that a caller ROTATES into place (R diag R^T, the usual
+                // way to build it) comes out symmetric up to an ulp.  The solver's cheapest route -- flux and ray
+                // direction of the leaving pair from the adjugate of W, no eigenvectors (prt_aniso.h) -- asks for
+                // eps[i][j] == eps[j][i] exactly, so such a tensor is stored as its symmetric part: an antisymmetric
+                // part below 1e-14 of the largest entry is rounding, not physics (a change of <= 1e-14 relative in the
+                // tensor against the 1e-10 parity bar; the uniaxial / isotropic classes are recognised with 1e-12,
+                // surface_table.classify_eps).  Anything more asymmetric is taken as given.
+                double scale = 0.0, asym = 0.0;
+                for (int q = 0; q < 9; ++q) scale = fmax(scale, fabs(r.eps_re[q]));
+                for (int i = 0; i < 3; ++i)
+                    for (int j = i + 1; j < 3; ++j) asym = fmax(asym, fabs(r.eps_re[3 * i + j] - r.eps_re[3 * j + i]));
+                if (asym > 0.0 && asym <= 1e-14 * scale)
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = i + 1; j < 3; ++j)
+                            d.eps_re[3 * i + j] = d.eps_re[3 * j + i] = 0.5 * (r.eps_re[3 * i + j] + r.eps_re[3 * j + i]);
+            }
             d.aniso_eo = r.aniso_eo;
             d.aniso_ee = r.aniso_ee;
             memcpy(d.aniso_axis, r.aniso_axis, sizeof d.aniso_axis);

@@ -110,3 +110,33 @@ def test_scale_preflight_dry_run_and_the_exchange_probe(gpu_device, tmp_path):
     chosen = line["config"]["exchange"]
     assert chosen in ("gather", "gather-direct") and probe[chosen] == min(v for v in probe.values() if v is not None)
     assert line["verified"]["ok"] and line["verified"]["all_ranks_ok"] and "error" not in line
+
+
+def test_a_rotated_symmetric_tensor_is_used_as_its_symmetric_part(gpu_device):
+    """prt_system_create stores a real tensor that is symmetric up to rounding (R diag R^T) as its symmetric part, which
+    opens the crystal solver's cheapest route (flux from the adjugate of W, prt_aniso.h) to it -- bench.py's aniso_biaxial
+    tensors: the trace equals the trace with the explicitly symmetrised tensors bit for bit and agrees with the oracle on
+    the caller's tensors (host build: tests/test_hostemu.py, same assertion)"""
+    from pyrate_amd import engine, systems
+    from oracle import seqtrace_np as oracle
+    def rot(ax, ay, az):
+        (ca, sa, cb, sb, cg, sg) = (np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay), np.cos(az), np.sin(az))
+        rx = np.array([[1, 0, 0], [0, ca, -sa], [0, sa, ca]])
+        ry = np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]])
+        rz = np.array([[cg, -sg, 0], [sg, cg, 0], [0, 0, 1]])
+        return rz.dot(ry).dot(rx)
+    (r1, r2) = (rot(0.4, 0.25, -0.3), rot(-0.2, 0.35, 0.15))
+    (e1, e2) = (r1.dot(np.diag([1.55 ** 2, 1.60 ** 2, 1.68 ** 2])).dot(r1.T), r2.dot(np.diag([1.62 ** 2, 1.66 ** 2, 1.71 ** 2])).dot(r2.T))
+    (o, k, e0) = systems.double_gauss_bundle(600, rpup=11.43, z0=-5.0, field_deg=2.0)
+    rays = [engine.to_device_rays(a, gpu_device) for a in (o, k, e0)]
+    raw = engine.DeviceSystem(systems.aniso_doublet_records(e1, e2), 0).trace(*rays)
+    sym = engine.DeviceSystem(systems.aniso_doublet_records(0.5 * (e1 + e1.T), 0.5 * (e2 + e2.T)), 0).trace(*rays)
+    with np.errstate(all="ignore"):
+        out = oracle.trace(systems.aniso_doublet_records(e1, e2), o, k, e0)
+    for s in range(len(out)):
+        assert torch.equal(raw.valid_out[s], sym.valid_out[s])
+        assert np.array_equal(raw.x_hit[s].cpu().numpy(), sym.x_hit[s].cpu().numpy(), equal_nan=True)
+        assert np.array_equal(raw.k_out[s].cpu().numpy(), sym.k_out[s].cpu().numpy(), equal_nan=True)
+        ko = np.real(out[s]["k_out"])
+        fin = np.all(np.isfinite(ko), axis=0)
+        assert np.abs(raw.k_out[s].cpu().numpy()[:, fin] - ko[:, fin]).max() < 1e-12
