@@ -232,7 +232,7 @@ class HostSystem(object):
             if self.complex_eps:
                 e_im = np.zeros_like(k_out)
                 a.e_out_im = _p(e_im)
-        if self.complex_eps or (want_k_im and not self.all_isotropic and mode == P.MODE_PATH and pitch):
+        if self.complex_eps or ((want_k_im or want_fields) and not self.all_isotropic and mode == P.MODE_PATH and pitch):
             k_im = np.full_like(k_out, np.nan)
             a.k_out_im = _p(k_im)
         self._check(self.lib.prt_trace_ex(self._h, ctypes.byref(a)))

@@ -254,6 +254,7 @@ T.test_host_build_bundle_generation_and_the_small_helpers()
 T.test_host_build_fused_image_plane_moments()
 T.test_host_build_empty_bundles_and_argument_errors()
 T.test_host_build_poisoned_rays_are_masks_never_crashes()
+T.test_host_build_wrappers_one_call_trace_timing_async_moments_and_the_image_redirect()
 print("RESULT " + json.dumps({"worst_k": worst}))
 '''
 
@@ -706,3 +707,100 @@ def test_host_build_a_rotated_symmetric_tensor_is_used_as_its_symmetric_part():
     ko = np.real(out[-1]["k_out"])
     fin = np.all(np.isfinite(ko), axis=0)
     assert np.abs(given[-1]["k_out"][:, fin] - ko[:, fin]).max() < 1e-12
+
+
+def test_host_build_wrappers_one_call_trace_timing_async_moments_and_the_image_redirect():
+    """the remaining entry points of include/prt.h on the host build: prt_trace_seq (no handle: tables cached by content,
+    more tables than the cache holds), prt_trace / prt_trace_timed (wrappers of prt_trace_ex), prt_bundle_moments_async
+    with the reference on the device (a point, a moments vector), the image-plane redirect of the last surface's record
+    (what a ray-sharded trace deposits into the all-gather's receive buffer), the tight per-surface calls"""
+    import ctypes
+    from pyrate_amd import systems, _lib as P
+    from pyrate_amd.surface_table import pack_table
+    lib = hostemu.load()
+    (o, k, e0) = systems.double_gauss_bundle(500, field_deg=3.0)
+    n = o.shape[1]
+    (oc, kc) = (np.ascontiguousarray(o), np.ascontiguousarray(k))
+    d0 = np.ascontiguousarray(k / np.sqrt((k * k).sum(axis=0)))
+    # prt_trace_seq: twelve different tables through an eight-entry cache, each twice
+    base = systems.double_gauss_records()
+    for rep in range(2):
+        for q in range(12):
+            recs = systems.double_gauss_records(587.6e-6 * (1 + 0.01 * q))
+            S = len(recs)
+            (x_hit, k_out, valid) = (np.full((S, 3, n), np.nan), np.full((S, 3, n), np.nan), np.zeros((S, n), dtype=np.uint8))
+            rc = lib.prt_trace_seq(pack_table(recs), S, n, oc.ctypes.data, kc.ctypes.data, d0.ctypes.data if q % 2 else None, None, P.MODE_PATH,
+                                   x_hit.ctypes.data, k_out.ctypes.data, valid.ctypes.data, None, 0, None)
+            assert rc == 0, lib.prt_last_error()
+            ref = hostemu.HostSystem(recs).trace(o, k, first_dir=P.FIRST_K, pitch=0)
+            for s in range(S):
+                assert np.array_equal(valid[s], ref[s]["valid"])
+                if q % 2:       # the caller's unit directions (k / |k| computed here) against the library's own: rounding
+                    assert np.allclose(x_hit[s], ref[s]["x_hit"], rtol=0, atol=1e-12, equal_nan=True)
+                else:
+                    assert np.array_equal(x_hit[s], ref[s]["x_hit"], equal_nan=True)
+    # prt_trace and prt_trace_timed
+    hs = hostemu.HostSystem(base)
+    S = len(base)
+    ref = hs.trace(o, k, e0, pitch=0)
+    ec = np.ascontiguousarray(np.real(e0))
+    for timed in (False, True):
+        (x_hit, k_out) = (np.full((S, 3, n), np.nan), np.full((S, 3, n), np.nan))
+        (valid, valid_out) = (np.zeros((S, n), dtype=np.uint8), np.zeros((S, n), dtype=np.uint8))
+        if timed:
+            ms = ctypes.c_double(-1.0)
+            rc = lib.prt_trace_timed(hs._h, n, 0, oc.ctypes.data, kc.ctypes.data, ec.ctypes.data, None, P.MODE_PATH, 0,
+                                     x_hit.ctypes.data, k_out.ctypes.data, valid.ctypes.data, valid_out.ctypes.data, None, 3,
+                                     ctypes.byref(ms))
+            assert rc == 0 and ms.value >= 0.0
+        else:
+            rc = lib.prt_trace(hs._h, n, 0, oc.ctypes.data, kc.ctypes.data, ec.ctypes.data, None, P.MODE_PATH, 0,
+                               x_hit.ctypes.data, k_out.ctypes.data, valid.ctypes.data, valid_out.ctypes.data, None, None)
+            assert rc == 0, lib.prt_last_error()
+        for s in range(S):
+            assert np.array_equal(k_out[s], ref[s]["k_out"], equal_nan=True) and np.array_equal(valid_out[s], ref[s]["valid_out"])
+    # the image-plane redirect: the last record lands in rows of its own, the path arrays' last rows stay untouched
+    pitch = int(lib.prt_recommended_pitch(n))
+    a = P.PrtTraceArgs()
+    a.struct_bytes = ctypes.sizeof(P.PrtTraceArgs)
+    (a.mode, a.n0, a.in_pitch, a.out_pitch) = (P.MODE_PATH | P.MODE_FLAGS, n, pitch, pitch)
+    (op, kp, ep) = [hostemu._rows(t, pitch) for t in (o, k, np.real(e0))]       # (the redirect wants 16-B aligned rows everywhere)
+    (a.x0, a.k0, a.e0_re, a.first_dir) = (op.ctypes.data, kp.ctypes.data, ep.ctypes.data, P.FIRST_E)
+    (x_hit, k_out, flags) = (np.full((S, 3, pitch), np.nan), np.full((S, 3, pitch), np.nan), np.full((S, pitch), 9, dtype=np.uint8))
+    img_pitch = pitch + 512
+    (x_img, k_img, f_img) = (np.full((3, img_pitch), np.nan), np.full((3, img_pitch), np.nan), np.full(img_pitch, 9, dtype=np.uint8))
+    (a.x_hit, a.k_out, a.valid) = (x_hit.ctypes.data, k_out.ctypes.data, flags.ctypes.data)
+    (a.x_img, a.k_img, a.valid_img, a.img_pitch) = (x_img.ctypes.data, k_img.ctypes.data, f_img.ctypes.data, img_pitch)
+    assert lib.prt_trace_ex(hs._h, ctypes.byref(a)) == 0, lib.prt_last_error()
+    assert np.all(np.isnan(x_hit[-1])) and np.all(flags[-1] == 9)
+    m = ref[-1]["valid_out"].astype(bool)
+    assert np.array_equal((f_img[:n] >> 1) & 1, ref[-1]["valid_out"]) and np.array_equal(f_img[:n] & 1, ref[-1]["valid"])
+    assert np.allclose(x_img[:, :n][:, m], ref[-1]["x_hit"][:, m], rtol=0, atol=1e-13)
+    assert np.allclose(x_hit[-2][:, :n][:, m], ref[-2]["x_hit"][:, m], rtol=0, atol=1e-13)
+    # moments with the reference on the device: a point, then the centroid of a first pass
+    x = np.ascontiguousarray(ref[-1]["x_hit"])
+    mask = np.ascontiguousarray(ref[-1]["valid_out"])
+    scratch = np.zeros(int(lib.prt_moments_scratch_doubles(n)))
+    (first, second) = (np.full(7, np.nan), np.full(7, np.nan))
+    point = np.array([0.0, 0.0, float(x[2, m].mean())])
+    assert lib.prt_bundle_moments_async(0, n, 0, x.ctypes.data, mask.ctypes.data, 0, point.ctypes.data, 1, first.ctypes.data,
+                                        scratch.ctypes.data, None) == 0
+    v = x[:, m] - point[:, None]
+    assert np.allclose(first, np.concatenate([[m.sum()], v.sum(axis=1), (v * v).sum(axis=1)]), rtol=1e-12, atol=1e-12)
+    plain = np.full(7, np.nan)
+    assert lib.prt_bundle_moments_async(0, n, 0, x.ctypes.data, mask.ctypes.data, 0, None, 0, plain.ctypes.data,
+                                        scratch.ctypes.data, None) == 0
+    assert lib.prt_bundle_moments_async(0, n, 0, x.ctypes.data, mask.ctypes.data, 0, plain.ctypes.data, 2, second.ctypes.data,
+                                        scratch.ctypes.data, None) == 0
+    v = x[:, m] - (x[:, m].sum(axis=1) / m.sum())[:, None]
+    assert np.allclose(second[4:], (v * v).sum(axis=1), rtol=1e-9, atol=1e-12) and abs(second[1]) < 1e-9
+    # the tight one-ray-per-thread calls (what the per-surface march of many crystals launches), isotropic surface
+    (xh, v1) = hs.propagate(0, o, k, e_re=np.real(e0))
+    assert np.array_equal(v1, ref[0]["valid"]) and np.allclose(xh[:, v1.astype(bool)], ref[0]["x_hit"][:, v1.astype(bool)], rtol=0, atol=1e-13)
+    k2 = np.full((3, n), np.nan)
+    w2 = np.zeros(n, dtype=np.uint8)
+    xhc = np.ascontiguousarray(xh)
+    assert lib.prt_interact(hs._h, 0, n, xhc.ctypes.data, kc.ctypes.data, v1.ctypes.data, k2.ctypes.data, None, None, None,
+                            w2.ctypes.data, None) == 0
+    assert np.array_equal(w2, ref[0]["valid_out"])
+    assert np.allclose(k2[:, w2.astype(bool)], ref[0]["k_out"][:, w2.astype(bool)], rtol=0, atol=1e-14)

@@ -121,3 +121,9 @@ def test_first_contact_surface_step_body_on_the_host_build(name, host_engine, no
 @pytest.mark.parametrize("n", _params(Z.test_surface_step_on_odd_and_tiny_bundles_and_tight_arrays, "n"))
 def test_first_contact_surface_step_sizes_on_the_host_build(n, host_engine, no_device_sync):
     Z.test_surface_step_on_odd_and_tiny_bundles_and_tight_arrays(n, HOST)
+
+
+@pytest.mark.parametrize("eps_kind", ["biaxial", "isotropic"])      # ("uniaxial" goes on into the drop-in layer: device only)
+def test_evanescent_modes_as_complex_wave_vectors_on_the_host_build(eps_kind, host_engine, no_device_sync):
+    """k_evanescent_fill (the post-pass that reports evanescent modes as complex k) and the E-field stores of the march"""
+    U.test_evanescent_modes_come_back_as_complex_wave_vectors(eps_kind, HOST)
