@@ -9,6 +9,9 @@ uniaxial / biaxial tensors, consecutive mirrors inside crystals, steep incidence
 evanescent crystal modes).
 
     python oracle/fuzz_vs_reference.py [n_systems] [first_seed]
+    PRT_FUZZ_ENGINE=hostbuild ...: the reference against the HOST BUILD OF THE KERNELS' SOURCES (tests/hostemu: libprt's
+    prt.hip compiled for x86-64, same C ABI) instead of the oracle -- the reference and the product's own code on the same
+    random systems, nothing in between (round 6, when no GPU was to be had)
     PRT_FUZZ_TIGHT=1 ...: every explicit shape of the reference with annotations["tol"] = 1e-14 (its fsolve converged,
     surface_shape.py:396, 457-458) and the comparison FLAT at 1e-10, no allowance (round 5; the largest raw deviation
     is printed)
@@ -35,6 +38,9 @@ A = mg.REFAPI
 # random stream than the campaigns on record, which ran without)
 EXTRA_SHAPES = _extra or bool(os.environ.get("PRT_FUZZ_EXTRA_SHAPES"))
 TIGHT = bool(os.environ.get("PRT_FUZZ_TIGHT"))
+ENGINE = os.environ.get("PRT_FUZZ_ENGINE", "oracle")
+if ENGINE == "hostbuild":
+    import hostemu                  # noqa: E402  (tests/hostemu)
 
 
 def random_eps(rng):
@@ -177,7 +183,10 @@ def main():
             assert pos + 1 == len(allb), (pos, len(allb))
             case.bundles = [allb[i] for i in keep]
             with np.errstate(all="ignore"):
-                out = oracle.trace(records, x0, k0, e0)
+                if ENGINE == "hostbuild":
+                    out = hostemu.HostSystem(records).trace(x0, k0, e0)
+                else:
+                    out = _golden.dense_from_oracle(oracle.trace(records, x0, k0, e0))
             # evanescent descendants have complex k in the reference: compare only while every k is real
             if any(np.any(np.abs(np.imag(b["k"])) > 1e-9) for b in case.bundles):
                 kind = "complex-k"
@@ -191,19 +200,23 @@ def main():
                 case.bundles = case.bundles[:upto + 2]
                 out = out[:upto]
             if TIGHT:
-                r = _golden.compare_dense_to_reference(case, _golden.dense_from_oracle(out), rtol_x=1e-10, atol_k=1e-10,
+                r = _golden.compare_dense_to_reference(case, out, rtol_x=1e-10, atol_k=1e-10,
                                                        explicit_tol=None)
+                if os.environ.get("PRT_FUZZ_VERBOSE") and max(r["raw_rel_x"], r["raw_abs_k"]) > 1e-12:
+                    print("seed %d: raw deviation %.2e (x, relative) %.2e (k); shapes %s" % (
+                        seed, r["raw_rel_x"], r["raw_abs_k"], [rec["shape"]["type"] for rec in case.table]))
                 worst[0] = max(worst[0], r["raw_rel_x"])
                 worst[1] = max(worst[1], r["raw_abs_k"])
                 n_explicit[0] += any(rec["shape"]["type"] != "conic" for rec in case.table)
             else:
-                r = _golden.compare_dense_to_reference(case, _golden.dense_from_oracle(out), rtol_x=1e-9, atol_k=1e-9,
+                r = _golden.compare_dense_to_reference(case, out, rtol_x=1e-9, atol_k=1e-9,
                                                        explicit_tol=explicit_tolerance)
             ncmp += r["n_compared"]
         except AssertionError as exc:
             bad.append((seed, "crystals" if crystals else "isotropic", str(exc)[:160]))
         except Exception as exc:
             bad.append((seed, "exception", repr(exc)[:200]))
+    print("engine: %s" % ("the host build of libprt's sources (tests/hostemu)" if ENGINE == "hostbuild" else "NumPy oracle"))
     print("systems %d, compared ray-surfaces %d, failures %d" % (_n, ncmp, len(bad)))
     if TIGHT:
         print("tight mode (reference tol = 1e-14, flat 1e-10): %d systems with explicit shapes compared; largest raw "
