@@ -94,6 +94,13 @@ def hip_rule_error(rec, r0, d):
     return float(np.max(np.abs(out[1][0][ok] - out[0][0][ok]) / np.maximum(1.0, np.abs(out[0][0][ok]))))
 
 
+HOST_BUILD = bool(os.environ.get("PRT_FUZZ_HOST_BUILD"))
+if HOST_BUILD:
+    sys.path.insert(0, os.path.join(mg.ROOT, "tests"))
+    import hostemu                  # noqa: E402
+host_worst = [0.0, 0.0, 0]
+
+
 def main():
     have_grad = True
     (n_ok, n_skipped, n_rays, worst_x, worst_k, worst_inc, worst_rule) = (0, 0, 0, 0.0, 0.0, 0.0, 0.0)
@@ -128,6 +135,19 @@ def main():
         outs = [onp.trace(records, x0, k0, e0)]
         if use_c and seqtrace_c.supports(records):
             outs.append(seqtrace_c.trace(records, x0, k0, e0))
+        if HOST_BUILD:
+            # the kernels' own Newton loop (stop rule, gradient moved to the root along the secant) as compiled from
+            # pyrate_amd/csrc for the host (tests/hostemu), on the same rays
+            hb = hostemu.HostSystem(records).trace(x0, k0, e0, want_nonconv=True)
+            for (si, bi) in enumerate(hit):
+                rbx = np.array(rb[bi].x[-1])
+                rid = rb[bi].rayID
+                dx = np.linalg.norm(hb[si]["x_hit"][:, rid] - rbx, axis=0) / np.maximum(np.linalg.norm(rbx, axis=0), 1.0)
+                host_worst[0] = max(host_worst[0], float(np.max(dx)))
+                host_worst[2] += int(np.count_nonzero(hb[si]["nonconv"][rid]))
+                if bi + 1 < len(rb):
+                    nb = rb[bi + 1]
+                    host_worst[1] = max(host_worst[1], float(np.max(np.abs(hb[si]["k_out"][:, nb.rayID] - np.real(np.array(nb.k[0]))))))
         # every bundle of the reference's path against the dense oracle arrays, joined on rayID
         for o in outs:
             for (si, bi) in enumerate(hit):
@@ -158,6 +178,10 @@ def main():
     if have_grad:
         print("HIP stop rule (1e-8 behind an observed contraction) vs the iteration run to 1e-15, emulated on the same rays: "
               "max |dt| / max(1, |t|) = %.2e" % worst_rule)
+    if HOST_BUILD:
+        print("the kernels' sources (host build, tests/hostemu) vs the converged reference, FLAT, same rays: max rel x %.2e, max "
+              "abs k %.2e, rays flagged nonconv: %d" % (host_worst[0], host_worst[1], host_worst[2]))
+        assert host_worst[0] < 1e-10 and host_worst[1] < 1e-10
     assert worst_x < 1e-10 and worst_k < 1e-10
 
 
