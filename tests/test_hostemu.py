@@ -20,10 +20,15 @@ from test_oracle_golden import explicit_tolerance
 
 hostemu = pytest.importorskip("hostemu")
 
-try:
-    hostemu.build()
-except Exception as exc:                                    # no clang++ on this box
-    pytest.skip("no host build of libprt: %s" % exc, allow_module_level=True)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _host_library():
+    """built on first use (not at import: `pytest -m gpu` on the GPU box collects this module and deselects all of it)"""
+    try:
+        hostemu.build()
+    except Exception as exc:                                    # no clang++ on this box
+        pytest.skip("no host build of libprt: %s" % exc)
 
 
 def host_trace(case, **kw):
