@@ -38,6 +38,13 @@
  *   prt_shape_eval       Shape.getSag / getGrad / getNormal   raytracer/surface_shape.py:71-112
  *   prt_compact          boolean fancy indexing [:, valid]    raytracer/material/material_isotropic.py:194-199
  *
+ * Threads.  Calls on DIFFERENT systems, the handle-free calls (prt_trace_seq and its table cache, the bundle generators,
+ * moments, compaction) and prt_system_create / destroy may run concurrently from any number of host threads;
+ * prt_last_error() is per thread; an arena has a lock of its own.  ONE system is used by one thread at a time:
+ * prt_system_update rewrites the host copy of the table and the staging ring without a lock (the reference's objects are
+ * not thread-safe either).  tests/test_hostemu.py runs both statements on the host build of these sources under
+ * ThreadSanitizer.
+ *
  * In-reference precedent for a C-ABI plugin behind Shape.intersect:
  * raytracer/surface_shape_zmxdll.py:228-404 (ctypes.CDLL, int return, caller-
  * allocated structs).

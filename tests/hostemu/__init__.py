@@ -32,7 +32,8 @@ def find_clang():
 
 
 def _out(sanitize):
-    return os.path.join(BUILD, "libprt_hostemu_san.so" if sanitize else "libprt_hostemu.so")
+    return os.path.join(BUILD, {False: "libprt_hostemu.so", True: "libprt_hostemu_san.so",
+                                "thread": "libprt_hostemu_tsan.so"}[sanitize])
 
 
 def build(sanitize=False, force=False):
@@ -48,7 +49,9 @@ def build(sanitize=False, force=False):
     os.makedirs(BUILD, exist_ok=True)
     cmd = [clang, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-shared", "-I" + HERE, "-ffp-contract=on",
            "-fno-math-errno", "-Wall", "-Wno-unused-function", "-Wno-unknown-attributes"]
-    if sanitize:
+    if sanitize == "thread":
+        cmd += ["-fsanitize=thread", "-shared-libsan", "-fno-omit-frame-pointer"]
+    elif sanitize:
         cmd += ["-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=undefined,float-cast-overflow", "-shared-libsan",
                 "-fno-omit-frame-pointer"]
     subprocess.run(cmd + [SOURCES[0], "-o", out + ".tmp"], check=True)
@@ -56,13 +59,15 @@ def build(sanitize=False, force=False):
     return out
 
 
-def sanitizer_preload():
-    """the shared AddressSanitizer runtime of the clang that built the sanitized library (LD_PRELOAD for an
-    uninstrumented python), or None"""
+def sanitizer_preload(which="asan"):
+    """the shared AddressSanitizer (``which`` "tsan": ThreadSanitizer) runtime of the clang that built the sanitized
+    library (LD_PRELOAD for an uninstrumented python), or None"""
     clang = find_clang()
     if clang is None:
         return None
-    p = subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    p = subprocess.run([clang, "-print-file-name=libclang_rt.%s-x86_64.so" % which], capture_output=True, text=True).stdout.strip()
+    if which != "asan":
+        return p if os.path.isabs(p) and os.path.exists(p) else None
     if not os.path.isabs(p) or not os.path.exists(p):
         p = subprocess.run([clang, "-print-file-name=libclang_rt.asan.so"], capture_output=True, text=True).stdout.strip()
     return p if os.path.isabs(p) and os.path.exists(p) else None

@@ -30,6 +30,10 @@
 #define HOSTEMU_ASAN 1
 #include <sanitizer/common_interface_defs.h>
 #endif
+#if __has_feature(thread_sanitizer)
+#define HOSTEMU_TSAN 1
+#include <sanitizer/tsan_interface.h>
+#endif
 #endif
 
 // ---- language ----------------------------------------------------------------------------------------------------
@@ -46,7 +50,8 @@ struct dim3 {
     uint32_t x, y, z;
     constexpr dim3(uint32_t x_ = 1, uint32_t y_ = 1, uint32_t z_ = 1) : x(x_), y(y_), z(z_) {}
 };
-inline dim3 threadIdx, blockIdx, blockDim, gridDim;
+// (thread_local: several host threads may launch at once -- each runs its own blocks on its own fibres)
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define warpSize 64
 
 // ---- the fibres of a block ------------------------------------------------------------------------------------------
@@ -77,6 +82,9 @@ struct fibre {
 #ifdef HOSTEMU_ASAN
     void *fake_stack = nullptr;
 #endif
+#ifdef HOSTEMU_TSAN
+    void *tsan_fiber = nullptr;
+#endif
 };
 
 struct block_state {
@@ -96,15 +104,21 @@ struct block_state {
     const void *sched_bottom = nullptr;
     size_t sched_size = 0;
 #endif
+#ifdef HOSTEMU_TSAN
+    void *sched_tsan = nullptr;
+#endif
 };
-inline block_state *g_block = nullptr;
-inline std::vector<char *> g_stacks;   // reused between blocks
+inline thread_local block_state *g_block = nullptr;
+inline thread_local std::vector<char *> g_stacks;   // reused between blocks
 
 inline void switch_to_sched(bool dying) {
     block_state &b = *g_block;
     fibre &f = b.fibres[b.current];
 #ifdef HOSTEMU_ASAN
     __sanitizer_start_switch_fiber(dying ? nullptr : &f.fake_stack, b.sched_bottom, b.sched_size);
+#endif
+#ifdef HOSTEMU_TSAN
+    __tsan_switch_to_fiber(b.sched_tsan, 0);
 #endif
     swapcontext(&f.ctx, &b.sched);
 #ifdef HOSTEMU_ASAN
@@ -214,7 +228,13 @@ inline void run_block(dim3 block, const std::function<void()> &body) {
         f.ctx.uc_stack.ss_size = STACK_BYTES;
         f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, (void (*)())trampoline, 0);
+#ifdef HOSTEMU_TSAN
+        f.tsan_fiber = __tsan_create_fiber(0);
+#endif
     }
+#ifdef HOSTEMU_TSAN
+    b.sched_tsan = __tsan_get_current_fiber();
+#endif
     int idle_passes = 0;
     while (b.live > 0) {
         const uint64_t before = b.progress;
@@ -225,6 +245,9 @@ inline void run_block(dim3 block, const std::function<void()> &body) {
             threadIdx = f.tid;
 #ifdef HOSTEMU_ASAN
             __sanitizer_start_switch_fiber(&b.sched_fake, f.stack, STACK_BYTES);
+#endif
+#ifdef HOSTEMU_TSAN
+            __tsan_switch_to_fiber(f.tsan_fiber, 0);
 #endif
             swapcontext(&b.sched, &f.ctx);
 #ifdef HOSTEMU_ASAN
@@ -241,6 +264,9 @@ inline void run_block(dim3 block, const std::function<void()> &body) {
             abort();
         }
     }
+#ifdef HOSTEMU_TSAN
+    for (int t = 0; t < n; ++t) __tsan_destroy_fiber(b.fibres[t].tsan_fiber);
+#endif
     g_block = nullptr;
 }
 

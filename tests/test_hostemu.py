@@ -260,6 +260,7 @@ T.test_host_build_fused_image_plane_moments()
 T.test_host_build_empty_bundles_and_argument_errors()
 T.test_host_build_poisoned_rays_are_masks_never_crashes()
 T.test_host_build_wrappers_one_call_trace_timing_async_moments_and_the_image_redirect()
+T.test_host_build_the_c_abi_from_several_host_threads()
 print("RESULT " + json.dumps({"worst_k": worst}))
 '''
 
@@ -809,3 +810,92 @@ def test_host_build_wrappers_one_call_trace_timing_async_moments_and_the_image_r
                             w2.ctypes.data, None) == 0
     assert np.array_equal(w2, ref[0]["valid_out"])
     assert np.allclose(k2[:, w2.astype(bool)], ref[0]["k_out"][:, w2.astype(bool)], rtol=0, atol=1e-14)
+
+
+def test_host_build_the_c_abi_from_several_host_threads():
+    """the library's shared host state under concurrent callers (ctypes releases the GIL inside a call; the stand-in
+    runtime keeps its launch state per OS thread): prt_trace_seq's table cache (a mutex, more tables than entries, evictions
+    while other threads launch), prt_system_create / update / destroy, thread-local error strings -- every result equals
+    the single-threaded one, no thread sees another thread's error text.  Also run under AddressSanitizer (sanitizer test)."""
+    import ctypes
+    import threading
+    from pyrate_amd import systems, _lib as P
+    from pyrate_amd.surface_table import pack_table
+    lib = hostemu.load()
+    (o, k, e0) = systems.double_gauss_bundle(300, field_deg=2.0)
+    n = o.shape[1]
+    (oc, kc) = (np.ascontiguousarray(o), np.ascontiguousarray(k))
+    tables = [systems.double_gauss_records(587.6e-6 * (1 + 0.01 * q)) for q in range(12)]
+    packed = [pack_table(t) for t in tables]
+    S = len(tables[0])
+    want = [hostemu.HostSystem(t).trace(o, k, first_dir=P.FIRST_K, pitch=0) for t in tables]
+    errors = []
+
+    def worker(tid):
+        try:
+            rng = np.random.RandomState(tid)
+            for it in range(30):
+                q = int(rng.randint(0, 12))
+                if it % 3 == 0:          # the one-call form: the shared table cache
+                    (x_hit, k_out, valid) = (np.full((S, 3, n), np.nan), np.full((S, 3, n), np.nan), np.zeros((S, n), dtype=np.uint8))
+                    rc = lib.prt_trace_seq(packed[q], S, n, oc.ctypes.data, kc.ctypes.data, None, None, P.MODE_PATH,
+                                           x_hit.ctypes.data, k_out.ctypes.data, valid.ctypes.data, None, 0, None)
+                    assert rc == 0
+                    got = x_hit[-1]
+                elif it % 3 == 1:        # a system of this thread's own, updated in place to another table
+                    hs = hostemu.HostSystem(tables[(q + 1) % 12], lib=lib)
+                    assert lib.prt_system_update(hs._h, packed[q], S, None) == 0
+                    got = hs.trace(o, k, first_dir=P.FIRST_K, pitch=0)[-1]["x_hit"]
+                    hs.close()
+                else:                    # an error of this thread's own: its text must not leak into another thread
+                    bad = lib.prt_propagate_rows(None, tid, 1, None, 0, None, 0, None, None, None, 0, None, None, 0, None, None, None)
+                    assert bad == P.ERR_INVALID_ARG and b"prt_propagate_rows" in lib.prt_last_error()
+                    hs = hostemu.HostSystem(tables[q], lib=lib)
+                    got = hs.trace(o, k, first_dir=P.FIRST_K, pitch=0)[-1]["x_hit"]
+                    assert b"prt_propagate_rows" in lib.prt_last_error()       # still this thread's last error
+                    hs.close()
+                assert np.array_equal(got, want[q][-1]["x_hit"], equal_nan=True), (tid, it, q)
+        except BaseException as exc:          # noqa: BLE001
+            errors.append((tid, repr(exc)[:300]))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_host_build_under_thread_sanitizer():
+    """race detection on the library's shared host state (the table cache of the handle-free trace, system creation and
+    destruction, error strings): the concurrent callers of the test above under ThreadSanitizer -- no report; and the
+    negative control: two threads updating ONE system at once, which include/prt.h rules out, IS reported (a data race in
+    prt_system_update).  The stand-in runtime tells the sanitizer about its fibres."""
+    try:
+        lib = hostemu.build(sanitize="thread")
+    except Exception as exc:
+        pytest.skip("no ThreadSanitizer build on this box: %s" % exc)
+    tsan = hostemu.sanitizer_preload("tsan")
+    if tsan is None:
+        pytest.skip("clang's shared tsan runtime not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    head = "import sys\nsys.path.insert(0, %r); sys.path.insert(0, %r)\n" % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, LD_PRELOAD=tsan, PRT_HOSTEMU_LIBRARY=lib, TSAN_OPTIONS="exitcode=23:report_signal_unsafe=0")
+    good = head + "import test_hostemu as T\nT.test_host_build_the_c_abi_from_several_host_threads()\nprint('RESULT ok')\n"
+    r = subprocess.run([sys.executable, "-c", good], env=env, capture_output=True, text=True, timeout=1500)
+    assert "ThreadSanitizer" not in r.stderr and r.returncode == 0 and "RESULT ok" in r.stdout, r.stderr[-3000:]
+    bad = head + (
+        "import threading, hostemu\n"
+        "from pyrate_amd import systems\n"
+        "from pyrate_amd.surface_table import pack_table\n"
+        "lib = hostemu.load()\n"
+        "recs = systems.double_gauss_records()\n"
+        "hs = hostemu.HostSystem(recs, lib=lib)\n"
+        "tabs = [pack_table(systems.double_gauss_records(587.6e-6 * (1 + 0.01 * q))) for q in range(4)]\n"
+        "def w(t):\n"
+        "    for i in range(200):\n"
+        "        lib.prt_system_update(hs._h, tabs[(t + i) % 4], len(recs), None)\n"
+        "ts = [threading.Thread(target=w, args=(t,)) for t in range(2)]\n"
+        "[t.start() for t in ts]; [t.join() for t in ts]\n")
+    r = subprocess.run([sys.executable, "-c", bad], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 23 and "ThreadSanitizer: data race" in r.stderr and "prt_system_update" in r.stderr, r.stderr[-2000:]
