@@ -132,3 +132,40 @@ def test_first_contact_surface_step_sizes_on_the_host_build(n, host_engine, no_d
 def test_evanescent_modes_as_complex_wave_vectors_on_the_host_build(eps_kind, host_engine, no_device_sync):
     """k_evanescent_fill (the post-pass that reports evanescent modes as complex k) and the E-field stores of the march"""
     U.test_evanescent_modes_come_back_as_complex_wave_vectors(eps_kind, HOST)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_systems_surface_by_surface_on_the_host_build(seed):
+    """the random isotropic systems of the fuzz campaign (tilted frames, explicit shapes, mirrors, apertures; wide
+    bundles with misses and total internal reflection) walked surface by surface: prt_surface_step_rows and the pair
+    prt_propagate_rows + prt_interact_rows against the oracle on every surface -- masks identical, values to 1e-10"""
+    import numpy as np
+    import _golden
+    from oracle import seqtrace_np as oracle
+    rng = np.random.RandomState(1000 + seed)
+    recs = F.random_table(rng, int(rng.randint(3, 8)), seed % 2 == 1, seed % 3 != 0, seed % 4 == 3)
+    n = int(rng.choice([257, 1000, 1535]))
+    x0 = np.vstack((rng.uniform(-6, 6, n), rng.uniform(-6, 6, n), np.full(n, -2.0)))
+    u = np.vstack((rng.uniform(-0.12, 0.12, n), rng.uniform(-0.12, 0.12, n), np.ones(n)))
+    k0 = u / np.sqrt(np.sum(u ** 2, axis=0))
+    e0 = np.cross(k0, np.array([1., 0.3, 0.]), axisa=0, axisb=0).T.copy()
+    with np.errstate(all="ignore"):
+        out = oracle.trace(recs, x0, k0, e0)
+    hs = hostemu.HostSystem(recs)
+    pitch = int(hs.lib.prt_recommended_pitch(n)) if seed % 2 else None
+    (x, k, valid) = (x0, k0, None)
+    (xs, ks, valid_s) = (x0, k0, None)
+    for s in range(len(recs)):
+        first = dict(e_re=e0) if s == 0 else dict(default_e=False)
+        (xh, v) = hs.propagate_rows(s, x, k, valid_in=valid, pitch=pitch, **first)
+        (k2, vo) = hs.interact_rows(s, xh, k, valid_in=v, pitch=pitch)
+        (xh_f, k2_f, v_f, vo_f) = hs.surface_step_rows(s, xs, ks, valid_in=valid_s, pitch=pitch, **first)
+        for (gx, gk, gv, gw) in ((xh, k2, v, vo), (xh_f, k2_f, v_f, vo_f)):
+            assert np.array_equal(gv.astype(bool), out[s]["valid"]), (seed, s)
+            assert np.array_equal(gw.astype(bool), out[s]["valid_out"]), (seed, s)
+            m = out[s]["valid_out"]
+            xo = out[s]["x_hit"][:, m]
+            assert np.max(np.abs(gx[:, m] - xo) / _golden.relative_scale(xo), initial=0.0) < 1e-10, (seed, s)
+            assert np.max(np.abs(gk[:, m] - np.real(out[s]["k_out"])[:, m]), initial=0.0) < 1e-10, (seed, s)
+        (x, k, valid) = (xh, k2, vo)
+        (xs, ks, valid_s) = (xh_f, k2_f, vo_f)
