@@ -59,6 +59,15 @@ def build(sanitize=False, force=False):
     return out
 
 
+def build_all():
+    """the three builds (plain, address + undefined behaviour, thread) side by side: what a fresh checkout pays once,
+    about 90 s instead of 3 minutes"""
+    import concurrent.futures
+    with concurrent.futures.ThreadPoolExecutor(3) as pool:
+        jobs = [pool.submit(build, kind) for kind in (False, True, "thread")]
+        return [j.result() for j in jobs]
+
+
 def sanitizer_preload(which="asan"):
     """the shared AddressSanitizer (``which`` "tsan": ThreadSanitizer) runtime of the clang that built the sanitized
     library (LD_PRELOAD for an uninstrumented python), or None"""

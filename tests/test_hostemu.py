@@ -26,7 +26,7 @@ hostemu = pytest.importorskip("hostemu")
 def _host_library():
     """built on first use (not at import: `pytest -m gpu` on the GPU box collects this module and deselects all of it)"""
     try:
-        hostemu.build()
+        hostemu.build_all()
     except Exception as exc:                                    # no clang++ on this box
         pytest.skip("no host build of libprt: %s" % exc)
 
