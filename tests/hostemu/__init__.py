@@ -96,7 +96,7 @@ def load(path=None):
         fn = getattr(lib, name)
         fn.restype = restype
         fn.argtypes = argtypes
-    assert lib.prt_abi_version() == product.ABI_VERSION
+    assert lib.prt_abi_version() == 1000 + product.ABI_VERSION          # (hostemu_prt.cpp: the product refuses this build)
     assert lib.prt_sizeof_surface() == ctypes.sizeof(product.PrtSurface)
     assert lib.prt_sizeof_trace_args() == ctypes.sizeof(product.PrtTraceArgs)
     _libs[path] = lib

@@ -899,3 +899,18 @@ def test_host_build_under_thread_sanitizer():
         "[t.start() for t in ts]; [t.join() for t in ts]\n")
     r = subprocess.run([sys.executable, "-c", bad], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 23 and "ThreadSanitizer: data race" in r.stderr and "prt_system_update" in r.stderr, r.stderr[-2000:]
+
+
+def test_the_product_refuses_the_host_build(monkeypatch):
+    """pyrate_amd/_lib.py has a switch for alternative builds of the same ABI (PRT_LIBRARY, A/B experiments): pointed at the
+    host build it raises ImportError -- the host build answers prt_abi_version() with 1000 + the sources' version"""
+    import importlib
+    from pyrate_amd import _lib as product
+    path = hostemu.build()
+    assert hostemu.load().prt_abi_version() == 1000 + product.ABI_VERSION
+    monkeypatch.setattr(product, "LIB_PATH", path)
+    monkeypatch.setattr(product, "_lib", None)
+    with pytest.raises(ImportError) as err:
+        product.load()
+    assert "ABI version" in str(err.value)
+    assert product._lib is None
