@@ -261,6 +261,7 @@ T.test_host_build_empty_bundles_and_argument_errors()
 T.test_host_build_poisoned_rays_are_masks_never_crashes()
 T.test_host_build_wrappers_one_call_trace_timing_async_moments_and_the_image_redirect()
 T.test_host_build_the_c_abi_from_several_host_threads()
+T.test_host_build_size_sweep_around_the_block_and_wave_boundaries()
 print("RESULT " + json.dumps({"worst_k": worst}))
 '''
 
@@ -914,3 +915,61 @@ def test_the_product_refuses_the_host_build(monkeypatch):
         product.load()
     assert "ABI version" in str(err.value)
     assert product._lib is None
+
+
+def test_host_build_size_sweep_around_the_block_and_wave_boundaries():
+    """ray counts around every boundary of the launch geometry -- a thread owns two rays, a wave 128, a block of the march
+    256, the XCD-contiguous block map wants grids that are multiples of 8 -- for the fused march (path, image, flags), the
+    fused image-plane moments (whose tail threads join the reduction without a ray) and the crystal march (blocks of 256
+    threads, one ray each): every count gives the oracle's masks and values, and the moments of exactly its rays"""
+    import ctypes
+    from pyrate_amd import systems, _lib as P
+    lib = hostemu.load()
+    recs = systems.double_gauss_records()
+    (o, k, e0) = systems.double_gauss_bundle(6000, field_deg=4.0)
+    with np.errstate(all="ignore"):
+        out = oracle.trace(recs, o, k, e0)
+    hs = hostemu.HostSystem(recs)
+    sizes = sorted(set(list(range(1, 12)) + [63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 767, 1023, 1024, 1025,
+                                             2047, 2048, 2049, 2303, 2305, 4095, 4097, o.shape[1]]))
+    for n in sizes:
+        (on, kn, en) = (o[:, :n], k[:, :n], e0[:, :n])
+        for kw in (dict(), dict(mode=P.MODE_IMAGE), dict(flags=True), dict(pitch=0)):
+            d = hs.trace(on, kn, en, **kw)
+            for (s, rec) in enumerate(d):
+                so = (len(recs) - 1) if kw.get("mode") == P.MODE_IMAGE else s
+                assert np.array_equal(rec["valid_out"].astype(bool), out[so]["valid_out"][:n]), (n, kw, s)
+                m = out[so]["valid_out"][:n]
+                assert np.max(np.abs(rec["x_hit"][:, m] - out[so]["x_hit"][:, :n][:, m]), initial=0.0) < 1e-11, (n, kw, s)
+        # fused moments
+        pitch = int(lib.prt_recommended_pitch(n))
+        (x_img, k_img) = (np.full((3, pitch), np.nan), np.full((3, pitch), np.nan))
+        (v_img, w_img) = (np.zeros(pitch, dtype=np.uint8), np.zeros(pitch, dtype=np.uint8))
+        out7 = np.full(7, np.nan)
+        scratch = np.zeros(int(lib.prt_trace_moments_scratch_doubles(n)))
+        (oc, kc, ec) = [hostemu._rows(a, pitch) for a in (on, kn, en)]
+        rc = lib.prt_trace_moments(hs._h, n, pitch, oc.ctypes.data, kc.ctypes.data, ec.ctypes.data, None, P.MODE_IMAGE, pitch,
+                                   x_img.ctypes.data, k_img.ctypes.data, v_img.ctypes.data, w_img.ctypes.data, None,
+                                   out7.ctypes.data, scratch.ctypes.data, None)
+        assert rc == 0, lib.prt_last_error()
+        m = out[-1]["valid_out"][:n]
+        v = out[-1]["x_hit"][:, :n][:, m] - np.asarray(recs[-1]["g_shape"], dtype=float)[:, None]
+        want = np.concatenate([[m.sum()], v.sum(axis=1), (v * v).sum(axis=1)])
+        assert np.allclose(out7, want, rtol=1e-11, atol=1e-9), (n, out7, want)
+    # the crystal march
+    case = _golden.load_case("aniso_doublet_biaxial")
+    with np.errstate(all="ignore"):
+        outc = oracle.trace(case.table, case.x0, case.k0, case.E0)
+    hc = hostemu.HostSystem(case.table)
+    n0 = case.x0.shape[1]
+    big = 3 * 256 + 5
+    reps = -(-big // n0)
+    (xb, kb, eb) = [np.tile(np.real(a), (1, reps))[:, :big] for a in (case.x0, case.k0, case.E0)]
+    idx = np.arange(big) % n0
+    for n in (1, 2, 63, 64, 65, 255, 256, 257, 511, 513, big):
+        d = hc.trace(xb[:, :n], kb[:, :n], eb[:, :n])
+        for s in range(case.n_surfaces):
+            B = d[s]["k_out"].shape[1] // n
+            ref_k = np.real(outc[s]["k_out"]).reshape(3, B, n0)[:, :, idx[:n]].reshape(3, B * n)
+            fin = np.all(np.isfinite(ref_k), axis=0)
+            assert np.max(np.abs(d[s]["k_out"][:, fin] - ref_k[:, fin]), initial=0.0) < 1e-11, (n, s)
