@@ -28,9 +28,27 @@ def pytest_configure(config):
         pass
 
 
+# PRT_TESTS_ENGINE_ON_HOST=1 python -m pytest tests -m gpu ...: the `-m gpu` tests with the product's Python (engine.py, the
+# drop-in layer) on the HOST build of libprt's sources (tests/hostemu/engine_on_host.py) -- a mode of the TEST SUITE for a
+# box without a GPU (tests/test_hostemu_campaigns.py runs a selection this way); the product itself has no such mode.
+ENGINE_ON_HOST = os.environ.get("PRT_TESTS_ENGINE_ON_HOST", "0") == "1"
+
+
+@pytest.fixture(scope="session", autouse=ENGINE_ON_HOST)
+def _engine_on_host():
+    if not ENGINE_ON_HOST:
+        yield None
+        return
+    from hostemu.engine_on_host import engine_on_host
+    with engine_on_host() as engine:
+        yield engine
+
+
 @pytest.fixture(scope="session")
 def gpu_device():
     import torch
+    if ENGINE_ON_HOST:
+        return torch.device("cpu")
     if not torch.cuda.is_available():
         pytest.fail("test marked gpu but no HIP device is visible")
     return torch.device("cuda", 0)

@@ -169,3 +169,33 @@ def test_random_systems_surface_by_surface_on_the_host_build(seed):
             assert np.max(np.abs(gk[:, m] - np.real(out[s]["k_out"])[:, m]), initial=0.0) < 1e-10, (seed, s)
         (x, k, valid) = (xh, k2, vo)
         (xs, ks, valid_s) = (xh_f, k2_f, vo_f)
+
+
+HOST_MODE_FILES = ["test_gpu_dropin.py", "test_gpu_analysis.py", "test_gpu_absorbing.py", "test_gpu_uniform.py",
+                   "test_gpu_parity.py", "test_gpu_fuzz.py", "test_gpu_zz_first_contact.py"]
+# what needs the device itself: bundles of 1e6 rays and more (minutes each in the emulation), the placement arena (no
+# virtual-memory API on the host), the bench / multi-rank processes
+HOST_MODE_DESELECT = ("not full_size and not 1e8 and not scales_exactly and not preflight and not arena and not 1000000 "
+                      "and not collimated_host_arrays")
+
+
+def test_the_gpu_suite_with_the_products_own_python_on_the_host_build():
+    """`PRT_TESTS_ENGINE_ON_HOST=1 pytest -m gpu`: the `-m gpu` tests as they are, with pyrate_amd/engine.py and the drop-in
+    layer (raytracer/, dropin.py, the analysis classes) running UNCHANGED on the host build of libprt's sources with CPU
+    tensors (tests/hostemu/engine_on_host.py patches the places where engine.py asks torch for a CUDA device or stream;
+    tests/conftest.py hands the tests a CPU device).  Seven of the ten GPU test files, everything in them that does not
+    need the device itself: >= 340 tests, none failing.  This is the Python the build container otherwise never executes
+    -- DeviceSystem.surface_step and the symmetric-tensor change of round 6 met it here first."""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PRT_TESTS_ENGINE_ON_HOST="1")
+    cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "--timeout", "300", "-n", "6",
+           "-k", HOST_MODE_DESELECT] + [os.path.join(root, "tests", f) for f in HOST_MODE_FILES]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    m = re.search(r"(\d+) passed", tail)
+    assert r.returncode == 0 and m and "failed" not in tail and "error" not in tail, (r.stdout[-3000:], r.stderr[-1500:])
+    assert int(m.group(1)) >= 340, tail
