@@ -55,6 +55,11 @@ def engine_on_host():
         mp.setattr(torch.cuda, "current_device", lambda: 0)
         mp.setattr(torch.cuda, "current_stream", lambda *a, **k: _Stream())
         mp.setattr(torch.cuda, "empty_cache", lambda: None)
+
+        def pageable(fn):           # page-locked host buffers need a device runtime: plain host memory here
+            return lambda *a, **k: fn(*a, **{key: v for (key, v) in k.items() if key != "pin_memory"})
+        mp.setattr(torch, "zeros", pageable(torch.zeros))
+        mp.setattr(torch, "empty", pageable(torch.empty))
         mp.setattr(engine, "raw_stream", lambda device: 0)
         mp.setattr(engine, "_current_device", lambda: None)
         mp.setattr(torch.Tensor, "is_cuda", property(lambda self: True), raising=False)

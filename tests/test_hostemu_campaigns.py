@@ -172,19 +172,19 @@ def test_random_systems_surface_by_surface_on_the_host_build(seed):
 
 
 HOST_MODE_FILES = ["test_gpu_dropin.py", "test_gpu_analysis.py", "test_gpu_absorbing.py", "test_gpu_uniform.py",
-                   "test_gpu_parity.py", "test_gpu_fuzz.py", "test_gpu_zz_first_contact.py"]
+                   "test_gpu_parity.py", "test_gpu_fuzz.py", "test_gpu_zz_first_contact.py", "test_gpu_demos.py"]
 # what needs the device itself: bundles of 1e6 rays and more (minutes each in the emulation), the placement arena (no
 # virtual-memory API on the host), the bench / multi-rank processes
 HOST_MODE_DESELECT = ("not full_size and not 1e8 and not scales_exactly and not preflight and not arena and not 1000000 "
-                      "and not collimated_host_arrays")
+                      "and not collimated_host_arrays and not bench")
 
 
 def test_the_gpu_suite_with_the_products_own_python_on_the_host_build():
     """`PRT_TESTS_ENGINE_ON_HOST=1 pytest -m gpu`: the `-m gpu` tests as they are, with pyrate_amd/engine.py and the drop-in
     layer (raytracer/, dropin.py, the analysis classes) running UNCHANGED on the host build of libprt's sources with CPU
     tensors (tests/hostemu/engine_on_host.py patches the places where engine.py asks torch for a CUDA device or stream;
-    tests/conftest.py hands the tests a CPU device).  Seven of the ten GPU test files, everything in them that does not
-    need the device itself: >= 340 tests, none failing.  This is the Python the build container otherwise never executes
+    tests/conftest.py hands the tests a CPU device).  Eight of the ten GPU test files (the demo scripts included), everything in them that
+    does not need the device itself: >= 354 tests, none failing.  This is the Python the build container otherwise never executes
     -- DeviceSystem.surface_step and the symmetric-tensor change of round 6 met it here first."""
     import os
     import re
@@ -198,4 +198,4 @@ def test_the_gpu_suite_with_the_products_own_python_on_the_host_build():
     tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
     m = re.search(r"(\d+) passed", tail)
     assert r.returncode == 0 and m and "failed" not in tail and "error" not in tail, (r.stdout[-3000:], r.stderr[-1500:])
-    assert int(m.group(1)) >= 340, tail
+    assert int(m.group(1)) >= 354, tail
