@@ -587,6 +587,21 @@ def run_single_gpu(args, dev, watchdog, headline):
         per_trace["plugin"] = 2 * recs[-1]["surfaces"]
         configs.append("plugin")
         torch.cuda.empty_cache()
+        # The fused step of one surface (DeviceSystem.surface_step / prt_surface_step_rows: 98 B per op).  Written after
+        # round 6's last GPU lease: verified on the host build of the sources and through engine.py in the test suite's
+        # host mode, compiled for gfx950, never timed.  Its first contact with a device must not cost the
+        # line anything: a failure is reported on stderr and the record is simply absent; no PMC pass of its own.
+        stage("measure surface_step")
+        try:
+            step_rec = measure_plugin(args, dev, 10_000_000, with_oracle=not args.no_cpu_baseline, fused=True)
+            if step_rec["verified"]["ok"]:
+                recs.append(step_rec)
+            else:
+                print("bench.py: surface_step measured but NOT verified, record dropped: %r" % (step_rec["verified"],),
+                      file=sys.stderr)
+        except Exception as exc:          # noqa: BLE001
+            print("bench.py: surface_step not measured: %r" % (exc,), file=sys.stderr)
+        torch.cuda.empty_cache()
         stage("measure image_moments")
         recs.append(measure_image_moments(args, dev, 10_000_000))
         torch.cuda.empty_cache()
