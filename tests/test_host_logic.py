@@ -942,6 +942,23 @@ def test_bench_condenses_a_full_run_into_a_line_the_driver_can_keep():
                                                    "aniso_chain", "plugin", "image_moments", "scaling_point_1e8_rays"}
     assert d["config"]["configs_summary"]["plugin"][3] is not None          # measured traffic of the per-surface path
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["verified"]["ok"]
+    # the guarded tenth record of the default run (the fused surface step, same shape as the plugin record)
+    import copy
+    step = copy.deepcopy([c for c in recs if c["name"] == "plugin"][0])
+    step["name"] = "surface_step"
+    step["roofline"]["kernel"] = "k_surface_step_rows"
+    i_plugin = [c["name"] for c in recs].index("plugin")
+    recs10 = recs[:i_plugin + 1] + [step] + recs[i_plugin + 1:]
+    line10 = bench.compact_single(base, recs10[0], recs10, detail["scaling_point"], detail["e2e"], detail["arena"], detail["build"],
+                                  detail["wall_s_by_stage"])
+    (r, w) = os.pipe()
+    bench.emit(w, line10)
+    os.close(w)
+    text10 = os.read(r, 1 << 16).decode()
+    os.close(r)
+    d10 = json.loads(text10)
+    assert len(text10) < 4096 and "surface_step" in d10["config"]["configs_summary"] and "truncated" not in d10
+    assert d10["roofline"] == d["roofline"] and d10["value"] == d["value"]
     # a record that outgrows the limit is cut down, not printed
     fat = dict(line, config=dict(line["config"], configs_summary={("cfg%d" % i): [1.0, 0.5, True, 1.0, "x" * 90] for i in range(90)}))
     (r, w) = os.pipe()
