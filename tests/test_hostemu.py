@@ -262,6 +262,7 @@ T.test_host_build_poisoned_rays_are_masks_never_crashes()
 T.test_host_build_wrappers_one_call_trace_timing_async_moments_and_the_image_redirect()
 T.test_host_build_the_c_abi_from_several_host_threads()
 T.test_host_build_size_sweep_around_the_block_and_wave_boundaries()
+T.test_host_build_malformed_tables_are_error_codes()
 print("RESULT " + json.dumps({"worst_k": worst}))
 '''
 
@@ -973,3 +974,55 @@ def test_host_build_size_sweep_around_the_block_and_wave_boundaries():
             ref_k = np.real(outc[s]["k_out"]).reshape(3, B, n0)[:, :, idx[:n]].reshape(3, B * n)
             fin = np.all(np.isfinite(ref_k), axis=0)
             assert np.max(np.abs(d[s]["k_out"][:, fin] - ref_k[:, fin]), initial=0.0) < 1e-11, (n, s)
+
+
+def test_host_build_malformed_tables_are_error_codes():
+    """a C caller's prt_surface_t with fields out of range (an unknown shape, coefficient counts beyond the arrays, a sag
+    grid without data, polynomial powers outside the tables, enums out of range): prt_system_create / prt_system_update
+    answer with an error code and a text that names the surface -- under the sanitizers too: nothing is read beyond the
+    record before it is validated"""
+    import copy
+    from pyrate_amd import systems, _lib as P
+    from pyrate_amd.surface_table import pack_table
+    lib = hostemu.load()
+    good = systems.asphere_records()
+    xy = _golden.load_case("xypoly_field5").table
+    i_xy = [i for (i, r) in enumerate(xy) if r["shape"]["type"] not in ("conic",)][0]
+
+    def create(table, n):
+        import ctypes
+        h = ctypes.c_void_p()
+        rc = lib.prt_system_create(table, n, 0, ctypes.byref(h))
+        if rc == 0:
+            lib.prt_system_destroy(h)
+        return rc, lib.prt_last_error().decode()
+    assert create(pack_table(good), len(good))[0] == 0
+
+    def broken(records, surface, **fields):
+        t = pack_table(copy.deepcopy(records))
+        t2 = type(t)()                       # (pack_table may hand out a cached array: work on a copy)
+        import ctypes
+        ctypes.memmove(t2, t, ctypes.sizeof(t))
+        for (name, value) in fields.items():
+            if "[" in name:
+                (arr, idx) = name[:-1].split("[")
+                getattr(t2[surface], arr)[int(idx)] = value
+            else:
+                setattr(t2[surface], name, value)
+        return t2
+    i_as = [i for (i, r) in enumerate(good) if r["shape"]["type"] == "asphere"][0]
+    cases = [(good, i_as, dict(shape_type=99), P.ERR_UNSUPPORTED), (good, i_as, dict(shape_type=-1), P.ERR_UNSUPPORTED),
+             (good, i_as, dict(n_coeffs=-3), P.ERR_INVALID_ARG), (good, i_as, dict(n_coeffs=100000), P.ERR_INVALID_ARG),
+             (good, 0, dict(ap_type=7), P.ERR_INVALID_ARG), (good, 0, dict(interaction=5), P.ERR_INVALID_ARG),
+             (good, 0, dict(mat_type=-2), P.ERR_INVALID_ARG),
+             (xy, i_xy, {"xpow[0]": 10000}, P.ERR_INVALID_ARG), (xy, i_xy, {"ypow[0]": -1}, P.ERR_INVALID_ARG)]
+    for (records, surface, fields, want) in cases:
+        (rc, text) = create(broken(records, surface, **fields), len(records))
+        assert rc == want and ("surface %d" % surface) in text, (fields, rc, text)
+    # a healthy system refuses such a table in an update as well, and keeps working
+    hs = hostemu.HostSystem(good)
+    (o, k, e0) = systems.double_gauss_bundle(100, rpup=9.0, z0=-5.0)
+    before = hs.trace(o, k, e0)
+    assert lib.prt_system_update(hs._h, broken(good, i_as, n_coeffs=-3), len(good), None) == P.ERR_INVALID_ARG
+    after = hs.trace(o, k, e0)
+    assert np.array_equal(before[-1]["x_hit"], after[-1]["x_hit"], equal_nan=True)
