@@ -199,3 +199,27 @@ def test_the_gpu_suite_with_the_products_own_python_on_the_host_build():
     m = re.search(r"(\d+) passed", tail)
     assert r.returncode == 0 and m and "failed" not in tail and "error" not in tail, (r.stdout[-3000:], r.stderr[-1500:])
     assert int(m.group(1)) >= 354, tail
+
+
+def test_the_bench_sweeps_surface_by_surface_on_the_host_build():
+    """benchmarks/configs.plugin_sweep -- what bench.py's `plugin` and (guarded, round 6) `surface_step` records time -- with
+    engine.py on the host build: the pair of calls per surface and the fused step both end on the fused march's image-plane
+    record (masks bit for bit, values to rounding), which is the check measure_plugin applies on the device"""
+    from hostemu.engine_on_host import engine_on_host
+    with engine_on_host():
+        from benchmarks import configs
+        from pyrate_amd import _lib
+        for fused in (False, True):
+            (sweep, ctx) = configs.plugin_sweep(HOST, 5000, placement="torch", fused=fused)
+            seen = []
+            ctx["tap"] = lambda s, xh, v, k, w: seen.append(s)
+            sweep()
+            (last, wl, sysd) = (ctx["last"], ctx["wl"], ctx["sysd"])
+            assert seen == list(range(wl["S"]))
+            ob = sysd.alloc_outputs(wl["n_local"], _lib.MODE_IMAGE, packed_flags=False, placement="torch")
+            sysd.trace_into(wl["x0"], wl["k0"], ob, wl["e0"])
+            res = sysd.views(ob)
+            mk = res.valid_out[0].bool()
+            assert torch.equal(last["valid"], res.valid_out[0]) and torch.equal(last["hit"], res.valid[0]) and int(mk.sum()) > 4000
+            assert float((last["x"][:, mk] - res.x_hit[0][:, mk]).abs().max()) < 1e-12
+            assert float((last["k"][:, mk] - res.k_out[0][:, mk]).abs().max()) < 1e-13
