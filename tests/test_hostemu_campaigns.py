@@ -223,3 +223,63 @@ def test_the_bench_sweeps_surface_by_surface_on_the_host_build():
             assert torch.equal(last["valid"], res.valid_out[0]) and torch.equal(last["hit"], res.valid[0]) and int(mk.sum()) > 4000
             assert float((last["x"][:, mk] - res.x_hit[0][:, mk]).abs().max()) < 1e-12
             assert float((last["k"][:, mk] - res.k_out[0][:, mk]).abs().max()) < 1e-13
+
+
+def test_the_default_bench_run_python_on_the_host_build(monkeypatch):
+    """benchmarks/configs.run_single_gpu -- everything `python bench.py` does on one GPU between parsing its arguments and
+    printing the line: the nine configurations, the guarded tenth (fused surface step), image mode with fused moments, the
+    end-to-end drop-in call, verification of what the launches wrote, the compact line -- with engine.py on the host
+    build, bundle sizes clamped to a thousand rays, HIP events replaced by a clock, no profiler passes, no arena, no
+    1e8-ray point.  Numbers mean nothing here; the Python does: every record is there and verified, the line has the
+    contract's keys and fits."""
+    import importlib.util
+    import json
+    import os
+    import sys
+    import time
+    import types
+    from hostemu.engine_on_host import engine_on_host
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    class Clock(object):
+        def __init__(self, enable_timing=False):
+            self.t = 0.0
+
+        def record(self, stream=None):
+            self.t = time.perf_counter()
+
+        def synchronize(self):
+            pass
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+    with engine_on_host():
+        monkeypatch.setattr(torch.cuda, "Event", Clock)
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--no-cpu-baseline", "--traffic", "none", "--no-scaling-point", "--steps", "2",
+                                          "--warmup", "1"])
+        spec = importlib.util.spec_from_file_location("bench_on_host", os.path.join(root, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        args = bench.parse_args()
+        from benchmarks import configs
+        cap = 1000
+        (ms, mp_, mi, me) = (configs.measure_single, configs.measure_plugin, configs.measure_image_moments, configs.measure_e2e)
+        monkeypatch.setattr(configs, "measure_single",
+                            lambda c, a, d, rays, **kw: ms(c, a, d, (40 if c == "aniso_chain" else min(rays, cap)), **kw))
+        monkeypatch.setattr(configs, "measure_plugin", lambda a, d, rays, **kw: mp_(a, d, min(rays, cap), **kw))
+        monkeypatch.setattr(configs, "measure_image_moments", lambda a, d, rays: mi(a, d, min(rays, cap)))
+        monkeypatch.setattr(configs, "measure_e2e", lambda d, **kw: me(d, rays=cap, small_rays=300, calls=2))
+        wd = types.SimpleNamespace(stage="", done=lambda: None)
+        (recs, scaling_point, e2e, arena_stats, wall) = configs.run_single_gpu(args, HOST, wd, "doublegauss")
+        base = {"metric": "ray_surface_ops_per_s", "unit": "ray-surface-ops/s", "n_gpus": 1, "steps": args.steps,
+                "warmup": args.warmup, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+                "data": "synthetic"}
+        line = bench.compact_single(base, recs[0], recs, scaling_point, e2e, arena_stats, {"sha256_16": "host build"}, wall)
+    names = [r["name"] for r in recs]
+    assert names == ["doublegauss", "asphere", "aniso", "xypoly", "benchmark", "aniso_biaxial", "aniso_chain", "plugin",
+                     "surface_step", "image_moments"], names
+    assert all(r["verified"]["ok"] for r in recs), [(r["name"], r["verified"]["ok"]) for r in recs]
+    text = json.dumps(line)
+    assert len(text) < 8192 and set(names) <= set(line["config"]["configs_summary"]) and line["e2e"] and line["verified"]["ok"]
+    for key in ("metric", "value", "unit", "ms_per_step", "roofline", "config", "verified", "e2e"):
+        assert key in line, key
