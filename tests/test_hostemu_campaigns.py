@@ -283,3 +283,49 @@ def test_the_default_bench_run_python_on_the_host_build(monkeypatch):
     assert len(text) < 8192 and set(names) <= set(line["config"]["configs_summary"]) and line["e2e"] and line["verified"]["ok"]
     for key in ("metric", "value", "unit", "ms_per_step", "roofline", "config", "verified", "e2e"):
         assert key in line, key
+
+
+@pytest.mark.parametrize("exchange", ["auto", "stats"])
+def test_the_multi_rank_bench_program_with_two_ranks_on_the_host_build(exchange):
+    """benchmarks/multirank.run_multi -- what `bench.py --gpus N` runs per rank -- with TWO ranks (two processes, gloo), engine.py
+    on the host build: the bundle is split, every rank traces and verifies its shard, the per-step exchange runs; with
+    `--exchange auto` and PRT_BENCH_PROBE_DRY=1 the start-up PROBE times both forms of the image-plane gather (in-place
+    collective, direct peer writes through shared buffers) and all ranks take the faster one.  The N > 1 program has never run
+    on more than one GPU (no node in any round) and its probe was written after round 6's last GPU lease: this is where its
+    Python first ran with two ranks."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "hostemu", "bench_ranks_on_host.py")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), PRT_BENCH_PROBE_DRY="1")
+        procs.append(subprocess.Popen([sys.executable, script, "--exchange", exchange], env=env, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    lines = {}
+    for (so, _) in outs:
+        for ln in so.splitlines():
+            if ln.startswith("RANK "):
+                lines[int(ln.split()[1])] = json.loads(ln.split(" ", 2)[2])
+    assert lines[1] is None and lines[0] is not None
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["bytes"] < 8192
+    assert line["verified"]["ok"] and line["verified"]["all_ranks_ok"] and line["verified"]["ok_per_rank"] == [True, True]
+    assert 3500 < line["config"]["rays_total"] <= 4000
+    if exchange == "auto":
+        probe = line["config"]["exchange_probe_ms"]
+        assert set(probe) == {"gather", "gather-direct"} and probe["gather"] > 0
+        chosen = line["config"]["exchange"]
+        assert chosen in probe and probe[chosen] == min(v for v in probe.values() if v is not None)
+    else:
+        assert line["config"]["exchange"] == "stats" and line["config"]["exchange_probe_ms"] is None
