@@ -285,9 +285,9 @@ def test_the_default_bench_run_python_on_the_host_build(monkeypatch):
         assert key in line, key
 
 
-@pytest.mark.parametrize("exchange", ["auto", "stats"])
-def test_the_multi_rank_bench_program_with_two_ranks_on_the_host_build(exchange):
-    """benchmarks/multirank.run_multi -- what `bench.py --gpus N` runs per rank -- with TWO ranks (two processes, gloo), engine.py
+@pytest.mark.parametrize("exchange,world", [("auto", 2), ("stats", 2), ("auto", 4)])
+def test_the_multi_rank_bench_program_with_two_ranks_on_the_host_build(exchange, world):
+    """benchmarks/multirank.run_multi -- what `bench.py --gpus N` runs per rank -- with two and with four ranks (one process each, gloo), engine.py
     on the host build: the bundle is split, every rank traces and verifies its shard, the per-step exchange runs; with
     `--exchange auto` and PRT_BENCH_PROBE_DRY=1 the start-up PROBE times both forms of the image-plane gather (in-place
     collective, direct peer writes through shared buffers) and all ranks take the faster one.  The N > 1 program has never run
@@ -305,8 +305,8 @@ def test_the_multi_rank_bench_program_with_two_ranks_on_the_host_build(exchange)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = os.path.join(root, "tests", "hostemu", "bench_ranks_on_host.py")
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), PRT_BENCH_PROBE_DRY="1")
         procs.append(subprocess.Popen([sys.executable, script, "--exchange", exchange], env=env, cwd=root,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -317,10 +317,10 @@ def test_the_multi_rank_bench_program_with_two_ranks_on_the_host_build(exchange)
         for ln in so.splitlines():
             if ln.startswith("RANK "):
                 lines[int(ln.split()[1])] = json.loads(ln.split(" ", 2)[2])
-    assert lines[1] is None and lines[0] is not None
+    assert all(lines[r] is None for r in range(1, world)) and lines[0] is not None
     line = lines[0]
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["bytes"] < 8192
-    assert line["verified"]["ok"] and line["verified"]["all_ranks_ok"] and line["verified"]["ok_per_rank"] == [True, True]
+    assert line["n_gpus"] == world and line["value"] > 0 and line["bytes"] < 8192
+    assert line["verified"]["ok"] and line["verified"]["all_ranks_ok"] and line["verified"]["ok_per_rank"] == [True] * world
     assert 3500 < line["config"]["rays_total"] <= 4000
     if exchange == "auto":
         probe = line["config"]["exchange_probe_ms"]
