@@ -10,10 +10,12 @@
 //     instantiation, which grid, which layout) -- is compared with the oracle and the golden vectors before a GPU
 //     has seen a change.
 // What it is NOT: a model of the hardware.  Threads of a block run as cooperative fibres on one OS thread (a block at a
-// time, blocks in order), `__syncthreads` / wave shuffles / ballots are rendezvous points between the fibres,
+// time, blocks in order; several host threads may launch at once, each with its own fibres), `__syncthreads` is a
+// rendezvous of the block's live threads, wave votes / shuffles are rendezvous of the lanes that are active at one call site,
 // v_rcp_f64 / v_rsq_f64 are exact divisions, memory is malloc'ed.  Results agree with the GPU's to rounding, not to
 // the bit.  "Device pointers" are host pointers.  The product has no CPU path: pyrate_amd/_lib.py loads
-// pyrate_amd/csrc/libprt.so (the gfx950 build) or raises.
+// pyrate_amd/csrc/libprt.so (the gfx950 build) or raises -- and refuses THIS build by its ABI version (hostemu_prt.cpp).
+// Sanitizers: the fibres are announced to AddressSanitizer and ThreadSanitizer (start / finish_switch_fiber, __tsan_*_fiber).
 #pragma once
 #include <math.h>
 #include <stdint.h>
